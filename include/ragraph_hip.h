@@ -1,0 +1,162 @@
+/*
+ * ragraph_hip.h -- C ABI of libragraph_hip.so: the MI355X (gfx950) retrieve-and-propagate hot path of RAGraph.
+ *
+ * The reference (Artessay/RAGraph) has no FFI: its hot path is in-process torch calls.  This header is the
+ * boundary a maintainer binds instead of those torch op chains (ctypes stub: INTEGRATION.md).  Each entry point
+ * cites the reference lines (relative to the reference repo root) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host; row-major, contiguous, fp32;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous on it;
+ *   - no allocation, no synchronisation and no global state inside a call (graph-capturable, thread-safe per
+ *     stream); scratch comes from the caller via (ws, ws_bytes) sized by the matching *_workspace_bytes();
+ *   - return 0 on success, a negative RAGRAPH_E* code otherwise; ragraph_last_error() gives the thread's last
+ *     message.  There is NO CPU fallback: without a gfx950 device every compute entry returns RAGRAPH_EDEVICE.
+ *
+ * Numerics contract (what "parity" means; restated on the CPU in oracle/ragraph_oracle.c)
+ *   - every dot product (cosine scores, GEMM, SpMM) is ONE fp32 fmaf chain in natural index order starting from
+ *     +0 -- exactly what v_mfma_f32_32x32x2_f32 / _16x16x4_f32 compute -- so scores are bit-identical to the oracle
+ *     regardless of batch size, tiling, split count or GPU count;
+ *   - top-k order is canonical: score descending, then index ascending (torch.topk leaves ties unspecified);
+ *   - row L2 norms use the fixed reduction tree documented at ragraph_normalize_rows_f32.
+ */
+#ifndef RAGRAPH_HIP_H
+#define RAGRAPH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAGRAPH_ABI_VERSION 1
+
+#define RAGRAPH_OK 0
+#define RAGRAPH_EINVAL (-1)    /* bad argument (shape, alignment, null pointer)            */
+#define RAGRAPH_EUNSUPPORTED (-2) /* valid request outside what the kernels cover (see each entry) */
+#define RAGRAPH_EWORKSPACE (-3) /* ws_bytes smaller than *_workspace_bytes()                */
+#define RAGRAPH_EDEVICE (-4)   /* HIP runtime / launch failure, or no gfx950 device        */
+
+/* activation selector of the fused epilogues */
+#define RAGRAPH_ACT_NONE 0
+#define RAGRAPH_ACT_RELU 1   /* Propagation.py:25  F.relu                          */
+#define RAGRAPH_ACT_PRELU 2  /* layers/gcn.py:9,40 nn.PReLU(), one shared alpha    */
+#define RAGRAPH_ACT_LEAKY 3  /* TaskDecoder.py:7   nn.LeakyReLU(), slope = alpha   */
+#define RAGRAPH_ACT_ELU 4    /* RAGraph_node/downprompt.py:14 nn.ELU(), alpha = 1  */
+
+int ragraph_abi_version(void);
+const char* ragraph_last_error(void);
+/* 0 if a gfx950 device is usable by this process, RAGRAPH_EDEVICE otherwise (never touches the GPU at load time). */
+int ragraph_device_check(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * a1  F.normalize(x, p=2, dim=-1, eps=1e-12)   -- RAGraph_node/ragraph_utils/SimilarityFunctions.py:8,11
+ *     out[r,:] = X[r,:] / max(||X[r,:]||_2, 1e-12).  In-place (out == X) allowed.  Any D >= 1.
+ *     Norm tree: lane l of 64 accumulates x[l]^2, x[l+64]^2, ... with fmaf (ascending), then the 64 partials are
+ *     combined by a butterfly: p[l] += p[l^32]; ^16; ^8; ^4; ^2; ^1.  sqrtf and the division are correctly rounded.
+ */
+int ragraph_normalize_rows_f32(const float* X, int64_t n, int D, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * a1+a2  fused cosine scores + top-k  -- SimilarityFunctions.py:6-16 + ToyGraphBase.py:66-67
+ *        (torch.topk(normalize(Q) @ normalize(K).T, k, largest=True, sorted=True)); edge slab loop
+ *        RAGraph_edge/modules/RAGraph.py:298-311.  The B x N score matrix is never written.
+ *   Q   [B,D] raw (un-normalised) queries; normalised inside (a1) into the workspace.
+ *   Kn  [N,D] key bank ALREADY row-normalised by ragraph_normalize_rows_f32 (done once per bank version; the
+ *       reference re-normalises its stored keys on every call, SimilarityFunctions.py:11).
+ *   k   1 <= k <= min(N, RAGRAPH_TOPK_MAX).  D in {64,128,256}.  B,N >= 1.
+ *   idx_base  added to every returned index (this shard's first global row).
+ *   out_scores [B,k] fp32 descending; out_idx [B,k] int64 (torch indexing dtype).
+ *   Unsupported (returns RAGRAPH_EUNSUPPORTED): other D, k > RAGRAPH_TOPK_MAX.  NaN scores are never selected
+ *   (torch.topk would rank NaN first) -- inputs are finite by contract.
+ */
+#define RAGRAPH_TOPK_MAX 64
+size_t ragraph_topk_cosine_workspace_bytes(int64_t B, int64_t N, int D, int k);
+int ragraph_topk_cosine_f32(const float* Q, int64_t B, const float* Kn, int64_t N, int D, int k, int64_t idx_base,
+                            float* out_scores, int64_t* out_idx, void* ws, size_t ws_bytes, void* stream);
+
+/* Cross-shard / cross-split merge of sorted top-k lists (no counterpart in the reference: it is single-GPU).
+ *   scores,idx [G,B,k] (list g of query b at ((g*B)+b)*k) -> out [B,k], canonical order; result independent of G.
+ *   G*k <= 4096.
+ */
+int ragraph_topk_merge_f32(const float* scores, const int64_t* idx, int G, int64_t B, int k, float* out_scores,
+                           int64_t* out_idx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * a2  value/label gather  -- ToyGraphBase.py:70-71  resource_values[topk_indices], resource_labels[topk_indices]
+ *     out[m,:] = V[idx[m] - idx_base, :] for m in [0,M); rows with idx outside [idx_base, idx_base+N) are written
+ *     as zeros (lets each shard gather only the winners it owns; a sum over shards completes it).  Any D >= 1.
+ */
+int ragraph_gather_rows_f32(const float* V, int64_t N, int D, const int64_t* idx, int64_t M, int64_t idx_base,
+                            float* out, void* stream);
+
+/* a8  sum_k V[idx] and mean_k L[idx]  -- RAGraph_node/RAGraph.py:48-49 (torch.sum / torch.mean over dim=1),
+ *     edge: RAGraph_edge/modules/RAGraph.py:314,321 (mean of values: pass scale = 1/k through `v_scale`).
+ *     sum_V[b,:] = v_scale * sum_{j<k} V[idx[b,j]]   (sequential j, fp32 adds);  mean_L[b,:] = (sum_j L[idx[b,j]]) / k.
+ *     L / mean_L may be NULL (edge flavour has no labels).  Out-of-shard indices contribute zero.
+ */
+int ragraph_gather_reduce_f32(const float* V, int D, const float* L, int C, int64_t N, const int64_t* idx, int64_t B,
+                              int k, int64_t idx_base, float v_scale, float* sum_V, float* mean_L, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * a4/a9/a1  dense  Y = act(X @ W^T + b)   -- layers/gcn.py:32 (self.fc, no bias), TaskDecoder.py:15-16
+ *           (fc1+LeakyReLU, fc2), and the materialised score matrix of SimilarityFunctions.py:14 (X=Qn, W=Kn).
+ *     X [M,K], W [N,K] (nn.Linear weight layout), bias [N] or NULL, Y [M,N].  Any M,N,K >= 1.
+ *     Each Y[m,n] is one fmaf chain over k = 0..K-1 from +0; then + bias (one fp32 add); then act.
+ */
+int ragraph_linear_f32(const float* X, int64_t M, int K, const float* W, int64_t N, const float* bias, int act,
+                       float alpha, float* Y, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * a4/a7/a11  CSR SpMM with fused epilogue
+ *     Y[r,:] = act( sum_{e in row r} val[e] * X[col[e],:]  + bias ) + beta * Y_in[r,:]
+ *   replaces torch.mm(adj, seq_fts) + bias + PReLU (layers/gcn.py:36-40), relu(adj_normalized @ x)
+ *   (Propagation.py:22-25) and the gather-scale-scatter_add of RAGraph_edge/modules/RAGraph.py:232-240 (edges sorted
+ *   by destination once; no atomics, so the sum order is the CSR order and the result is deterministic).
+ *   rowptr [n+1] int64, col [nnz] int32, val [nnz] fp32, X [n_cols,D], Y [n,D]; D % 4 == 0; X,Y 16-byte aligned.
+ *   Row sum = one fmaf chain in CSR order from +0.  bias [D] or NULL; Y_in [n,D] or NULL (beta ignored then).
+ *   Y must not alias X.
+ */
+int ragraph_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n, const float* X, int D,
+                         const float* bias, int act, float alpha, float beta, const float* Y_in, float* Y,
+                         void* stream);
+
+/* a7  adj / adj.sum(dim=1, keepdim=True)  -- Propagation.py:15-16.  val_out[e] = val[e] / rowsum(row(e)), rowsum =
+ *     sequential fp32 adds in CSR order.  In-place allowed.  (A zero row sum gives inf/nan exactly as the reference.) */
+int ragraph_csr_row_normalize_f32(const int64_t* rowptr, const float* val, int64_t n, float* val_out, void* stream);
+
+/* a12  torch_scatter.scatter_softmax(x, dst)  -- RAGraph_edge/modules/RAGraph.py:261 (torch_scatter 2.1.2: per
+ *      segment max, exp(x - max), divide by the segment sum).  Segments = CSR rows (edges sorted by destination). */
+int ragraph_segment_softmax_f32(const int64_t* rowptr, const float* x, int64_t n, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * a8  fusion arithmetic  -- RAGraph_node/RAGraph.py:53  hidden = query*(1-w) + rag*w  (two multiplies, one add,
+ *     NOT contracted to an fma, matching the eager reference).  a,b,out [n] elementwise; in-place allowed. */
+int ragraph_axpby_f32(const float* a, float wa, const float* b, float wb, int64_t n, float* out, void* stream);
+
+/* a8  torch.softmax(decode_label, dim=1) * (1-lambda) + rag_label * lambda  -- RAGraph_node/RAGraph.py:55-57.
+ *     logits [B,C], rag_label [B,C] or NULL (then plain softmax; log_mode=1 gives log_softmax, downprompt.py:54).
+ *     C <= 1024. */
+int ragraph_softmax_mix_f32(const float* logits, const float* rag_label, int64_t B, int C, float lambda, int log_mode,
+                            float* out, void* stream);
+
+/* a8 (graph flavour)  torch.mean(x, dim=0)  -- RAGraph_graph/RAGraph.py:50,63; a10 segment sum readout
+ *     split_and_batchify_graph_feats  -- RAGraph_graph/downprompt.py:98-112.
+ *     out[g,:] = scale_g * sum_{r in [seg_ptr[g], seg_ptr[g+1])} (w ? w[:] * X[r,:] : X[r,:]),  sequential r.
+ *     mean_mode=1: scale_g = 1/len_g, else 1.  w [D] = downstreamprompt weight (downprompt.py:154-168) or NULL;
+ *     elu=1 applies ELU to w*x before summing?  No: the graph flavour sums w*x (downprompt.py:21,167); the node flavour
+ *     has no readout.  D % 4 == 0. */
+int ragraph_segment_reduce_f32(const float* X, int D, const int64_t* seg_ptr, int64_t G, const float* w, int mean_mode,
+                               float* out, void* stream);
+
+/* a10  cosine-to-prototype logits  -- RAGraph_graph/downprompt.py:41-56 (predict: cosine_similarity to each class
+ *      mean, eps=1e-8, then log_softmax) and RAGraph_node/downprompt.py:41-46 (softmax).
+ *      emb [G,D], proto [C,D] -> out [G,C];  mode 0 = raw cosine, 1 = softmax, 2 = log_softmax.  C <= 64. */
+int ragraph_proto_cosine_f32(const float* emb, int64_t G, int D, const float* proto, int C, int mode, float* out,
+                             void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAGRAPH_HIP_H */

@@ -1,0 +1,287 @@
+// Row-wise helpers around the two big kernels: L2 normalisation, winner gathers, fusion arithmetic, class softmax.
+// All are HBM-bound elementwise / gather work: coalesced float4 (16 B per lane) accesses, one wave per row.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace ragraph {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---- a1: F.normalize(x, p=2, dim=-1, eps=1e-12) (SimilarityFunctions.py:8,11) ---------------------------------------
+// One wave per row.  Norm tree (the oracle restates it): lane l accumulates, with fmaf, the squares of the elements of
+// its float4 chunks c = l, l+64, ... (element order inside a chunk 0..3), then a 6-step xor butterfly 32,16,...,1.
+template <bool VEC4>
+__global__ void __launch_bounds__(256) normalize_rows_kernel(const float* __restrict__ X, int64_t n, int D,
+                                                             float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const float* x = X + row * D;
+  float* o = out + row * D;
+  const int nchunk = (D + 3) >> 2;
+  float p = 0.f;
+  if (VEC4) {
+    for (int c = lane; c < nchunk; c += 64) {
+      const float4 v = reinterpret_cast<const float4*>(x)[c];
+      p = fmaf(v.x, v.x, p);
+      p = fmaf(v.y, v.y, p);
+      p = fmaf(v.z, v.z, p);
+      p = fmaf(v.w, v.w, p);
+    }
+  } else {
+    for (int c = lane; c < nchunk; c += 64) {
+      for (int e = 4 * c; e < 4 * c + 4 && e < D; ++e) p = fmaf(x[e], x[e], p);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) p = __fadd_rn(p, __shfl_xor(p, off));
+  const float d = fmaxf(sqrtf(p), 1e-12f);
+  if (VEC4) {
+    for (int c = lane; c < nchunk; c += 64) {
+      float4 v = reinterpret_cast<const float4*>(x)[c];
+      v.x = v.x / d; v.y = v.y / d; v.z = v.z / d; v.w = v.w / d;
+      reinterpret_cast<float4*>(o)[c] = v;
+    }
+  } else {
+    for (int e = lane; e < D; e += 64) o[e] = x[e] / d;
+  }
+}
+
+// ---- a2: V[idx] (ToyGraphBase.py:70-71) -----------------------------------------------------------------------------
+template <bool VEC4>
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restrict__ V, int64_t N, int D,
+                                                          const int64_t* __restrict__ idx, int64_t M, int64_t base,
+                                                          float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int64_t r = idx[m] - base;
+  const bool own = (r >= 0 && r < N);
+  if (VEC4) {
+    const int D4 = D >> 2;
+    for (int c = lane; c < D4; c += 64) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (own) v = reinterpret_cast<const float4*>(V + r * D)[c];
+      reinterpret_cast<float4*>(out + m * D)[c] = v;
+    }
+  } else {
+    for (int e = lane; e < D; e += 64) out[m * D + e] = own ? V[r * D + e] : 0.f;
+  }
+}
+
+// ---- a8: sum_k V[idx], mean_k L[idx] (RAGraph.py:48-49); one wave per query, winners added in rank order -------------
+__global__ void __launch_bounds__(256) gather_reduce_kernel(const float* __restrict__ V, int D,
+                                                            const float* __restrict__ L, int C, int64_t N,
+                                                            const int64_t* __restrict__ idx, int64_t B, int k,
+                                                            int64_t base, float v_scale, float* __restrict__ sumV,
+                                                            float* __restrict__ meanL) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int64_t* ib = idx + b * k;
+  for (int e = lane; e < D; e += 64) {
+    float acc = 0.f;
+    for (int jx = 0; jx < k; ++jx) {
+      const int64_t r = ib[jx] - base;
+      if (r >= 0 && r < N) acc = __fadd_rn(acc, V[r * D + e]);
+    }
+    sumV[b * D + e] = (v_scale == 1.f) ? acc : __fmul_rn(acc, v_scale);
+  }
+  if (L && meanL) {
+    for (int c = lane; c < C; c += 64) {
+      float acc = 0.f;
+      for (int jx = 0; jx < k; ++jx) {
+        const int64_t r = ib[jx] - base;
+        if (r >= 0 && r < N) acc = __fadd_rn(acc, L[r * C + c]);
+      }
+      meanL[b * C + c] = acc / (float)k;
+    }
+  }
+}
+
+// ---- a8: hidden = a*wa + b*wb, uncontracted (RAGraph.py:53) ---------------------------------------------------------
+__global__ void __launch_bounds__(256) axpby_kernel(const float* __restrict__ a, float wa, const float* __restrict__ b,
+                                                    float wb, int64_t n, float* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    out[i] = __fadd_rn(__fmul_rn(a[i], wa), __fmul_rn(b[i], wb));
+}
+
+// ---- a8: softmax(logits)*(1-lambda) + rag_label*lambda (RAGraph.py:55-57); one thread per row, C is a class count ----
+__global__ void __launch_bounds__(256) softmax_mix_kernel(const float* __restrict__ logits,
+                                                          const float* __restrict__ rag, int64_t B, int C,
+                                                          float lambda, int log_mode, float* __restrict__ out) {
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const float* x = logits + b * C;
+  float m = x[0];
+  for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s = __fadd_rn(s, expf(x[c] - m));
+  const float one_m = 1.f - lambda;
+  const float ls = logf(s);
+  for (int c = 0; c < C; ++c) {
+    float p;
+    if (log_mode)
+      p = (x[c] - m) - ls;
+    else
+      p = expf(x[c] - m) / s;
+    if (rag) p = __fadd_rn(__fmul_rn(p, one_m), __fmul_rn(rag[b * C + c], lambda));
+    out[b * C + c] = p;
+  }
+}
+
+// ---- a10: cosine to class prototypes (+softmax / log_softmax), downprompt.py:41-56; one wave per embedding ----------
+__global__ void __launch_bounds__(256) proto_cosine_kernel(const float* __restrict__ emb, int64_t G, int D,
+                                                           const float* __restrict__ proto, int C, int mode,
+                                                           float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= G) return;
+  const float* x = emb + g * D;
+  float xx = 0.f;
+  for (int e = lane; e < D; e += 64) xx = fmaf(x[e], x[e], xx);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) xx = __fadd_rn(xx, __shfl_xor(xx, off));
+  float myv = 0.f;  // lane c keeps the cosine to class c
+  for (int c = 0; c < C; ++c) {
+    const float* pc = proto + (int64_t)c * D;
+    float xy = 0.f, yy = 0.f;
+    for (int e = lane; e < D; e += 64) {
+      xy = fmaf(x[e], pc[e], xy);
+      yy = fmaf(pc[e], pc[e], yy);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      xy = __fadd_rn(xy, __shfl_xor(xy, off));
+      yy = __fadd_rn(yy, __shfl_xor(yy, off));
+    }
+    // torch.cosine_similarity(x, y, dim=0, eps=1e-8): x.y / (max(|x|, eps) * max(|y|, eps))
+    const float cs = xy / (fmaxf(sqrtf(xx), 1e-8f) * fmaxf(sqrtf(yy), 1e-8f));
+    if (lane == c) myv = cs;
+  }
+  if (mode != 0) {
+    float v = (lane < C) ? myv : RG_NEG_INF;
+    float m = v;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    float ex = (lane < C) ? expf(v - m) : 0.f;
+    float s = ex;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s = __fadd_rn(s, __shfl_xor(s, off));
+    myv = (mode == 1) ? ex / s : (v - m) - logf(s);
+  }
+  if (lane < C) out[g * C + lane] = myv;
+}
+
+}  // namespace ragraph
+
+using namespace ragraph;
+
+extern "C" int ragraph_abi_version(void) { return RAGRAPH_ABI_VERSION; }
+extern "C" const char* ragraph_last_error(void) { return g_err; }
+
+extern "C" int ragraph_device_check(void) {
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    set_error("no HIP device visible: %s", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    return RAGRAPH_EDEVICE;
+  }
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    set_error("cannot query the current HIP device");
+    return RAGRAPH_EDEVICE;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("device %d is %s; libragraph_hip.so carries gfx950 (MI355X) code only", dev, prop.gcnArchName);
+    return RAGRAPH_EDEVICE;
+  }
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_normalize_rows_f32(const float* X, int64_t n, int D, float* out, void* stream) {
+  RG_REQUIRE(X && out, RAGRAPH_EINVAL, "normalize_rows: null pointer");
+  RG_REQUIRE(n >= 0 && D >= 1, RAGRAPH_EINVAL, "normalize_rows: n=%lld D=%d", (long long)n, D);
+  if (n == 0) return RAGRAPH_OK;
+  const bool vec = (D % 4 == 0) && aligned16(X) && aligned16(out);
+  dim3 grid((unsigned)cdiv(n, 4));
+  if (vec)
+    hipLaunchKernelGGL(normalize_rows_kernel<true>, grid, dim3(256), 0, as_stream(stream), X, n, D, out);
+  else
+    hipLaunchKernelGGL(normalize_rows_kernel<false>, grid, dim3(256), 0, as_stream(stream), X, n, D, out);
+  RG_CHECK_LAUNCH("normalize_rows");
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_gather_rows_f32(const float* V, int64_t N, int D, const int64_t* idx, int64_t M,
+                                       int64_t idx_base, float* out, void* stream) {
+  RG_REQUIRE(V && idx && out, RAGRAPH_EINVAL, "gather_rows: null pointer");
+  RG_REQUIRE(N >= 0 && D >= 1 && M >= 0, RAGRAPH_EINVAL, "gather_rows: bad shape");
+  if (M == 0) return RAGRAPH_OK;
+  const bool vec = (D % 4 == 0) && aligned16(V) && aligned16(out);
+  dim3 grid((unsigned)cdiv(M, 4));
+  if (vec)
+    hipLaunchKernelGGL(gather_rows_kernel<true>, grid, dim3(256), 0, as_stream(stream), V, N, D, idx, M, idx_base, out);
+  else
+    hipLaunchKernelGGL(gather_rows_kernel<false>, grid, dim3(256), 0, as_stream(stream), V, N, D, idx, M, idx_base, out);
+  RG_CHECK_LAUNCH("gather_rows");
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_gather_reduce_f32(const float* V, int D, const float* L, int C, int64_t N, const int64_t* idx,
+                                         int64_t B, int k, int64_t idx_base, float v_scale, float* sum_V,
+                                         float* mean_L, void* stream) {
+  RG_REQUIRE(V && idx && sum_V, RAGRAPH_EINVAL, "gather_reduce: null pointer");
+  RG_REQUIRE(D >= 1 && k >= 1 && B >= 0 && N >= 0, RAGRAPH_EINVAL, "gather_reduce: bad shape");
+  RG_REQUIRE((L == nullptr) == (mean_L == nullptr), RAGRAPH_EINVAL, "gather_reduce: L and mean_L go together");
+  RG_REQUIRE(!L || C >= 1, RAGRAPH_EINVAL, "gather_reduce: C=%d", C);
+  if (B == 0) return RAGRAPH_OK;
+  hipLaunchKernelGGL(gather_reduce_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, as_stream(stream), V, D, L, C, N,
+                     idx, B, k, idx_base, v_scale, sum_V, mean_L);
+  RG_CHECK_LAUNCH("gather_reduce");
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_axpby_f32(const float* a, float wa, const float* b, float wb, int64_t n, float* out,
+                                 void* stream) {
+  RG_REQUIRE(a && b && out, RAGRAPH_EINVAL, "axpby: null pointer");
+  if (n <= 0) return RAGRAPH_OK;
+  int64_t blocks = cdiv(n, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a, wa, b, wb, n, out);
+  RG_CHECK_LAUNCH("axpby");
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_softmax_mix_f32(const float* logits, const float* rag_label, int64_t B, int C, float lambda,
+                                       int log_mode, float* out, void* stream) {
+  RG_REQUIRE(logits && out, RAGRAPH_EINVAL, "softmax_mix: null pointer");
+  RG_REQUIRE(C >= 1 && C <= 1024, RAGRAPH_EUNSUPPORTED, "softmax_mix: C=%d not in [1,1024]", C);
+  if (B <= 0) return RAGRAPH_OK;
+  hipLaunchKernelGGL(softmax_mix_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, as_stream(stream), logits,
+                     rag_label, B, C, lambda, log_mode, out);
+  RG_CHECK_LAUNCH("softmax_mix");
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_proto_cosine_f32(const float* emb, int64_t G, int D, const float* proto, int C, int mode,
+                                        float* out, void* stream) {
+  RG_REQUIRE(emb && proto && out, RAGRAPH_EINVAL, "proto_cosine: null pointer");
+  RG_REQUIRE(C >= 1 && C <= 64, RAGRAPH_EUNSUPPORTED, "proto_cosine: C=%d not in [1,64]", C);
+  RG_REQUIRE(D >= 1 && mode >= 0 && mode <= 2, RAGRAPH_EINVAL, "proto_cosine: bad D/mode");
+  if (G <= 0) return RAGRAPH_OK;
+  hipLaunchKernelGGL(proto_cosine_kernel, dim3((unsigned)cdiv(G, 4)), dim3(256), 0, as_stream(stream), emb, G, D, proto,
+                     C, mode, out);
+  RG_CHECK_LAUNCH("proto_cosine");
+  return RAGRAPH_OK;
+}

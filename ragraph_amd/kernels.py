@@ -1,0 +1,249 @@
+"""torch.Tensor front end of the C ABI (include/ragraph_hip.h).
+
+PyTorch is plumbing here: it owns HBM allocations and the HIP stream; every number is produced by libragraph_hip.so.
+All functions require CUDA(=ROCm) tensors and raise `RagraphNativeError` otherwise -- there is no eager fallback.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _native as N
+from ._native import ACT_ELU, ACT_LEAKY, ACT_NONE, ACT_PRELU, ACT_RELU, RagraphNativeError  # noqa: F401
+
+_device_ok = False
+
+
+def _ready():
+    global _device_ok
+    if not _device_ok:
+        N.require_device()
+        _device_ok = True
+    return N.lib()
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RagraphNativeError(f"{name}: expected a ROCm device tensor (ragraph_amd has no CPU fallback)")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _idxc(t: torch.Tensor, name: str, dtype=torch.int64) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RagraphNativeError(f"{name}: expected a ROCm device tensor")
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def normalize_rows(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """F.normalize(x, p=2, dim=-1) -- SimilarityFunctions.py:8,11."""
+    L = _ready()
+    x = _f32c(x, "normalize_rows.x")
+    x2 = x.reshape(-1, x.shape[-1])
+    if out is None:
+        out = torch.empty_like(x2)
+    N.check(L.ragraph_normalize_rows_f32(x2.data_ptr(), x2.shape[0], x2.shape[1], out.data_ptr(), _stream()),
+            "normalize_rows")
+    return out.reshape(x.shape)
+
+
+_ws_cache: dict = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """One grow-only scratch buffer per (device, stream): calls on a stream are ordered, so reuse is safe."""
+    key = (device, _stream())
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def topk_cosine(q: torch.Tensor, keys_normalized: torch.Tensor, k: int, idx_base: int = 0):
+    """Fused normalize(q) @ keys_normalized.T -> top-k.  Returns (scores [B,k] f32, idx [B,k] i64), canonical order.
+
+    SimilarityFunctions.py:6-16 + ToyGraphBase.py:66-67.  `keys_normalized` must come from normalize_rows()."""
+    L = _ready()
+    q = _f32c(q, "topk_cosine.q")
+    kn = _f32c(keys_normalized, "topk_cosine.keys")
+    if q.dim() != 2 or kn.dim() != 2 or q.shape[1] != kn.shape[1]:
+        raise RagraphNativeError(f"topk_cosine: bad shapes {tuple(q.shape)} x {tuple(kn.shape)}")
+    B, D = q.shape
+    Nk = kn.shape[0]
+    scores = torch.empty((B, k), dtype=torch.float32, device=q.device)
+    idx = torch.empty((B, k), dtype=torch.int64, device=q.device)
+    if B == 0:
+        return scores, idx
+    nbytes = L.ragraph_topk_cosine_workspace_bytes(B, Nk, D, k)
+    ws = _workspace(nbytes, q.device)
+    N.check(L.ragraph_topk_cosine_f32(q.data_ptr(), B, kn.data_ptr(), Nk, D, k, idx_base, scores.data_ptr(),
+                                      idx.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "topk_cosine")
+    return scores, idx
+
+
+def topk_merge(scores: torch.Tensor, idx: torch.Tensor):
+    """[G,B,k] per-shard lists -> canonical [B,k]."""
+    L = _ready()
+    scores = _f32c(scores, "topk_merge.scores")
+    idx = _idxc(idx, "topk_merge.idx")
+    G, B, k = scores.shape
+    out_s = torch.empty((B, k), dtype=torch.float32, device=scores.device)
+    out_i = torch.empty((B, k), dtype=torch.int64, device=scores.device)
+    N.check(L.ragraph_topk_merge_f32(scores.data_ptr(), idx.data_ptr(), G, B, k, out_s.data_ptr(), out_i.data_ptr(),
+                                     _stream()), "topk_merge")
+    return out_s, out_i
+
+
+def gather_rows(v: torch.Tensor, idx: torch.Tensor, idx_base: int = 0) -> torch.Tensor:
+    """v[idx] -- ToyGraphBase.py:70-71.  Rows outside [idx_base, idx_base+N) come back as zeros."""
+    L = _ready()
+    v = _f32c(v, "gather_rows.v")
+    idx = _idxc(idx, "gather_rows.idx")
+    out = torch.empty(tuple(idx.shape) + (v.shape[1],), dtype=torch.float32, device=v.device)
+    N.check(L.ragraph_gather_rows_f32(v.data_ptr(), v.shape[0], v.shape[1], idx.data_ptr(), idx.numel(), idx_base,
+                                      out.data_ptr(), _stream()), "gather_rows")
+    return out
+
+
+def gather_reduce(v: torch.Tensor, labels: torch.Tensor | None, idx: torch.Tensor, idx_base: int = 0,
+                  v_scale: float = 1.0):
+    """(v_scale * sum_k v[idx], mean_k labels[idx]) -- RAGraph.py:48-49; edge modules/RAGraph.py:321 (v_scale=1/k)."""
+    L = _ready()
+    v = _f32c(v, "gather_reduce.v")
+    idx = _idxc(idx, "gather_reduce.idx")
+    B, k = idx.shape
+    sum_v = torch.empty((B, v.shape[1]), dtype=torch.float32, device=v.device)
+    mean_l = None
+    C = 0
+    if labels is not None:
+        labels = _f32c(labels, "gather_reduce.labels")
+        C = labels.shape[1]
+        mean_l = torch.empty((B, C), dtype=torch.float32, device=v.device)
+    N.check(L.ragraph_gather_reduce_f32(v.data_ptr(), v.shape[1], _ptr(labels), C, v.shape[0], idx.data_ptr(), B, k,
+                                        idx_base, float(v_scale), sum_v.data_ptr(), _ptr(mean_l), _stream()),
+            "gather_reduce")
+    return sum_v, mean_l
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None, act: int = ACT_NONE,
+           alpha: float = 0.0) -> torch.Tensor:
+    """act(x @ weight.T + bias) -- layers/gcn.py:32, TaskDecoder.py:15-16."""
+    L = _ready()
+    x = _f32c(x, "linear.x")
+    w = _f32c(weight, "linear.weight")
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1])
+    if w.dim() != 2 or w.shape[1] != x2.shape[1]:
+        raise RagraphNativeError(f"linear: bad shapes {tuple(x.shape)} x {tuple(w.shape)}")
+    b = None if bias is None else _f32c(bias, "linear.bias")
+    y = torch.empty((x2.shape[0], w.shape[0]), dtype=torch.float32, device=x.device)
+    if x2.shape[0] > 0:
+        N.check(L.ragraph_linear_f32(x2.data_ptr(), x2.shape[0], x2.shape[1], w.data_ptr(), w.shape[0], _ptr(b), act,
+                                     float(alpha), y.data_ptr(), _stream()), "linear")
+    return y.reshape(tuple(lead) + (w.shape[0],))
+
+
+def spmm_csr(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, x: torch.Tensor,
+             bias: torch.Tensor | None = None, act: int = ACT_NONE, alpha: float = 0.0, beta: float = 0.0,
+             y_in: torch.Tensor | None = None) -> torch.Tensor:
+    """act(A @ x + bias) + beta*y_in for CSR A -- layers/gcn.py:36-40, Propagation.py:22-25, edge _agg."""
+    L = _ready()
+    rowptr = _idxc(rowptr, "spmm_csr.rowptr")
+    col = _idxc(col, "spmm_csr.col", torch.int32)
+    val = _f32c(val, "spmm_csr.val")
+    x = _f32c(x, "spmm_csr.x")
+    n = rowptr.numel() - 1
+    D = x.shape[1]
+    b = None if bias is None else _f32c(bias, "spmm_csr.bias")
+    yi = None if y_in is None else _f32c(y_in, "spmm_csr.y_in")
+    y = torch.empty((n, D), dtype=torch.float32, device=x.device)
+    N.check(L.ragraph_spmm_csr_f32(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), n, x.data_ptr(), D, _ptr(b), act,
+                                   float(alpha), float(beta), _ptr(yi), y.data_ptr(), _stream()), "spmm_csr")
+    return y
+
+
+def csr_row_normalize(rowptr: torch.Tensor, val: torch.Tensor) -> torch.Tensor:
+    """val / rowsum -- Propagation.py:15-16."""
+    L = _ready()
+    rowptr = _idxc(rowptr, "csr_row_normalize.rowptr")
+    val = _f32c(val, "csr_row_normalize.val")
+    out = torch.empty_like(val)
+    N.check(L.ragraph_csr_row_normalize_f32(rowptr.data_ptr(), val.data_ptr(), rowptr.numel() - 1, out.data_ptr(),
+                                            _stream()), "csr_row_normalize")
+    return out
+
+
+def segment_softmax(rowptr: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """scatter_softmax over CSR rows -- RAGraph_edge/modules/RAGraph.py:261."""
+    L = _ready()
+    rowptr = _idxc(rowptr, "segment_softmax.rowptr")
+    x = _f32c(x, "segment_softmax.x")
+    out = torch.zeros_like(x)
+    N.check(L.ragraph_segment_softmax_f32(rowptr.data_ptr(), x.data_ptr(), rowptr.numel() - 1, out.data_ptr(),
+                                          _stream()), "segment_softmax")
+    return out
+
+
+def axpby(a: torch.Tensor, wa: float, b: torch.Tensor, wb: float) -> torch.Tensor:
+    """a*wa + b*wb (uncontracted) -- RAGraph.py:53."""
+    L = _ready()
+    a = _f32c(a, "axpby.a")
+    b = _f32c(b, "axpby.b")
+    if a.shape != b.shape:
+        raise RagraphNativeError(f"axpby: shapes differ {tuple(a.shape)} vs {tuple(b.shape)}")
+    out = torch.empty_like(a)
+    N.check(L.ragraph_axpby_f32(a.data_ptr(), float(wa), b.data_ptr(), float(wb), a.numel(), out.data_ptr(),
+                                _stream()), "axpby")
+    return out
+
+
+def softmax_mix(logits: torch.Tensor, rag_label: torch.Tensor | None, lam: float = 0.0,
+                log_mode: bool = False) -> torch.Tensor:
+    """softmax(logits)*(1-lam) + rag_label*lam -- RAGraph.py:55-57."""
+    L = _ready()
+    logits = _f32c(logits, "softmax_mix.logits")
+    lg = logits.reshape(-1, logits.shape[-1])
+    rl = None if rag_label is None else _f32c(rag_label, "softmax_mix.rag_label").reshape(lg.shape)
+    out = torch.empty_like(lg)
+    N.check(L.ragraph_softmax_mix_f32(lg.data_ptr(), _ptr(rl), lg.shape[0], lg.shape[1], float(lam), int(log_mode),
+                                      out.data_ptr(), _stream()), "softmax_mix")
+    return out.reshape(logits.shape)
+
+
+def segment_reduce(x: torch.Tensor, seg_ptr: torch.Tensor, w: torch.Tensor | None = None,
+                   mean_mode: bool = False) -> torch.Tensor:
+    """Per-segment sum (or mean) of rows, optionally of w*x -- RAGraph_graph/RAGraph.py:50,63; downprompt.py:98-112."""
+    L = _ready()
+    x = _f32c(x, "segment_reduce.x")
+    seg_ptr = _idxc(seg_ptr, "segment_reduce.seg_ptr")
+    wv = None if w is None else _f32c(w, "segment_reduce.w").reshape(-1)
+    G = seg_ptr.numel() - 1
+    out = torch.empty((G, x.shape[1]), dtype=torch.float32, device=x.device)
+    N.check(L.ragraph_segment_reduce_f32(x.data_ptr(), x.shape[1], seg_ptr.data_ptr(), G, _ptr(wv), int(mean_mode),
+                                         out.data_ptr(), _stream()), "segment_reduce")
+    return out
+
+
+def proto_cosine(emb: torch.Tensor, proto: torch.Tensor, mode: int = 0) -> torch.Tensor:
+    """cosine(emb_g, proto_c) (+softmax / log_softmax) -- downprompt.py:41-56."""
+    L = _ready()
+    emb = _f32c(emb, "proto_cosine.emb")
+    proto = _f32c(proto, "proto_cosine.proto")
+    G, D = emb.shape
+    C = proto.shape[0]
+    out = torch.empty((G, C), dtype=torch.float32, device=emb.device)
+    N.check(L.ragraph_proto_cosine_f32(emb.data_ptr(), G, D, proto.data_ptr(), C, mode, out.data_ptr(), _stream()),
+            "proto_cosine")
+    return out

@@ -1,0 +1,235 @@
+"""HIP kernels (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bar: BIT-EXACT for every fmaf-chain kernel (scores, linear, SpMM, norms, gathers, sums) and for all indices; 1e-6
+for the kernels that call expf/logf (softmax family), whose libm differs between host and device.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+def _bank(rng, N, D):
+    return cref.normalize_rows(rng.standard_normal((N, D), dtype=np.float32))
+
+
+@pytest.mark.parametrize("n,D", [(1, 1), (5, 3), (7, 64), (33, 128), (257, 256), (4, 1433), (3, 300)])
+def test_normalize_rows_bit_exact(dev, n, D):
+    from ragraph_amd import kernels as K
+
+    x = _rng(n * 1000 + D).standard_normal((n, D), dtype=np.float32)
+    x[0] *= 1e-3
+    if n > 1:
+        x[1] = 0.0  # zero row: eps clamp -> zeros (F.normalize eps semantics)
+    got = K.normalize_rows(_t(x, dev)).cpu().numpy()
+    ref = cref.normalize_rows(x)
+    assert np.array_equal(got, ref)
+    # and it is F.normalize up to rounding of the norm
+    tref = torch.nn.functional.normalize(torch.from_numpy(x), p=2, dim=-1).numpy()
+    assert np.allclose(got, tref, atol=1e-6)
+
+
+@pytest.mark.parametrize(
+    "B,N,D,k",
+    [
+        (1, 1000, 256, 3),       # graph flavour: one query
+        (7, 33, 64, 5),          # tiny bank, ragged tile
+        (64, 4096, 64, 10),
+        (300, 5000, 128, 8),     # > one query tile, N not a stage multiple
+        (256, 20000, 256, 10),
+        (513, 70001, 256, 10),   # several splits, ragged everything
+        (40, 10, 256, 10),       # k == N
+        (100, 3000, 256, 1),
+        (50, 9000, 256, 32),     # k at the fused kernel's maximum
+    ],
+)
+def test_topk_cosine_bit_exact(dev, B, N, D, k):
+    from ragraph_amd import kernels as K
+
+    rng = _rng(B * 7 + N + D + k)
+    kn = _bank(rng, N, D)
+    q = rng.standard_normal((B, D), dtype=np.float32)
+    s, i = K.topk_cosine(_t(q, dev), _t(kn, dev), k, idx_base=5)
+    rs, ri = cref.topk_cosine(q, kn, k, idx_base=5)
+    assert np.array_equal(i.cpu().numpy(), ri)
+    assert np.array_equal(s.cpu().numpy(), rs)
+
+
+def test_topk_cosine_duplicates_and_zero_query(dev):
+    """Toy banks hold exact duplicate keys (multinomial with replacement, ToyGraphBase.py:98); torch.topk leaves the
+    order of ties open, the library breaks them towards the lower index."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(11)
+    base = _bank(rng, 500, 256)
+    kn = np.concatenate([base, base[::-1], base[:100]], axis=0)  # every key 2-3 times
+    q = rng.standard_normal((70, 256), dtype=np.float32)
+    q[3] = 0.0  # zero-norm query: all scores 0 -> lowest k indices
+    s, i = K.topk_cosine(_t(q, dev), _t(kn, dev), 10)
+    rs, ri = cref.topk_cosine(q, kn, 10)
+    assert np.array_equal(i.cpu().numpy(), ri)
+    assert np.array_equal(s.cpu().numpy(), rs)
+    assert np.array_equal(ri[3], np.arange(10))
+
+
+def test_topk_merge_matches_single_shard(dev):
+    from ragraph_amd import kernels as K
+
+    rng = _rng(5)
+    N, D, B, k, G = 8000, 128, 77, 10, 4
+    kn = _bank(rng, N, D)
+    q = rng.standard_normal((B, D), dtype=np.float32)
+    qd, knd = _t(q, dev), _t(kn, dev)
+    full_s, full_i = K.topk_cosine(qd, knd, k)
+    per = N // G
+    ss, ii = [], []
+    for g in range(G):
+        s, i = K.topk_cosine(qd, knd[g * per:(g + 1) * per].contiguous(), k, idx_base=g * per)
+        ss.append(s)
+        ii.append(i)
+    ms, mi = K.topk_merge(torch.stack(ss), torch.stack(ii))
+    assert torch.equal(mi, full_i) and torch.equal(ms, full_s)
+    rs, ri = cref.topk_merge(torch.stack(ss).cpu().numpy(), torch.stack(ii).cpu().numpy())
+    assert np.array_equal(mi.cpu().numpy(), ri) and np.array_equal(ms.cpu().numpy(), rs)
+
+
+def test_gather_rows_and_reduce(dev):
+    from ragraph_amd import kernels as K
+
+    rng = _rng(9)
+    N, D, C, B, k = 1000, 256, 3, 37, 10
+    V = rng.standard_normal((N, D), dtype=np.float32)
+    L = np.eye(C, dtype=np.float32)[rng.integers(0, C, N)]
+    idx = rng.integers(0, N, (B, k))
+    assert np.array_equal(K.gather_rows(_t(V, dev), _t(idx, dev)).cpu().numpy(), V[idx])
+    sv, ml = K.gather_reduce(_t(V, dev), _t(L, dev), _t(idx, dev))
+    rsv, rml = cref.gather_reduce(V, L, idx)
+    assert np.array_equal(sv.cpu().numpy(), rsv) and np.array_equal(ml.cpu().numpy(), rml)
+    assert np.allclose(rsv, V[idx].sum(1), atol=1e-5) and np.allclose(rml, L[idx].mean(1), atol=1e-6)
+    # shard semantics: winners outside [base, base+N) contribute zero; two half-shards sum to the whole
+    h = N // 2
+    a, _ = K.gather_reduce(_t(V[:h], dev), None, _t(idx, dev), idx_base=0)
+    b, _ = K.gather_reduce(_t(V[h:], dev), None, _t(idx, dev), idx_base=h)
+    ra, _ = cref.gather_reduce(V[:h], None, idx, idx_base=0)
+    assert np.array_equal(a.cpu().numpy(), ra)
+    assert np.allclose((a + b).cpu().numpy(), rsv, atol=1e-5)
+    # edge flavour: mean of values (v_scale = 1/k), odd width
+    V3 = rng.standard_normal((N, 30), dtype=np.float32)
+    m, _ = K.gather_reduce(_t(V3, dev), None, _t(idx, dev), v_scale=1.0 / k)
+    rm, _ = cref.gather_reduce(V3, None, idx, v_scale=1.0 / k)
+    assert np.array_equal(m.cpu().numpy(), rm)
+
+
+@pytest.mark.parametrize("M,K_,N_,act", [(1, 1, 1, 0), (33, 18, 256, 2), (200, 1433, 256, 0), (130, 256, 3, 3),
+                                         (65, 256, 256, 3), (64, 64, 64, 1)])
+def test_linear_bit_exact(dev, M, K_, N_, act):
+    from ragraph_amd import kernels as K
+
+    rng = _rng(M + K_ + N_)
+    X = rng.standard_normal((M, K_), dtype=np.float32)
+    W = (rng.standard_normal((N_, K_), dtype=np.float32) / np.sqrt(K_)).astype(np.float32)
+    b = rng.standard_normal(N_, dtype=np.float32)
+    got = K.linear(_t(X, dev), _t(W, dev), _t(b, dev), act=act, alpha=0.25).cpu().numpy()
+    ref = cref.linear(X, W, b, act=act, alpha=0.25)
+    assert np.array_equal(got, ref)
+    got = K.linear(_t(X, dev), _t(W, dev)).cpu().numpy()
+    assert np.array_equal(got, cref.linear(X, W))
+    assert np.allclose(got, X @ W.T, atol=1e-4)
+
+
+def _rand_csr(rng, n, ncols, mean_deg, empty_rows=True):
+    deg = rng.poisson(mean_deg, n)
+    if empty_rows and n > 2:
+        deg[1] = 0
+    if n > 3:
+        deg[3] = 5 * mean_deg + 67  # one long row
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(deg)
+    col = rng.integers(0, ncols, rowptr[-1]).astype(np.int32)
+    val = rng.random(rowptr[-1], dtype=np.float32) + 0.1
+    return rowptr, col, val
+
+
+@pytest.mark.parametrize("n,D,act", [(50, 256, 2), (300, 64, 1), (77, 128, 0), (10, 4, 1), (40, 512, 3), (64, 20, 0)])
+def test_spmm_csr_bit_exact(dev, n, D, act):
+    from ragraph_amd import kernels as K
+
+    rng = _rng(n + D)
+    rowptr, col, val = _rand_csr(rng, n, n, 6)
+    X = rng.standard_normal((n, D), dtype=np.float32)
+    b = rng.standard_normal(D, dtype=np.float32)
+    Yin = rng.standard_normal((n, D), dtype=np.float32)
+    args = (_t(rowptr, dev), _t(col, dev), _t(val, dev), _t(X, dev))
+    got = K.spmm_csr(*args, bias=_t(b, dev), act=act, alpha=0.25).cpu().numpy()
+    assert np.array_equal(got, cref.spmm_csr(rowptr, col, val, X, bias=b, act=act, alpha=0.25))
+    got = K.spmm_csr(*args, act=act, alpha=0.25, beta=1.0, y_in=_t(Yin, dev)).cpu().numpy()
+    assert np.array_equal(got, cref.spmm_csr(rowptr, col, val, X, act=act, alpha=0.25, beta=1.0, Y_in=Yin))
+
+
+def test_csr_row_normalize_and_segment_softmax(dev):
+    from ragraph_amd import kernels as K
+
+    rng = _rng(3)
+    rowptr, col, val = _rand_csr(rng, 500, 500, 8, empty_rows=False)
+    got = K.csr_row_normalize(_t(rowptr, dev), _t(val, dev)).cpu().numpy()
+    assert np.array_equal(got, cref.csr_row_normalize(rowptr, val))
+    rowptr2, _, x = _rand_csr(rng, 400, 400, 5, empty_rows=True)
+    got = K.segment_softmax(_t(rowptr2, dev), _t(x, dev)).cpu().numpy()
+    ref = cref.segment_softmax(rowptr2, x)
+    assert np.allclose(got, ref, rtol=1e-6, atol=1e-7)
+    sums = np.add.reduceat(got, rowptr2[:-1][np.diff(rowptr2) > 0])
+    assert np.allclose(sums, 1.0, atol=1e-5)
+
+
+def test_segment_reduce_axpby_softmax_proto(dev):
+    from ragraph_amd import kernels as K
+
+    rng = _rng(21)
+    X = rng.standard_normal((300, 256), dtype=np.float32)
+    sizes = np.array([10, 1, 80, 0, 39, 170])
+    seg = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    w = rng.standard_normal(256, dtype=np.float32)
+    for ww, mm in [(None, True), (w, False), (None, False)]:
+        got = K.segment_reduce(_t(X, dev), _t(seg, dev), None if ww is None else _t(ww, dev), mean_mode=mm)
+        ref = cref.segment_reduce(X, seg, ww, mean_mode=mm)
+        ok = np.isfinite(ref)
+        assert np.array_equal(got.cpu().numpy()[ok], ref[ok])
+    a = rng.standard_normal((100, 256), dtype=np.float32)
+    b = rng.standard_normal((100, 256), dtype=np.float32)
+    assert np.array_equal(K.axpby(_t(a, dev), 0.7, _t(b, dev), 0.3).cpu().numpy(), cref.axpby(a, 0.7, b, 0.3))
+    lg = rng.standard_normal((1000, 3), dtype=np.float32) * 3
+    rl = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 1000)]
+    got = K.softmax_mix(_t(lg, dev), _t(rl, dev), 0.5).cpu().numpy()
+    assert np.allclose(got, cref.softmax_mix(lg, rl, 0.5), atol=1e-6)
+    got = K.softmax_mix(_t(lg, dev), None, 0.0, log_mode=True).cpu().numpy()
+    assert np.allclose(got, cref.softmax_mix(lg, None, 0.0, log_mode=True), atol=1e-5)
+    emb = rng.standard_normal((50, 256), dtype=np.float32)
+    for C in (2, 6):
+        proto = rng.standard_normal((C, 256), dtype=np.float32)
+        for mode in (0, 1, 2):
+            got = K.proto_cosine(_t(emb, dev), _t(proto, dev), mode).cpu().numpy()
+            assert np.allclose(got, cref.proto_cosine(emb, proto, mode), atol=1e-5)
+
+
+def test_errors_are_loud(dev):
+    from ragraph_amd import kernels as K
+
+    q = torch.randn(4, 100, device=dev)
+    kn = torch.randn(50, 100, device=dev)
+    with pytest.raises(K.RagraphNativeError):
+        K.topk_cosine(q, kn, 5)  # D not in {64,128,256}
+    with pytest.raises(K.RagraphNativeError):
+        K.topk_cosine(torch.randn(4, 64, device=dev), torch.randn(3, 64, device=dev), 5)  # k > N
+    with pytest.raises(K.RagraphNativeError):
+        K.topk_cosine(torch.randn(4, 64), torch.randn(30, 64), 5)  # CPU tensors: no fallback
