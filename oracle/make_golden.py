@@ -1,0 +1,405 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (Artessay/RAGraph at /root/reference) on seeded inputs.
+
+Runs only in the build container (the reference does not exist on the GPU box); the committed .npz files are pure data
+(inputs + the reference's outputs).  The reference is imported in place under import shims -- nothing is copied:
+
+  * torch_geometric / torch_scatter / setproctitle are absent here: stub modules are put in sys.modules
+    (scatter_softmax is restated per torch_scatter 2.1.2's documented algorithm: exp(x - segment max) / segment sum);
+  * the reference hard-codes .cuda(): Tensor.cuda / Module.cuda become identity (CPU run);
+  * RAGraph_node*/models/__init__.py imports four modules that do not exist in the repository: pre-seeded as empty.
+
+Every fixture that carries top-k indices is checked to be TIE-FREE: the minimum gap between adjacent scores among
+each query's top-(k+1) must exceed 1e-5 (fp32 summation-order noise at these sizes is ~1e-7), so the indices are
+well defined independently of the BLAS the reference happened to run on.
+
+Usage:  python oracle/make_golden.py   (writes tests/golden/)
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+import sys
+import types
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+import torch.nn as nn
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+_REF_TOPLEVEL = ("models", "layers", "ragraph_utils", "utils", "preprompt", "RAGraph", "downprompt", "modules", "aug",
+                 "dataset")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# shims
+# ---------------------------------------------------------------------------------------------------------------------
+def _install_shims():
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    nn.Module.cuda = lambda self, *a, **k: self
+
+    tg = types.ModuleType("torch_geometric")
+    tgl = types.ModuleType("torch_geometric.loader")
+    tgd = types.ModuleType("torch_geometric.datasets")
+
+    class DataLoader:  # minimal: iterates a list of pre-batched objects
+        def __init__(self, dataset, batch_size=1, shuffle=False):
+            self.dataset = dataset
+
+        def __iter__(self):
+            return iter(self.dataset)
+
+    class TUDataset:  # only used as a type annotation by the reference
+        pass
+
+    tgl.DataLoader = DataLoader
+    tgd.TUDataset = TUDataset
+    tg.loader, tg.datasets = tgl, tgd
+    sys.modules.update({"torch_geometric": tg, "torch_geometric.loader": tgl, "torch_geometric.datasets": tgd})
+
+    ts = types.ModuleType("torch_scatter")
+
+    def scatter_softmax(src, index, dim=-1, dim_size=None):
+        assert src.dim() == 1
+        n = int(dim_size) if dim_size is not None else int(index.max()) + 1
+        mx = torch.full((n,), float("-inf"), dtype=src.dtype).scatter_reduce(0, index, src, reduce="amax")
+        ex = torch.exp(src - mx[index])
+        den = torch.zeros(n, dtype=src.dtype).scatter_add_(0, index, ex)
+        return ex / den[index]
+
+    ts.scatter_softmax = scatter_softmax
+    sys.modules["torch_scatter"] = ts
+    sys.modules["setproctitle"] = types.ModuleType("setproctitle")
+    sys.modules["setproctitle"].setproctitle = lambda *a, **k: None
+
+
+@contextlib.contextmanager
+def ref_project(name: str, argv=None):
+    """Import context for one of the reference's five sub-projects (they share top-level module names)."""
+    path = os.path.join(REF, name)
+    old_argv, old_cwd = sys.argv, os.getcwd()
+    for m in [m for m in sys.modules if m.split(".")[0] in _REF_TOPLEVEL]:
+        del sys.modules[m]
+    for missing in ("GAT", "GCN", "GIN", "GraphSAGE"):  # RAGraph_node/models/__init__.py:7-10 import non-existent files
+        mod = types.ModuleType(f"models.{missing}")
+        setattr(mod, missing, object)
+        sys.modules[f"models.{missing}"] = mod
+    sys.path.insert(0, path)
+    os.chdir(path)
+    if argv is not None:
+        sys.argv = argv
+    try:
+        yield
+    finally:
+        sys.path.remove(path)
+        os.chdir(old_cwd)
+        sys.argv = old_argv
+        for m in [m for m in sys.modules if m.split(".")[0] in _REF_TOPLEVEL]:
+            del sys.modules[m]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# synthetic inputs
+# ---------------------------------------------------------------------------------------------------------------------
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def unit_bank(n, d, seed):
+    return torch.nn.functional.normalize(torch.randn(n, d, generator=gen(seed)), p=2, dim=-1)
+
+
+def random_graph_adj(n, mean_deg, seed):
+    """Dense symmetric-normalised adjacency with self loops, as ragraph_utils/utility.py:19-26,66 produces."""
+    rng = np.random.default_rng(seed)
+    m = int(n * mean_deg / 2)
+    r, c = rng.integers(0, n, m), rng.integers(0, n, m)
+    keep = r != c
+    a = sp.coo_matrix((np.ones(keep.sum()), (r[keep], c[keep])), shape=(n, n)).tocsr()
+    a = ((a + a.T) > 0).astype(np.float64)
+    ring = sp.coo_matrix((np.ones(n), (np.arange(n), (np.arange(n) + 1) % n)), shape=(n, n))
+    a = ((a + ring + ring.T) > 0).astype(np.float64)
+    a = a + sp.eye(n)
+    d = np.asarray(a.sum(1)).flatten() ** -0.5
+    a = sp.diags(d) @ a @ sp.diags(d)
+    return torch.tensor(a.todense(), dtype=torch.float32)
+
+
+def min_topk_gap(scores: torch.Tensor, k: int) -> float:
+    kk = min(k + 1, scores.shape[-1])
+    top = torch.topk(scores.double(), kk, dim=-1).values
+    return float((top[..., :-1] - top[..., 1:]).min()) if kk > 1 else float("inf")
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    conv = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **conv)
+    print(f"  wrote {name}.npz  " + ", ".join(f"{k}{tuple(v.shape)}" for k, v in conv.items()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fixtures
+# ---------------------------------------------------------------------------------------------------------------------
+def g1_cosine_topk():
+    """SimilarityFunctions.calculate_cosine_similarity + torch.topk (ToyGraphBase.py:57,67)."""
+    with ref_project("RAGraph_node"):
+        from ragraph_utils.SimilarityFunctions import SimilarityFunctions as SF
+
+        for tag, (B, N, D, seed) in {"a": (64, 4096, 64, 1), "b": (96, 8192, 256, 2), "c": (33, 1000, 128, 3)}.items():
+            K = unit_bank(N, D, 100 + seed)
+            # keep the first B queries of a 4x pool whose top-11 scores are pairwise > 1e-5 apart (tie-free fixture)
+            pool = torch.randn(4 * B, D, generator=gen(200 + seed))
+            Sp = SF.calculate_cosine_similarity(pool, K)
+            top = torch.topk(Sp.double(), 11, dim=-1).values
+            ok = ((top[:, :-1] - top[:, 1:]).min(dim=1).values > 2e-5).nonzero().flatten()[:B]
+            assert len(ok) == B
+            Q = pool[ok].clone()
+            S = SF.calculate_cosine_similarity(Q, K)
+            out = {"Q": Q, "K": K, "scores_full_first8": S[:8]}
+            for k in (1, 4, 5, 10):
+                assert min_topk_gap(S, k) > 1e-5, "fixture has near-ties; change the seed"
+                ts, ti = torch.topk(S, k, largest=True, sorted=True)
+                out[f"topk_scores_k{k}"] = ts
+                out[f"topk_idx_k{k}"] = ti
+            save(f"g1{tag}_cosine_topk", **out)
+
+
+def _node_model(F_in, C, D=256, seed=0):
+    """Reference PrePrompt + RAGraph (node flavour) with an injected bank.  Must be called inside ref_project."""
+    from preprompt import PrePrompt
+    from RAGraph import RAGraph
+
+    torch.manual_seed(seed)
+    pre = PrePrompt(F_in, D, "prelu", 1, 0.3)
+    pre.eval()
+
+    class EmptyDS(list):
+        num_node_attributes = F_in
+
+    model = RAGraph(pre, EmptyDS(), F_in, C, D, finetune=True, noise_finetune=False)
+    model.eval()
+    return pre, model
+
+
+def g3_to_g6_node():
+    """GCN layer, k-hop propagation, retrieve incl. duplicate keys, TaskDecoder and the full RAGraph_node.forward."""
+    with ref_project("RAGraph_node"):
+        from ragraph_utils import Propagation
+        from ragraph_utils.ToyGraphBase import ToyGraphBase
+
+        F_in, C, D, n = 18, 3, 256, 200
+        pre, model = _node_model(F_in, C, D, seed=0)
+        with torch.no_grad():  # non-trivial bias / PReLU slope so the fused epilogue is exercised
+            pre.gcn.convs[0].bias.copy_(0.1 * torch.randn(D, generator=gen(11)))
+            pre.gcn.convs[0].act.weight.fill_(0.2)
+        adj = random_graph_adj(n, 3.7, seed=7)
+        X = torch.rand(n, F_in, generator=gen(12))
+        gcn = pre.gcn.convs[0]
+
+        # G4: one GCN layer (layers/gcn.py:26-40) == PrePrompt.inference (preprompt.py:57-66)
+        with torch.no_grad():
+            h = pre.inference(X, adj)
+            h_layer = gcn((X, adj))
+        assert torch.equal(h, h_layer)
+        save("g4_gcn_layer", X=X, adj=adj, W=gcn.fc.weight, bias=gcn.bias, alpha=gcn.act.weight, H=h)
+
+        # G5: Propagation.aggregate_k_hop_features (Propagation.py:7-27)
+        out = {"adj": adj, "x": h}
+        for k in (0, 1, 2, 3):
+            out[f"y_k{k}"] = Propagation.aggregate_k_hop_features(adj, h, k)
+        save("g5_propagation", **out)
+
+        # bank: unit keys near a random subset of h (so retrieval finds neighbours), smoothed values, one-hot labels
+        N = 2000
+        hn = torch.nn.functional.normalize(h, dim=-1)
+        for bank_seed in range(13, 1013, 100):  # first bank seed whose top-(k+1) scores are > 1e-5 apart for every node
+            K = torch.nn.functional.normalize(torch.randn(N, D, generator=gen(bank_seed)), p=2, dim=-1)
+            if min_topk_gap(hn @ K.t(), C + 1) > 1e-5:
+                break
+        else:
+            raise AssertionError("no tie-free bank seed found")
+        V = torch.randn(N, D, generator=gen(14))
+        L = torch.nn.functional.one_hot(torch.randint(0, C, (N,), generator=gen(15)), C).float()
+        tgb: ToyGraphBase = model.toy_graph_base
+        tgb.resource_keys, tgb.resource_values, tgb.resource_labels = K, V, L
+        k = tgb.retrieve_num  # num_class + 1 (ToyGraphBase.py:22)
+        with torch.no_grad():
+            S = torch.nn.functional.normalize(h, dim=-1) @ torch.nn.functional.normalize(K, dim=-1).t()
+            assert min_topk_gap(S, k) > 1e-5
+            rag_e, rag_l = tgb.retrieve(h, adj, False)
+            logits = model(X, adj)
+            dec_in = torch.randn(50, D, generator=gen(16))
+            dec_out = model.decoder(dec_in)
+        save("g6_node_forward", X=X, adj=adj, W=gcn.fc.weight, bias=gcn.bias, alpha=gcn.act.weight, keys=K, values=V,
+             labels=L, k=np.int64(k), topk_idx=torch.topk(S, k).indices, rag_embeddings=rag_e, rag_labels=rag_l,
+             fc1_w=model.decoder.fc1.weight, fc1_b=model.decoder.fc1.bias, fc2_w=model.decoder.fc2.weight,
+             fc2_b=model.decoder.fc2.bias, dec_in=dec_in, dec_out=dec_out, retrieve_weight=np.float32(model.retrieve_weight),
+             label_weight=np.float32(model.label_weight), hops=np.int64(model.query_graph_hop), logits=logits)
+
+        # G3: bank with exact duplicate keys (ToyGraphBase.py:98 samples with replacement): torch.topk's tie order is
+        # unspecified, so only what RAGraph.forward consumes is recorded: sum_k V[idx], mean_k L[idx] (RAGraph.py:48-49).
+        # Duplicates carry identical values and labels (same node sampled twice), as in a real toy bank.
+        base_n = 400
+        sel = torch.randint(0, base_n, (1200,), generator=gen(17))
+        Kd, Vd, Ld = K[:base_n][sel], V[:base_n][sel], L[:base_n][sel]
+        tgb.resource_keys, tgb.resource_values, tgb.resource_labels = Kd, Vd, Ld
+        with torch.no_grad():
+            rag_e, rag_l = tgb.retrieve(h, adj, False)
+        save("g3_duplicate_keys", Q=h, keys=Kd, values=Vd, labels=Ld, k=np.int64(k), sum_values=rag_e.sum(1),
+             mean_labels=rag_l.mean(1))
+
+
+def g2_g7_graph():
+    """Graph flavour: 1-D query retrieve (unsqueeze semantics) and the full RAGraph_graph.forward."""
+    with ref_project("RAGraph_graph"):
+        from preprompt import PrePrompt
+        from RAGraph import RAGraph
+        from ragraph_utils import TaskDecoder, ToyGraphBase
+
+        F_in, C, D, n = 1, 2, 256, 39
+        torch.manual_seed(3)
+        pre = PrePrompt(F_in, D, "prelu", 1, 0.3)
+        pre.eval()
+        with torch.no_grad():
+            pre.gcn.convs[0].bias.copy_(0.05 * torch.randn(D, generator=gen(31)))
+        # RAGraph.__init__ needs data/fewshot_* blobs that are not in the repository (FewShotBase.py:9-12) and never
+        # uses them in forward: assemble the object field by field instead of calling __init__.
+        model = RAGraph.__new__(RAGraph)
+        nn.Module.__init__(model)
+        model.emb_size, model.num_class, model.pretrain_model = D, C, pre
+        model.retrieve_weight, model.label_weight = 0.3, 0.3  # RAGraph_graph/RAGraph.py:25-26
+        model.finetune, model.noise_finetune, model.query_graph_hop = True, False, 1
+        model.toy_graph_base = ToyGraphBase(pre, C, D, model.query_graph_hop)
+        model.decoder = TaskDecoder(D, D, C)
+        model.eval()
+        N = 1500
+        K = unit_bank(N, D, 32)
+        V = torch.randn(N, D, generator=gen(33))
+        L = torch.nn.functional.one_hot(torch.randint(0, C, (N,), generator=gen(34)), C).float()
+        tgb = model.toy_graph_base
+        tgb.resource_keys, tgb.resource_values, tgb.resource_labels = K, V, L
+        adj = random_graph_adj(n, 3.7, seed=9)
+        X = torch.rand(n, F_in, generator=gen(35))
+        gcn = pre.gcn.convs[0]
+        with torch.no_grad():
+            h = pre.inference(X, adj)
+            g = h.mean(dim=0)
+            S = torch.nn.functional.normalize(g, dim=-1) @ K.t()
+            k = tgb.retrieve_num
+            assert min_topk_gap(S.unsqueeze(0), k) > 1e-5
+            rag_e, rag_l = tgb.retrieve(g, adj, False)
+            logits = model(X, adj)
+        save("g7_graph_forward", X=X, adj=adj, W=gcn.fc.weight, bias=gcn.bias, alpha=gcn.act.weight, H=h, keys=K,
+             values=V, labels=L, k=np.int64(k), topk_idx=torch.topk(S, k).indices, rag_embeddings=rag_e,
+             rag_labels=rag_l, fc1_w=model.decoder.fc1.weight, fc1_b=model.decoder.fc1.bias,
+             fc2_w=model.decoder.fc2.weight, fc2_b=model.decoder.fc2.bias,
+             retrieve_weight=np.float32(model.retrieve_weight), label_weight=np.float32(model.label_weight),
+             logits=logits)
+
+
+def g10_downprompt():
+    """GraphPrompt downstream readout (RAGraph_graph/downprompt.py): w*h, per-graph sum, cosine to class means."""
+    with ref_project("RAGraph_graph"):
+        import downprompt as dp
+
+        D = 256
+        torch.manual_seed(5)
+        ds = dp.downstreamprompt(D)
+        h = torch.randn(300, D, generator=gen(51))
+        graph_len = torch.tensor([10, 1, 80, 39, 170])
+        with torch.no_grad():
+            wh = ds(h)
+            emb = dp.split_and_batchify_graph_feats(wh, graph_len)
+            out = {"h": h, "w": ds.weight, "graph_len": graph_len, "graph_emb": emb}
+            for C in (2, 6):
+                ave = torch.randn(C, D, generator=gen(52 + C))
+                out[f"proto_c{C}"] = ave
+                out[f"logp_c{C}"] = dp.predict(emb.shape[0], C, emb, ave)
+        save("g10_downprompt", **out)
+
+
+def g9_edge():
+    """RAGraph_edge finetune-phase generate(): time softmax, 3 x _agg, slab-wise retrieval, fusion."""
+    argv = ["x", "--device", "cpu", "--data_path", "dataset/amazon", "--log", "0", "--emb_dropout", "0"]
+    with ref_project("RAGraph_edge", argv=argv):
+        from modules.RAGraph import RAGraph
+
+        U, I, E, D = 300, 200, 2000, 64
+        # Nodes with identical neighbour sets get identical keys after aggregation (exact score ties, whose order
+        # torch.topk leaves open and whose VALUES differ), so the fixture graph gives every node >= 3 random partners.
+        rng = np.random.default_rng(10)
+        u = np.concatenate([rng.integers(0, U, E), np.repeat(np.arange(U), 3)])
+        i = np.concatenate([rng.integers(0, I, E), rng.integers(0, I, 3 * U)])
+        u = np.concatenate([u, rng.integers(0, U, 3 * I)])
+        i = np.concatenate([i, np.repeat(np.arange(I), 3)])
+        pairs = np.unique(np.stack([u, i], 1), axis=0)
+        u, i = pairs[:, 0], pairs[:, 1]
+        t = rng.integers(0, 720, len(u))
+        graph = sp.coo_matrix((np.ones(len(u)), (u, i)), shape=(U, I))
+        etd = {}
+        for a, b, tt in zip(u, i, t):  # edge_time_dict[src][dst] for both directions (utils/dataloader.py)
+            etd.setdefault(int(a), {})[int(b) + U] = int(tt)
+            etd.setdefault(int(b) + U, {})[int(a)] = int(tt)
+
+        class DS:
+            num_users, num_items = U, I
+            edge_time_dict = etd
+
+        DS.graph = graph
+        ue = 0.1 * torch.randn(U, D, generator=gen(61))
+        ie = 0.1 * torch.randn(I, D, generator=gen(62))
+
+        class Pre:
+            def generate(self):
+                return ue.clone(), ie.clone()
+
+        torch.manual_seed(6)
+        model = RAGraph(DS, Pre(), phase="finetune", use_RAG=True, use_noise=False, use_LoRA=False)
+        model.eval()
+        model.batch_size = 128  # several slabs (modules/RAGraph.py:298)
+        model.retrieve_num = 10
+        with torch.no_grad():
+            time_norm = model._relative_edge_time_encoding(model.edges, model.edge_times)
+            norm = model.edge_norm * 1 / 2 + time_norm * 1 / 2
+            all_emb = model.emb_gate(torch.cat([model.user_embedding, model.item_embedding], 0))
+            agg1 = model._agg(all_emb, model.edges, norm)
+            S = torch.nn.functional.normalize(all_emb, dim=-1) @ torch.nn.functional.normalize(model.resource_keys, dim=-1).t()
+            top = torch.topk(S.double(), 11, dim=-1).values
+            row_gap = (top[:, :-1] - top[:, 1:]).min(dim=1).values  # per query: min adjacent gap in its top-11
+            gap = float(row_gap.min())
+            user_out, item_out = model.generate()
+        # Smoothed embeddings are highly similar, so a few of the 500 queries have near-ties; the fixture records the
+        # per-row gap and the parity test checks indices / outputs on the rows whose gap exceeds 1e-5.
+        frac = float((row_gap > 1e-5).double().mean())
+        print(f"  edge fixture: min top-11 gap {gap:.2e}; rows with gap > 1e-5: {100 * frac:.1f} %")
+        assert frac > 0.9
+        save("g9_edge_generate", edges=model.edges, edge_norm=model.edge_norm, edge_times=model.edge_times,
+             num_users=np.int64(U), num_items=np.int64(I), user_embedding=model.user_embedding,
+             item_embedding=model.item_embedding, gating_weight=model.gating_weight, gating_bias=model.gating_bias,
+             resource_keys=model.resource_keys, resource_values=model.resource_values, time_norm=time_norm,
+             gated_emb=all_emb, agg1=agg1, topk_idx=torch.topk(S, 10).indices, row_gap=row_gap,
+             retrieve_weight=np.float32(model.retrieve_weight), num_layers=np.int64(3), user_out=user_out,
+             item_out=item_out)
+
+
+def main():
+    assert os.path.isdir(REF), "the reference is only mounted in the build container"
+    _install_shims()
+    torch.set_num_threads(4)
+    print("generating golden vectors from", REF)
+    g1_cosine_topk()
+    g3_to_g6_node()
+    g2_g7_graph()
+    g10_downprompt()
+    g9_edge()
+
+
+if __name__ == "__main__":
+    main()
