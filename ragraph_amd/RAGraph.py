@@ -1,0 +1,90 @@
+"""Mirror of RAGraph_node/RAGraph.py and RAGraph_graph/RAGraph.py: encode -> retrieve -> propagate -> fuse -> decode.
+
+Same constructor and forward signatures as the reference (including its `feture_size` spelling); hyper-parameters are
+the reference's hard-coded constants exposed as attributes.
+"""
+import torch
+import torch.nn as nn
+
+from . import autograd as A
+from . import kernels as K
+from .graph import as_csr
+from .ragraph_utils import Propagation, TaskDecoder, ToyGraphBase
+
+
+class RAGraph(nn.Module):
+    """Node classification flavour -- RAGraph_node/RAGraph.py:10-63."""
+
+    flavour = "node"
+
+    def __init__(self, pretrain_model, resource_dataset, feture_size, num_class, emb_size, finetune=True,
+                 noise_finetune=False, device="cuda") -> None:
+        super().__init__()
+        self.emb_size = emb_size
+        self.num_class = num_class
+        self.pretrain_model = pretrain_model
+        self.retrieve_weight, self.label_weight, self.query_graph_hop = self._hyper()
+        self.finetune = finetune
+        self.noise_finetune = noise_finetune
+        if self.noise_finetune:
+            assert self.finetune
+        self.toy_graph_base = ToyGraphBase(pretrain_model, num_class, emb_size, self.query_graph_hop, device=device,
+                                           flavour=self.flavour)
+        if resource_dataset is not None:
+            self.toy_graph_base.build_toy_graph(resource_dataset)
+        if self.finetune:
+            self.decoder = TaskDecoder(emb_size, emb_size, num_class)
+            self.reset_parameters()
+        self.to(device)
+
+    def _hyper(self):
+        return 0.5, 0.5, 3  # RAGraph_node/RAGraph.py:18-19,26
+
+    def reset_parameters(self):
+        self.decoder.reset_parameters()
+
+    def _queries(self, emb, g):
+        return emb
+
+    def _pool(self, x, g):
+        return x
+
+    def forward(self, features, adj):
+        g = as_csr(adj)
+        pretrain_embedddings = self.pretrain_model.inference(features, g)                      # RAGraph.py:40
+        add_noise = self.training and self.noise_finetune
+        tgb = self.toy_graph_base
+        queries = self._queries(pretrain_embedddings, g)
+        if add_noise:
+            rag_embeddings, rag_labels = tgb.retrieve(queries, g, True)                        # :43 (noise branch)
+            rag_label = rag_labels.mean(dim=1)
+            rag_embedding = rag_embeddings.sum(dim=1)
+        else:
+            rag_embedding, rag_label, _ = tgb.retrieve_reduced(queries)                        # :43,48-49 fused
+        if not self.finetune:
+            return rag_label                                                                   # :60-63
+        query_embeddings = self._pool(
+            Propagation.aggregate_k_hop_features(g, pretrain_embedddings, self.query_graph_hop), g)  # :51
+        hidden = A.axpby(query_embeddings, 1 - self.retrieve_weight, rag_embedding, self.retrieve_weight)  # :53
+        decode_label = self.decoder(hidden)                                                    # :54
+        return A.softmax_mix(decode_label, rag_label, self.label_weight)                       # :55-57
+
+
+class RAGraphGraph(RAGraph):
+    """Graph classification flavour -- RAGraph_graph/RAGraph.py:7-75: one mean-pooled query per graph."""
+
+    flavour = "graph"
+
+    def _hyper(self):
+        return 0.3, 0.3, 1  # RAGraph_graph/RAGraph.py:25-26,33
+
+    @staticmethod
+    def _mean_rows(x):
+        seg = torch.tensor([0, x.shape[0]], dtype=torch.int64, device=x.device)
+        return K.segment_reduce(x, seg, mean_mode=True)  # [1,D]
+
+    def _queries(self, emb, g):
+        return self._mean_rows(emb)        # RAGraph_graph/RAGraph.py:50 (1-D query -> one row)
+
+    def _pool(self, x, g):
+        return self._mean_rows(x)          # :63

@@ -1,0 +1,139 @@
+"""Mirror of RAGraph_edge/modules/RAGraph.py (inference side): LightGCN-style propagation with time-softmax edge
+weights, retrieval over all users+items, fusion.  Training-side pieces (LoRA, BPR loss, edge dropout) are out of scope
+(SURVEY.md section 2 row 9); the gating layer is kept because generate() applies it.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from .graph import CSRGraph
+
+
+class RAGraph(nn.Module):
+    def __init__(self, dataset, pretrained_model=None, phase="finetune", use_RAG=True, use_noise=False,
+                 use_LoRA=False, LoRA_rank=16, emb_size=64, num_layers=3, retrieve_num=10, retrieve_weight=0.3,
+                 batch_size=4096, device="cuda"):
+        """dataset: .num_users, .num_items, .edges [2E,2] int64 (src,dst, both directions), .edge_norm [2E] fp32,
+        .edge_times [2E] int64 (the tensors modules/RAGraph.py:22-27 derives from the scipy graph).
+        pretrained_model: .generate() -> (user_emb, item_emb)."""
+        super().__init__()
+        if use_LoRA:
+            raise NotImplementedError("LoRA fine-tuning (modules/RAGraph.py:121-160) is training-side; out of scope")
+        self.num_users, self.num_items = dataset.num_users, dataset.num_items
+        self.emb_size, self.num_layers = emb_size, num_layers
+        self.edges = dataset.edges.to(device)
+        self.edge_norm = dataset.edge_norm.to(device).float()
+        self.edge_times = dataset.edge_times.to(device)
+        self.phase, self.use_RAG = phase, use_RAG
+        self.use_noise = use_noise and phase == "finetune"
+        self.retrieve_weight, self.retrieve_num, self.batch_size = retrieve_weight, retrieve_num, batch_size  # :33-85
+        self.noise_retrieve_num = 1
+        self.resource_keys = self.resource_values = None
+        self._keys_normalized = None
+        self._csr_cache = None
+        ue, ie = pretrained_model.generate()
+        self.user_embedding = nn.Parameter(ue.detach().clone().to(device))
+        self.item_embedding = nn.Parameter(ie.detach().clone().to(device))
+        if phase == "finetune":   # :163-168
+            self.gating_weight = nn.Parameter(nn.init.xavier_uniform_(torch.empty(emb_size, emb_size, device=device)))
+            self.gating_bias = nn.Parameter(nn.init.xavier_uniform_(torch.empty(1, emb_size, device=device)))
+        else:
+            self.gating_weight = self.gating_bias = None
+        if use_RAG:
+            self._make_resource_graph(pretrained_model)
+
+    # ---- helpers ---------------------------------------------------------------------------------------------------
+    def _csr(self, edges):
+        """Destination-sorted CSR of an edge list (stable: keeps scatter_add_'s accumulation order), cached per list."""
+        key = (edges.data_ptr(), edges.shape[0])
+        if self._csr_cache is None or self._csr_cache[0] != key:
+            n = self.num_users + self.num_items
+            g, perm = CSRGraph.from_coo(edges[:, 1], edges[:, 0], torch.ones(edges.shape[0], device=edges.device), n)
+            self._csr_cache = (key, g, perm)
+        return self._csr_cache[1], self._csr_cache[2]
+
+    def emb_gate(self, x):
+        """modules/RAGraph.py:168: x * sigmoid(x @ W + b) (dropout p = 0 at inference)."""
+        if self.gating_weight is None:
+            return x
+        z = K.linear(x, self.gating_weight.t().contiguous(), self.gating_bias.reshape(-1))
+        return x * torch.sigmoid(z)
+
+    def _agg(self, all_emb, edges, edge_norm):
+        """modules/RAGraph.py:232-240: out[dst] += emb[src] * norm, as one CSR SpMM (no atomics)."""
+        g, perm = self._csr(edges)
+        return K.spmm_csr(g.rowptr, g.col, edge_norm[perm].contiguous(), all_emb)
+
+    def _relative_edge_time_encoding(self, edges, edge_times, max_step=None):
+        """modules/RAGraph.py:250-263.  Returns the softmax in ORIGINAL edge order."""
+        g, perm = self._csr(edges)
+        t = edge_times.float()
+        if max_step is None:
+            max_step = t.max()
+        tmin = t.min()
+        t = (t - tmin) / (max_step - tmin)
+        sm = K.segment_softmax(g.rowptr, t[perm].contiguous())
+        out = torch.empty_like(sm)
+        out[perm] = sm
+        return out
+
+    def _make_resource_graph(self, pretrained_model):
+        """modules/RAGraph.py:185-226 with num_augment_scale = num_inverse_sample = 0 (the finetune-phase settings,
+        :45-50): keys = embeddings after num_layers aggregations, values = sum of the even layers."""
+        ue, ie = pretrained_model.generate()
+        all_emb = torch.cat([ue, ie], dim=0).to(self.edges.device).float()
+        res = [all_emb]
+        for _ in range(self.num_layers):
+            res.append(self._agg(res[-1], self.edges, self.edge_norm))
+        vals = res[0]
+        for r in res[2::2]:
+            vals = K.axpby(vals, 1.0, r, 1.0)
+        self.resource_keys, self.resource_values = res[-1], vals
+        self._keys_normalized = None
+
+    @property
+    def keys_normalized(self):
+        if self._keys_normalized is None:
+            self._keys_normalized = K.normalize_rows(self.resource_keys)
+        return self._keys_normalized
+
+    # ---- forward ---------------------------------------------------------------------------------------------------
+    def forward(self, edges, edge_norm, edge_times, max_time_step=None):
+        """modules/RAGraph.py:265-333."""
+        g, perm = self._csr(edges)
+        t = edge_times.float()
+        tmax = t.max() if max_time_step is None else max_time_step
+        tmin = t.min()
+        t = ((t - tmin) / (tmax - tmin))[perm].contiguous()
+        time_norm = K.segment_softmax(g.rowptr, t)                                             # :266
+        norm = K.axpby(edge_norm[perm].contiguous(), 0.5, time_norm, 0.5)                      # :267
+        all_emb = self.emb_gate(torch.cat([self.user_embedding, self.item_embedding], dim=0)).detach()  # :276-277
+        res = [all_emb]
+        for _ in range(self.num_layers):                                                       # :280-283
+            res.append(K.spmm_csr(g.rowptr, g.col, norm, res[-1]))
+        total = res[0]
+        for r in res[1:]:                                                                      # :327 sum(res_emb)
+            total = K.axpby(total, 1.0, r, 1.0)
+        if self.use_RAG and self.phase in ("vanilla", "finetune"):
+            add_noise = self.use_noise and self.training
+            k = self.retrieve_num + (self.noise_retrieve_num if add_noise else 0)             # :308
+            # :298-324: the reference walks the queries in slabs of batch_size only to bound its B x N score matrix;
+            # the fused kernel never builds that matrix, so all queries go in one launch.
+            _, idx = K.topk_cosine(res[0], self.keys_normalized, k)
+            if add_noise:
+                noise = torch.randint(0, self.resource_values.shape[0], (idx.shape[0], self.noise_retrieve_num),
+                                      device=idx.device)
+                idx = torch.cat([idx, noise], dim=1)
+            rag, _ = K.gather_reduce(self.resource_values, None, idx, v_scale=1.0 / idx.shape[1])  # :314,321 mean
+            total = K.axpby(total, 1 - self.retrieve_weight, rag, self.retrieve_weight)        # :328
+        return total.split([self.num_users, self.num_items], dim=0)
+
+    @torch.no_grad()
+    def generate(self, max_time_step=None):
+        return self.forward(self.edges, self.edge_norm, self.edge_times, max_time_step=max_time_step)
+
+    @torch.no_grad()
+    def rating(self, user_emb, item_emb):
+        return K.linear(user_emb, item_emb)   # modules/RAGraph.py:362-364: user_emb @ item_emb.T

@@ -1,0 +1,109 @@
+"""CSR adjacency on the device: the hot path's input format.
+
+The reference hands a DENSE n x n normalised adjacency to every layer (ragraph_utils/utility.py:45-69,
+layers/gcn.py:36, Propagation.py:15-22): 40 GB per copy at n = 1e5.  The kernels take CSR (int64 rowptr, int32 col,
+fp32 val); `as_csr` accepts what reference callers pass (a dense tensor) or a CSRGraph, and converts once.
+
+Structure conversion (nonzero / stable sort / cumsum) uses torch ops as plumbing: it is integer bookkeeping done once
+per graph, outside the per-forward path; every floating-point result comes from libragraph_hip.so.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import torch
+
+from . import kernels as K
+
+
+@dataclass
+class CSRGraph:
+    rowptr: torch.Tensor  # [n+1] int64
+    col: torch.Tensor     # [nnz] int32
+    val: torch.Tensor     # [nnz] fp32
+    n: int
+    _row_normalized: torch.Tensor | None = field(default=None, repr=False)
+
+    @property
+    def shape(self):
+        return (self.n, self.n)
+
+    @property
+    def nnz(self) -> int:
+        return int(self.col.numel())
+
+    @property
+    def device(self):
+        return self.val.device
+
+    def squeeze(self, dim=0):  # reference code calls adj.squeeze(dim=0) on the dense tensor (layers/gcn.py:36)
+        return self
+
+    def cuda(self):  # reference code calls .cuda() on its inputs (layers/gcn.py:28-29)
+        return self
+
+    def row_normalized_values(self) -> torch.Tensor:
+        """adj / adj.sum(1) on the non-zeros (Propagation.py:15-16), cached per graph."""
+        if self._row_normalized is None:
+            self._row_normalized = K.csr_row_normalize(self.rowptr, self.val)
+        return self._row_normalized
+
+    # ---- constructors ------------------------------------------------------------------------------------------
+    @staticmethod
+    def from_dense(adj: torch.Tensor) -> "CSRGraph":
+        """Non-zeros of a dense [n,n] (or [1,n,n]) adjacency, rows ascending, columns ascending within a row."""
+        a = adj.squeeze(0) if adj.dim() == 3 else adj
+        n = a.shape[0]
+        nz = torch.nonzero(a, as_tuple=False)  # row-major order
+        rows, cols = nz[:, 0], nz[:, 1]
+        rowptr = torch.zeros(n + 1, dtype=torch.int64, device=a.device)
+        rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n), 0)
+        return CSRGraph(rowptr, cols.to(torch.int32), a[rows, cols].float().contiguous(), n)
+
+    @staticmethod
+    def from_coo(rows: torch.Tensor, cols: torch.Tensor, vals: torch.Tensor, n: int, sort_cols: bool = False):
+        """COO -> CSR over `rows`, STABLE in the given edge order (the order scatter_add_ accumulates in,
+        RAGraph_edge/modules/utils.py:17-32).  Returns (graph, perm): perm[e'] = original edge id of CSR slot e'."""
+        rows = rows.to(torch.int64)
+        key = rows * n + cols.to(torch.int64) if sort_cols else rows
+        perm = torch.sort(key, stable=True).indices
+        rowptr = torch.zeros(n + 1, dtype=torch.int64, device=rows.device)
+        rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n), 0)
+        g = CSRGraph(rowptr, cols[perm].to(torch.int32).contiguous(), vals[perm].float().contiguous(), n)
+        return g, perm
+
+    @staticmethod
+    def from_edge_index_sym_normalized(edge_index: torch.Tensor, n: int) -> "CSRGraph":
+        """D^-1/2 (A + I) D^-1/2 directly in CSR -- what ragraph_utils/utility.py:19-26,45-66 builds densely through
+        scipy (coo_matrix of ones -> todense sums duplicate edges; + eye; normalize_adj).  The normalisation is done
+        in float64 and cast to fp32 last, as scipy + torch.FloatTensor do."""
+        dev = edge_index.device
+        loops = torch.arange(n, device=dev, dtype=torch.int64)
+        r = torch.cat([edge_index[0].to(torch.int64), loops])
+        c = torch.cat([edge_index[1].to(torch.int64), loops])
+        key, counts = torch.unique(r * n + c, return_counts=True)  # sorted: row-major, ascending columns
+        r, c = key // n, key % n
+        vals = counts.double()
+        deg = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, r, vals)
+        dinv = deg.pow(-0.5)
+        dinv[torch.isinf(dinv)] = 0.0
+        # normalize_adj (utility.py:19-26) returns (A D)^T D = D A^T D: entry (i,j) = d_i * A[j,i] * d_j, with d from A's
+        # ROW sums.  Emit the transposed pattern so a directed edge list gives the reference's matrix too.
+        v = (vals * dinv[r]) * dinv[c]
+        order = torch.sort(c * n + r).indices
+        out_r, out_c, v = c[order], r[order], v[order]
+        rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        rowptr[1:] = torch.cumsum(torch.bincount(out_r, minlength=n), 0)
+        return CSRGraph(rowptr, out_c.to(torch.int32), v.float().contiguous(), n)
+
+
+def as_csr(adj) -> CSRGraph:
+    """Accept what the reference call surface passes (dense [n,n] / [1,n,n] tensor) or a CSRGraph."""
+    if isinstance(adj, CSRGraph):
+        return adj
+    if isinstance(adj, torch.Tensor):
+        if adj.layout == torch.sparse_csr:
+            return CSRGraph(adj.crow_indices().to(torch.int64), adj.col_indices().to(torch.int32),
+                            adj.values().float().contiguous(), adj.shape[-1])
+        return CSRGraph.from_dense(adj)
+    raise TypeError(f"adjacency must be a dense tensor, a sparse CSR tensor or a CSRGraph, not {type(adj)}")

@@ -1,0 +1,39 @@
+"""Mirror of RAGraph_*/preprompt.py :: PrePrompt -- the inference side (encoder stack); pre-training losses are out
+of scope."""
+import torch
+import torch.nn as nn
+
+from .gcnlayers import GcnLayers
+
+
+class PrePrompt(nn.Module):
+    def __init__(self, n_in, n_h, activation, num_layers_num, p):
+        super().__init__()
+        self.gcn = GcnLayers(n_in, n_h, num_layers_num, p)
+
+    def embed(self, seq, adj, sparse, msk, LP):
+        """preprompt.py:57-62.  Returns (h, c).  The node flavour's c is the 3-hop subgraph readout that a Python loop
+        over nnz(A^3) computes (preprompt.py:8-27) and inference() throws away; here c is the plain mean readout of h
+        (the graph flavour's AvgReadout, RAGraph_graph/preprompt.py:48-54)."""
+        h = self.gcn(seq, adj, sparse, LP).squeeze(0)
+        return h.detach(), h.mean(dim=0, keepdim=True).detach()
+
+    def inference(self, features, adj):
+        """preprompt.py:64-66: L GCN layers, detached."""
+        return self.gcn(features, adj, False, False).squeeze(0).detach()
+
+    def encode(self, features, adj):  # RAGraph_node_fewshot/preprompt.py:74-75
+        return self.gcn.encode(features, adj)
+
+    def decode(self, features, adj):  # RAGraph_node_fewshot/preprompt.py:77-78
+        return self.gcn.decode(features, adj)
+
+    def load_reference_state_dict(self, state_dict):
+        """Load a reference checkpoint (modelset/model_*.pkl): keeps gcn.convs.* / gcn.bns.*, ignores the duplicated
+        gcn.g_net.* aliases and the pre-training heads (dgi, graphcledge, graphclmask, lp)."""
+        own = self.state_dict()
+        picked = {k: v for k, v in state_dict.items() if k in own}
+        missing = [k for k in own if k not in picked and not k.startswith("gcn.g_net.") and "bns" not in k]
+        if missing:
+            raise KeyError(f"reference checkpoint lacks {missing}")
+        return self.load_state_dict(picked, strict=False)

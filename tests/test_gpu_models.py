@@ -1,0 +1,265 @@
+"""The host-side mirror of the reference's call surface (ragraph_amd.*), driven on the GPU, against
+  (a) the golden vectors the reference itself produced (tests/golden, made by oracle/make_golden.py), and
+  (b) the CPU oracle's whole-forward restatements (oracle/pipeline.py) -- bit-exact where no expf is involved.
+These tests read like the reference's own usage: build PrePrompt / RAGraph, call model(features, adj).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref, pipeline
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return dict(np.load(os.path.join(GOLD, name + ".npz")))
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _load_encoder(pre, g, dev):
+    conv = pre.gcn.convs[0]
+    with torch.no_grad():
+        conv.fc.weight.copy_(T(g["W"], dev))
+        conv.bias.copy_(T(g["bias"], dev))
+        conv.act.weight.copy_(T(g["alpha"], dev))
+
+
+def _load_decoder(dec, g, dev):
+    with torch.no_grad():
+        dec.fc1.weight.copy_(T(g["fc1_w"], dev)); dec.fc1.bias.copy_(T(g["fc1_b"], dev))
+        dec.fc2.weight.copy_(T(g["fc2_w"], dev)); dec.fc2.bias.copy_(T(g["fc2_b"], dev))
+
+
+def test_similarity_functions_g1(dev):
+    from ragraph_amd.ragraph_utils import SimilarityFunctions
+
+    g = gold("g1a_cosine_topk")
+    S = SimilarityFunctions.calculate_cosine_similarity(T(g["Q"][:8], dev), T(g["K"], dev))
+    assert np.allclose(S.cpu().numpy(), g["scores_full_first8"], atol=2e-6)
+    s1 = SimilarityFunctions.calculate_cosine_similarity(T(g["Q"][0], dev), T(g["K"], dev))  # 1-D query (graph flavour)
+    assert s1.shape == (g["K"].shape[0],) and torch.equal(s1, S[0])
+    ts, ti = torch.topk(S, 10)
+    assert np.array_equal(ti.cpu().numpy(), g["topk_idx_k10"][:8])
+
+
+def test_gcn_layer_g4_and_propagation_g5(dev):
+    from ragraph_amd.graph import CSRGraph
+    from ragraph_amd.preprompt import PrePrompt
+    from ragraph_amd.ragraph_utils import Propagation
+
+    g = gold("g4_gcn_layer")
+    pre = PrePrompt(g["X"].shape[1], 256, "prelu", 1, 0.3).to(dev)
+    _load_encoder(pre, g, dev)
+    adj = T(g["adj"], dev)
+    H = pre.inference(T(g["X"], dev), adj)                       # dense adjacency, exactly the reference's call
+    assert np.allclose(H.cpu().numpy(), g["H"], atol=1e-5)
+    H2 = pre.inference(T(g["X"], dev), CSRGraph.from_dense(adj))  # CSR input: same numbers
+    assert torch.equal(H, H2)
+    ref = pipeline.gcn_layer(g["X"], cref.dense_to_csr(g["adj"]), g["W"], g["bias"], g["alpha"][0])
+    assert np.array_equal(H.cpu().numpy(), ref)                  # bit-exact vs the oracle
+    h, c = pre.embed(T(g["X"], dev), adj, False, None, False)
+    assert torch.equal(h, H) and c.shape == (1, 256)
+
+    g5 = gold("g5_propagation")
+    for k in (0, 1, 2, 3):
+        y = Propagation.aggregate_k_hop_features(T(g5["adj"], dev), T(g5["x"], dev), k)
+        assert np.allclose(y.cpu().numpy(), g5[f"y_k{k}"], atol=1e-5)
+        assert np.array_equal(y.cpu().numpy(), pipeline.propagate(cref.dense_to_csr(g5["adj"]), g5["x"], k))
+
+
+def test_node_forward_g6(dev):
+    from ragraph_amd.preprompt import PrePrompt
+    from ragraph_amd.RAGraph import RAGraph
+
+    g = gold("g6_node_forward")
+    F_in, C = g["X"].shape[1], g["labels"].shape[1]
+    pre = PrePrompt(F_in, 256, "prelu", 1, 0.3).to(dev)
+    _load_encoder(pre, g, dev)
+    model = RAGraph(pre, None, F_in, C, 256, finetune=True, noise_finetune=False, device=dev)
+    _load_decoder(model.decoder, g, dev)
+    model.toy_graph_base.add_resources(T(g["keys"], dev), T(g["values"], dev), T(g["labels"], dev))
+    model.eval()
+    assert model.toy_graph_base.retrieve_num == int(g["k"])
+    X, adj = T(g["X"], dev), T(g["adj"], dev)
+    with torch.no_grad():
+        logits = model(X, adj)
+        h = pre.inference(X, adj)
+        e, l = model.toy_graph_base.retrieve(h, adj, False)
+        dec = model.decoder(T(g["dec_in"], dev))
+    assert np.allclose(logits.cpu().numpy(), g["logits"], atol=1e-5)
+    assert np.array_equal(e.cpu().numpy(), g["rag_embeddings"]) and np.array_equal(l.cpu().numpy(), g["rag_labels"])
+    assert np.allclose(dec.cpu().numpy(), g["dec_out"], atol=1e-5)
+    _, idx = model.toy_graph_base.topk(h, int(g["k"]))
+    assert np.array_equal(idx.cpu().numpy(), g["topk_idx"])
+    # vs the oracle's restatement of RAGraph.forward: same indices, logits to expf rounding
+    p = {k: g[k] for k in ("W", "bias", "fc1_w", "fc1_b", "fc2_w", "fc2_b")}
+    p["alpha"] = g["alpha"][0]
+    ol, oi, oh = pipeline.node_forward(g["X"], cref.dense_to_csr(g["adj"]), p, g["keys"], g["values"], g["labels"],
+                                       int(g["k"]), int(g["hops"]), 0.5, 0.5)
+    assert np.array_equal(h.cpu().numpy(), oh) and np.array_equal(idx.cpu().numpy(), oi)
+    assert np.allclose(logits.cpu().numpy(), ol, atol=1e-6)
+    # finetune=False branch returns the mean retrieved label (RAGraph.py:60-63)
+    model.finetune = False
+    with torch.no_grad():
+        lab = model(X, adj)
+    assert np.allclose(lab.cpu().numpy(), g["rag_labels"].mean(1), atol=1e-6)
+
+
+def test_duplicate_keys_g3(dev):
+    from ragraph_amd.ragraph_utils import ToyGraphBase
+
+    g = gold("g3_duplicate_keys")
+    tgb = ToyGraphBase(None, g["labels"].shape[1], 256, 3, device=dev)
+    tgb.add_resources(T(g["keys"], dev), T(g["values"], dev), T(g["labels"], dev))
+    sv, ml, idx = tgb.retrieve_reduced(T(g["Q"], dev), int(g["k"]))
+    assert np.allclose(sv.cpu().numpy(), g["sum_values"], atol=1e-5)
+    assert np.allclose(ml.cpu().numpy(), g["mean_labels"], atol=1e-6)
+    _, oi = cref.topk_cosine(g["Q"], cref.normalize_rows(g["keys"]), int(g["k"]))
+    assert np.array_equal(idx.cpu().numpy(), oi)
+
+
+def test_graph_forward_g7(dev):
+    from ragraph_amd.preprompt import PrePrompt
+    from ragraph_amd.RAGraph import RAGraphGraph
+
+    g = gold("g7_graph_forward")
+    C = g["labels"].shape[1]
+    pre = PrePrompt(1, 256, "prelu", 1, 0.3).to(dev)
+    _load_encoder(pre, g, dev)
+    model = RAGraphGraph(pre, None, 1, C, 256, device=dev)
+    _load_decoder(model.decoder, g, dev)
+    model.toy_graph_base.add_resources(T(g["keys"], dev), T(g["values"], dev), T(g["labels"], dev))
+    model.eval()
+    assert model.toy_graph_base.retrieve_num == int(g["k"])
+    X, adj = T(g["X"], dev), T(g["adj"], dev)
+    with torch.no_grad():
+        logits = model(X, adj)
+        h = pre.inference(X, adj)
+        e, l = model.toy_graph_base.retrieve(h.mean(dim=0), adj, False)   # 1-D query as the reference passes it
+    assert np.allclose(logits.cpu().numpy(), g["logits"], atol=1e-5)
+    assert e.shape == g["rag_embeddings"].shape
+    assert np.array_equal(l.cpu().numpy(), g["rag_labels"])
+    assert np.allclose(e.cpu().numpy(), g["rag_embeddings"], atol=0)
+
+
+def test_edge_generate_g9(dev):
+    from ragraph_amd.RAGraph_edge import RAGraph as RAGraphEdge
+
+    g = gold("g9_edge_generate")
+    U, I = int(g["num_users"]), int(g["num_items"])
+
+    class DS:
+        num_users, num_items = U, I
+        edges, edge_norm, edge_times = T(g["edges"], dev), T(g["edge_norm"], dev), T(g["edge_times"], dev)
+
+    class Pre:
+        def generate(self):
+            return T(g["user_embedding"], dev), T(g["item_embedding"], dev)
+
+    model = RAGraphEdge(DS, Pre(), phase="finetune", use_RAG=True, retrieve_num=10, device=dev)
+    with torch.no_grad():
+        model.gating_weight.copy_(T(g["gating_weight"], dev))
+        model.gating_bias.copy_(T(g["gating_bias"], dev))
+    model.eval()
+    # the bank the reference built from the same embeddings: keys = 3x aggregated, values = even layers
+    assert np.allclose(model.resource_keys.cpu().numpy(), g["resource_keys"], atol=1e-6)
+    assert np.allclose(model.resource_values.cpu().numpy(), g["resource_values"], atol=1e-6)
+    tn = model._relative_edge_time_encoding(model.edges, model.edge_times)
+    assert np.allclose(tn.cpu().numpy(), g["time_norm"], atol=1e-6)
+    gated = model.emb_gate(torch.cat([model.user_embedding, model.item_embedding]).detach())
+    assert np.allclose(gated.cpu().numpy(), g["gated_emb"], atol=1e-6)
+    uo, io = model.generate()
+    out = torch.cat([uo, io]).cpu().numpy()
+    ref = np.concatenate([g["user_out"], g["item_out"]])
+    ok = g["row_gap"] > 1e-5
+    assert np.allclose(out[ok], ref[ok], atol=1e-5)
+    assert np.allclose(out, ref, atol=5e-3)
+    # bit-exact against the oracle's restatement fed the same gated embeddings and bank
+    o_out, o_idx, *_ = pipeline.edge_forward(g["edges"], g["edge_norm"], g["edge_times"], gated.cpu().numpy(),
+                                             model.resource_keys.cpu().numpy(), model.resource_values.cpu().numpy(),
+                                             10, float(g["retrieve_weight"]), 3)
+    assert np.allclose(out, o_out, atol=1e-6)
+
+
+def test_downprompt_g10(dev):
+    from ragraph_amd import downprompt as dp
+
+    g = gold("g10_downprompt")
+    m = dp.downprompt(None, None, None, 256, 2).to(dev)
+    with torch.no_grad():
+        m.downprompt.weight.copy_(T(g["w"], dev))
+    emb = m(T(g["h"], dev), T(g["graph_len"], dev))
+    assert np.allclose(emb.cpu().numpy(), g["graph_emb"], atol=1e-4)
+    for C in (2, 6):
+        lp = dp.predict(emb.shape[0], C, emb, T(g[f"proto_c{C}"], dev))
+        assert np.allclose(lp.cpu().numpy(), g[f"logp_c{C}"], atol=1e-5)
+
+
+def test_bank_build_and_finetune_step(dev):
+    """The reference's driver loop in miniature (finetune-rag.py:57-84): build the bank from a resource dataset, one
+    Adam step on the decoder, loss decreases; retrieving a stored key returns that key first."""
+    from ragraph_amd.data import DataLoader, synthetic_tu_dataset
+    from ragraph_amd.preprompt import PrePrompt
+    from ragraph_amd.RAGraph import RAGraph
+    from ragraph_amd.ragraph_utils import process_tu_dataset, seed_everything
+
+    seed_everything(0)
+    ds = synthetic_tu_dataset(num_graphs=12, num_node_attributes=18, num_node_labels=3, seed=9)
+    pre = PrePrompt(18, 256, "prelu", 1, 0.3).to(dev)
+    model = RAGraph(pre, ds[:6], 18, 3, 256, finetune=True, device=dev)
+    tgb = model.toy_graph_base
+    assert tgb.resource_keys.shape == (6 * 4 * 10, 256)       # 6 graphs x (1 + 3 augmentations) x 10 samples
+    assert tgb.resource_labels.shape[1] == 3 and torch.isfinite(tgb.resource_values).all()
+    # rows 0..9 come from the un-augmented graph; the augmented copies multiply their features by a Bernoulli mask of
+    # probability sample_prob * 0.01 (Augmentation.py:17-18), i.e. almost surely zero -> zero keys, as in the reference
+    s, _ = tgb.topk(tgb.resource_keys[:10], 1)
+    assert torch.allclose(s, torch.ones_like(s), atol=1e-5)   # a stored key's best match has cosine 1
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    model.train()
+    losses = []
+    batch = next(iter(DataLoader(ds[6:], batch_size=6)))
+    feats, adj, labels = process_tu_dataset(batch, 18, device=dev)
+    for _ in range(5):
+        opt.zero_grad()
+        out = model(feats, adj)
+        loss = torch.nn.functional.cross_entropy(out, labels.argmax(1))
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(p.grad is not None for p in model.decoder.parameters())
+    assert losses[-1] < losses[0]
+
+
+def test_decoder_gradients_match_torch(dev):
+    from ragraph_amd import autograd as A
+    from ragraph_amd import kernels as K
+
+    torch.manual_seed(0)
+    x = torch.randn(37, 256, device=dev, requires_grad=True)
+    w1 = (torch.randn(256, 256, device=dev) / 16).requires_grad_()
+    b1 = torch.randn(256, device=dev, requires_grad=True)
+    w2 = (torch.randn(3, 256, device=dev) / 16).requires_grad_()
+    b2 = torch.randn(3, device=dev, requires_grad=True)
+    rl = torch.nn.functional.one_hot(torch.randint(0, 3, (37,), device=dev), 3).float()
+    tgt = torch.randint(0, 3, (37,), device=dev)
+
+    def run(lin, smx):
+        h = lin(x, w1, b1, True)
+        return torch.nn.functional.nll_loss(torch.log(smx(lin(h, w2, b2, False), rl)), tgt)
+
+    ours = run(lambda a, w, b, act: A.linear(a, w, b, act=K.ACT_LEAKY if act else K.ACT_NONE, alpha=0.01),
+               lambda lg, r: A.softmax_mix(lg, r, 0.5))
+    g_ours = torch.autograd.grad(ours, [x, w1, b1, w2, b2])
+    ref = run(lambda a, w, b, act: torch.nn.functional.leaky_relu(torch.nn.functional.linear(a, w, b), 0.01) if act
+              else torch.nn.functional.linear(a, w, b), lambda lg, r: torch.softmax(lg, 1) * 0.5 + r * 0.5)
+    g_ref = torch.autograd.grad(ref, [x, w1, b1, w2, b2])
+    assert torch.allclose(ours, ref, atol=1e-5)
+    for a, b in zip(g_ours, g_ref):
+        assert torch.allclose(a, b, atol=1e-5, rtol=1e-4)
