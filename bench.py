@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""bench.py -- RAGraph retrieve-and-propagate hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): RAGraph_node forward on a synthetic 100k-node graph (F=128, mean degree ~10)
+against a 1M-key x 256-d bank, k=10, C=3.  One step = one full forward: GCN encode -> fused cosine+top-k retrieval of
+every node against the bank -> winners' value-sum / label-mean -> 3-hop propagation -> fusion + decoder + softmax-mix.
+value = retrieved queries (= nodes) per second, whole job.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the 1M-key bank is row-sharded across the ranks (strong
+scaling on the metric's own bank); every rank scores all queries against its shard, one RCCL all_gather of the
+per-shard top-k + canonical merge, one all_reduce of the owned winners' sums (ragraph_amd/sharded.py).  The cheap GNN
+part is replicated.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel (the fused
+top-k: fp32-MFMA-bound at this batch size) and, at N = 1, `cpu_baseline` (the torch-CPU port of the reference's op
+chain, oracle/ref_torch.py, on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0          # spec; ~6300 achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nodes", type=int, default=100_000)
+    ap.add_argument("--feat", type=int, default=128)
+    ap.add_argument("--bank", type=int, default=1_000_000)
+    ap.add_argument("--dim", type=int, default=256)
+    ap.add_argument("--classes", type=int, default=3)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="queries timed on the CPU baseline")
+    ap.add_argument("--small-batch", action="store_true", help="also time the HBM-bound B<=16 retrieval regime")
+    return ap.parse_args()
+
+
+class EventTimer:
+    """Wraps a kernels.* entry so each call is bracketed by events on the stream it launches on (torch's current
+    stream -- the C ABI is handed exactly that stream)."""
+
+    def __init__(self, module, name):
+        self.module, self.name, self.orig = module, name, getattr(module, name)
+        self.events = []
+        self.enabled = False
+        setattr(module, name, self)
+
+    def __call__(self, *a, **kw):
+        if not self.enabled:
+            return self.orig(*a, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = self.orig(*a, **kw)
+        e1.record()
+        self.events.append((e0, e1))
+        return out
+
+    def mean_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.events) / max(len(self.events), 1)
+
+
+def build_workload(args, dev, rank, world):
+    from ragraph_amd import kernels as K
+    from ragraph_amd.data import synthetic_bank, synthetic_big_graph
+    from ragraph_amd.graph import CSRGraph
+    from ragraph_amd.preprompt import PrePrompt
+    from ragraph_amd.RAGraph import RAGraph
+    from ragraph_amd.sharded import ShardedToyGraphBase, shard_bounds
+
+    torch.manual_seed(0)
+    pre = PrePrompt(args.feat, args.dim, "prelu", 1, 0.3).to(dev)
+    model = RAGraph(pre, None, args.feat, args.classes, args.dim, finetune=True, device=dev)
+    model.toy_graph_base.retrieve_num = args.k
+    model.eval()
+    ei = synthetic_big_graph(args.nodes, 10, seed=8, device=dev)
+    adj = CSRGraph.from_edge_index_sym_normalized(ei, args.nodes)
+    feats = torch.randn(args.nodes, args.feat, device=dev, generator=torch.Generator(device=dev).manual_seed(4321))
+    Kb, Vb, Lb = synthetic_bank(args.bank, args.dim, args.classes, device=dev)
+    Kb = K.normalize_rows(Kb)  # stored unit-norm, as the reference stores keys (ToyGraphBase.py:109)
+    if world > 1:
+        lo, hi = shard_bounds(args.bank, world, rank)
+        model.toy_graph_base = ShardedToyGraphBase(Kb[lo:hi].contiguous(), Vb[lo:hi].contiguous(),
+                                                   Lb[lo:hi].contiguous(), lo, args.k)
+        del Kb, Vb, Lb
+        n_local = hi - lo
+    else:
+        model.toy_graph_base.set_resources(Kb, Vb, Lb)
+        _ = model.toy_graph_base.keys_normalized
+        n_local = args.bank
+    torch.cuda.synchronize()
+    return model, feats, adj, n_local
+
+
+def gnn_only_rate(model, feats, adj, steps):
+    from ragraph_amd.ragraph_utils import Propagation
+
+    def run():
+        h = model.pretrain_model.inference(feats, adj)
+        return Propagation.aggregate_k_hop_features(adj, h, model.query_graph_hop)
+
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    return feats.shape[0] * steps / (time.perf_counter() - t0)
+
+
+def small_batch_rates(tgb, dim, k, dev):
+    """HBM-bound regime (graph classification: one query per forward): bank passes per second."""
+    from ragraph_amd import kernels as K
+
+    out = {}
+    kn = tgb.keys_normalized
+    for B in (1, 16):
+        q = torch.randn(B, dim, device=dev)
+        for _ in range(3):
+            K.topk_cosine(q, kn, k)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            K.topk_cosine(q, kn, k)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        gbs = kn.numel() * 4 / ms / 1e6
+        out[f"B{B}"] = {"ms": round(ms, 4), "queries_per_s": round(B / ms * 1e3, 1), "bank_GBps": round(gbs, 1),
+                        "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+    return out
+
+
+def cpu_baseline(args, model, feats, adj):
+    """The reference's op chain on the host cores (oracle/ref_torch.py): GNN part on the whole graph (sparse CSR: the
+    reference's dense adjacency would be 40 GB), retrieval on a bounded sample of the queries with the bank
+    re-normalised per slab as the reference does; extrapolated to the full forward."""
+    from oracle import ref_torch
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n = feats.shape[0]
+    sample = min(args.cpu_sample, n)
+    conv = model.pretrain_model.gcn.convs[0]
+    p = {"W": conv.fc.weight.detach().cpu(), "bias": conv.bias.detach().cpu(), "alpha": conv.act.weight.detach().cpu()}
+    tgb = model.toy_graph_base
+    keys, vals, labs = tgb.resource_keys.cpu(), tgb.resource_values.cpu(), tgb.resource_labels.cpu()
+    adj_cpu = torch.sparse_csr_tensor(adj.rowptr.cpu(), adj.col.cpu().long(), adj.val.cpu(), (n, n))
+    X = feats.cpu()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        h = ref_torch.gcn_layer(X, adj_cpu, p["W"], p["bias"], p["alpha"])
+        ref_torch.propagate(adj_cpu, h, model.query_graph_hop)
+        t_gnn = time.perf_counter() - t0
+        slab = 512
+        ref_torch.retrieve(h[:slab], keys, vals, labs, args.k, slab=slab)  # warm-up slab (page-in, thread pool)
+        t0 = time.perf_counter()
+        ref_torch.retrieve(h[:sample], keys, vals, labs, args.k, slab=slab)
+        t_ret = time.perf_counter() - t0
+    est_full = t_gnn + t_ret * (n / sample)
+    return {"value": round(n / est_full, 2), "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"GNN encode+{model.query_graph_hop}-hop on all {n} nodes ({t_gnn:.2f}s, torch sparse CSR) + retrieval "
+                      f"of {sample} of the {n} queries in slabs of {slab} vs the full {keys.shape[0]}x{keys.shape[1]} bank "
+                      f"({t_ret:.2f}s, bank re-normalised per slab as the reference does), extrapolated to {n} queries",
+            "retrieval_only_queries_per_s": round(sample / t_ret, 2)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in ragraph_amd)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from ragraph_amd import kernels as K
+
+    topk_timer = EventTimer(K, "topk_cosine")
+    model, feats, adj, n_local = build_workload(args, dev, rank, world)
+
+    def step():
+        with torch.no_grad():
+            return model(feats, adj)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    topk_timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    topk_timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out).all()
+
+    n = args.nodes
+    ms_step = elapsed / args.steps * 1e3
+    topk_ms = topk_timer.mean_ms()
+    flops = 2.0 * n * n_local * args.dim
+    achieved = flops / (topk_ms * 1e-3) / 1e12
+    result = {
+        "metric": "retrieved-queries/sec (RAGraph_node forward: GCN encode + cosine/top-k retrieval + 3-hop propagate + decode)",
+        "value": round(n / (elapsed / args.steps), 1),
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_step, 3),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"RAGraph_node forward, synthetic {n}-node graph (F={args.feat}, mean degree ~10), "
+                               f"{args.bank}-key x {args.dim}-d bank, k={args.k}, C={args.classes} "
+                               f"(BASELINE.json configs[1])",
+                   "bank_rows_per_gpu": n_local,
+                   "parallelism": "single GPU" if world == 1 else
+                   f"bank row-sharded x{world}, RCCL all_gather of per-shard top-k + all_reduce of owned sums"},
+        "roofline": {"kernel": "ragraph::topk_stream_kernel<256> (fused cosine+top-k, v_mfma_f32_32x32x2_f32)",
+                     "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "launch_ms": round(topk_ms, 3),
+                     "note": "algorithmic flops 2*B*N*D per launch / mean launch time from events on the launch "
+                             "stream (includes the <0.1 % query-normalise and select kernels of the same ABI call)"},
+    }
+    if world == 1:
+        result["gnn_fwd_nodes_per_s"] = round(gnn_only_rate(model, feats, adj, max(args.steps, 3)), 1)
+        if args.small_batch:
+            result["retrieval_small_batch"] = small_batch_rates(model.toy_graph_base, args.dim, args.k, dev)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args, model, feats, adj)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

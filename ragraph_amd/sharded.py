@@ -1,0 +1,83 @@
+"""Key-bank sharding across the GPUs of one node: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" in the CPU tests).  The reference is single-GPU (no collective call exists in it).
+
+Partition: rank r owns bank rows [base_r, base_r + N_r).  Per retrieve:
+  1. every rank runs the fused cosine+top-k kernel on ITS shard with idx_base = base_r      -> [B,k] scores + global ids
+  2. ONE all_gather of the (B,k) score and id tensors (B*k*12 bytes per rank: latency-bound, single hop on the
+     fully connected xGMI mesh)                                                               -> [G,B,k]
+  3. every rank merges the G lists with the canonical order (score desc, id asc)            -> identical on all ranks,
+     and identical to the 1-GPU result bit for bit (scores are shard-independent fmaf chains)
+  4. every rank sums the value / label rows of the winners IT owns; one all_reduce(sum) of [B, D+C] finishes
+     sum_k V[idx], mean_k L[idx] (what RAGraph.forward consumes, RAGraph.py:48-49) -- no [B,k,D] traffic.
+Indices and scores are exact for any G; the value sums differ from 1 GPU only by fp32 re-association (<= 1e-6 rel).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(N: int, world: int, rank: int):
+    """Contiguous, balanced row ranges: the first N % world ranks hold one extra row."""
+    q, r = divmod(N, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+class ShardedToyGraphBase:
+    """Retrieval over a row-sharded bank.  `ops` supplies the five kernels (default: ragraph_amd.kernels, i.e. the HIP
+    library); the CPU tests inject an oracle-backed object to exercise the collective logic under gloo."""
+
+    def __init__(self, keys, values, labels, idx_base: int, retrieve_num: int, group=None, ops=None):
+        if ops is None:
+            from . import kernels as ops  # the HIP library; raises loudly without a GPU
+        self.ops = ops
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.idx_base = int(idx_base)
+        self.retrieve_num = retrieve_num
+        self.resource_keys, self.resource_values, self.resource_labels = keys, values, labels
+        self.keys_normalized = ops.normalize_rows(keys)
+
+    def topk(self, search_keys, k=None):
+        """Global canonical top-k: (scores [B,k], idx [B,k]) identical on every rank."""
+        k = self.retrieve_num if k is None else k
+        q = search_keys.reshape(1, -1) if search_keys.dim() == 1 else search_keys
+        n_local = self.keys_normalized.shape[0]
+        kl = min(k, n_local)
+        s, i = self.ops.topk_cosine(q, self.keys_normalized, kl, idx_base=self.idx_base)
+        if kl < k:  # a shard smaller than k: pad with sentinels that lose every comparison
+            pad_s = torch.full((q.shape[0], k - kl), float("-inf"), dtype=s.dtype, device=s.device)
+            pad_i = torch.full((q.shape[0], k - kl), torch.iinfo(torch.int64).max, dtype=i.dtype, device=i.device)
+            s, i = torch.cat([s, pad_s], 1), torch.cat([i, pad_i], 1)
+        if self.world == 1:
+            return s, i
+        B = s.shape[0]
+        gs = torch.empty((self.world * B, k), dtype=s.dtype, device=s.device)   # rank-major concatenation
+        gi = torch.empty((self.world * B, k), dtype=i.dtype, device=i.device)
+        dist.all_gather_into_tensor(gs, s.contiguous(), group=self.group)
+        dist.all_gather_into_tensor(gi, i.contiguous(), group=self.group)
+        return self.ops.topk_merge(gs.view(self.world, B, k), gi.view(self.world, B, k))
+
+    def retrieve_reduced(self, search_keys, k=None):
+        """(sum_k V[idx], mean_k L[idx], idx) over the whole bank."""
+        k = self.retrieve_num if k is None else k
+        _, idx = self.topk(search_keys, k)
+        sum_v, _ = self.ops.gather_reduce(self.resource_values, None, idx, idx_base=self.idx_base)
+        sum_l, _ = self.ops.gather_reduce(self.resource_labels, None, idx, idx_base=self.idx_base)
+        if self.world > 1:
+            packed = torch.cat([sum_v, sum_l], dim=1)
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
+            sum_v, sum_l = packed[:, :sum_v.shape[1]].contiguous(), packed[:, sum_v.shape[1]:].contiguous()
+        return sum_v, sum_l / float(k), idx  # label counts are small integers: exact sums, one rounded division
+
+    def retrieve(self, search_keys, search_adj=None, add_noise=False):
+        """Public (B,k,D)/(B,k,C) form of ToyGraphBase.retrieve: owner-gather + all_reduce (zeros elsewhere)."""
+        _, idx = self.topk(search_keys, self.retrieve_num)
+        e = self.ops.gather_rows(self.resource_values, idx, idx_base=self.idx_base)
+        l = self.ops.gather_rows(self.resource_labels, idx, idx_base=self.idx_base)
+        if self.world > 1:
+            dist.all_reduce(e, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(l, op=dist.ReduceOp.SUM, group=self.group)
+        return e, l

@@ -1,0 +1,88 @@
+"""World-size-2 gloo test of the sharded retrieval logic (ragraph_amd/sharded.py) on CPU.  The per-shard kernels are
+replaced by an oracle-backed `ops` object (tests may use the oracle; the product default is the HIP library), so what
+is exercised is the collective path: shard bounds, idx_base, all_gather, canonical merge, owner-sum + all_reduce."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import cref
+
+
+class OracleOps:
+    """The five kernels of ragraph_amd.kernels, answered by the CPU checker on torch CPU tensors."""
+
+    @staticmethod
+    def normalize_rows(x):
+        return torch.from_numpy(cref.normalize_rows(x.numpy()))
+
+    @staticmethod
+    def topk_cosine(q, kn, k, idx_base=0):
+        s, i = cref.topk_cosine(q.numpy(), kn.numpy(), k, idx_base)
+        return torch.from_numpy(s), torch.from_numpy(i)
+
+    @staticmethod
+    def topk_merge(s, i):
+        a, b = cref.topk_merge(s.numpy(), i.numpy())
+        return torch.from_numpy(a), torch.from_numpy(b)
+
+    @staticmethod
+    def gather_reduce(v, l, idx, idx_base=0, v_scale=1.0):
+        a, b = cref.gather_reduce(v.numpy(), None if l is None else l.numpy(), idx.numpy(), idx_base, v_scale)
+        return torch.from_numpy(a), (None if b is None else torch.from_numpy(b))
+
+    @staticmethod
+    def gather_rows(v, idx, idx_base=0):
+        return torch.from_numpy(cref.gather_rows(v.numpy(), idx.numpy(), idx_base))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, N, D, C, B, k, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ragraph_amd.sharded import ShardedToyGraphBase, shard_bounds
+
+        rng = np.random.default_rng(0)  # same bank on every rank, each keeps its slice
+        keys = cref.normalize_rows(rng.standard_normal((N, D), dtype=np.float32))
+        vals = rng.standard_normal((N, D), dtype=np.float32)
+        labs = np.eye(C, dtype=np.float32)[rng.integers(0, C, N)]
+        q = rng.standard_normal((B, D), dtype=np.float32)
+        lo, hi = shard_bounds(N, world, rank)
+        tgb = ShardedToyGraphBase(torch.from_numpy(keys[lo:hi]), torch.from_numpy(vals[lo:hi]),
+                                  torch.from_numpy(labs[lo:hi]), lo, k, ops=OracleOps)
+        s, i = tgb.topk(torch.from_numpy(q))
+        sv, ml, _ = tgb.retrieve_reduced(torch.from_numpy(q))
+        e, l = tgb.retrieve(torch.from_numpy(q))
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), s=s.numpy(), i=i.numpy(), sv=sv.numpy(), ml=ml.numpy(),
+                 e=e.numpy(), l=l.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,k", [(3001, 10), (12, 10)])  # second case: shards (6 rows) smaller than k
+def test_sharded_retrieval_world2_matches_single(tmp_path, N, k):
+    D, C, B, world = 64, 3, 37, 2
+    mp.spawn(_worker, args=(world, _free_port(), N, D, C, B, k, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(0)
+    keys = cref.normalize_rows(rng.standard_normal((N, D), dtype=np.float32))
+    vals = rng.standard_normal((N, D), dtype=np.float32)
+    labs = np.eye(C, dtype=np.float32)[rng.integers(0, C, N)]
+    q = rng.standard_normal((B, D), dtype=np.float32)
+    rs, ri = cref.topk_cosine(q, cref.normalize_rows(keys), k)  # the bank object normalises its stored keys once
+    rsv, rml = cref.gather_reduce(vals, labs, ri)
+    r0, r1 = (dict(np.load(tmp_path / f"r{r}.npz")) for r in range(world))
+    for r in (r0, r1):
+        assert np.array_equal(r["i"], ri) and np.array_equal(r["s"], rs)  # bit-identical to one GPU, on every rank
+        assert np.allclose(r["sv"], rsv, atol=1e-5) and np.array_equal(r["ml"], rml)
+        assert np.array_equal(r["e"], vals[ri]) and np.array_equal(r["l"], labs[ri])
+    assert np.array_equal(r0["sv"], r1["sv"])
