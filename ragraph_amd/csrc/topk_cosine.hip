@@ -54,8 +54,37 @@ __device__ __forceinline__ void list_offer(float* ls, int* li, float* thr_q, int
   thr_q[q] = (k == 1) ? s : (cand_better(s, idx, w2_s, w2_i) ? w2_s : s);
 }
 
+// Wave-cooperative insert into a SORTED k-list (k <= 64) that lives in LDS as [k][QS]: lane p holds entry p, one
+// ballot finds the insert position, one shuffle shifts the tail.  All 64 lanes must call it with wave-uniform
+// (q, s, idx).  Returns the new k-th best score.
+__device__ __forceinline__ float list_insert_coop(float* ls, int* li, int q, int k, int QS, float s, int idx,
+                                                  int lane) {
+  const bool mine = lane < k;
+  float es = mine ? ls[lane * QS + q] : 0.f;
+  int ei = mine ? li[lane * QS + q] : 0;
+  // entries that stay ahead of the candidate: a prefix of the sorted list
+  const unsigned long long ahead = __ballot(mine && cand_better(es, ei, s, idx));
+  const int pos = __popcll(ahead);
+  const float us = __shfl_up(es, 1);
+  const int ui = __shfl_up(ei, 1);
+  if (pos < k) {  // wave-uniform
+    if (lane == pos) {
+      es = s;
+      ei = idx;
+    } else if (lane > pos) {
+      es = us;
+      ei = ui;
+    }
+    if (mine && lane >= pos) {
+      ls[lane * QS + q] = es;
+      li[lane * QS + q] = ei;
+    }
+  }
+  return __shfl(es, k - 1);
+}
+
 struct TopkParams {
-  const float* Qn;   // [B,D] normalised queries
+  const float* Qn;   // [B,D] normalised queries (big kernel) / RAW queries (small-batch kernel)
   const float* Kn;   // [N,D] normalised keys
   int64_t B, N;
   int k;
@@ -232,11 +261,190 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Small-batch variant (B <= 16): graph classification sends ONE query per forward (RAGraph_graph/RAGraph.py:50), so
+// the pass over the bank is pure HBM streaming (arithmetic intensity B/2 flop/B).  Same numerics as the big kernel
+// (natural-order fmaf chain) on v_mfma_f32_16x16x4_f32: keys are the A operand (16 rows), the <= 16 queries sit in
+// D/4 VGPRs as the B operand, a lane ends up with 4 scores of ONE query (col = lane & 15, rows 4*(lane>>4)+r).
+//   * every WAVE streams its own 16 KiB tiles (tile t of wave w: t = w, w + #waves, ...): 16 global_load_dwordx4 per
+//     lane, each wave-instruction one full 1 KiB row at D=256; the next tile's loads are issued right after the
+//     current tile is written to the wave-private LDS image, so each wave keeps 16 KiB in flight and a CU 128 KiB
+//     (Little: ~25 KiB/CU needed at 10 B/clk/CU and ~2.5k cycles loaded latency);
+//   * LDS is only the transpose (row-major rows in, MFMA k-slots out): row stride D+2 floats makes the ds_read_b32 of
+//     lane (j, s) at [j][4m+s] hit 32 distinct banks per half-wave; no workgroup barrier in the loop;
+//   * MFMA needs 64 x 32 cycles per 16 KiB per SIMD = 4x the HBM rate, so the kernel stays HBM-bound up to B = 16.
+// ------------------------------------------------------------------------------------------------------------------
+template <int D>
+struct SmallCfg {
+  static constexpr int WAVES = 8;
+  static constexpr int SUB = 256 / D;              // 16-key MFMA sub-tiles per 16 KiB tile
+  static constexpr int TILE_KEYS = 16 * SUB;
+  static constexpr int ROW = D + 2;                // floats
+  static constexpr int TILE_FLOATS = TILE_KEYS * ROW;
+  static constexpr int RPI = 256 / D;              // rows covered by one wave-wide float4 load instruction
+  static size_t lds_bytes(int k) { return (size_t)WAVES * (sizeof(float) * (TILE_FLOATS + 16) + (size_t)k * 16 * 8); }
+};
+
+template <int D>
+__global__ void __launch_bounds__(512, 2) topk_smallb_kernel(TopkParams p) {
+  using C = SmallCfg<D>;
+  extern __shared__ float4 smem4[];
+  float* smem = reinterpret_cast<float*>(smem4);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, sl = lane >> 4;
+  const int k = p.k;
+  const int per_wave = C::TILE_FLOATS + 16 + 2 * k * 16;  // tile | thr[16] | ls[k][16] | li[k][16]
+  float* tile = smem + wave * per_wave;
+  float* thr_q = tile + C::TILE_FLOATS;
+  float* ls = thr_q + 16;
+  int* li = reinterpret_cast<int*>(ls + k * 16);
+
+  // B operand: query j, k-slots sl, sl+4, ...  (queries >= B are clamped; their lists are never offered to).
+  // The queries arrive RAW: each wave normalises them itself with the same reduction tree and the same correctly
+  // rounded sqrt / divide as normalize_rows_kernel (bit-identical), which saves a launch on this latency-bound path.
+  float breg[D / 4];
+  {
+    float my_d = 1.f;
+    const int nq = (int)p.B;
+    for (int jj = 0; jj < nq; ++jj) {
+      float pp = 0.f;
+      for (int c = lane; c < D / 4; c += 64) {
+        const float4 v = reinterpret_cast<const float4*>(p.Qn + (int64_t)jj * D)[c];
+        pp = fmaf(v.x, v.x, pp);
+        pp = fmaf(v.y, v.y, pp);
+        pp = fmaf(v.z, v.z, pp);
+        pp = fmaf(v.w, v.w, pp);
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) pp = __fadd_rn(pp, __shfl_xor(pp, off));
+      const float d = fmaxf(sqrtf(pp), 1e-12f);
+      if (jj == j || (j >= nq && jj == nq - 1)) my_d = d;
+    }
+    const int64_t q = (j < p.B) ? j : p.B - 1;
+    const float4* qp = reinterpret_cast<const float4*>(p.Qn + q * D);
+#pragma unroll
+    for (int m = 0; m < D / 4; ++m) {
+      const float4 v = qp[m];
+      const float x = sl == 0 ? v.x : sl == 1 ? v.y : sl == 2 ? v.z : v.w;
+      breg[m] = x / my_d;
+    }
+  }
+  for (int i = lane; i < k * 16; i += 64) {
+    ls[i] = RG_NEG_INF;
+    li[i] = RG_IDX_NONE;
+  }
+  if (lane < 16) thr_q[lane] = RG_NEG_INF;
+
+  const int64_t ntiles = (p.N + C::TILE_KEYS - 1) / C::TILE_KEYS;
+  const int64_t gw = (int64_t)blockIdx.x * C::WAVES + wave, nw = (int64_t)gridDim.x * C::WAVES;
+  const bool live = j < p.B;
+  float thr = live ? RG_NEG_INF : __builtin_huge_valf();
+
+  float4 pre[16];
+  const int lrow = lane / (D / 4), lcol = 4 * (lane % (D / 4));
+  auto load_tile = [&](int64_t t) {
+    const int64_t key0 = t * C::TILE_KEYS + lrow;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int64_t r = key0 + (int64_t)i * C::RPI;
+      if (r > p.N - 1) r = p.N - 1;
+      pre[i] = *reinterpret_cast<const float4*>(p.Kn + r * D + lcol);
+    }
+  };
+
+  int64_t t = gw;
+  if (t < ntiles) load_tile(t);
+  for (; t < ntiles; t += nw) {
+    // transpose image: row-major rows in (two 8-byte stores: odd rows are only 8-byte aligned at stride D+2)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float* d = tile + (lrow + i * C::RPI) * C::ROW + lcol;
+      *reinterpret_cast<float2*>(d) = make_float2(pre[i].x, pre[i].y);
+      *reinterpret_cast<float2*>(d + 2) = make_float2(pre[i].z, pre[i].w);
+    }
+    const int64_t tn = t + nw;
+    load_tile(tn < ntiles ? tn : t);  // next tile in flight under this tile's MFMAs (clamped reload on the last one)
+    __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll 1
+    for (int sub = 0; sub < C::SUB; ++sub) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* a = tile + (sub * 16 + j) * C::ROW + sl;
+#pragma unroll
+      for (int m = 0; m < D / 4; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * m], breg[m], acc, 0, 0, 0);
+
+      const float mx = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+      if (__any(mx >= thr)) {
+        // rare path: the wave inserts the candidates one at a time, all 64 lanes cooperating on each insert
+        const int key_base = (int)(t * C::TILE_KEYS) + sub * 16 + 4 * sl;
+        unsigned mask = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (acc[r] >= thr && key_base + r < (int)p.N) mask |= 1u << r;
+        unsigned long long pend = __ballot(mask != 0);
+        while (pend) {
+          const int src = __ffsll((long long)pend) - 1;          // wave-uniform: lowest lane with a candidate
+          const int r0 = __ffs(mask) - 1;                        // (meaningful on lane src)
+          const float my_sc = r0 == 1 ? acc[1] : r0 == 2 ? acc[2] : r0 == 3 ? acc[3] : acc[0];
+          const float sc = __shfl(my_sc, src);
+          const int idx = __shfl(key_base + r0, src);
+          const int q = src & 15;
+          const float nthr = list_insert_coop(ls, li, q, k, 16, sc, idx, lane);
+          if (live && j == q) thr = nthr;
+          if (lane == src) mask &= mask - 1;
+          // drop this lane's remaining candidates that the tightened threshold already excludes
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if ((mask >> r & 1u) && acc[r] < thr) mask &= ~(1u << r);
+          pend = __ballot(mask != 0);
+        }
+      }
+    }
+  }
+
+  // ---- workgroup merge: 8 wave lists per query -> one sorted partial per (query, workgroup) -------------------
+  __syncthreads();
+  for (int q = wave; q < (int)p.B; q += C::WAVES) {
+    float prev_s = __builtin_huge_valf();
+    int prev_i = -1;
+    for (int r = 0; r < k; ++r) {
+      float best_s = RG_NEG_INF;
+      int best_i = RG_IDX_NONE;
+      for (int c = lane; c < C::WAVES * k; c += 64) {
+        const float* wl = smem + (c / k) * per_wave + C::TILE_FLOATS + 16;
+        const float s = wl[(c % k) * 16 + q];
+        const int i = reinterpret_cast<const int*>(wl + k * 16)[(c % k) * 16 + q];
+        const bool after_prev = (s < prev_s) || (s == prev_s && i > prev_i);
+        if (after_prev && cand_better(s, i, best_s, best_i)) {
+          best_s = s;
+          best_i = i;
+        }
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const float os = __shfl_xor(best_s, off);
+        const int oi = __shfl_xor(best_i, off);
+        if (cand_better(os, oi, best_s, best_i)) {
+          best_s = os;
+          best_i = oi;
+        }
+      }
+      if (lane == 0) {
+        const int64_t o = ((int64_t)q * gridDim.x + blockIdx.x) * k + r;
+        p.part_s[o] = best_s;
+        p.part_i[o] = best_i;
+      }
+      prev_s = best_s;
+      prev_i = best_i;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Select the canonical top-k among M candidates per query (partials of the splits, or the per-GPU lists).
 // One wave per query; round r picks the best candidate strictly worse than round r-1's winner, so no marking is
 // needed and unsorted input is fine.  Candidate c of query b, list g: element (g*gs + b*bs + c), c in [0, k).
 // ------------------------------------------------------------------------------------------------------------------
-template <typename IdxT>
+template <typename IdxT, int CPL>  // CPL = candidates per lane held in registers (M <= 64 * CPL)
 __global__ void __launch_bounds__(256) topk_select_kernel(const float* __restrict__ cs, const IdxT* __restrict__ ci,
                                                           int G, int64_t B, int k, int64_t gs, int64_t bs,
                                                           int64_t idx_base, float* __restrict__ out_s,
@@ -245,21 +453,32 @@ __global__ void __launch_bounds__(256) topk_select_kernel(const float* __restric
   const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (b >= B) return;
   const int M = G * k;
+  // one coalesced sweep: every candidate is loaded exactly once, all loads in flight together
+  float s[CPL];
+  int64_t id[CPL];
+#pragma unroll
+  for (int u = 0; u < CPL; ++u) {
+    const int c = lane + 64 * u;
+    s[u] = RG_NEG_INF;
+    id[u] = INT64_MAX;
+    if (c < M) {
+      const int64_t o = (int64_t)(c / k) * gs + b * bs + (c % k);
+      s[u] = cs[o];
+      id[u] = (int64_t)ci[o];
+    }
+  }
   float prev_s = __builtin_huge_valf();
   int64_t prev_i = -1;  // everything is worse than (+inf, -1)
   for (int r = 0; r < k; ++r) {
     float best_s = RG_NEG_INF;
     int64_t best_i = INT64_MAX;
-    for (int c = lane; c < M; c += 64) {
-      const int g = c / k, e = c % k;
-      const int64_t o = g * gs + b * bs + e;
-      const float s = cs[o];
-      const int64_t i = (int64_t)ci[o];
-      const bool after_prev = (s < prev_s) || (s == prev_s && i > prev_i);
-      const bool beats = (s > best_s) || (s == best_s && i < best_i);
+#pragma unroll
+    for (int u = 0; u < CPL; ++u) {
+      const bool after_prev = (s[u] < prev_s) || (s[u] == prev_s && id[u] > prev_i);
+      const bool beats = (s[u] > best_s) || (s[u] == best_s && id[u] < best_i);
       if (after_prev && beats) {
-        best_s = s;
-        best_i = i;
+        best_s = s[u];
+        best_i = id[u];
       }
     }
 #pragma unroll
@@ -280,6 +499,117 @@ __global__ void __launch_bounds__(256) topk_select_kernel(const float* __restric
   }
 }
 
+// k-way merge of G SORTED lists per query (the small-batch kernel's per-workgroup partials; the per-GPU lists of the
+// sharded bank).  One wave per query: the lists are staged in LDS once, each lane keeps the heads of <= 4 lists in
+// registers, and a round costs one wave argmax plus one LDS read for the winner -- O(k log 64) instead of O(k * G*k/64).
+template <typename IdxT>
+__global__ void __launch_bounds__(64) topk_merge_sorted_kernel(const float* __restrict__ cs, const IdxT* __restrict__ ci,
+                                                               int G, int64_t B, int k, int64_t gs, int64_t bs,
+                                                               int64_t idx_base, float* __restrict__ out_s,
+                                                               int64_t* __restrict__ out_i) {
+  extern __shared__ float4 smem4[];
+  float* Ls = reinterpret_cast<float*>(smem4);        // [G*k]
+  IdxT* Li = reinterpret_cast<IdxT*>(Ls + G * k);     // [G*k]
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  const int M = G * k;
+  for (int c = lane; c < M; c += 64) {
+    const int64_t o = (int64_t)(c / k) * gs + b * bs + (c % k);
+    Ls[c] = cs[o];
+    Li[c] = ci[o];
+  }
+  __syncthreads();
+  float hs[4];
+  int64_t hi[4];
+  int hp[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int g = lane + 64 * u;
+    hp[u] = 0;
+    hs[u] = (g < G) ? Ls[g * k] : RG_NEG_INF;
+    hi[u] = (g < G) ? (int64_t)Li[g * k] : INT64_MAX;
+  }
+  for (int r = 0; r < k; ++r) {
+    float best_s = hs[0];
+    int64_t best_i = hi[0];
+    int best_u = 0;
+#pragma unroll
+    for (int u = 1; u < 4; ++u)
+      if ((hs[u] > best_s) || (hs[u] == best_s && hi[u] < best_i)) {
+        best_s = hs[u];
+        best_i = hi[u];
+        best_u = u;
+      }
+    float ws = best_s;
+    int64_t wi = best_i;
+    int wl = lane;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float os = __shfl_xor(ws, off);
+      const int64_t oi = __shfl_xor(wi, off);
+      const int ol = __shfl_xor(wl, off);
+      if ((os > ws) || (os == ws && oi < wi)) {
+        ws = os;
+        wi = oi;
+        wl = ol;
+      }
+    }
+    if (lane == 0) {
+      out_s[b * k + r] = ws;
+      out_i[b * k + r] = (wi == INT64_MAX) ? wi : wi + idx_base;
+    }
+    if (lane == wl) {  // advance the winning list (indices are unique, so exactly one lane / one head matches)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (u == best_u) {
+          const int g = lane + 64 * u;
+          const int np = ++hp[u];
+          hs[u] = (np < k) ? Ls[g * k + np] : RG_NEG_INF;
+          hi[u] = (np < k) ? (int64_t)Li[g * k + np] : INT64_MAX;
+        }
+    }
+  }
+}
+
+template <typename IdxT>
+static int launch_merge_sorted(const float* cs, const IdxT* ci, int G, int64_t B, int k, int64_t gs, int64_t bs,
+                               int64_t idx_base, float* out_s, int64_t* out_i, hipStream_t st) {
+  if (G > 256) {
+    set_error("topk merge: %d lists per query exceed 256", G);
+    return RAGRAPH_EUNSUPPORTED;
+  }
+  const size_t lds = (size_t)G * k * (sizeof(float) + sizeof(IdxT));
+  hipLaunchKernelGGL(topk_merge_sorted_kernel<IdxT>, dim3((unsigned)B), dim3(64), lds, st, cs, ci, G, B, k, gs, bs,
+                     idx_base, out_s, out_i);
+  RG_CHECK_LAUNCH("topk_merge_sorted");
+  return RAGRAPH_OK;
+}
+
+template <typename IdxT>
+static int launch_select(const float* cs, const IdxT* ci, int G, int64_t B, int k, int64_t gs, int64_t bs,
+                         int64_t idx_base, float* out_s, int64_t* out_i, hipStream_t st) {
+  const int M = G * k;
+  const int wpb = 4;
+  dim3 grid((unsigned)cdiv(B, wpb)), block(wpb * 64);
+#define RG_SEL(CPL_)                                                                                          \
+  hipLaunchKernelGGL((topk_select_kernel<IdxT, CPL_>), grid, block, 0, st, cs, ci, G, B, k, gs, bs, idx_base, \
+                     out_s, out_i)
+  if (M <= 64) RG_SEL(1);
+  else if (M <= 128) RG_SEL(2);
+  else if (M <= 256) RG_SEL(4);
+  else if (M <= 512) RG_SEL(8);
+  else if (M <= 1024) RG_SEL(16);
+  else if (M <= 2048) RG_SEL(32);
+  else if (M <= 4096) RG_SEL(64);
+  else {
+    set_error("topk select: %d candidates per query exceed 4096", M);
+    return RAGRAPH_EUNSUPPORTED;
+  }
+#undef RG_SEL
+  RG_CHECK_LAUNCH("topk_select");
+  return RAGRAPH_OK;
+}
+
 // ---- split planning ----------------------------------------------------------------------------------------------
 // Work items = qtiles x nsplit equal-length workgroups, one per CU at a time (LDS-limited).  Pick the split count that
 // fills whole rounds of 256 CUs while keeping each stream long enough that the list warm-up (~k ln(n/k) offers per
@@ -290,12 +620,30 @@ struct TopkPlan {
   size_t qn_bytes, part_s_bytes, part_i_bytes;
 };
 
+static const int SMALLB_MAX = 16;
+
 static TopkPlan plan_topk(int64_t B, int64_t N, int D, int k) {
+  if (B <= SMALLB_MAX) {  // small-batch kernel: nsplit = workgroups (one sorted partial list each)
+    const int tile_keys = 16 * (256 / D);
+    const int64_t ntiles = cdiv(N, tile_keys);
+    int64_t wgs = cdiv(ntiles, 8 * 2);  // >= 2 tiles per wave so the prefetch has something to overlap
+    if (wgs > 256) wgs = 256;
+    if (wgs * k > 4096) wgs = 4096 / k;  // the select kernel holds <= 4096 candidates per query
+    if (wgs < 1) wgs = 1;
+    TopkPlan ps;
+    ps.nsplit = (int)wgs;
+    ps.keys_per_split = 0;
+    ps.qn_bytes = align_up((size_t)B * D * sizeof(float), 256);
+    ps.part_s_bytes = align_up((size_t)B * wgs * k * sizeof(float), 256);
+    ps.part_i_bytes = align_up((size_t)B * wgs * k * sizeof(int), 256);
+    return ps;
+  }
   const int QT = 256, CUS = 256;
   const int stage_keys = 32 * (256 / D);
   const int64_t qtiles = cdiv(B, QT);
   const int64_t nstages = cdiv(N, stage_keys);
   int64_t max_split = nstages < 256 ? nstages : 256;
+  if (max_split * k > 4096) max_split = 4096 / k;  // the select kernel holds <= 4096 candidates per query
   const int64_t min_keys = 8192;  // below this the warm-up dominates
   int best = 1;
   double best_cost = 1e300;
@@ -342,6 +690,25 @@ static int launch_topk(const TopkParams& p, int64_t qtiles, hipStream_t st) {
   return RAGRAPH_OK;
 }
 
+template <int D>
+static int launch_smallb(const TopkParams& p, hipStream_t st) {
+  using C = SmallCfg<D>;
+  const size_t lds = C::lds_bytes(p.k);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_smallb_kernel<D>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      set_error("topk_cosine(small batch): cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+      return RAGRAPH_EDEVICE;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(topk_smallb_kernel<D>, dim3((unsigned)p.nsplit), dim3(512), lds, st, p);
+  RG_CHECK_LAUNCH("topk_cosine(small batch)");
+  return RAGRAPH_OK;
+}
+
 }  // namespace ragraph
 
 using namespace ragraph;
@@ -372,11 +739,14 @@ extern "C" int ragraph_topk_cosine_f32(const float* Q, int64_t B, const float* K
   float* part_s = reinterpret_cast<float*>(w + pl.qn_bytes);
   int* part_i = reinterpret_cast<int*>(w + pl.qn_bytes + pl.part_s_bytes);
 
-  int rc = ragraph_normalize_rows_f32(Q, B, D, Qn, stream);
-  if (rc != RAGRAPH_OK) return rc;
+  int rc = RAGRAPH_OK;
+  if (B > SMALLB_MAX) {  // the small-batch kernel normalises its <= 16 queries itself
+    rc = ragraph_normalize_rows_f32(Q, B, D, Qn, stream);
+    if (rc != RAGRAPH_OK) return rc;
+  }
 
   TopkParams p;
-  p.Qn = Qn;
+  p.Qn = (B > SMALLB_MAX) ? Qn : Q;
   p.Kn = Kn;
   p.B = B;
   p.N = N;
@@ -386,20 +756,23 @@ extern "C" int ragraph_topk_cosine_f32(const float* Q, int64_t B, const float* K
   p.part_s = part_s;
   p.part_i = part_i;
   const int64_t qtiles = cdiv(B, 256);
-  if (D == 256)
+  if (B <= SMALLB_MAX) {
+    rc = D == 256 ? launch_smallb<256>(p, st) : D == 128 ? launch_smallb<128>(p, st) : launch_smallb<64>(p, st);
+  } else if (D == 256) {
     rc = launch_topk<256>(p, qtiles, st);
-  else if (D == 128)
+  } else if (D == 128) {
     rc = launch_topk<128>(p, qtiles, st);
-  else
+  } else {
     rc = launch_topk<64>(p, qtiles, st);
+  }
   if (rc != RAGRAPH_OK) return rc;
 
   // partial layout [B][nsplit][k]: list g of query b at b*(nsplit*k) + g*k
-  const int wpb = 4;
-  hipLaunchKernelGGL(topk_select_kernel<int>, dim3((unsigned)cdiv(B, wpb)), dim3(wpb * 64), 0, st, part_s, part_i,
-                     pl.nsplit, B, k, (int64_t)k, (int64_t)pl.nsplit * k, idx_base, out_scores, out_idx);
-  RG_CHECK_LAUNCH("topk_select");
-  return RAGRAPH_OK;
+  if (B <= SMALLB_MAX)  // per-workgroup partials of the small-batch kernel are sorted
+    return launch_merge_sorted<int>(part_s, part_i, pl.nsplit, B, k, (int64_t)k, (int64_t)pl.nsplit * k, idx_base,
+                                    out_scores, out_idx, st);
+  return launch_select<int>(part_s, part_i, pl.nsplit, B, k, (int64_t)k, (int64_t)pl.nsplit * k, idx_base, out_scores,
+                            out_idx, st);
 }
 
 extern "C" int ragraph_topk_merge_f32(const float* scores, const int64_t* idx, int G, int64_t B, int k,
@@ -407,9 +780,6 @@ extern "C" int ragraph_topk_merge_f32(const float* scores, const int64_t* idx, i
   RG_REQUIRE(scores && idx && out_scores && out_idx, RAGRAPH_EINVAL, "topk_merge: null pointer");
   RG_REQUIRE(G >= 1 && B >= 1 && k >= 1, RAGRAPH_EINVAL, "topk_merge: G,B,k must be >= 1");
   RG_REQUIRE((int64_t)G * k <= 4096, RAGRAPH_EUNSUPPORTED, "topk_merge: G*k=%lld > 4096", (long long)G * k);
-  const int wpb = 4;
-  hipLaunchKernelGGL(topk_select_kernel<int64_t>, dim3((unsigned)cdiv(B, wpb)), dim3(wpb * 64), 0, as_stream(stream),
-                     scores, idx, G, B, k, (int64_t)B * k, (int64_t)k, (int64_t)0, out_scores, out_idx);
-  RG_CHECK_LAUNCH("topk_merge");
-  return RAGRAPH_OK;
+  return launch_select<int64_t>(scores, idx, G, B, k, (int64_t)B * k, (int64_t)k, (int64_t)0, out_scores, out_idx,
+                                as_stream(stream));
 }
