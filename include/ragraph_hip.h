@@ -65,13 +65,14 @@ int ragraph_normalize_rows_f32(const float* X, int64_t n, int D, float* out, voi
  *   Q   [B,D] raw (un-normalised) queries; normalised inside (a1) into the workspace.
  *   Kn  [N,D] key bank ALREADY row-normalised by ragraph_normalize_rows_f32 (done once per bank version; the
  *       reference re-normalises its stored keys on every call, SimilarityFunctions.py:11).
- *   k   1 <= k <= min(N, RAGRAPH_TOPK_MAX).  D in {64,128,256}.  B,N >= 1.
+ *   k   1 <= k <= min(N, RAGRAPH_TOPK_MAX).  D in {64,128,256}.  B,N >= 1.  B <= 16 takes the HBM-streaming
+ *       small-batch kernel (16x16x4 MFMA), larger B the MFMA-bound tile kernel (32x32x2); same numerics.
  *   idx_base  added to every returned index (this shard's first global row).
  *   out_scores [B,k] fp32 descending; out_idx [B,k] int64 (torch indexing dtype).
- *   Unsupported (returns RAGRAPH_EUNSUPPORTED): other D, k > RAGRAPH_TOPK_MAX.  NaN scores are never selected
+ *   Unsupported (returns RAGRAPH_EUNSUPPORTED): other D, k > RAGRAPH_TOPK_MAX, shards of >= 2^31 rows.  NaN scores are never selected
  *   (torch.topk would rank NaN first) -- inputs are finite by contract.
  */
-#define RAGRAPH_TOPK_MAX 64
+#define RAGRAPH_TOPK_MAX 32
 size_t ragraph_topk_cosine_workspace_bytes(int64_t B, int64_t N, int D, int k);
 int ragraph_topk_cosine_f32(const float* Q, int64_t B, const float* Kn, int64_t N, int D, int k, int64_t idx_base,
                             float* out_scores, int64_t* out_idx, void* ws, size_t ws_bytes, void* stream);
@@ -141,12 +142,11 @@ int ragraph_axpby_f32(const float* a, float wa, const float* b, float wb, int64_
 int ragraph_softmax_mix_f32(const float* logits, const float* rag_label, int64_t B, int C, float lambda, int log_mode,
                             float* out, void* stream);
 
-/* a8 (graph flavour)  torch.mean(x, dim=0)  -- RAGraph_graph/RAGraph.py:50,63; a10 segment sum readout
- *     split_and_batchify_graph_feats  -- RAGraph_graph/downprompt.py:98-112.
- *     out[g,:] = scale_g * sum_{r in [seg_ptr[g], seg_ptr[g+1])} (w ? w[:] * X[r,:] : X[r,:]),  sequential r.
- *     mean_mode=1: scale_g = 1/len_g, else 1.  w [D] = downstreamprompt weight (downprompt.py:154-168) or NULL;
- *     elu=1 applies ELU to w*x before summing?  No: the graph flavour sums w*x (downprompt.py:21,167); the node flavour
- *     has no readout.  D % 4 == 0. */
+/* a8 (graph flavour)  torch.mean(x, dim=0)  -- RAGraph_graph/RAGraph.py:50,63; a10 per-graph sum readout
+ *     split_and_batchify_graph_feats  -- RAGraph_graph/downprompt.py:98-112, with downstreamprompt's w * h
+ *     (downprompt.py:154-168) fused into the pass.
+ *     out[g,:] = scale_g * sum_{r in [seg_ptr[g], seg_ptr[g+1])} (w ? w[:] * X[r,:] : X[r,:]),  sequential r, fp32 adds.
+ *     mean_mode=1: scale_g = 1/len_g (a division), else 1.  w [D] or NULL.  D % 4 == 0; X, out, w 16-byte aligned. */
 int ragraph_segment_reduce_f32(const float* X, int D, const int64_t* seg_ptr, int64_t G, const float* w, int mean_mode,
                                float* out, void* stream);
 

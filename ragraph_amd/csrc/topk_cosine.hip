@@ -727,7 +727,8 @@ extern "C" int ragraph_topk_cosine_f32(const float* Q, int64_t B, const float* K
   RG_REQUIRE(k >= 1 && k <= N, RAGRAPH_EINVAL, "topk_cosine: k=%d out of range for N=%lld (torch.topk raises too)", k,
              (long long)N);
   RG_REQUIRE(D == 64 || D == 128 || D == 256, RAGRAPH_EUNSUPPORTED, "topk_cosine: D=%d not in {64,128,256}", D);
-  RG_REQUIRE(k <= 32, RAGRAPH_EUNSUPPORTED, "topk_cosine: k=%d > 32 not supported by the fused kernel yet", k);
+  RG_REQUIRE(k <= RAGRAPH_TOPK_MAX, RAGRAPH_EUNSUPPORTED, "topk_cosine: k=%d > %d not supported by the fused kernel", k,
+             RAGRAPH_TOPK_MAX);
   RG_REQUIRE(N < (int64_t)INT_MAX - 1024, RAGRAPH_EUNSUPPORTED, "topk_cosine: shard rows must fit int32");
   RG_REQUIRE(aligned16(Q) && aligned16(Kn) && aligned16(ws), RAGRAPH_EINVAL, "topk_cosine: Q, Kn, ws must be 16-B aligned");
   TopkPlan pl = plan_topk(B, N, D, k);
