@@ -53,8 +53,9 @@ int ragraph_device_check(void);
 /* ------------------------------------------------------------------------------------------------------------
  * a1  F.normalize(x, p=2, dim=-1, eps=1e-12)   -- RAGraph_node/ragraph_utils/SimilarityFunctions.py:8,11
  *     out[r,:] = X[r,:] / max(||X[r,:]||_2, 1e-12).  In-place (out == X) allowed.  Any D >= 1.
- *     Norm tree: lane l of 64 accumulates x[l]^2, x[l+64]^2, ... with fmaf (ascending), then the 64 partials are
- *     combined by a butterfly: p[l] += p[l^32]; ^16; ^8; ^4; ^2; ^1.  sqrtf and the division are correctly rounded.
+ *     Norm tree: "lane" l of 64 takes the float4 chunks c = l, l+64, ... of the row and accumulates the squares of
+ *     elements 4c..4c+3 (ascending) with fmaf; the 64 partials are combined by the butterfly p[l] += p[l^32]; ^16; ^8;
+ *     ^4; ^2; ^1.  sqrtf and the division are correctly rounded.
  */
 int ragraph_normalize_rows_f32(const float* X, int64_t n, int D, float* out, void* stream);
 

@@ -17,6 +17,8 @@
 //     resident query tiles; the kernel is MFMA-bound (arithmetic intensity = 128 flop/B), see DESIGN.md.
 //   * every score is one fmaf chain in natural k order (MFMA 32x32x2 semantics), so results do not depend on the
 //     split count, the query batch size, or how the bank is sharded across GPUs.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace ragraph {
@@ -92,6 +94,8 @@ struct TopkParams {
   int64_t keys_per_split;  // multiple of the stage size
   float* part_s;           // [B][nsplit][k]
   int* part_i;
+  int ablate;              // DIAGNOSTIC ONLY (env RAGRAPH_TOPK_ABLATE, results invalid when non-zero): bit0 skip the
+                           // top-k epilogue, bit1 skip global loads + LDS writes, bit2 skip the stage barrier
 };
 
 template <int D>
@@ -105,7 +109,7 @@ struct TopkCfg {
   static constexpr int STAGE_FLOATS = STAGE_KEYS * ROW;
   static constexpr int CHUNKS = STAGE_KEYS * (D / 4);   // float4 chunks per stage = 2048
   static constexpr int LOADS = CHUNKS / THREADS;        // float4 loads per thread per stage = 4
-  static size_t lds_bytes(int k) { return sizeof(float) * (2 * STAGE_FLOATS + QT) + (size_t)k * QT * 8; }
+  static size_t lds_bytes(int k) { return sizeof(float) * (2 * STAGE_FLOATS) + (size_t)k * QT * 8; }
 };
 
 template <int D>
@@ -114,9 +118,7 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
   // ONE __shared__ object; everything below is an offset from it so every access stays a ds_* instruction.
   extern __shared__ float4 smem4[];
   float* smem = reinterpret_cast<float*>(smem4);
-  constexpr int OFF_THR = 2 * C::STAGE_FLOATS;  // [QT]
-  constexpr int OFF_LS = OFF_THR + C::QT;       // [k][QT] scores, then [k][QT] indices
-  float* thr_q = smem + OFF_THR;
+  constexpr int OFF_LS = 2 * C::STAGE_FLOATS;   // [QT][k] scores, then [QT][k] indices: one SORTED list per query
   float* ls = smem + OFF_LS;
   int* li = reinterpret_cast<int*>(smem + OFF_LS + p.k * C::QT);
 
@@ -152,7 +154,6 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
     ls[i] = RG_NEG_INF;
     li[i] = RG_IDX_NONE;
   }
-  for (int i = tid; i < C::QT; i += C::THREADS) thr_q[i] = RG_NEG_INF;
 
   // ---- staging: thread t owns float4 chunks t, t+512, ... of the stage (row = chunk / (D/4)) ----------------
   // The loads are unconditional (the stage index is clamped, the write is skipped) so the four float4 stay in VGPRs.
@@ -172,20 +173,28 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
     pre2 = *reinterpret_cast<const float4*>(p.Kn + r2_ * D + scol);                               \
     pre3 = *reinterpret_cast<const float4*>(p.Kn + r3_ * D + scol);                               \
   } while (0)
+  // LDS image: row = [even k (D/2 floats) | odd k (D/2 floats)] + 16-B pad.  Lane (j,h) of the MFMA then reads the
+  // float4 {k = 2m+h : m = 4c..4c+3} of key j with ONE ds_read_b128 and no select; the de-interleave costs two 8-byte
+  // stores per staged float4 instead of one 16-byte store (store traffic is 1/8 of the read traffic).
+#define RG_ST2(dst_, a_, b_)                                                                      \
+  do { (dst_)[0] = (a_); (dst_)[1] = (b_); } while (0) /* two dwords -> ds_write2_b32, no register shuffling */
 #define RG_STAGE_WRITE(buf_)                                                                      \
   do {                                                                                            \
-    float* d_ = smem + (buf_) * C::STAGE_FLOATS + srow * C::ROW + scol;                           \
-    *reinterpret_cast<float4*>(d_) = pre0;                                                        \
-    *reinterpret_cast<float4*>(d_ + SROWS * C::ROW) = pre1;                                       \
-    *reinterpret_cast<float4*>(d_ + 2 * SROWS * C::ROW) = pre2;                                   \
-    *reinterpret_cast<float4*>(d_ + 3 * SROWS * C::ROW) = pre3;                                   \
+    float* d_ = smem + (buf_) * C::STAGE_FLOATS + srow * C::ROW + (scol >> 1);                    \
+    RG_ST2(d_, pre0.x, pre0.z);                                                                   \
+    RG_ST2(d_ + D / 2, pre0.y, pre0.w);                                                           \
+    RG_ST2(d_ + SROWS * C::ROW, pre1.x, pre1.z);                                                  \
+    RG_ST2(d_ + SROWS * C::ROW + D / 2, pre1.y, pre1.w);                                          \
+    RG_ST2(d_ + 2 * SROWS * C::ROW, pre2.x, pre2.z);                                              \
+    RG_ST2(d_ + 2 * SROWS * C::ROW + D / 2, pre2.y, pre2.w);                                      \
+    RG_ST2(d_ + 3 * SROWS * C::ROW, pre3.x, pre3.z);                                              \
+    RG_ST2(d_ + 3 * SROWS * C::ROW + D / 2, pre3.y, pre3.w);                                      \
   } while (0)
 
   RG_STAGE_LOAD(0);
   RG_STAGE_WRITE(0);
   __syncthreads();
 
-  const int ql = wave * 32 + j;  // query slot inside the workgroup
   float thr = RG_NEG_INF;
 
   for (int s = 0; s < nstages; ++s) {
@@ -199,23 +208,28 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const float* arow = smem + cur + (t * 32 + j) * C::ROW;
+      const float* arow = smem + cur + (t * 32 + j) * C::ROW + h * (D / 2);
 #pragma unroll
-      for (int c = 0; c < D / 4; ++c) {
-        const float4 v = *reinterpret_cast<const float4*>(arow + 4 * c);
-        const float a0 = h ? v.y : v.x;  // key[j][4c + h]
-        const float a1 = h ? v.w : v.z;  // key[j][4c + 2 + h]
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, breg[2 * c], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, breg[2 * c + 1], acc, 0, 0, 0);
+      for (int c = 0; c < D / 8; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(arow + 4 * c);  // key[j][2m+h], m = 4c..4c+3
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, breg[4 * c], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, breg[4 * c + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, breg[4 * c + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, breg[4 * c + 3], acc, 0, 0, 0);
       }
 
       // ---- epilogue: acc[r] = score(key row (r&3) + 8*(r>>2) + 4*h of the tile, query j) ------------------
       float m = acc[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+      if (p.ablate & 1) {
+        asm volatile("" ::"v"(m));
+        m = RG_NEG_INF;
+      }
       if (__any(m >= thr)) {
-        // rare path (~k ln(n/k) times per query over the stream): offer candidates one per lane per round, lowest
-        // key index first; the two half-waves (same queries) take turns so a list has one writer at a time.
+        // rare path (~k ln(n/k) times per query over the stream).  It must be SHORT: the stage barrier makes the whole
+        // workgroup wait for a wave that is in here.  The wave inserts its candidates one at a time with all 64 lanes
+        // cooperating on each insert (sorted list: one ballot for the position, one shuffle for the shift).
         const int key_base = (int)(n_begin + (int64_t)s * C::STAGE_KEYS + t * 32) + 4 * h;
         unsigned mask = 0;
 #pragma unroll
@@ -223,34 +237,42 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
           const int idx = key_base + (r & 3) + 8 * (r >> 2);
           if (acc[r] >= thr && idx < (int)n_end) mask |= 1u << r;
         }
-        while (__any(mask != 0)) {
-          const int r0 = __ffs(mask) - 1;  // -1 when this lane has nothing left
-          float sc = acc[0];
+        unsigned long long pend = __ballot(mask != 0);
+        while (pend) {
+          const int src = __ffsll((long long)pend) - 1;  // wave-uniform: lowest lane with a candidate
+          const int r0 = __ffs(mask) - 1;                // lowest pending register of THIS lane (used on lane src)
+          float my_sc = acc[0];
 #pragma unroll
-          for (int r = 1; r < 16; ++r) sc = (r0 == r) ? acc[r] : sc;
-          const int idx = key_base + (r0 & 3) + 8 * (r0 >> 2);
-#pragma unroll 1
-          for (int hh = 0; hh < 2; ++hh) {
-            if (mask != 0 && h == hh) list_offer(ls, li, thr_q, ql, k, C::QT, sc, idx);
+          for (int r = 1; r < 16; ++r) my_sc = (r0 == r) ? acc[r] : my_sc;
+          const float sc = __shfl(my_sc, src);
+          const int idx = __shfl(key_base + (r0 & 3) + 8 * (r0 >> 2), src);
+          const int qs = src & 31;
+          const float nthr = list_insert_coop(ls + (wave * 32 + qs) * k, li + (wave * 32 + qs) * k, 0, k, 1, sc, idx,
+                                              lane);
+          if (j == qs) thr = nthr;  // both half-wave lanes of that query
+          if (lane == src) mask &= mask - 1;
+          // drop remaining candidates the tightened threshold already excludes (only lanes of query qs can change)
+          if (j == qs && mask) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if ((mask >> r & 1u) && acc[r] < thr) mask &= ~(1u << r);
           }
-          mask &= mask - 1;
-          thr = thr_q[ql];
-          // candidates that no longer reach the tightened threshold can be dropped without an offer
+          pend = __ballot(mask != 0);
         }
       }
     }
 
-    if (more) RG_STAGE_WRITE((s + 1) & 1);
-    __syncthreads();
-    thr = thr_q[ql];  // the partner half-wave may have tightened it
+    if (more && !(p.ablate & 2)) RG_STAGE_WRITE((s + 1) & 1);
+    if (!(p.ablate & 4)) __syncthreads();
   }
 
 #undef RG_STAGE_LOAD
 #undef RG_STAGE_WRITE
+#undef RG_ST2
 
-  // ---- write this (tile, split)'s unsorted candidates; empty slots stay (-inf, IDX_NONE) --------------------
+  // ---- write this (tile, split)'s sorted candidates; empty slots stay (-inf, IDX_NONE) -----------------------
   for (int i = tid; i < k * C::QT; i += C::THREADS) {
-    const int pos = i / C::QT, q = i % C::QT;
+    const int q = i / k, pos = i % k;
     const int64_t qg = q0 + q;
     if (qg < p.B) {
       const int64_t o = (qg * p.nsplit + split) * k + pos;
@@ -756,6 +778,10 @@ extern "C" int ragraph_topk_cosine_f32(const float* Q, int64_t B, const float* K
   p.keys_per_split = pl.keys_per_split;
   p.part_s = part_s;
   p.part_i = part_i;
+  {
+    const char* ab = getenv("RAGRAPH_TOPK_ABLATE");
+    p.ablate = ab ? atoi(ab) : 0;
+  }
   const int64_t qtiles = cdiv(B, 256);
   if (B <= SMALLB_MAX) {
     rc = D == 256 ? launch_smallb<256>(p, st) : D == 128 ? launch_smallb<128>(p, st) : launch_smallb<64>(p, st);
