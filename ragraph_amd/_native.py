@@ -17,7 +17,7 @@ import torch  # noqa: F401  (must precede the dlopen, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libragraph_hip.so")
+SO_PATH = os.environ.get("RAGRAPH_HIP_SO", os.path.join(CSRC, "libragraph_hip.so"))  # override: A/B builds
 
 OK, EINVAL, EUNSUPPORTED, EWORKSPACE, EDEVICE = 0, -1, -2, -3, -4
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LEAKY, ACT_ELU = 0, 1, 2, 3, 4
