@@ -74,7 +74,7 @@ class EventTimer:
         return sum(a.elapsed_time(b) for a, b in self.events) / max(len(self.events), 1)
 
 
-def build_workload(args, dev, rank, world):
+def build_workload(args, dev, rank, world, force_dist=False):
     from ragraph_amd import kernels as K
     from ragraph_amd.data import synthetic_bank, synthetic_big_graph
     from ragraph_amd.graph import CSRGraph
@@ -92,10 +92,10 @@ def build_workload(args, dev, rank, world):
     feats = torch.randn(args.nodes, args.feat, device=dev, generator=torch.Generator(device=dev).manual_seed(4321))
     Kb, Vb, Lb = synthetic_bank(args.bank, args.dim, args.classes, device=dev)
     Kb = K.normalize_rows(Kb)  # stored unit-norm, as the reference stores keys (ToyGraphBase.py:109)
-    if world > 1:
+    if world > 1 or force_dist:
         lo, hi = shard_bounds(args.bank, world, rank)
         model.toy_graph_base = ShardedToyGraphBase(Kb[lo:hi].contiguous(), Vb[lo:hi].contiguous(),
-                                                   Lb[lo:hi].contiguous(), lo, args.k)
+                                                   Lb[lo:hi].contiguous(), lo, args.k, force_collectives=force_dist)
         del Kb, Vb, Lb
         n_local = hi - lo
     else:
@@ -192,14 +192,16 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in ragraph_amd)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_dist = os.environ.get("RAGRAPH_FORCE_DIST") == "1"  # 1-rank RCCL group: exercises the sharded path on one GPU
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from ragraph_amd import kernels as K
 
     topk_timer = EventTimer(K, "topk_cosine")
-    model, feats, adj, n_local = build_workload(args, dev, rank, world)
+    model, feats, adj, n_local = build_workload(args, dev, rank, world, force_dist)
 
     def step():
         with torch.no_grad():
@@ -264,7 +266,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(args, model, feats, adj)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -91,6 +91,8 @@ struct TopkParams {
   int64_t B, N;
   int k;
   int nsplit;
+  int64_t qtiles;          // query tiles of 256 (big kernel)
+  int xcd_map;             // 1: XCD-aware block mapping (enough query tiles to give every XCD its own)
   int64_t keys_per_split;  // multiple of the stage size
   float* part_s;           // [B][nsplit][k]
   int* part_i;
@@ -127,10 +129,35 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
   const int j = lane & 31, h = lane >> 5;
   const int k = p.k;
 
-  // block -> (query tile, key split); consecutive blocks differ in split, so the blocks that share an XCD
-  // (blockIdx % 8 equal) stream the same key range while they are co-resident (speed only).
-  const int split = blockIdx.x % p.nsplit;
-  const int64_t qtile = blockIdx.x / p.nsplit;
+  // block -> (query tile, key split), XCD-aware.  Blocks are dealt round-robin over the 8 XCDs (b % 8 labels the blocks
+  // that share an XCD and its 4 MiB L2) and an XCD runs 32 of them at a time.  XCD x owns query tiles x, x+8, ...; its
+  // blocks walk them in groups of 32 tiles, split-major inside a group, so the 32 co-resident workgroups of an XCD
+  // stream the SAME key range and 31 of 32 key fetches hit that L2.  Placement only affects speed; the padded grid's
+  // surplus blocks exit here.
+  int split;
+  int64_t qtile;
+  if (!p.xcd_map) {  // few query tiles: spread every (tile, split) over all XCDs; co-resident blocks share via MALL
+    split = blockIdx.x % p.nsplit;
+    qtile = blockIdx.x / p.nsplit;
+  } else {
+    const int x = blockIdx.x & 7;
+    const int64_t i = blockIdx.x >> 3;
+    const int64_t nq = (p.qtiles - x + 7) >> 3;  // query tiles owned by this XCD
+    constexpr int GQ = 32;
+    if (i >= nq * p.nsplit) return;
+    const int64_t full = nq / GQ, per_group = (int64_t)GQ * p.nsplit;
+    int64_t ql;
+    if (i < full * per_group) {
+      const int64_t r = i % per_group;
+      split = (int)(r / GQ);
+      ql = (i / per_group) * GQ + r % GQ;
+    } else {
+      const int64_t r = i - full * per_group, rem = nq - full * GQ;
+      split = (int)(r / rem);
+      ql = full * GQ + r % rem;
+    }
+    qtile = x + 8 * ql;
+  }
   const int64_t q0 = qtile * C::QT;
   const int64_t n_begin = (int64_t)split * p.keys_per_split;
   const int64_t n_end = min(p.N, n_begin + p.keys_per_split);
@@ -708,7 +735,8 @@ static int launch_topk(const TopkParams& p, int64_t qtiles, hipStream_t st) {
     }
     attr_set = true;
   }
-  const int64_t grid = qtiles * p.nsplit;
+  // XCD-aware mapping: grid padded so every XCD has a block for each of its items
+  const int64_t grid = p.xcd_map ? 8 * (cdiv(qtiles, 8) * p.nsplit) : qtiles * p.nsplit;
   hipLaunchKernelGGL(topk_stream_kernel<D>, dim3((unsigned)grid), dim3(C::THREADS), lds, st, p);
   RG_CHECK_LAUNCH("topk_cosine");
   return RAGRAPH_OK;
@@ -777,6 +805,8 @@ extern "C" int ragraph_topk_cosine_f32(const float* Q, int64_t B, const float* K
   p.N = N;
   p.k = k;
   p.nsplit = pl.nsplit;
+  p.qtiles = cdiv(B, 256);
+  p.xcd_map = p.qtiles >= 64 ? 1 : 0;
   p.keys_per_split = pl.keys_per_split;
   p.part_s = part_s;
   p.part_i = part_i;

@@ -28,7 +28,8 @@ class ShardedToyGraphBase:
     """Retrieval over a row-sharded bank.  `ops` supplies the five kernels (default: ragraph_amd.kernels, i.e. the HIP
     library); the CPU tests inject an oracle-backed object to exercise the collective logic under gloo."""
 
-    def __init__(self, keys, values, labels, idx_base: int, retrieve_num: int, group=None, ops=None):
+    def __init__(self, keys, values, labels, idx_base: int, retrieve_num: int, group=None, ops=None,
+                 force_collectives: bool = False):
         if ops is None:
             from . import kernels as ops  # the HIP library; raises loudly without a GPU
         self.ops = ops
@@ -36,6 +37,8 @@ class ShardedToyGraphBase:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.idx_base = int(idx_base)
+        # run the collectives even in a 1-rank group (exercises the RCCL path on a single-GPU box)
+        self.collective = self.world > 1 or (force_collectives and dist.is_initialized())
         self.retrieve_num = retrieve_num
         self.resource_keys, self.resource_values, self.resource_labels = keys, values, labels
         self.keys_normalized = ops.normalize_rows(keys)
@@ -51,7 +54,7 @@ class ShardedToyGraphBase:
             pad_s = torch.full((q.shape[0], k - kl), float("-inf"), dtype=s.dtype, device=s.device)
             pad_i = torch.full((q.shape[0], k - kl), torch.iinfo(torch.int64).max, dtype=i.dtype, device=i.device)
             s, i = torch.cat([s, pad_s], 1), torch.cat([i, pad_i], 1)
-        if self.world == 1:
+        if not self.collective:
             return s, i
         B = s.shape[0]
         gs = torch.empty((self.world * B, k), dtype=s.dtype, device=s.device)   # rank-major concatenation
@@ -66,7 +69,7 @@ class ShardedToyGraphBase:
         _, idx = self.topk(search_keys, k)
         sum_v, _ = self.ops.gather_reduce(self.resource_values, None, idx, idx_base=self.idx_base)
         sum_l, _ = self.ops.gather_reduce(self.resource_labels, None, idx, idx_base=self.idx_base)
-        if self.world > 1:
+        if self.collective:
             packed = torch.cat([sum_v, sum_l], dim=1)
             dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
             sum_v, sum_l = packed[:, :sum_v.shape[1]].contiguous(), packed[:, sum_v.shape[1]:].contiguous()
@@ -77,7 +80,7 @@ class ShardedToyGraphBase:
         _, idx = self.topk(search_keys, self.retrieve_num)
         e = self.ops.gather_rows(self.resource_values, idx, idx_base=self.idx_base)
         l = self.ops.gather_rows(self.resource_labels, idx, idx_base=self.idx_base)
-        if self.world > 1:
+        if self.collective:
             dist.all_reduce(e, op=dist.ReduceOp.SUM, group=self.group)
             dist.all_reduce(l, op=dist.ReduceOp.SUM, group=self.group)
         return e, l
