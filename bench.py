@@ -228,6 +228,14 @@ def main():
     assert torch.isfinite(out).all()
 
     n = args.nodes
+    traffic = None  # HBM-side GB per launch from the committed PMC run of this exact shape (cannot be sampled in-process)
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        key = f"topk_stream_kernel<{args.dim}> B={n} N={n_local} D={args.dim} k={args.k}"
+        if key in prof:
+            traffic = prof[key]["hbm_side_GB"]
+    except (OSError, ValueError):
+        pass
     ms_step = elapsed / args.steps * 1e3
     topk_ms = topk_timer.mean_ms()
     flops = 2.0 * n * n_local * args.dim
@@ -253,7 +261,9 @@ def main():
                    f"bank row-sharded x{world}, RCCL all_gather of per-shard top-k + all_reduce of owned sums"},
         "roofline": {"kernel": "ragraph::topk_stream_kernel<256> (fused cosine+top-k, v_mfma_f32_32x32x2_f32)",
                      "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                     "traffic_unit": "GB per launch, HBM side = (2*FETCH_SIZE + WRITE_SIZE) from rocprofv3 --pmc, "
+                                     "profiles/r1_pmc_traffic.json",
                      "launch_ms": round(topk_ms, 3),
                      "note": "algorithmic flops 2*B*N*D per launch / mean launch time from events on the launch "
                              "stream (includes the <0.1 % query-normalise and select kernels of the same ABI call)"},
