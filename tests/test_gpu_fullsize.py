@@ -1,0 +1,114 @@
+"""Parity at BASELINE.json's full sizes (1M x 256 bank, k=10; 4M x 64 edge bank), where the CPU oracle can only
+afford a sample: (a) the oracle on a random subset of the queries, bit-exact; (b) size-independent properties of the
+whole result -- query-batch independence (a score is one fmaf chain, so B, the tile/split plan and the kernel variant
+must not change any bit), shard-merge invariance (2 / 3 / 8 row shards merged == the single-shard result),
+descending canonical order, indices unique and in range, idempotence."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bank1m(dev):
+    from ragraph_amd import kernels as K
+
+    g = torch.Generator(device=dev).manual_seed(1234)
+    kn = K.normalize_rows(torch.randn(1_000_000, 256, device=dev, generator=g))
+    q = torch.randn(4096, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(4321))
+    return kn, q
+
+
+def test_full_bank_oracle_sample_and_properties(dev, bank1m):
+    from ragraph_amd import kernels as K
+
+    kn, q = bank1m
+    k = 10
+    s, i = K.topk_cosine(q, kn, k)
+    # (a) oracle on 48 sampled queries against the whole 1M-key bank
+    sel = torch.randperm(q.shape[0], generator=torch.Generator().manual_seed(0))[:48]
+    rs, ri = cref.topk_cosine(q[sel.to(dev)].cpu().numpy(), kn.cpu().numpy(), k)
+    assert np.array_equal(i[sel.to(dev)].cpu().numpy(), ri)
+    assert np.array_equal(s[sel.to(dev)].cpu().numpy(), rs)
+    # (b) properties of the full result
+    assert bool((s[:, :-1] >= s[:, 1:]).all())
+    assert int(i.min()) >= 0 and int(i.max()) < kn.shape[0]
+    srt = torch.sort(i, dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())
+    s2, i2 = K.topk_cosine(q, kn, k)
+    assert torch.equal(s, s2) and torch.equal(i, i2)  # idempotent / deterministic (no atomics anywhere)
+    # query-batch independence across kernel variants and split plans: B = 1, 7, 16 (small-batch kernel), 17, 300, 1000
+    for lo, B in [(5, 1), (100, 7), (32, 16), (64, 17), (1000, 300), (2000, 1000)]:
+        sb, ib = K.topk_cosine(q[lo:lo + B].contiguous(), kn, k)
+        assert torch.equal(ib, i[lo:lo + B]) and torch.equal(sb, s[lo:lo + B]), f"B={B} differs from the 4096 batch"
+    # smaller k is a prefix of larger k
+    s5, i5 = K.topk_cosine(q[:512].contiguous(), kn, 5)
+    assert torch.equal(i5, i[:512, :5]) and torch.equal(s5, s[:512, :5])
+
+
+@pytest.mark.parametrize("G", [2, 3, 8])
+def test_full_bank_shard_merge_invariance(dev, bank1m, G):
+    from ragraph_amd import kernels as K
+    from ragraph_amd.sharded import shard_bounds
+
+    kn, q = bank1m
+    qq = q[:1024].contiguous()
+    full_s, full_i = K.topk_cosine(qq, kn, 10)
+    ss, ii = [], []
+    for r in range(G):
+        lo, hi = shard_bounds(kn.shape[0], G, r)
+        s, i = K.topk_cosine(qq, kn[lo:hi], 10, idx_base=lo)
+        ss.append(s)
+        ii.append(i)
+    ms, mi = K.topk_merge(torch.stack(ss), torch.stack(ii))
+    assert torch.equal(mi, full_i) and torch.equal(ms, full_s)
+
+
+def test_edge_bank_4m_x64(dev):
+    """Config 5 shape: 4M x 64 bank, slabs of 4096 queries (RAGraph_edge/modules/RAGraph.py:45,298)."""
+    from ragraph_amd import kernels as K
+
+    g = torch.Generator(device=dev).manual_seed(7)
+    kn = K.normalize_rows(torch.randn(4_000_000, 64, device=dev, generator=g))
+    q = torch.randn(4096, 64, device=dev, generator=g)
+    s, i = K.topk_cosine(q, kn, 10)
+    sel = slice(100, 132)
+    rs, ri = cref.topk_cosine(q[sel].cpu().numpy(), kn.cpu().numpy(), 10)
+    assert np.array_equal(i[sel].cpu().numpy(), ri) and np.array_equal(s[sel].cpu().numpy(), rs)
+    s1, i1 = K.topk_cosine(q[7:8].contiguous(), kn, 10)  # small-batch kernel, D=64
+    assert torch.equal(i1, i[7:8]) and torch.equal(s1, s[7:8])
+    v = torch.randn(4_000_000, 64, device=dev, generator=g)
+    mean_v, _ = K.gather_reduce(v, None, i, v_scale=0.1)
+    ref, _ = cref.gather_reduce(v.cpu().numpy(), None, i[:64].cpu().numpy(), v_scale=0.1)
+    assert np.array_equal(mean_v[:64].cpu().numpy(), ref)
+
+
+def test_gnn_100k_nodes_matches_oracle(dev):
+    """Config-2 graph (100k nodes, ~1.1M non-zeros, D=256): GCN layer + 3-hop propagation, bit-exact vs the oracle."""
+    from oracle import pipeline
+    from ragraph_amd.data import synthetic_big_graph
+    from ragraph_amd.graph import CSRGraph
+    from ragraph_amd.preprompt import PrePrompt
+    from ragraph_amd.ragraph_utils import Propagation
+
+    n, F = 100_000, 128
+    torch.manual_seed(0)
+    adj = CSRGraph.from_edge_index_sym_normalized(synthetic_big_graph(n, 10, seed=8, device=dev), n)
+    X = torch.randn(n, F, device=dev)
+    pre = PrePrompt(F, 256, "prelu", 1, 0.3).to(dev)
+    with torch.no_grad():
+        pre.gcn.convs[0].bias.normal_(0, 0.1)
+        h = pre.inference(X, adj)
+        y = Propagation.aggregate_k_hop_features(adj, h, 3)
+    conv = pre.gcn.convs[0]
+    csr = (adj.rowptr.cpu().numpy(), adj.col.cpu().numpy(), adj.val.cpu().numpy())
+    oh = pipeline.gcn_layer(X.cpu().numpy(), csr, conv.fc.weight.detach().cpu().numpy(),
+                            conv.bias.detach().cpu().numpy(), float(conv.act.weight))
+    assert np.array_equal(h.cpu().numpy(), oh)
+    assert np.array_equal(y.cpu().numpy(), pipeline.propagate(csr, oh, 3))
+    # row-stochastic propagation of a constant stays constant (size-independent sanity property)
+    ones = torch.ones(n, 256, device=dev)
+    assert torch.allclose(Propagation.aggregate_k_hop_features(adj, ones, 2), ones, atol=1e-5)
