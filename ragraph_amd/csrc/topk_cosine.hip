@@ -111,18 +111,32 @@ struct TopkCfg {
   static constexpr int STAGE_FLOATS = STAGE_KEYS * ROW;
   static constexpr int CHUNKS = STAGE_KEYS * (D / 4);   // float4 chunks per stage = 2048
   static constexpr int LOADS = CHUNKS / THREADS;        // float4 loads per thread per stage = 4
-  static size_t lds_bytes(int k) { return sizeof(float) * (2 * STAGE_FLOATS) + (size_t)k * QT * 8; }
+  // RING = 2: double buffer + one workgroup barrier per stage.  RING = 3: three slots handed over through FULL / FREE
+  // counters in LDS, no barrier: a wave may run up to one stage ahead of or behind the others, so a wave that is busy
+  // inserting candidates does not stall the other seven (the barrier made every stage as slow as its slowest wave).
+  static size_t lds_bytes(int k, int ring) {
+    return sizeof(float) * ((size_t)ring * STAGE_FLOATS) + (size_t)k * QT * 8 + (ring == 3 ? 32 : 0);
+  }
 };
 
-template <int D>
+__device__ __forceinline__ void ring_wait(unsigned* ctr, unsigned target) {  // wave-uniform spin on an LDS counter
+  while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void ring_signal(unsigned* ctr, int lane) {  // after this wave's LDS accesses are complete
+  if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int D, int RING>
 __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
   using C = TopkCfg<D>;
   // ONE __shared__ object; everything below is an offset from it so every access stays a ds_* instruction.
   extern __shared__ float4 smem4[];
   float* smem = reinterpret_cast<float*>(smem4);
-  constexpr int OFF_LS = 2 * C::STAGE_FLOATS;   // [QT][k] scores, then [QT][k] indices: one SORTED list per query
+  constexpr int OFF_LS = RING * C::STAGE_FLOATS;  // [QT][k] scores, then [QT][k] indices: one SORTED list per query
   float* ls = smem + OFF_LS;
   int* li = reinterpret_cast<int*>(smem + OFF_LS + p.k * C::QT);
+  unsigned* full = reinterpret_cast<unsigned*>(smem + OFF_LS + 2 * p.k * C::QT);  // [3] wave-writes per slot (RING 3)
+  unsigned* freec = full + 4;                                                       // [3] wave-reads-done per slot
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -218,18 +232,10 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
     RG_ST2(d_ + 3 * SROWS * C::ROW + D / 2, pre3.y, pre3.w);                                      \
   } while (0)
 
-  RG_STAGE_LOAD(0);
-  RG_STAGE_WRITE(0);
-  __syncthreads();
-
   float thr = RG_NEG_INF;
 
-  for (int s = 0; s < nstages; ++s) {
-    const bool more = (s + 1 < nstages);
-    RG_STAGE_LOAD(more ? s + 1 : s);  // in flight under this stage's MFMAs
-    __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks the loads below the MFMA block (to save VGPRs)
-    const int cur = (s & 1) * C::STAGE_FLOATS;
-
+  // one stage of MFMAs + top-k epilogue for this wave's 32 queries
+  auto compute_stage = [&](int s, int cur) {
 #pragma unroll 1
     for (int t = 0; t < C::TILES; ++t) {
       f32x16 acc;
@@ -254,9 +260,8 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
         m = RG_NEG_INF;
       }
       if (__any(m >= thr)) {
-        // rare path (~k ln(n/k) times per query over the stream).  It must be SHORT: the stage barrier makes the whole
-        // workgroup wait for a wave that is in here.  The wave inserts its candidates one at a time with all 64 lanes
-        // cooperating on each insert (sorted list: one ballot for the position, one shuffle for the shift).
+        // rare path (~k ln(n/k) times per query over the stream): the wave inserts its candidates one at a time with
+        // all 64 lanes cooperating on each insert (sorted list: one ballot for the position, one shuffle for the shift).
         const int key_base = (int)(n_begin + (int64_t)s * C::STAGE_KEYS + t * 32) + 4 * h;
         unsigned mask = 0;
 #pragma unroll
@@ -288,9 +293,51 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
         }
       }
     }
+  };
 
-    if (more && !(p.ablate & 2)) RG_STAGE_WRITE((s + 1) & 1);
-    if (!(p.ablate & 4)) __syncthreads();
+  if constexpr (RING == 2) {
+    RG_STAGE_LOAD(0);
+    RG_STAGE_WRITE(0);
+    __syncthreads();
+    for (int s = 0; s < nstages; ++s) {
+      const bool more = (s + 1 < nstages);
+      RG_STAGE_LOAD(more ? s + 1 : s);  // in flight under this stage's MFMAs
+      __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks the loads below the MFMA block (to save VGPRs)
+      compute_stage(s, (s & 1) * C::STAGE_FLOATS);
+      if (more && !(p.ablate & 2)) RG_STAGE_WRITE((s + 1) & 1);
+      if (!(p.ablate & 4)) __syncthreads();
+    }
+  } else {
+    // slots 0 and 1 are filled up front; afterwards stage s+2 is loaded during stage s and written behind it
+    if (tid < 8) full[tid] = 0;
+    RG_STAGE_LOAD(0);
+    RG_STAGE_WRITE(0);
+    if (nstages > 1) {
+      RG_STAGE_LOAD(1);
+      RG_STAGE_WRITE(1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      full[0] = C::WAVES;
+      full[1] = C::WAVES;
+    }
+    __syncthreads();
+    for (int s = 0; s < nstages; ++s) {
+      const int slot = s % 3, gen = s / 3;
+      const bool ahead = (s + 2 < nstages);
+      RG_STAGE_LOAD(ahead ? s + 2 : s);  // two stages ahead, in flight under this stage's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      ring_wait(full + slot, (unsigned)(C::WAVES * (gen + 1)));      // all 8 waves have written stage s
+      compute_stage(s, slot * C::STAGE_FLOATS);
+      ring_signal(freec + slot, lane);                               // this wave is done reading stage s
+      if (ahead) {
+        const int ws = (s + 2) % 3;                                  // the slot stage s-1 lived in
+        ring_wait(freec + ws, (unsigned)(C::WAVES * ((s + 2) / 3))); // all 8 waves are done reading stage s-1
+        RG_STAGE_WRITE(ws);
+        ring_signal(full + ws, lane);
+      }
+    }
+    __syncthreads();
   }
 
 #undef RG_STAGE_LOAD
@@ -703,9 +750,9 @@ static TopkPlan plan_topk(int64_t B, int64_t N, int D, int k) {
     if (real != s) continue;
     const int64_t wgs = qtiles * s;
     const double rounds = (double)cdiv(wgs, CUS);
-    // measured on MI355X (k=10, D=256): insert-path + barrier coupling cost ~12.5k/n of a stream of n keys
-    // (19 % at n = 62.5k, 3 % at n = 500k); it scales with the number of candidates, i.e. with k.
-    const double warm = 1.0 + 1250.0 * (double)k / (double)per;
+    // measured on MI355X (k=10, D=256, barrier-free ring): the insert path costs ~7k/n of a stream of n keys
+    // (11 % at n = 62.5k, ~0 at n = 500k); it scales with the number of candidates, i.e. with k.
+    const double warm = 1.0 + 700.0 * (double)k / (double)per;
     const double cost = rounds * (double)per * warm;
     if (cost < best_cost * 0.999) {
       best_cost = cost;
@@ -721,13 +768,13 @@ static TopkPlan plan_topk(int64_t B, int64_t N, int D, int k) {
   return pl;
 }
 
-template <int D>
-static int launch_topk(const TopkParams& p, int64_t qtiles, hipStream_t st) {
+template <int D, int RING>
+static int launch_topk_ring(const TopkParams& p, int64_t qtiles, hipStream_t st) {
   using C = TopkCfg<D>;
-  const size_t lds = C::lds_bytes(p.k);
+  const size_t lds = C::lds_bytes(p.k, RING);
   static bool attr_set = false;  // raising the dynamic-LDS cap is idempotent; racing setters write the same value
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_stream_kernel<D>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_stream_kernel<D, RING>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       set_error("topk_cosine: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
@@ -737,9 +784,19 @@ static int launch_topk(const TopkParams& p, int64_t qtiles, hipStream_t st) {
   }
   // XCD-aware mapping: grid padded so every XCD has a block for each of its items
   const int64_t grid = p.xcd_map ? 8 * (cdiv(qtiles, 8) * p.nsplit) : qtiles * p.nsplit;
-  hipLaunchKernelGGL(topk_stream_kernel<D>, dim3((unsigned)grid), dim3(C::THREADS), lds, st, p);
+  hipLaunchKernelGGL((topk_stream_kernel<D, RING>), dim3((unsigned)grid), dim3(C::THREADS), lds, st, p);
   RG_CHECK_LAUNCH("topk_cosine");
   return RAGRAPH_OK;
+}
+
+template <int D>
+static int launch_topk(const TopkParams& p, int64_t qtiles, hipStream_t st) {
+  // the barrier-free 3-slot ring needs 3 x 33 KB of stages next to the 2 KB * k of lists in the 160 KB LDS
+  const char* ring_env = getenv("RAGRAPH_TOPK_RING");  // diagnostic override: 2 or 3
+  const bool fits3 = TopkCfg<D>::lds_bytes(p.k, 3) <= 160 * 1024;
+  const bool want3 = ring_env ? atoi(ring_env) == 3 : true;
+  if (fits3 && want3 && !(p.ablate & 6)) return launch_topk_ring<D, 3>(p, qtiles, st);
+  return launch_topk_ring<D, 2>(p, qtiles, st);
 }
 
 template <int D>
