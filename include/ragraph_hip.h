@@ -157,6 +157,30 @@ int ragraph_segment_reduce_f32(const float* X, int D, const int64_t* seg_ptr, in
 int ragraph_proto_cosine_f32(const float* emb, int64_t G, int D, const float* proto, int C, int mode, float* out,
                              void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * torch.topk(scores, k) over a MATERIALISED score matrix (canonical order, agrees with the fused kernel on equal
+ * scores) -- few-shot retrieve after mixing structure and semantic similarities
+ * (RAGraph_node_fewshot/ragraph_utils/ToyGraphBase.py:58-64) and the evaluation's top-20 of user x item ratings
+ * (RAGraph_edge/utils/metrics.py:116).  S [B, ld] row-major with N <= ld valid columns; k <= min(N, 64).
+ * out_scores [B,k], out_idx [B,k] int64. */
+int ragraph_topk_rows_f32(const float* S, int64_t B, int64_t N, int64_t ld, int k, float* out_scores,
+                          int64_t* out_idx, void* stream);
+
+/* batch_pred[i, pos_list] = value  -- RAGraph_edge/utils/metrics.py:210-214 (_mask_history_pos, value = -1e8).
+ * CSR (rowptr [B+1], col [nnz], both int64) lists the columns to overwrite in each row of S [B, ld]. */
+int ragraph_scatter_fill_f32(float* S, int64_t B, int64_t N, int64_t ld, const int64_t* rowptr, const int64_t* col,
+                             float value, void* stream);
+
+/* All-pairs shortest paths -- ragraph_utils/PositionAwareEncoder.py:27-48: dist = adj with 0 -> inf, diagonal 0, then
+ * n min-plus steps.  adj, dist dense [n,n] fp32 (dist may not alias adj).  n launches of an O(n^2) step: meant for the
+ * query graphs of the few-shot flavour (n ~ 30-600), not for the 100k-node graph. */
+int ragraph_floyd_warshall_f32(const float* adj, int n, float* dist, void* stream);
+
+/* PositionAwareEncoder.py:6-24: out[u,a] = 1/(dist[u, anchors[a]] + 1) if that distance < dis_q else 0.
+ * anchors [A] int64 (drawn by the caller: the reference uses torch.randint), out [n,A]. */
+int ragraph_position_code_f32(const float* dist, int n, const int64_t* anchors, int A, float dis_q, float* out,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -215,3 +215,28 @@ def coo_to_csr_by_dst(src, dst, n):
     np.add.at(rowptr, dst + 1, 1)
     rowptr = np.cumsum(rowptr)
     return rowptr, src[perm].astype(np.int32), perm
+
+
+def topk_rows(S, k):
+    S = _f32(S)
+    B, N = S.shape
+    s = np.empty((B, k), dtype=np.float32)
+    i = np.empty((B, k), dtype=np.int64)
+    lib().oracle_topk_rows(_p(S), _c64(B), _c64(N), _c64(N), _ci(k), _p(s), _p(i))
+    return s, i
+
+
+def floyd_warshall(adj):
+    adj = _f32(adj)
+    n = adj.shape[0]
+    d = np.empty_like(adj)
+    lib().oracle_floyd_warshall(_p(adj), _ci(n), _p(d))
+    return d
+
+
+def position_code(dist, anchors, dis_q=10.0):
+    dist, anchors = _f32(dist), _i64(anchors)
+    n, A = dist.shape[0], anchors.shape[0]
+    out = np.empty((n, A), dtype=np.float32)
+    lib().oracle_position_code(_p(dist), _ci(n), _p(anchors), _ci(A), _cf(dis_q), _p(out))
+    return out

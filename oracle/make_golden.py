@@ -389,6 +389,41 @@ def g9_edge():
              item_out=item_out)
 
 
+def g8_fewshot_retrieve():
+    """Few-shot node flavour: structural + semantic similarity, top-k (RAGraph_node_fewshot/ragraph_utils/ToyGraphBase.py
+    :47-79) and the position-aware codes (PositionAwareEncoder.py).  torch.manual_seed fixes the randint anchors."""
+    with ref_project("RAGraph_node_fewshot"):
+        from ragraph_utils.PositionAwareEncoder import PositionAwareEncoder
+        from ragraph_utils.ToyGraphBase import ToyGraphBase
+
+        D, C, n, N = 256, 3, 60, 1500
+        tgb = ToyGraphBase(None, C, D, 3, 5)
+        tgb.resource_values = torch.randn(N, D, generator=gen(82))
+        tgb.resource_labels = torch.nn.functional.one_hot(torch.randint(0, C, (N,), generator=gen(83)), C).float()
+        tgb.resource_positions = torch.rand(N, tgb.num_anchors, generator=gen(84)) * (torch.rand(N, tgb.num_anchors, generator=gen(85)) > 0.4)
+        adj = random_graph_adj(n, 3.0, seed=11)
+        q = torch.randn(n, D, generator=gen(86))
+        torch.manual_seed(1234)
+        anchors = torch.randint(low=0, high=n, size=(tgb.num_anchors,))
+        torch.manual_seed(1234)
+        pos = PositionAwareEncoder.encode_position_aware_code(adj, tgb.num_anchors, tgb.dis_q)
+        dist = PositionAwareEncoder.floyd_warshall(adj)
+        from ragraph_utils.SimilarityFunctions import SimilarityFunctions as SF
+        for bank_seed in range(81, 2081, 100):  # first key-bank seed whose mixed top-6 scores are > 1e-5 apart
+            tgb.resource_keys = unit_bank(N, D, bank_seed)
+            S = 0.001 * SF.calculate_cosine_similarity(pos, tgb.resource_positions) \
+                + 0.999 * SF.calculate_cosine_similarity(q, tgb.resource_keys)
+            if min_topk_gap(S, 5) > 1e-5:
+                break
+        else:
+            raise AssertionError("no tie-free bank seed found")
+        torch.manual_seed(1234)
+        rag_e, rag_l = tgb.retrieve(q, adj, False)
+        save("g8_fewshot_retrieve", adj=adj, Q=q, keys=tgb.resource_keys, values=tgb.resource_values,
+             labels=tgb.resource_labels, positions=tgb.resource_positions, anchors=anchors, dist=dist, pos_codes=pos,
+             k=np.int64(5), topk_idx=torch.topk(S, 5).indices, rag_embeddings=rag_e, rag_labels=rag_l)
+
+
 def main():
     assert os.path.isdir(REF), "the reference is only mounted in the build container"
     _install_shims()
@@ -399,6 +434,7 @@ def main():
     g2_g7_graph()
     g10_downprompt()
     g9_edge()
+    g8_fewshot_retrieve()
 
 
 if __name__ == "__main__":

@@ -106,3 +106,27 @@ def downprompt_logits(h, w, graph_len, proto, log_softmax=True):
     seg = np.concatenate([[0], np.cumsum(np.asarray(graph_len))]).astype(np.int64)
     emb = cref.segment_reduce(h, seg, w=np.asarray(w, dtype=np.float32).reshape(-1))
     return cref.proto_cosine(emb, proto, mode=2 if log_softmax else 0), emb
+
+
+def fewshot_scores(search_keys, adj_dense, anchors, keys, positions, structure_weight=0.001, semantic_weight=0.999,
+                   dis_q=10.0):
+    """RAGraph_node_fewshot/ragraph_utils/ToyGraphBase.py:47-61: w_s * cos(position codes) + w_m * cos(embeddings)."""
+    pos = cref.position_code(cref.floyd_warshall(adj_dense), anchors, dis_q)          # PositionAwareEncoder.py:6-24
+    s_struct = cref.linear(cref.normalize_rows(pos), cref.normalize_rows(positions))
+    s_sem = cref.linear(cref.normalize_rows(search_keys), cref.normalize_rows(keys))
+    return cref.axpby(s_struct, structure_weight, s_sem, semantic_weight), pos
+
+
+def fewshot_retrieve(search_keys, adj_dense, anchors, keys, values, labels, positions, k):
+    """ToyGraphBase.py:47-79 without noise."""
+    scores, pos = fewshot_scores(search_keys, adj_dense, anchors, keys, positions)
+    _, idx = cref.topk_rows(scores, int(k))
+    return cref.gather_rows(values, idx), cref.gather_rows(labels, idx), idx, pos
+
+
+def edge_topk_items(user_emb, item_emb, users, hist, k=20):
+    """RAGraph_edge/utils/metrics.py:104-116: rating, history mask (-1e8), top-k.  hist: list of item-id lists."""
+    rating = cref.linear(np.asarray(user_emb, dtype=np.float32)[users], item_emb)
+    for r, items in enumerate(hist):
+        rating[r, list(items)] = np.float32(-1e8)
+    return cref.topk_rows(rating, k)[1]

@@ -1,0 +1,206 @@
+// Top-k over a MATERIALISED score matrix, history masking, and the few-shot position codes.
+//
+//   topk_rows        torch.topk(scores, k)                    few-shot retrieve: 0.001*structure + 0.999*semantic
+//                                                             (RAGraph_node_fewshot/ragraph_utils/ToyGraphBase.py:58-64);
+//                                                             edge evaluation: top-20 of user x item ratings
+//                                                             (RAGraph_edge/utils/metrics.py:112-118)
+//   scatter_fill     batch_pred[i, pos_list] = -1e8           RAGraph_edge/utils/metrics.py:210-214 (_mask_history_pos)
+//   floyd_warshall   min-plus all-pairs closure               ragraph_utils/PositionAwareEncoder.py:27-48
+//   position_code    1/(d+1) if d < dis_q else 0 to anchors   PositionAwareEncoder.py:6-24
+//
+// topk_rows is HBM streaming (4 B per score): one 256-thread workgroup per row, 16 B/lane coalesced loads, a wave-level
+// threshold, and the wave-cooperative sorted insert shared with the fused kernels; the 4 wave lists are merged at the
+// end.  Canonical order (score desc, index asc), so it agrees with the fused cosine top-k on the same scores.
+#include "common.h"
+
+namespace ragraph {
+
+__device__ __forceinline__ float rows_insert_coop(float* ls, int* li, int k, float s, int idx, int lane) {
+  const bool mine = lane < k;
+  float es = mine ? ls[lane] : 0.f;
+  int ei = mine ? li[lane] : 0;
+  const unsigned long long ahead = __ballot(mine && cand_better(es, ei, s, idx));
+  const int pos = __popcll(ahead);
+  const float us = __shfl_up(es, 1);
+  const int ui = __shfl_up(ei, 1);
+  if (pos < k) {
+    if (lane == pos) {
+      es = s;
+      ei = idx;
+    } else if (lane > pos) {
+      es = us;
+      ei = ui;
+    }
+    if (mine && lane >= pos) {
+      ls[lane] = es;
+      li[lane] = ei;
+    }
+  }
+  return __shfl(es, k - 1);
+}
+
+__global__ void __launch_bounds__(256) topk_rows_kernel(const float* __restrict__ S, int64_t N, int64_t ld, int k,
+                                                        float* __restrict__ out_s, int64_t* __restrict__ out_i) {
+  __shared__ float ls[4][64];
+  __shared__ int li[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t b = blockIdx.x;
+  const float* row = S + b * ld;
+  if (lane < 64) {
+    ls[wave][lane] = RG_NEG_INF;
+    li[wave][lane] = RG_IDX_NONE;
+  }
+  float thr = RG_NEG_INF;
+  const bool vec = ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
+  const int64_t nvec = vec ? (N >> 2) : 0;  // float4 chunks; the tail (and unaligned rows) go scalar
+  for (int64_t c0 = (int64_t)wave * 64; c0 < nvec; c0 += 256) {
+    const int64_t c = c0 + lane;
+    float4 v = make_float4(RG_NEG_INF, RG_NEG_INF, RG_NEG_INF, RG_NEG_INF);
+    if (c < nvec) v = reinterpret_cast<const float4*>(row)[c];
+    const float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+    if (__any(m >= thr)) {
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        unsigned long long pend = __ballot(e[r] >= thr && c < nvec);
+        while (pend) {
+          const int src = __ffsll((long long)pend) - 1;
+          pend &= pend - 1;
+          const float sc = __shfl(e[r], src);
+          thr = rows_insert_coop(ls[wave], li[wave], k, sc, (int)(4 * (c0 + src) + r), lane);
+          pend &= __ballot(e[r] >= thr);
+        }
+      }
+    }
+  }
+  for (int64_t e0 = 4 * nvec + (int64_t)wave * 64; e0 < N; e0 += 256) {
+    const int64_t e = e0 + lane;
+    const float v = (e < N) ? row[e] : RG_NEG_INF;
+    unsigned long long pend = __ballot(v >= thr && e < N);
+    while (pend) {
+      const int src = __ffsll((long long)pend) - 1;
+      pend &= pend - 1;
+      thr = rows_insert_coop(ls[wave], li[wave], k, __shfl(v, src), (int)(e0 + src), lane);
+      pend &= __ballot(v >= thr);
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {  // merge the 4 sorted wave lists: k rounds of wave argmax over <= 4*k candidates
+    float prev_s = __builtin_huge_valf();
+    int prev_i = -1;
+    for (int r = 0; r < k; ++r) {
+      float best_s = RG_NEG_INF;
+      int best_i = RG_IDX_NONE;
+      for (int c = lane; c < 4 * k; c += 64) {
+        const float s = ls[c / k][c % k];
+        const int i = li[c / k][c % k];
+        const bool after_prev = (s < prev_s) || (s == prev_s && i > prev_i);
+        if (after_prev && cand_better(s, i, best_s, best_i)) {
+          best_s = s;
+          best_i = i;
+        }
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const float os = __shfl_xor(best_s, off);
+        const int oi = __shfl_xor(best_i, off);
+        if (cand_better(os, oi, best_s, best_i)) {
+          best_s = os;
+          best_i = oi;
+        }
+      }
+      if (lane == 0) {
+        out_s[b * k + r] = best_s;
+        out_i[b * k + r] = best_i;
+      }
+      prev_s = best_s;
+      prev_i = best_i;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) scatter_fill_kernel(float* __restrict__ S, int64_t ld,
+                                                           const int64_t* __restrict__ rowptr,
+                                                           const int64_t* __restrict__ col, float value) {
+  const int64_t b = blockIdx.x;
+  for (int64_t e = rowptr[b] + threadIdx.x; e < rowptr[b + 1]; e += 256) S[b * ld + col[e]] = value;
+}
+
+// One step k of Floyd-Warshall over the whole matrix: d[i][j] = min(d[i][j], d[i][k] + d[k][j]).  Row k and column k
+// are fixed points of step k (d[k][k] = 0), so the in-place update is race-free.
+__global__ void __launch_bounds__(256) fw_step_kernel(float* __restrict__ d, int n, int kk) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j >= n) return;
+  const float via = __fadd_rn(d[(int64_t)i * n + kk], d[(int64_t)kk * n + j]);
+  const float cur = d[(int64_t)i * n + j];
+  if (via < cur) d[(int64_t)i * n + j] = via;
+}
+
+// dist init: PositionAwareEncoder.py:38-41: dist = adj; dist[adj == 0] = inf; diagonal = 0
+__global__ void __launch_bounds__(256) fw_init_kernel(const float* __restrict__ adj, float* __restrict__ d, int n) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)n * n) return;
+  const int i = (int)(e / n), j = (int)(e % n);
+  const float a = adj[e];
+  d[e] = (i == j) ? 0.f : (a == 0.f ? __builtin_huge_valf() : a);
+}
+
+__global__ void __launch_bounds__(256) position_code_kernel(const float* __restrict__ d, int n,
+                                                            const int64_t* __restrict__ anchors, int A, float dis_q,
+                                                            float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)n * A) return;
+  const int u = (int)(e / A), a = (int)(e % A);
+  const float dist = d[(int64_t)u * n + anchors[a]];
+  out[e] = (dist < dis_q) ? 1.f / (dist + 1.f) : 0.f;
+}
+
+}  // namespace ragraph
+
+using namespace ragraph;
+
+extern "C" int ragraph_topk_rows_f32(const float* S, int64_t B, int64_t N, int64_t ld, int k, float* out_scores,
+                                     int64_t* out_idx, void* stream) {
+  RG_REQUIRE(S && out_scores && out_idx, RAGRAPH_EINVAL, "topk_rows: null pointer");
+  RG_REQUIRE(B >= 0 && N >= 1 && ld >= N, RAGRAPH_EINVAL, "topk_rows: bad shape");
+  RG_REQUIRE(k >= 1 && k <= N, RAGRAPH_EINVAL, "topk_rows: k=%d out of range for N=%lld", k, (long long)N);
+  RG_REQUIRE(k <= 64, RAGRAPH_EUNSUPPORTED, "topk_rows: k=%d > 64", k);
+  RG_REQUIRE(N < (int64_t)INT_MAX, RAGRAPH_EUNSUPPORTED, "topk_rows: N must fit int32");
+  if (B == 0) return RAGRAPH_OK;
+  hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)B), dim3(256), 0, as_stream(stream), S, N, ld, k, out_scores,
+                     out_idx);
+  RG_CHECK_LAUNCH("topk_rows");
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_scatter_fill_f32(float* S, int64_t B, int64_t N, int64_t ld, const int64_t* rowptr,
+                                        const int64_t* col, float value, void* stream) {
+  RG_REQUIRE(S && rowptr && (col || B == 0), RAGRAPH_EINVAL, "scatter_fill: null pointer");
+  RG_REQUIRE(B >= 0 && N >= 1 && ld >= N, RAGRAPH_EINVAL, "scatter_fill: bad shape");
+  if (B == 0) return RAGRAPH_OK;
+  hipLaunchKernelGGL(scatter_fill_kernel, dim3((unsigned)B), dim3(256), 0, as_stream(stream), S, ld, rowptr, col, value);
+  RG_CHECK_LAUNCH("scatter_fill");
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_floyd_warshall_f32(const float* adj, int n, float* dist, void* stream) {
+  RG_REQUIRE(adj && dist, RAGRAPH_EINVAL, "floyd_warshall: null pointer");
+  RG_REQUIRE(n >= 1 && n <= 46340, RAGRAPH_EINVAL, "floyd_warshall: n=%d", n);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(fw_init_kernel, dim3((unsigned)cdiv((int64_t)n * n, 256)), dim3(256), 0, st, adj, dist, n);
+  for (int kk = 0; kk < n; ++kk)
+    hipLaunchKernelGGL(fw_step_kernel, dim3((unsigned)cdiv(n, 256), (unsigned)n), dim3(256), 0, st, dist, n, kk);
+  RG_CHECK_LAUNCH("floyd_warshall");
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_position_code_f32(const float* dist, int n, const int64_t* anchors, int A, float dis_q,
+                                         float* out, void* stream) {
+  RG_REQUIRE(dist && anchors && out, RAGRAPH_EINVAL, "position_code: null pointer");
+  RG_REQUIRE(n >= 1 && A >= 1, RAGRAPH_EINVAL, "position_code: bad shape");
+  hipLaunchKernelGGL(position_code_kernel, dim3((unsigned)cdiv((int64_t)n * A, 256)), dim3(256), 0, as_stream(stream),
+                     dist, n, anchors, A, dis_q, out);
+  RG_CHECK_LAUNCH("position_code");
+  return RAGRAPH_OK;
+}

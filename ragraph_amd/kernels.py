@@ -247,3 +247,52 @@ def proto_cosine(emb: torch.Tensor, proto: torch.Tensor, mode: int = 0) -> torch
     N.check(L.ragraph_proto_cosine_f32(emb.data_ptr(), G, D, proto.data_ptr(), C, mode, out.data_ptr(), _stream()),
             "proto_cosine")
     return out
+
+
+def topk_rows(scores: torch.Tensor, k: int):
+    """torch.topk(scores, k) over a materialised [B,N] matrix, canonical tie order -- few-shot retrieve
+    (RAGraph_node_fewshot/.../ToyGraphBase.py:64), edge evaluation (RAGraph_edge/utils/metrics.py:116)."""
+    L = _ready()
+    s = _f32c(scores, "topk_rows.scores")
+    if s.dim() != 2:
+        raise RagraphNativeError(f"topk_rows: expected [B,N], got {tuple(s.shape)}")
+    B, Nn = s.shape
+    out_s = torch.empty((B, k), dtype=torch.float32, device=s.device)
+    out_i = torch.empty((B, k), dtype=torch.int64, device=s.device)
+    N.check(L.ragraph_topk_rows_f32(s.data_ptr(), B, Nn, Nn, k, out_s.data_ptr(), out_i.data_ptr(), _stream()),
+            "topk_rows")
+    return out_s, out_i
+
+
+def scatter_fill_(scores: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, value: float) -> torch.Tensor:
+    """In place: scores[b, col[rowptr[b]:rowptr[b+1]]] = value -- metrics.py:210-214 (_mask_history_pos)."""
+    L = _ready()
+    if not (scores.is_cuda and scores.dtype == torch.float32 and scores.is_contiguous() and scores.dim() == 2):
+        raise RagraphNativeError("scatter_fill_: scores must be a contiguous fp32 [B,N] device tensor")
+    rowptr = _idxc(rowptr, "scatter_fill_.rowptr")
+    col = _idxc(col, "scatter_fill_.col")
+    B, Nn = scores.shape
+    N.check(L.ragraph_scatter_fill_f32(scores.data_ptr(), B, Nn, Nn, rowptr.data_ptr(), col.data_ptr(), float(value),
+                                       _stream()), "scatter_fill")
+    return scores
+
+
+def floyd_warshall(adj_dense: torch.Tensor) -> torch.Tensor:
+    """All-pairs shortest paths with the adjacency VALUES as edge lengths -- PositionAwareEncoder.py:27-48."""
+    L = _ready()
+    a = _f32c(adj_dense, "floyd_warshall.adj")
+    n = a.shape[0]
+    d = torch.empty_like(a)
+    N.check(L.ragraph_floyd_warshall_f32(a.data_ptr(), n, d.data_ptr(), _stream()), "floyd_warshall")
+    return d
+
+
+def position_code(dist: torch.Tensor, anchors: torch.Tensor, dis_q: float = 10.0) -> torch.Tensor:
+    """1/(d+1) if d < dis_q else 0 to each anchor -- PositionAwareEncoder.py:6-24."""
+    L = _ready()
+    d = _f32c(dist, "position_code.dist")
+    anchors = _idxc(anchors, "position_code.anchors")
+    out = torch.empty((d.shape[0], anchors.numel()), dtype=torch.float32, device=d.device)
+    N.check(L.ragraph_position_code_f32(d.data_ptr(), d.shape[0], anchors.data_ptr(), anchors.numel(), float(dis_q),
+                                        out.data_ptr(), _stream()), "position_code")
+    return out

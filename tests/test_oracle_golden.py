@@ -120,3 +120,24 @@ def test_g10_downprompt():
         logp, emb = pipeline.downprompt_logits(g["h"], g["w"], g["graph_len"], g[f"proto_c{C}"])
         assert np.allclose(emb, g["graph_emb"], atol=1e-4)
         assert np.allclose(logp, g[f"logp_c{C}"], atol=1e-5)
+
+
+def test_g8_fewshot_structural_retrieve():
+    g = gold("g8_fewshot_retrieve")
+    assert np.array_equal(cref.floyd_warshall(g["adj"]), g["dist"])          # min-plus closure: exact
+    e, l, idx, pos = pipeline.fewshot_retrieve(g["Q"], g["adj"], g["anchors"], g["keys"], g["values"], g["labels"],
+                                               g["positions"], int(g["k"]))
+    assert np.allclose(pos, g["pos_codes"], atol=1e-7)
+    assert np.array_equal(idx, g["topk_idx"])
+    assert np.array_equal(e, g["rag_embeddings"]) and np.array_equal(l, g["rag_labels"])
+
+
+def test_topk_rows_matches_torch_topk_on_tie_free_rows():
+    rng = np.random.default_rng(3)
+    S = rng.standard_normal((33, 5000)).astype(np.float32)
+    s, i = cref.topk_rows(S, 20)
+    ts, ti = torch.topk(torch.from_numpy(S), 20)
+    assert np.array_equal(i, ti.numpy()) and np.array_equal(s, ts.numpy())
+    S[:, ::7] = 0.25  # ties: canonical order = lower index first
+    s, i = cref.topk_rows(np.minimum(S, 0.25), 10)
+    assert (s == 0.25).all() and np.array_equal(i[0], np.sort(i[0]))
