@@ -85,6 +85,24 @@ __device__ __forceinline__ float list_insert_coop(float* ls, int* li, int q, int
   return __shfl(es, k - 1);
 }
 
+// Lane-private insert into the sorted k-list at `ls/li` (this lane's query): shift from the tail.  Used in the DENSE
+// regime (first tiles of a stream, when most lanes hold candidates): 32 queries insert in parallel, ~1k cycles per
+// round of up to 64 candidates, where the cooperative insert would take them one at a time.
+__device__ __forceinline__ void list_insert_lane(float* ls, int* li, int k, float s, int idx) {
+  if (!cand_better(s, idx, ls[k - 1], li[k - 1])) return;
+  int p = k - 1;
+  while (p > 0) {
+    const float ps = ls[p - 1];
+    const int pi = li[p - 1];
+    if (!cand_better(s, idx, ps, pi)) break;
+    ls[p] = ps;
+    li[p] = pi;
+    --p;
+  }
+  ls[p] = s;
+  li[p] = idx;
+}
+
 struct TopkParams {
   const float* Qn;   // [B,D] normalised queries (big kernel) / RAW queries (small-batch kernel)
   const float* Kn;   // [N,D] normalised keys
@@ -270,6 +288,31 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
           if (acc[r] >= thr && idx < (int)n_end) mask |= 1u << r;
         }
         unsigned long long pend = __ballot(mask != 0);
+        if (__popcll(pend) > 8) {
+          // DENSE regime (start of a stream): every lane inserts into its own query's list; the two half-wave lanes of
+          // a query take turns.  Afterwards both re-read the list's k-th score as their threshold.
+          float* qls = ls + (wave * 32 + j) * k;
+          int* qli = li + (wave * 32 + j) * k;
+          while (pend) {
+            const int r0 = __ffs(mask) - 1;
+            float my_sc = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) my_sc = (r0 == r) ? acc[r] : my_sc;
+            const int idx = key_base + (r0 & 3) + 8 * (r0 >> 2);
+#pragma unroll 1
+            for (int hh = 0; hh < 2; ++hh) {
+              if (mask != 0 && h == hh) list_insert_lane(qls, qli, k, my_sc, idx);
+            }
+            mask &= mask - 1;
+            thr = qls[k - 1];
+            if (mask) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                if ((mask >> r & 1u) && acc[r] < thr) mask &= ~(1u << r);
+            }
+            pend = __ballot(mask != 0);
+          }
+        }
         while (pend) {
           const int src = __ffsll((long long)pend) - 1;  // wave-uniform: lowest lane with a candidate
           const int r0 = __ffs(mask) - 1;                // lowest pending register of THIS lane (used on lane src)
@@ -740,7 +783,7 @@ static TopkPlan plan_topk(int64_t B, int64_t N, int D, int k) {
   const int64_t nstages = cdiv(N, stage_keys);
   int64_t max_split = nstages < 256 ? nstages : 256;
   if (max_split * k > 4096) max_split = 4096 / k;  // the select kernel holds <= 4096 candidates per query
-  const int64_t min_keys = 8192;  // below this the warm-up dominates
+  const int64_t min_keys = 4 * stage_keys;  // a split needs a few stages for its prefetch pipeline to make sense
   int best = 1;
   double best_cost = 1e300;
   for (int64_t s = 1; s <= max_split; ++s) {
@@ -752,7 +795,9 @@ static TopkPlan plan_topk(int64_t B, int64_t N, int D, int k) {
     const double rounds = (double)cdiv(wgs, CUS);
     // measured on MI355X (k=10, D=256, barrier-free ring): the insert path costs ~7k/n of a stream of n keys
     // (11 % at n = 62.5k, ~0 at n = 500k); it scales with the number of candidates, i.e. with k.
-    const double warm = 1.0 + 700.0 * (double)k / (double)per;
+    // Short streams saturate (every tile has candidates): capped at 2x, so small banks still spread over all CUs.
+    double warm = 1.0 + 700.0 * (double)k / (double)per;
+    if (warm > 2.0) warm = 2.0;
     const double cost = rounds * (double)per * warm;
     if (cost < best_cost * 0.999) {
       best_cost = cost;
