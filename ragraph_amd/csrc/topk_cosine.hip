@@ -88,19 +88,19 @@ __device__ __forceinline__ float list_insert_coop(float* ls, int* li, int q, int
 // Lane-private insert into the sorted k-list at `ls/li` (this lane's query): shift from the tail.  Used in the DENSE
 // regime (first tiles of a stream, when most lanes hold candidates): 32 queries insert in parallel, ~1k cycles per
 // round of up to 64 candidates, where the cooperative insert would take them one at a time.
-__device__ __forceinline__ void list_insert_lane(float* ls, int* li, int k, float s, int idx) {
-  if (!cand_better(s, idx, ls[k - 1], li[k - 1])) return;
+__device__ __forceinline__ void list_insert_lane(float* ls, int* li, int k, int stride, float s, int idx) {
+  if (!cand_better(s, idx, ls[(k - 1) * stride], li[(k - 1) * stride])) return;
   int p = k - 1;
   while (p > 0) {
-    const float ps = ls[p - 1];
-    const int pi = li[p - 1];
+    const float ps = ls[(p - 1) * stride];
+    const int pi = li[(p - 1) * stride];
     if (!cand_better(s, idx, ps, pi)) break;
-    ls[p] = ps;
-    li[p] = pi;
+    ls[p * stride] = ps;
+    li[p * stride] = pi;
     --p;
   }
-  ls[p] = s;
-  li[p] = idx;
+  ls[p * stride] = s;
+  li[p * stride] = idx;
 }
 
 struct TopkParams {
@@ -114,6 +114,7 @@ struct TopkParams {
   int64_t keys_per_split;  // multiple of the stage size
   float* part_s;           // [B][nsplit][k]
   int* part_i;
+  const float* thr_init;   // small-batch kernel: per-query lower bound of the k-th best score at [q*k + k-1], or NULL
   int ablate;              // DIAGNOSTIC ONLY (env RAGRAPH_TOPK_ABLATE, results invalid when non-zero): bit0 skip the
                            // top-k epilogue, bit1 skip global loads + LDS writes, bit2 skip the stage barrier
 };
@@ -301,7 +302,7 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
             const int idx = key_base + (r0 & 3) + 8 * (r0 >> 2);
 #pragma unroll 1
             for (int hh = 0; hh < 2; ++hh) {
-              if (mask != 0 && h == hh) list_insert_lane(qls, qli, k, my_sc, idx);
+              if (mask != 0 && h == hh) list_insert_lane(qls, qli, k, 1, my_sc, idx);
             }
             mask &= mask - 1;
             thr = qls[k - 1];
@@ -476,7 +477,10 @@ __global__ void __launch_bounds__(512, 2) topk_smallb_kernel(TopkParams p) {
   const int64_t ntiles = (p.N + C::TILE_KEYS - 1) / C::TILE_KEYS;
   const int64_t gw = (int64_t)blockIdx.x * C::WAVES + wave, nw = (int64_t)gridDim.x * C::WAVES;
   const bool live = j < p.B;
-  float thr = live ? RG_NEG_INF : __builtin_huge_valf();
+  // A floor from the sampled pre-pass (k-th best over a prefix of the bank) is a valid lower bound of the final k-th
+  // best: keys below it can never be selected, so the lists only ever see the few keys that can.
+  const float thr_floor = (live && p.thr_init) ? p.thr_init[(int64_t)j * k + k - 1] : RG_NEG_INF;
+  float thr = live ? thr_floor : __builtin_huge_valf();
 
   float4 pre[16];
   const int lrow = lane / (D / 4), lcol = 4 * (lane % (D / 4));
@@ -520,6 +524,23 @@ __global__ void __launch_bounds__(512, 2) topk_smallb_kernel(TopkParams p) {
         for (int r = 0; r < 4; ++r)
           if (acc[r] >= thr && key_base + r < (int)p.N) mask |= 1u << r;
         unsigned long long pend = __ballot(mask != 0);
+        if (__popcll(pend) > 8) {
+          // DENSE regime (no floor yet, or many queries): lane-private inserts, the 4 lanes of a query take turns
+          while (pend) {
+            const int r0 = __ffs(mask) - 1;
+            const float my_sc = r0 == 1 ? acc[1] : r0 == 2 ? acc[2] : r0 == 3 ? acc[3] : acc[0];
+#pragma unroll 1
+            for (int ss = 0; ss < 4; ++ss) {
+              if (mask != 0 && sl == ss) list_insert_lane(ls + j, li + j, k, 16, my_sc, key_base + r0);
+            }
+            mask &= mask - 1;
+            if (live) thr = fmaxf(thr_floor, ls[(k - 1) * 16 + j]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if ((mask >> r & 1u) && acc[r] < thr) mask &= ~(1u << r);
+            pend = __ballot(mask != 0);
+          }
+        }
         while (pend) {
           const int src = __ffsll((long long)pend) - 1;          // wave-uniform: lowest lane with a candidate
           const int r0 = __ffs(mask) - 1;                        // (meaningful on lane src)
@@ -528,7 +549,7 @@ __global__ void __launch_bounds__(512, 2) topk_smallb_kernel(TopkParams p) {
           const int idx = __shfl(key_base + r0, src);
           const int q = src & 15;
           const float nthr = list_insert_coop(ls, li, q, k, 16, sc, idx, lane);
-          if (live && j == q) thr = nthr;
+          if (live && j == q) thr = fmaxf(thr_floor, nthr);
           if (lane == src) mask &= mask - 1;
           // drop this lane's remaining candidates that the tightened threshold already excludes
 #pragma unroll
@@ -793,10 +814,10 @@ static TopkPlan plan_topk(int64_t B, int64_t N, int D, int k) {
     if (real != s) continue;
     const int64_t wgs = qtiles * s;
     const double rounds = (double)cdiv(wgs, CUS);
-    // measured on MI355X (k=10, D=256, barrier-free ring): the insert path costs ~7k/n of a stream of n keys
-    // (11 % at n = 62.5k, ~0 at n = 500k); it scales with the number of candidates, i.e. with k.
+    // measured on MI355X (k=10, D=256, barrier-free ring + hybrid insert): the insert path costs ~4.2k/n of a stream
+    // of n keys (7 % at n = 62.5k, ~0 at n = 500k); it scales with the number of candidates, i.e. with k.
     // Short streams saturate (every tile has candidates): capped at 2x, so small banks still spread over all CUs.
-    double warm = 1.0 + 700.0 * (double)k / (double)per;
+    double warm = 1.0 + 420.0 * (double)k / (double)per;
     if (warm > 2.0) warm = 2.0;
     const double cost = rounds * (double)per * warm;
     if (cost < best_cost * 0.999) {
@@ -917,7 +938,24 @@ extern "C" int ragraph_topk_cosine_f32(const float* Q, int64_t B, const float* K
     p.ablate = ab ? atoi(ab) : 0;
   }
   const int64_t qtiles = cdiv(B, 256);
+  p.thr_init = nullptr;
   if (B <= SMALLB_MAX) {
+    // 4..16 queries: each of the ~2000 waves sees only N/2000 keys, so its lists would stay in their warm-up for the
+    // whole stream.  A pre-pass over a 4096-key prefix (1/256 of a 1M bank) gives every query the k-th best score of
+    // that prefix -- a valid lower bound of the final k-th best -- and the main pass then only ever inserts the
+    // ~k*N/4096 keys per query that beat it.  For 1-3 queries the two extra launches cost more than they save.
+    const int64_t prefix = 4096;
+    if (B >= 4 && N >= 16 * prefix && k <= prefix) {
+      TopkParams pp = p;
+      pp.N = prefix;
+      pp.nsplit = (int)cdiv(cdiv(prefix, 16 * (256 / D)), 8);  // one tile per wave
+      rc = D == 256 ? launch_smallb<256>(pp, st) : D == 128 ? launch_smallb<128>(pp, st) : launch_smallb<64>(pp, st);
+      if (rc != RAGRAPH_OK) return rc;
+      rc = launch_merge_sorted<int>(part_s, part_i, pp.nsplit, B, k, (int64_t)k, (int64_t)pp.nsplit * k, 0, out_scores,
+                                    out_idx, st);
+      if (rc != RAGRAPH_OK) return rc;
+      p.thr_init = out_scores;  // read by the main pass, overwritten by the final merge after it (stream order)
+    }
     rc = D == 256 ? launch_smallb<256>(p, st) : D == 128 ? launch_smallb<128>(p, st) : launch_smallb<64>(p, st);
   } else if (D == 256) {
     rc = launch_topk<256>(p, qtiles, st);
