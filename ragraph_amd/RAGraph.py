@@ -88,3 +88,20 @@ class RAGraphGraph(RAGraph):
 
     def _pool(self, x, g):
         return self._mean_rows(x)          # :63
+
+    @torch.no_grad()
+    def forward_batch(self, features, adj, graph_ptr):
+        """G graphs in one pass (the reference runs batch_size = 1, finetune-rag.py:27): `adj` is the block-diagonal CSR
+        of the batch, `graph_ptr` [G+1] the node offsets.  Row g of the result equals forward() on graph g alone --
+        every step is per-node or per-segment, and a score does not depend on the query batch."""
+        g = as_csr(adj)
+        seg = graph_ptr.to(features.device, torch.int64)
+        emb = self.pretrain_model.inference(features, g)                                        # :49
+        rag_embedding, rag_label, _ = self.toy_graph_base.retrieve_reduced(
+            K.segment_reduce(emb, seg, mean_mode=True))                                          # :50-60, G queries
+        if not self.finetune:
+            return rag_label
+        query = K.segment_reduce(Propagation.aggregate_k_hop_features(g, emb, self.query_graph_hop), seg,
+                                 mean_mode=True)                                                 # :62-63
+        hidden = K.axpby(query, 1 - self.retrieve_weight, rag_embedding, self.retrieve_weight)   # :65
+        return K.softmax_mix(self.decoder(hidden), rag_label, self.label_weight)                 # :66-69
