@@ -68,12 +68,13 @@ int ragraph_normalize_rows_f32(const float* X, int64_t n, int D, float* out, voi
  *       reference re-normalises its stored keys on every call, SimilarityFunctions.py:11).
  *   k   1 <= k <= min(N, RAGRAPH_TOPK_MAX).  D in {64,128,256}.  B,N >= 1.  B <= 16 takes the HBM-streaming
  *       small-batch kernel (16x16x4 MFMA), larger B the MFMA-bound tile kernel (32x32x2); same numerics.
+ *       32 < k <= 64 materialises ~1 GiB slabs of scores in the workspace (dense kernel + row top-k), same bits.
  *   idx_base  added to every returned index (this shard's first global row).
  *   out_scores [B,k] fp32 descending; out_idx [B,k] int64 (torch indexing dtype).
  *   Unsupported (returns RAGRAPH_EUNSUPPORTED): other D, k > RAGRAPH_TOPK_MAX, shards of >= 2^31 rows.  NaN scores are never selected
  *   (torch.topk would rank NaN first) -- inputs are finite by contract.
  */
-#define RAGRAPH_TOPK_MAX 32
+#define RAGRAPH_TOPK_MAX 64
 size_t ragraph_topk_cosine_workspace_bytes(int64_t B, int64_t N, int D, int k);
 int ragraph_topk_cosine_f32(const float* Q, int64_t B, const float* Kn, int64_t N, int D, int k, int64_t idx_base,
                             float* out_scores, int64_t* out_idx, void* ws, size_t ws_bytes, void* stream);

@@ -21,7 +21,7 @@ SO_PATH = os.environ.get("RAGRAPH_HIP_SO", os.path.join(CSRC, "libragraph_hip.so
 
 OK, EINVAL, EUNSUPPORTED, EWORKSPACE, EDEVICE = 0, -1, -2, -3, -4
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LEAKY, ACT_ELU = 0, 1, 2, 3, 4
-TOPK_MAX = 32
+TOPK_MAX = 64
 
 _vp, _i64, _i32, _f32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 

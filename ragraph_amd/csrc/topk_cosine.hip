@@ -888,11 +888,34 @@ static int launch_smallb(const TopkParams& p, hipStream_t st) {
 
 using namespace ragraph;
 
+// 32 < k <= 64 (e.g. RAGraph_edge 'vanilla' phase on amazon, retrieve_num = 50, modules/RAGraph.py:40): the per-query
+// lists no longer fit next to the stages in LDS, so the scores of a slab of queries are materialised with the dense
+// kernel (the same fmaf chains, hence the same bits) and selected by topk_rows -- the reference's own slab idiom
+// (modules/RAGraph.py:298-311), kept on the device.
+static int64_t slab_rows_for(int64_t B, int64_t N) {
+  int64_t rows = ((int64_t)1 << 30) / (4 * N);  // ~1 GiB of scores per slab
+  if (rows < 64) rows = 64;
+  return rows < B ? rows : B;
+}
+
 extern "C" size_t ragraph_topk_cosine_workspace_bytes(int64_t B, int64_t N, int D, int k) {
   if (B < 1 || N < 1 || k < 1 || (D != 64 && D != 128 && D != 256)) return 0;
+  if (k > 32) return align_up((size_t)B * D * sizeof(float), 256) + (size_t)slab_rows_for(B, N) * N * sizeof(float);
   TopkPlan pl = plan_topk(B, N, D, k);
   return pl.qn_bytes + pl.part_s_bytes + pl.part_i_bytes;
 }
+
+extern "C" int ragraph_topk_rows_f32(const float* S, int64_t B, int64_t N, int64_t ld, int k, float* out_scores,
+                                     int64_t* out_idx, void* stream);
+extern "C" int ragraph_linear_f32(const float* X, int64_t M, int K, const float* W, int64_t N, const float* bias,
+                                  int act, float alpha, float* Y, void* stream);
+
+namespace ragraph {
+__global__ void __launch_bounds__(256) add_idx_base_kernel(int64_t* idx, int64_t n, int64_t base) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) idx[i] += base;
+}
+}  // namespace ragraph
 
 extern "C" int ragraph_topk_cosine_f32(const float* Q, int64_t B, const float* Kn, int64_t N, int D, int k,
                                        int64_t idx_base, float* out_scores, int64_t* out_idx, void* ws,
@@ -906,6 +929,25 @@ extern "C" int ragraph_topk_cosine_f32(const float* Q, int64_t B, const float* K
              RAGRAPH_TOPK_MAX);
   RG_REQUIRE(N < (int64_t)INT_MAX - 1024, RAGRAPH_EUNSUPPORTED, "topk_cosine: shard rows must fit int32");
   RG_REQUIRE(aligned16(Q) && aligned16(Kn) && aligned16(ws), RAGRAPH_EINVAL, "topk_cosine: Q, Kn, ws must be 16-B aligned");
+  if (k > 32) {  // materialised slabs, see slab_rows_for()
+    const size_t qn_bytes = align_up((size_t)B * D * sizeof(float), 256);
+    const int64_t rows = slab_rows_for(B, N);
+    RG_REQUIRE(ws_bytes >= qn_bytes + (size_t)rows * N * sizeof(float), RAGRAPH_EWORKSPACE, "topk_cosine: workspace too small");
+    float* Qn = reinterpret_cast<float*>(ws);
+    float* S = reinterpret_cast<float*>(static_cast<char*>(ws) + qn_bytes);
+    int rc = ragraph_normalize_rows_f32(Q, B, D, Qn, stream);
+    for (int64_t b0 = 0; rc == RAGRAPH_OK && b0 < B; b0 += rows) {
+      const int64_t nb = (B - b0 < rows) ? B - b0 : rows;
+      rc = ragraph_linear_f32(Qn + b0 * D, nb, D, Kn, N, nullptr, RAGRAPH_ACT_NONE, 0.f, S, stream);
+      if (rc == RAGRAPH_OK) rc = ragraph_topk_rows_f32(S, nb, N, N, k, out_scores + b0 * k, out_idx + b0 * k, stream);
+    }
+    if (rc == RAGRAPH_OK && idx_base != 0) {
+      hipLaunchKernelGGL(add_idx_base_kernel, dim3((unsigned)cdiv(B * k, 256)), dim3(256), 0, as_stream(stream), out_idx,
+                         B * k, idx_base);
+      RG_CHECK_LAUNCH("topk_cosine(add base)");
+    }
+    return rc;
+  }
   TopkPlan pl = plan_topk(B, N, D, k);
   RG_REQUIRE(ws_bytes >= pl.qn_bytes + pl.part_s_bytes + pl.part_i_bytes, RAGRAPH_EWORKSPACE,
              "topk_cosine: workspace %zu < %zu", ws_bytes, pl.qn_bytes + pl.part_s_bytes + pl.part_i_bytes);

@@ -52,6 +52,8 @@ def test_normalize_rows_bit_exact(dev, n, D):
         (40, 10, 256, 10),       # k == N
         (100, 3000, 256, 1),
         (50, 9000, 256, 32),     # k at the fused kernel's maximum
+        (300, 9000, 64, 50),     # 32 < k <= 64: materialised slabs + row top-k (edge 'vanilla' retrieve_num = 50)
+        (3, 2000, 256, 64),
         (5, 70000, 256, 10),     # small-batch kernel with the sampled-threshold pre-pass (4 <= B <= 16, N >= 64k)
         (16, 131072, 64, 7),
         (3, 70000, 128, 10),     # small-batch kernel without the pre-pass
