@@ -78,6 +78,9 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restric
 }
 
 // ---- a8: sum_k V[idx], mean_k L[idx] (RAGraph.py:48-49); one wave per query, winners added in rank order -------------
+// Gather-bound (B*k random 1 KiB rows): 16 B per lane so one wave-instruction fetches a whole row at D = 256, and the
+// loads of 8 winners are issued before the first add so 8 row gathers are in flight per wave.
+template <bool VEC4>
 __global__ void __launch_bounds__(256) gather_reduce_kernel(const float* __restrict__ V, int D,
                                                             const float* __restrict__ L, int C, int64_t N,
                                                             const int64_t* __restrict__ idx, int64_t B, int k,
@@ -87,13 +90,43 @@ __global__ void __launch_bounds__(256) gather_reduce_kernel(const float* __restr
   const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
   const int64_t* ib = idx + b * k;
-  for (int e = lane; e < D; e += 64) {
-    float acc = 0.f;
-    for (int jx = 0; jx < k; ++jx) {
-      const int64_t r = ib[jx] - base;
-      if (r >= 0 && r < N) acc = __fadd_rn(acc, V[r * D + e]);
+  if (VEC4) {
+    const int D4 = D >> 2;
+    for (int c = lane; c < D4; c += 64) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j0 = 0; j0 < k; j0 += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (j0 + u < k) {
+            const int64_t r = ib[j0 + u] - base;
+            if (r >= 0 && r < N) v[u] = reinterpret_cast<const float4*>(V + r * D)[c];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (j0 + u < k) {  // out-of-shard winners add +0, which leaves every partial sum unchanged
+            acc.x = __fadd_rn(acc.x, v[u].x); acc.y = __fadd_rn(acc.y, v[u].y);
+            acc.z = __fadd_rn(acc.z, v[u].z); acc.w = __fadd_rn(acc.w, v[u].w);
+          }
+        }
+      }
+      if (v_scale != 1.f) {
+        acc.x = __fmul_rn(acc.x, v_scale); acc.y = __fmul_rn(acc.y, v_scale);
+        acc.z = __fmul_rn(acc.z, v_scale); acc.w = __fmul_rn(acc.w, v_scale);
+      }
+      reinterpret_cast<float4*>(sumV + b * D)[c] = acc;
     }
-    sumV[b * D + e] = (v_scale == 1.f) ? acc : __fmul_rn(acc, v_scale);
+  } else {
+    for (int e = lane; e < D; e += 64) {
+      float acc = 0.f;
+      for (int jx = 0; jx < k; ++jx) {
+        const int64_t r = ib[jx] - base;
+        if (r >= 0 && r < N) acc = __fadd_rn(acc, V[r * D + e]);
+      }
+      sumV[b * D + e] = (v_scale == 1.f) ? acc : __fmul_rn(acc, v_scale);
+    }
   }
   if (L && meanL) {
     for (int c = lane; c < C; c += 64) {
@@ -246,8 +279,13 @@ extern "C" int ragraph_gather_reduce_f32(const float* V, int D, const float* L, 
   RG_REQUIRE((L == nullptr) == (mean_L == nullptr), RAGRAPH_EINVAL, "gather_reduce: L and mean_L go together");
   RG_REQUIRE(!L || C >= 1, RAGRAPH_EINVAL, "gather_reduce: C=%d", C);
   if (B == 0) return RAGRAPH_OK;
-  hipLaunchKernelGGL(gather_reduce_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, as_stream(stream), V, D, L, C, N,
-                     idx, B, k, idx_base, v_scale, sum_V, mean_L);
+  const bool vec = (D % 4 == 0) && aligned16(V) && aligned16(sum_V);
+  if (vec)
+    hipLaunchKernelGGL(gather_reduce_kernel<true>, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, as_stream(stream), V, D, L,
+                       C, N, idx, B, k, idx_base, v_scale, sum_V, mean_L);
+  else
+    hipLaunchKernelGGL(gather_reduce_kernel<false>, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, as_stream(stream), V, D, L,
+                       C, N, idx, B, k, idx_base, v_scale, sum_V, mean_L);
   RG_CHECK_LAUNCH("gather_reduce");
   return RAGRAPH_OK;
 }

@@ -23,39 +23,6 @@
 
 namespace ragraph {
 
-// ------------------------------------------------------------------------------------------------------------------
-// Per-query candidate list in LDS, unsorted, replace-the-worst policy.
-//   ls/li: [k][QT] (position-major so the 32 lanes of a half-wave hit 32 banks), thr_q[QT] = score of the worst kept.
-// Offered to by at most one lane per query at a time (the two half-waves that share a query are serialised).
-// ------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void list_offer(float* ls, int* li, float* thr_q, int q, int k, int QT, float s, int idx) {
-  // one scan: worst and second-worst of the current list
-  float w_s = ls[q];
-  int w_i = li[q];
-  int w_p = 0;
-  float w2_s = __builtin_huge_valf();  // "better than anything" until a second element is seen
-  int w2_i = -1;
-  for (int p = 1; p < k; ++p) {
-    const float cs = ls[p * QT + q];
-    const int ci = li[p * QT + q];
-    if (cand_better(w_s, w_i, cs, ci)) {  // (cs,ci) is worse than the current worst -> new worst
-      w2_s = w_s;
-      w2_i = w_i;
-      w_s = cs;
-      w_i = ci;
-      w_p = p;
-    } else if (cand_better(w2_s, w2_i, cs, ci)) {
-      w2_s = cs;
-      w2_i = ci;
-    }
-  }
-  if (!cand_better(s, idx, w_s, w_i)) return;  // not better than the k-th best: list unchanged
-  ls[w_p * QT + q] = s;
-  li[w_p * QT + q] = idx;
-  // new worst = worse of (second worst, the new element)
-  thr_q[q] = (k == 1) ? s : (cand_better(s, idx, w2_s, w2_i) ? w2_s : s);
-}
-
 // Wave-cooperative insert into a SORTED k-list (k <= 64) that lives in LDS as [k][QS]: lane p holds entry p, one
 // ballot finds the insert position, one shuffle shifts the tail.  All 64 lanes must call it with wave-uniform
 // (q, s, idx).  Returns the new k-th best score.
@@ -421,7 +388,7 @@ struct SmallCfg {
   static constexpr int ROW = D + 2;                // floats
   static constexpr int TILE_FLOATS = TILE_KEYS * ROW;
   static constexpr int RPI = 256 / D;              // rows covered by one wave-wide float4 load instruction
-  static size_t lds_bytes(int k) { return (size_t)WAVES * (sizeof(float) * (TILE_FLOATS + 16) + (size_t)k * 16 * 8); }
+  static size_t lds_bytes(int k) { return (size_t)WAVES * (sizeof(float) * TILE_FLOATS + (size_t)k * 16 * 8); }
 };
 
 template <int D>
@@ -432,10 +399,9 @@ __global__ void __launch_bounds__(512, 2) topk_smallb_kernel(TopkParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, sl = lane >> 4;
   const int k = p.k;
-  const int per_wave = C::TILE_FLOATS + 16 + 2 * k * 16;  // tile | thr[16] | ls[k][16] | li[k][16]
+  const int per_wave = C::TILE_FLOATS + 2 * k * 16;  // tile | ls[k][16] | li[k][16]  (one sorted list per query)
   float* tile = smem + wave * per_wave;
-  float* thr_q = tile + C::TILE_FLOATS;
-  float* ls = thr_q + 16;
+  float* ls = tile + C::TILE_FLOATS;
   int* li = reinterpret_cast<int*>(ls + k * 16);
 
   // B operand: query j, k-slots sl, sl+4, ...  (queries >= B are clamped; their lists are never offered to).
@@ -472,7 +438,6 @@ __global__ void __launch_bounds__(512, 2) topk_smallb_kernel(TopkParams p) {
     ls[i] = RG_NEG_INF;
     li[i] = RG_IDX_NONE;
   }
-  if (lane < 16) thr_q[lane] = RG_NEG_INF;
 
   const int64_t ntiles = (p.N + C::TILE_KEYS - 1) / C::TILE_KEYS;
   const int64_t gw = (int64_t)blockIdx.x * C::WAVES + wave, nw = (int64_t)gridDim.x * C::WAVES;
@@ -570,7 +535,7 @@ __global__ void __launch_bounds__(512, 2) topk_smallb_kernel(TopkParams p) {
       float best_s = RG_NEG_INF;
       int best_i = RG_IDX_NONE;
       for (int c = lane; c < C::WAVES * k; c += 64) {
-        const float* wl = smem + (c / k) * per_wave + C::TILE_FLOATS + 16;
+        const float* wl = smem + (c / k) * per_wave + C::TILE_FLOATS;
         const float s = wl[(c % k) * 16 + q];
         const int i = reinterpret_cast<const int*>(wl + k * 16)[(c % k) * 16 + q];
         const bool after_prev = (s < prev_s) || (s == prev_s && i > prev_i);
