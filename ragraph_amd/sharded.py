@@ -7,9 +7,11 @@ Partition: rank r owns bank rows [base_r, base_r + N_r).  Per retrieve:
      fully connected xGMI mesh)                                                               -> [G,B,k]
   3. every rank merges the G lists with the canonical order (score desc, id asc)            -> identical on all ranks,
      and identical to the 1-GPU result bit for bit (scores are shard-independent fmaf chains)
-  4. every rank sums the value / label rows of the winners IT owns; one all_reduce(sum) of [B, D+C] finishes
-     sum_k V[idx], mean_k L[idx] (what RAGraph.forward consumes, RAGraph.py:48-49) -- no [B,k,D] traffic.
-Indices and scores are exact for any G; the value sums differ from 1 GPU only by fp32 re-association (<= 1e-6 rel).
+  4. values / labels: either REPLICATED on every rank (default in bench.py: 1 GB at 1M x 256 -- nothing next to 288 GB
+     of HBM -- so sum_k V[idx], mean_k L[idx] are local gathers, bit-identical to 1 GPU, and the all_gather of step 2 is
+     the only collective), or row-sharded like the keys: every rank sums the winners IT owns and one all_reduce(sum)
+     of [B, D+C] finishes it (no [B,k,D] traffic; sums then differ from 1 GPU by fp32 re-association, <= 1e-6 rel).
+Indices and scores are exact for any G.
 """
 from __future__ import annotations
 
@@ -29,7 +31,9 @@ class ShardedToyGraphBase:
     library); the CPU tests inject an oracle-backed object to exercise the collective logic under gloo."""
 
     def __init__(self, keys, values, labels, idx_base: int, retrieve_num: int, group=None, ops=None,
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, values_replicated: bool = False):
+        """keys: this rank's key rows.  values/labels: this rank's rows (values_replicated=False) or the WHOLE bank's
+        (values_replicated=True)."""
         if ops is None:
             from . import kernels as ops  # the HIP library; raises loudly without a GPU
         self.ops = ops
@@ -37,6 +41,7 @@ class ShardedToyGraphBase:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.idx_base = int(idx_base)
+        self.values_replicated = values_replicated
         # run the collectives even in a 1-rank group (exercises the RCCL path on a single-GPU box)
         self.collective = self.world > 1 or (force_collectives and dist.is_initialized())
         self.retrieve_num = retrieve_num
@@ -67,6 +72,9 @@ class ShardedToyGraphBase:
         """(sum_k V[idx], mean_k L[idx], idx) over the whole bank."""
         k = self.retrieve_num if k is None else k
         _, idx = self.topk(search_keys, k)
+        if self.values_replicated:  # every winner's row is local: same kernel, same bits as a single GPU
+            sum_v, mean_l = self.ops.gather_reduce(self.resource_values, self.resource_labels, idx)
+            return sum_v, mean_l, idx
         sum_v, _ = self.ops.gather_reduce(self.resource_values, None, idx, idx_base=self.idx_base)
         sum_l, _ = self.ops.gather_reduce(self.resource_labels, None, idx, idx_base=self.idx_base)
         if self.collective:
@@ -78,6 +86,8 @@ class ShardedToyGraphBase:
     def retrieve(self, search_keys, search_adj=None, add_noise=False):
         """Public (B,k,D)/(B,k,C) form of ToyGraphBase.retrieve: owner-gather + all_reduce (zeros elsewhere)."""
         _, idx = self.topk(search_keys, self.retrieve_num)
+        if self.values_replicated:
+            return self.ops.gather_rows(self.resource_values, idx), self.ops.gather_rows(self.resource_labels, idx)
         e = self.ops.gather_rows(self.resource_values, idx, idx_base=self.idx_base)
         l = self.ops.gather_rows(self.resource_labels, idx, idx_base=self.idx_base)
         if self.collective:

@@ -63,8 +63,11 @@ def _worker(rank, world, port, N, D, C, B, k, out_dir):
         s, i = tgb.topk(torch.from_numpy(q))
         sv, ml, _ = tgb.retrieve_reduced(torch.from_numpy(q))
         e, l = tgb.retrieve(torch.from_numpy(q))
+        rep = ShardedToyGraphBase(torch.from_numpy(keys[lo:hi]), torch.from_numpy(vals), torch.from_numpy(labs), lo, k,
+                                  ops=OracleOps, values_replicated=True)
+        rsv, rml, ri = rep.retrieve_reduced(torch.from_numpy(q))
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), s=s.numpy(), i=i.numpy(), sv=sv.numpy(), ml=ml.numpy(),
-                 e=e.numpy(), l=l.numpy())
+                 e=e.numpy(), l=l.numpy(), rsv=rsv.numpy(), rml=rml.numpy(), ri=ri.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -85,4 +88,6 @@ def test_sharded_retrieval_world2_matches_single(tmp_path, N, k):
         assert np.array_equal(r["i"], ri) and np.array_equal(r["s"], rs)  # bit-identical to one GPU, on every rank
         assert np.allclose(r["sv"], rsv, atol=1e-5) and np.array_equal(r["ml"], rml)
         assert np.array_equal(r["e"], vals[ri]) and np.array_equal(r["l"], labs[ri])
+        # replicated values: bit-identical to the single-GPU sums, no all_reduce
+        assert np.array_equal(r["ri"], ri) and np.array_equal(r["rsv"], rsv) and np.array_equal(r["rml"], rml)
     assert np.array_equal(r0["sv"], r1["sv"])
