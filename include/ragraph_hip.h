@@ -158,6 +158,14 @@ int ragraph_segment_reduce_f32(const float* X, int D, const int64_t* seg_ptr, in
 int ragraph_proto_cosine_f32(const float* emb, int64_t G, int D, const float* proto, int C, int mode, float* out,
                              void* stream);
 
+/* a13  emb_gate: out = x * sigmoid(z)  -- RAGraph_edge/modules/RAGraph.py:168 (z = x @ gating_weight + gating_bias
+ *      comes from ragraph_linear_f32).  Elementwise over n values; in-place allowed. */
+int ragraph_sigmoid_gate_f32(const float* x, const float* z, int64_t n, float* out, void* stream);
+
+/* a12  edge_times.float(), then (t - t_min) / (t_max - t_min)  -- RAGraph_edge/modules/RAGraph.py:254-257.
+ *      t [n] int64 time steps; t_min / t_max are the caller's reductions (max_step overrides t_max, :255-256). */
+int ragraph_time_rescale_f32(const int64_t* t, int64_t n, float t_min, float t_max, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * torch.topk(scores, k) over a MATERIALISED score matrix (canonical order, agrees with the fused kernel on equal
  * scores) -- few-shot retrieve after mixing structure and semantic similarities

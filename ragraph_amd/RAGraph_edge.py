@@ -54,12 +54,28 @@ class RAGraph(nn.Module):
             self._csr_cache = (key, g, perm)
         return self._csr_cache[1], self._csr_cache[2]
 
+    def _gate_wt(self):
+        """gating_weight^T (the linear kernel takes nn.Linear layout), re-made only when the parameter changes."""
+        w = self.gating_weight
+        tag = (w.data_ptr(), w._version)
+        if getattr(self, "_gate_cache", (None, None))[0] != tag:
+            self._gate_cache = (tag, w.detach().t().contiguous())
+        return self._gate_cache[1]
+
     def emb_gate(self, x):
         """modules/RAGraph.py:168: x * sigmoid(x @ W + b) (dropout p = 0 at inference)."""
         if self.gating_weight is None:
             return x
-        z = K.linear(x, self.gating_weight.t().contiguous(), self.gating_bias.reshape(-1))
-        return x * torch.sigmoid(z)
+        z = K.linear(x, self._gate_wt(), self.gating_bias.reshape(-1))
+        return K.sigmoid_gate(x, z)
+
+    def _time_range(self, edge_times, max_time_step):
+        """(min, max) of the time steps as host scalars (kernel arguments), cached per edge-time tensor."""
+        tag = (edge_times.data_ptr(), edge_times.shape[0])
+        if getattr(self, "_trange", (None,))[0] != tag:
+            self._trange = (tag, float(edge_times.min()), float(edge_times.max()))
+        tmax = self._trange[2] if max_time_step is None else float(max_time_step)
+        return self._trange[1], tmax
 
     def _agg(self, all_emb, edges, edge_norm):
         """modules/RAGraph.py:232-240: out[dst] += emb[src] * norm, as one CSR SpMM (no atomics)."""
@@ -69,11 +85,9 @@ class RAGraph(nn.Module):
     def _relative_edge_time_encoding(self, edges, edge_times, max_step=None):
         """modules/RAGraph.py:250-263.  Returns the softmax in ORIGINAL edge order."""
         g, perm = self._csr(edges)
-        t = edge_times.float()
-        if max_step is None:
-            max_step = t.max()
-        tmin = t.min()
-        t = (t - tmin) / (max_step - tmin)
+        tmin = float(edge_times.min())
+        tmax = float(edge_times.max()) if max_step is None else float(max_step)
+        t = K.time_rescale(edge_times, tmin, tmax)
         sm = K.segment_softmax(g.rowptr, t[perm].contiguous())
         out = torch.empty_like(sm)
         out[perm] = sm
@@ -103,10 +117,8 @@ class RAGraph(nn.Module):
     def forward(self, edges, edge_norm, edge_times, max_time_step=None):
         """modules/RAGraph.py:265-333."""
         g, perm = self._csr(edges)
-        t = edge_times.float()
-        tmax = t.max() if max_time_step is None else max_time_step
-        tmin = t.min()
-        t = ((t - tmin) / (tmax - tmin))[perm].contiguous()
+        tmin, tmax = self._time_range(edge_times, max_time_step)
+        t = K.time_rescale(edge_times[perm].contiguous(), tmin, tmax)                           # :254-257
         time_norm = K.segment_softmax(g.rowptr, t)                                             # :266
         norm = K.axpby(edge_norm[perm].contiguous(), 0.5, time_norm, 0.5)                      # :267
         all_emb = self.emb_gate(torch.cat([self.user_embedding, self.item_embedding], dim=0)).detach()  # :276-277

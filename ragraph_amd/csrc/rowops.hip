@@ -148,6 +148,22 @@ __global__ void __launch_bounds__(256) axpby_kernel(const float* __restrict__ a,
     out[i] = __fadd_rn(__fmul_rn(a[i], wa), __fmul_rn(b[i], wb));
 }
 
+// ---- a13: emb_gate  x * sigmoid(z)  (RAGraph_edge/modules/RAGraph.py:168; z = x @ W + b from the linear kernel) --------
+__global__ void __launch_bounds__(256) sigmoid_gate_kernel(const float* __restrict__ x, const float* __restrict__ z,
+                                                           int64_t n, float* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    out[i] = __fmul_rn(x[i], 1.f / (1.f + expf(-z[i])));
+}
+
+// ---- a12: (t - t_min) / (t_max - t_min) on int64 time steps (RAGraph_edge/modules/RAGraph.py:254-257) ----------------
+__global__ void __launch_bounds__(256) time_rescale_kernel(const int64_t* __restrict__ t, int64_t n, float tmin,
+                                                           float tmax, float* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const float den = tmax - tmin;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = ((float)t[i] - tmin) / den;
+}
+
 // ---- a8: softmax(logits)*(1-lambda) + rag_label*lambda (RAGraph.py:55-57); one thread per row, C is a class count ----
 __global__ void __launch_bounds__(256) softmax_mix_kernel(const float* __restrict__ logits,
                                                           const float* __restrict__ rag, int64_t B, int C,
@@ -321,5 +337,26 @@ extern "C" int ragraph_proto_cosine_f32(const float* emb, int64_t G, int D, cons
   hipLaunchKernelGGL(proto_cosine_kernel, dim3((unsigned)cdiv(G, 4)), dim3(256), 0, as_stream(stream), emb, G, D, proto,
                      C, mode, out);
   RG_CHECK_LAUNCH("proto_cosine");
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_sigmoid_gate_f32(const float* x, const float* z, int64_t n, float* out, void* stream) {
+  RG_REQUIRE(x && z && out, RAGRAPH_EINVAL, "sigmoid_gate: null pointer");
+  if (n <= 0) return RAGRAPH_OK;
+  int64_t blocks = cdiv(n, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sigmoid_gate_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, z, n, out);
+  RG_CHECK_LAUNCH("sigmoid_gate");
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_time_rescale_f32(const int64_t* t, int64_t n, float t_min, float t_max, float* out,
+                                        void* stream) {
+  RG_REQUIRE(t && out, RAGRAPH_EINVAL, "time_rescale: null pointer");
+  if (n <= 0) return RAGRAPH_OK;
+  int64_t blocks = cdiv(n, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(time_rescale_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), t, n, t_min, t_max, out);
+  RG_CHECK_LAUNCH("time_rescale");
   return RAGRAPH_OK;
 }

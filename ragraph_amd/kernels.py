@@ -296,3 +296,23 @@ def position_code(dist: torch.Tensor, anchors: torch.Tensor, dis_q: float = 10.0
     N.check(L.ragraph_position_code_f32(d.data_ptr(), d.shape[0], anchors.data_ptr(), anchors.numel(), float(dis_q),
                                         out.data_ptr(), _stream()), "position_code")
     return out
+
+
+def sigmoid_gate(x: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+    """x * sigmoid(z) -- the embedding gate of RAGraph_edge/modules/RAGraph.py:168."""
+    L = _ready()
+    x = _f32c(x, "sigmoid_gate.x")
+    z = _f32c(z, "sigmoid_gate.z")
+    out = torch.empty_like(x)
+    N.check(L.ragraph_sigmoid_gate_f32(x.data_ptr(), z.data_ptr(), x.numel(), out.data_ptr(), _stream()), "sigmoid_gate")
+    return out
+
+
+def time_rescale(t: torch.Tensor, t_min: float, t_max: float) -> torch.Tensor:
+    """(t - t_min) / (t_max - t_min) on int64 time steps -- RAGraph_edge/modules/RAGraph.py:254-257."""
+    L = _ready()
+    t = _idxc(t, "time_rescale.t")
+    out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+    N.check(L.ragraph_time_rescale_f32(t.data_ptr(), t.numel(), float(t_min), float(t_max), out.data_ptr(), _stream()),
+            "time_rescale")
+    return out
