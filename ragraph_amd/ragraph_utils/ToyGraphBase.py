@@ -130,6 +130,21 @@ class ToyGraphBase:
         sum_v, mean_l = K.gather_reduce(self.resource_values, self.resource_labels, idx)
         return sum_v, mean_l, idx
 
+    # ---- persistence (the reference rebuilds its bank on every run) -------------------
+    def save(self, path: str) -> None:
+        """keys | values | labels as one .pt (the normalised-key cache is derived and rebuilt on load)."""
+        torch.save({"format": "ragraph_amd.bank.v1", "keys": self.resource_keys.cpu(), "values": self.resource_values.cpu(),
+                    "labels": self.resource_labels.cpu()}, path)
+
+    def load(self, path: str, append: bool = False) -> None:
+        blob = torch.load(path, map_location="cpu")
+        if blob.get("format") != "ragraph_amd.bank.v1":
+            raise ValueError(f"{path}: not a ragraph_amd bank file")
+        if not append:
+            for b in (self._keys, self._values, self._labels):
+                b.n = 0
+        self.add_resources(blob["keys"], blob["values"], blob["labels"])
+
     def show(self):
         print("resource_keys", self.resource_keys.shape)
         print("resource_values", self.resource_values.shape)

@@ -327,3 +327,21 @@ def test_forward_is_hip_graph_capturable(dev):
         graph.replay()
         torch.cuda.synchronize()
     assert torch.equal(captured, eager)
+
+
+def test_bank_save_load_roundtrip(dev, tmp_path):
+    from ragraph_amd.ragraph_utils import ToyGraphBase
+
+    tgb = ToyGraphBase(None, 3, 256, 3, device=dev)
+    k, v = torch.randn(500, 256, device=dev), torch.randn(500, 256, device=dev)
+    l = torch.nn.functional.one_hot(torch.randint(0, 3, (500,), device=dev), 3).float()
+    tgb.add_resources(torch.nn.functional.normalize(k, dim=-1), v, l)
+    q = torch.randn(9, 256, device=dev)
+    a = tgb.retrieve_reduced(q)
+    tgb.save(str(tmp_path / "bank.pt"))
+    t2 = ToyGraphBase(None, 3, 256, 3, device=dev)
+    t2.load(str(tmp_path / "bank.pt"))
+    b = t2.retrieve_reduced(q)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    t2.load(str(tmp_path / "bank.pt"), append=True)   # appended duplicates: ties resolve to the lower index
+    assert t2.resource_keys.shape[0] == 1000 and torch.equal(t2.retrieve_reduced(q)[2][:, 0], a[2][:, 0])
