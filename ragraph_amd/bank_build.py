@@ -35,10 +35,12 @@ def compute_sample_prob(adj: torch.Tensor) -> torch.Tensor:
     P[zero] = 1.0 / n
     Pt = P.t().contiguous()
     p = torch.full((n,), 1.0 / n, device=adj.device)
-    for _ in range(1000):
-        new_p = (1 - 0.85) / n + 0.85 * torch.mv(Pt, p)
-        done = torch.norm(new_p - p, p=1) < 1e-6
-        p = new_p
+    for _ in range(125):  # convergence is tested once per 8 power iterations: one host sync instead of eight
+        done = None
+        for _ in range(8):
+            new_p = (1 - 0.85) / n + 0.85 * torch.mv(Pt, p)
+            done = torch.norm(new_p - p, p=1) < 1e-6
+            p = new_p
         if bool(done):
             break
     dc = adj.sum(dim=0) / max(n - 1, 1)

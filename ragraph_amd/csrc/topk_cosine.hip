@@ -628,22 +628,23 @@ __global__ void __launch_bounds__(256) topk_select_kernel(const float* __restric
 // sharded bank).  One wave per query: the lists are staged in LDS once, each lane keeps the heads of <= 4 lists in
 // registers, and a round costs one wave argmax plus one LDS read for the winner -- O(k log 64) instead of O(k * G*k/64).
 template <typename IdxT>
-__global__ void __launch_bounds__(64) topk_merge_sorted_kernel(const float* __restrict__ cs, const IdxT* __restrict__ ci,
+__global__ void __launch_bounds__(256) topk_merge_sorted_kernel(const float* __restrict__ cs, const IdxT* __restrict__ ci,
                                                                int G, int64_t B, int k, int64_t gs, int64_t bs,
                                                                int64_t idx_base, float* __restrict__ out_s,
                                                                int64_t* __restrict__ out_i) {
   extern __shared__ float4 smem4[];
   float* Ls = reinterpret_cast<float*>(smem4);        // [G*k]
   IdxT* Li = reinterpret_cast<IdxT*>(Ls + G * k);     // [G*k]
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const int64_t b = blockIdx.x;
   const int M = G * k;
-  for (int c = lane; c < M; c += 64) {
+  for (int c = threadIdx.x; c < M; c += 256) {  // all 4 waves stage; wave 0 merges
     const int64_t o = (int64_t)(c / k) * gs + b * bs + (c % k);
     Ls[c] = cs[o];
     Li[c] = ci[o];
   }
   __syncthreads();
+  if (threadIdx.x >= 64) return;
   float hs[4];
   int64_t hi[4];
   int hp[4];
@@ -704,7 +705,7 @@ static int launch_merge_sorted(const float* cs, const IdxT* ci, int G, int64_t B
     return RAGRAPH_EUNSUPPORTED;
   }
   const size_t lds = (size_t)G * k * (sizeof(float) + sizeof(IdxT));
-  hipLaunchKernelGGL(topk_merge_sorted_kernel<IdxT>, dim3((unsigned)B), dim3(64), lds, st, cs, ci, G, B, k, gs, bs,
+  hipLaunchKernelGGL(topk_merge_sorted_kernel<IdxT>, dim3((unsigned)B), dim3(256), lds, st, cs, ci, G, B, k, gs, bs,
                      idx_base, out_s, out_i);
   RG_CHECK_LAUNCH("topk_merge_sorted");
   return RAGRAPH_OK;
