@@ -1,4 +1,6 @@
-"""Mirror of RAGraph_*/ragraph_utils/TaskDecoder.py: fc2(LeakyReLU(fc1(x))), same parameter names (fc1, fc2)."""
+"""Decoder head of RAGraph (mirrors RAGraph_*/ragraph_utils/TaskDecoder.py: a two-layer MLP with LeakyReLU between,
+state_dict keys fc1.* / fc2.*).  The nn.Linear objects only hold the parameters; both GEMMs run on the HIP linear
+kernel, the first with LeakyReLU fused into its epilogue, and are differentiable through ragraph_amd.autograd."""
 import torch.nn as nn
 
 from .. import autograd as A
@@ -6,17 +8,25 @@ from .. import kernels as K
 
 
 class TaskDecoder(nn.Module):
+    NEGATIVE_SLOPE = 0.01  # nn.LeakyReLU() default, TaskDecoder.py:7
+
     def __init__(self, input_dim, hiddden_dim, output_dim):
         super().__init__()
-        self.fc1 = nn.Linear(input_dim, hiddden_dim)   # parameter containers only; the math runs in libragraph_hip
-        self.act = nn.LeakyReLU()
-        self.fc2 = nn.Linear(hiddden_dim, output_dim)
+        widths = {"fc1": (input_dim, hiddden_dim), "fc2": (hiddden_dim, output_dim)}
+        for name, (fan_in, fan_out) in widths.items():
+            self.add_module(name, nn.Linear(fan_in, fan_out))
+
+    def layers(self):
+        return self.fc1, self.fc2
 
     def reset_parameters(self):
-        self.fc1.reset_parameters()
-        self.fc2.reset_parameters()
+        for layer in self.layers():
+            layer.reset_parameters()
 
     def forward(self, x):
-        # TaskDecoder.py:14-17; LeakyReLU is fused into the first GEMM's epilogue
-        h = A.linear(x, self.fc1.weight, self.fc1.bias, act=K.ACT_LEAKY, alpha=self.act.negative_slope)
-        return A.linear(h, self.fc2.weight, self.fc2.bias)
+        first, second = self.layers()
+        hidden = A.linear(x, first.weight, first.bias, act=K.ACT_LEAKY, alpha=self.NEGATIVE_SLOPE)
+        return A.linear(hidden, second.weight, second.bias)
+
+    def extra_repr(self):
+        return f"{self.fc1.in_features} -> {self.fc1.out_features} -> {self.fc2.out_features}, HIP linear kernels"
