@@ -824,9 +824,12 @@ static int launch_topk_ring(const TopkParams& p, int64_t qtiles, hipStream_t st)
 template <int D>
 static int launch_topk(const TopkParams& p, int64_t qtiles, hipStream_t st) {
   // the barrier-free 3-slot ring needs 3 x 33 KB of stages next to the 2 KB * k of lists in the 160 KB LDS
-  const char* ring_env = getenv("RAGRAPH_TOPK_RING");  // diagnostic override: 2 or 3
+  static const int ring_env = [] {  // diagnostic override (read once): RAGRAPH_TOPK_RING = 2 or 3
+    const char* e = getenv("RAGRAPH_TOPK_RING");
+    return e ? atoi(e) : 3;
+  }();
   const bool fits3 = TopkCfg<D>::lds_bytes(p.k, 3) <= 160 * 1024;
-  const bool want3 = ring_env ? atoi(ring_env) == 3 : true;
+  const bool want3 = ring_env == 3;
   if (fits3 && want3 && !(p.ablate & 6)) return launch_topk_ring<D, 3>(p, qtiles, st);
   return launch_topk_ring<D, 2>(p, qtiles, st);
 }
@@ -941,10 +944,11 @@ extern "C" int ragraph_topk_cosine_f32(const float* Q, int64_t B, const float* K
   p.keys_per_split = pl.keys_per_split;
   p.part_s = part_s;
   p.part_i = part_i;
-  {
-    const char* ab = getenv("RAGRAPH_TOPK_ABLATE");
-    p.ablate = ab ? atoi(ab) : 0;
-  }
+  static const int ablate_env = [] {  // timing-only diagnostic switches (read once), see TopkParams::ablate
+    const char* e = getenv("RAGRAPH_TOPK_ABLATE");
+    return e ? atoi(e) : 0;
+  }();
+  p.ablate = ablate_env;
   const int64_t qtiles = cdiv(B, 256);
   p.thr_init = nullptr;
   if (B <= SMALLB_MAX) {
