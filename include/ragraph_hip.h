@@ -66,8 +66,9 @@ int ragraph_normalize_rows_f32(const float* X, int64_t n, int D, float* out, voi
  *   Q   [B,D] raw (un-normalised) queries; normalised inside (a1) into the workspace.
  *   Kn  [N,D] key bank ALREADY row-normalised by ragraph_normalize_rows_f32 (done once per bank version; the
  *       reference re-normalises its stored keys on every call, SimilarityFunctions.py:11).
- *   k   1 <= k <= min(N, RAGRAPH_TOPK_MAX).  D in {64,128,256}.  B,N >= 1.  B <= 16 takes the HBM-streaming
- *       small-batch kernel (16x16x4 MFMA), larger B the MFMA-bound tile kernel (32x32x2); same numerics.
+ *   k   1 <= k <= min(N, RAGRAPH_TOPK_MAX).  D in {64,128,256}.  B,N >= 1.  B <= 128 takes the wave-streaming
+ *       kernel (groups of 16 queries on 16x16x4 MFMA; HBM-bound up to 16 queries), larger B the MFMA-bound tile
+ *       kernel (256 queries per workgroup on 32x32x2); same numerics, so B never changes a bit of the result.
  *       32 < k <= 64 materialises ~1 GiB slabs of scores in the workspace (dense kernel + row top-k), same bits.
  *   idx_base  added to every returned index (this shard's first global row).
  *   out_scores [B,k] fp32 descending; out_idx [B,k] int64 (torch indexing dtype).

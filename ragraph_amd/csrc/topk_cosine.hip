@@ -76,6 +76,7 @@ struct TopkParams {
   int64_t B, N;
   int k;
   int nsplit;
+  int ngroups;             // small/mid-batch kernel: groups of 16 queries (workgroup b serves group b % ngroups)
   int64_t qtiles;          // query tiles of 256 (big kernel)
   int xcd_map;             // 1: XCD-aware block mapping (enough query tiles to give every XCD its own)
   int64_t keys_per_split;  // multiple of the stage size
@@ -407,14 +408,21 @@ __global__ void __launch_bounds__(512, 2) topk_smallb_kernel(TopkParams p) {
   // B operand: query j, k-slots sl, sl+4, ...  (queries >= B are clamped; their lists are never offered to).
   // The queries arrive RAW: each wave normalises them itself with the same reduction tree and the same correctly
   // rounded sqrt / divide as normalize_rows_kernel (bit-identical), which saves a launch on this latency-bound path.
+  // Workgroup b serves query group b % G (16 queries) and is the (b / G)-th of the gridDim.x / G workgroups that sweep
+  // the bank for that group.  With G > 1 every group streams the whole bank; the groups run side by side, so the
+  // re-reads are L2 / Infinity-Cache hits and HBM still sees the bank about once.
+  const int G = p.ngroups;
+  const int grp = blockIdx.x % G;
+  const int wgi = blockIdx.x / G, nwg = gridDim.x / G;
+  const int64_t qbase = (int64_t)grp * 16;
   float breg[D / 4];
   {
     float my_d = 1.f;
-    const int nq = (int)p.B;
+    const int nq = (int)min((int64_t)16, p.B - qbase);  // queries of this group
     for (int jj = 0; jj < nq; ++jj) {
       float pp = 0.f;
       for (int c = lane; c < D / 4; c += 64) {
-        const float4 v = reinterpret_cast<const float4*>(p.Qn + (int64_t)jj * D)[c];
+        const float4 v = reinterpret_cast<const float4*>(p.Qn + (qbase + jj) * D)[c];
         pp = fmaf(v.x, v.x, pp);
         pp = fmaf(v.y, v.y, pp);
         pp = fmaf(v.z, v.z, pp);
@@ -425,7 +433,7 @@ __global__ void __launch_bounds__(512, 2) topk_smallb_kernel(TopkParams p) {
       const float d = fmaxf(sqrtf(pp), 1e-12f);
       if (jj == j || (j >= nq && jj == nq - 1)) my_d = d;
     }
-    const int64_t q = (j < p.B) ? j : p.B - 1;
+    const int64_t q = (qbase + j < p.B) ? qbase + j : p.B - 1;
     const float4* qp = reinterpret_cast<const float4*>(p.Qn + q * D);
 #pragma unroll
     for (int m = 0; m < D / 4; ++m) {
@@ -440,11 +448,11 @@ __global__ void __launch_bounds__(512, 2) topk_smallb_kernel(TopkParams p) {
   }
 
   const int64_t ntiles = (p.N + C::TILE_KEYS - 1) / C::TILE_KEYS;
-  const int64_t gw = (int64_t)blockIdx.x * C::WAVES + wave, nw = (int64_t)gridDim.x * C::WAVES;
-  const bool live = j < p.B;
+  const int64_t gw = (int64_t)wgi * C::WAVES + wave, nw = (int64_t)nwg * C::WAVES;
+  const bool live = qbase + j < p.B;
   // A floor from the sampled pre-pass (k-th best over a prefix of the bank) is a valid lower bound of the final k-th
   // best: keys below it can never be selected, so the lists only ever see the few keys that can.
-  const float thr_floor = (live && p.thr_init) ? p.thr_init[(int64_t)j * k + k - 1] : RG_NEG_INF;
+  const float thr_floor = (live && p.thr_init) ? p.thr_init[(qbase + j) * k + k - 1] : RG_NEG_INF;
   float thr = live ? thr_floor : __builtin_huge_valf();
 
   float4 pre[16];
@@ -528,7 +536,7 @@ __global__ void __launch_bounds__(512, 2) topk_smallb_kernel(TopkParams p) {
 
   // ---- workgroup merge: 8 wave lists per query -> one sorted partial per (query, workgroup) -------------------
   __syncthreads();
-  for (int q = wave; q < (int)p.B; q += C::WAVES) {
+  for (int q = wave; q < 16 && qbase + q < p.B; q += C::WAVES) {
     float prev_s = __builtin_huge_valf();
     int prev_i = -1;
     for (int r = 0; r < k; ++r) {
@@ -554,7 +562,7 @@ __global__ void __launch_bounds__(512, 2) topk_smallb_kernel(TopkParams p) {
         }
       }
       if (lane == 0) {
-        const int64_t o = ((int64_t)q * gridDim.x + blockIdx.x) * k + r;
+        const int64_t o = ((qbase + q) * nwg + wgi) * k + r;
         p.part_s[o] = best_s;
         p.part_i[o] = best_i;
       }
@@ -746,14 +754,26 @@ struct TopkPlan {
   size_t qn_bytes, part_s_bytes, part_i_bytes;
 };
 
-static const int SMALLB_MAX = 16;
+// Up to this many queries take the wave-streaming kernel (groups of 16 queries, 16x16x4 MFMA): it fills the chip at any
+// batch size, whereas the tile kernel needs >= a few query tiles of 256 to do so (measured crossover).
+static const int SMALLB_MAX = 128;  // measured at N = 1M, D = 256: streaming 0.49 / 0.78 / 1.36 ms at B = 32 / 64 / 128; tile kernel 1.5 ms flat up to B = 256
+// its 8 wave-private 16 KiB tiles + lists must fit the 160 KiB LDS
+static bool use_streaming(int64_t B, int k) {
+  static const int64_t bmax = [] {  // RAGRAPH_TOPK_STREAM_MAX: diagnostic override of the crossover (read once)
+    const char* e = getenv("RAGRAPH_TOPK_STREAM_MAX");
+    return e ? (int64_t)atoi(e) : (int64_t)SMALLB_MAX;
+  }();
+  return B <= bmax && 8 * (16512 + 128 * (size_t)k) <= 160 * 1024;
+}
 
 static TopkPlan plan_topk(int64_t B, int64_t N, int D, int k) {
-  if (B <= SMALLB_MAX) {  // small-batch kernel: nsplit = workgroups (one sorted partial list each)
+  if (use_streaming(B, k)) {  // streaming kernel: nsplit = workgroups PER GROUP (one sorted partial list each)
     const int tile_keys = 16 * (256 / D);
     const int64_t ntiles = cdiv(N, tile_keys);
+    const int64_t G = cdiv(B, 16);
     int64_t wgs = cdiv(ntiles, 8 * 2);  // >= 2 tiles per wave so the prefetch has something to overlap
-    if (wgs > 256) wgs = 256;
+    const int64_t cap = G <= 2 ? 256 : (512 / G > 0 ? 512 / G : 1);  // ~256-512 workgroups in total
+    if (wgs > cap) wgs = cap;
     if (wgs * k > 4096) wgs = 4096 / k;  // the select kernel holds <= 4096 candidates per query
     if (wgs < 1) wgs = 1;
     TopkPlan ps;
@@ -848,7 +868,7 @@ static int launch_smallb(const TopkParams& p, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(topk_smallb_kernel<D>, dim3((unsigned)p.nsplit), dim3(512), lds, st, p);
+  hipLaunchKernelGGL(topk_smallb_kernel<D>, dim3((unsigned)(p.nsplit * p.ngroups)), dim3(512), lds, st, p);
   RG_CHECK_LAUNCH("topk_cosine(small batch)");
   return RAGRAPH_OK;
 }
@@ -927,18 +947,20 @@ extern "C" int ragraph_topk_cosine_f32(const float* Q, int64_t B, const float* K
   int* part_i = reinterpret_cast<int*>(w + pl.qn_bytes + pl.part_s_bytes);
 
   int rc = RAGRAPH_OK;
-  if (B > SMALLB_MAX) {  // the small-batch kernel normalises its <= 16 queries itself
+  const bool streaming = use_streaming(B, k);
+  if (!streaming) {  // the streaming kernel normalises its queries itself
     rc = ragraph_normalize_rows_f32(Q, B, D, Qn, stream);
     if (rc != RAGRAPH_OK) return rc;
   }
 
   TopkParams p;
-  p.Qn = (B > SMALLB_MAX) ? Qn : Q;
+  p.Qn = streaming ? Q : Qn;
   p.Kn = Kn;
   p.B = B;
   p.N = N;
   p.k = k;
   p.nsplit = pl.nsplit;
+  p.ngroups = (int)cdiv(B, 16);
   p.qtiles = cdiv(B, 256);
   p.xcd_map = p.qtiles >= 64 ? 1 : 0;
   p.keys_per_split = pl.keys_per_split;
@@ -951,8 +973,8 @@ extern "C" int ragraph_topk_cosine_f32(const float* Q, int64_t B, const float* K
   p.ablate = ablate_env;
   const int64_t qtiles = cdiv(B, 256);
   p.thr_init = nullptr;
-  if (B <= SMALLB_MAX) {
-    // 4..16 queries: each of the ~2000 waves sees only N/2000 keys, so its lists would stay in their warm-up for the
+  if (streaming) {
+    // >= 4 queries: each of the ~2000 waves sees only N/2000 keys, so its lists would stay in their warm-up for the
     // whole stream.  A pre-pass over a 4096-key prefix (1/256 of a 1M bank) gives every query the k-th best score of
     // that prefix -- a valid lower bound of the final k-th best -- and the main pass then only ever inserts the
     // ~k*N/4096 keys per query that beat it.  For 1-3 queries the two extra launches cost more than they save.
@@ -960,7 +982,8 @@ extern "C" int ragraph_topk_cosine_f32(const float* Q, int64_t B, const float* K
     if (B >= 4 && N >= 16 * prefix && k <= prefix) {
       TopkParams pp = p;
       pp.N = prefix;
-      pp.nsplit = (int)cdiv(cdiv(prefix, 16 * (256 / D)), 8);  // one tile per wave
+      pp.nsplit = (int)cdiv(cdiv(prefix, 16 * (256 / D)), 8);  // one tile per wave ...
+      if (pp.nsplit > pl.nsplit) pp.nsplit = pl.nsplit;         // ... within the main pass's partial-list workspace
       rc = D == 256 ? launch_smallb<256>(pp, st) : D == 128 ? launch_smallb<128>(pp, st) : launch_smallb<64>(pp, st);
       if (rc != RAGRAPH_OK) return rc;
       rc = launch_merge_sorted<int>(part_s, part_i, pp.nsplit, B, k, (int64_t)k, (int64_t)pp.nsplit * k, 0, out_scores,
@@ -979,7 +1002,7 @@ extern "C" int ragraph_topk_cosine_f32(const float* Q, int64_t B, const float* K
   if (rc != RAGRAPH_OK) return rc;
 
   // partial layout [B][nsplit][k]: list g of query b at b*(nsplit*k) + g*k
-  if (B <= SMALLB_MAX)  // per-workgroup partials of the small-batch kernel are sorted
+  if (streaming)  // per-workgroup partials of the streaming kernel are sorted
     return launch_merge_sorted<int>(part_s, part_i, pl.nsplit, B, k, (int64_t)k, (int64_t)pl.nsplit * k, idx_base,
                                     out_scores, out_idx, st);
   return launch_select<int>(part_s, part_i, pl.nsplit, B, k, (int64_t)k, (int64_t)pl.nsplit * k, idx_base, out_scores,

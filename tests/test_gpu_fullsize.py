@@ -40,8 +40,9 @@ def test_full_bank_oracle_sample_and_properties(dev, bank1m):
     assert bool((srt[:, 1:] != srt[:, :-1]).all())
     s2, i2 = K.topk_cosine(q, kn, k)
     assert torch.equal(s, s2) and torch.equal(i, i2)  # idempotent / deterministic (no atomics anywhere)
-    # query-batch independence across kernel variants and split plans: B = 1, 7, 16 (small-batch kernel), 17, 300, 1000
-    for lo, B in [(5, 1), (100, 7), (32, 16), (64, 17), (1000, 300), (2000, 1000)]:
+    # query-batch independence across kernel variants and split plans: B = 1..128 (streaming kernel, 1-8 groups of 16
+    # queries, with and without the pre-pass), 129, 300, 1000 (tile kernel, 1-4 query tiles)
+    for lo, B in [(5, 1), (100, 7), (32, 16), (64, 17), (500, 100), (700, 128), (800, 129), (1000, 300), (2000, 1000)]:
         sb, ib = K.topk_cosine(q[lo:lo + B].contiguous(), kn, k)
         assert torch.equal(ib, i[lo:lo + B]) and torch.equal(sb, s[lo:lo + B]), f"B={B} differs from the 4096 batch"
     # smaller k is a prefix of larger k

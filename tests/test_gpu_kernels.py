@@ -57,6 +57,9 @@ def test_normalize_rows_bit_exact(dev, n, D):
         (5, 70000, 256, 10),     # small-batch kernel with the sampled-threshold pre-pass (4 <= B <= 16, N >= 64k)
         (16, 131072, 64, 7),
         (3, 70000, 128, 10),     # small-batch kernel without the pre-pass
+        (100, 70000, 256, 10),   # streaming kernel, 7 groups of 16 queries (last one ragged), with pre-pass
+        (128, 100000, 64, 5),    # 8 groups (largest batch the streaming kernel takes)
+        (40, 3000, 256, 31),     # largest k the streaming kernel's LDS holds
     ],
 )
 def test_topk_cosine_bit_exact(dev, B, N, D, k):
