@@ -757,17 +757,18 @@ struct TopkPlan {
 // Up to this many queries take the wave-streaming kernel (groups of 16 queries, 16x16x4 MFMA): it fills the chip at any
 // batch size, whereas the tile kernel needs >= a few query tiles of 256 to do so (measured crossover).
 static const int SMALLB_MAX = 128;  // measured at N = 1M, D = 256: streaming 0.49 / 0.78 / 1.36 ms at B = 32 / 64 / 128; tile kernel 1.5 ms flat up to B = 256
-// its 8 wave-private 16 KiB tiles + lists must fit the 160 KiB LDS
-static bool use_streaming(int64_t B, int k) {
+// its 8 wave-private 16 KiB tiles + lists must fit the 160 KiB LDS (k <= 31 at D = 256, 30 at D = 128, 28 at D = 64)
+static bool use_streaming(int64_t B, int k, int D) {
   static const int64_t bmax = [] {  // RAGRAPH_TOPK_STREAM_MAX: diagnostic override of the crossover (read once)
     const char* e = getenv("RAGRAPH_TOPK_STREAM_MAX");
     return e ? (int64_t)atoi(e) : (int64_t)SMALLB_MAX;
   }();
-  return B <= bmax && 8 * (16512 + 128 * (size_t)k) <= 160 * 1024;
+  const size_t tile_bytes = sizeof(float) * 16 * (256 / D) * (D + 2);  // SmallCfg<D>::TILE_FLOATS
+  return B <= bmax && 8 * (tile_bytes + 128 * (size_t)k) <= 160 * 1024;
 }
 
 static TopkPlan plan_topk(int64_t B, int64_t N, int D, int k) {
-  if (use_streaming(B, k)) {  // streaming kernel: nsplit = workgroups PER GROUP (one sorted partial list each)
+  if (use_streaming(B, k, D)) {  // streaming kernel: nsplit = workgroups PER GROUP (one sorted partial list each)
     const int tile_keys = 16 * (256 / D);
     const int64_t ntiles = cdiv(N, tile_keys);
     const int64_t G = cdiv(B, 16);
@@ -947,7 +948,7 @@ extern "C" int ragraph_topk_cosine_f32(const float* Q, int64_t B, const float* K
   int* part_i = reinterpret_cast<int*>(w + pl.qn_bytes + pl.part_s_bytes);
 
   int rc = RAGRAPH_OK;
-  const bool streaming = use_streaming(B, k);
+  const bool streaming = use_streaming(B, k, D);
   if (!streaming) {  // the streaming kernel normalises its queries itself
     rc = ragraph_normalize_rows_f32(Q, B, D, Qn, stream);
     if (rc != RAGRAPH_OK) return rc;

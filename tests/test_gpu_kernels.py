@@ -241,3 +241,55 @@ def test_errors_are_loud(dev):
         K.topk_cosine(torch.randn(4, 64, device=dev), torch.randn(3, 64, device=dev), 5)  # k > N
     with pytest.raises(K.RagraphNativeError):
         K.topk_cosine(torch.randn(4, 64), torch.randn(30, 64), 5)  # CPU tensors: no fallback
+
+
+def test_topk_cosine_fuzz_against_oracle(dev):
+    """60 random shapes across all kernel paths (streaming with 1-8 groups, with / without the pre-pass; tile kernel
+    with 1-3 query tiles, ring and barrier variants; materialised k > 32), ragged sizes, duplicate keys, zero queries."""
+    from ragraph_amd import kernels as K
+
+    rng = np.random.default_rng(2024)
+    for trial in range(60):
+        D = int(rng.choice([64, 128, 256]))
+        B = int(rng.choice([1, 2, 3, 5, 15, 16, 17, 31, 33, 64, 100, 128, 129, 200, 257, 520]))
+        N = int(rng.choice([1, 2, 7, 31, 33, 100, 511, 1000, 4097, 9999, 70001]))
+        k = int(min(N, rng.choice([1, 2, 3, 5, 10, 17, 31, 32, 33, 50, 64])))
+        keys = rng.standard_normal((N, D), dtype=np.float32)
+        if trial % 3 == 0 and N > 4:
+            keys[N // 2:] = keys[: N - N // 2]            # duplicates -> exact ties
+        kn = cref.normalize_rows(keys)
+        q = rng.standard_normal((B, D), dtype=np.float32)
+        if trial % 5 == 0:
+            q[rng.integers(0, B)] = 0.0                   # zero-norm query
+        base = int(rng.choice([0, 7, 1_000_000]))
+        s, i = K.topk_cosine(_t(q, dev), _t(kn, dev), k, idx_base=base)
+        rs, ri = cref.topk_cosine(q, kn, k, idx_base=base)
+        assert np.array_equal(i.cpu().numpy(), ri), f"indices differ: B={B} N={N} D={D} k={k}"
+        assert np.array_equal(s.cpu().numpy(), rs), f"scores differ: B={B} N={N} D={D} k={k}"
+
+
+def test_spmm_linear_fuzz_against_oracle(dev):
+    """Random shapes for the CSR SpMM (all lane-group variants, empty / long rows, every epilogue) and the dense kernel."""
+    from ragraph_amd import kernels as K
+
+    rng = np.random.default_rng(77)
+    for trial in range(40):
+        n = int(rng.choice([1, 2, 5, 63, 64, 65, 300, 1025]))
+        ncols = int(rng.choice([1, 7, 64, 500]))
+        D = int(rng.choice([4, 8, 12, 60, 64, 68, 128, 192, 256, 260, 512]))
+        rowptr, col, val = _rand_csr(rng, n, ncols, int(rng.choice([0, 1, 4, 20])), empty_rows=True)
+        X = rng.standard_normal((ncols, D), dtype=np.float32)
+        act = int(rng.integers(0, 5))
+        b = rng.standard_normal(D, dtype=np.float32) if trial % 2 else None
+        Yin = rng.standard_normal((n, D), dtype=np.float32) if trial % 3 == 0 else None
+        got = K.spmm_csr(_t(rowptr, dev), _t(col, dev), _t(val, dev), _t(X, dev), bias=None if b is None else _t(b, dev),
+                         act=act, alpha=0.3, beta=0.5, y_in=None if Yin is None else _t(Yin, dev)).cpu().numpy()
+        ref = cref.spmm_csr(rowptr, col, val, X, bias=b, act=act, alpha=0.3, beta=0.5, Y_in=Yin)
+        if act == 4:  # ELU calls expm1f: libm differs between host and device
+            assert np.allclose(got, ref, rtol=1e-6, atol=1e-6), f"spmm n={n} D={D} act={act}"
+        else:
+            assert np.array_equal(got, ref), f"spmm n={n} D={D} act={act}"
+        M, Kd, Nd = int(rng.choice([1, 31, 64, 65, 200])), int(rng.choice([1, 5, 32, 33, 100, 257])), int(rng.choice([1, 3, 64, 70]))
+        A = rng.standard_normal((M, Kd), dtype=np.float32)
+        W = rng.standard_normal((Nd, Kd), dtype=np.float32)
+        assert np.array_equal(K.linear(_t(A, dev), _t(W, dev)).cpu().numpy(), cref.linear(A, W)), f"linear {M}x{Kd}x{Nd}"
