@@ -80,6 +80,18 @@ size_t ragraph_topk_cosine_workspace_bytes(int64_t B, int64_t N, int D, int k);
 int ragraph_topk_cosine_f32(const float* Q, int64_t B, const float* Kn, int64_t N, int D, int k, int64_t idx_base,
                             float* out_scores, int64_t* out_idx, void* ws, size_t ws_bytes, void* stream);
 
+/* Bank-resident form of a1.  The reference keeps resource_keys on the device between calls (ToyGraphBase.py:40-48
+ * set_resources / add_resources); the stored bank here is Kn plus, optionally, a PACKED copy of the same rows
+ * (row n = [Kn[n][0], Kn[n][2], ... | Kn[n][1], Kn[n][3], ...]) made once per bank update by ragraph_pack_keys_f32.
+ * With Kp != NULL, D = 256 and k <= 14 the tile kernel (B > 128) moves the key stream HBM -> LDS by DMA
+ * (global_load_lds_dwordx4) instead of through registers.  Results are bit-identical with and without Kp;
+ * ragraph_topk_cosine_f32 is this call with Kp = NULL.  Kp holds exactly the values of Kn (caller's contract).
+ */
+int ragraph_pack_keys_f32(const float* Kn, int64_t N, int D, float* Kp, void* stream);
+int ragraph_topk_cosine_bank_f32(const float* Q, int64_t B, const float* Kn, const float* Kp, int64_t N, int D, int k,
+                                 int64_t idx_base, float* out_scores, int64_t* out_idx, void* ws, size_t ws_bytes,
+                                 void* stream);
+
 /* Cross-shard / cross-split merge of sorted top-k lists (no counterpart in the reference: it is single-GPU).
  *   scores,idx [G,B,k] (list g of query b at ((g*B)+b)*k) -> out [B,k], canonical order; result independent of G.
  *   G*k <= 4096.

@@ -33,6 +33,8 @@ SIGNATURES = {
     "ragraph_normalize_rows_f32": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "ragraph_topk_cosine_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
     "ragraph_topk_cosine_f32": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "ragraph_pack_keys_f32": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "ragraph_topk_cosine_bank_f32": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _sz, _vp]),
     "ragraph_topk_merge_f32": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     "ragraph_gather_rows_f32": (_i32, [_vp, _i64, _i32, _vp, _i64, _i64, _vp, _vp]),
     "ragraph_gather_reduce_f32": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp, _i64, _i32, _i64, _f32, _vp, _vp, _vp]),

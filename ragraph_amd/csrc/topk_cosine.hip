@@ -73,6 +73,7 @@ __device__ __forceinline__ void list_insert_lane(float* ls, int* li, int k, int 
 struct TopkParams {
   const float* Qn;   // [B,D] normalised queries (big kernel) / RAW queries (small-batch kernel)
   const float* Kn;   // [N,D] normalised keys
+  const float* Kp;   // [N,D] the same rows packed [even k | odd k] (ragraph_pack_keys_f32) for the LDS-DMA ring, or NULL
   int64_t B, N;
   int k;
   int nsplit;
@@ -101,8 +102,10 @@ struct TopkCfg {
   // RING = 2: double buffer + one workgroup barrier per stage.  RING = 3: three slots handed over through FULL / FREE
   // counters in LDS, no barrier: a wave may run up to one stage ahead of or behind the others, so a wave that is busy
   // inserting candidates does not stall the other seven (the barrier made every stage as slow as its slowest wave).
+  // RING = 4 (D = 256, packed bank): four slots filled by LDS-DMA (global_load_lds_dwordx4), same counters; the fourth
+  // slot pays for the later FULL signal (a DMA is signalled one stage after it was issued) so the one-stage slack stays.
   static size_t lds_bytes(int k, int ring) {
-    return sizeof(float) * ((size_t)ring * STAGE_FLOATS) + (size_t)k * QT * 8 + (ring == 3 ? 32 : 0);
+    return sizeof(float) * ((size_t)ring * STAGE_FLOATS) + (size_t)k * QT * 8 + (ring >= 3 ? 32 : 0);
   }
 };
 
@@ -113,6 +116,9 @@ __device__ __forceinline__ void ring_signal(unsigned* ctr, int lane) {  // after
   if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+typedef __attribute__((address_space(3))) void lds_void;        // operand types of __builtin_amdgcn_global_load_lds
+typedef __attribute__((address_space(1))) const void gbl_void;
+
 template <int D, int RING>
 __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
   using C = TopkCfg<D>;
@@ -122,8 +128,8 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
   constexpr int OFF_LS = RING * C::STAGE_FLOATS;  // [QT][k] scores, then [QT][k] indices: one SORTED list per query
   float* ls = smem + OFF_LS;
   int* li = reinterpret_cast<int*>(smem + OFF_LS + p.k * C::QT);
-  unsigned* full = reinterpret_cast<unsigned*>(smem + OFF_LS + 2 * p.k * C::QT);  // [3] wave-writes per slot (RING 3)
-  unsigned* freec = full + 4;                                                       // [3] wave-reads-done per slot
+  unsigned* full = reinterpret_cast<unsigned*>(smem + OFF_LS + 2 * p.k * C::QT);  // [RING] wave-writes per slot
+  unsigned* freec = full + 4;                                                       // [RING] wave-reads-done per slot
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -319,6 +325,57 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
       if (more && !(p.ablate & 2)) RG_STAGE_WRITE((s + 1) & 1);
       if (!(p.ablate & 4)) __syncthreads();
     }
+  } else if constexpr (RING == 4) {
+    // LDS-DMA ring over the PACKED bank: a stage row is 1 KiB contiguous in HBM and in LDS, so ONE
+    // global_load_lds_dwordx4 per row (wave-uniform LDS base, lane l -> bytes 16 l) fills it with no VGPRs and no
+    // ds_write.  Wave w owns rows 4w..4w+3 of every stage.  Stage s+3 is issued at the end of iteration s into the slot
+    // stage s-1 lived in, retired (s_waitcnt vmcnt(0)) and signalled FULL at the end of iteration s+1, read in s+3.
+    static_assert(D == 256, "one wave-instruction must cover exactly one padded LDS row");
+    const unsigned lds_base = (unsigned)(size_t)(lds_void*)smem;  // LDS byte address of the dynamic segment
+    auto dma_stage = [&](int s_, int slot_) {
+      const int64_t key0_ = n_begin + (int64_t)s_ * C::STAGE_KEYS + wave * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t r_ = min(key0_ + i, p.N - 1);  // tail: duplicate the last key, masked by index later
+        const float* g_ = p.Kp + r_ * D + 4 * lane;
+        // Issued as asm, not __builtin_amdgcn_global_load_lds: hipcc makes every later ds_read wait vmcnt(0) for a DMA
+        // it knows about (possible alias), which would expose the DMA latency at the top of each stage.  The waits for
+        // these loads are the explicit s_waitcnt vmcnt(0) statements below.
+        const unsigned dst_ = lds_base + 4u * (unsigned)(slot_ * C::STAGE_FLOATS + (wave * 4 + i) * C::ROW);
+        unsigned keep_;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            : "=&s"(keep_)
+            : "v"(g_), "s"(__builtin_amdgcn_readfirstlane(dst_))
+            : "memory");
+      }
+    };
+    if (tid < 8) full[tid] = 0;
+    const int pro = nstages < 3 ? nstages : 3;
+    for (int s = 0; s < pro; ++s) dma_stage(s, s);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < pro) full[tid] = C::WAVES;
+    __syncthreads();
+    int pending = -1;
+    for (int s = 0; s < nstages; ++s) {
+      const int slot = s & 3, gen = s >> 2;
+      ring_wait(full + slot, (unsigned)(C::WAVES * (gen + 1)));      // all 8 waves' rows of stage s have landed
+      compute_stage(s, slot * C::STAGE_FLOATS);
+      ring_signal(freec + slot, lane);                               // this wave is done reading stage s
+      if (pending >= 0) {                                            // the DMA issued one iteration ago
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ring_signal(full + pending, lane);
+        pending = -1;
+      }
+      if (s + 3 < nstages) {
+        const int ws = (s + 3) & 3;                                  // the slot stage s-1 lived in
+        ring_wait(freec + ws, (unsigned)(C::WAVES * ((s + 3) >> 2))); // all 8 waves are done reading stage s-1
+        dma_stage(s + 3, ws);
+        pending = ws;
+      }
+    }
+    __syncthreads();
   } else {
     // slots 0 and 1 are filled up front; afterwards stage s+2 is loaded during stage s and written behind it
     if (tid < 8) full[tid] = 0;
@@ -845,12 +902,16 @@ static int launch_topk_ring(const TopkParams& p, int64_t qtiles, hipStream_t st)
 template <int D>
 static int launch_topk(const TopkParams& p, int64_t qtiles, hipStream_t st) {
   // the barrier-free 3-slot ring needs 3 x 33 KB of stages next to the 2 KB * k of lists in the 160 KB LDS
-  static const int ring_env = [] {  // diagnostic override (read once): RAGRAPH_TOPK_RING = 2 or 3
+  static const int ring_env = [] {  // diagnostic override (read once): RAGRAPH_TOPK_RING = 2, 3 or 4
     const char* e = getenv("RAGRAPH_TOPK_RING");
-    return e ? atoi(e) : 3;
+    return e ? atoi(e) : 4;
   }();
   const bool fits3 = TopkCfg<D>::lds_bytes(p.k, 3) <= 160 * 1024;
-  const bool want3 = ring_env == 3;
+  const bool want3 = ring_env >= 3;
+  if constexpr (D == 256) {
+    const bool fits4 = TopkCfg<D>::lds_bytes(p.k, 4) <= 160 * 1024;
+    if (p.Kp && fits4 && ring_env != 2 && ring_env != 3 && !(p.ablate & 6)) return launch_topk_ring<D, 4>(p, qtiles, st);
+  }
   if (fits3 && want3 && !(p.ablate & 6)) return launch_topk_ring<D, 3>(p, qtiles, st);
   return launch_topk_ring<D, 2>(p, qtiles, st);
 }
@@ -907,10 +968,50 @@ __global__ void __launch_bounds__(256) add_idx_base_kernel(int64_t* idx, int64_t
 }
 }  // namespace ragraph
 
+namespace ragraph {
+// Kp[n] = [Kn[n][0], Kn[n][2], ... | Kn[n][1], Kn[n][3], ...]: the tile kernel's LDS row image, made once per bank
+// update so the stream can be moved HBM -> LDS by DMA.  One float4 of output per thread.
+__global__ void __launch_bounds__(256) pack_keys_kernel(const float* __restrict__ Kn, int64_t n4, int D,
+                                                        float* __restrict__ Kp) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // output float4 index
+  if (i >= n4) return;
+  const int per_row = D / 4, half = D / 8;
+  const int64_t row = i / per_row;
+  const int c = (int)(i % per_row);
+  const int odd = c >= half;
+  const int m0 = 4 * (c - (odd ? half : 0));  // first pair index of this chunk
+  const float* src = Kn + row * D + 2 * m0 + odd;
+  float4 v;
+  v.x = src[0];
+  v.y = src[2];
+  v.z = src[4];
+  v.w = src[6];
+  reinterpret_cast<float4*>(Kp)[i] = v;
+}
+}  // namespace ragraph
+
+extern "C" int ragraph_pack_keys_f32(const float* Kn, int64_t N, int D, float* Kp, void* stream) {
+  RG_REQUIRE(Kn && Kp, RAGRAPH_EINVAL, "pack_keys: null pointer");
+  RG_REQUIRE(N >= 1, RAGRAPH_EINVAL, "pack_keys: N=%lld must be >= 1", (long long)N);
+  RG_REQUIRE(D == 64 || D == 128 || D == 256, RAGRAPH_EUNSUPPORTED, "pack_keys: D=%d not in {64,128,256}", D);
+  RG_REQUIRE(aligned16(Kn) && aligned16(Kp) && Kn != Kp, RAGRAPH_EINVAL, "pack_keys: Kn, Kp must be distinct, 16-B aligned");
+  const int64_t n4 = N * (D / 4);
+  hipLaunchKernelGGL(pack_keys_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, as_stream(stream), Kn, n4, D, Kp);
+  RG_CHECK_LAUNCH("pack_keys");
+  return RAGRAPH_OK;
+}
+
 extern "C" int ragraph_topk_cosine_f32(const float* Q, int64_t B, const float* Kn, int64_t N, int D, int k,
                                        int64_t idx_base, float* out_scores, int64_t* out_idx, void* ws,
                                        size_t ws_bytes, void* stream) {
+  return ragraph_topk_cosine_bank_f32(Q, B, Kn, nullptr, N, D, k, idx_base, out_scores, out_idx, ws, ws_bytes, stream);
+}
+
+extern "C" int ragraph_topk_cosine_bank_f32(const float* Q, int64_t B, const float* Kn, const float* Kp, int64_t N,
+                                            int D, int k, int64_t idx_base, float* out_scores, int64_t* out_idx,
+                                            void* ws, size_t ws_bytes, void* stream) {
   RG_REQUIRE(Q && Kn && out_scores && out_idx && ws, RAGRAPH_EINVAL, "topk_cosine: null pointer");
+  RG_REQUIRE(!Kp || aligned16(Kp), RAGRAPH_EINVAL, "topk_cosine: Kp must be 16-B aligned");
   RG_REQUIRE(B >= 1 && N >= 1, RAGRAPH_EINVAL, "topk_cosine: B=%lld N=%lld must be >= 1", (long long)B, (long long)N);
   RG_REQUIRE(k >= 1 && k <= N, RAGRAPH_EINVAL, "topk_cosine: k=%d out of range for N=%lld (torch.topk raises too)", k,
              (long long)N);
@@ -957,6 +1058,7 @@ extern "C" int ragraph_topk_cosine_f32(const float* Q, int64_t B, const float* K
   TopkParams p;
   p.Qn = streaming ? Q : Qn;
   p.Kn = Kn;
+  p.Kp = Kp;
   p.B = B;
   p.N = N;
   p.k = k;

@@ -71,13 +71,38 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
-def topk_cosine(q: torch.Tensor, keys_normalized: torch.Tensor, k: int, idx_base: int = 0):
+def pack_keys(keys_normalized: torch.Tensor) -> torch.Tensor:
+    """Packed copy of the bank (row = [even k | odd k]) for the LDS-DMA ring of the tile kernel; made once per bank
+    update and passed to topk_cosine(keys_packed=...)."""
+    L = _ready()
+    kn = _f32c(keys_normalized, "pack_keys.keys")
+    out = torch.empty_like(kn)
+    if kn.shape[0] == 0:
+        return out
+    N.check(L.ragraph_pack_keys_f32(kn.data_ptr(), kn.shape[0], kn.shape[1], out.data_ptr(), _stream()), "pack_keys")
+    return out
+
+
+def packed_keys_help(B: int, D: int, k: int) -> bool:
+    """True when topk_cosine(B queries, k) would use a packed bank copy (tile kernel, D = 256, 4-slot ring fits)."""
+    return B > 128 and D == 256 and k <= 14
+
+
+def topk_cosine(q: torch.Tensor, keys_normalized: torch.Tensor, k: int, idx_base: int = 0,
+                keys_packed: torch.Tensor | None = None):
     """Fused normalize(q) @ keys_normalized.T -> top-k.  Returns (scores [B,k] f32, idx [B,k] i64), canonical order.
 
-    SimilarityFunctions.py:6-16 + ToyGraphBase.py:66-67.  `keys_normalized` must come from normalize_rows()."""
+    SimilarityFunctions.py:6-16 + ToyGraphBase.py:66-67.  `keys_normalized` must come from normalize_rows();
+    `keys_packed` (optional) from pack_keys(keys_normalized) -- same bits out, faster key stream for B > 128."""
     L = _ready()
     q = _f32c(q, "topk_cosine.q")
     kn = _f32c(keys_normalized, "topk_cosine.keys")
+    kp = 0
+    if keys_packed is not None:
+        kpt = _f32c(keys_packed, "topk_cosine.keys_packed")
+        if kpt.shape != kn.shape:
+            raise RagraphNativeError(f"topk_cosine: keys_packed {tuple(kpt.shape)} != keys {tuple(kn.shape)}")
+        kp = kpt.data_ptr()
     if q.dim() != 2 or kn.dim() != 2 or q.shape[1] != kn.shape[1]:
         raise RagraphNativeError(f"topk_cosine: bad shapes {tuple(q.shape)} x {tuple(kn.shape)}")
     B, D = q.shape
@@ -88,8 +113,8 @@ def topk_cosine(q: torch.Tensor, keys_normalized: torch.Tensor, k: int, idx_base
         return scores, idx
     nbytes = L.ragraph_topk_cosine_workspace_bytes(B, Nk, D, k)
     ws = _workspace(nbytes, q.device)
-    N.check(L.ragraph_topk_cosine_f32(q.data_ptr(), B, kn.data_ptr(), Nk, D, k, idx_base, scores.data_ptr(),
-                                      idx.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "topk_cosine")
+    N.check(L.ragraph_topk_cosine_bank_f32(q.data_ptr(), B, kn.data_ptr(), kp, Nk, D, k, idx_base, scores.data_ptr(),
+                                           idx.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "topk_cosine")
     return scores, idx
 
 

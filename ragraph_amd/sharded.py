@@ -47,6 +47,7 @@ class ShardedToyGraphBase:
         self.retrieve_num = retrieve_num
         self.resource_keys, self.resource_values, self.resource_labels = keys, values, labels
         self.keys_normalized = ops.normalize_rows(keys)
+        self._keys_packed = None  # built on the first large-batch lookup when `ops` offers it (the HIP library does)
 
     def topk(self, search_keys, k=None):
         """Global canonical top-k: (scores [B,k], idx [B,k]) identical on every rank."""
@@ -54,7 +55,14 @@ class ShardedToyGraphBase:
         q = search_keys.reshape(1, -1) if search_keys.dim() == 1 else search_keys
         n_local = self.keys_normalized.shape[0]
         kl = min(k, n_local)
-        s, i = self.ops.topk_cosine(q, self.keys_normalized, kl, idx_base=self.idx_base)
+        helps = getattr(self.ops, "packed_keys_help", None)
+        if helps is not None and helps(q.shape[0], q.shape[1], kl):
+            if self._keys_packed is None:
+                self._keys_packed = self.ops.pack_keys(self.keys_normalized)
+            s, i = self.ops.topk_cosine(q, self.keys_normalized, kl, idx_base=self.idx_base,
+                                        keys_packed=self._keys_packed)
+        else:
+            s, i = self.ops.topk_cosine(q, self.keys_normalized, kl, idx_base=self.idx_base)
         if kl < k:  # a shard smaller than k: pad with sentinels that lose every comparison
             pad_s = torch.full((q.shape[0], k - kl), float("-inf"), dtype=s.dtype, device=s.device)
             pad_i = torch.full((q.shape[0], k - kl), torch.iinfo(torch.int64).max, dtype=i.dtype, device=i.device)

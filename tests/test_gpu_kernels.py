@@ -243,6 +243,52 @@ def test_errors_are_loud(dev):
         K.topk_cosine(torch.randn(4, 64), torch.randn(30, 64), 5)  # CPU tensors: no fallback
 
 
+@pytest.mark.parametrize(
+    "B,N,k",
+    [
+        (129, 31, 5),          # one ragged stage
+        (200, 64, 10),         # exactly two stages: prologue only
+        (257, 97, 3),          # three stages + ragged tail, two query tiles
+        (300, 4099, 10),       # several ring generations
+        (513, 70001, 14),      # several splits; largest k the 4-slot ring holds
+        (1000, 20000, 1),
+    ],
+)
+def test_topk_cosine_packed_bank_bit_exact(dev, B, N, k):
+    """LDS-DMA ring over the packed bank copy (D = 256, B > 128, k <= 14) vs the oracle, and the pack layout itself."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(B + 3 * N + k)
+    kn = _bank(rng, N, 256)
+    if N > 8:
+        kn[N // 2:] = kn[: N - N // 2]                    # duplicates -> exact ties across stages
+    q = rng.standard_normal((B, 256), dtype=np.float32)
+    q[B // 2] = 0.0
+    knd = _t(kn, dev)
+    kp = K.pack_keys(knd)
+    want = np.concatenate([kn[:, 0::2], kn[:, 1::2]], axis=1)
+    assert np.array_equal(kp.cpu().numpy(), want)
+    assert K.packed_keys_help(B, 256, k)
+    s, i = K.topk_cosine(_t(q, dev), knd, k, idx_base=11, keys_packed=kp)
+    rs, ri = cref.topk_cosine(q, kn, k, idx_base=11)
+    assert np.array_equal(i.cpu().numpy(), ri)
+    assert np.array_equal(s.cpu().numpy(), rs)
+    # shapes outside the DMA path ignore the packed copy (same entry point, same bits)
+    s2, i2 = K.topk_cosine(_t(q[:7], dev), knd, min(k, 3), keys_packed=kp)
+    rs2, ri2 = cref.topk_cosine(q[:7], kn, min(k, 3))
+    assert np.array_equal(i2.cpu().numpy(), ri2) and np.array_equal(s2.cpu().numpy(), rs2)
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_pack_keys_other_dims(dev, D):
+    from ragraph_amd import kernels as K
+
+    rng = _rng(D)
+    kn = _bank(rng, 37, D)
+    kp = K.pack_keys(_t(kn, dev)).cpu().numpy()
+    assert np.array_equal(kp, np.concatenate([kn[:, 0::2], kn[:, 1::2]], axis=1))
+
+
 def test_topk_cosine_fuzz_against_oracle(dev):
     """60 random shapes across all kernel paths (streaming with 1-8 groups, with / without the pre-pass; tile kernel
     with 1-3 query tiles, ring and barrier variants; materialised k > 32), ragged sizes, duplicate keys, zero queries."""

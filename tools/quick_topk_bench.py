@@ -13,19 +13,20 @@ if len(sys.argv) > 1:
 for B, N, D, k in shapes:
     kn = K.normalize_rows(torch.randn(N, D, device=dev))
     q = torch.randn(B, D, device=dev)
+    kp = K.pack_keys(kn) if (K.packed_keys_help(B, D, k) and not os.environ.get("QTB_NO_PACK")) else None
     for _ in range(2):
-        K.topk_cosine(q, kn, k)
+        K.topk_cosine(q, kn, k, keys_packed=kp)
     torch.cuda.synchronize()
     reps = 3 if B * N > 1e10 else 10
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        K.topk_cosine(q, kn, k)
+        K.topk_cosine(q, kn, k, keys_packed=kp)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     fl = 2.0 * B * N * D
     by = 4.0 * N * D
-    print(f"B={B} N={N} D={D} k={k}: {ms:.3f} ms  {B / ms * 1e3:.0f} q/s  {fl / ms / 1e9:.1f} TFLOP/s  bank-pass {by / ms / 1e6:.0f} GB/s",
+    print(f"[{'packed' if kp is not None else 'natural'}] B={B} N={N} D={D} k={k}: {ms:.3f} ms  {B / ms * 1e3:.0f} q/s  {fl / ms / 1e9:.1f} TFLOP/s  bank-pass {by / ms / 1e6:.0f} GB/s",
           flush=True)
-    del kn, q
+    del kn, q, kp
