@@ -70,6 +70,39 @@ __device__ __forceinline__ void list_insert_lane(float* ls, int* li, int k, int 
   li[p * stride] = idx;
 }
 
+// How a group of W workgroups shares the `left` (< W) query tiles that remain after its full rounds; NS = stages in a
+// pass over the bank.  Evaluated identically on the host (slot count) and in the kernel (segment walk).
+//   aligned: each tile is cut into m = W / left equal pieces, one per workgroup (one list warm-up per workgroup; the
+//            W - m*left spare workgroups idle, so the round lasts NS / m stages);
+//   linear : the tiles are laid end to end and the line of left*NS stages is cut into W equal pieces (perfect balance,
+//            but a piece usually straddles a tile boundary: two warm-ups per workgroup).
+// `warm` = one list warm-up in stage units (~420 k keys, measured); the cheaper of the two wins.
+struct GroupShare {
+  int aligned;
+  int64_t m, per;  // aligned: pieces per tile, stages per piece
+  int64_t Lb;      // linear: stages per workgroup
+  int64_t slots;   // partial lists a tile can end up with
+};
+__host__ __device__ inline GroupShare share_leftover(int64_t left, int64_t NS, int W, int lb_min, int warm) {
+  GroupShare g;
+  g.aligned = 1;
+  g.m = 1;
+  g.per = NS;
+  g.Lb = 0;
+  g.slots = 1;
+  if (left <= 0) return g;
+  int64_t m = W / left;
+  const int64_t mmax = NS / lb_min > 1 ? NS / lb_min : 1;  // no piece shorter than lb_min stages
+  if (m > mmax) m = mmax;
+  g.m = m;
+  g.per = (NS + m - 1) / m;
+  g.Lb = (left * NS + W - 1) / W;
+  if (g.Lb < lb_min) g.Lb = lb_min;
+  g.aligned = (g.per + warm <= g.Lb + 2 * (int64_t)warm) ? 1 : 0;
+  g.slots = g.aligned ? m : (NS + g.Lb - 1) / g.Lb + 1;
+  return g;
+}
+
 struct TopkParams {
   const float* Qn;   // [B,D] normalised queries (big kernel) / RAW queries (small-batch kernel)
   const float* Kn;   // [N,D] normalised keys
@@ -80,7 +113,10 @@ struct TopkParams {
   int ngroups;             // small/mid-batch kernel: groups of 16 queries (workgroup b serves group b % ngroups)
   int64_t qtiles;          // query tiles of 256 (big kernel)
   int xcd_map;             // 1: XCD-aware block mapping (enough query tiles to give every XCD its own)
-  int64_t keys_per_split;  // multiple of the stage size
+  int wgs_per_group;       // big kernel: persistent workgroups per group (one group per XCD when xcd_map, else one group)
+  int lb_min;              // big kernel: shortest share of the leftover tiles a workgroup takes (stages)
+  int warm_stages;         // big kernel: cost of one list warm-up in stages (planning only)
+  int64_t nstages_total;   // big kernel: stages in one full pass over the bank
   float* part_s;           // [B][nsplit][k]
   int* part_i;
   const float* thr_init;   // small-batch kernel: per-query lower bound of the k-th best score at [q*k + k-1], or NULL
@@ -132,43 +168,61 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
   unsigned* freec = full + 4;                                                       // [RING] wave-reads-done per slot
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // known-uniform: row / list bases stay in SGPRs
   const int j = lane & 31, h = lane >> 5;
   const int k = p.k;
 
-  // block -> (query tile, key split), XCD-aware.  Blocks are dealt round-robin over the 8 XCDs (b % 8 labels the blocks
-  // that share an XCD and its 4 MiB L2) and an XCD runs 32 of them at a time.  XCD x owns query tiles x, x+8, ...; its
-  // blocks walk them in groups of 32 tiles, split-major inside a group, so the 32 co-resident workgroups of an XCD
-  // stream the SAME key range and 31 of 32 key fetches hit that L2.  Placement only affects speed; the padded grid's
-  // surplus blocks exit here.
-  int split;
-  int64_t qtile;
-  if (!p.xcd_map) {  // few query tiles: spread every (tile, split) over all XCDs; co-resident blocks share via MALL
-    split = blockIdx.x % p.nsplit;
-    qtile = blockIdx.x / p.nsplit;
+  // ---- persistent workgroups, one per CU (LDS-limited), each walking a short list of SEGMENTS ------------------
+  // A segment = (query tile, contiguous stage range of the bank) with its own sorted lists and one partial-list slot.
+  // Workgroups are dealt round-robin over the 8 XCDs (b % 8 labels the blocks that share an XCD and its 4 MiB L2), so
+  // with xcd_map the 32 workgroups of XCD x form a group that owns query tiles x, x+8, ...; otherwise all workgroups
+  // form one group owning every tile.  A group of W workgroups with nq tiles first runs nq / W rounds of FULL passes
+  // (workgroup c takes tile round*W + c; all W stream the same keys at the same time, so 31 of 32 key fetches hit that
+  // L2), then cuts the nq % W leftover tiles, laid end to end as one line of r*NS stages, into W equal pieces: every CU
+  // gets the same number of stages (no tail round) and a tile is cut into as few, as long streams as balance allows
+  // (each cut costs one list warm-up, ~k ln(n/k) inserts per query).  Placement only affects speed.
+  const int W = p.wgs_per_group;
+  const int x = p.xcd_map ? (int)(blockIdx.x & 7) : 0;
+  const int c = p.xcd_map ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int64_t nq = p.xcd_map ? ((p.qtiles - x + 7) >> 3) : p.qtiles;  // query tiles owned by this group
+  const int64_t NS = p.nstages_total;
+  const int full_rounds = (int)(nq / W);
+  const int64_t left = nq % W;
+  const GroupShare gs = share_leftover(left, NS, W, p.lb_min, p.warm_stages);
+  const int64_t Lb = gs.Lb;
+  int64_t lin = (int64_t)c * Lb;
+  const int64_t lin_end = min(lin + Lb, left * NS);
+
+  for (int it = 0;; ++it) {
+  int64_t ql, st0, st1;
+  int split;  // this segment's slot among the tile's partial lists
+  if (it < full_rounds) {
+    ql = (int64_t)it * W + c;
+    st0 = 0;
+    st1 = NS;
+    split = 0;
+  } else if (gs.aligned) {
+    const int64_t jt = c / gs.m;
+    split = (int)(c % gs.m);
+    st0 = split * gs.per;
+    if (it > full_rounds || jt >= left || st0 >= NS) break;
+    st1 = min(NS, st0 + gs.per);
+    ql = (int64_t)full_rounds * W + jt;
   } else {
-    const int x = blockIdx.x & 7;
-    const int64_t i = blockIdx.x >> 3;
-    const int64_t nq = (p.qtiles - x + 7) >> 3;  // query tiles owned by this XCD
-    constexpr int GQ = 32;
-    if (i >= nq * p.nsplit) return;
-    const int64_t full = nq / GQ, per_group = (int64_t)GQ * p.nsplit;
-    int64_t ql;
-    if (i < full * per_group) {
-      const int64_t r = i % per_group;
-      split = (int)(r / GQ);
-      ql = (i / per_group) * GQ + r % GQ;
-    } else {
-      const int64_t r = i - full * per_group, rem = nq - full * GQ;
-      split = (int)(r / rem);
-      ql = full * GQ + r % rem;
-    }
-    qtile = x + 8 * ql;
+    if (lin >= lin_end) break;
+    const int64_t jt = lin / NS;  // leftover tile this piece of the line falls in
+    st0 = lin - jt * NS;
+    st1 = min(NS, st0 + (lin_end - lin));
+    ql = (int64_t)full_rounds * W + jt;
+    split = c - (int)((jt * NS) / Lb);  // workgroup (jt*NS)/Lb holds the tile's first stage
+    lin += st1 - st0;
   }
+  const int64_t qtile = p.xcd_map ? x + 8 * ql : ql;
   const int64_t q0 = qtile * C::QT;
-  const int64_t n_begin = (int64_t)split * p.keys_per_split;
-  const int64_t n_end = min(p.N, n_begin + p.keys_per_split);
-  const int nstages = (int)((n_end - n_begin + C::STAGE_KEYS - 1) / C::STAGE_KEYS);
+  const int64_t n_begin = st0 * C::STAGE_KEYS;
+  const int64_t n_end = min(p.N, st1 * C::STAGE_KEYS);
+  const int nstages = (int)(st1 - st0);
 
   // ---- B operand: this lane's query (row q0 + wave*32 + j), k-slots h, h+2, h+4, ... ------------------------
   float breg[D / 2];
@@ -176,11 +230,21 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
     int64_t q = q0 + wave * 32 + j;
     if (q > p.B - 1) q = p.B - 1;  // clamp: results of padded queries are never written
     const float4* qp = reinterpret_cast<const float4*>(p.Qn + q * D);
+    // in batches of 16 loads: hipcc otherwise issues all D/4 loads at once and spills long-lived lane constants around
+    // that 256-VGPR peak, with the reloads landing inside the stage loop
+    constexpr int QB = 16;
 #pragma unroll
-    for (int c = 0; c < D / 4; ++c) {
-      const float4 v = qp[c];
-      breg[2 * c] = h ? v.y : v.x;
-      breg[2 * c + 1] = h ? v.w : v.z;
+    for (int c0 = 0; c0 < D / 4; c0 += QB) {
+#pragma unroll
+      for (int c = c0; c < c0 + QB; ++c) {
+        const float4 v = qp[c];
+        breg[2 * c] = h ? v.y : v.x;
+        breg[2 * c + 1] = h ? v.w : v.z;
+      }
+      // pin each batch's selects behind its loads: 16 float4 of temporaries instead of 64
+#pragma unroll
+      for (int c = c0; c < c0 + QB; ++c) asm volatile("" : "+v"(breg[2 * c]), "+v"(breg[2 * c + 1]));
+      asm volatile("" ::: "memory");
     }
   }
 
@@ -332,21 +396,22 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
     // stage s-1 lived in, retired (s_waitcnt vmcnt(0)) and signalled FULL at the end of iteration s+1, read in s+3.
     static_assert(D == 256, "one wave-instruction must cover exactly one padded LDS row");
     const unsigned lds_base = (unsigned)(size_t)(lds_void*)smem;  // LDS byte address of the dynamic segment
+    const unsigned lane16 = 16u * lane;  // the lane's byte offset inside a 1 KiB row, in HBM and in LDS
     auto dma_stage = [&](int s_, int slot_) {
       const int64_t key0_ = n_begin + (int64_t)s_ * C::STAGE_KEYS + wave * 4;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int64_t r_ = min(key0_ + i, p.N - 1);  // tail: duplicate the last key, masked by index later
-        const float* g_ = p.Kp + r_ * D + 4 * lane;
+        const float* g_ = p.Kp + r_ * D;              // wave-uniform row base (SGPR pair) + lane16
         // Issued as asm, not __builtin_amdgcn_global_load_lds: hipcc makes every later ds_read wait vmcnt(0) for a DMA
         // it knows about (possible alias), which would expose the DMA latency at the top of each stage.  The waits for
         // these loads are the explicit s_waitcnt vmcnt(0) statements below.
         const unsigned dst_ = lds_base + 4u * (unsigned)(slot_ * C::STAGE_FLOATS + (wave * 4 + i) * C::ROW);
         unsigned keep_;
         asm volatile(
-            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
             : "=&s"(keep_)
-            : "v"(g_), "s"(__builtin_amdgcn_readfirstlane(dst_))
+            : "v"(lane16), "s"(dst_), "s"(g_)
             : "memory");
       }
     };
@@ -413,7 +478,7 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
 #undef RG_STAGE_WRITE
 #undef RG_ST2
 
-  // ---- write this (tile, split)'s sorted candidates; empty slots stay (-inf, IDX_NONE) -----------------------
+  // ---- write this segment's sorted candidates; empty list entries stay (-inf, IDX_NONE) ---------------------
   for (int i = tid; i < k * C::QT; i += C::THREADS) {
     const int q = i / k, pos = i % k;
     const int64_t qg = q0 + q;
@@ -423,6 +488,20 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
       p.part_i[o] = li[i];
     }
   }
+  if (st1 == NS) {  // the tile's last segment: blank the slots this tile does not use
+    const int unused = (p.nsplit - 1 - split) * k;
+    for (int i = tid; i < unused * C::QT; i += C::THREADS) {
+      const int q = i / unused, pos = i % unused;
+      const int64_t qg = q0 + q;
+      if (qg < p.B) {
+        const int64_t o = (qg * p.nsplit + split + 1) * k + pos;
+        p.part_s[o] = RG_NEG_INF;
+        p.part_i[o] = RG_IDX_NONE;
+      }
+    }
+  }
+  __syncthreads();  // the lists and flags are re-initialised by the next segment
+  }  // segments
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -801,15 +880,26 @@ static int launch_select(const float* cs, const IdxT* ci, int G, int64_t B, int 
   return RAGRAPH_OK;
 }
 
-// ---- split planning ----------------------------------------------------------------------------------------------
-// Work items = qtiles x nsplit equal-length workgroups, one per CU at a time (LDS-limited).  Pick the split count that
-// fills whole rounds of 256 CUs while keeping each stream long enough that the list warm-up (~k ln(n/k) offers per
-// query) stays small next to its MFMA time.
+// ---- work planning -----------------------------------------------------------------------------------------------
+// Tile kernel: one persistent workgroup per CU walks segments (see the kernel); the plan fixes the group shape and the
+// number of partial-list slots per query.  Streaming kernel: nsplit = workgroups per query group.
 struct TopkPlan {
-  int nsplit;
-  int64_t keys_per_split;
+  int nsplit;          // partial lists per query
+  int xcd_map, wgs_per_group, lb_min, warm_stages;
+  int64_t nstages_total;
   size_t qn_bytes, part_s_bytes, part_i_bytes;
 };
+
+static int device_cus() {  // CUs of the current device, a multiple of 8 (one workgroup of the tile kernel per CU)
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        n < 8)
+      n = 256;  // MI355X; also what the planner assumes when no device is visible (workspace queries on a CPU box)
+    return n / 8 * 8;
+  }();
+  return cus;
+}
 
 // Up to this many queries take the wave-streaming kernel (groups of 16 queries, 16x16x4 MFMA): it fills the chip at any
 // batch size, whereas the tile kernel needs >= a few query tiles of 256 to do so (measured crossover).
@@ -836,45 +926,40 @@ static TopkPlan plan_topk(int64_t B, int64_t N, int D, int k) {
     if (wgs < 1) wgs = 1;
     TopkPlan ps;
     ps.nsplit = (int)wgs;
-    ps.keys_per_split = 0;
+    ps.xcd_map = ps.wgs_per_group = ps.lb_min = ps.warm_stages = 0;
+    ps.nstages_total = 0;
     ps.qn_bytes = align_up((size_t)B * D * sizeof(float), 256);
     ps.part_s_bytes = align_up((size_t)B * wgs * k * sizeof(float), 256);
     ps.part_i_bytes = align_up((size_t)B * wgs * k * sizeof(int), 256);
     return ps;
   }
-  const int QT = 256, CUS = 256;
+  const int QT = 256, CUS = device_cus();
   const int stage_keys = 32 * (256 / D);
   const int64_t qtiles = cdiv(B, QT);
-  const int64_t nstages = cdiv(N, stage_keys);
-  int64_t max_split = nstages < 256 ? nstages : 256;
-  if (max_split * k > 4096) max_split = 4096 / k;  // the select kernel holds <= 4096 candidates per query
-  const int64_t min_keys = 4 * stage_keys;  // a split needs a few stages for its prefetch pipeline to make sense
-  int best = 1;
-  double best_cost = 1e300;
-  for (int64_t s = 1; s <= max_split; ++s) {
-    const int64_t per = cdiv(nstages, s) * stage_keys;
-    if (s > 1 && per < min_keys) break;
-    const int64_t real = cdiv(N, per);  // splits that actually hold keys
-    if (real != s) continue;
-    const int64_t wgs = qtiles * s;
-    const double rounds = (double)cdiv(wgs, CUS);
-    // measured on MI355X (k=10, D=256, barrier-free ring + hybrid insert): the insert path costs ~4.2k/n of a stream
-    // of n keys (7 % at n = 62.5k, ~0 at n = 500k); it scales with the number of candidates, i.e. with k.
-    // Short streams saturate (every tile has candidates): capped at 2x, so small banks still spread over all CUs.
-    double warm = 1.0 + 420.0 * (double)k / (double)per;
-    if (warm > 2.0) warm = 2.0;
-    const double cost = rounds * (double)per * warm;
-    if (cost < best_cost * 0.999) {
-      best_cost = cost;
-      best = (int)s;
-    }
-  }
+  const int64_t NS = cdiv(N, stage_keys);
   TopkPlan pl;
-  pl.nsplit = best;
-  pl.keys_per_split = cdiv(nstages, best) * stage_keys;
+  pl.xcd_map = qtiles >= 64 ? 1 : 0;  // enough query tiles to give every XCD its own
+  const int G = pl.xcd_map ? 8 : 1;
+  pl.wgs_per_group = CUS / G;
+  pl.nstages_total = NS;
+  // a piece of the leftover line is at least 4 stages (its prefetch pipeline) and long enough that no tile is cut into
+  // more lists than the select kernel holds (4096 candidates per query)
+  const int64_t cap = 4096 / k;
+  int64_t lb_min = cdiv(NS, cap - 1);
+  if (lb_min < 4) lb_min = 4;
+  pl.lb_min = (int)lb_min;
+  // measured on MI355X (k = 10, D = 256): a list warm-up costs about as much as streaming 420 k keys
+  pl.warm_stages = (int)cdiv(420 * (int64_t)k, stage_keys);
+  int64_t slots = 1;
+  for (int x = 0; x < G; ++x) {
+    const int64_t nq = pl.xcd_map ? (qtiles - x + 7) / 8 : qtiles;
+    const GroupShare gs = share_leftover(nq % pl.wgs_per_group, NS, pl.wgs_per_group, pl.lb_min, pl.warm_stages);
+    if (gs.slots > slots) slots = gs.slots;
+  }
+  pl.nsplit = (int)slots;
   pl.qn_bytes = align_up((size_t)B * D * sizeof(float), 256);
-  pl.part_s_bytes = align_up((size_t)B * best * k * sizeof(float), 256);
-  pl.part_i_bytes = align_up((size_t)B * best * k * sizeof(int), 256);
+  pl.part_s_bytes = align_up((size_t)B * slots * k * sizeof(float), 256);
+  pl.part_i_bytes = align_up((size_t)B * slots * k * sizeof(int), 256);
   return pl;
 }
 
@@ -892,8 +977,7 @@ static int launch_topk_ring(const TopkParams& p, int64_t qtiles, hipStream_t st)
     }
     attr_set = true;
   }
-  // XCD-aware mapping: grid padded so every XCD has a block for each of its items
-  const int64_t grid = p.xcd_map ? 8 * (cdiv(qtiles, 8) * p.nsplit) : qtiles * p.nsplit;
+  const int64_t grid = (int64_t)p.wgs_per_group * (p.xcd_map ? 8 : 1);  // one persistent workgroup per CU
   hipLaunchKernelGGL((topk_stream_kernel<D, RING>), dim3((unsigned)grid), dim3(C::THREADS), lds, st, p);
   RG_CHECK_LAUNCH("topk_cosine");
   return RAGRAPH_OK;
@@ -1065,8 +1149,11 @@ extern "C" int ragraph_topk_cosine_bank_f32(const float* Q, int64_t B, const flo
   p.nsplit = pl.nsplit;
   p.ngroups = (int)cdiv(B, 16);
   p.qtiles = cdiv(B, 256);
-  p.xcd_map = p.qtiles >= 64 ? 1 : 0;
-  p.keys_per_split = pl.keys_per_split;
+  p.xcd_map = pl.xcd_map;
+  p.wgs_per_group = pl.wgs_per_group;
+  p.lb_min = pl.lb_min;
+  p.warm_stages = pl.warm_stages;
+  p.nstages_total = pl.nstages_total;
   p.part_s = part_s;
   p.part_i = part_i;
   static const int ablate_env = [] {  // timing-only diagnostic switches (read once), see TopkParams::ablate
