@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "segment_plan.h"
 
 namespace ragraph {
 
@@ -70,39 +71,6 @@ __device__ __forceinline__ void list_insert_lane(float* ls, int* li, int k, int 
   li[p * stride] = idx;
 }
 
-// How a group of W workgroups shares the `left` (< W) query tiles that remain after its full rounds; NS = stages in a
-// pass over the bank.  Evaluated identically on the host (slot count) and in the kernel (segment walk).
-//   aligned: each tile is cut into m = W / left equal pieces, one per workgroup (one list warm-up per workgroup; the
-//            W - m*left spare workgroups idle, so the round lasts NS / m stages);
-//   linear : the tiles are laid end to end and the line of left*NS stages is cut into W equal pieces (perfect balance,
-//            but a piece usually straddles a tile boundary: two warm-ups per workgroup).
-// `warm` = one list warm-up in stage units (~420 k keys, measured); the cheaper of the two wins.
-struct GroupShare {
-  int aligned;
-  int64_t m, per;  // aligned: pieces per tile, stages per piece
-  int64_t Lb;      // linear: stages per workgroup
-  int64_t slots;   // partial lists a tile can end up with
-};
-__host__ __device__ inline GroupShare share_leftover(int64_t left, int64_t NS, int W, int lb_min, int warm) {
-  GroupShare g;
-  g.aligned = 1;
-  g.m = 1;
-  g.per = NS;
-  g.Lb = 0;
-  g.slots = 1;
-  if (left <= 0) return g;
-  int64_t m = W / left;
-  const int64_t mmax = NS / lb_min > 1 ? NS / lb_min : 1;  // no piece shorter than lb_min stages
-  if (m > mmax) m = mmax;
-  g.m = m;
-  g.per = (NS + m - 1) / m;
-  g.Lb = (left * NS + W - 1) / W;
-  if (g.Lb < lb_min) g.Lb = lb_min;
-  g.aligned = (g.per + warm <= g.Lb + 2 * (int64_t)warm) ? 1 : 0;
-  g.slots = g.aligned ? m : (NS + g.Lb - 1) / g.Lb + 1;
-  return g;
-}
-
 struct TopkParams {
   const float* Qn;   // [B,D] normalised queries (big kernel) / RAW queries (small-batch kernel)
   const float* Kn;   // [N,D] normalised keys
@@ -116,6 +84,7 @@ struct TopkParams {
   int wgs_per_group;       // big kernel: persistent workgroups per group (one group per XCD when xcd_map, else one group)
   int lb_min;              // big kernel: shortest share of the leftover tiles a workgroup takes (stages)
   int warm_stages;         // big kernel: cost of one list warm-up in stages (planning only)
+  int depth[2];            // big kernel: lockstep steps of the plan for groups with as many tiles as group 0 / one fewer
   int64_t nstages_total;   // big kernel: stages in one full pass over the bank
   float* part_s;           // [B][nsplit][k]
   int* part_i;
@@ -177,47 +146,20 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
   // A segment = (query tile, contiguous stage range of the bank) with its own sorted lists and one partial-list slot.
   // Workgroups are dealt round-robin over the 8 XCDs (b % 8 labels the blocks that share an XCD and its 4 MiB L2), so
   // with xcd_map the 32 workgroups of XCD x form a group that owns query tiles x, x+8, ...; otherwise all workgroups
-  // form one group owning every tile.  A group of W workgroups with nq tiles first runs nq / W rounds of FULL passes
-  // (workgroup c takes tile round*W + c; all W stream the same keys at the same time, so 31 of 32 key fetches hit that
-  // L2), then cuts the nq % W leftover tiles, laid end to end as one line of r*NS stages, into W equal pieces: every CU
-  // gets the same number of stages (no tail round) and a tile is cut into as few, as long streams as balance allows
-  // (each cut costs one list warm-up, ~k ln(n/k) inserts per query).  Placement only affects speed.
-  const int W = p.wgs_per_group;
+  // form one group owning every tile.  segment_plan.h hands every workgroup of a group the same number of stages, in
+  // as few segments as that allows, and lines the segments up so that workgroups running side by side read the same
+  // stages (a stage then comes from HBM once per group; the other 31 of 32 fetches hit that L2).  Placement only
+  // affects speed: any plan that covers every (tile, stage) once gives the same result.
   const int x = p.xcd_map ? (int)(blockIdx.x & 7) : 0;
-  const int c = p.xcd_map ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int64_t nq = p.xcd_map ? ((p.qtiles - x + 7) >> 3) : p.qtiles;  // query tiles owned by this group
   const int64_t NS = p.nstages_total;
-  const int full_rounds = (int)(nq / W);
-  const int64_t left = nq % W;
-  const GroupShare gs = share_leftover(left, NS, W, p.lb_min, p.warm_stages);
-  const int64_t Lb = gs.Lb;
-  int64_t lin = (int64_t)c * Lb;
-  const int64_t lin_end = min(lin + Lb, left * NS);
-
-  for (int it = 0;; ++it) {
-  int64_t ql, st0, st1;
-  int split;  // this segment's slot among the tile's partial lists
-  if (it < full_rounds) {
-    ql = (int64_t)it * W + c;
-    st0 = 0;
-    st1 = NS;
-    split = 0;
-  } else if (gs.aligned) {
-    const int64_t jt = c / gs.m;
-    split = (int)(c % gs.m);
-    st0 = split * gs.per;
-    if (it > full_rounds || jt >= left || st0 >= NS) break;
-    st1 = min(NS, st0 + gs.per);
-    ql = (int64_t)full_rounds * W + jt;
-  } else {
-    if (lin >= lin_end) break;
-    const int64_t jt = lin / NS;  // leftover tile this piece of the line falls in
-    st0 = lin - jt * NS;
-    st1 = min(NS, st0 + (lin_end - lin));
-    ql = (int64_t)full_rounds * W + jt;
-    split = c - (int)((jt * NS) / Lb);  // workgroup (jt*NS)/Lb holds the tile's first stage
-    lin += st1 - st0;
-  }
+  const int64_t nq0 = p.xcd_map ? ((p.qtiles + 7) >> 3) : p.qtiles;     // group 0's count; the others have nq0 or nq0-1
+  SegmentWalker walker(nq, NS, p.wgs_per_group, p.lb_min, p.warm_stages, p.depth[nq != nq0],
+                       p.xcd_map ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);
+  Segment seg;
+  while (walker.next(seg)) {
+  const int64_t ql = seg.tile, st0 = seg.st0, st1 = seg.st1;
+  const int split = seg.slot;  // this segment's slot among the tile's partial lists
   const int64_t qtile = p.xcd_map ? x + 8 * ql : ql;
   const int64_t q0 = qtile * C::QT;
   const int64_t n_begin = st0 * C::STAGE_KEYS;
@@ -488,7 +430,7 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
       p.part_i[o] = li[i];
     }
   }
-  if (st1 == NS) {  // the tile's last segment: blank the slots this tile does not use
+  if (seg.last) {  // the tile's last segment: blank the slots this tile does not use
     const int unused = (p.nsplit - 1 - split) * k;
     for (int i = tid; i < unused * C::QT; i += C::THREADS) {
       const int q = i / unused, pos = i % unused;
@@ -885,13 +827,17 @@ static int launch_select(const float* cs, const IdxT* ci, int G, int64_t B, int 
 // number of partial-list slots per query.  Streaming kernel: nsplit = workgroups per query group.
 struct TopkPlan {
   int nsplit;          // partial lists per query
-  int xcd_map, wgs_per_group, lb_min, warm_stages;
+  int xcd_map, wgs_per_group, lb_min, warm_stages, depth[2];
   int64_t nstages_total;
   size_t qn_bytes, part_s_bytes, part_i_bytes;
 };
 
 static int device_cus() {  // CUs of the current device, a multiple of 8 (one workgroup of the tile kernel per CU)
   static const int cus = [] {
+    if (const char* e = getenv("RAGRAPH_TOPK_CUS")) {  // test hook (read once): plan for this many workgroups
+      const int v = atoi(e);
+      if (v >= 8) return v / 8 * 8;
+    }
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
         n < 8)
@@ -926,7 +872,7 @@ static TopkPlan plan_topk(int64_t B, int64_t N, int D, int k) {
     if (wgs < 1) wgs = 1;
     TopkPlan ps;
     ps.nsplit = (int)wgs;
-    ps.xcd_map = ps.wgs_per_group = ps.lb_min = ps.warm_stages = 0;
+    ps.xcd_map = ps.wgs_per_group = ps.lb_min = ps.warm_stages = ps.depth[0] = ps.depth[1] = 0;
     ps.nstages_total = 0;
     ps.qn_bytes = align_up((size_t)B * D * sizeof(float), 256);
     ps.part_s_bytes = align_up((size_t)B * wgs * k * sizeof(float), 256);
@@ -951,10 +897,26 @@ static TopkPlan plan_topk(int64_t B, int64_t N, int D, int k) {
   // measured on MI355X (k = 10, D = 256): a list warm-up costs about as much as streaming 420 k keys
   pl.warm_stages = (int)cdiv(420 * (int64_t)k, stage_keys);
   int64_t slots = 1;
-  for (int x = 0; x < G; ++x) {
-    const int64_t nq = pl.xcd_map ? (qtiles - x + 7) / 8 : qtiles;
-    const GroupShare gs = share_leftover(nq % pl.wgs_per_group, NS, pl.wgs_per_group, pl.lb_min, pl.warm_stages);
-    if (gs.slots > slots) slots = gs.slots;
+  const int64_t nq0 = pl.xcd_map ? (qtiles + 7) / 8 : qtiles;
+  for (int v = 0; v < 2; ++v) {  // groups own nq0 or (some of them, with the XCD mapping) nq0 - 1 tiles
+    const int64_t nq = nq0 - v;
+    pl.depth[v] = 0;
+    if (nq < 1 || (v == 1 && (!pl.xcd_map || qtiles % 8 == 0))) continue;
+    const SegmentWalker::Choice ch = SegmentWalker::choose_depth(nq, NS, pl.wgs_per_group, pl.lb_min, pl.warm_stages);
+    static const int depth_cap = [] {  // RAGRAPH_TOPK_DEPTH: diagnostic cap on the lockstep steps (read once)
+      const char* e = getenv("RAGRAPH_TOPK_DEPTH");
+      return e ? atoi(e) : 1 << 30;
+    }();
+    pl.depth[v] = ch.depth < depth_cap ? ch.depth : depth_cap;
+    int64_t sl = ch.slots;
+    if (pl.depth[v] != ch.depth) {  // recount the slots of the capped plan
+      SegmentWalker w(nq, NS, pl.wgs_per_group, pl.lb_min, pl.warm_stages, pl.depth[v], -1);
+      Segment sg;
+      while (w.next(sg)) {
+      }
+      sl = w.used;
+    }
+    if (sl > slots) slots = sl;
   }
   pl.nsplit = (int)slots;
   pl.qn_bytes = align_up((size_t)B * D * sizeof(float), 256);
@@ -1153,6 +1115,8 @@ extern "C" int ragraph_topk_cosine_bank_f32(const float* Q, int64_t B, const flo
   p.wgs_per_group = pl.wgs_per_group;
   p.lb_min = pl.lb_min;
   p.warm_stages = pl.warm_stages;
+  p.depth[0] = pl.depth[0];
+  p.depth[1] = pl.depth[1];
   p.nstages_total = pl.nstages_total;
   p.part_s = part_s;
   p.part_i = part_i;

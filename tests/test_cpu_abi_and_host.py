@@ -161,3 +161,17 @@ def test_edge_list_ingestion_matches_reference_recipe(tmp_path):
     assert np.array_equal(ds.edge_times.numpy(), ref_times)
     rp, cols = ds.history_csr([0, 3, 5], device="cpu")
     assert rp.tolist()[0] == 0 and rp.tolist()[-1] == cols.numel()
+
+
+def test_segment_plan_covers_every_stage_once(tmp_path):
+    """The tile kernel's work plan (segment_plan.h) is plain C++: build the exhaustive checker with g++ and run it
+    (82k (tiles, stages, workgroups) combinations: exact coverage, slot order, last flags, slot bound)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "check_segment_plan")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "ragraph_amd", "csrc"),
+                           os.path.join(root, "tools", "check_segment_plan.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert "segment plans checked" in out.stdout
