@@ -260,7 +260,7 @@ def main():
                    "bank_rows_per_gpu": n_local,
                    "parallelism": "single GPU" if world == 1 else
                    f"key bank row-sharded x{world} (values replicated), one RCCL all_gather of the per-shard top-k per step"},
-        "roofline": {"kernel": "ragraph::topk_stream_kernel<256> (fused cosine+top-k, v_mfma_f32_32x32x2_f32)",
+        "roofline": {"kernel": "ragraph::topk_stream_kernel<256, 4> (fused cosine+top-k, v_mfma_f32_32x32x2_f32, LDS-DMA key ring)",
                      "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                      "traffic_unit": "GB per launch, HBM side = (2*FETCH_SIZE + WRITE_SIZE) from rocprofv3 --pmc, "
