@@ -90,7 +90,8 @@ struct TopkParams {
   int* part_i;
   const float* thr_init;   // small-batch kernel: per-query lower bound of the k-th best score at [q*k + k-1], or NULL
   int ablate;              // DIAGNOSTIC ONLY (env RAGRAPH_TOPK_ABLATE, results invalid when non-zero): bit0 skip the
-                           // top-k epilogue, bit1 skip global loads + LDS writes, bit2 skip the stage barrier
+                           // top-k epilogue, bit1 skip global loads + LDS writes, bit2 skip the stage barrier (both
+                           // 2-slot variant); DMA ring: bit4 skip the DMA, bit5 skip the FULL / FREE counters
 };
 
 template <int D>
@@ -123,6 +124,13 @@ __device__ __forceinline__ void ring_signal(unsigned* ctr, int lane) {  // after
 
 typedef __attribute__((address_space(3))) void lds_void;        // operand types of __builtin_amdgcn_global_load_lds
 typedef __attribute__((address_space(1))) const void gbl_void;
+
+#ifdef RG_TOPK_TIMING  // diagnostic build only (tools/dev): per-wave cycle totals of the DMA ring's phases
+__device__ unsigned long long g_topk_timing[8];
+#define RG_T(var_) const unsigned long long var_ = __builtin_amdgcn_s_memtime()
+#else
+#define RG_T(var_)
+#endif
 
 template <int D, int RING>
 __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
@@ -232,6 +240,9 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
   } while (0)
 
   float thr = RG_NEG_INF;
+#ifdef RG_TOPK_TIMING
+  unsigned long long tw_epi = 0;
+#endif
 
   // one stage of MFMAs + top-k epilogue for this wave's 32 queries
   auto compute_stage = [&](int s, int cur) {
@@ -251,6 +262,7 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
       }
 
       // ---- epilogue: acc[r] = score(key row (r&3) + 8*(r>>2) + 4*h of the tile, query j) ------------------
+      RG_T(te0);
       float m = acc[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
@@ -316,6 +328,9 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
           pend = __ballot(mask != 0);
         }
       }
+#ifdef RG_TOPK_TIMING
+      tw_epi += __builtin_amdgcn_s_memtime() - te0;
+#endif
     }
   };
 
@@ -365,23 +380,50 @@ __global__ void __launch_bounds__(512, 2) topk_stream_kernel(TopkParams p) {
     if (tid < pro) full[tid] = C::WAVES;
     __syncthreads();
     int pending = -1;
+    const bool no_dma = p.ablate & 16, no_flags = p.ablate & 32;  // timing-only diagnostics (results invalid)
+#ifdef RG_TOPK_TIMING
+    unsigned long long tw_full = 0, tw_comp = 0, tw_sig = 0, tw_free = 0, tw_dma = 0;
+#endif
     for (int s = 0; s < nstages; ++s) {
       const int slot = s & 3, gen = s >> 2;
-      ring_wait(full + slot, (unsigned)(C::WAVES * (gen + 1)));      // all 8 waves' rows of stage s have landed
+      RG_T(t0);
+      if (!no_flags) ring_wait(full + slot, (unsigned)(C::WAVES * (gen + 1)));  // all 8 waves' rows of stage s have landed
+      RG_T(t1);
       compute_stage(s, slot * C::STAGE_FLOATS);
-      ring_signal(freec + slot, lane);                               // this wave is done reading stage s
+      RG_T(t2);
+      if (!no_flags) ring_signal(freec + slot, lane);                // this wave is done reading stage s
       if (pending >= 0) {                                            // the DMA issued one iteration ago
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ring_signal(full + pending, lane);
+        if (!no_flags) ring_signal(full + pending, lane);
         pending = -1;
       }
+      RG_T(t3);
+#ifdef RG_TOPK_TIMING
+      unsigned long long t4 = t3, t5 = t3;
+#endif
       if (s + 3 < nstages) {
         const int ws = (s + 3) & 3;                                  // the slot stage s-1 lived in
-        ring_wait(freec + ws, (unsigned)(C::WAVES * ((s + 3) >> 2))); // all 8 waves are done reading stage s-1
-        dma_stage(s + 3, ws);
+        if (!no_flags) ring_wait(freec + ws, (unsigned)(C::WAVES * ((s + 3) >> 2)));  // all 8 waves are done reading stage s-1
+#ifdef RG_TOPK_TIMING
+        t4 = __builtin_amdgcn_s_memtime();
+#endif
+        if (!no_dma) dma_stage(s + 3, ws);
         pending = ws;
+#ifdef RG_TOPK_TIMING
+        t5 = __builtin_amdgcn_s_memtime();
+#endif
       }
+#ifdef RG_TOPK_TIMING
+      tw_full += t1 - t0; tw_comp += t2 - t1; tw_sig += t3 - t2; tw_free += t4 - t3; tw_dma += t5 - t4;
+#endif
     }
+#ifdef RG_TOPK_TIMING
+    if (lane == 0) {
+      atomicAdd(&g_topk_timing[0], tw_full); atomicAdd(&g_topk_timing[1], tw_comp); atomicAdd(&g_topk_timing[2], tw_sig);
+      atomicAdd(&g_topk_timing[3], tw_free); atomicAdd(&g_topk_timing[4], tw_dma); atomicAdd(&g_topk_timing[5], (unsigned long long)nstages);
+      atomicAdd(&g_topk_timing[6], tw_epi);
+    }
+#endif
     __syncthreads();
   } else {
     // slots 0 and 1 are filled up front; afterwards stage s+2 is loaded during stage s and written behind it
@@ -940,8 +982,23 @@ static int launch_topk_ring(const TopkParams& p, int64_t qtiles, hipStream_t st)
     attr_set = true;
   }
   const int64_t grid = (int64_t)p.wgs_per_group * (p.xcd_map ? 8 : 1);  // one persistent workgroup per CU
+#ifdef RG_TOPK_TIMING
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_topk_timing), zero, sizeof(zero));
+#endif
   hipLaunchKernelGGL((topk_stream_kernel<D, RING>), dim3((unsigned)grid), dim3(C::THREADS), lds, st, p);
   RG_CHECK_LAUNCH("topk_cosine");
+#ifdef RG_TOPK_TIMING
+  (void)hipDeviceSynchronize();
+  unsigned long long t[8];
+  (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_topk_timing), sizeof(t));
+  if (t[5]) {
+    const double n = (double)t[5];  // wave-stages
+    fprintf(stderr, "[topk timing] RING=%d wave-stages=%.0f cycles/stage: wait_full %.1f compute %.1f (of which epilogue %.1f) "
+            "signal+vmcnt %.1f wait_free %.1f dma_issue %.1f total %.1f\n", RING, n, t[0] / n, t[1] / n, t[6] / n, t[2] / n,
+            t[3] / n, t[4] / n, (t[0] + t[1] + t[2] + t[3] + t[4]) / n);
+  }
+#endif
   return RAGRAPH_OK;
 }
 
