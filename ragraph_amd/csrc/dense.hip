@@ -63,6 +63,249 @@ __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ X
   }
 }
 
+// ---- large shapes: 128 x 128 block tile, 4 waves x (64 x 64), K chunks of 32 double-buffered through LDS -----------
+// Used when M >= 128, N >= 128, K % 4 == 0 and the rows are 16-B aligned (the GCN encode of c2: 100k x 128 -> 256).
+// Same numerics as linear_kernel (every output is the k = 0..K-1 fmaf chain the MFMA computes, bias added after), so
+// the two kernels are interchangeable bit for bit.  Per wave and K chunk: 4 A-row + 4 B-row ds_read_b128 feed 64 MFMAs
+// (each fragment is used by two tiles); the LDS image is de-interleaved like the top-k kernel's (row = [even k | odd k]
+// + 16 B pad: one conflict-free ds_read_b128 = four MFMA steps); the next chunk's 8 float4 per thread are in flight
+// under the MFMAs and written behind them; one barrier per chunk.
+constexpr int TBM = 128, TBN = 128, TKC = 32, TLD = TKC + 4;
+
+__global__ void __launch_bounds__(256, 2) linear_tile_kernel(const float* __restrict__ X, int64_t M, int K,
+                                                             const float* __restrict__ W, int64_t N,
+                                                             const float* __restrict__ bias, int act, float alpha,
+                                                             float* __restrict__ Y) {
+  extern __shared__ float4 lin_smem4[];
+  float* smem = reinterpret_cast<float*>(lin_smem4);  // A[2][128][TLD] then B[2][128][TLD]
+  constexpr int BUF = TBM * TLD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.x * TBM;
+  const int64_t n0 = (int64_t)blockIdx.y * TBN;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // staging: thread t owns float4 q = t % 8 (k = 4q..4q+3 of the chunk) of rows t / 8 + 32 u, u = 0..3, of A and of B
+  const int srow = tid >> 3, sq = tid & 7;
+  float4 pa[4], pb[4];
+  auto stage_load = [&](int k0) {
+    const int kk = k0 + 4 * sq;
+    const bool kin = kk < K;  // K % 4 == 0: a float4 is inside or outside as a whole
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t gm = m0 + srow + 32 * u, gn = n0 + srow + 32 * u;
+      pa[u] = (kin && gm < M) ? *reinterpret_cast<const float4*>(X + gm * K + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+      pb[u] = (kin && gn < N) ? *reinterpret_cast<const float4*>(W + gn * K + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stage_write = [&](int buf) {
+    float* A = smem + buf * BUF;
+    float* B = smem + 2 * BUF + buf * BUF;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float* da = A + (srow + 32 * u) * TLD + 2 * sq;
+      float* db = B + (srow + 32 * u) * TLD + 2 * sq;
+      da[0] = pa[u].x; da[1] = pa[u].z; da[TKC / 2] = pa[u].y; da[TKC / 2 + 1] = pa[u].w;
+      db[0] = pb[u].x; db[1] = pb[u].z; db[TKC / 2] = pb[u].y; db[TKC / 2 + 1] = pb[u].w;
+    }
+  };
+
+  const int nchunks = (K + TKC - 1) / TKC;
+  stage_load(0);
+  stage_write(0);
+  __syncthreads();
+  for (int s = 0; s < nchunks; ++s) {
+    const bool more = s + 1 < nchunks;
+    if (more) stage_load((s + 1) * TKC);  // in flight under this chunk's MFMAs
+    const float* A = smem + (s & 1) * BUF + (wr * 64 + j) * TLD + h * (TKC / 2);
+    const float* B = smem + 2 * BUF + (s & 1) * BUF + (wc * 64 + j) * TLD + h * (TKC / 2);
+#pragma unroll
+    for (int c = 0; c < TKC / 8; ++c) {
+      const float4 a0 = *reinterpret_cast<const float4*>(A + 4 * c);
+      const float4 a1 = *reinterpret_cast<const float4*>(A + 32 * TLD + 4 * c);
+      const float4 b0 = *reinterpret_cast<const float4*>(B + 4 * c);
+      const float4 b1 = *reinterpret_cast<const float4*>(B + 32 * TLD + 4 * c);
+#define RG_STEP(e_)                                                                        \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.e_, b0.e_, acc[0][0], 0, 0, 0);       \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.e_, b1.e_, acc[0][1], 0, 0, 0);       \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.e_, b0.e_, acc[1][0], 0, 0, 0);       \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.e_, b1.e_, acc[1][1], 0, 0, 0);
+      RG_STEP(x) RG_STEP(y) RG_STEP(z) RG_STEP(w)
+#undef RG_STEP
+    }
+    if (more) stage_write((s + 1) & 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int64_t n = n0 + wc * 64 + b * 32 + j;
+    if (n >= N) continue;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < M) {
+          float v = acc[a][b][r];
+          if (bias) v = __fadd_rn(v, bv);
+          Y[m * N + n] = apply_act(v, act, alpha);
+        }
+      }
+  }
+}
+
+// ---- tall X, N <= 256-wide blocks: stream the rows of X past W held in registers --------------------------------
+// The GCN encode of c2 is 100k x 128 -> 256: X is read once, Y written once (153 MB) against 6.5 GFLOP, i.e. it should
+// run at the speed of its memory traffic.  Same structure as the fused top-k tile kernel (topk_cosine.hip) with the
+// roles keys -> rows of X (streamed in 32 KiB stages through LDS, de-interleaved [even k | odd k] rows, one
+// conflict-free ds_read_b128 per four MFMAs) and queries -> rows of W (wave w keeps the 32 output columns
+// n0 + 32 w .. + 31 as its B operand in K/2 VGPRs for the whole stream); the epilogue stores the 32 x 32 accumulator
+// tile (+ bias, activation) instead of selecting from it.  Double buffered with one barrier per stage; the next
+// stage's four float4 per thread are in flight under the MFMAs.  Same fmaf chains as the other two kernels.
+template <int KD>
+struct LinStreamCfg {
+  static constexpr int WAVES = 8, THREADS = 512;
+  static constexpr int TILES = 256 / KD;            // 32-row MFMA tiles per stage
+  static constexpr int STAGE_ROWS = 32 * TILES;     // 32 KiB of X per stage
+  static constexpr int ROW = KD + 4;                // padded LDS row (floats)
+  static constexpr int STAGE_FLOATS = STAGE_ROWS * ROW;
+  static constexpr size_t LDS_BYTES = sizeof(float) * 2 * STAGE_FLOATS;
+};
+
+template <int KD>
+__global__ void __launch_bounds__(512, 2) linear_stream_kernel(const float* __restrict__ X, int64_t M,
+                                                               const float* __restrict__ W, int64_t N,
+                                                               const float* __restrict__ bias, int act, float alpha,
+                                                               float* __restrict__ Y, int64_t stages_per_wg) {
+  using C = LinStreamCfg<KD>;
+  extern __shared__ float4 lin_smem4[];
+  float* smem = reinterpret_cast<float*>(lin_smem4);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t n = (int64_t)blockIdx.y * 256 + wave * 32 + j;  // this lane's output column
+  const int64_t total_stages = (M + C::STAGE_ROWS - 1) / C::STAGE_ROWS;
+  const int64_t st0 = (int64_t)blockIdx.x * stages_per_wg;
+  const int64_t st1 = min(total_stages, st0 + stages_per_wg);
+  if (st0 >= st1) return;
+  const int nstages = (int)(st1 - st0);
+
+  // B operand: row n of W (clamped; columns >= N are computed and never stored), k-slots h, h+2, ...
+  float breg[KD / 2];
+  {
+    const float4* wp = reinterpret_cast<const float4*>(W + (n < N ? n : N - 1) * KD);
+#pragma unroll
+    for (int c0 = 0; c0 < KD / 4; c0 += 16) {
+#pragma unroll
+      for (int c = c0; c < c0 + 16 && c < KD / 4; ++c) {
+        const float4 v = wp[c];
+        breg[2 * c] = h ? v.y : v.x;
+        breg[2 * c + 1] = h ? v.w : v.z;
+      }
+#pragma unroll
+      for (int c = c0; c < c0 + 16 && c < KD / 4; ++c) asm volatile("" : "+v"(breg[2 * c]), "+v"(breg[2 * c + 1]));
+      asm volatile("" ::: "memory");
+    }
+  }
+  const float bv = (bias && n < N) ? bias[n] : 0.f;
+
+  // staging: thread t owns float4 chunks t, t + 512, ... of the stage (row = chunk / (KD/4)); rows >= M are clamped
+  float4 pre0, pre1, pre2, pre3;
+  const int srow = tid / (KD / 4), scol = 4 * (tid % (KD / 4));
+  constexpr int SROWS = C::THREADS / (KD / 4);
+  auto stage_load = [&](int64_t s_) {
+    const int64_t r_ = (st0 + s_) * C::STAGE_ROWS + srow, last_ = M - 1;
+    pre0 = *reinterpret_cast<const float4*>(X + min(r_, last_) * KD + scol);
+    pre1 = *reinterpret_cast<const float4*>(X + min(r_ + SROWS, last_) * KD + scol);
+    pre2 = *reinterpret_cast<const float4*>(X + min(r_ + 2 * SROWS, last_) * KD + scol);
+    pre3 = *reinterpret_cast<const float4*>(X + min(r_ + 3 * SROWS, last_) * KD + scol);
+  };
+  auto stage_write = [&](int buf) {
+    float* d = smem + buf * C::STAGE_FLOATS + srow * C::ROW + (scol >> 1);
+#define RG_W2(o_, v_)                                   \
+  d[(o_)] = (v_).x; d[(o_) + 1] = (v_).z;               \
+  d[(o_) + KD / 2] = (v_).y; d[(o_) + KD / 2 + 1] = (v_).w;
+    RG_W2(0, pre0) RG_W2(SROWS * C::ROW, pre1) RG_W2(2 * SROWS * C::ROW, pre2) RG_W2(3 * SROWS * C::ROW, pre3)
+#undef RG_W2
+  };
+
+  stage_load(0);
+  stage_write(0);
+  __syncthreads();
+  for (int s = 0; s < nstages; ++s) {
+    const bool more = s + 1 < nstages;
+    stage_load(more ? s + 1 : s);
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads above the MFMA block
+#pragma unroll 1
+    for (int t = 0; t < C::TILES; ++t) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* arow = smem + (s & 1) * C::STAGE_FLOATS + (t * 32 + j) * C::ROW + h * (KD / 2);
+#pragma unroll
+      for (int c = 0; c < KD / 8; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(arow + 4 * c);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, breg[4 * c], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, breg[4 * c + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, breg[4 * c + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, breg[4 * c + 3], acc, 0, 0, 0);
+      }
+      // acc[r] = Y[row (r&3) + 8 (r>>2) + 4 h of the tile][n]: for a fixed r the 32 lanes of a half-wave store 128 B
+      const int64_t m_base = (st0 + s) * C::STAGE_ROWS + t * 32 + 4 * h;
+      if (n < N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t m = m_base + (r & 3) + 8 * (r >> 2);
+          if (m < M) {
+            float v = acc[r];
+            if (bias) v = __fadd_rn(v, bv);
+            Y[m * N + n] = apply_act(v, act, alpha);
+          }
+        }
+      }
+    }
+    if (more) stage_write((s + 1) & 1);
+    __syncthreads();
+  }
+}
+
+template <int KD>
+static int launch_linear_stream(const float* X, int64_t M, const float* W, int64_t N, const float* bias, int act,
+                                float alpha, float* Y, hipStream_t st) {
+  using C = LinStreamCfg<KD>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_stream_kernel<KD>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("linear: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+      return RAGRAPH_EDEVICE;
+    }
+    attr_set = true;
+  }
+  const int64_t total_stages = cdiv(M, C::STAGE_ROWS);
+  const int64_t col_blocks = cdiv(N, 256);
+  // ~2 workgroups per CU in flight (LDS 66 KB, <= 128 VGPRs); at least 4 stages each so the pipeline fills
+  int64_t wgs = 512 / col_blocks;
+  if (wgs < 1) wgs = 1;
+  int64_t per = cdiv(total_stages, wgs);
+  if (per < 4) per = 4;
+  wgs = cdiv(total_stages, per);
+  hipLaunchKernelGGL(linear_stream_kernel<KD>, dim3((unsigned)wgs, (unsigned)col_blocks), dim3(C::THREADS), C::LDS_BYTES,
+                     st, X, M, W, N, bias, act, alpha, Y, per);
+  RG_CHECK_LAUNCH("linear(stream)");
+  return RAGRAPH_OK;
+}
+
 }  // namespace ragraph
 
 using namespace ragraph;
@@ -73,6 +316,35 @@ extern "C" int ragraph_linear_f32(const float* X, int64_t M, int K, const float*
   RG_REQUIRE(M >= 1 && N >= 1 && K >= 1, RAGRAPH_EINVAL, "linear: M,N,K must be >= 1");
   RG_REQUIRE(act >= RAGRAPH_ACT_NONE && act <= RAGRAPH_ACT_ELU, RAGRAPH_EINVAL, "linear: bad act %d", act);
   RG_REQUIRE(cdiv(N, LBN) <= 65535, RAGRAPH_EUNSUPPORTED, "linear: N=%lld too large for one launch", (long long)N);
+  static const bool tile_ok = [] {  // RAGRAPH_LINEAR_TILE=0: diagnostic switch back to the small-tile kernel (read once)
+    const char* e = getenv("RAGRAPH_LINEAR_TILE");
+    return !(e && atoi(e) == 0);
+  }();
+  // tall X against blocks of 256 columns; the last block's idle waves must stay under 25 % of all of them
+  if (tile_ok && M >= 4096 && (K == 64 || K == 128 || K == 256) && aligned16(X) && aligned16(W) &&
+      4 * N >= 3 * 256 * cdiv(N, 256) && cdiv(N, 256) <= 65535) {
+    hipStream_t st = as_stream(stream);
+    return K == 256 ? launch_linear_stream<256>(X, M, W, N, bias, act, alpha, Y, st)
+           : K == 128 ? launch_linear_stream<128>(X, M, W, N, bias, act, alpha, Y, st)
+                      : launch_linear_stream<64>(X, M, W, N, bias, act, alpha, Y, st);
+  }
+  if (tile_ok && M >= TBM && N >= TBN && K % 4 == 0 && aligned16(X) && aligned16(W)) {
+    const size_t lds = sizeof(float) * 4 * TBM * TLD;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tile_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) {
+        set_error("linear: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+        return RAGRAPH_EDEVICE;
+      }
+      attr_set = true;
+    }
+    dim3 grid((unsigned)cdiv(M, TBM), (unsigned)cdiv(N, TBN));
+    hipLaunchKernelGGL(linear_tile_kernel, grid, dim3(256), lds, as_stream(stream), X, M, K, W, N, bias, act, alpha, Y);
+    RG_CHECK_LAUNCH("linear(tile)");
+    return RAGRAPH_OK;
+  }
   dim3 grid((unsigned)cdiv(M, LBM), (unsigned)cdiv(N, LBN));
   hipLaunchKernelGGL(linear_kernel, grid, dim3(256), 0, as_stream(stream), X, M, K, W, N, bias, act, alpha, Y);
   RG_CHECK_LAUNCH("linear");

@@ -140,7 +140,14 @@ def test_gather_rows_and_reduce(dev):
 
 
 @pytest.mark.parametrize("M,K_,N_,act", [(1, 1, 1, 0), (33, 18, 256, 2), (200, 1433, 256, 0), (130, 256, 3, 3),
-                                         (65, 256, 256, 3), (64, 64, 64, 1)])
+                                         (65, 256, 256, 3), (64, 64, 64, 1),
+                                         # the 128 x 128 tile kernel (M, N >= 128, K % 4 == 0): ragged tiles, K not a
+                                         # multiple of the 32-wide chunk, one chunk, many chunks
+                                         (300, 128, 256, 2), (129, 36, 130, 1), (128, 4, 128, 0), (1000, 260, 384, 3),
+                                         (257, 1000, 129, 0),
+                                         # the streaming kernel (M >= 4096, K in {64,128,256}, N in (192,256] per block)
+                                         (4096, 128, 256, 2), (4133, 256, 250, 3), (5000, 64, 512, 0), (4100, 128, 700, 1),
+                                         (9000, 128, 193, 2)])
 def test_linear_bit_exact(dev, M, K_, N_, act):
     from ragraph_amd import kernels as K
 
@@ -335,7 +342,8 @@ def test_spmm_linear_fuzz_against_oracle(dev):
             assert np.allclose(got, ref, rtol=1e-6, atol=1e-6), f"spmm n={n} D={D} act={act}"
         else:
             assert np.array_equal(got, ref), f"spmm n={n} D={D} act={act}"
-        M, Kd, Nd = int(rng.choice([1, 31, 64, 65, 200])), int(rng.choice([1, 5, 32, 33, 100, 257])), int(rng.choice([1, 3, 64, 70]))
+        M, Kd, Nd = (int(rng.choice([1, 31, 64, 65, 200, 333])), int(rng.choice([1, 5, 32, 33, 100, 257, 64, 132])),
+                     int(rng.choice([1, 3, 64, 70, 128, 200])))
         A = rng.standard_normal((M, Kd), dtype=np.float32)
         W = rng.standard_normal((Nd, Kd), dtype=np.float32)
         assert np.array_equal(K.linear(_t(A, dev), _t(W, dev)).cpu().numpy(), cref.linear(A, W)), f"linear {M}x{Kd}x{Nd}"

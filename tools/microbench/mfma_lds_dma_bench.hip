@@ -279,6 +279,103 @@ void run14(const char* name, const float* keys, int64_t nkeys) {
   hipFree(d);
 }
 
+
+// The same ring with v_mfma_f32_16x16x4_f32: two 16-query groups per wave (two independent 4-VGPR accumulator chains
+// fed by the same A fragment), two 16-key sub-tiles per 32-key stage.  Same flops and LDS traffic as the 32x32x2 form,
+// half the accumulator write bandwidth.  FLAGS = 0: burst DMA only; 1: burst DMA + FULL/FREE counters (kernel ring).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int FLAGS>
+__global__ void __launch_bounds__(512, 2) k16(const float* __restrict__ keys, int64_t nkeys, float* out, int iters, float a) {
+  extern __shared__ float4 smem4[];
+  float* smem = (float*)smem4;
+  constexpr int ROW = 260, STAGE = 32 * ROW;
+  const int lane = threadIdx.x & 63, j = lane & 15, sl = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int i = threadIdx.x; i < 4 * STAGE; i += 512) smem[i] = a + i * 1e-7f;
+  __syncthreads();
+  float b0[64], b1[64];
+#pragma unroll
+  for (int m = 0; m < 64; ++m) { b0[m] = a + m * 1e-6f + lane * 1e-7f; b1[m] = a - m * 1e-6f + lane * 1e-7f; }
+  float keep = 0.f;
+  const unsigned lds_base = (unsigned)(size_t)(lds_void*)smem;
+  const unsigned lane16 = 16u * lane;
+  unsigned* full = reinterpret_cast<unsigned*>(smem + 4 * STAGE);
+  unsigned* freec = full + 4;
+  if (threadIdx.x < 8) full[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x < 3) full[threadIdx.x] = 8;
+  __syncthreads();
+  int pending = -1;
+  for (int it = 0; it < iters; ++it) {
+    const int slot = it & 3, ws = (it + 3) & 3;
+    const int64_t key0 = ((int64_t)it * 32) % (nkeys - 32);
+    if (FLAGS) ring_wait(full + slot, 8u * ((it >> 2) + 1));
+    float mx = -1e30f;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const float* arow = smem + slot * STAGE + (sub * 16 + j) * ROW + sl * 64;
+      f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(arow + 4 * c);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, b0[4 * c], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, b1[4 * c], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, b0[4 * c + 1], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, b1[4 * c + 1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, b0[4 * c + 2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, b1[4 * c + 2], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, b0[4 * c + 3], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, b1[4 * c + 3], acc1, 0, 0, 0);
+      }
+      mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(acc0[0], acc0[1]), fmaxf(acc0[2], acc0[3])),
+                           fmaxf(fmaxf(acc1[0], acc1[1]), fmaxf(acc1[2], acc1[3]))));
+    }
+    if (__any(mx >= 1e30f)) keep += mx;
+    if (FLAGS) {
+      ring_signal(freec + slot, lane);
+      if (pending >= 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ring_signal(full + pending, lane);
+      }
+      ring_wait(freec + ws, 8u * ((it + 3) >> 2));
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave * 4 + i;
+      dma_row(keys + (key0 + row) * 256, lds_base + 4u * (ws * STAGE + row * ROW), lane16);
+    }
+    pending = ws;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  out[blockIdx.x * blockDim.x + threadIdx.x] = keep;
+}
+template <int FLAGS>
+void run16(const char* name, const float* keys, int64_t nkeys) {
+  float* d;
+  hipMalloc(&d, 256 * 512 * 4);
+  hipFuncSetAttribute((const void*)k16<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  int iters = 4000;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const size_t lds = 4 * 32 * 260 * 4 + 20480;
+  k16<FLAGS><<<256, 512, lds>>>(keys, nkeys, d, 10, 1.0f);
+  hipDeviceSynchronize();
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0);
+    k16<FLAGS><<<256, 512, lds>>>(keys, nkeys, d, iters, 1.0001f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  double flop = 256.0 * 8 * iters * 256.0 * 2048.0;
+  printf("%-64s %8.3f ms  %7.1f TFLOP/s\n", name, best, flop / best / 1e9);
+  hipFree(d);
+}
+
 template <int MODE>
 void run(const char* name, const float* keys, int64_t nkeys) {
   float* d;
@@ -324,6 +421,8 @@ int main() {
   run<13>("kernel ring, s_setprio 3 inside the MFMA section", keys, nkeys);
   run<6>("kernel ring (repeat)", keys, nkeys);
   run14("ring with everything inside the MFMA stream (two accumulators)", keys, nkeys);
+  run16<0>("16x16x4 x 2 chains: burst DMA, no counters", keys, nkeys);
+  run16<1>("16x16x4 x 2 chains: kernel ring (burst DMA + counters)", keys, nkeys);
   run<0>("no DMA (repeat)", keys, nkeys);
   return 0;
 }
