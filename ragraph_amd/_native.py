@@ -34,6 +34,12 @@ SIGNATURES = {
     "ragraph_topk_cosine_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
     "ragraph_topk_cosine_f32": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _sz, _vp]),
     "ragraph_pack_keys_f32": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "ragraph_keys_bf16_rows": (_i64, [_i64]),
+    "ragraph_keys_to_bf16": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "ragraph_topk_cosine_filtered_cap": (_i32, [_i32]),
+    "ragraph_topk_cosine_filtered_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
+    "ragraph_topk_cosine_filtered_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp,
+                                                _sz, _vp]),
     "ragraph_topk_cosine_bank_f32": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _sz, _vp]),
     "ragraph_topk_merge_f32": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     "ragraph_gather_rows_f32": (_i32, [_vp, _i64, _i32, _vp, _i64, _i64, _vp, _vp]),

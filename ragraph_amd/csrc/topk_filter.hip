@@ -1,0 +1,583 @@
+// Exact cosine top-k through a bf16 MFMA filter  (SimilarityFunctions.py:6-16 + ToyGraphBase.py:66-67, large batches).
+//
+// The fp32 tile kernel (topk_cosine.hip) spends 2·B·N·D fp32 MFMA flops; the bf16 matrix cores are 16x faster.  This
+// path returns the SAME bits with most of the work on them:
+//   1. sample pass (exact, fp32 kernel): top-k of every query over the first Ns keys.  Its k-th score theta[q] is a
+//      lower bound of the final k-th best exact score of q.
+//   2. filter pass (this file, bf16 MFMA over the whole bank): approximate scores s~ = bf16(q)·bf16(key), fp32
+//      accumulate.  Both vectors have unit norm, every element is rounded to 8 significant bits, so by Cauchy-Schwarz
+//      |s~ - s| <= (2^-8 + 2^-16)·|q|·|key| + accumulation error < EPS = 2^-8 + 2^-11 for EVERY pair.  A key of the
+//      exact top-k has s >= theta[q], hence s~ >= theta[q] - EPS: every key that passes goes to the query's candidate
+//      list (global append).  Nothing else can be in the result.
+//   3. rescoring pass: the exact score of every candidate as the fp32 fmaf chain in natural k order from +0 (one lane
+//      per candidate) -- the same chain the f32 MFMA and the oracle compute, so the same bits -- and the canonical
+//      top-k (score descending, index ascending) of the candidates.
+// A query whose candidate list overflows its capacity (adversarial banks: thousands of keys within EPS of the k-th
+// best) is counted in *overflow and must be re-run through ragraph_topk_cosine_bank_f32 by the caller; the other
+// queries' results are exact regardless.
+//
+// Filter kernel: workgroup = 8 waves x 64 queries = 512 queries; a wave keeps its queries as the B operands of
+// v_mfma_f32_32x32x16_bf16 (two groups of 32: 2 x 64 VGPRs) and streams the bf16 bank (512 B per key) through an
+// 8-slot LDS ring of 16 KiB stages (32 keys) filled by LDS-DMA, two rows per global_load_lds_dwordx4, handed over by
+// FULL/FREE counters.  One ds_read_b128 (8 bf16 of one key row) feeds two MFMAs (one per query group).  The LDS image is
+// XOR-swizzled through the DMA's per-lane SOURCE address (16-B chunk c of row j sits at chunk c ^ (j & 15)), which
+// makes the ds_read_b128 of the 32 rows conflict-free without padding.  Work plan: segment_plan.h with zero warm-up
+// cost (there are no lists): every workgroup gets the same number of stages.
+#include "common.h"
+#include "segment_plan.h"
+
+namespace ragraph {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void_f;
+
+constexpr float FILTER_EPS = 0.00390625f + 0.00048828125f;  // 2^-8 + 2^-11, see the header comment
+constexpr int CHUNK = 16;  // candidate slots a lane reserves at a time
+
+template <int SUBS>  // 32-key MFMA sub-tiles per ring stage: the ring hand-over (flags, DMA issue) is paid once per stage
+struct FilterCfg {
+  static constexpr int D = 256;
+  static constexpr int WAVES = 8, THREADS = 512;
+  static constexpr int QT = 512;                 // queries per workgroup
+  static constexpr int STAGE_KEYS = 32 * SUBS;
+  static constexpr int ROW_BYTES = D * 2;        // one bf16 key
+  static constexpr int STAGE_BYTES = STAGE_KEYS * ROW_BYTES;  // 16 KiB per sub-tile
+  static constexpr int SLOTS = 8 / SUBS;         // 128 KiB of ring; the hand-over protocol needs >= 3 slots
+  static constexpr int PAIRS = 2 * SUBS;         // row pairs (1 KiB DMA instructions) per wave and stage
+  static constexpr size_t LDS_BYTES = (size_t)SLOTS * STAGE_BYTES + 64;
+};
+
+struct FilterParams {
+  const float* Qn;        // [B,256] normalised queries (fp32)
+  const uint16_t* Kb;     // [round_up(N,128),256] bf16 keys, rows >= N zero
+  const float* thr;       // [B] theta[q] - EPS
+  int* count;             // [B] candidates appended so far
+  int* cand;              // [B,cap] candidate key indices (local to this shard)
+  int64_t B, N;
+  int cap;
+  int64_t qtiles, nstages_total;
+  int xcd_map, wgs_per_group, lb_min, depth[2];
+};
+
+__device__ __forceinline__ void fring_wait(unsigned* ctr, unsigned target) {
+  while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void fring_signal(unsigned* ctr, int lane) {
+  if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Rows [N, round_up(N,128)) of Kb are zero so the stream never needs a tail clamp (a ring stage is <= 128 keys).
+__global__ void __launch_bounds__(256) keys_to_bf16_kernel(const float* __restrict__ Kn, int64_t N, int64_t Npad,
+                                                           uint16_t* __restrict__ Kb) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread = 8 elements
+  if (i >= Npad * 32) return;
+  const int64_t row = i >> 5;
+  bf16x8 o;
+  if (row < N) {
+    const float4 a = reinterpret_cast<const float4*>(Kn)[2 * i], b = reinterpret_cast<const float4*>(Kn)[2 * i + 1];
+    o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
+    o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)0.f;
+  }
+  reinterpret_cast<bf16x8*>(Kb)[i] = o;
+}
+
+// thr[q] = theta[q] - EPS from the sample pass's k-th score; count[q] = 0.
+__global__ void __launch_bounds__(256) filter_prepare_kernel(const float* __restrict__ sample_scores, int64_t B, int k,
+                                                             float* __restrict__ thr, int* __restrict__ count,
+                                                             int* __restrict__ overflow, int ablate) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q == 0) *overflow = 0;
+  if (q >= B) return;
+  thr[q] = ablate ? __builtin_huge_valf() : __fsub_rn(sample_scores[q * k + k - 1], FILTER_EPS);
+  count[q] = 0;
+}
+
+#ifdef RG_TOPK_TIMING  // diagnostic build only: per-wave cycle totals of the ring's phases
+__device__ unsigned long long g_filter_timing[8];
+#define RG_FT(var_) const unsigned long long var_ = __builtin_amdgcn_s_memtime()
+#else
+#define RG_FT(var_)
+#endif
+
+// BAR = true: one s_barrier per stage hands the ring over (every wave retires its own rows of stage s with a counted
+// vmcnt, the barrier then says both "stage s has landed" and "everybody is done with stage s-1", whose slot the next
+// DMA overwrites).  BAR = false: FULL / FREE counters (waves may drift a stage apart).
+template <int SUBS, bool BAR>
+__global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
+  using C = FilterCfg<SUBS>;
+  extern __shared__ float4 fsmem4[];
+  char* smem = reinterpret_cast<char*>(fsmem4);
+  unsigned* full = reinterpret_cast<unsigned*>(smem + C::SLOTS * C::STAGE_BYTES);  // [8] then freec [8]
+  unsigned* freec = full + C::SLOTS;
+  const unsigned lds_base = (unsigned)(size_t)(lds_void_f*)smem;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, g = lane >> 5;
+
+  // DMA source offsets of this lane for the wave's row pairs (pair i = rows 2i, 2i+1 of the wave's 2*PAIRS rows of a
+  // stage): LDS byte 16 l of a pair is row (l >> 5) of the pair at chunk position l & 31, which holds source chunk
+  // pos ^ (row & 15).
+  unsigned voff[C::PAIRS];
+#pragma unroll
+  for (int i = 0; i < C::PAIRS; ++i) {
+    const int row = 2 * C::PAIRS * wave + 2 * i + g;  // row inside the stage
+    voff[i] = (unsigned)(2 * i + g) * C::ROW_BYTES + (unsigned)((j ^ (row & 15)) * 16);
+  }
+  auto dma_stage = [&](int64_t stage_abs, int slot) {  // stage_abs: stage index over the whole bank
+    const char* gbase =
+        reinterpret_cast<const char*>(p.Kb) + (stage_abs * C::STAGE_KEYS + 2 * C::PAIRS * wave) * C::ROW_BYTES;
+#pragma unroll
+    for (int i = 0; i < C::PAIRS; ++i) {
+      const unsigned dst = lds_base + (unsigned)(slot * C::STAGE_BYTES + (2 * C::PAIRS * wave + 2 * i) * C::ROW_BYTES);
+      unsigned keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(voff[i]), "s"(dst), "s"(gbase)
+          : "memory");
+    }
+  };
+  // A fragment of lane (j, g) for k-step t: row j, source chunk c = 2t + g, stored at position c ^ (j & 15).  With
+  // c0 = g ^ (j & 15): position = (2t ^ c0) for t < 8 and (2(t-8) ^ c0) + 16 for t >= 8, so eight per-lane addresses
+  // plus the immediate offsets 256 B (t >= 8) and 16 KiB (next sub-tile) reach every fragment of a stage.
+  unsigned apos[8];
+  {
+    const unsigned c0 = (unsigned)(g ^ (j & 15));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) apos[i] = lds_base + (unsigned)j * C::ROW_BYTES + (((unsigned)(2 * i) ^ c0) << 4);
+  }
+
+  const int x = p.xcd_map ? (int)(blockIdx.x & 7) : 0;
+  const int64_t nq = p.xcd_map ? ((p.qtiles - x + 7) >> 3) : p.qtiles;
+  const int64_t nq0 = p.xcd_map ? ((p.qtiles + 7) >> 3) : p.qtiles;
+  SegmentWalker walker(nq, p.nstages_total, p.wgs_per_group, p.lb_min, 0, p.depth[nq != nq0],
+                       p.xcd_map ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);
+  Segment seg;
+  while (walker.next(seg)) {
+    const int64_t qtile = p.xcd_map ? x + 8 * seg.tile : seg.tile;
+    const int64_t q_lo = qtile * C::QT + wave * 64 + j, q_hi = q_lo + 32;
+    const int64_t st0 = seg.st0;
+    const int nstages = (int)(seg.st1 - seg.st0);
+
+    // ---- B operands: queries q_lo / q_hi, k-step t = elements 16 t + 8 g .. + 7, converted to bf16 (RNE) ----------
+    bf16x8 b0[16], b1[16];
+    {
+      const float* r0 = p.Qn + (q_lo < p.B ? q_lo : p.B - 1) * C::D + 8 * g;
+      const float* r1 = p.Qn + (q_hi < p.B ? q_hi : p.B - 1) * C::D + 8 * g;
+#pragma unroll
+      for (int t0 = 0; t0 < 16; t0 += 4) {  // batches of 4 steps = 16 float4 in flight
+#pragma unroll
+        for (int t = t0; t < t0 + 4; ++t) {
+          const float4 u0 = *reinterpret_cast<const float4*>(r0 + 16 * t), u1 = *reinterpret_cast<const float4*>(r0 + 16 * t + 4);
+          const float4 w0 = *reinterpret_cast<const float4*>(r1 + 16 * t), w1 = *reinterpret_cast<const float4*>(r1 + 16 * t + 4);
+          b0[t][0] = (__bf16)u0.x; b0[t][1] = (__bf16)u0.y; b0[t][2] = (__bf16)u0.z; b0[t][3] = (__bf16)u0.w;
+          b0[t][4] = (__bf16)u1.x; b0[t][5] = (__bf16)u1.y; b0[t][6] = (__bf16)u1.z; b0[t][7] = (__bf16)u1.w;
+          b1[t][0] = (__bf16)w0.x; b1[t][1] = (__bf16)w0.y; b1[t][2] = (__bf16)w0.z; b1[t][3] = (__bf16)w0.w;
+          b1[t][4] = (__bf16)w1.x; b1[t][5] = (__bf16)w1.y; b1[t][6] = (__bf16)w1.z; b1[t][7] = (__bf16)w1.w;
+        }
+#pragma unroll
+        for (int t = t0; t < t0 + 4; ++t) asm volatile("" : "+v"(b0[t]), "+v"(b1[t]));
+        asm volatile("" ::: "memory");
+      }
+    }
+    // padded queries never pass: +inf threshold
+    const float thr0 = q_lo < p.B ? p.thr[q_lo] : __builtin_huge_valf();
+    const float thr1 = q_hi < p.B ? p.thr[q_hi] : __builtin_huge_valf();
+    // Candidate slots are reserved CHUNK at a time (one returning atomic per 16 candidates of a lane; the candidate
+    // itself is a plain store); unused slots of a chunk keep the buffer's -1 fill and are skipped by the rescoring.
+    int base0 = 0, used0 = CHUNK, base1 = 0, used1 = CHUNK;
+
+    // ---- ring prologue ------------------------------------------------------------------------------------------
+    const int pro = nstages < C::SLOTS - 1 ? nstages : C::SLOTS - 1;
+    if constexpr (BAR) {
+      for (int s = 0; s < pro; ++s) dma_stage(st0 + s, s);
+    } else {
+      if (tid < 2 * C::SLOTS) full[tid] = 0;
+      for (int s = 0; s < pro; ++s) dma_stage(st0 + s, s);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid < pro) full[tid] = C::WAVES;
+      __syncthreads();
+    }
+
+    int pending = -1;
+#ifdef RG_TOPK_TIMING
+    unsigned long long tw[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    for (int s = 0; s < nstages; ++s) {
+      const int slot = s & (C::SLOTS - 1), gen = s / C::SLOTS;
+      RG_FT(t0);
+      if constexpr (BAR) {
+        // my rows of stage s have landed once at most the (SLOTS-2)*PAIRS younger DMAs are outstanding (loads retire in
+        // order; younger stores only make the wait stricter); near the end fewer were issued: wait for everything
+        if (s + C::SLOTS - 2 < nstages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((C::SLOTS - 2) * C::PAIRS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + C::SLOTS - 1 < nstages) dma_stage(st0 + s + C::SLOTS - 1, (s + C::SLOTS - 1) & (C::SLOTS - 1));
+      } else {
+        fring_wait(full + slot, (unsigned)(C::WAVES * (gen + 1)));
+      }
+      RG_FT(t1);
+      // epilogue of sub-tile u: acc[r] = approximate score of key row (r&3) + 8 (r>>2) + 4 g of the sub-tile
+      auto epilogue = [&](int u, const f32x16& a0, const f32x16& a1) {
+        float m0 = a0[0], m1 = a1[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) {
+          m0 = fmaxf(m0, a0[r]);
+          m1 = fmaxf(m1, a1[r]);
+        }
+        if (__any(m0 >= thr0 || m1 >= thr1)) {
+          const int key_base = (int)((st0 + s) * C::STAGE_KEYS) + 32 * u + 4 * g;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = key_base + (r & 3) + 8 * (r >> 2);
+            if (a0[r] >= thr0 && key < (int)p.N) {
+              if (used0 == CHUNK) {
+                base0 = atomicAdd(p.count + q_lo, CHUNK);
+                used0 = 0;
+              }
+              if (base0 + used0 < p.cap) p.cand[q_lo * p.cap + base0 + used0] = key;
+              ++used0;
+            }
+            if (a1[r] >= thr1 && key < (int)p.N) {
+              if (used1 == CHUNK) {
+                base1 = atomicAdd(p.count + q_hi, CHUNK);
+                used1 = 0;
+              }
+              if (base1 + used1 < p.cap) p.cand[q_hi * p.cap + base1 + used1] = key;
+              ++used1;
+            }
+          }
+        }
+      };
+      // ---- SUBS sub-tiles of 32 keys x 64 queries, 16 k-steps each; one A fragment per step feeds both query groups.
+      // A step is only 64 cycles of MFMA, less than an LDS round trip, so the fragment reads run FOUR steps ahead of
+      // their MFMAs (hipcc's own schedule keeps one ahead and the matrix pipe idles half the time).  They are asm
+      // loads, invisible to hipcc's waitcnt bookkeeping: RG_FWAIT counts them (LDS returns in order; anything else
+      // outstanding only makes the wait stricter) and names the fragment so its MFMAs stay behind the wait.
+      unsigned addr[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) addr[i] = apos[i] + (unsigned)(slot * C::STAGE_BYTES);
+      f32x16 acc0, acc1;
+      f32x4 fr[4];
+#define RG_FREAD(n_)                                                                                       \
+  asm volatile("ds_read_b128 %0, %1 offset:%2"                                                             \
+               : "=v"(fr[(n_)&3])                                                                           \
+               : "v"(addr[(n_)&7]), "i"(((n_) / 16) * 32 * C::ROW_BYTES + ((((n_) % 16) >= 8) ? 256 : 0)))
+#define RG_FWAIT(c_, n_) asm volatile("s_waitcnt lgkmcnt(" #c_ ")" : "+v"(fr[(n_)&3]))
+#define RG_FSTEP(n_)                                                                                       \
+  if constexpr ((n_) < 16 * SUBS) {                                                                        \
+    if constexpr ((n_) % 16 == 0) {                                                                        \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;                               \
+    }                                                                                                      \
+    if constexpr ((n_) + 3 < 16 * SUBS) RG_FWAIT(3, n_);                                                    \
+    else if constexpr ((n_) + 2 < 16 * SUBS) RG_FWAIT(2, n_);                                               \
+    else if constexpr ((n_) + 1 < 16 * SUBS) RG_FWAIT(1, n_);                                               \
+    else RG_FWAIT(0, n_);                                                                                   \
+    {                                                                                                      \
+      const bf16x8 a_ = __builtin_bit_cast(bf16x8, fr[(n_)&3]);                                             \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b0[(n_) % 16], acc0, 0, 0, 0);                     \
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b1[(n_) % 16], acc1, 0, 0, 0);                     \
+    }                                                                                                      \
+    if constexpr ((n_) + 4 < 16 * SUBS) RG_FREAD((n_) + 4);                                                 \
+    if constexpr ((n_) % 16 == 15) epilogue((n_) / 16, acc0, acc1);                                         \
+  }
+      RG_FREAD(0);
+      RG_FREAD(1);
+      RG_FREAD(2);
+      RG_FREAD(3);
+      RG_FSTEP(0) RG_FSTEP(1) RG_FSTEP(2) RG_FSTEP(3) RG_FSTEP(4) RG_FSTEP(5) RG_FSTEP(6) RG_FSTEP(7)
+      RG_FSTEP(8) RG_FSTEP(9) RG_FSTEP(10) RG_FSTEP(11) RG_FSTEP(12) RG_FSTEP(13) RG_FSTEP(14) RG_FSTEP(15)
+      RG_FSTEP(16) RG_FSTEP(17) RG_FSTEP(18) RG_FSTEP(19) RG_FSTEP(20) RG_FSTEP(21) RG_FSTEP(22) RG_FSTEP(23)
+      RG_FSTEP(24) RG_FSTEP(25) RG_FSTEP(26) RG_FSTEP(27) RG_FSTEP(28) RG_FSTEP(29) RG_FSTEP(30) RG_FSTEP(31)
+#undef RG_FSTEP
+#undef RG_FWAIT
+#undef RG_FREAD
+      RG_FT(t2);
+      if constexpr (!BAR) {
+        fring_signal(freec + slot, lane);
+        if (pending >= 0) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          fring_signal(full + pending, lane);
+          pending = -1;
+        }
+      }
+      RG_FT(t3);
+#ifdef RG_TOPK_TIMING
+      unsigned long long t4 = t3, t5 = t3;
+#endif
+      if (!BAR && s + C::SLOTS - 1 < nstages) {
+        const int ws = (s + C::SLOTS - 1) & (C::SLOTS - 1);  // the slot stage s-1 lived in
+        fring_wait(freec + ws, (unsigned)(C::WAVES * ((s + C::SLOTS - 1) / C::SLOTS)));
+#ifdef RG_TOPK_TIMING
+        t4 = __builtin_amdgcn_s_memtime();
+#endif
+        dma_stage(st0 + s + C::SLOTS - 1, ws);
+        pending = ws;
+#ifdef RG_TOPK_TIMING
+        t5 = __builtin_amdgcn_s_memtime();
+#endif
+      }
+#ifdef RG_TOPK_TIMING
+      tw[0] += t1 - t0; tw[1] += t2 - t1; tw[2] += t3 - t2; tw[3] += t4 - t3; tw[4] += t5 - t4; tw[5] += 1;
+#endif
+    }
+#ifdef RG_TOPK_TIMING
+    if (lane == 0)
+      for (int i = 0; i < 6; ++i) atomicAdd(&g_filter_timing[i], tw[i]);
+#endif
+    __syncthreads();  // flags are re-initialised by the next segment
+  }
+}
+
+// One wave per query: exact scores of its candidates (one lane per candidate, the k = 0..255 fmaf chain from +0) and
+// the canonical top-k of them.  CPL = candidates per lane (cap <= 64 * CPL).
+template <int CPL>
+__global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restrict__ Qn, const float* __restrict__ Kn,
+                                                           const int* __restrict__ count, const int* __restrict__ cand,
+                                                           int64_t B, int cap, int k, int64_t idx_base,
+                                                           float* __restrict__ out_s, int64_t* __restrict__ out_i,
+                                                           int* __restrict__ overflow, int64_t* __restrict__ overflow_idx) {
+  constexpr int D = 256;
+  __shared__ float4 qs[4][D / 4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 4 + w;
+  if (b >= B) return;  // whole wave
+  qs[w][lane] = reinterpret_cast<const float4*>(Qn + b * D)[lane];  // 64 lanes x float4 = the query row
+  __builtin_amdgcn_wave_barrier();
+  int n = count[b];
+  if (n > cap) {  // slots reserved beyond the capacity: candidates were dropped
+    if (lane == 0) {
+      const int pos = atomicAdd(overflow, 1);
+      if (overflow_idx) overflow_idx[pos] = b;
+    }
+    n = cap;
+  }
+  float s[CPL];
+  int64_t id[CPL];
+#pragma unroll
+  for (int u = 0; u < CPL; ++u) {
+    const int c = lane + 64 * u;
+    s[u] = RG_NEG_INF;
+    id[u] = INT64_MAX;
+    const int key = c < n ? cand[b * cap + c] : -1;
+    if (key >= 0) {
+      const float4* kr = reinterpret_cast<const float4*>(Kn + (int64_t)key * D);
+      float acc = 0.f;
+#pragma unroll 8
+      for (int d4 = 0; d4 < D / 4; ++d4) {
+        const float4 kv = kr[d4], qv = qs[w][d4];
+        acc = fmaf(qv.x, kv.x, acc);
+        acc = fmaf(qv.y, kv.y, acc);
+        acc = fmaf(qv.z, kv.z, acc);
+        acc = fmaf(qv.w, kv.w, acc);
+      }
+      s[u] = acc;
+      id[u] = key;
+    }
+  }
+  float prev_s = __builtin_huge_valf();
+  int64_t prev_i = -1;  // everything is worse than (+inf, -1)
+  for (int r = 0; r < k; ++r) {
+    float best_s = RG_NEG_INF;
+    int64_t best_i = INT64_MAX;
+#pragma unroll
+    for (int u = 0; u < CPL; ++u) {
+      const bool after_prev = (s[u] < prev_s) || (s[u] == prev_s && id[u] > prev_i);
+      const bool beats = (s[u] > best_s) || (s[u] == best_s && id[u] < best_i);
+      if (after_prev && beats) {
+        best_s = s[u];
+        best_i = id[u];
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float os = __shfl_xor(best_s, off);
+      const int64_t oi = __shfl_xor(best_i, off);
+      if ((os > best_s) || (os == best_s && oi < best_i)) {
+        best_s = os;
+        best_i = oi;
+      }
+    }
+    if (lane == 0) {
+      out_s[b * k + r] = best_s;
+      out_i[b * k + r] = best_i == INT64_MAX ? INT64_MAX : best_i + idx_base;
+    }
+    prev_s = best_s;
+    prev_i = best_i;
+  }
+}
+
+static int filter_device_cus() {
+  static const int cus = [] {
+    if (const char* e = getenv("RAGRAPH_TOPK_CUS")) {
+      const int v = atoi(e);
+      if (v >= 8) return v / 8 * 8;
+    }
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
+      n = 256;
+    return n / 8 * 8;
+  }();
+  return cus;
+}
+
+}  // namespace ragraph
+
+using namespace ragraph;
+
+static int64_t filter_sample_keys(int64_t N) {
+  int64_t ns = N / 32;  // 1/32 of the bank: the exact pass costs 3 % of a full one and leaves ~32 k candidates per query
+  if (ns < 16384) ns = 16384;
+  return ns < N ? ns : N;
+}
+
+extern "C" int ragraph_keys_to_bf16(const float* Kn, int64_t N, int D, uint16_t* Kb, void* stream) {
+  RG_REQUIRE(Kn && Kb, RAGRAPH_EINVAL, "keys_to_bf16: null pointer");
+  RG_REQUIRE(N >= 1, RAGRAPH_EINVAL, "keys_to_bf16: N=%lld must be >= 1", (long long)N);
+  RG_REQUIRE(D == 256, RAGRAPH_EUNSUPPORTED, "keys_to_bf16: D=%d (only 256)", D);
+  RG_REQUIRE(aligned16(Kn) && aligned16(Kb), RAGRAPH_EINVAL, "keys_to_bf16: pointers must be 16-B aligned");
+  const int64_t npad = ragraph_keys_bf16_rows(N);
+  hipLaunchKernelGGL(keys_to_bf16_kernel, dim3((unsigned)cdiv(npad * 32, 256)), dim3(256), 0, as_stream(stream), Kn, N,
+                     npad, Kb);
+  RG_CHECK_LAUNCH("keys_to_bf16");
+  return RAGRAPH_OK;
+}
+
+extern "C" int64_t ragraph_keys_bf16_rows(int64_t N) { return N < 1 ? 0 : (N + 127) / 128 * 128; }  // whole stages
+
+extern "C" int ragraph_topk_cosine_filtered_cap(int k) { return 2048; }
+
+extern "C" size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_t N, int D, int k) {
+  if (B < 1 || N < 1 || k < 1 || D != 256) return 0;
+  const int cap = ragraph_topk_cosine_filtered_cap(k);
+  return ragraph_topk_cosine_workspace_bytes(B, filter_sample_keys(N), D, k) + align_up((size_t)B * D * sizeof(float), 256) +
+         align_up((size_t)B * sizeof(float), 256) + align_up((size_t)B * sizeof(int), 256) +
+         align_up((size_t)B * cap * sizeof(int), 256);
+}
+
+extern "C" int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const float* Kn, const float* Kp,
+                                                const uint16_t* Kb, int64_t N, int D, int k, int64_t idx_base,
+                                                float* out_scores, int64_t* out_idx, int* overflow,
+                                                int64_t* overflow_idx, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(Q && Kn && Kb && out_scores && out_idx && overflow && ws, RAGRAPH_EINVAL, "topk_cosine_filtered: null pointer");
+  RG_REQUIRE(D == 256, RAGRAPH_EUNSUPPORTED, "topk_cosine_filtered: D=%d (only 256)", D);
+  RG_REQUIRE(B >= 1 && N >= 1 && k >= 1 && k <= 32 && k <= N, RAGRAPH_EINVAL, "topk_cosine_filtered: bad B/N/k");
+  RG_REQUIRE(N < (int64_t)INT_MAX - 1024, RAGRAPH_EUNSUPPORTED, "topk_cosine_filtered: shard rows must fit int32");
+  RG_REQUIRE(aligned16(Q) && aligned16(Kn) && aligned16(Kb) && aligned16(ws), RAGRAPH_EINVAL,
+             "topk_cosine_filtered: pointers must be 16-B aligned");
+  const size_t need = ragraph_topk_cosine_filtered_workspace_bytes(B, N, D, k);
+  RG_REQUIRE(ws_bytes >= need, RAGRAPH_EWORKSPACE, "topk_cosine_filtered: workspace %zu < %zu", ws_bytes, need);
+  hipStream_t st = as_stream(stream);
+  const int cap = ragraph_topk_cosine_filtered_cap(k);
+  const int64_t ns = filter_sample_keys(N);
+
+  char* w = static_cast<char*>(ws);
+  const size_t sample_ws = ragraph_topk_cosine_workspace_bytes(B, ns, D, k);
+  float* Qn = reinterpret_cast<float*>(w + sample_ws);
+  float* thr = reinterpret_cast<float*>(reinterpret_cast<char*>(Qn) + align_up((size_t)B * D * sizeof(float), 256));
+  int* count = reinterpret_cast<int*>(reinterpret_cast<char*>(thr) + align_up((size_t)B * sizeof(float), 256));
+  int* cand = reinterpret_cast<int*>(reinterpret_cast<char*>(count) + align_up((size_t)B * sizeof(int), 256));
+
+  // 1. exact sample pass over the first ns keys (out_scores / out_idx are scratch here)
+  int rc = ragraph_topk_cosine_bank_f32(Q, B, Kn, Kp, ns, D, k, 0, out_scores, out_idx, ws, sample_ws, stream);
+  if (rc != RAGRAPH_OK) return rc;
+  rc = ragraph_normalize_rows_f32(Q, B, D, Qn, stream);
+  if (rc != RAGRAPH_OK) return rc;
+  static const int ablate = [] {  // RAGRAPH_FILTER_ABLATE=1: no key passes the filter (timing only, results invalid)
+    const char* e = getenv("RAGRAPH_FILTER_ABLATE");
+    return e ? atoi(e) : 0;
+  }();
+  hipLaunchKernelGGL(filter_prepare_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, out_scores, B, k, thr, count,
+                     overflow, ablate);
+  RG_CHECK_LAUNCH("topk_cosine_filtered(prepare)");
+  if (hipMemsetAsync(cand, 0xFF, (size_t)B * cap * sizeof(int), st) != hipSuccess) {  // every slot = -1 (unused)
+    set_error("topk_cosine_filtered: memset failed");
+    return RAGRAPH_EDEVICE;
+  }
+
+  // 2. bf16 filter over the whole bank
+  FilterParams p;
+  p.Qn = Qn;
+  p.Kb = Kb;
+  p.thr = thr;
+  p.count = count;
+  p.cand = cand;
+  p.B = B;
+  p.N = N;
+  p.cap = cap;
+  static const int subs = [] {  // RAGRAPH_FILTER_SUBS = 1 | 2: keys per ring stage / 32 (diagnostic, read once)
+    const char* e = getenv("RAGRAPH_FILTER_SUBS");
+    const int v = e ? atoi(e) : 2;
+    return (v == 1 || v == 2) ? v : 2;  // 4 would leave 2 slots: the ring needs a stage in flight beside the one being read
+  }();
+  const int stage_keys = 32 * subs;
+  p.qtiles = cdiv(B, 512);
+  p.nstages_total = cdiv(N, stage_keys);
+  const int CUS = filter_device_cus();
+  p.xcd_map = p.qtiles >= 64 ? 1 : 0;
+  p.wgs_per_group = CUS / (p.xcd_map ? 8 : 1);
+  p.lb_min = 8;
+  const int64_t nq0 = p.xcd_map ? (p.qtiles + 7) / 8 : p.qtiles;
+  for (int v = 0; v < 2; ++v) {
+    const int64_t nq = nq0 - v;
+    p.depth[v] = 0;
+    if (nq < 1 || (v == 1 && (!p.xcd_map || p.qtiles % 8 == 0))) continue;
+    p.depth[v] = SegmentWalker::choose_depth(nq, p.nstages_total, p.wgs_per_group, p.lb_min, 0).depth;
+  }
+  static const bool use_barrier = [] {  // RAGRAPH_FILTER_SYNC = flags | barrier (diagnostic, read once)
+    const char* e = getenv("RAGRAPH_FILTER_SYNC");
+    return !(e && e[0] == 'f');
+  }();
+#define RG_LAUNCH_FILTER(S_, B_)                                                                                      \
+  do {                                                                                                                \
+    static bool attr_set = false;                                                                                     \
+    if (!attr_set) {                                                                                                  \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_filter_kernel<S_, B_>),                  \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)FilterCfg<S_>::LDS_BYTES);  \
+      if (e != hipSuccess) {                                                                                          \
+        set_error("topk_cosine_filtered: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));                  \
+        return RAGRAPH_EDEVICE;                                                                                       \
+      }                                                                                                               \
+      attr_set = true;                                                                                                \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((topk_filter_kernel<S_, B_>), dim3((unsigned)CUS), dim3(512), FilterCfg<S_>::LDS_BYTES, st, p); \
+  } while (0)
+  if (subs == 1 && use_barrier) RG_LAUNCH_FILTER(1, true);
+  else if (subs == 1) RG_LAUNCH_FILTER(1, false);
+  else if (use_barrier) RG_LAUNCH_FILTER(2, true);
+  else RG_LAUNCH_FILTER(2, false);
+#undef RG_LAUNCH_FILTER
+  RG_CHECK_LAUNCH("topk_cosine_filtered(filter)");
+#ifdef RG_TOPK_TIMING
+  {
+    (void)hipDeviceSynchronize();
+    unsigned long long t[8];
+    (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_filter_timing), sizeof(t));
+    const double n = (double)t[5];
+    if (n > 0)
+      fprintf(stderr, "[filter timing] SUBS=%d wave-stages=%.0f ticks/stage: wait_full %.1f compute %.1f signal+vmcnt %.1f "
+              "wait_free %.1f dma_issue %.1f total %.1f\n", subs, n, t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n,
+              (t[0] + t[1] + t[2] + t[3] + t[4]) / n);
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_filter_timing), zero, sizeof(zero));
+  }
+#endif
+
+  // 3. exact rescoring + canonical selection
+  dim3 grid((unsigned)cdiv(B, 4)), block(256);
+  if (cap <= 1024)
+    hipLaunchKernelGGL(topk_rescore_kernel<16>, grid, block, 0, st, Qn, Kn, count, cand, B, cap, k, idx_base, out_scores,
+                       out_idx, overflow, overflow_idx);
+  else
+    hipLaunchKernelGGL(topk_rescore_kernel<32>, grid, block, 0, st, Qn, Kn, count, cand, B, cap, k, idx_base, out_scores,
+                       out_idx, overflow, overflow_idx);
+  RG_CHECK_LAUNCH("topk_cosine_filtered(rescore)");
+  return RAGRAPH_OK;
+}

@@ -118,6 +118,65 @@ def topk_cosine(q: torch.Tensor, keys_normalized: torch.Tensor, k: int, idx_base
     return scores, idx
 
 
+def keys_to_bf16(keys_normalized: torch.Tensor) -> torch.Tensor:
+    """bf16 copy of the bank for topk_cosine_filtered (rows padded with zeros to a multiple of 128; int16 storage)."""
+    L = _ready()
+    kn = _f32c(keys_normalized, "keys_to_bf16.keys")
+    rows = L.ragraph_keys_bf16_rows(kn.shape[0])
+    out = torch.empty((rows, kn.shape[1]), dtype=torch.int16, device=kn.device)
+    if kn.shape[0]:
+        N.check(L.ragraph_keys_to_bf16(kn.data_ptr(), kn.shape[0], kn.shape[1], out.data_ptr(), _stream()), "keys_to_bf16")
+    return out
+
+
+def filter_helps(B: int, n_keys: int, D: int, k: int) -> bool:
+    """True when the bf16-filtered exact top-k is the faster way to the same bits: enough queries to fill 512-query
+    tiles on every CU and a bank large enough that its 1/32 exact sample pass is a small part of the work."""
+    return D == 256 and k <= 32 and B >= 8192 and n_keys >= 262144
+
+
+def topk_cosine_filtered(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf16: torch.Tensor, k: int,
+                         idx_base: int = 0, keys_packed: torch.Tensor | None = None):
+    """Exact top-k (same bits as topk_cosine) through the bf16 MFMA filter.  Returns (scores, idx, n_overflow): the few
+    queries whose candidate list overflowed (none on ordinary banks) are recomputed here with the fp32 kernel, so the
+    result is complete; `n_overflow` says how many there were.  Reading that count synchronises with the stream -- use
+    topk_cosine where a call must stay asynchronous (graph capture)."""
+    L = _ready()
+    q = _f32c(q, "topk_cosine_filtered.q")
+    kn = _f32c(keys_normalized, "topk_cosine_filtered.keys")
+    B, D = q.shape
+    Nk = kn.shape[0]
+    if keys_bf16.dtype != torch.int16 or not keys_bf16.is_contiguous() or keys_bf16.shape[1] != D or \
+            keys_bf16.shape[0] != L.ragraph_keys_bf16_rows(Nk):
+        raise RagraphNativeError("topk_cosine_filtered: keys_bf16 must come from keys_to_bf16(keys_normalized)")
+    kp = 0
+    if keys_packed is not None:
+        kpt = _f32c(keys_packed, "topk_cosine_filtered.keys_packed")
+        if kpt.shape != kn.shape:
+            raise RagraphNativeError("topk_cosine_filtered: keys_packed shape mismatch")
+        kp = kpt.data_ptr()
+    scores = torch.empty((B, k), dtype=torch.float32, device=q.device)
+    idx = torch.empty((B, k), dtype=torch.int64, device=q.device)
+    overflow = torch.zeros(1, dtype=torch.int32, device=q.device)
+    overflow_idx = torch.empty(B, dtype=torch.int64, device=q.device)
+    nbytes = L.ragraph_topk_cosine_filtered_workspace_bytes(B, Nk, D, k)
+    if nbytes == 0:
+        raise RagraphNativeError(f"topk_cosine_filtered: unsupported shape B={B} N={Nk} D={D} k={k}")
+    ws = _workspace(nbytes, q.device)
+    N.check(L.ragraph_topk_cosine_filtered_f32(q.data_ptr(), B, kn.data_ptr(), kp, keys_bf16.data_ptr(), Nk, D, k, idx_base,
+                                               scores.data_ptr(), idx.data_ptr(), overflow.data_ptr(),
+                                               overflow_idx.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+            "topk_cosine_filtered")
+    n_over = int(overflow.item())
+    if n_over:
+        rows = overflow_idx[:n_over]
+        s2, i2 = topk_cosine(q.index_select(0, rows), kn, k, idx_base=idx_base,
+                             keys_packed=keys_packed if packed_keys_help(n_over, D, k) else None)
+        scores.index_copy_(0, rows, s2)
+        idx.index_copy_(0, rows, i2)
+    return scores, idx, n_over
+
+
 def topk_merge(scores: torch.Tensor, idx: torch.Tensor):
     """[G,B,k] per-shard lists -> canonical [B,k]."""
     L = _ready()

@@ -347,3 +347,50 @@ def test_spmm_linear_fuzz_against_oracle(dev):
         A = rng.standard_normal((M, Kd), dtype=np.float32)
         W = rng.standard_normal((Nd, Kd), dtype=np.float32)
         assert np.array_equal(K.linear(_t(A, dev), _t(W, dev)).cpu().numpy(), cref.linear(A, W)), f"linear {M}x{Kd}x{Nd}"
+
+
+@pytest.mark.parametrize(
+    "B,N,k",
+    [
+        (700, 40000, 10),      # sample = 16384 keys, two query tiles (one ragged), one group of workgroups
+        (513, 33000, 1),
+        (1500, 70001, 14),     # N not a multiple of 32: zero-padded bf16 rows are masked by index
+        (600, 20000, 32),
+    ],
+)
+def test_topk_cosine_filtered_bit_exact(dev, B, N, k):
+    """bf16-filtered exact top-k vs the oracle: indices and scores bit-identical, no overflow on random banks."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(B + N + k)
+    kn = _bank(rng, N, 256)
+    q = rng.standard_normal((B, 256), dtype=np.float32)
+    knd = _t(kn, dev)
+    kb = K.keys_to_bf16(knd)
+    assert kb.shape[0] % 128 == 0 and kb.shape[0] >= N
+    s, i, over = K.topk_cosine_filtered(_t(q, dev), knd, kb, k, idx_base=9)
+    assert over == 0
+    rs, ri = cref.topk_cosine(q, kn, k, idx_base=9)
+    assert np.array_equal(i.cpu().numpy(), ri)
+    assert np.array_equal(s.cpu().numpy(), rs)
+
+
+def test_topk_cosine_filtered_overflow_falls_back(dev):
+    """A bank of near-duplicates puts thousands of keys within EPS of every query's k-th best, and a zero query ties
+    every key at 0: the filter reports those queries and the wrapper recomputes them with the fp32 kernel -- the result
+    is still bit-identical to the oracle."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(5)
+    base = rng.standard_normal((1, 256), dtype=np.float32)
+    keys = base + 1e-3 * rng.standard_normal((20000, 256), dtype=np.float32)
+    kn = cref.normalize_rows(keys)
+    q = np.concatenate([base + 1e-3 * rng.standard_normal((300, 256), dtype=np.float32),
+                        np.zeros((1, 256), dtype=np.float32),
+                        rng.standard_normal((50, 256), dtype=np.float32)]).astype(np.float32)
+    knd = _t(kn, dev)
+    s, i, over = K.topk_cosine_filtered(_t(q, dev), knd, K.keys_to_bf16(knd), 10)
+    assert over >= 301
+    rs, ri = cref.topk_cosine(q, kn, 10)
+    assert np.array_equal(i.cpu().numpy(), ri)
+    assert np.array_equal(s.cpu().numpy(), rs)

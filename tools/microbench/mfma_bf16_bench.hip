@@ -1,0 +1,115 @@
+// Microbenchmark 5: the bf16 filter kernel's inner pattern: v_mfma_f32_32x32x16_bf16, two accumulator chains (two
+// groups of 32 queries) sharing one A fragment (8 bf16 of a key row) per k-step, 16 k-steps per 32-key sub-tile.
+//   MODE 0: A fragments constant in registers (pure MFMA issue rate, B operands = 128 VGPRs as in the kernel)
+//   MODE 1: A fragments from LDS, hipcc's schedule            MODE 2: + v_max epilogue per sub-tile
+//   MODE 3: A from LDS, asm reads 4 steps ahead + epilogue    MODE 4: MODE 3 with ONE wave per SIMD (256 threads)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int MODE>
+__global__ void __launch_bounds__(512, 2) k(float* out, int iters, float a) {
+  extern __shared__ float4 smem4[];
+  char* smem = (char*)smem4;
+  const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
+  for (int i = threadIdx.x; i < 16384 / 4; i += blockDim.x) ((float*)smem)[i] = a + i * 1e-7f;
+  __syncthreads();
+  bf16x8 b0[16], b1[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { b0[t][e] = (__bf16)(a + t * 1e-3f + e * 1e-2f + lane * 1e-4f); b1[t][e] = (__bf16)(a - t * 1e-3f + lane * 1e-4f); }
+  float keep = 0.f;
+  const unsigned lds_base = (unsigned)(size_t)(lds_void*)smem;
+  unsigned addr[8];
+  const unsigned c0 = (unsigned)(g ^ (j & 15));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) addr[i] = lds_base + (unsigned)j * 512 + (((unsigned)(2 * i) ^ c0) << 4);
+  bf16x8 areg[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) areg[i][e] = (__bf16)(a + i + e * 0.1f);
+  for (int it = 0; it < iters; ++it) {
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    if (MODE == 0) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[t & 3], b0[t], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[t & 3], b1[t], acc1, 0, 0, 0);
+      }
+    } else if (MODE == 1 || MODE == 2) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const bf16x8 av = *reinterpret_cast<const bf16x8*>(smem + j * 512 + (((unsigned)(2 * t + g) ^ (unsigned)(j & 15)) << 4));
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b0[t], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b1[t], acc1, 0, 0, 0);
+      }
+    } else {
+      f32x4 fr[4];
+#define FREAD(n_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[(n_)&3]) : "v"(addr[(n_)&7]), "i"(((n_) >= 8) ? 256 : 0))
+#define FWAIT(c_, n_) asm volatile("s_waitcnt lgkmcnt(" #c_ ")" : "+v"(fr[(n_)&3]))
+#define FSTEP(n_)                                                                          \
+  {                                                                                        \
+    if constexpr ((n_) + 3 < 16) FWAIT(3, n_);                                             \
+    else if constexpr ((n_) + 2 < 16) FWAIT(2, n_);                                        \
+    else if constexpr ((n_) + 1 < 16) FWAIT(1, n_);                                        \
+    else FWAIT(0, n_);                                                                     \
+    const bf16x8 a_ = __builtin_bit_cast(bf16x8, fr[(n_)&3]);                              \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b0[n_], acc0, 0, 0, 0);             \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b1[n_], acc1, 0, 0, 0);             \
+    if constexpr ((n_) + 4 < 16) FREAD((n_) + 4);                                          \
+  }
+      FREAD(0); FREAD(1); FREAD(2); FREAD(3);
+      FSTEP(0) FSTEP(1) FSTEP(2) FSTEP(3) FSTEP(4) FSTEP(5) FSTEP(6) FSTEP(7)
+      FSTEP(8) FSTEP(9) FSTEP(10) FSTEP(11) FSTEP(12) FSTEP(13) FSTEP(14) FSTEP(15)
+    }
+    if (MODE >= 2) {
+      float m0 = acc0[0], m1 = acc1[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) { m0 = fmaxf(m0, acc0[r]); m1 = fmaxf(m1, acc1[r]); }
+      if (__any(m0 >= 1e30f || m1 >= 1e30f)) keep += m0 + m1;
+    } else {
+      asm volatile("" ::"v"(acc0[0]), "v"(acc0[15]), "v"(acc1[0]), "v"(acc1[15]));
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = keep;
+}
+template <int MODE>
+void run(const char* name, int threads) {
+  float* d;
+  hipMalloc(&d, 256 * 512 * 4);
+  hipFuncSetAttribute((const void*)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  int iters = 20000;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const size_t lds = 140 * 1024;  // one workgroup per CU as in the kernel
+  k<MODE><<<256, threads, lds>>>(d, 10, 1.0f);
+  hipDeviceSynchronize();
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0);
+    k<MODE><<<256, threads, lds>>>(d, iters, 1.0001f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  double flop = 256.0 * (threads / 64) * iters * 32.0 * 32768.0;
+  printf("%-60s %8.3f ms  %7.1f TFLOP/s\n", name, best, flop / best / 1e9);
+  hipFree(d);
+}
+int main() {
+  run<0>("A in registers, 2 waves/SIMD", 512);
+  run<0>("A in registers, 1 wave/SIMD", 256);
+  run<1>("A from LDS (hipcc schedule), 2 waves/SIMD", 512);
+  run<2>("  + v_max epilogue", 512);
+  run<3>("A from LDS, asm reads 4 ahead + epilogue, 2 waves/SIMD", 512);
+  run<3>("A from LDS, asm reads 4 ahead + epilogue, 1 wave/SIMD", 256);
+  return 0;
+}
