@@ -115,6 +115,12 @@ int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const float* Kn,
                                      int64_t N, int D, int k, int64_t idx_base, float* out_scores, int64_t* out_idx,
                                      int* overflow, int64_t* overflow_idx, void* ws, size_t ws_bytes, void* stream);
 
+/* Measurement hook (bench.py): when enabled, ragraph_topk_cosine_filtered_f32 brackets its bf16 filter kernel with
+ * events on the caller's stream; ragraph_profile_last_filter_ms() waits for the latest one and returns its
+ * duration in ms (negative if none).  Not part of the reference's interface. */
+int ragraph_profile_filter_kernel(int on);
+float ragraph_profile_last_filter_ms(void);
+
 /* Cross-shard / cross-split merge of sorted top-k lists (no counterpart in the reference: it is single-GPU).
  *   scores,idx [G,B,k] (list g of query b at ((g*B)+b)*k) -> out [B,k], canonical order; result independent of G.
  *   G*k <= 4096.

@@ -36,6 +36,8 @@ SIGNATURES = {
     "ragraph_pack_keys_f32": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "ragraph_keys_bf16_rows": (_i64, [_i64]),
     "ragraph_keys_to_bf16": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "ragraph_profile_filter_kernel": (_i32, [_i32]),
+    "ragraph_profile_last_filter_ms": (ctypes.c_float, []),
     "ragraph_topk_cosine_filtered_cap": (_i32, [_i32]),
     "ragraph_topk_cosine_filtered_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
     "ragraph_topk_cosine_filtered_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp,

@@ -48,6 +48,7 @@ class ShardedToyGraphBase:
         self.resource_keys, self.resource_values, self.resource_labels = keys, values, labels
         self.keys_normalized = ops.normalize_rows(keys)
         self._keys_packed = None  # built on the first large-batch lookup when `ops` offers it (the HIP library does)
+        self._keys_bf16 = None
 
     def topk(self, search_keys, k=None):
         """Global canonical top-k: (scores [B,k], idx [B,k]) identical on every rank."""
@@ -56,11 +57,19 @@ class ShardedToyGraphBase:
         n_local = self.keys_normalized.shape[0]
         kl = min(k, n_local)
         helps = getattr(self.ops, "packed_keys_help", None)
+        kp = None
         if helps is not None and helps(q.shape[0], q.shape[1], kl):
             if self._keys_packed is None:
                 self._keys_packed = self.ops.pack_keys(self.keys_normalized)
-            s, i = self.ops.topk_cosine(q, self.keys_normalized, kl, idx_base=self.idx_base,
-                                        keys_packed=self._keys_packed)
+            kp = self._keys_packed
+        fhelps = getattr(self.ops, "filter_helps", None)
+        if fhelps is not None and fhelps(q.shape[0], n_local, q.shape[1], kl):
+            if self._keys_bf16 is None:  # bf16-filtered exact top-k of this shard: same bits, several times faster
+                self._keys_bf16 = self.ops.keys_to_bf16(self.keys_normalized)
+            s, i, _ = self.ops.topk_cosine_filtered(q, self.keys_normalized, self._keys_bf16, kl,
+                                                    idx_base=self.idx_base, keys_packed=kp)
+        elif kp is not None:
+            s, i = self.ops.topk_cosine(q, self.keys_normalized, kl, idx_base=self.idx_base, keys_packed=kp)
         else:
             s, i = self.ops.topk_cosine(q, self.keys_normalized, kl, idx_base=self.idx_base)
         if kl < k:  # a shard smaller than k: pad with sentinels that lose every comparison

@@ -113,3 +113,22 @@ def test_gnn_100k_nodes_matches_oracle(dev):
     # row-stochastic propagation of a constant stays constant (size-independent sanity property)
     ones = torch.ones(n, 256, device=dev)
     assert torch.allclose(Propagation.aggregate_k_hop_features(adj, ones, 2), ones, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_filtered_topk_matches_fp32_kernel_at_full_size(dev):
+    """c2-sized bank (1M x 256): the bf16-filtered exact top-k returns the same bits as the fp32 kernel for 20k queries,
+    and as the oracle on a sample of them."""
+    from oracle import cref
+    from ragraph_amd import kernels as K
+
+    g = torch.Generator(device=dev).manual_seed(11)
+    kn = K.normalize_rows(torch.randn(1_000_000, 256, device=dev, generator=g))
+    q = torch.randn(20_000, 256, device=dev, generator=g)
+    assert K.filter_helps(q.shape[0], kn.shape[0], 256, 10)
+    s1, i1, over = K.topk_cosine_filtered(q, kn, K.keys_to_bf16(kn), 10, idx_base=5, keys_packed=K.pack_keys(kn))
+    s0, i0 = K.topk_cosine(q, kn, 10, idx_base=5)
+    assert torch.equal(i0, i1) and torch.equal(s0, s1)
+    rows = torch.arange(0, 20_000, 1250)
+    rs, ri = cref.topk_cosine(q[rows].cpu().numpy(), kn.cpu().numpy(), 10, idx_base=5)
+    assert np.array_equal(i1[rows].cpu().numpy(), ri) and np.array_equal(s1[rows].cpu().numpy(), rs)
