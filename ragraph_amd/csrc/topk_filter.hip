@@ -53,9 +53,10 @@ struct FilterParams {
   const float* thr;       // [B] theta[q] - EPS
   int* count;             // [B] candidates appended so far
   int* cand;              // [B,cap] candidate key indices (local to this shard)
-  int64_t B, N;
+  int64_t B, N;           // N = end of the key range (keys >= N never pass)
   int cap;
-  int64_t qtiles, nstages_total;
+  int64_t stage_base;     // first stage of the key range this launch filters
+  int64_t qtiles, nstages_total;  // nstages_total = stages in the range
   int xcd_map, wgs_per_group, lb_min, depth[2];
 };
 
@@ -84,15 +85,17 @@ __global__ void __launch_bounds__(256) keys_to_bf16_kernel(const float* __restri
   reinterpret_cast<bf16x8*>(Kb)[i] = o;
 }
 
-// thr[q] = theta[q] - EPS from the sample pass's k-th score; count[q] = 0.
-__global__ void __launch_bounds__(256) filter_prepare_kernel(const float* __restrict__ sample_scores, int64_t B, int k,
+// thr[q] = (k-th exact score of the previous level) - EPS; count[q] = 0.  `first`: also clear the overflow bookkeeping.
+__global__ void __launch_bounds__(256) filter_prepare_kernel(const float* __restrict__ prev_scores, int64_t B, int k,
                                                              float* __restrict__ thr, int* __restrict__ count,
-                                                             int* __restrict__ overflow, int ablate) {
+                                                             int* __restrict__ overflow, unsigned char* __restrict__ flag,
+                                                             int first, int ablate) {
   const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (q == 0) *overflow = 0;
+  if (first && q == 0) *overflow = 0;
   if (q >= B) return;
-  thr[q] = ablate ? __builtin_huge_valf() : __fsub_rn(sample_scores[q * k + k - 1], FILTER_EPS);
+  thr[q] = ablate ? __builtin_huge_valf() : __fsub_rn(prev_scores[q * k + k - 1], FILTER_EPS);
   count[q] = 0;
+  if (first) flag[q] = 0;
 }
 
 #ifdef RG_TOPK_TIMING  // diagnostic build only: per-wave cycle totals of the ring's phases
@@ -186,19 +189,23 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
       }
     }
     // padded queries never pass: +inf threshold
-    const float thr0 = q_lo < p.B ? p.thr[q_lo] : __builtin_huge_valf();
-    const float thr1 = q_hi < p.B ? p.thr[q_hi] : __builtin_huge_valf();
+    float thr0 = q_lo < p.B ? p.thr[q_lo] : __builtin_huge_valf();
+    float thr1 = q_hi < p.B ? p.thr[q_hi] : __builtin_huge_valf();
     // Candidate slots are reserved CHUNK at a time (one returning atomic per 16 candidates of a lane; the candidate
     // itself is a plain store); unused slots of a chunk keep the buffer's -1 fill and are skipped by the rescoring.
     int base0 = 0, used0 = CHUNK, base1 = 0, used1 = CHUNK;
+    // hipcc does not know about the asm DMA loads, and any vmcnt(0) it emits inside the stage loop (for a global load it
+    // still considers pending at the loop's back edge) would drain them every sub-tile: retire the thresholds here and
+    // hand them to the loop as plain register values
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(thr0), "+v"(thr1) : : "memory");
 
     // ---- ring prologue ------------------------------------------------------------------------------------------
     const int pro = nstages < C::SLOTS - 1 ? nstages : C::SLOTS - 1;
     if constexpr (BAR) {
-      for (int s = 0; s < pro; ++s) dma_stage(st0 + s, s);
+      for (int s = 0; s < pro; ++s) dma_stage(p.stage_base + st0 + s, s);
     } else {
       if (tid < 2 * C::SLOTS) full[tid] = 0;
-      for (int s = 0; s < pro; ++s) dma_stage(st0 + s, s);
+      for (int s = 0; s < pro; ++s) dma_stage(p.stage_base + st0 + s, s);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid < pro) full[tid] = C::WAVES;
@@ -218,7 +225,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
         if (s + C::SLOTS - 2 < nstages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((C::SLOTS - 2) * C::PAIRS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (s + C::SLOTS - 1 < nstages) dma_stage(st0 + s + C::SLOTS - 1, (s + C::SLOTS - 1) & (C::SLOTS - 1));
+        if (s + C::SLOTS - 1 < nstages) dma_stage(p.stage_base + st0 + s + C::SLOTS - 1, (s + C::SLOTS - 1) & (C::SLOTS - 1));
       } else {
         fring_wait(full + slot, (unsigned)(C::WAVES * (gen + 1)));
       }
@@ -232,13 +239,14 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
           m1 = fmaxf(m1, a1[r]);
         }
         if (__any(m0 >= thr0 || m1 >= thr1)) {
-          const int key_base = (int)((st0 + s) * C::STAGE_KEYS) + 32 * u + 4 * g;
+          const int key_base = (int)((p.stage_base + st0 + s) * C::STAGE_KEYS) + 32 * u + 4 * g;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int key = key_base + (r & 3) + 8 * (r >> 2);
             if (a0[r] >= thr0 && key < (int)p.N) {
               if (used0 == CHUNK) {
                 base0 = atomicAdd(p.count + q_lo, CHUNK);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(base0) : : "memory");  // retired here, not at every later use
                 used0 = 0;
               }
               if (base0 + used0 < p.cap) p.cand[q_lo * p.cap + base0 + used0] = key;
@@ -247,6 +255,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
             if (a1[r] >= thr1 && key < (int)p.N) {
               if (used1 == CHUNK) {
                 base1 = atomicAdd(p.count + q_hi, CHUNK);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(base1) : : "memory");
                 used1 = 0;
               }
               if (base1 + used1 < p.cap) p.cand[q_hi * p.cap + base1 + used1] = key;
@@ -317,7 +326,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
 #ifdef RG_TOPK_TIMING
         t4 = __builtin_amdgcn_s_memtime();
 #endif
-        dma_stage(st0 + s + C::SLOTS - 1, ws);
+        dma_stage(p.stage_base + st0 + s + C::SLOTS - 1, ws);
         pending = ws;
 #ifdef RG_TOPK_TIMING
         t5 = __builtin_amdgcn_s_memtime();
@@ -335,14 +344,18 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
   }
 }
 
-// One wave per query: exact scores of its candidates (one lane per candidate, the k = 0..255 fmaf chain from +0) and
-// the canonical top-k of them.  CPL = candidates per lane (cap <= 64 * CPL).
+// One wave per query: exact scores of its candidates (one lane per candidate, the k = 0..255 fmaf chain from +0), merged
+// with the previous level's exact top-k (prev_*: local indices, may alias out_*), and the canonical top-k of them.
+// CPL = candidates per lane (cap <= 64 * CPL).  A query whose list overflowed (now or at an earlier level: flag) is
+// appended to overflow_idx by the final level.
 template <int CPL>
 __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restrict__ Qn, const float* __restrict__ Kn,
                                                            const int* __restrict__ count, const int* __restrict__ cand,
                                                            int64_t B, int cap, int k, int64_t idx_base,
-                                                           float* __restrict__ out_s, int64_t* __restrict__ out_i,
-                                                           int* __restrict__ overflow, int64_t* __restrict__ overflow_idx) {
+                                                           const float* prev_s, const int64_t* prev_i, int final_level,
+                                                           float* out_s, int64_t* out_i, int* __restrict__ overflow,
+                                                           int64_t* __restrict__ overflow_idx,
+                                                           unsigned char* __restrict__ flag) {
   constexpr int D = 256;
   __shared__ float4 qs[4][D / 4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -351,20 +364,36 @@ __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restri
   qs[w][lane] = reinterpret_cast<const float4*>(Qn + b * D)[lane];  // 64 lanes x float4 = the query row
   __builtin_amdgcn_wave_barrier();
   int n = count[b];
+  bool over = flag[b] != 0;
   if (n > cap) {  // slots reserved beyond the capacity: candidates were dropped
-    if (lane == 0) {
-      const int pos = atomicAdd(overflow, 1);
-      if (overflow_idx) overflow_idx[pos] = b;
-    }
+    over = true;
     n = cap;
   }
-  float s[CPL];
-  int64_t id[CPL];
+  if (lane == 0) {
+    if (final_level) {
+      if (over) {
+        const int pos = atomicAdd(overflow, 1);
+        if (overflow_idx) overflow_idx[pos] = b;
+      }
+    } else if (over) {
+      flag[b] = 1;
+    }
+  }
+  float s[CPL + 1];
+  int64_t id[CPL + 1];
+  // the previous level's winners ride along as already-scored candidates (lane l holds entry l; k <= 32)
+  s[CPL] = RG_NEG_INF;
+  id[CPL] = INT64_MAX;
+  if (prev_s && lane < k) {
+    s[CPL] = prev_s[b * k + lane];
+    id[CPL] = prev_i[b * k + lane];
+  }
 #pragma unroll
   for (int u = 0; u < CPL; ++u) {
     const int c = lane + 64 * u;
     s[u] = RG_NEG_INF;
     id[u] = INT64_MAX;
+    if (64 * u >= n) continue;  // wave-uniform: most queries fill only the first few slots
     const int key = c < n ? cand[b * cap + c] : -1;
     if (key >= 0) {
       const float4* kr = reinterpret_cast<const float4*>(Kn + (int64_t)key * D);
@@ -381,14 +410,16 @@ __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restri
       id[u] = key;
     }
   }
-  float prev_s = __builtin_huge_valf();
-  int64_t prev_i = -1;  // everything is worse than (+inf, -1)
+  const int64_t base = final_level ? idx_base : 0;
+  float prev_sc = __builtin_huge_valf();
+  int64_t prev_id = -1;  // everything is worse than (+inf, -1)
   for (int r = 0; r < k; ++r) {
     float best_s = RG_NEG_INF;
     int64_t best_i = INT64_MAX;
 #pragma unroll
-    for (int u = 0; u < CPL; ++u) {
-      const bool after_prev = (s[u] < prev_s) || (s[u] == prev_s && id[u] > prev_i);
+    for (int u = 0; u <= CPL; ++u) {
+      if (u < CPL && 64 * u >= n) continue;  // empty slots (wave-uniform)
+      const bool after_prev = (s[u] < prev_sc) || (s[u] == prev_sc && id[u] > prev_id);
       const bool beats = (s[u] > best_s) || (s[u] == best_s && id[u] < best_i);
       if (after_prev && beats) {
         best_s = s[u];
@@ -406,10 +437,10 @@ __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restri
     }
     if (lane == 0) {
       out_s[b * k + r] = best_s;
-      out_i[b * k + r] = best_i == INT64_MAX ? INT64_MAX : best_i + idx_base;
+      out_i[b * k + r] = best_i == INT64_MAX ? INT64_MAX : best_i + base;
     }
-    prev_s = best_s;
-    prev_i = best_i;
+    prev_sc = best_s;
+    prev_id = best_i;
   }
 }
 
@@ -432,35 +463,62 @@ static int filter_device_cus() {
 
 using namespace ragraph;
 
-// Optional timing of the filter kernel alone (bench.py's roofline): events recorded around its launch on the caller's
-// stream.  Off by default; enabling creates the two events once.
-static hipEvent_t g_prof_ev[2];
+// Optional timing of the filter kernel alone (bench.py's roofline): events recorded around its launches on the caller's
+// stream.  Off by default; enabling creates the events once.
+static hipEvent_t g_prof_ev[2 * 3];
 static int g_prof_created = 0, g_prof_on = 0, g_prof_have = 0;
 extern "C" int ragraph_profile_filter_kernel(int on) {
   if (on && !g_prof_created) {
-    if (hipEventCreate(&g_prof_ev[0]) != hipSuccess || hipEventCreate(&g_prof_ev[1]) != hipSuccess) {
-      set_error("profile: cannot create events");
-      return RAGRAPH_EDEVICE;
-    }
+    for (int i = 0; i < 2 * 3; ++i)
+      if (hipEventCreate(&g_prof_ev[i]) != hipSuccess) {
+        set_error("profile: cannot create events");
+        return RAGRAPH_EDEVICE;
+      }
     g_prof_created = 1;
   }
   g_prof_on = on ? 1 : 0;
   g_prof_have = 0;
   return RAGRAPH_OK;
 }
-// Milliseconds of the most recent filter-kernel launch (synchronises with it), or a negative number if none was timed.
+// Milliseconds the filter kernel ran in the most recent call (its launches summed; synchronises with them), or a
+// negative number if none was timed.
 extern "C" float ragraph_profile_last_filter_ms(void) {
   if (!g_prof_on || !g_prof_have) return -1.f;
-  float ms = -1.f;
-  if (hipEventSynchronize(g_prof_ev[1]) != hipSuccess || hipEventElapsedTime(&ms, g_prof_ev[0], g_prof_ev[1]) != hipSuccess)
-    return -1.f;
-  return ms;
+  float total = 0.f;
+  for (int l = 0; l < g_prof_have; ++l) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_prof_ev[2 * l + 1]) != hipSuccess ||
+        hipEventElapsedTime(&ms, g_prof_ev[2 * l], g_prof_ev[2 * l + 1]) != hipSuccess)
+      return -1.f;
+    total += ms;
+  }
+  return total;
 }
 
-static int64_t filter_sample_keys(int64_t N) {
-  int64_t ns = N / 32;  // 1/32 of the bank: the exact pass costs 3 % of a full one and leaves ~32 k candidates per query
-  if (ns < 16384) ns = 16384;
-  return ns < N ? ns : N;
+// Levels: exact fp32 top-k over the first n0 = N/256 keys, then bf16 filter + exact rescoring over [0, N/32),
+// [N/32, N/4) and [N/4, N).  A level's k-th exact score is the next level's bound, so a level only lets through
+// ~1.25 k (its size / what came before) keys per query: ~100, ~100 and ~40 -- the bulk of the bank is filtered with a
+// threshold that almost nothing passes.
+constexpr int FILTER_MAX_LEVELS = 3;
+static int64_t filter_level0_keys(int64_t N) {
+  int64_t n0 = N / 256;
+  if (n0 < 4096) n0 = 4096;
+  return n0 < N ? n0 : N;
+}
+// Ends of the filter levels (multiples of 128 = whole ring stages, except the last = N); returns their number.
+static int filter_level_ends(int64_t N, int64_t ends[FILTER_MAX_LEVELS]) {
+  const int64_t n0 = filter_level0_keys(N);
+  int n = 0;
+  int64_t prev = n0;
+  for (int64_t frac : {32, 4}) {
+    int64_t e = (N / frac + 127) / 128 * 128;
+    if (e < 4 * prev) e = (4 * prev + 127) / 128 * 128;  // a level is at least 4x what came before
+    if (e * 2 >= N) break;                                 // too close to the end: the last level takes the rest
+    ends[n++] = e;
+    prev = e;
+  }
+  ends[n++] = N;
+  return n;
 }
 
 extern "C" int ragraph_keys_to_bf16(const float* Kn, int64_t N, int D, uint16_t* Kb, void* stream) {
@@ -482,52 +540,28 @@ extern "C" int ragraph_topk_cosine_filtered_cap(int k) { return 2048; }
 extern "C" size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_t N, int D, int k) {
   if (B < 1 || N < 1 || k < 1 || D != 256) return 0;
   const int cap = ragraph_topk_cosine_filtered_cap(k);
-  return ragraph_topk_cosine_workspace_bytes(B, filter_sample_keys(N), D, k) + align_up((size_t)B * D * sizeof(float), 256) +
-         align_up((size_t)B * sizeof(float), 256) + align_up((size_t)B * sizeof(int), 256) +
+  return ragraph_topk_cosine_workspace_bytes(B, filter_level0_keys(N), D, k) + align_up((size_t)B * D * sizeof(float), 256) +
+         align_up((size_t)B * sizeof(float), 256) + align_up((size_t)B * sizeof(int), 256) + align_up((size_t)B, 256) +
          align_up((size_t)B * cap * sizeof(int), 256);
 }
 
-extern "C" int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const float* Kn, const float* Kp,
-                                                const uint16_t* Kb, int64_t N, int D, int k, int64_t idx_base,
-                                                float* out_scores, int64_t* out_idx, int* overflow,
-                                                int64_t* overflow_idx, void* ws, size_t ws_bytes, void* stream) {
-  RG_REQUIRE(Q && Kn && Kb && out_scores && out_idx && overflow && ws, RAGRAPH_EINVAL, "topk_cosine_filtered: null pointer");
-  RG_REQUIRE(D == 256, RAGRAPH_EUNSUPPORTED, "topk_cosine_filtered: D=%d (only 256)", D);
-  RG_REQUIRE(B >= 1 && N >= 1 && k >= 1 && k <= 32 && k <= N, RAGRAPH_EINVAL, "topk_cosine_filtered: bad B/N/k");
-  RG_REQUIRE(N < (int64_t)INT_MAX - 1024, RAGRAPH_EUNSUPPORTED, "topk_cosine_filtered: shard rows must fit int32");
-  RG_REQUIRE(aligned16(Q) && aligned16(Kn) && aligned16(Kb) && aligned16(ws), RAGRAPH_EINVAL,
-             "topk_cosine_filtered: pointers must be 16-B aligned");
-  const size_t need = ragraph_topk_cosine_filtered_workspace_bytes(B, N, D, k);
-  RG_REQUIRE(ws_bytes >= need, RAGRAPH_EWORKSPACE, "topk_cosine_filtered: workspace %zu < %zu", ws_bytes, need);
-  hipStream_t st = as_stream(stream);
-  const int cap = ragraph_topk_cosine_filtered_cap(k);
-  const int64_t ns = filter_sample_keys(N);
-
-  char* w = static_cast<char*>(ws);
-  const size_t sample_ws = ragraph_topk_cosine_workspace_bytes(B, ns, D, k);
-  float* Qn = reinterpret_cast<float*>(w + sample_ws);
-  float* thr = reinterpret_cast<float*>(reinterpret_cast<char*>(Qn) + align_up((size_t)B * D * sizeof(float), 256));
-  int* count = reinterpret_cast<int*>(reinterpret_cast<char*>(thr) + align_up((size_t)B * sizeof(float), 256));
-  int* cand = reinterpret_cast<int*>(reinterpret_cast<char*>(count) + align_up((size_t)B * sizeof(int), 256));
-
-  // 1. exact sample pass over the first ns keys (out_scores / out_idx are scratch here)
-  int rc = ragraph_topk_cosine_bank_f32(Q, B, Kn, Kp, ns, D, k, 0, out_scores, out_idx, ws, sample_ws, stream);
-  if (rc != RAGRAPH_OK) return rc;
-  rc = ragraph_normalize_rows_f32(Q, B, D, Qn, stream);
-  if (rc != RAGRAPH_OK) return rc;
+// One filter level: thresholds from the exact scores in out_scores, bf16 filter over keys [key0, key1), rescoring
+// (+ merge with out_* when `merge`).
+static int run_filter_level(const float* Qn, const float* Kn, const uint16_t* Kb, int64_t B, int64_t key0, int64_t key1,
+                            int k, int64_t idx_base, int first, int merge, int final_level, float* out_scores,
+                            int64_t* out_idx, int* overflow, int64_t* overflow_idx, float* thr, int* count,
+                            unsigned char* flag, int* cand, int cap, int level, hipStream_t st) {
   static const int ablate = [] {  // RAGRAPH_FILTER_ABLATE=1: no key passes the filter (timing only, results invalid)
     const char* e = getenv("RAGRAPH_FILTER_ABLATE");
     return e ? atoi(e) : 0;
   }();
   hipLaunchKernelGGL(filter_prepare_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, out_scores, B, k, thr, count,
-                     overflow, ablate);
+                     overflow, flag, first, ablate);
   RG_CHECK_LAUNCH("topk_cosine_filtered(prepare)");
   if (hipMemsetAsync(cand, 0xFF, (size_t)B * cap * sizeof(int), st) != hipSuccess) {  // every slot = -1 (unused)
     set_error("topk_cosine_filtered: memset failed");
     return RAGRAPH_EDEVICE;
   }
-
-  // 2. bf16 filter over the whole bank
   FilterParams p;
   p.Qn = Qn;
   p.Kb = Kb;
@@ -535,7 +569,7 @@ extern "C" int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const
   p.count = count;
   p.cand = cand;
   p.B = B;
-  p.N = N;
+  p.N = key1;
   p.cap = cap;
   static const int subs = [] {  // RAGRAPH_FILTER_SUBS = 1 | 2: keys per ring stage / 32 (diagnostic, read once)
     const char* e = getenv("RAGRAPH_FILTER_SUBS");
@@ -543,8 +577,9 @@ extern "C" int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const
     return (v == 1 || v == 2) ? v : 2;  // 4 would leave 2 slots: the ring needs a stage in flight beside the one being read
   }();
   const int stage_keys = 32 * subs;
+  p.stage_base = key0 / stage_keys;  // key0 is a multiple of 128
   p.qtiles = cdiv(B, 512);
-  p.nstages_total = cdiv(N, stage_keys);
+  p.nstages_total = cdiv(key1 - key0, stage_keys);
   const int CUS = filter_device_cus();
   p.xcd_map = p.qtiles >= 64 ? 1 : 0;
   p.wgs_per_group = CUS / (p.xcd_map ? 8 : 1);
@@ -574,15 +609,15 @@ extern "C" int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const
     }                                                                                                                 \
     hipLaunchKernelGGL((topk_filter_kernel<S_, B_>), dim3((unsigned)CUS), dim3(512), FilterCfg<S_>::LDS_BYTES, st, p); \
   } while (0)
-  if (g_prof_on) (void)hipEventRecord(g_prof_ev[0], st);
+  if (g_prof_on) (void)hipEventRecord(g_prof_ev[2 * level], st);
   if (subs == 1 && use_barrier) RG_LAUNCH_FILTER(1, true);
   else if (subs == 1) RG_LAUNCH_FILTER(1, false);
   else if (use_barrier) RG_LAUNCH_FILTER(2, true);
   else RG_LAUNCH_FILTER(2, false);
 #undef RG_LAUNCH_FILTER
   if (g_prof_on) {
-    (void)hipEventRecord(g_prof_ev[1], st);
-    g_prof_have = 1;
+    (void)hipEventRecord(g_prof_ev[2 * level + 1], st);
+    g_prof_have = level + 1;
   }
   RG_CHECK_LAUNCH("topk_cosine_filtered(filter)");
 #ifdef RG_TOPK_TIMING
@@ -592,22 +627,65 @@ extern "C" int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const
     (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_filter_timing), sizeof(t));
     const double n = (double)t[5];
     if (n > 0)
-      fprintf(stderr, "[filter timing] SUBS=%d wave-stages=%.0f ticks/stage: wait_full %.1f compute %.1f signal+vmcnt %.1f "
-              "wait_free %.1f dma_issue %.1f total %.1f\n", subs, n, t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n,
-              (t[0] + t[1] + t[2] + t[3] + t[4]) / n);
+      fprintf(stderr, "[filter timing] level %d SUBS=%d wave-stages=%.0f ticks/stage: wait_full %.1f compute %.1f signal+vmcnt "
+              "%.1f wait_free %.1f dma_issue %.1f total %.1f\n", level, subs, n, t[0] / n, t[1] / n, t[2] / n, t[3] / n,
+              t[4] / n, (t[0] + t[1] + t[2] + t[3] + t[4]) / n);
     unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_filter_timing), zero, sizeof(zero));
   }
 #endif
-
-  // 3. exact rescoring + canonical selection
+  // exact rescoring (+ merge) + canonical selection
   dim3 grid((unsigned)cdiv(B, 4)), block(256);
+  const float* ps = merge ? out_scores : nullptr;
+  const int64_t* pi = merge ? out_idx : nullptr;
   if (cap <= 1024)
-    hipLaunchKernelGGL(topk_rescore_kernel<16>, grid, block, 0, st, Qn, Kn, count, cand, B, cap, k, idx_base, out_scores,
-                       out_idx, overflow, overflow_idx);
+    hipLaunchKernelGGL(topk_rescore_kernel<16>, grid, block, 0, st, Qn, Kn, count, cand, B, cap, k, idx_base, ps, pi,
+                       final_level, out_scores, out_idx, overflow, overflow_idx, flag);
   else
-    hipLaunchKernelGGL(topk_rescore_kernel<32>, grid, block, 0, st, Qn, Kn, count, cand, B, cap, k, idx_base, out_scores,
-                       out_idx, overflow, overflow_idx);
+    hipLaunchKernelGGL(topk_rescore_kernel<32>, grid, block, 0, st, Qn, Kn, count, cand, B, cap, k, idx_base, ps, pi,
+                       final_level, out_scores, out_idx, overflow, overflow_idx, flag);
   RG_CHECK_LAUNCH("topk_cosine_filtered(rescore)");
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const float* Kn, const float* Kp,
+                                                const uint16_t* Kb, int64_t N, int D, int k, int64_t idx_base,
+                                                float* out_scores, int64_t* out_idx, int* overflow,
+                                                int64_t* overflow_idx, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(Q && Kn && Kb && out_scores && out_idx && overflow && ws, RAGRAPH_EINVAL, "topk_cosine_filtered: null pointer");
+  RG_REQUIRE(D == 256, RAGRAPH_EUNSUPPORTED, "topk_cosine_filtered: D=%d (only 256)", D);
+  RG_REQUIRE(B >= 1 && N >= 1 && k >= 1 && k <= 32 && k <= N, RAGRAPH_EINVAL, "topk_cosine_filtered: bad B/N/k");
+  RG_REQUIRE(N < (int64_t)INT_MAX - 1024, RAGRAPH_EUNSUPPORTED, "topk_cosine_filtered: shard rows must fit int32");
+  RG_REQUIRE(aligned16(Q) && aligned16(Kn) && aligned16(Kb) && aligned16(ws), RAGRAPH_EINVAL,
+             "topk_cosine_filtered: pointers must be 16-B aligned");
+  const size_t need = ragraph_topk_cosine_filtered_workspace_bytes(B, N, D, k);
+  RG_REQUIRE(ws_bytes >= need, RAGRAPH_EWORKSPACE, "topk_cosine_filtered: workspace %zu < %zu", ws_bytes, need);
+  hipStream_t st = as_stream(stream);
+  const int cap = ragraph_topk_cosine_filtered_cap(k);
+  int64_t n0 = filter_level0_keys(N);
+  if (n0 < k) n0 = k < N ? k : N;
+  int64_t ends[FILTER_MAX_LEVELS];
+  const int nlev = filter_level_ends(N, ends);
+
+  char* w = static_cast<char*>(ws);
+  const size_t sample_ws = ragraph_topk_cosine_workspace_bytes(B, filter_level0_keys(N), D, k);
+  float* Qn = reinterpret_cast<float*>(w + sample_ws);
+  float* thr = reinterpret_cast<float*>(reinterpret_cast<char*>(Qn) + align_up((size_t)B * D * sizeof(float), 256));
+  int* count = reinterpret_cast<int*>(reinterpret_cast<char*>(thr) + align_up((size_t)B * sizeof(float), 256));
+  unsigned char* flag = reinterpret_cast<unsigned char*>(count) + align_up((size_t)B * sizeof(int), 256);
+  int* cand = reinterpret_cast<int*>(flag + align_up((size_t)B, 256));
+
+  // level 0: exact top-k over the first n0 keys (out_scores / out_idx hold every level's running result, local indices)
+  int rc = ragraph_topk_cosine_bank_f32(Q, B, Kn, Kp, n0, D, k, 0, out_scores, out_idx, ws, sample_ws, stream);
+  if (rc != RAGRAPH_OK) return rc;
+  rc = ragraph_normalize_rows_f32(Q, B, D, Qn, stream);
+  if (rc != RAGRAPH_OK) return rc;
+  int64_t key0 = 0;
+  for (int l = 0; l < nlev; ++l) {  // the first level re-reads [0, n0): its keys pass the bound and need no merge
+    rc = run_filter_level(Qn, Kn, Kb, B, key0, ends[l], k, idx_base, l == 0, l > 0, l == nlev - 1, out_scores, out_idx,
+                          overflow, overflow_idx, thr, count, flag, cand, cap, l, st);
+    if (rc != RAGRAPH_OK) return rc;
+    key0 = ends[l];
+  }
   return RAGRAPH_OK;
 }
