@@ -130,9 +130,9 @@ def keys_to_bf16(keys_normalized: torch.Tensor) -> torch.Tensor:
 
 
 def filter_helps(B: int, n_keys: int, D: int, k: int) -> bool:
-    """True when the bf16-filtered exact top-k is the faster way to the same bits: enough queries to fill 512-query
-    tiles on every CU and a bank large enough that its 1/32 exact sample pass is a small part of the work."""
-    return D == 256 and k <= 32 and B >= 8192 and n_keys >= 262144
+    """True when the bf16-filtered exact top-k is the faster way to the same bits (measured on MI355X: 1.6 vs 2.6 ms at
+    512 queries x 1M keys, 0.83 vs 1.53 ms at 4096 x 65536, 50 vs 366 ms at 100k x 1M)."""
+    return D == 256 and k <= 32 and B >= 512 and n_keys >= 65536
 
 
 def topk_cosine_filtered(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf16: torch.Tensor, k: int,

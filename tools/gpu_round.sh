@@ -27,5 +27,7 @@ cat $O/pytest.txt $O/smoke.txt $O/bench.json 2>/dev/null
 tail -3 $O/stats.log
 head -4 $O/trace_summary.txt
 head -5 $O/kernel_stats.csv
-grep -A3 topk_stream $O/pmc_fetch.txt | head -8
-grep -A3 topk_stream $O/pmc_write.txt | head -8
+grep -A2 "topk_filter\|topk_stream" $O/pmc_fetch.txt | head -12
+grep -A2 "topk_filter\|topk_stream" $O/pmc_write.txt | head -12
+RAGRAPH_FORCE_DIST=1 python bench.py --no-cpu-baseline 2>/dev/null | grep metric | cut -c1-260 > $O/bench_forced_dist.txt; cat $O/bench_forced_dist.txt
+python bench.py --exact-fp32 --no-cpu-baseline 2>/dev/null | grep metric > $O/bench_exact_fp32.json; cut -c1-200 $O/bench_exact_fp32.json
