@@ -267,8 +267,9 @@ def main():
                             "profiles/r1_pmc_traffic.json",
             "launch_ms": round(kernel_ms, 3),
             "note": "algorithmic flops 2*B*N*D of the score matrix / mean duration of the filter kernel (events "
-                    "recorded around its launch inside the library). The whole exact retrieval call (fp32 sample pass "
-                    f"over N/32 keys + this kernel + exact fp32 rescoring of the survivors) takes {call_ms:.2f} ms",
+                    "recorded around its launches inside the library, three filter levels per call summed). The whole "
+                    f"exact retrieval call (fp32 top-k over the first N/256 keys + this kernel + exact fp32 rescoring "
+                    f"of the survivors) takes {call_ms:.2f} ms; --exact-fp32 runs the fp32 MFMA kernel alone",
             "retrieval_call_ms": round(call_ms, 3),
         }
     else:

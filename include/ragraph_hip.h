@@ -93,18 +93,19 @@ int ragraph_topk_cosine_bank_f32(const float* Q, int64_t B, const float* Kn, con
                                  void* stream);
 
 /* a1, large batches: the same result through a bf16 MFMA filter (ragraph_amd/csrc/topk_filter.hip).
- *   Exact by construction: (1) the fp32 kernel finds the top-k of every query over the first N/32 keys; its k-th score
- *   bounds the final k-th best from below; (2) a bf16 MFMA pass over the whole bank (16x the fp32 matrix rate) keeps
- *   every key whose approximate score is within EPS = 2^-8 + 2^-11 of that bound -- unit vectors rounded to 8
- *   significant bits cannot move a dot product by more (Cauchy-Schwarz); (3) the survivors (~300 per query on random
- *   banks) are rescored with the natural-order fp32 fmaf chain and selected in canonical order: the same bits as
- *   ragraph_topk_cosine_f32.  D = 256, k <= 32.
+ *   Exact by construction: (1) the fp32 kernel finds the top-k of every query over the first N/256 keys; its k-th score
+ *   bounds the final k-th best from below; (2) a bf16 MFMA pass (16x the fp32 matrix rate) over the next, larger part of
+ *   the bank keeps every key whose approximate score is within EPS = 2^-8 + 2^-11 of that bound -- unit vectors rounded
+ *   to 8 significant bits cannot move a dot product by more (Cauchy-Schwarz); (3) the survivors (~100 per query) are
+ *   rescored with the natural-order fp32 fmaf chain and selected in canonical order, which gives the exact top-k of
+ *   everything seen so far and a tighter bound for the next level ([0,N/32), [N/32,N/4), [N/4,N)).  The result has the
+ *   same bits as ragraph_topk_cosine_f32.  D = 256, k <= 32.
  *   Kb   bf16 copy of Kn made by ragraph_keys_to_bf16 (ragraph_keys_bf16_rows(N) rows x D, uint16 storage).
- *   Kp   optional packed fp32 copy (ragraph_pack_keys_f32) for the sample pass, or NULL.
+ *   Kp   optional packed fp32 copy (ragraph_pack_keys_f32) for the fp32 level, or NULL.
  *   overflow  device int, set by the call: number of queries whose candidate list exceeded its capacity
- *        (ragraph_topk_cosine_filtered_cap(k)); only possible on banks with thousands of keys within EPS of a query's
- *        k-th best.  Their rows of the result are NOT valid: the caller re-runs those queries (or the batch) through
- *        ragraph_topk_cosine_bank_f32.  All other rows are exact.
+ *        (ragraph_topk_cosine_filtered_cap(k)) at some level; only possible on banks with thousands of keys within EPS
+ *        of a query's k-th best (near-duplicate banks, zero queries).  Their rows of the result are NOT valid: the
+ *        caller re-runs those queries (or the batch) through ragraph_topk_cosine_bank_f32.  All other rows are exact.
  *   overflow_idx  optional device int64[B]: the first *overflow entries receive the row numbers of those queries.
  */
 int64_t ragraph_keys_bf16_rows(int64_t N);
