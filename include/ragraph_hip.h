@@ -95,7 +95,7 @@ int ragraph_topk_cosine_bank_f32(const float* Q, int64_t B, const float* Kn, con
 /* a1, large batches: the same result through a bf16 MFMA filter (ragraph_amd/csrc/topk_filter.hip).
  *   Exact by construction: (1) the fp32 kernel finds the top-k of every query over the first N/256 keys; its k-th score
  *   bounds the final k-th best from below; (2) a bf16 MFMA pass (16x the fp32 matrix rate) over the next, larger part of
- *   the bank keeps every key whose approximate score is within EPS = 2^-8 + 2^-11 of that bound -- unit vectors rounded
+ *   the bank keeps every key whose approximate score is within EPS = 2^-7 + 2^-10 of that bound -- unit vectors rounded
  *   to 8 significant bits cannot move a dot product by more (Cauchy-Schwarz); (3) the survivors (~100 per query) are
  *   rescored with the natural-order fp32 fmaf chain and selected in canonical order, which gives the exact top-k of
  *   everything seen so far and a tighter bound for the next level ([0,N/32), [N/32,N/4), [N/4,N)).  The result has the

@@ -5,8 +5,8 @@
 //   1. sample pass (exact, fp32 kernel): top-k of every query over the first Ns keys.  Its k-th score theta[q] is a
 //      lower bound of the final k-th best exact score of q.
 //   2. filter pass (this file, bf16 MFMA over the whole bank): approximate scores s~ = bf16(q)·bf16(key), fp32
-//      accumulate.  Both vectors have unit norm, every element is rounded to 8 significant bits, so by Cauchy-Schwarz
-//      |s~ - s| <= (2^-8 + 2^-16)·|q|·|key| + accumulation error < EPS = 2^-8 + 2^-11 for EVERY pair.  A key of the
+//      accumulate.  Both vectors have unit norm, every element is rounded to 8 significant bits (relative error <= 2^-8),
+//      so by Cauchy-Schwarz |s~ - s| <= (2^-7 + 2^-16)·|q|·|key| + accumulation error < EPS = 2^-7 + 2^-10 for EVERY pair.  A key of the
 //      exact top-k has s >= theta[q], hence s~ >= theta[q] - EPS: every key that passes goes to the query's candidate
 //      list (global append).  Nothing else can be in the result.
 //   3. rescoring pass: the exact score of every candidate as the fp32 fmaf chain in natural k order from +0 (one lane
@@ -31,7 +31,12 @@ namespace ragraph {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void_f;
 
-constexpr float FILTER_EPS = 0.00390625f + 0.00048828125f;  // 2^-8 + 2^-11, see the header comment
+// bf16 keeps 8 significant bits: round-to-nearest moves an element by at most 2^-8 of its magnitude, so the rounded
+// vectors are q + dq, k + dk with |dq| <= 2^-8 |q|, |dk| <= 2^-8 |k| (Euclidean norms), and
+// |(q+dq).(k+dk) - q.k| <= |dq||k| + |q||dk| + |dq||dk| <= 2^-7 + 2^-16 for unit rows.  The fp32 accumulation of the exact
+// bf16 products and the rounding of the exact chain itself add < 2^-14 each; 2^-10 covers them and the 1e-7 by which a
+// normalised row's norm can exceed 1.
+constexpr float FILTER_EPS = 0.0078125f + 0.0009765625f;  // 2^-7 + 2^-10
 constexpr int CHUNK = 16;  // candidate slots a lane reserves at a time
 
 template <int SUBS>  // 32-key MFMA sub-tiles per ring stage: the ring hand-over (flags, DMA issue) is paid once per stage
