@@ -31,7 +31,7 @@ class RAGraph(nn.Module):
         self.retrieve_weight, self.retrieve_num, self.batch_size = retrieve_weight, retrieve_num, batch_size  # :33-85
         self.noise_retrieve_num = 1
         self.resource_keys = self.resource_values = None
-        self._keys_normalized = None
+        self._keys_normalized = self._index = None
         self._csr_cache = None
         ue, ie = pretrained_model.generate()
         self.user_embedding = nn.Parameter(ue.detach().clone().to(device))
@@ -105,7 +105,7 @@ class RAGraph(nn.Module):
         for r in res[2::2]:
             vals = K.axpby(vals, 1.0, r, 1.0)
         self.resource_keys, self.resource_values = res[-1], vals
-        self._keys_normalized = None
+        self._keys_normalized = self._index = None
 
     @property
     def keys_normalized(self):
@@ -133,7 +133,9 @@ class RAGraph(nn.Module):
             k = self.retrieve_num + (self.noise_retrieve_num if add_noise else 0)             # :308
             # :298-324: the reference walks the queries in slabs of batch_size only to bound its B x N score matrix;
             # the fused kernel never builds that matrix, so all queries go in one launch.
-            _, idx = K.topk_cosine(res[0], self.keys_normalized, k)
+            if self._index is None:
+                self._index = K.KeyIndex(self.keys_normalized)
+            _, idx = self._index.topk(res[0], k)
             if add_noise:
                 noise = torch.randint(0, self.resource_values.shape[0], (idx.shape[0], self.noise_retrieve_num),
                                       device=idx.device)

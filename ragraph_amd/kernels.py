@@ -177,6 +177,9 @@ def topk_cosine_filtered(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf
     return scores, idx, n_over
 
 
+from .kernels_index import KeyIndex  # noqa: E402,F401  (bank copies + dispatch to the fastest exact top-k)
+
+
 def topk_merge(scores: torch.Tensor, idx: torch.Tensor):
     """[G,B,k] per-shard lists -> canonical [B,k]."""
     L = _ready()

@@ -56,8 +56,7 @@ class ToyGraphBase:
         self._values = _Bank(emb_size, self.device)
         self._labels = _Bank(num_class, self.device)
         self._keys_normalized = None  # cache, invalidated by every append
-        self._keys_packed = None      # cache of K.pack_keys(keys_normalized), built on the first large-batch lookup
-        self._keys_bf16 = None        # cache of K.keys_to_bf16(keys_normalized) for the bf16-filtered exact top-k
+        self._index = None            # K.KeyIndex of this bank version (packed / bf16 copies made on first use)
 
     # ---- bank state (attribute names of the reference) ---------------------------------------------------------
     @property
@@ -78,13 +77,13 @@ class ToyGraphBase:
         self._keys.append(keys)
         self._values.append(values)
         self._labels.append(labels)
-        self._keys_normalized = self._keys_packed = self._keys_bf16 = None
+        self._keys_normalized = self._index = None
 
     def set_resources(self, keys: Tensor, values: Tensor, labels: Tensor) -> None:
         """Adopt caller-owned device tensors as the bank without copying (e.g. a 1M-row synthetic bank)."""
         for b, t in ((self._keys, keys), (self._values, values), (self._labels, labels)):
             b.buf, b.n = t.to(self.device, torch.float32).contiguous(), t.shape[0]
-        self._keys_normalized = self._keys_packed = self._keys_bf16 = None
+        self._keys_normalized = self._index = None
 
     @property
     def keys_normalized(self) -> Tensor:
@@ -105,18 +104,9 @@ class ToyGraphBase:
         q = search_keys.reshape(1, -1) if search_keys.dim() == 1 else search_keys
         if self.resource_keys.shape[0] < k:
             raise RuntimeError(f"selected index k out of range: bank has {self.resource_keys.shape[0]} rows, k={k}")
-        kp = None
-        if K.packed_keys_help(q.shape[0], q.shape[1], k):  # large batches stream a packed bank copy by LDS-DMA
-            if self._keys_packed is None:
-                self._keys_packed = K.pack_keys(self.keys_normalized)
-            kp = self._keys_packed
-        if K.filter_helps(q.shape[0], self.resource_keys.shape[0], q.shape[1], k):
-            # very large batches: bf16 MFMA filter + exact fp32 rescoring -- the same bits, several times faster
-            if self._keys_bf16 is None:
-                self._keys_bf16 = K.keys_to_bf16(self.keys_normalized)
-            s, i, _ = K.topk_cosine_filtered(q, self.keys_normalized, self._keys_bf16, k, keys_packed=kp)
-            return s, i
-        return K.topk_cosine(q, self.keys_normalized, k, keys_packed=kp)
+        if self._index is None:
+            self._index = K.KeyIndex(self.keys_normalized)
+        return self._index.topk(q, k)  # fp32 streaming / tile kernel or, for large batches, the bf16-filtered exact path
 
     def retrieve(self, search_keys: Tensor, search_adj, add_noise: bool):
         """ToyGraphBase.py:47-81 -> (rag_embeddings [B,k',D], rag_labels [B,k',C]).  A 1-D query (graph flavour,

@@ -47,8 +47,8 @@ class ShardedToyGraphBase:
         self.retrieve_num = retrieve_num
         self.resource_keys, self.resource_values, self.resource_labels = keys, values, labels
         self.keys_normalized = ops.normalize_rows(keys)
-        self._keys_packed = None  # built on the first large-batch lookup when `ops` offers it (the HIP library does)
-        self._keys_bf16 = None
+        from .kernels_index import KeyIndex  # torch-only helper: copies for the faster kernels, made on first use
+        self._index = KeyIndex(self.keys_normalized, ops)
 
     def topk(self, search_keys, k=None):
         """Global canonical top-k: (scores [B,k], idx [B,k]) identical on every rank."""
@@ -56,22 +56,7 @@ class ShardedToyGraphBase:
         q = search_keys.reshape(1, -1) if search_keys.dim() == 1 else search_keys
         n_local = self.keys_normalized.shape[0]
         kl = min(k, n_local)
-        helps = getattr(self.ops, "packed_keys_help", None)
-        kp = None
-        if helps is not None and helps(q.shape[0], q.shape[1], kl):
-            if self._keys_packed is None:
-                self._keys_packed = self.ops.pack_keys(self.keys_normalized)
-            kp = self._keys_packed
-        fhelps = getattr(self.ops, "filter_helps", None)
-        if fhelps is not None and fhelps(q.shape[0], n_local, q.shape[1], kl):
-            if self._keys_bf16 is None:  # bf16-filtered exact top-k of this shard: same bits, several times faster
-                self._keys_bf16 = self.ops.keys_to_bf16(self.keys_normalized)
-            s, i, _ = self.ops.topk_cosine_filtered(q, self.keys_normalized, self._keys_bf16, kl,
-                                                    idx_base=self.idx_base, keys_packed=kp)
-        elif kp is not None:
-            s, i = self.ops.topk_cosine(q, self.keys_normalized, kl, idx_base=self.idx_base, keys_packed=kp)
-        else:
-            s, i = self.ops.topk_cosine(q, self.keys_normalized, kl, idx_base=self.idx_base)
+        s, i = self._index.topk(q, kl, idx_base=self.idx_base)
         if kl < k:  # a shard smaller than k: pad with sentinels that lose every comparison
             pad_s = torch.full((q.shape[0], k - kl), float("-inf"), dtype=s.dtype, device=s.device)
             pad_i = torch.full((q.shape[0], k - kl), torch.iinfo(torch.int64).max, dtype=i.dtype, device=i.device)
