@@ -48,6 +48,13 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="queries timed on the CPU baseline")
     ap.add_argument("--small-batch", action="store_true", help="also time the HBM-bound B<=16 retrieval regime")
+    ap.add_argument("--shard", choices=("queries", "keys"), default="queries",
+                    help="N > 1: split the query batch over the GPUs with the bank replicated (default; no data-path "
+                         "collective, one all_gather of the [n, C] outputs), or row-shard the key bank with an RCCL "
+                         "all_gather of the per-shard top-k (the layout for banks that should not be replicated)")
+    ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="G",
+                    help="single process: time what rank 0 of a G-GPU job would compute (no collectives); an estimate "
+                         "of the per-rank step for DESIGN.md, never the bench line of a real multi-GPU run")
     ap.add_argument("--exact-fp32", action="store_true",
                     help="retrieve with the fp32 MFMA kernel only (no bf16 filter): the previous headline path")
     return ap.parse_args()
@@ -95,7 +102,29 @@ def build_workload(args, dev, rank, world, force_dist=False):
     feats = torch.randn(args.nodes, args.feat, device=dev, generator=torch.Generator(device=dev).manual_seed(4321))
     Kb, Vb, Lb = synthetic_bank(args.bank, args.dim, args.classes, device=dev)
     Kb = K.normalize_rows(Kb)  # stored unit-norm, as the reference stores keys (ToyGraphBase.py:109)
-    if world > 1 or force_dist:
+    emu = args.emulate_rank_of
+    if emu > 1 and args.shard == "queries":
+        class _Slice:  # rank 0 of `emu`, no process group
+            world, rank, collective = emu, 0, False
+
+            def bounds(self, B):
+                return shard_bounds(B, emu, 0)
+
+            def gather_rows(self, local, B):
+                return local
+        model.query_shard = _Slice()
+        model.toy_graph_base.set_resources(Kb, Vb, Lb)
+        n_local = args.bank
+    elif emu > 1:
+        lo, hi = shard_bounds(args.bank, emu, 0)
+        model.toy_graph_base = ShardedToyGraphBase(Kb[lo:hi].contiguous(), Vb, Lb, lo, args.k, values_replicated=True)
+        n_local = hi - lo
+    elif (world > 1 or force_dist) and args.shard == "queries":
+        from ragraph_amd.sharded import QueryShard
+        model.query_shard = QueryShard(force_collectives=force_dist)
+        model.toy_graph_base.set_resources(Kb, Vb, Lb)
+        n_local = args.bank
+    elif world > 1 or force_dist:
         lo, hi = shard_bounds(args.bank, world, rank)
         # keys row-sharded; values / labels replicated (1 GB of 288 GB) so the top-k all_gather is the only collective
         model.toy_graph_base = ShardedToyGraphBase(Kb[lo:hi].contiguous(), Vb, Lb, lo, args.k,
@@ -244,15 +273,18 @@ def main():
     traffic = None  # HBM-side GB per launch from the committed PMC run of this exact shape (cannot be sampled in-process)
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-        key = (f"topk_filter_kernel B={n} N={n_local} D={args.dim} k={args.k}" if not args.exact_fp32 and
-               K.filter_helps(n, n_local, args.dim, args.k) else
-               f"topk_stream_kernel<{args.dim}> B={n} N={n_local} D={args.dim} k={args.k}")
+        nq_key = -(-n // (max(world, args.emulate_rank_of, 1) if args.shard == "queries" else 1))
+        key = (f"topk_filter_kernel B={nq_key} N={n_local} D={args.dim} k={args.k}" if not args.exact_fp32 and
+               K.filter_helps(nq_key, n_local, args.dim, args.k) else
+               f"topk_stream_kernel<{args.dim}> B={nq_key} N={n_local} D={args.dim} k={args.k}")
         if key in prof:
             traffic = prof[key]["hbm_side_GB"]
     except (OSError, ValueError):
         pass
     ms_step = elapsed / args.steps * 1e3
-    flops = 2.0 * n * n_local * args.dim
+    shard_div = max(world, args.emulate_rank_of, 1) if args.shard == "queries" else 1
+    n_q_local = -(-n // shard_div)  # queries this rank scores against its n_local keys
+    flops = 2.0 * n_q_local * n_local * args.dim
     filtered = len(filt_timer.events) > 0
     if filtered:
         # dominant kernel = the bf16 filter (its own events inside the library, ragraph_profile_last_filter_ms)
@@ -303,10 +335,16 @@ def main():
                                f"(BASELINE.json configs[1])",
                    "bank_rows_per_gpu": n_local,
                    "parallelism": "single GPU" if world == 1 else
-                   f"key bank row-sharded x{world} (values replicated), one RCCL all_gather of the per-shard top-k per step"},
+                   (f"query batch split x{world}, bank replicated on every GPU (1 GB of 288 GB): no data-path collective, "
+                    f"one RCCL all_gather of the [n, C] outputs per step" if args.shard == "queries" else
+                    f"key bank row-sharded x{world} (values replicated), one RCCL all_gather of the per-shard top-k per "
+                    f"step")},
         "roofline": roofline,
     }
-    if world == 1:
+    if args.emulate_rank_of > 1:
+        result["emulated"] = (f"rank 0 of a {args.emulate_rank_of}-GPU job ({args.shard}-sharded), no collectives: "
+                              f"value is NOT a job throughput")
+    if world == 1 and args.emulate_rank_of <= 1:
         result["gnn_fwd_nodes_per_s"] = round(gnn_only_rate(model, feats, adj, max(args.steps, 3)), 1)
         if args.small_batch:
             result["retrieval_small_batch"] = small_batch_rates(model.toy_graph_base, args.dim, args.k, dev)

@@ -49,12 +49,16 @@ class RAGraph(nn.Module):
     def _pool(self, x, g):
         return x
 
+    query_shard = None  # ragraph_amd.sharded.QueryShard: answer only this rank's rows of the batch (inference)
+
     def forward(self, features, adj):
         g = as_csr(adj)
         pretrain_embedddings = self.pretrain_model.inference(features, g)                      # RAGraph.py:40
         add_noise = self.training and self.noise_finetune
         tgb = self.toy_graph_base
         queries = self._queries(pretrain_embedddings, g)
+        if self.query_shard is not None and not self.training and self.flavour == "node":
+            return self._forward_query_shard(queries, pretrain_embedddings, g)
         if add_noise:
             rag_embeddings, rag_labels = tgb.retrieve(queries, g, True)                        # :43 (noise branch)
             rag_label = rag_labels.mean(dim=1)
@@ -68,6 +72,22 @@ class RAGraph(nn.Module):
         hidden = A.axpby(query_embeddings, 1 - self.retrieve_weight, rag_embedding, self.retrieve_weight)  # :53
         decode_label = self.decoder(hidden)                                                    # :54
         return A.softmax_mix(decode_label, rag_label, self.label_weight)                       # :55-57
+
+
+    def _forward_query_shard(self, queries, emb, g):
+        """Multi-GPU inference with a replicated bank: the cheap graph part runs on every rank, the retrieval and the
+        decoder only on this rank's slice of the nodes; one all_gather of the [n, C] outputs puts the whole result on
+        every rank.  Row for row the same arithmetic as forward()."""
+        qs = self.query_shard
+        n = queries.shape[0]
+        lo, hi = qs.bounds(n)
+        rag_embedding, rag_label, _ = self.toy_graph_base.retrieve_reduced(queries[lo:hi].contiguous())
+        if not self.finetune:
+            return qs.gather_rows(rag_label, n)
+        query_embeddings = Propagation.aggregate_k_hop_features(g, emb, self.query_graph_hop)[lo:hi].contiguous()
+        hidden = A.axpby(query_embeddings, 1 - self.retrieve_weight, rag_embedding, self.retrieve_weight)
+        out = A.softmax_mix(self.decoder(hidden), rag_label, self.label_weight)
+        return qs.gather_rows(out, n)
 
 
 class RAGraphGraph(RAGraph):

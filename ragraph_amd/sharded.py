@@ -26,6 +26,43 @@ def shard_bounds(N: int, world: int, rank: int):
     return lo, lo + q + (1 if rank < r else 0)
 
 
+class QueryShard:
+    """The other way to use G GPUs: the bank (1 GB at 1M x 256 -- nothing next to 288 GB of HBM) is REPLICATED and the
+    batch of queries is split, rank r answering rows shard_bounds(B, G, r).  Queries are independent, so there is no
+    data-path collective at all; the only exchange is the all_gather of the per-query results (C logits per node),
+    which every rank needs only if it wants the whole output.  Results are those of one GPU bit for bit (a score does
+    not depend on the query batch).  Key sharding (ShardedToyGraphBase) is for banks that should not be replicated."""
+
+    def __init__(self, group=None, force_collectives: bool = False):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.collective = self.world > 1 or (force_collectives and dist.is_initialized())
+
+    def bounds(self, B: int):
+        return shard_bounds(B, self.world, self.rank)
+
+    def gather_rows(self, local: torch.Tensor, B: int) -> torch.Tensor:
+        """[hi-lo, C] per rank -> [B, C] on every rank (rows in query order).  Ranks hold ceil or floor(B / G) rows:
+        padded to the larger size for one all_gather_into_tensor, then the padding rows are dropped."""
+        if not self.collective:
+            return local
+        per = -(-B // self.world)
+        lo, hi = self.bounds(B)
+        buf = local
+        if hi - lo < per:
+            buf = torch.cat([local, local.new_zeros((per - (hi - lo),) + tuple(local.shape[1:]))], 0)
+        out = local.new_empty((self.world * per,) + tuple(local.shape[1:]))
+        dist.all_gather_into_tensor(out, buf.contiguous(), group=self.group)
+        if self.world * per == B:
+            return out
+        parts = []
+        for r in range(self.world):
+            a, b = shard_bounds(B, self.world, r)
+            parts.append(out[r * per: r * per + (b - a)])
+        return torch.cat(parts, 0)
+
+
 class ShardedToyGraphBase:
     """Retrieval over a row-sharded bank.  `ops` supplies the five kernels (default: ragraph_amd.kernels, i.e. the HIP
     library); the CPU tests inject an oracle-backed object to exercise the collective logic under gloo."""

@@ -91,3 +91,29 @@ def test_sharded_retrieval_world2_matches_single(tmp_path, N, k):
         # replicated values: bit-identical to the single-GPU sums, no all_reduce
         assert np.array_equal(r["ri"], ri) and np.array_equal(r["rsv"], rsv) and np.array_equal(r["rml"], rml)
     assert np.array_equal(r0["sv"], r1["sv"])
+
+
+def _qs_worker(rank, world, port, B, C, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ragraph_amd.sharded import QueryShard
+
+        qs = QueryShard()
+        lo, hi = qs.bounds(B)
+        full = torch.arange(B * C, dtype=torch.float32).reshape(B, C)  # what one GPU would produce
+        got = qs.gather_rows(full[lo:hi].contiguous(), B)               # each rank contributes only its rows
+        np.savez(os.path.join(out_dir, f"q{rank}.npz"), got=got.numpy(), lo=lo, hi=hi)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [37, 40, 3])  # ragged split, even split, fewer rows than... no: 3 rows over 2 ranks
+def test_query_shard_gather_world2(tmp_path, B):
+    """Query sharding: every rank answers its slice of the batch; the all_gather puts the rows back in query order."""
+    C, world = 3, 2
+    mp.spawn(_qs_worker, args=(world, _free_port(), B, C, str(tmp_path)), nprocs=world, join=True)
+    want = np.arange(B * C, dtype=np.float32).reshape(B, C)
+    r0, r1 = (dict(np.load(tmp_path / f"q{r}.npz")) for r in range(world))
+    assert np.array_equal(r0["got"], want) and np.array_equal(r1["got"], want)
+    assert r0["lo"] == 0 and r0["hi"] == r1["lo"] and r1["hi"] == B
