@@ -37,7 +37,6 @@ typedef __attribute__((address_space(3))) void lds_void_f;
 // bf16 products and the rounding of the exact chain itself add < 2^-14 each; 2^-10 covers them and the 1e-7 by which a
 // normalised row's norm can exceed 1.
 constexpr float FILTER_EPS = 0.0078125f + 0.0009765625f;  // 2^-7 + 2^-10
-constexpr int CHUNK = 16;  // candidate slots a lane reserves at a time
 
 template <int SUBS>  // 32-key MFMA sub-tiles per ring stage: the ring hand-over (flags, DMA issue) is paid once per stage
 struct FilterCfg {
@@ -60,6 +59,8 @@ struct FilterParams {
   int* cand;              // [B,cap] candidate key indices (local to this shard)
   int64_t B, N;           // N = end of the key range (keys >= N never pass)
   int cap;
+  int chunk;              // slots a lane reserves per returning atomic (1..16): small when a query tile is cut into
+                          // many short segments, so that half-empty chunks do not eat the list
   int64_t stage_base;     // first stage of the key range this launch filters
   int64_t qtiles, nstages_total;  // nstages_total = stages in the range
   int xcd_map, wgs_per_group, lb_min, depth[2];
@@ -196,8 +197,9 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     // padded queries never pass: +inf threshold
     float thr0 = q_lo < p.B ? p.thr[q_lo] : __builtin_huge_valf();
     float thr1 = q_hi < p.B ? p.thr[q_hi] : __builtin_huge_valf();
-    // Candidate slots are reserved CHUNK at a time (one returning atomic per 16 candidates of a lane; the candidate
+    // Candidate slots are reserved p.chunk at a time (one returning atomic per chunk of a lane's candidates; the candidate
     // itself is a plain store); unused slots of a chunk keep the buffer's -1 fill and are skipped by the rescoring.
+    const int CHUNK = p.chunk;
     int base0 = 0, used0 = CHUNK, base1 = 0, used1 = CHUNK;
     // hipcc does not know about the asm DMA loads, and any vmcnt(0) it emits inside the stage loop (for a global load it
     // still considers pending at the loop's back edge) would drain them every sub-tile: retire the thresholds here and
@@ -589,6 +591,11 @@ static int run_filter_level(const float* Qn, const float* Kn, const uint16_t* Kb
   p.xcd_map = p.qtiles >= 64 ? 1 : 0;
   p.wgs_per_group = CUS / (p.xcd_map ? 8 : 1);
   p.lb_min = 8;
+  {  // ~150 candidates per query and level, spread over the tile's segments and the two half-waves of a query
+    const int64_t segs = p.qtiles >= CUS ? 2 : cdiv(CUS, p.qtiles);
+    const int64_t per_lane = 150 / (2 * segs);
+    p.chunk = per_lane >= 16 ? 16 : per_lane >= 8 ? 8 : per_lane >= 4 ? 4 : per_lane >= 2 ? 2 : 1;
+  }
   const int64_t nq0 = p.xcd_map ? (p.qtiles + 7) / 8 : p.qtiles;
   for (int v = 0; v < 2; ++v) {
     const int64_t nq = nq0 - v;

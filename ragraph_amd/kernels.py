@@ -5,6 +5,8 @@ All functions require CUDA(=ROCm) tensors and raise `RagraphNativeError` otherwi
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _native as N
@@ -130,9 +132,12 @@ def keys_to_bf16(keys_normalized: torch.Tensor) -> torch.Tensor:
 
 
 def filter_helps(B: int, n_keys: int, D: int, k: int) -> bool:
-    """True when the bf16-filtered exact top-k is the faster way to the same bits (measured on MI355X: 1.6 vs 2.6 ms at
-    512 queries x 1M keys, 0.83 vs 1.53 ms at 4096 x 65536, 50 vs 366 ms at 100k x 1M)."""
-    return D == 256 and k <= 32 and B >= 512 and n_keys >= 65536
+    """True when the bf16-filtered exact top-k is the faster way to the same bits.  Measured on MI355X (ms, filtered vs
+    fp32 kernels): 64 queries x 1M keys 0.57 vs 0.75, 300 x 1M 0.67 vs 2.57, 4096 x 65536 0.83 vs 1.53, 100k x 1M 51 vs
+    366; the fp32 kernels win below ~5e7 query-key pairs (32 x 1M: 0.54 vs 0.48; 256 x 100k: 0.43 vs 0.38)."""
+    if os.environ.get("RAGRAPH_EXACT_FP32") == "1":  # e.g. under HIP-graph capture: the filtered call reads a count back
+        return False
+    return D == 256 and k <= 32 and B >= 48 and n_keys >= 65536 and B * n_keys >= 48_000_000
 
 
 def topk_cosine_filtered(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf16: torch.Tensor, k: int,
