@@ -10,18 +10,31 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <int MODE>
+template <int MODE, int RANDOM>
 __global__ void __launch_bounds__(512, 2) k(float* out, int iters, float a) {
   extern __shared__ float4 smem4[];
   char* smem = (char*)smem4;
   const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
-  for (int i = threadIdx.x; i < 16384 / 4; i += blockDim.x) ((float*)smem)[i] = a + i * 1e-7f;
+  // RANDOM != 0: operands are pseudo-random bf16 in [-1, 1) (what real unit rows look like to the data path: the chip
+  // holds a lower clock on random bits than on near-constant ones)
+  for (int i = threadIdx.x; i < 16384 / 2; i += blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    const float v = RANDOM ? ((int)(h & 0xFFFF) - 32768) * (1.f / 32768.f) : a + i * 1e-7f;
+    ((__bf16*)smem)[i] = (__bf16)v;
+  }
   __syncthreads();
   bf16x8 b0[16], b1[16];
 #pragma unroll
   for (int t = 0; t < 16; ++t)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { b0[t][e] = (__bf16)(a + t * 1e-3f + e * 1e-2f + lane * 1e-4f); b1[t][e] = (__bf16)(a - t * 1e-3f + lane * 1e-4f); }
+    for (int e = 0; e < 8; ++e) {
+      unsigned h = (unsigned)(threadIdx.x * 131 + t * 17 + e) * 2654435761u;
+      h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+      const float v = ((int)(h & 0xFFFF) - 32768) * (1.f / 32768.f) * 0.0625f;
+      b0[t][e] = RANDOM ? (__bf16)v : (__bf16)(a + t * 1e-3f + e * 1e-2f + lane * 1e-4f);
+      b1[t][e] = RANDOM ? (__bf16)(-v * 0.7f + 0.001f * e) : (__bf16)(a - t * 1e-3f + lane * 1e-4f);
+    }
   float keep = 0.f;
   const unsigned lds_base = (unsigned)(size_t)(lds_void*)smem;
   unsigned addr[8];
@@ -80,21 +93,21 @@ __global__ void __launch_bounds__(512, 2) k(float* out, int iters, float a) {
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = keep;
 }
-template <int MODE>
+template <int MODE, int RANDOM>
 void run(const char* name, int threads) {
   float* d;
   hipMalloc(&d, 256 * 512 * 4);
-  hipFuncSetAttribute((const void*)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute((const void*)k<MODE, RANDOM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   int iters = 20000;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   const size_t lds = 140 * 1024;  // one workgroup per CU as in the kernel
-  k<MODE><<<256, threads, lds>>>(d, 10, 1.0f);
+  k<MODE, RANDOM><<<256, threads, lds>>>(d, 10, 1.0f);
   hipDeviceSynchronize();
   float best = 1e30f;
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(e0);
-    k<MODE><<<256, threads, lds>>>(d, iters, 1.0001f);
+    k<MODE, RANDOM><<<256, threads, lds>>>(d, iters, 1.0001f);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -105,11 +118,14 @@ void run(const char* name, int threads) {
   hipFree(d);
 }
 int main() {
-  run<0>("A in registers, 2 waves/SIMD", 512);
-  run<0>("A in registers, 1 wave/SIMD", 256);
-  run<1>("A from LDS (hipcc schedule), 2 waves/SIMD", 512);
-  run<2>("  + v_max epilogue", 512);
-  run<3>("A from LDS, asm reads 4 ahead + epilogue, 2 waves/SIMD", 512);
-  run<3>("A from LDS, asm reads 4 ahead + epilogue, 1 wave/SIMD", 256);
+  run<0, 0>("A in registers, 2 waves/SIMD", 512);
+  run<0, 0>("A in registers, 1 wave/SIMD", 256);
+  run<1, 0>("A from LDS (hipcc schedule), 2 waves/SIMD", 512);
+  run<2, 0>("  + v_max epilogue", 512);
+  run<3, 0>("A from LDS, asm reads 4 ahead + epilogue, 2 waves/SIMD", 512);
+  run<3, 0>("A from LDS, asm reads 4 ahead + epilogue, 1 wave/SIMD", 256);
+  run<3, 1>("the same on RANDOM operands, 2 waves/SIMD", 512);
+  run<3, 1>("the same on RANDOM operands, 1 wave/SIMD", 256);
+  run<0, 1>("A in registers, RANDOM B operands, 2 waves/SIMD", 512);
   return 0;
 }
