@@ -10,16 +10,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // wait until at most n LDS reads are outstanding; naming the fragments keeps their MFMAs behind the wait
 #define WAIT_LGKM(n, a, b) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a), "+v"(b))
 
-template <int MODE>  // 0: hipcc schedule; 1: hand pipelined one pair ahead; 2: two pairs ahead
+template <int MODE, int RANDOM>  // 0: hipcc schedule; 1: hand pipelined one pair ahead; RANDOM: pseudo-random operands
 __global__ void __launch_bounds__(512, 2) k(float* out, int iters, float a) {
   extern __shared__ float4 smem4[];
   float* smem = (float*)smem4;
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  for (int i = threadIdx.x; i < 32 * 260; i += 512) smem[i] = a + i * 1e-7f;
+  for (int i = threadIdx.x; i < 32 * 260; i += 512) {
+    unsigned hsh = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+    hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
+    smem[i] = RANDOM ? ((int)(hsh & 0xFFFFFF) - 8388608) * (1.f / 8388608.f) * 0.0625f : a + i * 1e-7f;
+  }
   __syncthreads();
   float breg[128];
 #pragma unroll
-  for (int m = 0; m < 128; ++m) breg[m] = a + m * 1e-6f + lane * 1e-7f;
+  for (int m = 0; m < 128; ++m) {
+    unsigned hsh = (unsigned)(threadIdx.x * 131 + m) * 2654435761u;
+    hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
+    breg[m] = RANDOM ? ((int)(hsh & 0xFFFFFF) - 8388608) * (1.f / 8388608.f) * 0.0625f : a + m * 1e-6f + lane * 1e-7f;
+  }
   float keep = 0.f;
   const float* arow = smem + j * 260 + h * 128;
   const unsigned aaddr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)arow;
@@ -76,18 +84,18 @@ __global__ void __launch_bounds__(512, 2) k(float* out, int iters, float a) {
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = keep;
 }
-template <int MODE>
+template <int MODE, int RANDOM>
 void run(const char* name) {
   float* d;
   hipMalloc(&d, 256 * 512 * 4);
-  hipFuncSetAttribute((const void*)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  hipFuncSetAttribute((const void*)k<MODE, RANDOM>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   int iters = 2000;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  k<MODE><<<256, 512, 34 * 1024>>>(d, 10, 1.0f);
+  k<MODE, RANDOM><<<256, 512, 34 * 1024>>>(d, 10, 1.0f);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  k<MODE><<<256, 512, 34 * 1024>>>(d, iters, 1.0001f);
+  k<MODE, RANDOM><<<256, 512, 34 * 1024>>>(d, iters, 1.0001f);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -96,9 +104,11 @@ void run(const char* name) {
   hipFree(d);
 }
 int main() {
-  run<0>("hipcc schedule (read pair, wait, 8 MFMA)");
-  run<1>("hand pipelined, one pair ahead");
-  run<0>("hipcc schedule (repeat)");
-  run<1>("hand pipelined, one pair ahead (repeat)");
+  run<0, 0>("hipcc schedule (read pair, wait, 8 MFMA)");
+  run<1, 0>("hand pipelined, one pair ahead");
+  run<0, 0>("hipcc schedule (repeat)");
+  run<1, 0>("hand pipelined, one pair ahead (repeat)");
+  run<0, 1>("hipcc schedule, RANDOM operands");
+  run<1, 1>("hand pipelined, RANDOM operands");
   return 0;
 }
