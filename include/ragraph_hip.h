@@ -95,8 +95,9 @@ int ragraph_topk_cosine_bank_f32(const float* Q, int64_t B, const float* Kn, con
 /* a1, large batches: the same result through a bf16 MFMA filter (ragraph_amd/csrc/topk_filter.hip).
  *   Exact by construction: (1) the fp32 kernel finds the top-k of every query over the first N/256 keys; its k-th score
  *   bounds the final k-th best from below; (2) a bf16 MFMA pass (16x the fp32 matrix rate) over the next, larger part of
- *   the bank keeps every key whose approximate score is within EPS = 2^-7 + 2^-10 of that bound -- unit vectors rounded
- *   to 8 significant bits cannot move a dot product by more (Cauchy-Schwarz); (3) the survivors (~100 per query) are
+ *   the bank keeps every key whose approximate score is within eps(q) of that bound, where eps(q) = |dq| + max|dk| +
+ *   |dq| max|dk| (+ rounding slack) is computed from the actual bf16 rounding errors dq of the query and dk of the bank
+ *   rows (<= 2^-7, typically 0.003): by Cauchy-Schwarz no pair's dot product moves by more; (3) the survivors (~100 per query) are
  *   rescored with the natural-order fp32 fmaf chain and selected in canonical order, which gives the exact top-k of
  *   everything seen so far and a tighter bound for the next level ([0,N/32), [N/32,N/4), [N/4,N)).  The result has the
  *   same bits as ragraph_topk_cosine_f32.  D = 256, k <= 32.

@@ -5,9 +5,10 @@
 //   1. sample pass (exact, fp32 kernel): top-k of every query over the first Ns keys.  Its k-th score theta[q] is a
 //      lower bound of the final k-th best exact score of q.
 //   2. filter pass (this file, bf16 MFMA over the whole bank): approximate scores s~ = bf16(q)·bf16(key), fp32
-//      accumulate.  Both vectors have unit norm, every element is rounded to 8 significant bits (relative error <= 2^-8),
-//      so by Cauchy-Schwarz |s~ - s| <= (2^-7 + 2^-16)·|q|·|key| + accumulation error < EPS = 2^-7 + 2^-10 for EVERY pair.  A key of the
-//      exact top-k has s >= theta[q], hence s~ >= theta[q] - EPS: every key that passes goes to the query's candidate
+//      accumulate.  With q^ = q + dq, k^ = k + dk: |s~ - s| <= |dq||k| + |q||dk| + |dq||dk| + accumulation error
+//      (Cauchy-Schwarz) <= eps(q), computed from the query's actual |dq| and the bank's largest |dk| (<= 2^-7 in the worst
+//      case, ~0.003 typically) -- a bound for EVERY pair.  A key of the
+//      exact top-k has s >= theta[q], hence s~ >= theta[q] - eps(q): every key that passes goes to the query's candidate
 //      list (global append).  Nothing else can be in the result.
 //   3. rescoring pass: the exact score of every candidate as the fp32 fmaf chain in natural k order from +0 (one lane
 //      per candidate) -- the same chain the f32 MFMA and the oracle compute, so the same bits -- and the canonical
@@ -31,12 +32,15 @@ namespace ragraph {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void_f;
 
-// bf16 keeps 8 significant bits: round-to-nearest moves an element by at most 2^-8 of its magnitude, so the rounded
-// vectors are q + dq, k + dk with |dq| <= 2^-8 |q|, |dk| <= 2^-8 |k| (Euclidean norms), and
-// |(q+dq).(k+dk) - q.k| <= |dq||k| + |q||dk| + |dq||dk| <= 2^-7 + 2^-16 for unit rows.  The fp32 accumulation of the exact
-// bf16 products and the rounding of the exact chain itself add < 2^-14 each; 2^-10 covers them and the 1e-7 by which a
-// normalised row's norm can exceed 1.
-constexpr float FILTER_EPS = 0.0078125f + 0.0009765625f;  // 2^-7 + 2^-10
+// Error bound of the bf16 scores.  The rounded rows are q + dq and k + dk, so
+//   |(q+dq).(k+dk) - q.k| <= |dq||k| + |q||dk| + |dq||dk|      (Cauchy-Schwarz, Euclidean norms)
+// bf16 keeps 8 significant bits, i.e. |dq| <= 2^-8 |q| at worst, but the actual |dq| of a query and the largest |dk| of
+// the bank are known exactly: ragraph_keys_to_bf16 leaves max_k |dk| behind the bank copy and the query side is
+// computed per call.  eps(q) = (|dq| + max|dk| + |dq| max|dk|)(1 + 2^-10) + 2^-12: the factor covers the fp32 rounding
+// of the norms and the 1e-7 by which a normalised row's norm can exceed 1, the constant the fp32 accumulation of the
+// (exact) bf16 products and the rounding of the exact chain itself (< 2^-14 each).  Typically eps ~ 0.003, a third of
+// the worst case 2^-7.
+constexpr float FILTER_EPS_SLACK = 0.000244140625f;  // 2^-12
 
 template <int SUBS>  // 32-key MFMA sub-tiles per ring stage: the ring hand-over (flags, DMA issue) is paid once per stage
 struct FilterCfg {
@@ -75,31 +79,66 @@ __device__ __forceinline__ void fring_signal(unsigned* ctr, int lane) {
 
 // Rows [N, round_up(N,128)) of Kb are zero so the stream never needs a tail clamp (a ring stage is <= 128 keys).
 __global__ void __launch_bounds__(256) keys_to_bf16_kernel(const float* __restrict__ Kn, int64_t N, int64_t Npad,
-                                                           uint16_t* __restrict__ Kb) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread = 8 elements
-  if (i >= Npad * 32) return;
+                                                           uint16_t* __restrict__ Kb, unsigned* __restrict__ max_err2) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread = 8 elements; 32 threads = one row
   const int64_t row = i >> 5;
   bf16x8 o;
-  if (row < N) {
+  float e2 = 0.f;
+  if (i < Npad * 32 && row < N) {
     const float4 a = reinterpret_cast<const float4*>(Kn)[2 * i], b = reinterpret_cast<const float4*>(Kn)[2 * i + 1];
-    o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
-    o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      o[e] = (__bf16)x[e];
+      const float d = x[e] - (float)o[e];
+      e2 = fmaf(d, d, e2);
+    }
   } else {
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (__bf16)0.f;
   }
-  reinterpret_cast<bf16x8*>(Kb)[i] = o;
+  if (i < Npad * 32) reinterpret_cast<bf16x8*>(Kb)[i] = o;
+  // |dk|^2 of the row = sum over its 32 threads (one half-wave); the bank's maximum by an integer max (non-negative
+  // floats order like their bit patterns)
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) e2 += __shfl_xor(e2, off);
+  if ((threadIdx.x & 31) == 0 && e2 > 0.f) atomicMax(max_err2, __float_as_uint(e2));
 }
 
-// thr[q] = (k-th exact score of the previous level) - EPS; count[q] = 0.  `first`: also clear the overflow bookkeeping.
+// |dq| per query: q - bf16(q) over the normalised row (one half-wave per query).
+__global__ void __launch_bounds__(256) filter_query_err_kernel(const float* __restrict__ Qn, int64_t B,
+                                                               float* __restrict__ eq) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t q = i >> 5;
+  float e2 = 0.f;
+  if (q < B) {
+    const float4 a = reinterpret_cast<const float4*>(Qn)[2 * i], b = reinterpret_cast<const float4*>(Qn)[2 * i + 1];
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float d = x[e] - (float)(__bf16)x[e];
+      e2 = fmaf(d, d, e2);
+    }
+  }
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) e2 += __shfl_xor(e2, off);
+  if ((threadIdx.x & 31) == 0 && q < B) eq[q] = sqrtf(e2);
+}
+
+// thr[q] = (k-th exact score of the previous level) - eps(q); count[q] = 0.  `first`: also clear the overflow bookkeeping.
 __global__ void __launch_bounds__(256) filter_prepare_kernel(const float* __restrict__ prev_scores, int64_t B, int k,
+                                                             const float* __restrict__ eq,
+                                                             const unsigned* __restrict__ max_kerr2,
                                                              float* __restrict__ thr, int* __restrict__ count,
                                                              int* __restrict__ overflow, unsigned char* __restrict__ flag,
                                                              int first, int ablate) {
   const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (first && q == 0) *overflow = 0;
   if (q >= B) return;
-  thr[q] = ablate ? __builtin_huge_valf() : __fsub_rn(prev_scores[q * k + k - 1], FILTER_EPS);
+  const float ek = sqrtf(__uint_as_float(*max_kerr2));
+  const float e = eq[q];
+  const float eps = fmaf(fmaf(e, ek, e + ek), 1.0009765625f, FILTER_EPS_SLACK);  // rounding direction is inside the factor
+  thr[q] = ablate ? __builtin_huge_valf() : __fsub_rn(prev_scores[q * k + k - 1], eps);
   count[q] = 0;
   if (first) flag[q] = 0;
 }
@@ -528,19 +567,27 @@ static int filter_level_ends(int64_t N, int64_t ends[FILTER_MAX_LEVELS]) {
   return n;
 }
 
+static int64_t filter_padded_rows(int64_t N) { return (N + 127) / 128 * 128; }
+
 extern "C" int ragraph_keys_to_bf16(const float* Kn, int64_t N, int D, uint16_t* Kb, void* stream) {
   RG_REQUIRE(Kn && Kb, RAGRAPH_EINVAL, "keys_to_bf16: null pointer");
   RG_REQUIRE(N >= 1, RAGRAPH_EINVAL, "keys_to_bf16: N=%lld must be >= 1", (long long)N);
   RG_REQUIRE(D == 256, RAGRAPH_EUNSUPPORTED, "keys_to_bf16: D=%d (only 256)", D);
   RG_REQUIRE(aligned16(Kn) && aligned16(Kb), RAGRAPH_EINVAL, "keys_to_bf16: pointers must be 16-B aligned");
-  const int64_t npad = ragraph_keys_bf16_rows(N);
+  const int64_t npad = filter_padded_rows(N);
+  unsigned* tail = reinterpret_cast<unsigned*>(Kb + npad * D);  // the extra row: max_k |dk|^2 as float bits
+  if (hipMemsetAsync(tail, 0, (size_t)D * sizeof(uint16_t), as_stream(stream)) != hipSuccess) {
+    set_error("keys_to_bf16: memset failed");
+    return RAGRAPH_EDEVICE;
+  }
   hipLaunchKernelGGL(keys_to_bf16_kernel, dim3((unsigned)cdiv(npad * 32, 256)), dim3(256), 0, as_stream(stream), Kn, N,
-                     npad, Kb);
+                     npad, Kb, tail);
   RG_CHECK_LAUNCH("keys_to_bf16");
   return RAGRAPH_OK;
 }
 
-extern "C" int64_t ragraph_keys_bf16_rows(int64_t N) { return N < 1 ? 0 : (N + 127) / 128 * 128; }  // whole stages
+// bank rows padded to whole ring stages + one row that carries the bank's largest rounding error
+extern "C" int64_t ragraph_keys_bf16_rows(int64_t N) { return N < 1 ? 0 : filter_padded_rows(N) + 1; }
 
 extern "C" int ragraph_topk_cosine_filtered_cap(int k) { return 2048; }
 
@@ -548,7 +595,7 @@ extern "C" size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_
   if (B < 1 || N < 1 || k < 1 || D != 256) return 0;
   const int cap = ragraph_topk_cosine_filtered_cap(k);
   return ragraph_topk_cosine_workspace_bytes(B, filter_level0_keys(N), D, k) + align_up((size_t)B * D * sizeof(float), 256) +
-         align_up((size_t)B * sizeof(float), 256) + align_up((size_t)B * sizeof(int), 256) + align_up((size_t)B, 256) +
+         2 * align_up((size_t)B * sizeof(float), 256) + align_up((size_t)B * sizeof(int), 256) + align_up((size_t)B, 256) +
          align_up((size_t)B * cap * sizeof(int), 256);
 }
 
@@ -556,14 +603,15 @@ extern "C" size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_
 // (+ merge with out_* when `merge`).
 static int run_filter_level(const float* Qn, const float* Kn, const uint16_t* Kb, int64_t B, int64_t key0, int64_t key1,
                             int k, int64_t idx_base, int first, int merge, int final_level, float* out_scores,
-                            int64_t* out_idx, int* overflow, int64_t* overflow_idx, float* thr, int* count,
-                            unsigned char* flag, int* cand, int cap, int level, hipStream_t st) {
+                            int64_t* out_idx, int* overflow, int64_t* overflow_idx, float* thr, const float* eq,
+                            const unsigned* max_kerr2, int* count, unsigned char* flag, int* cand, int cap, int level,
+                            hipStream_t st) {
   static const int ablate = [] {  // RAGRAPH_FILTER_ABLATE=1: no key passes the filter (timing only, results invalid)
     const char* e = getenv("RAGRAPH_FILTER_ABLATE");
     return e ? atoi(e) : 0;
   }();
-  hipLaunchKernelGGL(filter_prepare_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, out_scores, B, k, thr, count,
-                     overflow, flag, first, ablate);
+  hipLaunchKernelGGL(filter_prepare_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, out_scores, B, k, eq, max_kerr2,
+                     thr, count, overflow, flag, first, ablate);
   RG_CHECK_LAUNCH("topk_cosine_filtered(prepare)");
   if (hipMemsetAsync(cand, 0xFF, (size_t)B * cap * sizeof(int), st) != hipSuccess) {  // every slot = -1 (unused)
     set_error("topk_cosine_filtered: memset failed");
@@ -683,7 +731,9 @@ extern "C" int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const
   const size_t sample_ws = ragraph_topk_cosine_workspace_bytes(B, filter_level0_keys(N), D, k);
   float* Qn = reinterpret_cast<float*>(w + sample_ws);
   float* thr = reinterpret_cast<float*>(reinterpret_cast<char*>(Qn) + align_up((size_t)B * D * sizeof(float), 256));
-  int* count = reinterpret_cast<int*>(reinterpret_cast<char*>(thr) + align_up((size_t)B * sizeof(float), 256));
+  float* eq = reinterpret_cast<float*>(reinterpret_cast<char*>(thr) + align_up((size_t)B * sizeof(float), 256));
+  int* count = reinterpret_cast<int*>(reinterpret_cast<char*>(eq) + align_up((size_t)B * sizeof(float), 256));
+  const unsigned* max_kerr2 = reinterpret_cast<const unsigned*>(Kb + filter_padded_rows(N) * D);
   unsigned char* flag = reinterpret_cast<unsigned char*>(count) + align_up((size_t)B * sizeof(int), 256);
   int* cand = reinterpret_cast<int*>(flag + align_up((size_t)B, 256));
 
@@ -692,10 +742,12 @@ extern "C" int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const
   if (rc != RAGRAPH_OK) return rc;
   rc = ragraph_normalize_rows_f32(Q, B, D, Qn, stream);
   if (rc != RAGRAPH_OK) return rc;
+  hipLaunchKernelGGL(filter_query_err_kernel, dim3((unsigned)cdiv(B * 32, 256)), dim3(256), 0, st, Qn, B, eq);
+  RG_CHECK_LAUNCH("topk_cosine_filtered(query error)");
   int64_t key0 = 0;
   for (int l = 0; l < nlev; ++l) {  // the first level re-reads [0, n0): its keys pass the bound and need no merge
     rc = run_filter_level(Qn, Kn, Kb, B, key0, ends[l], k, idx_base, l == 0, l > 0, l == nlev - 1, out_scores, out_idx,
-                          overflow, overflow_idx, thr, count, flag, cand, cap, l, st);
+                          overflow, overflow_idx, thr, eq, max_kerr2, count, flag, cand, cap, l, st);
     if (rc != RAGRAPH_OK) return rc;
     key0 = ends[l];
   }

@@ -121,7 +121,7 @@ def topk_cosine(q: torch.Tensor, keys_normalized: torch.Tensor, k: int, idx_base
 
 
 def keys_to_bf16(keys_normalized: torch.Tensor) -> torch.Tensor:
-    """bf16 copy of the bank for topk_cosine_filtered (rows padded with zeros to a multiple of 128; int16 storage)."""
+    """bf16 copy of the bank for topk_cosine_filtered (rows zero-padded to a multiple of 128 + one row holding the largest rounding error; int16 storage)."""
     L = _ready()
     kn = _f32c(keys_normalized, "keys_to_bf16.keys")
     rows = L.ragraph_keys_bf16_rows(kn.shape[0])

@@ -367,7 +367,7 @@ def test_topk_cosine_filtered_bit_exact(dev, B, N, k):
     q = rng.standard_normal((B, 256), dtype=np.float32)
     knd = _t(kn, dev)
     kb = K.keys_to_bf16(knd)
-    assert kb.shape[0] % 128 == 0 and kb.shape[0] >= N
+    assert (kb.shape[0] - 1) % 128 == 0 and kb.shape[0] > N  # padded to whole stages + one row with the bank's max rounding error
     s, i, over = K.topk_cosine_filtered(_t(q, dev), knd, kb, k, idx_base=9)
     assert over == 0
     rs, ri = cref.topk_cosine(q, kn, k, idx_base=9)
