@@ -390,10 +390,78 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
   }
 }
 
-// One wave per query: exact scores of its candidates (one lane per candidate, the k = 0..255 fmaf chain from +0), merged
-// with the previous level's exact top-k (prev_*: local indices, may alias out_*), and the canonical top-k of them.
-// CPL = candidates per lane (cap <= 64 * CPL).  A query whose list overflowed (now or at an earlier level: flag) is
-// appended to overflow_idx by the final level.
+// Rescoring of one query by one wave with NS candidate slots per lane (n <= 64 * NS reserved slots): exact scores (one
+// lane per candidate, the k = 0..255 fmaf chain from +0), merge with the previous level's winners, canonical top-k.
+template <int NS>
+__device__ __forceinline__ void rescore_query(const float4* __restrict__ qrow, const float* __restrict__ Kn,
+                                              const int* __restrict__ cand, int n, int lane, int k, int64_t base,
+                                              const float* prev_s, const int64_t* prev_i, float* out_s, int64_t* out_i) {
+  constexpr int D = 256;
+  float s[NS + 1];
+  int64_t id[NS + 1];
+  // the previous level's winners ride along as already-scored candidates (lane l holds entry l; k <= 32)
+  s[NS] = RG_NEG_INF;
+  id[NS] = INT64_MAX;
+  if (prev_s && lane < k) {
+    s[NS] = prev_s[lane];
+    id[NS] = prev_i[lane];
+  }
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    const int c = lane + 64 * u;
+    s[u] = RG_NEG_INF;
+    id[u] = INT64_MAX;
+    const int key = c < n ? cand[c] : -1;
+    if (key >= 0) {
+      const float4* kr = reinterpret_cast<const float4*>(Kn + (int64_t)key * D);
+      float acc = 0.f;
+#pragma unroll 8
+      for (int d4 = 0; d4 < D / 4; ++d4) {
+        const float4 kv = kr[d4], qv = qrow[d4];
+        acc = fmaf(qv.x, kv.x, acc);
+        acc = fmaf(qv.y, kv.y, acc);
+        acc = fmaf(qv.z, kv.z, acc);
+        acc = fmaf(qv.w, kv.w, acc);
+      }
+      s[u] = acc;
+      id[u] = key;
+    }
+  }
+  float prev_sc = __builtin_huge_valf();
+  int64_t prev_id = -1;  // everything is worse than (+inf, -1)
+  for (int r = 0; r < k; ++r) {
+    float best_s = RG_NEG_INF;
+    int64_t best_i = INT64_MAX;
+#pragma unroll
+    for (int u = 0; u <= NS; ++u) {
+      const bool after_prev = (s[u] < prev_sc) || (s[u] == prev_sc && id[u] > prev_id);
+      const bool beats = (s[u] > best_s) || (s[u] == best_s && id[u] < best_i);
+      if (after_prev && beats) {
+        best_s = s[u];
+        best_i = id[u];
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float os = __shfl_xor(best_s, off);
+      const int64_t oi = __shfl_xor(best_i, off);
+      if ((os > best_s) || (os == best_s && oi < best_i)) {
+        best_s = os;
+        best_i = oi;
+      }
+    }
+    if (lane == 0) {
+      out_s[r] = best_s;
+      out_i[r] = best_i == INT64_MAX ? INT64_MAX : best_i + base;
+    }
+    prev_sc = best_s;
+    prev_id = best_i;
+  }
+}
+
+// One wave per query.  prev_* (the previous level's exact top-k, local indices) may alias out_*.  A query whose list
+// overflowed (now or at an earlier level: flag) is appended to overflow_idx by the final level.  Most queries hold far
+// fewer candidates than the capacity: the slot count is a wave-uniform choice among 1, 2, 4, 8 and CPL.
 template <int CPL>
 __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restrict__ Qn, const float* __restrict__ Kn,
                                                            const int* __restrict__ count, const int* __restrict__ cand,
@@ -425,69 +493,17 @@ __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restri
       flag[b] = 1;
     }
   }
-  float s[CPL + 1];
-  int64_t id[CPL + 1];
-  // the previous level's winners ride along as already-scored candidates (lane l holds entry l; k <= 32)
-  s[CPL] = RG_NEG_INF;
-  id[CPL] = INT64_MAX;
-  if (prev_s && lane < k) {
-    s[CPL] = prev_s[b * k + lane];
-    id[CPL] = prev_i[b * k + lane];
-  }
-#pragma unroll
-  for (int u = 0; u < CPL; ++u) {
-    const int c = lane + 64 * u;
-    s[u] = RG_NEG_INF;
-    id[u] = INT64_MAX;
-    if (64 * u >= n) continue;  // wave-uniform: most queries fill only the first few slots
-    const int key = c < n ? cand[b * cap + c] : -1;
-    if (key >= 0) {
-      const float4* kr = reinterpret_cast<const float4*>(Kn + (int64_t)key * D);
-      float acc = 0.f;
-#pragma unroll 8
-      for (int d4 = 0; d4 < D / 4; ++d4) {
-        const float4 kv = kr[d4], qv = qs[w][d4];
-        acc = fmaf(qv.x, kv.x, acc);
-        acc = fmaf(qv.y, kv.y, acc);
-        acc = fmaf(qv.z, kv.z, acc);
-        acc = fmaf(qv.w, kv.w, acc);
-      }
-      s[u] = acc;
-      id[u] = key;
-    }
-  }
   const int64_t base = final_level ? idx_base : 0;
-  float prev_sc = __builtin_huge_valf();
-  int64_t prev_id = -1;  // everything is worse than (+inf, -1)
-  for (int r = 0; r < k; ++r) {
-    float best_s = RG_NEG_INF;
-    int64_t best_i = INT64_MAX;
-#pragma unroll
-    for (int u = 0; u <= CPL; ++u) {
-      if (u < CPL && 64 * u >= n) continue;  // empty slots (wave-uniform)
-      const bool after_prev = (s[u] < prev_sc) || (s[u] == prev_sc && id[u] > prev_id);
-      const bool beats = (s[u] > best_s) || (s[u] == best_s && id[u] < best_i);
-      if (after_prev && beats) {
-        best_s = s[u];
-        best_i = id[u];
-      }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const float os = __shfl_xor(best_s, off);
-      const int64_t oi = __shfl_xor(best_i, off);
-      if ((os > best_s) || (os == best_s && oi < best_i)) {
-        best_s = os;
-        best_i = oi;
-      }
-    }
-    if (lane == 0) {
-      out_s[b * k + r] = best_s;
-      out_i[b * k + r] = best_i == INT64_MAX ? INT64_MAX : best_i + base;
-    }
-    prev_sc = best_s;
-    prev_id = best_i;
-  }
+  const float* ps = prev_s ? prev_s + b * k : nullptr;
+  const int64_t* pi = prev_i ? prev_i + b * k : nullptr;
+  const int* cb = cand + b * cap;
+#define RG_RESCORE(NS_) rescore_query<NS_>(qs[w], Kn, cb, n, lane, k, base, ps, pi, out_s + b * k, out_i + b * k)
+  if (n <= 64) RG_RESCORE(1);
+  else if (n <= 128) RG_RESCORE(2);
+  else if (n <= 256) RG_RESCORE(4);
+  else if (n <= 512) RG_RESCORE(8);
+  else RG_RESCORE(CPL);
+#undef RG_RESCORE
 }
 
 static int filter_device_cus() {
