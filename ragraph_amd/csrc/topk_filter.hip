@@ -102,7 +102,10 @@ __global__ void __launch_bounds__(256) keys_to_bf16_kernel(const float* __restri
   // floats order like their bit patterns)
 #pragma unroll
   for (int off = 16; off >= 1; off >>= 1) e2 += __shfl_xor(e2, off);
-  if ((threadIdx.x & 31) == 0 && e2 > 0.f) atomicMax(max_err2, __float_as_uint(e2));
+  // (a plain read first: after the first few rows almost none beats the running maximum, so almost none pays for the
+  // atomic on this one address)
+  if ((threadIdx.x & 31) == 0 && __float_as_uint(e2) > __hip_atomic_load(max_err2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(max_err2, __float_as_uint(e2));
 }
 
 // |dq| per query: q - bf16(q) over the normalised row (one half-wave per query).
