@@ -394,3 +394,23 @@ def test_topk_cosine_filtered_overflow_falls_back(dev):
     rs, ri = cref.topk_cosine(q, kn, 10)
     assert np.array_equal(i.cpu().numpy(), ri)
     assert np.array_equal(s.cpu().numpy(), rs)
+
+
+def test_key_index_dispatch_same_bits(dev, monkeypatch):
+    """KeyIndex picks the kernel by shape (streaming, tile + packed copy, bf16-filtered): every choice returns the bits
+    of the oracle, and RAGRAPH_EXACT_FP32=1 keeps a call on the fp32 kernels."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(99)
+    kn = _bank(rng, 70000, 256)
+    knd = _t(kn, dev)
+    index = K.KeyIndex(knd)
+    for B in (3, 200, 800):  # 800 x 70000 pairs: filtered; 200: tile kernel with the packed copy; 3: streaming kernel
+        q = rng.standard_normal((B, 256), dtype=np.float32)
+        assert K.filter_helps(B, 70000, 256, 10) == (B == 800)
+        s, i = index.topk(_t(q, dev), 10, idx_base=4)
+        rs, ri = cref.topk_cosine(q, kn, 10, idx_base=4)
+        assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs)
+    assert index._bf16 is not None and index._packed is not None
+    monkeypatch.setenv("RAGRAPH_EXACT_FP32", "1")
+    assert not K.filter_helps(800, 70000, 256, 10)
