@@ -240,7 +240,8 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     float thr0 = q_lo < p.B ? p.thr[q_lo] : __builtin_huge_valf();
     float thr1 = q_hi < p.B ? p.thr[q_hi] : __builtin_huge_valf();
     // Candidate slots are reserved p.chunk at a time (one returning atomic per chunk of a lane's candidates; the candidate
-    // itself is a plain store); unused slots of a chunk keep the buffer's -1 fill and are skipped by the rescoring.
+    // itself is a plain store); the unused slots of a segment's last chunk are set to -1 when the segment ends and are
+    // skipped by the rescoring.
     const int CHUNK = p.chunk;
     int base0 = 0, used0 = CHUNK, base1 = 0, used1 = CHUNK;
     // hipcc does not know about the asm DMA loads, and any vmcnt(0) it emits inside the stage loop (for a global load it
@@ -389,6 +390,12 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     if (lane == 0)
       for (int i = 0; i < 6; ++i) atomicAdd(&g_filter_timing[i], tw[i]);
 #endif
+    // close the segment's open chunks: the slots a lane reserved and did not fill are marked unused (-1), so the
+    // candidate buffer needs no clearing between calls
+    for (int u = used0; u < CHUNK; ++u)
+      if (base0 + u < p.cap) p.cand[q_lo * p.cap + base0 + u] = -1;
+    for (int u = used1; u < CHUNK; ++u)
+      if (base1 + u < p.cap) p.cand[q_hi * p.cap + base1 + u] = -1;
     __syncthreads();  // flags are re-initialised by the next segment
   }
 }
@@ -632,10 +639,6 @@ static int run_filter_level(const float* Qn, const float* Kn, const uint16_t* Kb
   hipLaunchKernelGGL(filter_prepare_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, out_scores, B, k, eq, max_kerr2,
                      thr, count, overflow, flag, first, ablate);
   RG_CHECK_LAUNCH("topk_cosine_filtered(prepare)");
-  if (hipMemsetAsync(cand, 0xFF, (size_t)B * cap * sizeof(int), st) != hipSuccess) {  // every slot = -1 (unused)
-    set_error("topk_cosine_filtered: memset failed");
-    return RAGRAPH_EDEVICE;
-  }
   FilterParams p;
   p.Qn = Qn;
   p.Kb = Kb;
