@@ -440,3 +440,43 @@ def test_topk_cosine_filtered_fuzz_against_oracle(dev):
         rs, ri = cref.topk_cosine(q, kn, k, idx_base=base)
         assert np.array_equal(i.cpu().numpy(), ri), f"indices differ: B={B} N={N} k={k} (overflowed {over})"
         assert np.array_equal(s.cpu().numpy(), rs), f"scores differ: B={B} N={N} k={k}"
+
+
+def test_topk_cosine_filtered_adversarial_rounding(dev):
+    """Inputs built to make the bf16 rounding errors of a query and its best key ALIGN (half of the elements sit just
+    below a rounding midpoint, so bf16 rounds them all down): the winner's approximate score drops by ~0.4 % while the
+    exact threshold, set by near-duplicates in the first level, stays ~0.05 % below it.  The filter's bound must keep
+    the winner; the result must still be the oracle's bits."""
+    from ragraph_amd import kernels as K
+
+    rng = np.random.default_rng(31337)
+    N, D, k, nq = 70000, 256, 5, 64
+    keys = rng.standard_normal((N, D)).astype(np.float32)
+    keys /= np.linalg.norm(keys, axis=1, keepdims=True)
+    qs = []
+    for j in range(nq):
+        pick = rng.permutation(D) < D // 2
+        sign = rng.choice([-1.0, 1.0], D)
+        a = 2.0 ** -4 * (1 + 2.0 ** -8 * 0.97)                 # rounds DOWN to 2^-4 in bf16 (0.97 of half an ulp)
+        b = np.sqrt((1.0 - (D // 2) * a * a) / (D - D // 2))  # unit norm
+        v = (np.where(pick, a, b) * sign).astype(np.float32)
+        qs.append(v)
+        keys[N - 1 - j] = v                                    # the true best key, met in the LAST filter level
+        for d in range(8):                                     # near-duplicates in the first 4096 rows set the bound
+            noise = rng.standard_normal(D).astype(np.float32)
+            w = v + (0.02 + 0.004 * d) * noise / np.linalg.norm(noise)
+            keys[j * 8 + d] = w / np.linalg.norm(w)
+    q = np.stack(qs).astype(np.float32)
+    kn = cref.normalize_rows(keys)
+    knd = _t(kn, dev)
+    s, i, over = K.topk_cosine_filtered(_t(q, dev), knd, K.keys_to_bf16(knd), k)
+    rs, ri = cref.topk_cosine(q, kn, k)
+    assert np.array_equal(ri[:, 0], N - 1 - np.arange(nq))     # the construction: each query's best key is its twin
+    # how much the bf16 score of the twin is off (the thing the bound has to cover)
+    import torch
+    qn = cref.normalize_rows(q)
+    qb = torch.from_numpy(qn).to(torch.bfloat16).float().numpy()
+    kb = torch.from_numpy(kn[ri[:, 0]]).to(torch.bfloat16).float().numpy()
+    drop = rs[:, 0] - (qb * kb).sum(1)
+    assert drop.min() > 0.002, drop.min()                      # aligned errors: an order of magnitude above random
+    assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs)
