@@ -100,7 +100,7 @@ int ragraph_topk_cosine_bank_f32(const float* Q, int64_t B, const float* Kn, con
  *   rows (<= 2^-7, typically 0.003): by Cauchy-Schwarz no pair's dot product moves by more; (3) the survivors (~100 per query) are
  *   rescored with the natural-order fp32 fmaf chain and selected in canonical order, which gives the exact top-k of
  *   everything seen so far and a tighter bound for the next level ([0,N/32), [N/32,N/4), [N/4,N)).  The result has the
- *   same bits as ragraph_topk_cosine_f32.  D = 256, k <= 32.
+ *   same bits as ragraph_topk_cosine_f32.  D in {64,128,256}, k <= 32.
  *   Kb   bf16 copy of Kn made by ragraph_keys_to_bf16 (ragraph_keys_bf16_rows(N) rows x D, uint16 storage).
  *   Kp   optional packed fp32 copy (ragraph_pack_keys_f32) for the fp32 level, or NULL.
  *   overflow  device int, set by the call: number of queries whose candidate list exceeded its capacity

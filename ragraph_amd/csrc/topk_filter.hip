@@ -1,29 +1,30 @@
-// Exact cosine top-k through a bf16 MFMA filter  (SimilarityFunctions.py:6-16 + ToyGraphBase.py:66-67, large batches).
+// Exact cosine top-k through a bf16 MFMA filter  (SimilarityFunctions.py:6-16 + ToyGraphBase.py:66-67, large batches;
+// D = 64 is the edge flavour's RAGraph_edge/modules/RAGraph.py:298-324).
 //
 // The fp32 tile kernel (topk_cosine.hip) spends 2·B·N·D fp32 MFMA flops; the bf16 matrix cores are 16x faster.  This
 // path returns the SAME bits with most of the work on them:
-//   1. sample pass (exact, fp32 kernel): top-k of every query over the first Ns keys.  Its k-th score theta[q] is a
+//   1. level 0 (exact, fp32 kernel): top-k of every query over the first N/256 keys.  Its k-th score theta[q] is a
 //      lower bound of the final k-th best exact score of q.
-//   2. filter pass (this file, bf16 MFMA over the whole bank): approximate scores s~ = bf16(q)·bf16(key), fp32
-//      accumulate.  With q^ = q + dq, k^ = k + dk: |s~ - s| <= |dq||k| + |q||dk| + |dq||dk| + accumulation error
+//   2. filter (this file, bf16 MFMA): approximate scores s~ = bf16(q)·bf16(key), fp32 accumulate, over the next, larger
+//      part of the bank.  With q^ = q + dq, k^ = k + dk: |s~ - s| <= |dq||k| + |q||dk| + |dq||dk| + accumulation error
 //      (Cauchy-Schwarz) <= eps(q), computed from the query's actual |dq| and the bank's largest |dk| (<= 2^-7 in the worst
-//      case, ~0.003 typically) -- a bound for EVERY pair.  A key of the
-//      exact top-k has s >= theta[q], hence s~ >= theta[q] - eps(q): every key that passes goes to the query's candidate
-//      list (global append).  Nothing else can be in the result.
-//   3. rescoring pass: the exact score of every candidate as the fp32 fmaf chain in natural k order from +0 (one lane
-//      per candidate) -- the same chain the f32 MFMA and the oracle compute, so the same bits -- and the canonical
-//      top-k (score descending, index ascending) of the candidates.
-// A query whose candidate list overflows its capacity (adversarial banks: thousands of keys within EPS of the k-th
+//      case, ~0.003 typically) -- a bound for EVERY pair.  A key of the exact top-k has s >= theta[q], hence
+//      s~ >= theta[q] - eps(q): every key that passes goes to the query's candidate list; nothing else can be in the result.
+//   3. rescoring: the exact score of every candidate as the fp32 fmaf chain in natural k order from +0 (one lane per
+//      candidate) -- the chain the f32 MFMA and the oracle compute, so the same bits -- merged with the previous level's
+//      winners, canonical top-k (score descending, index ascending).  That is the exact top-k of everything seen so far
+//      and a tighter theta for the next level: [0, N/32), [N/32, N/4), [N/4, N).
+// A query whose candidate list overflows its capacity (adversarial banks: thousands of keys within eps of the k-th
 // best) is counted in *overflow and must be re-run through ragraph_topk_cosine_bank_f32 by the caller; the other
 // queries' results are exact regardless.
 //
 // Filter kernel: workgroup = 8 waves x 64 queries = 512 queries; a wave keeps its queries as the B operands of
-// v_mfma_f32_32x32x16_bf16 (two groups of 32: 2 x 64 VGPRs) and streams the bf16 bank (512 B per key) through an
-// 8-slot LDS ring of 16 KiB stages (32 keys) filled by LDS-DMA, two rows per global_load_lds_dwordx4, handed over by
-// FULL/FREE counters.  One ds_read_b128 (8 bf16 of one key row) feeds two MFMAs (one per query group).  The LDS image is
-// XOR-swizzled through the DMA's per-lane SOURCE address (16-B chunk c of row j sits at chunk c ^ (j & 15)), which
-// makes the ds_read_b128 of the 32 rows conflict-free without padding.  Work plan: segment_plan.h with zero warm-up
-// cost (there are no lists): every workgroup gets the same number of stages.
+// v_mfma_f32_32x32x16_bf16 (two groups of 32: 2 x D/4 VGPRs) and streams the bf16 bank (2 D bytes per key) through a
+// 4-slot LDS ring of 32 KiB stages (64 / 128 / 256 keys at D = 256 / 128 / 64) filled by LDS-DMA, 1 KiB per
+// global_load_lds_dwordx4, handed over by FULL/FREE counters.  One ds_read_b128 (8 bf16 of one key row) feeds two MFMAs
+// (one per query group).  The LDS image is XOR-swizzled through the DMA's per-lane SOURCE address (16-B chunk c of row j
+// sits at chunk c ^ f(j)), which makes the ds_read_b128 of 32 rows conflict-free without padding.  Work plan:
+// segment_plan.h with zero warm-up cost (there are no lists): every workgroup gets the same number of stages.
 #include "common.h"
 #include "segment_plan.h"
 
@@ -42,24 +43,36 @@ typedef __attribute__((address_space(3))) void lds_void_f;
 // the worst case 2^-7.
 constexpr float FILTER_EPS_SLACK = 0.000244140625f;  // 2^-12
 
-template <int SUBS>  // 32-key MFMA sub-tiles per ring stage: the ring hand-over (flags, DMA issue) is paid once per stage
+constexpr int FILTER_STAGE_BYTES = 32 * 1024;  // one ring slot
+constexpr int FILTER_PAD_KEYS = 256;           // bank rows are padded to whole stages of any D (256 keys at D = 64)
+
+template <int D_>
 struct FilterCfg {
-  static constexpr int D = 256;
+  static constexpr int D = D_;
   static constexpr int WAVES = 8, THREADS = 512;
-  static constexpr int QT = 512;                 // queries per workgroup
-  static constexpr int STAGE_KEYS = 32 * SUBS;
-  static constexpr int ROW_BYTES = D * 2;        // one bf16 key
-  static constexpr int STAGE_BYTES = STAGE_KEYS * ROW_BYTES;  // 16 KiB per sub-tile
-  static constexpr int SLOTS = 8 / SUBS;         // 128 KiB of ring; the hand-over protocol needs >= 3 slots
-  static constexpr int PAIRS = 2 * SUBS;         // row pairs (1 KiB DMA instructions) per wave and stage
+  static constexpr int QT = 512;                          // queries per workgroup
+  static constexpr int ROW_BYTES = D * 2;                 // one bf16 key
+  static constexpr int CR = D / 8;                        // 16-B chunks per row
+  static constexpr int KSTEPS = D / 16;                   // MFMA k-steps per 32-key sub-tile
+  static constexpr int STAGE_BYTES = FILTER_STAGE_BYTES;
+  static constexpr int STAGE_KEYS = STAGE_BYTES / ROW_BYTES;  // 64 / 128 / 256
+  static constexpr int SUBS = STAGE_KEYS / 32;            // 32-key MFMA sub-tiles per stage: 2 / 4 / 8
+  static constexpr int NSTEP = SUBS * KSTEPS;             // = 32 MFMA steps (x 2 query groups) per stage for every D
+  static constexpr int SLOTS = 4;                         // 128 KiB of ring; the hand-over protocol needs >= 3 slots
+  static constexpr int DMAS = STAGE_BYTES / 1024 / WAVES; // 1 KiB DMA instructions per wave and stage = 4
+  static constexpr int RPI = 1024 / ROW_BYTES;            // key rows per DMA instruction: 2 / 4 / 8
   static constexpr size_t LDS_BYTES = (size_t)SLOTS * STAGE_BYTES + 64;
+  // swizzle f(row): rows that share a 256-B LDS bank row (16 chunks) must differ, and so must the 16 rows of a
+  // ds_read_b128 lane group
+  __host__ __device__ static constexpr int swz(int row) { return CR >= 16 ? (row & 15) : ((row / (16 / CR)) & (CR - 1)); }
 };
+static_assert(FilterCfg<256>::NSTEP == 32 && FilterCfg<128>::NSTEP == 32 && FilterCfg<64>::NSTEP == 32, "32 steps per stage");
 
 struct FilterParams {
-  const float* Qn;        // [B,256] normalised queries (fp32)
-  const uint16_t* Kb;     // [round_up(N,128),256] bf16 keys, rows >= N zero
-  const float* thr;       // [B] theta[q] - EPS
-  int* count;             // [B] candidates appended so far
+  const float* Qn;        // [B,D] normalised queries (fp32)
+  const uint16_t* Kb;     // [round_up(N,256),D] bf16 keys, rows >= N zero
+  const float* thr;       // [B] theta[q] - eps(q)
+  int* count;             // [B] candidate slots reserved so far
   int* cand;              // [B,cap] candidate key indices (local to this shard)
   int64_t B, N;           // N = end of the key range (keys >= N never pass)
   int cap;
@@ -77,14 +90,17 @@ __device__ __forceinline__ void fring_signal(unsigned* ctr, int lane) {
   if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// Rows [N, round_up(N,128)) of Kb are zero so the stream never needs a tail clamp (a ring stage is <= 128 keys).
+// fp32 -> bf16 (round to nearest even) of the bank, rows [N, Npad) zero so the stream never needs a tail clamp, and
+// max_k |dk|^2 of the bank (see FILTER_EPS_SLACK) by an integer max: non-negative floats order like their bit patterns.
+template <int D>
 __global__ void __launch_bounds__(256) keys_to_bf16_kernel(const float* __restrict__ Kn, int64_t N, int64_t Npad,
                                                            uint16_t* __restrict__ Kb, unsigned* __restrict__ max_err2) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread = 8 elements; 32 threads = one row
-  const int64_t row = i >> 5;
+  constexpr int TPR = D / 8;  // threads per row (one thread = 8 elements): 8 / 16 / 32, inside one half-wave
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = i / TPR;
   bf16x8 o;
   float e2 = 0.f;
-  if (i < Npad * 32 && row < N) {
+  if (i < Npad * TPR && row < N) {
     const float4 a = reinterpret_cast<const float4*>(Kn)[2 * i], b = reinterpret_cast<const float4*>(Kn)[2 * i + 1];
     const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
@@ -97,22 +113,23 @@ __global__ void __launch_bounds__(256) keys_to_bf16_kernel(const float* __restri
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (__bf16)0.f;
   }
-  if (i < Npad * 32) reinterpret_cast<bf16x8*>(Kb)[i] = o;
-  // |dk|^2 of the row = sum over its 32 threads (one half-wave); the bank's maximum by an integer max (non-negative
-  // floats order like their bit patterns)
+  if (i < Npad * TPR) reinterpret_cast<bf16x8*>(Kb)[i] = o;
 #pragma unroll
-  for (int off = 16; off >= 1; off >>= 1) e2 += __shfl_xor(e2, off);
+  for (int off = TPR / 2; off >= 1; off >>= 1) e2 += __shfl_xor(e2, off);
   // (a plain read first: after the first few rows almost none beats the running maximum, so almost none pays for the
   // atomic on this one address)
-  if ((threadIdx.x & 31) == 0 && __float_as_uint(e2) > __hip_atomic_load(max_err2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+  if ((threadIdx.x & (TPR - 1)) == 0 &&
+      __float_as_uint(e2) > __hip_atomic_load(max_err2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
     atomicMax(max_err2, __float_as_uint(e2));
 }
 
-// |dq| per query: q - bf16(q) over the normalised row (one half-wave per query).
+// |dq| per query: q - bf16(q) over the normalised row (D/8 lanes per query).
+template <int D>
 __global__ void __launch_bounds__(256) filter_query_err_kernel(const float* __restrict__ Qn, int64_t B,
                                                                float* __restrict__ eq) {
+  constexpr int TPR = D / 8;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t q = i >> 5;
+  const int64_t q = i / TPR;
   float e2 = 0.f;
   if (q < B) {
     const float4 a = reinterpret_cast<const float4*>(Qn)[2 * i], b = reinterpret_cast<const float4*>(Qn)[2 * i + 1];
@@ -124,8 +141,8 @@ __global__ void __launch_bounds__(256) filter_query_err_kernel(const float* __re
     }
   }
 #pragma unroll
-  for (int off = 16; off >= 1; off >>= 1) e2 += __shfl_xor(e2, off);
-  if ((threadIdx.x & 31) == 0 && q < B) eq[q] = sqrtf(e2);
+  for (int off = TPR / 2; off >= 1; off >>= 1) e2 += __shfl_xor(e2, off);
+  if ((threadIdx.x & (TPR - 1)) == 0 && q < B) eq[q] = sqrtf(e2);
 }
 
 // thr[q] = (k-th exact score of the previous level) - eps(q); count[q] = 0.  `first`: also clear the overflow bookkeeping.
@@ -153,15 +170,12 @@ __device__ unsigned long long g_filter_timing[8];
 #define RG_FT(var_)
 #endif
 
-// BAR = true: one s_barrier per stage hands the ring over (every wave retires its own rows of stage s with a counted
-// vmcnt, the barrier then says both "stage s has landed" and "everybody is done with stage s-1", whose slot the next
-// DMA overwrites).  BAR = false: FULL / FREE counters (waves may drift a stage apart).
-template <int SUBS, bool BAR>
+template <int D>
 __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
-  using C = FilterCfg<SUBS>;
+  using C = FilterCfg<D>;
   extern __shared__ float4 fsmem4[];
   char* smem = reinterpret_cast<char*>(fsmem4);
-  unsigned* full = reinterpret_cast<unsigned*>(smem + C::SLOTS * C::STAGE_BYTES);  // [8] then freec [8]
+  unsigned* full = reinterpret_cast<unsigned*>(smem + C::SLOTS * C::STAGE_BYTES);  // [SLOTS] then freec [SLOTS]
   unsigned* freec = full + C::SLOTS;
   const unsigned lds_base = (unsigned)(size_t)(lds_void_f*)smem;
 
@@ -170,21 +184,21 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, g = lane >> 5;
 
-  // DMA source offsets of this lane for the wave's row pairs (pair i = rows 2i, 2i+1 of the wave's 2*PAIRS rows of a
-  // stage): LDS byte 16 l of a pair is row (l >> 5) of the pair at chunk position l & 31, which holds source chunk
-  // pos ^ (row & 15).
-  unsigned voff[C::PAIRS];
+  // DMA source offsets of this lane for the wave's DMAS instructions of a stage.  Instruction i of wave w fills LDS bytes
+  // [(DMAS w + i) KiB, + 1 KiB) of the slot = RPI consecutive rows; LDS byte 16 l of it is row l / CR of the instruction at
+  // chunk position l % CR, which holds source chunk pos ^ swz(row in stage).
+  unsigned voff[C::DMAS];
 #pragma unroll
-  for (int i = 0; i < C::PAIRS; ++i) {
-    const int row = 2 * C::PAIRS * wave + 2 * i + g;  // row inside the stage
-    voff[i] = (unsigned)(2 * i + g) * C::ROW_BYTES + (unsigned)((j ^ (row & 15)) * 16);
+  for (int i = 0; i < C::DMAS; ++i) {
+    const int rin = lane / C::CR, pos = lane % C::CR;
+    const int row = (C::DMAS * wave + i) * C::RPI + rin;  // row inside the stage
+    voff[i] = (unsigned)(i * 1024 + rin * C::ROW_BYTES + ((pos ^ C::swz(row)) << 4));
   }
   auto dma_stage = [&](int64_t stage_abs, int slot) {  // stage_abs: stage index over the whole bank
-    const char* gbase =
-        reinterpret_cast<const char*>(p.Kb) + (stage_abs * C::STAGE_KEYS + 2 * C::PAIRS * wave) * C::ROW_BYTES;
+    const char* gbase = reinterpret_cast<const char*>(p.Kb) + stage_abs * C::STAGE_BYTES + C::DMAS * wave * 1024;
 #pragma unroll
-    for (int i = 0; i < C::PAIRS; ++i) {
-      const unsigned dst = lds_base + (unsigned)(slot * C::STAGE_BYTES + (2 * C::PAIRS * wave + 2 * i) * C::ROW_BYTES);
+    for (int i = 0; i < C::DMAS; ++i) {
+      const unsigned dst = lds_base + (unsigned)(slot * C::STAGE_BYTES + (C::DMAS * wave + i) * 1024);
       unsigned keep;
       asm volatile(
           "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
@@ -193,14 +207,15 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
           : "memory");
     }
   };
-  // A fragment of lane (j, g) for k-step t: row j, source chunk c = 2t + g, stored at position c ^ (j & 15).  With
-  // c0 = g ^ (j & 15): position = (2t ^ c0) for t < 8 and (2(t-8) ^ c0) + 16 for t >= 8, so eight per-lane addresses
-  // plus the immediate offsets 256 B (t >= 8) and 16 KiB (next sub-tile) reach every fragment of a stage.
-  unsigned apos[8];
+  // A fragment of lane (j, g) for k-step t of a sub-tile: row j (swz depends only on j: sub-tiles start at multiples of
+  // 32 rows), source chunk c = 2t + g, stored at position c ^ swz(j) = 2t ^ c0 with c0 = g ^ swz(j).  Eight per-lane
+  // addresses (t & 7) plus immediate offsets (256 B for t >= 8 at D = 256; the sub-tile) reach every fragment of a stage.
+  constexpr int NA = C::KSTEPS < 8 ? C::KSTEPS : 8;
+  unsigned apos[NA];
   {
-    const unsigned c0 = (unsigned)(g ^ (j & 15));
+    const unsigned c0 = (unsigned)(g ^ C::swz(j));
 #pragma unroll
-    for (int i = 0; i < 8; ++i) apos[i] = lds_base + (unsigned)j * C::ROW_BYTES + (((unsigned)(2 * i) ^ c0) << 4);
+    for (int i = 0; i < NA; ++i) apos[i] = lds_base + (unsigned)j * C::ROW_BYTES + (((unsigned)(2 * i) ^ c0) << 4);
   }
 
   const int x = p.xcd_map ? (int)(blockIdx.x & 7) : 0;
@@ -216,12 +231,12 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     const int nstages = (int)(seg.st1 - seg.st0);
 
     // ---- B operands: queries q_lo / q_hi, k-step t = elements 16 t + 8 g .. + 7, converted to bf16 (RNE) ----------
-    bf16x8 b0[16], b1[16];
+    bf16x8 b0[C::KSTEPS], b1[C::KSTEPS];
     {
-      const float* r0 = p.Qn + (q_lo < p.B ? q_lo : p.B - 1) * C::D + 8 * g;
-      const float* r1 = p.Qn + (q_hi < p.B ? q_hi : p.B - 1) * C::D + 8 * g;
+      const float* r0 = p.Qn + (q_lo < p.B ? q_lo : p.B - 1) * D + 8 * g;
+      const float* r1 = p.Qn + (q_hi < p.B ? q_hi : p.B - 1) * D + 8 * g;
 #pragma unroll
-      for (int t0 = 0; t0 < 16; t0 += 4) {  // batches of 4 steps = 16 float4 in flight
+      for (int t0 = 0; t0 < C::KSTEPS; t0 += 4) {  // batches of 4 steps = 16 float4 in flight
 #pragma unroll
         for (int t = t0; t < t0 + 4; ++t) {
           const float4 u0 = *reinterpret_cast<const float4*>(r0 + 16 * t), u1 = *reinterpret_cast<const float4*>(r0 + 16 * t + 4);
@@ -251,16 +266,12 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
 
     // ---- ring prologue ------------------------------------------------------------------------------------------
     const int pro = nstages < C::SLOTS - 1 ? nstages : C::SLOTS - 1;
-    if constexpr (BAR) {
-      for (int s = 0; s < pro; ++s) dma_stage(p.stage_base + st0 + s, s);
-    } else {
-      if (tid < 2 * C::SLOTS) full[tid] = 0;
-      for (int s = 0; s < pro; ++s) dma_stage(p.stage_base + st0 + s, s);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid < pro) full[tid] = C::WAVES;
-      __syncthreads();
-    }
+    if (tid < 2 * C::SLOTS) full[tid] = 0;
+    for (int s = 0; s < pro; ++s) dma_stage(p.stage_base + st0 + s, s);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < pro) full[tid] = C::WAVES;
+    __syncthreads();
 
     int pending = -1;
 #ifdef RG_TOPK_TIMING
@@ -269,18 +280,24 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     for (int s = 0; s < nstages; ++s) {
       const int slot = s & (C::SLOTS - 1), gen = s / C::SLOTS;
       RG_FT(t0);
-      if constexpr (BAR) {
-        // my rows of stage s have landed once at most the (SLOTS-2)*PAIRS younger DMAs are outstanding (loads retire in
-        // order; younger stores only make the wait stricter); near the end fewer were issued: wait for everything
-        if (s + C::SLOTS - 2 < nstages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((C::SLOTS - 2) * C::PAIRS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (s + C::SLOTS - 1 < nstages) dma_stage(p.stage_base + st0 + s + C::SLOTS - 1, (s + C::SLOTS - 1) & (C::SLOTS - 1));
-      } else {
-        fring_wait(full + slot, (unsigned)(C::WAVES * (gen + 1)));
-      }
+      fring_wait(full + slot, (unsigned)(C::WAVES * (gen + 1)));
       RG_FT(t1);
       // epilogue of sub-tile u: acc[r] = approximate score of key row (r&3) + 8 (r>>2) + 4 g of the sub-tile
+      auto append = [&](const f32x16& a, float thr, int64_t q, int& base, int& used, int key_base) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key_base + (r & 3) + 8 * (r >> 2);
+          if (a[r] >= thr && key < (int)p.N) {
+            if (used == CHUNK) {
+              base = atomicAdd(p.count + q, CHUNK);
+              asm volatile("s_waitcnt vmcnt(0)" : "+v"(base) : : "memory");  // retired here, not at every later use
+              used = 0;
+            }
+            if (base + used < p.cap) p.cand[q * p.cap + base + used] = key;
+            ++used;
+          }
+        }
+      };
       auto epilogue = [&](int u, const f32x16& a0, const f32x16& a1) {
         float m0 = a0[0], m1 = a1[0];
 #pragma unroll
@@ -290,87 +307,66 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
         }
         if (__any(m0 >= thr0 || m1 >= thr1)) {
           const int key_base = (int)((p.stage_base + st0 + s) * C::STAGE_KEYS) + 32 * u + 4 * g;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = key_base + (r & 3) + 8 * (r >> 2);
-            if (a0[r] >= thr0 && key < (int)p.N) {
-              if (used0 == CHUNK) {
-                base0 = atomicAdd(p.count + q_lo, CHUNK);
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(base0) : : "memory");  // retired here, not at every later use
-                used0 = 0;
-              }
-              if (base0 + used0 < p.cap) p.cand[q_lo * p.cap + base0 + used0] = key;
-              ++used0;
-            }
-            if (a1[r] >= thr1 && key < (int)p.N) {
-              if (used1 == CHUNK) {
-                base1 = atomicAdd(p.count + q_hi, CHUNK);
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(base1) : : "memory");
-                used1 = 0;
-              }
-              if (base1 + used1 < p.cap) p.cand[q_hi * p.cap + base1 + used1] = key;
-              ++used1;
-            }
-          }
+          append(a0, thr0, q_lo, base0, used0, key_base);
+          append(a1, thr1, q_hi, base1, used1, key_base);
         }
       };
-      // ---- SUBS sub-tiles of 32 keys x 64 queries, 16 k-steps each; one A fragment per step feeds both query groups.
+      // ---- SUBS sub-tiles of 32 keys x 64 queries, KSTEPS k-steps each; one A fragment per step feeds both query groups.
       // A step is only 64 cycles of MFMA, less than an LDS round trip, so the fragment reads run FOUR steps ahead of
       // their MFMAs (hipcc's own schedule keeps one ahead and the matrix pipe idles half the time).  They are asm
       // loads, invisible to hipcc's waitcnt bookkeeping: RG_FWAIT counts them (LDS returns in order; anything else
       // outstanding only makes the wait stricter) and names the fragment so its MFMAs stay behind the wait.
-      unsigned addr[8];
+      unsigned addr[NA];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) addr[i] = apos[i] + (unsigned)(slot * C::STAGE_BYTES);
+      for (int i = 0; i < NA; ++i) addr[i] = apos[i] + (unsigned)(slot * C::STAGE_BYTES);
       f32x16 acc0, acc1;
       f32x4 fr[4];
 #define RG_FREAD(n_)                                                                                       \
   asm volatile("ds_read_b128 %0, %1 offset:%2"                                                             \
                : "=v"(fr[(n_)&3])                                                                           \
-               : "v"(addr[(n_)&7]), "i"(((n_) / 16) * 32 * C::ROW_BYTES + ((((n_) % 16) >= 8) ? 256 : 0)))
+               : "v"(addr[((n_) % C::KSTEPS) & 7]),                                                         \
+                 "i"(((n_) / C::KSTEPS) * 32 * C::ROW_BYTES + ((((n_) % C::KSTEPS) >= 8) ? 256 : 0)))
 #define RG_FWAIT(c_, n_) asm volatile("s_waitcnt lgkmcnt(" #c_ ")" : "+v"(fr[(n_)&3]))
 #define RG_FSTEP(n_)                                                                                       \
-  if constexpr ((n_) < 16 * SUBS) {                                                                        \
-    if constexpr ((n_) % 16 == 0) {                                                                        \
+  {                                                                                                        \
+    if constexpr ((n_) % C::KSTEPS == 0) {                                                                 \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;                               \
     }                                                                                                      \
-    if constexpr ((n_) + 3 < 16 * SUBS) RG_FWAIT(3, n_);                                                    \
-    else if constexpr ((n_) + 2 < 16 * SUBS) RG_FWAIT(2, n_);                                               \
-    else if constexpr ((n_) + 1 < 16 * SUBS) RG_FWAIT(1, n_);                                               \
+    if constexpr ((n_) + 3 < C::NSTEP) RG_FWAIT(3, n_);                                                     \
+    else if constexpr ((n_) + 2 < C::NSTEP) RG_FWAIT(2, n_);                                                \
+    else if constexpr ((n_) + 1 < C::NSTEP) RG_FWAIT(1, n_);                                                \
     else RG_FWAIT(0, n_);                                                                                   \
     {                                                                                                      \
       const bf16x8 a_ = __builtin_bit_cast(bf16x8, fr[(n_)&3]);                                             \
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b0[(n_) % 16], acc0, 0, 0, 0);                     \
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b1[(n_) % 16], acc1, 0, 0, 0);                     \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b0[(n_) % C::KSTEPS], acc0, 0, 0, 0);              \
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b1[(n_) % C::KSTEPS], acc1, 0, 0, 0);              \
     }                                                                                                      \
-    if constexpr ((n_) + 4 < 16 * SUBS) RG_FREAD((n_) + 4);                                                 \
-    if constexpr ((n_) % 16 == 15) epilogue((n_) / 16, acc0, acc1);                                         \
+    if constexpr ((n_) + 4 < C::NSTEP) RG_FREAD((n_) + 4);                                                  \
+    if constexpr ((n_) % C::KSTEPS == C::KSTEPS - 1) epilogue((n_) / C::KSTEPS, acc0, acc1);                \
   }
+#define RG_FSTEP8(n_) RG_FSTEP(n_) RG_FSTEP((n_) + 1) RG_FSTEP((n_) + 2) RG_FSTEP((n_) + 3) \
+    RG_FSTEP((n_) + 4) RG_FSTEP((n_) + 5) RG_FSTEP((n_) + 6) RG_FSTEP((n_) + 7)
       RG_FREAD(0);
       RG_FREAD(1);
       RG_FREAD(2);
       RG_FREAD(3);
-      RG_FSTEP(0) RG_FSTEP(1) RG_FSTEP(2) RG_FSTEP(3) RG_FSTEP(4) RG_FSTEP(5) RG_FSTEP(6) RG_FSTEP(7)
-      RG_FSTEP(8) RG_FSTEP(9) RG_FSTEP(10) RG_FSTEP(11) RG_FSTEP(12) RG_FSTEP(13) RG_FSTEP(14) RG_FSTEP(15)
-      RG_FSTEP(16) RG_FSTEP(17) RG_FSTEP(18) RG_FSTEP(19) RG_FSTEP(20) RG_FSTEP(21) RG_FSTEP(22) RG_FSTEP(23)
-      RG_FSTEP(24) RG_FSTEP(25) RG_FSTEP(26) RG_FSTEP(27) RG_FSTEP(28) RG_FSTEP(29) RG_FSTEP(30) RG_FSTEP(31)
+      RG_FSTEP8(0) RG_FSTEP8(8) RG_FSTEP8(16) RG_FSTEP8(24)
+#undef RG_FSTEP8
 #undef RG_FSTEP
 #undef RG_FWAIT
 #undef RG_FREAD
       RG_FT(t2);
-      if constexpr (!BAR) {
-        fring_signal(freec + slot, lane);
-        if (pending >= 0) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          fring_signal(full + pending, lane);
-          pending = -1;
-        }
+      fring_signal(freec + slot, lane);
+      if (pending >= 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        fring_signal(full + pending, lane);
+        pending = -1;
       }
       RG_FT(t3);
 #ifdef RG_TOPK_TIMING
       unsigned long long t4 = t3, t5 = t3;
 #endif
-      if (!BAR && s + C::SLOTS - 1 < nstages) {
+      if (s + C::SLOTS - 1 < nstages) {
         const int ws = (s + C::SLOTS - 1) & (C::SLOTS - 1);  // the slot stage s-1 lived in
         fring_wait(freec + ws, (unsigned)(C::WAVES * ((s + C::SLOTS - 1) / C::SLOTS)));
 #ifdef RG_TOPK_TIMING
@@ -401,12 +397,11 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
 }
 
 // Rescoring of one query by one wave with NS candidate slots per lane (n <= 64 * NS reserved slots): exact scores (one
-// lane per candidate, the k = 0..255 fmaf chain from +0), merge with the previous level's winners, canonical top-k.
-template <int NS>
+// lane per candidate, the k = 0..D-1 fmaf chain from +0), merge with the previous level's winners, canonical top-k.
+template <int D, int NS>
 __device__ __forceinline__ void rescore_query(const float4* __restrict__ qrow, const float* __restrict__ Kn,
                                               const int* __restrict__ cand, int n, int lane, int k, int64_t base,
                                               const float* prev_s, const int64_t* prev_i, float* out_s, int64_t* out_i) {
-  constexpr int D = 256;
   float s[NS + 1];
   int64_t id[NS + 1];
   // the previous level's winners ride along as already-scored candidates (lane l holds entry l; k <= 32)
@@ -472,7 +467,7 @@ __device__ __forceinline__ void rescore_query(const float4* __restrict__ qrow, c
 // One wave per query.  prev_* (the previous level's exact top-k, local indices) may alias out_*.  A query whose list
 // overflowed (now or at an earlier level: flag) is appended to overflow_idx by the final level.  Most queries hold far
 // fewer candidates than the capacity: the slot count is a wave-uniform choice among 1, 2, 4, 8 and CPL.
-template <int CPL>
+template <int D, int CPL>
 __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restrict__ Qn, const float* __restrict__ Kn,
                                                            const int* __restrict__ count, const int* __restrict__ cand,
                                                            int64_t B, int cap, int k, int64_t idx_base,
@@ -480,12 +475,11 @@ __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restri
                                                            float* out_s, int64_t* out_i, int* __restrict__ overflow,
                                                            int64_t* __restrict__ overflow_idx,
                                                            unsigned char* __restrict__ flag) {
-  constexpr int D = 256;
   __shared__ float4 qs[4][D / 4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t b = (int64_t)blockIdx.x * 4 + w;
   if (b >= B) return;  // whole wave
-  qs[w][lane] = reinterpret_cast<const float4*>(Qn + b * D)[lane];  // 64 lanes x float4 = the query row
+  if (lane < D / 4) qs[w][lane] = reinterpret_cast<const float4*>(Qn + b * D)[lane];  // the query row
   __builtin_amdgcn_wave_barrier();
   int n = count[b];
   bool over = flag[b] != 0;
@@ -507,7 +501,7 @@ __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restri
   const float* ps = prev_s ? prev_s + b * k : nullptr;
   const int64_t* pi = prev_i ? prev_i + b * k : nullptr;
   const int* cb = cand + b * cap;
-#define RG_RESCORE(NS_) rescore_query<NS_>(qs[w], Kn, cb, n, lane, k, base, ps, pi, out_s + b * k, out_i + b * k)
+#define RG_RESCORE(NS_) rescore_query<D, NS_>(qs[w], Kn, cb, n, lane, k, base, ps, pi, out_s + b * k, out_i + b * k)
   if (n <= 64) RG_RESCORE(1);
   else if (n <= 128) RG_RESCORE(2);
   else if (n <= 256) RG_RESCORE(4);
@@ -577,15 +571,16 @@ static int64_t filter_level0_keys(int64_t N) {
   if (n0 < 4096) n0 = 4096;
   return n0 < N ? n0 : N;
 }
-// Ends of the filter levels (multiples of 128 = whole ring stages, except the last = N); returns their number.
+static int64_t filter_round_up(int64_t n) { return (n + FILTER_PAD_KEYS - 1) / FILTER_PAD_KEYS * FILTER_PAD_KEYS; }
+// Ends of the filter levels (whole ring stages of any D, except the last = N); returns their number.
 static int filter_level_ends(int64_t N, int64_t ends[FILTER_MAX_LEVELS]) {
   const int64_t n0 = filter_level0_keys(N);
   int n = 0;
   int64_t prev = n0;
   for (int64_t frac : {32, 4}) {
-    int64_t e = (N / frac + 127) / 128 * 128;
-    if (e < 4 * prev) e = (4 * prev + 127) / 128 * 128;  // a level is at least 4x what came before
-    if (e * 2 >= N) break;                                 // too close to the end: the last level takes the rest
+    int64_t e = filter_round_up(N / frac);
+    if (e < 4 * prev) e = filter_round_up(4 * prev);  // a level is at least 4x what came before
+    if (e * 2 >= N) break;                            // too close to the end: the last level takes the rest
     ends[n++] = e;
     prev = e;
   }
@@ -593,32 +588,35 @@ static int filter_level_ends(int64_t N, int64_t ends[FILTER_MAX_LEVELS]) {
   return n;
 }
 
-static int64_t filter_padded_rows(int64_t N) { return (N + 127) / 128 * 128; }
+static bool filter_dim_ok(int D) { return D == 64 || D == 128 || D == 256; }
 
 extern "C" int ragraph_keys_to_bf16(const float* Kn, int64_t N, int D, uint16_t* Kb, void* stream) {
   RG_REQUIRE(Kn && Kb, RAGRAPH_EINVAL, "keys_to_bf16: null pointer");
   RG_REQUIRE(N >= 1, RAGRAPH_EINVAL, "keys_to_bf16: N=%lld must be >= 1", (long long)N);
-  RG_REQUIRE(D == 256, RAGRAPH_EUNSUPPORTED, "keys_to_bf16: D=%d (only 256)", D);
+  RG_REQUIRE(filter_dim_ok(D), RAGRAPH_EUNSUPPORTED, "keys_to_bf16: D=%d not in {64,128,256}", D);
   RG_REQUIRE(aligned16(Kn) && aligned16(Kb), RAGRAPH_EINVAL, "keys_to_bf16: pointers must be 16-B aligned");
-  const int64_t npad = filter_padded_rows(N);
+  const int64_t npad = filter_round_up(N);
   unsigned* tail = reinterpret_cast<unsigned*>(Kb + npad * D);  // the extra row: max_k |dk|^2 as float bits
-  if (hipMemsetAsync(tail, 0, (size_t)D * sizeof(uint16_t), as_stream(stream)) != hipSuccess) {
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(tail, 0, (size_t)D * sizeof(uint16_t), st) != hipSuccess) {
     set_error("keys_to_bf16: memset failed");
     return RAGRAPH_EDEVICE;
   }
-  hipLaunchKernelGGL(keys_to_bf16_kernel, dim3((unsigned)cdiv(npad * 32, 256)), dim3(256), 0, as_stream(stream), Kn, N,
-                     npad, Kb, tail);
+  const dim3 grid((unsigned)cdiv(npad * (D / 8), 256));
+  if (D == 256) hipLaunchKernelGGL(keys_to_bf16_kernel<256>, grid, dim3(256), 0, st, Kn, N, npad, Kb, tail);
+  else if (D == 128) hipLaunchKernelGGL(keys_to_bf16_kernel<128>, grid, dim3(256), 0, st, Kn, N, npad, Kb, tail);
+  else hipLaunchKernelGGL(keys_to_bf16_kernel<64>, grid, dim3(256), 0, st, Kn, N, npad, Kb, tail);
   RG_CHECK_LAUNCH("keys_to_bf16");
   return RAGRAPH_OK;
 }
 
 // bank rows padded to whole ring stages + one row that carries the bank's largest rounding error
-extern "C" int64_t ragraph_keys_bf16_rows(int64_t N) { return N < 1 ? 0 : filter_padded_rows(N) + 1; }
+extern "C" int64_t ragraph_keys_bf16_rows(int64_t N) { return N < 1 ? 0 : filter_round_up(N) + 1; }
 
 extern "C" int ragraph_topk_cosine_filtered_cap(int k) { return 2048; }
 
 extern "C" size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_t N, int D, int k) {
-  if (B < 1 || N < 1 || k < 1 || D != 256) return 0;
+  if (B < 1 || N < 1 || k < 1 || !filter_dim_ok(D)) return 0;
   const int cap = ragraph_topk_cosine_filtered_cap(k);
   return ragraph_topk_cosine_workspace_bytes(B, filter_level0_keys(N), D, k) + align_up((size_t)B * D * sizeof(float), 256) +
          2 * align_up((size_t)B * sizeof(float), 256) + align_up((size_t)B * sizeof(int), 256) + align_up((size_t)B, 256) +
@@ -627,11 +625,13 @@ extern "C" size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_
 
 // One filter level: thresholds from the exact scores in out_scores, bf16 filter over keys [key0, key1), rescoring
 // (+ merge with out_* when `merge`).
+template <int D>
 static int run_filter_level(const float* Qn, const float* Kn, const uint16_t* Kb, int64_t B, int64_t key0, int64_t key1,
                             int k, int64_t idx_base, int first, int merge, int final_level, float* out_scores,
                             int64_t* out_idx, int* overflow, int64_t* overflow_idx, float* thr, const float* eq,
                             const unsigned* max_kerr2, int* count, unsigned char* flag, int* cand, int cap, int level,
                             hipStream_t st) {
+  using C = FilterCfg<D>;
   static const int ablate = [] {  // RAGRAPH_FILTER_ABLATE=1: no key passes the filter (timing only, results invalid)
     const char* e = getenv("RAGRAPH_FILTER_ABLATE");
     return e ? atoi(e) : 0;
@@ -648,15 +648,9 @@ static int run_filter_level(const float* Qn, const float* Kn, const uint16_t* Kb
   p.B = B;
   p.N = key1;
   p.cap = cap;
-  static const int subs = [] {  // RAGRAPH_FILTER_SUBS = 1 | 2: keys per ring stage / 32 (diagnostic, read once)
-    const char* e = getenv("RAGRAPH_FILTER_SUBS");
-    const int v = e ? atoi(e) : 2;
-    return (v == 1 || v == 2) ? v : 2;  // 4 would leave 2 slots: the ring needs a stage in flight beside the one being read
-  }();
-  const int stage_keys = 32 * subs;
-  p.stage_base = key0 / stage_keys;  // key0 is a multiple of 128
-  p.qtiles = cdiv(B, 512);
-  p.nstages_total = cdiv(key1 - key0, stage_keys);
+  p.stage_base = key0 / C::STAGE_KEYS;  // key0 is a multiple of 256
+  p.qtiles = cdiv(B, C::QT);
+  p.nstages_total = cdiv(key1 - key0, C::STAGE_KEYS);
   const int CUS = filter_device_cus();
   p.xcd_map = p.qtiles >= 64 ? 1 : 0;
   p.wgs_per_group = CUS / (p.xcd_map ? 8 : 1);
@@ -673,30 +667,18 @@ static int run_filter_level(const float* Qn, const float* Kn, const uint16_t* Kb
     if (nq < 1 || (v == 1 && (!p.xcd_map || p.qtiles % 8 == 0))) continue;
     p.depth[v] = SegmentWalker::choose_depth(nq, p.nstages_total, p.wgs_per_group, p.lb_min, 0).depth;
   }
-  static const bool use_barrier = [] {  // RAGRAPH_FILTER_SYNC = flags | barrier (diagnostic, read once)
-    const char* e = getenv("RAGRAPH_FILTER_SYNC");
-    return e && e[0] == 'b';  // the counters are ~5 % faster (measured)
-  }();
-#define RG_LAUNCH_FILTER(S_, B_)                                                                                      \
-  do {                                                                                                                \
-    static bool attr_set = false;                                                                                     \
-    if (!attr_set) {                                                                                                  \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_filter_kernel<S_, B_>),                  \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)FilterCfg<S_>::LDS_BYTES);  \
-      if (e != hipSuccess) {                                                                                          \
-        set_error("topk_cosine_filtered: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));                  \
-        return RAGRAPH_EDEVICE;                                                                                       \
-      }                                                                                                               \
-      attr_set = true;                                                                                                \
-    }                                                                                                                 \
-    hipLaunchKernelGGL((topk_filter_kernel<S_, B_>), dim3((unsigned)CUS), dim3(512), FilterCfg<S_>::LDS_BYTES, st, p); \
-  } while (0)
+  static bool attr_set = false;  // per D (template instance)
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_filter_kernel<D>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("topk_cosine_filtered: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+      return RAGRAPH_EDEVICE;
+    }
+    attr_set = true;
+  }
   if (g_prof_on) (void)hipEventRecord(g_prof_ev[2 * level], st);
-  if (subs == 1 && use_barrier) RG_LAUNCH_FILTER(1, true);
-  else if (subs == 1) RG_LAUNCH_FILTER(1, false);
-  else if (use_barrier) RG_LAUNCH_FILTER(2, true);
-  else RG_LAUNCH_FILTER(2, false);
-#undef RG_LAUNCH_FILTER
+  hipLaunchKernelGGL(topk_filter_kernel<D>, dim3((unsigned)CUS), dim3(C::THREADS), C::LDS_BYTES, st, p);
   if (g_prof_on) {
     (void)hipEventRecord(g_prof_ev[2 * level + 1], st);
     g_prof_have = level + 1;
@@ -709,9 +691,9 @@ static int run_filter_level(const float* Qn, const float* Kn, const uint16_t* Kb
     (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_filter_timing), sizeof(t));
     const double n = (double)t[5];
     if (n > 0)
-      fprintf(stderr, "[filter timing] level %d SUBS=%d wave-stages=%.0f ticks/stage: wait_full %.1f compute %.1f signal+vmcnt "
-              "%.1f wait_free %.1f dma_issue %.1f total %.1f\n", level, subs, n, t[0] / n, t[1] / n, t[2] / n, t[3] / n,
-              t[4] / n, (t[0] + t[1] + t[2] + t[3] + t[4]) / n);
+      fprintf(stderr, "[filter timing] level %d D=%d wave-stages=%.0f ticks/stage: wait_full %.1f compute %.1f signal+vmcnt "
+              "%.1f wait_free %.1f dma_issue %.1f total %.1f\n", level, D, n, t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n,
+              (t[0] + t[1] + t[2] + t[3] + t[4]) / n);
     unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_filter_timing), zero, sizeof(zero));
   }
@@ -720,28 +702,16 @@ static int run_filter_level(const float* Qn, const float* Kn, const uint16_t* Kb
   dim3 grid((unsigned)cdiv(B, 4)), block(256);
   const float* ps = merge ? out_scores : nullptr;
   const int64_t* pi = merge ? out_idx : nullptr;
-  if (cap <= 1024)
-    hipLaunchKernelGGL(topk_rescore_kernel<16>, grid, block, 0, st, Qn, Kn, count, cand, B, cap, k, idx_base, ps, pi,
-                       final_level, out_scores, out_idx, overflow, overflow_idx, flag);
-  else
-    hipLaunchKernelGGL(topk_rescore_kernel<32>, grid, block, 0, st, Qn, Kn, count, cand, B, cap, k, idx_base, ps, pi,
-                       final_level, out_scores, out_idx, overflow, overflow_idx, flag);
+  hipLaunchKernelGGL((topk_rescore_kernel<D, 32>), grid, block, 0, st, Qn, Kn, count, cand, B, cap, k, idx_base, ps, pi,
+                     final_level, out_scores, out_idx, overflow, overflow_idx, flag);
   RG_CHECK_LAUNCH("topk_cosine_filtered(rescore)");
   return RAGRAPH_OK;
 }
 
-extern "C" int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const float* Kn, const float* Kp,
-                                                const uint16_t* Kb, int64_t N, int D, int k, int64_t idx_base,
-                                                float* out_scores, int64_t* out_idx, int* overflow,
-                                                int64_t* overflow_idx, void* ws, size_t ws_bytes, void* stream) {
-  RG_REQUIRE(Q && Kn && Kb && out_scores && out_idx && overflow && ws, RAGRAPH_EINVAL, "topk_cosine_filtered: null pointer");
-  RG_REQUIRE(D == 256, RAGRAPH_EUNSUPPORTED, "topk_cosine_filtered: D=%d (only 256)", D);
-  RG_REQUIRE(B >= 1 && N >= 1 && k >= 1 && k <= 32 && k <= N, RAGRAPH_EINVAL, "topk_cosine_filtered: bad B/N/k");
-  RG_REQUIRE(N < (int64_t)INT_MAX - 1024, RAGRAPH_EUNSUPPORTED, "topk_cosine_filtered: shard rows must fit int32");
-  RG_REQUIRE(aligned16(Q) && aligned16(Kn) && aligned16(Kb) && aligned16(ws), RAGRAPH_EINVAL,
-             "topk_cosine_filtered: pointers must be 16-B aligned");
-  const size_t need = ragraph_topk_cosine_filtered_workspace_bytes(B, N, D, k);
-  RG_REQUIRE(ws_bytes >= need, RAGRAPH_EWORKSPACE, "topk_cosine_filtered: workspace %zu < %zu", ws_bytes, need);
+template <int D>
+static int run_filtered(const float* Q, int64_t B, const float* Kn, const float* Kp, const uint16_t* Kb, int64_t N, int k,
+                        int64_t idx_base, float* out_scores, int64_t* out_idx, int* overflow, int64_t* overflow_idx,
+                        void* ws, void* stream) {
   hipStream_t st = as_stream(stream);
   const int cap = ragraph_topk_cosine_filtered_cap(k);
   int64_t n0 = filter_level0_keys(N);
@@ -755,23 +725,43 @@ extern "C" int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const
   float* thr = reinterpret_cast<float*>(reinterpret_cast<char*>(Qn) + align_up((size_t)B * D * sizeof(float), 256));
   float* eq = reinterpret_cast<float*>(reinterpret_cast<char*>(thr) + align_up((size_t)B * sizeof(float), 256));
   int* count = reinterpret_cast<int*>(reinterpret_cast<char*>(eq) + align_up((size_t)B * sizeof(float), 256));
-  const unsigned* max_kerr2 = reinterpret_cast<const unsigned*>(Kb + filter_padded_rows(N) * D);
   unsigned char* flag = reinterpret_cast<unsigned char*>(count) + align_up((size_t)B * sizeof(int), 256);
   int* cand = reinterpret_cast<int*>(flag + align_up((size_t)B, 256));
+  const unsigned* max_kerr2 = reinterpret_cast<const unsigned*>(Kb + filter_round_up(N) * D);
 
   // level 0: exact top-k over the first n0 keys (out_scores / out_idx hold every level's running result, local indices)
-  int rc = ragraph_topk_cosine_bank_f32(Q, B, Kn, Kp, n0, D, k, 0, out_scores, out_idx, ws, sample_ws, stream);
+  int rc = ragraph_topk_cosine_bank_f32(Q, B, Kn, D == 256 ? Kp : nullptr, n0, D, k, 0, out_scores, out_idx, ws, sample_ws,
+                                        stream);
   if (rc != RAGRAPH_OK) return rc;
   rc = ragraph_normalize_rows_f32(Q, B, D, Qn, stream);
   if (rc != RAGRAPH_OK) return rc;
-  hipLaunchKernelGGL(filter_query_err_kernel, dim3((unsigned)cdiv(B * 32, 256)), dim3(256), 0, st, Qn, B, eq);
+  hipLaunchKernelGGL(filter_query_err_kernel<D>, dim3((unsigned)cdiv(B * (D / 8), 256)), dim3(256), 0, st, Qn, B, eq);
   RG_CHECK_LAUNCH("topk_cosine_filtered(query error)");
   int64_t key0 = 0;
   for (int l = 0; l < nlev; ++l) {  // the first level re-reads [0, n0): its keys pass the bound and need no merge
-    rc = run_filter_level(Qn, Kn, Kb, B, key0, ends[l], k, idx_base, l == 0, l > 0, l == nlev - 1, out_scores, out_idx,
-                          overflow, overflow_idx, thr, eq, max_kerr2, count, flag, cand, cap, l, st);
+    rc = run_filter_level<D>(Qn, Kn, Kb, B, key0, ends[l], k, idx_base, l == 0, l > 0, l == nlev - 1, out_scores, out_idx,
+                             overflow, overflow_idx, thr, eq, max_kerr2, count, flag, cand, cap, l, st);
     if (rc != RAGRAPH_OK) return rc;
     key0 = ends[l];
   }
   return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const float* Kn, const float* Kp,
+                                                const uint16_t* Kb, int64_t N, int D, int k, int64_t idx_base,
+                                                float* out_scores, int64_t* out_idx, int* overflow,
+                                                int64_t* overflow_idx, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(Q && Kn && Kb && out_scores && out_idx && overflow && ws, RAGRAPH_EINVAL, "topk_cosine_filtered: null pointer");
+  RG_REQUIRE(filter_dim_ok(D), RAGRAPH_EUNSUPPORTED, "topk_cosine_filtered: D=%d not in {64,128,256}", D);
+  RG_REQUIRE(B >= 1 && N >= 1 && k >= 1 && k <= 32 && k <= N, RAGRAPH_EINVAL, "topk_cosine_filtered: bad B/N/k");
+  RG_REQUIRE(N < (int64_t)INT_MAX - 1024, RAGRAPH_EUNSUPPORTED, "topk_cosine_filtered: shard rows must fit int32");
+  RG_REQUIRE(aligned16(Q) && aligned16(Kn) && aligned16(Kb) && aligned16(ws), RAGRAPH_EINVAL,
+             "topk_cosine_filtered: pointers must be 16-B aligned");
+  const size_t need = ragraph_topk_cosine_filtered_workspace_bytes(B, N, D, k);
+  RG_REQUIRE(ws_bytes >= need, RAGRAPH_EWORKSPACE, "topk_cosine_filtered: workspace %zu < %zu", ws_bytes, need);
+  if (D == 256)
+    return run_filtered<256>(Q, B, Kn, Kp, Kb, N, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, stream);
+  if (D == 128)
+    return run_filtered<128>(Q, B, Kn, Kp, Kb, N, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, stream);
+  return run_filtered<64>(Q, B, Kn, Kp, Kb, N, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, stream);
 }

@@ -137,7 +137,7 @@ def filter_helps(B: int, n_keys: int, D: int, k: int) -> bool:
     366; the fp32 kernels win below ~5e7 query-key pairs (32 x 1M: 0.54 vs 0.48; 256 x 100k: 0.43 vs 0.38)."""
     if os.environ.get("RAGRAPH_EXACT_FP32") == "1":  # e.g. under HIP-graph capture: the filtered call reads a count back
         return False
-    return D == 256 and k <= 32 and B >= 48 and n_keys >= 65536 and B * n_keys >= 48_000_000
+    return D in (64, 128, 256) and k <= 32 and B >= 48 and n_keys >= 65536 and B * n_keys * D >= 48_000_000 * 256
 
 
 def topk_cosine_filtered(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf16: torch.Tensor, k: int,

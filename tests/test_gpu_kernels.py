@@ -375,6 +375,22 @@ def test_topk_cosine_filtered_bit_exact(dev, B, N, k):
     assert np.array_equal(s.cpu().numpy(), rs)
 
 
+@pytest.mark.parametrize("D,B,N,k", [(64, 700, 40000, 10), (64, 1500, 70001, 5), (128, 513, 33000, 7), (128, 900, 66000, 32)])
+def test_topk_cosine_filtered_other_dims_bit_exact(dev, D, B, N, k):
+    """The filter at D = 64 (the edge flavour's embedding size) and 128: 8 / 4 sub-tiles per ring stage, other swizzles."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(D + B + N + k)
+    kn = _bank(rng, N, D)
+    kn[N // 2:N // 2 + 40] = kn[:40]                      # exact duplicates -> ties
+    q = rng.standard_normal((B, D), dtype=np.float32)
+    knd = _t(kn, dev)
+    s, i, over = K.topk_cosine_filtered(_t(q, dev), knd, K.keys_to_bf16(knd), k, idx_base=2)
+    rs, ri = cref.topk_cosine(q, kn, k, idx_base=2)
+    assert np.array_equal(i.cpu().numpy(), ri)
+    assert np.array_equal(s.cpu().numpy(), rs)
+
+
 def test_topk_cosine_filtered_overflow_falls_back(dev):
     """A bank of near-duplicates puts thousands of keys within EPS of every query's k-th best, and a zero query ties
     every key at 0: the filter reports those queries and the wrapper recomputes them with the fp32 kernel -- the result

@@ -14,7 +14,7 @@ for B, N, D, k in shapes:
     kn = K.normalize_rows(torch.randn(N, D, device=dev))
     q = torch.randn(B, D, device=dev)
     kp = K.pack_keys(kn) if (K.packed_keys_help(B, D, k) and not os.environ.get("QTB_NO_PACK")) else None
-    filt = bool(os.environ.get("QTB_FILTER")) and D == 256
+    filt = bool(os.environ.get("QTB_FILTER")) and D in (64, 128, 256)
     K.filter_helps = lambda *a, **kw: False  # the plain entry below is the fp32 path
     kb = K.keys_to_bf16(kn) if filt else None
     if filt:
