@@ -439,23 +439,24 @@ def test_topk_cosine_filtered_fuzz_against_oracle(dev):
     from ragraph_amd import kernels as K
 
     rng = np.random.default_rng(4242)
-    for trial in range(10):
+    for trial in range(14):
         B = int(rng.choice([1, 37, 300, 513, 900, 1500]))
-        N = int(rng.choice([4100, 16500, 20001, 40000, 70003]))
+        N = int(rng.choice([300, 1000, 4100, 16500, 20001, 40000, 70003]))
         k = int(rng.choice([1, 2, 5, 10, 17, 32]))
-        keys = rng.standard_normal((N, 256), dtype=np.float32)
-        if trial % 3 == 0:
+        D = int(rng.choice([64, 128, 256, 256]))
+        keys = rng.standard_normal((N, D), dtype=np.float32)
+        if trial % 3 == 0 and N > 200:
             keys[N // 2:N // 2 + 64] = keys[:64]          # exact duplicates -> ties
         kn = cref.normalize_rows(keys)
-        q = rng.standard_normal((B, 256), dtype=np.float32)
+        q = rng.standard_normal((B, D), dtype=np.float32)
         if trial % 4 == 1:
             q[rng.integers(0, B)] = 0.0                   # zero query: every key ties at 0 -> overflow -> fallback
         base = int(rng.choice([0, 11]))
         knd = _t(kn, dev)
         s, i, over = K.topk_cosine_filtered(_t(q, dev), knd, K.keys_to_bf16(knd), k, idx_base=base)
         rs, ri = cref.topk_cosine(q, kn, k, idx_base=base)
-        assert np.array_equal(i.cpu().numpy(), ri), f"indices differ: B={B} N={N} k={k} (overflowed {over})"
-        assert np.array_equal(s.cpu().numpy(), rs), f"scores differ: B={B} N={N} k={k}"
+        assert np.array_equal(i.cpu().numpy(), ri), f"indices differ: B={B} N={N} D={D} k={k} (overflowed {over})"
+        assert np.array_equal(s.cpu().numpy(), rs), f"scores differ: B={B} N={N} D={D} k={k}"
 
 
 def test_topk_cosine_filtered_adversarial_rounding(dev):
