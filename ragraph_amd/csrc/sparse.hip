@@ -16,6 +16,10 @@
 
 namespace ragraph {
 
+// A row's edges are consumed in chunks of CH = 16: the first lanes of the row's lane group load the chunk's (col, val)
+// pairs with ONE coalesced load each, the group broadcasts them, and all gathers of the chunk are issued back to back
+// before the first fmaf -- three dependent memory latencies per row (rowptr, edge list, X rows) instead of one pair per
+// four edges.  The sum is still the sequential fmaf chain in CSR order.
 template <int LPR>
 __global__ void __launch_bounds__(256) spmm_csr_kernel(const int64_t* __restrict__ rowptr,
                                                        const int32_t* __restrict__ col,
@@ -24,33 +28,44 @@ __global__ void __launch_bounds__(256) spmm_csr_kernel(const int64_t* __restrict
                                                        const float* __restrict__ bias, int act, float alpha, float beta,
                                                        const float* __restrict__ Yin, float* __restrict__ Y) {
   constexpr int RPB = 256 / LPR;  // rows per block
+  constexpr int CH = 16;          // edges per chunk (<= LPR)
   const int lr = threadIdx.x % LPR;
-  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
-  if (row >= n) return;
-  const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
+  const int gbase = (threadIdx.x & 63) - lr;  // first lane of this row's group inside the wave
+  int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+  const bool live = row < n;  // dead groups run along with zero edges: the shuffles need every lane
+  if (!live) row = n - 1;
+  const int64_t e0 = rowptr[row];
+  const int deg = live ? (int)(rowptr[row + 1] - e0) : 0;
   const int D4 = D >> 2;
   const float4* X4 = reinterpret_cast<const float4*>(X);
 
-  for (int c4 = lr; c4 < D4; c4 += LPR) {
+  for (int c4 = lr; c4 < ((D4 + LPR - 1) / LPR) * LPR; c4 += LPR) {  // uniform trip count: shuffles inside
+    const bool colok = c4 < D4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int64_t e = e0;
-    for (; e + 4 <= e1; e += 4) {
-      const int c0 = col[e], c1 = col[e + 1], c2 = col[e + 2], c3 = col[e + 3];
-      const float v0 = val[e], v1 = val[e + 1], v2 = val[e + 2], v3 = val[e + 3];
-      const float4 x0 = X4[(int64_t)c0 * D4 + c4];
-      const float4 x1 = X4[(int64_t)c1 * D4 + c4];
-      const float4 x2 = X4[(int64_t)c2 * D4 + c4];
-      const float4 x3 = X4[(int64_t)c3 * D4 + c4];
-      acc.x = fmaf(v0, x0.x, acc.x); acc.y = fmaf(v0, x0.y, acc.y); acc.z = fmaf(v0, x0.z, acc.z); acc.w = fmaf(v0, x0.w, acc.w);
-      acc.x = fmaf(v1, x1.x, acc.x); acc.y = fmaf(v1, x1.y, acc.y); acc.z = fmaf(v1, x1.z, acc.z); acc.w = fmaf(v1, x1.w, acc.w);
-      acc.x = fmaf(v2, x2.x, acc.x); acc.y = fmaf(v2, x2.y, acc.y); acc.z = fmaf(v2, x2.z, acc.z); acc.w = fmaf(v2, x2.w, acc.w);
-      acc.x = fmaf(v3, x3.x, acc.x); acc.y = fmaf(v3, x3.y, acc.y); acc.z = fmaf(v3, x3.z, acc.z); acc.w = fmaf(v3, x3.w, acc.w);
+    for (int base = 0; base < deg; base += CH) {
+      int my_c = 0;
+      float my_v = 0.f;
+      if (lr < CH && base + lr < deg) {
+        my_c = col[e0 + base + lr];
+        my_v = val[e0 + base + lr];
+      }
+      const int cnt = deg - base < CH ? deg - base : CH;
+      float4 x[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int c = __shfl(my_c, gbase + i);
+        x[i] = (i < cnt && colok) ? X4[(int64_t)c * D4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const float v = __shfl(my_v, gbase + i);
+        if (i < cnt) {
+          acc.x = fmaf(v, x[i].x, acc.x); acc.y = fmaf(v, x[i].y, acc.y);
+          acc.z = fmaf(v, x[i].z, acc.z); acc.w = fmaf(v, x[i].w, acc.w);
+        }
+      }
     }
-    for (; e < e1; ++e) {
-      const float v = val[e];
-      const float4 x = X4[(int64_t)col[e] * D4 + c4];
-      acc.x = fmaf(v, x.x, acc.x); acc.y = fmaf(v, x.y, acc.y); acc.z = fmaf(v, x.z, acc.z); acc.w = fmaf(v, x.w, acc.w);
-    }
+    if (!live || !colok) continue;
     if (bias) {
       const float4 b = reinterpret_cast<const float4*>(bias)[c4];
       acc.x = __fadd_rn(acc.x, b.x); acc.y = __fadd_rn(acc.y, b.y); acc.z = __fadd_rn(acc.z, b.z); acc.w = __fadd_rn(acc.w, b.w);
