@@ -61,7 +61,8 @@ struct FilterCfg {
   static constexpr int SLOTS = 4;                         // 128 KiB of ring; the hand-over protocol needs >= 3 slots
   static constexpr int DMAS = STAGE_BYTES / 1024 / WAVES; // 1 KiB DMA instructions per wave and stage = 4
   static constexpr int RPI = 1024 / ROW_BYTES;            // key rows per DMA instruction: 2 / 4 / 8
-  static constexpr size_t LDS_BYTES = (size_t)SLOTS * STAGE_BYTES + 64;
+  static constexpr int CAND_BUF = 480;                    // entries of a wave's candidate buffer (8 B each)
+  static constexpr size_t LDS_BYTES = (size_t)SLOTS * STAGE_BYTES + 64 + (size_t)WAVES * CAND_BUF * 8;
   // swizzle f(row): rows that share a 256-B LDS bank row (16 chunks) must differ, and so must the 16 rows of a
   // ds_read_b128 lane group
   __host__ __device__ static constexpr int swz(int row) { return CR >= 16 ? (row & 15) : ((row / (16 / CR)) & (CR - 1)); }
@@ -76,8 +77,6 @@ struct FilterParams {
   int* cand;              // [B,cap] candidate key indices (local to this shard)
   int64_t B, N;           // N = end of the key range (keys >= N never pass)
   int cap;
-  int chunk;              // slots a lane reserves per returning atomic (1..16): small when a query tile is cut into
-                          // many short segments, so that half-empty chunks do not eat the list
   int64_t stage_base;     // first stage of the key range this launch filters
   int64_t qtiles, nstages_total;  // nstages_total = stages in the range
   int xcd_map, wgs_per_group, lb_min, depth[2];
@@ -195,7 +194,12 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     voff[i] = (unsigned)(i * 1024 + rin * C::ROW_BYTES + ((pos ^ C::swz(row)) << 4));
   }
   auto dma_stage = [&](int64_t stage_abs, int slot) {  // stage_abs: stage index over the whole bank
-    const char* gbase = reinterpret_cast<const char*>(p.Kb) + stage_abs * C::STAGE_BYTES + C::DMAS * wave * 1024;
+    // (wave-uniform by construction; the readfirstlanes keep it in SGPRs whatever hipcc's divergence analysis makes of
+    // the loop around it)
+    const uint64_t goff = (uint64_t)stage_abs * C::STAGE_BYTES + (uint64_t)(C::DMAS * wave * 1024);
+    const char* gbase = reinterpret_cast<const char*>(p.Kb) +
+                        (((uint64_t)__builtin_amdgcn_readfirstlane((unsigned)(goff >> 32)) << 32) |
+                         (uint64_t)__builtin_amdgcn_readfirstlane((unsigned)goff));
 #pragma unroll
     for (int i = 0; i < C::DMAS; ++i) {
       const unsigned dst = lds_base + (unsigned)(slot * C::STAGE_BYTES + (C::DMAS * wave + i) * 1024);
@@ -254,11 +258,39 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     // padded queries never pass: +inf threshold
     float thr0 = q_lo < p.B ? p.thr[q_lo] : __builtin_huge_valf();
     float thr1 = q_hi < p.B ? p.thr[q_hi] : __builtin_huge_valf();
-    // Candidate slots are reserved p.chunk at a time (one returning atomic per chunk of a lane's candidates; the candidate
-    // itself is a plain store); the unused slots of a segment's last chunk are set to -1 when the segment ends and are
-    // skipped by the rescoring.
-    const int CHUNK = p.chunk;
-    int base0 = 0, used0 = CHUNK, base1 = 0, used1 = CHUNK;
+    // Candidates: a sub-tile that holds any (one wave-uniform test of the accumulators' maxima) turns each lane's 16 scores
+    // per query group into a pass MASK without a branch, and the lanes with a non-zero mask push one 8-byte entry
+    // {(query within the wave) << 26 | offset of the lane's key group from key_org, mask} into a wave-private LDS buffer
+    // (position by ballot + mbcnt).  No atomics and no memory wait inside the MFMA stream, ~100 VALU instructions that
+    // fit under the other wave's MFMAs.  A full buffer, and the end of the segment, flush the entries to the queries'
+    // lists in global memory: one returning atomic per entry (64 entries per round trip), then the keys of its mask.
+    // key_org moves up (after a flush) every 2^16 stages so that offsets stay inside 26 bits.
+    uint2* wbuf = reinterpret_cast<uint2*>(smem + C::SLOTS * C::STAGE_BYTES + 64) + wave * C::CAND_BUF;
+    const int64_t q_wave = qtile * C::QT + wave * 64;
+    int wcnt = 0;  // wave-uniform
+    int key_org = (int)((p.stage_base + st0) * C::STAGE_KEYS);
+    auto flush = [&]() {
+      for (int i0 = 0; i0 < wcnt; i0 += 64) {
+        const int i = i0 + lane;
+        if (i < wcnt) {
+          const uint2 e = wbuf[i];
+          const int64_t q = q_wave + (e.x >> 26);
+          const int key0 = key_org + (int)(e.x & 0x3FFFFFFu);
+          unsigned mk = e.y;
+          int slot = atomicAdd(p.count + q, __popc(mk));
+          // retired here on every path: a return hipcc still considers pending where the flush rejoins the stage loop
+          // would put its vmcnt(0) -- which also drains the DMA ring -- in front of every sub-tile
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(slot) : : "memory");
+          while (mk) {
+            const int r = __ffs(mk) - 1;
+            mk &= mk - 1;
+            if (slot < p.cap) p.cand[q * p.cap + slot] = key0 + (r & 3) + 8 * (r >> 2);
+            ++slot;
+          }
+        }
+      }
+      wcnt = 0;
+    };
     // hipcc does not know about the asm DMA loads, and any vmcnt(0) it emits inside the stage loop (for a global load it
     // still considers pending at the loop's back edge) would drain them every sub-tile: retire the thresholds here and
     // hand them to the loop as plain register values
@@ -279,23 +311,26 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
 #endif
     for (int s = 0; s < nstages; ++s) {
       const int slot = s & (C::SLOTS - 1), gen = s / C::SLOTS;
+      if ((s & 0xFFFF) == 0 && s > 0) {  // keep the entries' key offsets inside 26 bits
+        flush();
+        key_org += 0x10000 * C::STAGE_KEYS;
+      }
       RG_FT(t0);
       fring_wait(full + slot, (unsigned)(C::WAVES * (gen + 1)));
       RG_FT(t1);
       // epilogue of sub-tile u: acc[r] = approximate score of key row (r&3) + 8 (r>>2) + 4 g of the sub-tile
-      auto append = [&](const f32x16& a, float thr, int64_t q, int& base, int& used, int key_base) {
+      auto pass_mask = [&](const f32x16& a, float thr) {
+        unsigned mk = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = key_base + (r & 3) + 8 * (r >> 2);
-          if (a[r] >= thr && key < (int)p.N) {
-            if (used == CHUNK) {
-              base = atomicAdd(p.count + q, CHUNK);
-              asm volatile("s_waitcnt vmcnt(0)" : "+v"(base) : : "memory");  // retired here, not at every later use
-              used = 0;
-            }
-            if (base + used < p.cap) p.cand[q * p.cap + base + used] = key;
-            ++used;
-          }
+        for (int r = 0; r < 16; ++r) mk |= (a[r] >= thr) ? (1u << r) : 0u;
+        return mk;
+      };
+      auto push = [&](unsigned mk, unsigned word0) {
+        const unsigned long long m = __ballot(mk != 0);
+        if (m) {
+          const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+          if (mk) wbuf[pos] = make_uint2(word0, mk);
+          wcnt += __popcll(m);
         }
       };
       auto epilogue = [&](int u, const f32x16& a0, const f32x16& a1) {
@@ -306,9 +341,20 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
           m1 = fmaxf(m1, a1[r]);
         }
         if (__any(m0 >= thr0 || m1 >= thr1)) {
-          const int key_base = (int)((p.stage_base + st0 + s) * C::STAGE_KEYS) + 32 * u + 4 * g;
-          append(a0, thr0, q_lo, base0, used0, key_base);
-          append(a1, thr1, q_hi, base1, used1, key_base);
+          const int stage_key0 = (int)((p.stage_base + st0 + s) * C::STAGE_KEYS);
+          const int key_base = stage_key0 + 32 * u + 4 * g;  // the lane's keys: key_base + (r & 3) + 8 (r >> 2)
+          unsigned k0 = pass_mask(a0, thr0), k1 = pass_mask(a1, thr1);
+          if (stage_key0 + C::STAGE_KEYS > (int)p.N) {  // the range's last stage: keys >= N (padding, or the next level's)
+            unsigned vm = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) vm |= (key_base + (r & 3) + 8 * (r >> 2) < (int)p.N) ? (1u << r) : 0u;
+            k0 &= vm;
+            k1 &= vm;
+          }
+          if (wcnt > C::CAND_BUF - 128) flush();  // a sub-tile pushes at most 2 x 64 entries
+          const unsigned off = (unsigned)(key_base - key_org);
+          push(k0, ((unsigned)j << 26) | off);
+          push(k1, ((unsigned)(j + 32) << 26) | off);
         }
       };
       // ---- SUBS sub-tiles of 32 keys x 64 queries, KSTEPS k-steps each; one A fragment per step feeds both query groups.
@@ -386,12 +432,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     if (lane == 0)
       for (int i = 0; i < 6; ++i) atomicAdd(&g_filter_timing[i], tw[i]);
 #endif
-    // close the segment's open chunks: the slots a lane reserved and did not fill are marked unused (-1), so the
-    // candidate buffer needs no clearing between calls
-    for (int u = used0; u < CHUNK; ++u)
-      if (base0 + u < p.cap) p.cand[q_lo * p.cap + base0 + u] = -1;
-    for (int u = used1; u < CHUNK; ++u)
-      if (base1 + u < p.cap) p.cand[q_hi * p.cap + base1 + u] = -1;
+    flush();
     __syncthreads();  // flags are re-initialised by the next segment
   }
 }
@@ -655,11 +696,6 @@ static int run_filter_level(const float* Qn, const float* Kn, const uint16_t* Kb
   p.xcd_map = p.qtiles >= 64 ? 1 : 0;
   p.wgs_per_group = CUS / (p.xcd_map ? 8 : 1);
   p.lb_min = 8;
-  {  // ~150 candidates per query and level, spread over the tile's segments and the two half-waves of a query
-    const int64_t segs = p.qtiles >= CUS ? 2 : cdiv(CUS, p.qtiles);
-    const int64_t per_lane = 150 / (2 * segs);
-    p.chunk = per_lane >= 16 ? 16 : per_lane >= 8 ? 8 : per_lane >= 4 ? 4 : per_lane >= 2 ? 2 : 1;
-  }
   const int64_t nq0 = p.xcd_map ? (p.qtiles + 7) / 8 : p.qtiles;
   for (int v = 0; v < 2; ++v) {
     const int64_t nq = nq0 - v;
