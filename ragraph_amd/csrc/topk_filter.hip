@@ -27,6 +27,7 @@
 // segment_plan.h with zero warm-up cost (there are no lists): every workgroup gets the same number of stages.
 #include "common.h"
 #include "segment_plan.h"
+#include <cmath>
 
 namespace ragraph {
 
@@ -602,31 +603,86 @@ extern "C" float ragraph_profile_last_filter_ms(void) {
   return total;
 }
 
-// Levels: exact fp32 top-k over the first n0 = N/256 keys, then bf16 filter + exact rescoring over [0, N/32),
-// [N/32, N/4) and [N/4, N).  A level's k-th exact score is the next level's bound, so a level only lets through
-// ~1.25 k (its size / what came before) keys per query: ~100, ~100 and ~40 -- the bulk of the bank is filtered with a
-// threshold that almost nothing passes.
+// Schedule of a call: exact fp32 top-k over the first n0 keys (its k-th score is the first bound), then bf16 filter +
+// exact rescoring over [0, e1), [e1, e2), ... [.., N).  A level's k-th exact score is the next level's bound, so a level
+// lets through ~1.3 k (its end / the previous end) keys per query.
+//   * Large batches (the bench's 100 k queries): n0 = N/256, ends N/32, N/4, N -- ~100, ~100 and ~40 candidates per
+//     query; level 0 is the fp32 tile kernel.  The matrix work dominates, three levels keep the rescoring at ~8 %.
+//   * Small and medium batches (B <= 16384): a level costs ~60 us whatever it filters (launches, ring prologue, the
+//     rescoring kernel's latency) while candidates are cheap, so fewer, steeper levels win; and level 0 is a slab --
+//     the dense kernel (same fmaf chains as everything else) writes the B x n0 scores, topk_rows selects -- which
+//     spreads over the whole chip where the tile kernel would run one query tile on a few CUs.  n0 and the number of
+//     levels minimise   slab(B, n0) + L (60 us + B * 1.3 k r * 0.4 ns),  r = (N / n0)^(1/L),  under 1.3 k r <= cap / 2.
 constexpr int FILTER_MAX_LEVELS = 3;
-static int64_t filter_level0_keys(int64_t N) {
-  int64_t n0 = N / 256;
-  if (n0 < 4096) n0 = 4096;
-  return n0 < N ? n0 : N;
-}
 static int64_t filter_round_up(int64_t n) { return (n + FILTER_PAD_KEYS - 1) / FILTER_PAD_KEYS * FILTER_PAD_KEYS; }
-// Ends of the filter levels (whole ring stages of any D, except the last = N); returns their number.
-static int filter_level_ends(int64_t N, int64_t ends[FILTER_MAX_LEVELS]) {
-  const int64_t n0 = filter_level0_keys(N);
-  int n = 0;
-  int64_t prev = n0;
-  for (int64_t frac : {32, 4}) {
-    int64_t e = filter_round_up(N / frac);
-    if (e < 4 * prev) e = filter_round_up(4 * prev);  // a level is at least 4x what came before
-    if (e * 2 >= N) break;                            // too close to the end: the last level takes the rest
-    ends[n++] = e;
-    prev = e;
+
+struct FilterSchedule {
+  int64_t n0;                       // level 0: exact top-k over keys [0, n0)
+  int slab0;                        // level 0 by dense kernel + topk_rows (needs B * n0 floats of workspace)
+  int nlev;                         // filter levels
+  int64_t ends[FILTER_MAX_LEVELS];  // their ends (multiples of 256 except the last = N)
+};
+
+constexpr int64_t FILTER_SLAB_MAX_B = 16384;
+constexpr int64_t FILTER_SLAB_MAX_SCORES = (int64_t)1 << 26;  // 256 MiB of scores
+
+static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k) {
+  FilterSchedule sc;
+  const int cap = 2048;
+  if (B > FILTER_SLAB_MAX_B || N < 4 * 4096) {
+    int64_t n0 = N / 256;
+    if (n0 < 4096) n0 = 4096;
+    if (n0 > N) n0 = N;
+    if (n0 < k) n0 = k < N ? k : N;
+    sc.n0 = n0;
+    sc.slab0 = 0;
+    sc.nlev = 0;
+    int64_t prev = n0;
+    for (int64_t frac : {32, 4}) {
+      int64_t e = filter_round_up(N / frac);
+      if (e < 4 * prev) e = filter_round_up(4 * prev);  // a level is at least 4x what came before
+      if (e * 2 >= N) break;                            // too close to the end: the last level takes the rest
+      sc.ends[sc.nlev++] = e;
+      prev = e;
+    }
+    sc.ends[sc.nlev++] = N;
+    return sc;
   }
-  ends[n++] = N;
-  return n;
+  double best = 1e30;
+  int64_t best_n0 = 4096;
+  int best_L = FILTER_MAX_LEVELS;
+  for (int64_t n0 = 4096; n0 * 4 <= N && B * n0 <= FILTER_SLAB_MAX_SCORES; n0 *= 2) {
+    const double slab = 30.0 + (double)B * (double)n0 * (2.0 * D / 1.0e8 + 4.0 / 3.0e6);
+    for (int L = 1; L <= FILTER_MAX_LEVELS; ++L) {
+      const double r = pow((double)N / (double)n0, 1.0 / L);
+      if (1.3 * k * r > cap / 2) continue;
+      const double cost = slab + L * (60.0 + (double)B * 1.3 * k * r * 0.4e-3);
+      if (cost < best) {
+        best = cost;
+        best_n0 = n0;
+        best_L = L;
+      }
+    }
+  }
+  sc.n0 = best_n0;
+  sc.slab0 = 1;
+  sc.nlev = 0;
+  const double r = pow((double)N / (double)best_n0, 1.0 / best_L);
+  double e = (double)best_n0;
+  for (int l = 0; l + 1 < best_L; ++l) {
+    e *= r;
+    const int64_t ei = filter_round_up((int64_t)e);
+    if (ei * 2 >= N) break;
+    sc.ends[sc.nlev++] = ei;
+  }
+  sc.ends[sc.nlev++] = N;
+  return sc;
+}
+
+// workspace of level 0: the tile kernel's, or the score slab
+static size_t filter_level0_ws(const FilterSchedule& sc, int64_t B, int D, int k) {
+  return sc.slab0 ? align_up((size_t)B * (size_t)sc.n0 * sizeof(float), 256)
+                  : ragraph_topk_cosine_workspace_bytes(B, sc.n0, D, k);
 }
 
 static bool filter_dim_ok(int D) { return D == 64 || D == 128 || D == 256; }
@@ -659,7 +715,8 @@ extern "C" int ragraph_topk_cosine_filtered_cap(int k) { return 2048; }
 extern "C" size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_t N, int D, int k) {
   if (B < 1 || N < 1 || k < 1 || !filter_dim_ok(D)) return 0;
   const int cap = ragraph_topk_cosine_filtered_cap(k);
-  return ragraph_topk_cosine_workspace_bytes(B, filter_level0_keys(N), D, k) + align_up((size_t)B * D * sizeof(float), 256) +
+  const FilterSchedule sc = filter_schedule(B, N, D, k);
+  return filter_level0_ws(sc, B, D, k) + align_up((size_t)B * D * sizeof(float), 256) +
          2 * align_up((size_t)B * sizeof(float), 256) + align_up((size_t)B * sizeof(int), 256) + align_up((size_t)B, 256) +
          align_up((size_t)B * cap * sizeof(int), 256);
 }
@@ -750,13 +807,12 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
                         void* ws, void* stream) {
   hipStream_t st = as_stream(stream);
   const int cap = ragraph_topk_cosine_filtered_cap(k);
-  int64_t n0 = filter_level0_keys(N);
-  if (n0 < k) n0 = k < N ? k : N;
-  int64_t ends[FILTER_MAX_LEVELS];
-  const int nlev = filter_level_ends(N, ends);
+  const FilterSchedule sc = filter_schedule(B, N, D, k);
+  const int nlev = sc.nlev;
+  const int64_t* ends = sc.ends;
 
   char* w = static_cast<char*>(ws);
-  const size_t sample_ws = ragraph_topk_cosine_workspace_bytes(B, filter_level0_keys(N), D, k);
+  const size_t sample_ws = filter_level0_ws(sc, B, D, k);
   float* Qn = reinterpret_cast<float*>(w + sample_ws);
   float* thr = reinterpret_cast<float*>(reinterpret_cast<char*>(Qn) + align_up((size_t)B * D * sizeof(float), 256));
   float* eq = reinterpret_cast<float*>(reinterpret_cast<char*>(thr) + align_up((size_t)B * sizeof(float), 256));
@@ -766,10 +822,16 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   const unsigned* max_kerr2 = reinterpret_cast<const unsigned*>(Kb + filter_round_up(N) * D);
 
   // level 0: exact top-k over the first n0 keys (out_scores / out_idx hold every level's running result, local indices)
-  int rc = ragraph_topk_cosine_bank_f32(Q, B, Kn, D == 256 ? Kp : nullptr, n0, D, k, 0, out_scores, out_idx, ws, sample_ws,
-                                        stream);
+  int rc = ragraph_normalize_rows_f32(Q, B, D, Qn, stream);
   if (rc != RAGRAPH_OK) return rc;
-  rc = ragraph_normalize_rows_f32(Q, B, D, Qn, stream);
+  if (sc.slab0) {
+    float* S = reinterpret_cast<float*>(w);
+    rc = ragraph_linear_f32(Qn, B, D, Kn, sc.n0, nullptr, RAGRAPH_ACT_NONE, 0.f, S, stream);
+    if (rc == RAGRAPH_OK) rc = ragraph_topk_rows_f32(S, B, sc.n0, sc.n0, k, out_scores, out_idx, stream);
+  } else {
+    rc = ragraph_topk_cosine_bank_f32(Q, B, Kn, D == 256 ? Kp : nullptr, sc.n0, D, k, 0, out_scores, out_idx, ws, sample_ws,
+                                      stream);
+  }
   if (rc != RAGRAPH_OK) return rc;
   hipLaunchKernelGGL(filter_query_err_kernel<D>, dim3((unsigned)cdiv(B * (D / 8), 256)), dim3(256), 0, st, Qn, B, eq);
   RG_CHECK_LAUNCH("topk_cosine_filtered(query error)");
