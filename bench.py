@@ -156,27 +156,31 @@ def gnn_only_rate(model, feats, adj, steps):
 
 
 def small_batch_rates(tgb, dim, k, dev):
-    """HBM-bound regime (graph classification: one query per forward): bank passes per second."""
+    """Retrieval alone against batch size through the product dispatch (KeyIndex: fp32 streaming kernel for a handful of
+    queries -- graph classification sends ONE per forward, the HBM-bound regime --, the bf16-filtered exact path from a
+    dozen up): ms per call and bank passes per second (the fp32 bank's bytes / time, whichever copy was streamed)."""
     from ragraph_amd import kernels as K
 
     out = {}
     kn = tgb.keys_normalized
-    for B in (1, 16):
+    index = tgb._index if tgb._index is not None else K.KeyIndex(kn)
+    for B in (1, 16, 64, 256, 4096):
         q = torch.randn(B, dim, device=dev)
         for _ in range(3):
-            K.topk_cosine(q, kn, k)
+            index.topk(q, k)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 20
         e0.record()
         for _ in range(reps):
-            K.topk_cosine(q, kn, k)
+            index.topk(q, k)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         gbs = kn.numel() * 4 / ms / 1e6
         out[f"B{B}"] = {"ms": round(ms, 4), "queries_per_s": round(B / ms * 1e3, 1), "bank_GBps": round(gbs, 1),
-                        "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+                        "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                        "path": "bf16-filtered" if K.filter_helps(B, kn.shape[0], dim, k) else "fp32"}
     return out
 
 

@@ -53,22 +53,34 @@ __global__ void __launch_bounds__(256) topk_rows_kernel(const float* __restrict_
   float thr = RG_NEG_INF;
   const bool vec = ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
   const int64_t nvec = vec ? (N >> 2) : 0;  // float4 chunks; the tail (and unaligned rows) go scalar
-  for (int64_t c0 = (int64_t)wave * 64; c0 < nvec; c0 += 256) {
-    const int64_t c = c0 + lane;
-    float4 v = make_float4(RG_NEG_INF, RG_NEG_INF, RG_NEG_INF, RG_NEG_INF);
-    if (c < nvec) v = reinterpret_cast<const float4*>(row)[c];
-    const float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
-    if (__any(m >= thr)) {
-      const float e[4] = {v.x, v.y, v.z, v.w};
+  // four 16-B loads per lane in flight: a row is streamed by only four waves, one load at a time would pay the memory
+  // latency per 1 KiB
+  for (int64_t c00 = (int64_t)wave * 64; c00 < nvec; c00 += 1024) {
+    float4 vv[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        unsigned long long pend = __ballot(e[r] >= thr && c < nvec);
-        while (pend) {
-          const int src = __ffsll((long long)pend) - 1;
-          pend &= pend - 1;
-          const float sc = __shfl(e[r], src);
-          thr = rows_insert_coop(ls[wave], li[wave], k, sc, (int)(4 * (c0 + src) + r), lane);
-          pend &= __ballot(e[r] >= thr);
+    for (int u = 0; u < 4; ++u) {
+      const int64_t c = c00 + 256 * u + lane;
+      vv[u] = make_float4(RG_NEG_INF, RG_NEG_INF, RG_NEG_INF, RG_NEG_INF);
+      if (c < nvec) vv[u] = reinterpret_cast<const float4*>(row)[c];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t c0 = c00 + 256 * u;
+      const int64_t c = c0 + lane;
+      const float4 v = vv[u];
+      const float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+      if (__any(m >= thr)) {
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          unsigned long long pend = __ballot(e[r] >= thr && c < nvec);
+          while (pend) {
+            const int src = __ffsll((long long)pend) - 1;
+            pend &= pend - 1;
+            const float sc = __shfl(e[r], src);
+            thr = rows_insert_coop(ls[wave], li[wave], k, sc, (int)(4 * (c0 + src) + r), lane);
+            pend &= __ballot(e[r] >= thr);
+          }
         }
       }
     }

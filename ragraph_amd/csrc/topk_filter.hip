@@ -170,9 +170,14 @@ __device__ unsigned long long g_filter_timing[8];
 #define RG_FT(var_)
 #endif
 
-template <int D>
+// QW = queries per wave: 64 (two groups of 32 sharing every A fragment; query tile = 512) or 32 (one group, tile = 256:
+// batches of <= 256 queries, which would otherwise spend half their matrix work on padding).
+template <int D, int QW>
 __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
   using C = FilterCfg<D>;
+  static_assert(QW == 64 || QW == 32, "one or two query groups per wave");
+  constexpr int QT = C::WAVES * QW;
+  constexpr bool TWO = (QW == 64);
   extern __shared__ float4 fsmem4[];
   char* smem = reinterpret_cast<char*>(fsmem4);
   unsigned* full = reinterpret_cast<unsigned*>(smem + C::SLOTS * C::STAGE_BYTES);  // [SLOTS] then freec [SLOTS]
@@ -231,7 +236,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
   Segment seg;
   while (walker.next(seg)) {
     const int64_t qtile = p.xcd_map ? x + 8 * seg.tile : seg.tile;
-    const int64_t q_lo = qtile * C::QT + wave * 64 + j, q_hi = q_lo + 32;
+    const int64_t q_lo = qtile * QT + wave * QW + j, q_hi = q_lo + 32;
     const int64_t st0 = seg.st0;
     const int nstages = (int)(seg.st1 - seg.st0);
 
@@ -245,7 +250,11 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
 #pragma unroll
         for (int t = t0; t < t0 + 4; ++t) {
           const float4 u0 = *reinterpret_cast<const float4*>(r0 + 16 * t), u1 = *reinterpret_cast<const float4*>(r0 + 16 * t + 4);
-          const float4 w0 = *reinterpret_cast<const float4*>(r1 + 16 * t), w1 = *reinterpret_cast<const float4*>(r1 + 16 * t + 4);
+          float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
+          if constexpr (TWO) {
+            w0 = *reinterpret_cast<const float4*>(r1 + 16 * t);
+            w1 = *reinterpret_cast<const float4*>(r1 + 16 * t + 4);
+          }
           b0[t][0] = (__bf16)u0.x; b0[t][1] = (__bf16)u0.y; b0[t][2] = (__bf16)u0.z; b0[t][3] = (__bf16)u0.w;
           b0[t][4] = (__bf16)u1.x; b0[t][5] = (__bf16)u1.y; b0[t][6] = (__bf16)u1.z; b0[t][7] = (__bf16)u1.w;
           b1[t][0] = (__bf16)w0.x; b1[t][1] = (__bf16)w0.y; b1[t][2] = (__bf16)w0.z; b1[t][3] = (__bf16)w0.w;
@@ -258,7 +267,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     }
     // padded queries never pass: +inf threshold
     float thr0 = q_lo < p.B ? p.thr[q_lo] : __builtin_huge_valf();
-    float thr1 = q_hi < p.B ? p.thr[q_hi] : __builtin_huge_valf();
+    float thr1 = (TWO && q_hi < p.B) ? p.thr[q_hi] : __builtin_huge_valf();
     // Candidates: a sub-tile that holds any (one wave-uniform test of the accumulators' maxima) turns each lane's 16 scores
     // per query group into a pass MASK without a branch, and the lanes with a non-zero mask push one 8-byte entry
     // {(query within the wave) << 26 | offset of the lane's key group from key_org, mask} into a wave-private LDS buffer
@@ -267,7 +276,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     // lists in global memory: one returning atomic per entry (64 entries per round trip), then the keys of its mask.
     // key_org moves up (after a flush) every 2^16 stages so that offsets stay inside 26 bits.
     uint2* wbuf = reinterpret_cast<uint2*>(smem + C::SLOTS * C::STAGE_BYTES + 64) + wave * C::CAND_BUF;
-    const int64_t q_wave = qtile * C::QT + wave * 64;
+    const int64_t q_wave = qtile * QT + wave * QW;
     int wcnt = 0;  // wave-uniform
     int key_org = (int)((p.stage_base + st0) * C::STAGE_KEYS);
     auto flush = [&]() {
@@ -335,16 +344,16 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
         }
       };
       auto epilogue = [&](int u, const f32x16& a0, const f32x16& a1) {
-        float m0 = a0[0], m1 = a1[0];
+        float m0 = a0[0], m1 = TWO ? a1[0] : RG_NEG_INF;
 #pragma unroll
         for (int r = 1; r < 16; ++r) {
           m0 = fmaxf(m0, a0[r]);
-          m1 = fmaxf(m1, a1[r]);
+          if constexpr (TWO) m1 = fmaxf(m1, a1[r]);
         }
-        if (__any(m0 >= thr0 || m1 >= thr1)) {
+        if (__any(m0 >= thr0 || (TWO && m1 >= thr1))) {
           const int stage_key0 = (int)((p.stage_base + st0 + s) * C::STAGE_KEYS);
           const int key_base = stage_key0 + 32 * u + 4 * g;  // the lane's keys: key_base + (r & 3) + 8 (r >> 2)
-          unsigned k0 = pass_mask(a0, thr0), k1 = pass_mask(a1, thr1);
+          unsigned k0 = pass_mask(a0, thr0), k1 = TWO ? pass_mask(a1, thr1) : 0u;
           if (stage_key0 + C::STAGE_KEYS > (int)p.N) {  // the range's last stage: keys >= N (padding, or the next level's)
             unsigned vm = 0;
 #pragma unroll
@@ -355,7 +364,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
           if (wcnt > C::CAND_BUF - 128) flush();  // a sub-tile pushes at most 2 x 64 entries
           const unsigned off = (unsigned)(key_base - key_org);
           push(k0, ((unsigned)j << 26) | off);
-          push(k1, ((unsigned)(j + 32) << 26) | off);
+          if constexpr (TWO) push(k1, ((unsigned)(j + 32) << 26) | off);
         }
       };
       // ---- SUBS sub-tiles of 32 keys x 64 queries, KSTEPS k-steps each; one A fragment per step feeds both query groups.
@@ -386,7 +395,8 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     {                                                                                                      \
       const bf16x8 a_ = __builtin_bit_cast(bf16x8, fr[(n_)&3]);                                             \
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b0[(n_) % C::KSTEPS], acc0, 0, 0, 0);              \
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b1[(n_) % C::KSTEPS], acc1, 0, 0, 0);              \
+      if constexpr (TWO)                                                                                    \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b1[(n_) % C::KSTEPS], acc1, 0, 0, 0);            \
     }                                                                                                      \
     if constexpr ((n_) + 4 < C::NSTEP) RG_FREAD((n_) + 4);                                                  \
     if constexpr ((n_) % C::KSTEPS == C::KSTEPS - 1) epilogue((n_) / C::KSTEPS, acc0, acc1);                \
@@ -438,6 +448,43 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
   }
 }
 
+// Canonical top-k (score descending, index ascending) of the 64 x NSL (score, id) pairs a wave holds in registers:
+// k rounds of wave argmax over what comes after the previous winner.  Lane 0 writes the result (ids + base).
+template <int NSL>
+__device__ __forceinline__ void wave_select(const float (&s)[NSL], const int64_t (&id)[NSL], int k, int lane, int64_t base,
+                                            float* out_s, int64_t* out_i) {
+  float prev_sc = __builtin_huge_valf();
+  int64_t prev_id = -1;  // everything is worse than (+inf, -1)
+  for (int r = 0; r < k; ++r) {
+    float best_s = RG_NEG_INF;
+    int64_t best_i = INT64_MAX;
+#pragma unroll
+    for (int u = 0; u < NSL; ++u) {
+      const bool after_prev = (s[u] < prev_sc) || (s[u] == prev_sc && id[u] > prev_id);
+      const bool beats = (s[u] > best_s) || (s[u] == best_s && id[u] < best_i);
+      if (after_prev && beats) {
+        best_s = s[u];
+        best_i = id[u];
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float os = __shfl_xor(best_s, off);
+      const int64_t oi = __shfl_xor(best_i, off);
+      if ((os > best_s) || (os == best_s && oi < best_i)) {
+        best_s = os;
+        best_i = oi;
+      }
+    }
+    if (lane == 0) {
+      out_s[r] = best_s;
+      out_i[r] = best_i == INT64_MAX ? INT64_MAX : best_i + base;
+    }
+    prev_sc = best_s;
+    prev_id = best_i;
+  }
+}
+
 // Rescoring of one query by one wave with NS candidate slots per lane (n <= 64 * NS reserved slots): exact scores (one
 // lane per candidate, the k = 0..D-1 fmaf chain from +0), merge with the previous level's winners, canonical top-k.
 template <int D, int NS>
@@ -474,36 +521,7 @@ __device__ __forceinline__ void rescore_query(const float4* __restrict__ qrow, c
       id[u] = key;
     }
   }
-  float prev_sc = __builtin_huge_valf();
-  int64_t prev_id = -1;  // everything is worse than (+inf, -1)
-  for (int r = 0; r < k; ++r) {
-    float best_s = RG_NEG_INF;
-    int64_t best_i = INT64_MAX;
-#pragma unroll
-    for (int u = 0; u <= NS; ++u) {
-      const bool after_prev = (s[u] < prev_sc) || (s[u] == prev_sc && id[u] > prev_id);
-      const bool beats = (s[u] > best_s) || (s[u] == best_s && id[u] < best_i);
-      if (after_prev && beats) {
-        best_s = s[u];
-        best_i = id[u];
-      }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const float os = __shfl_xor(best_s, off);
-      const int64_t oi = __shfl_xor(best_i, off);
-      if ((os > best_s) || (os == best_s && oi < best_i)) {
-        best_s = os;
-        best_i = oi;
-      }
-    }
-    if (lane == 0) {
-      out_s[r] = best_s;
-      out_i[r] = best_i == INT64_MAX ? INT64_MAX : best_i + base;
-    }
-    prev_sc = best_s;
-    prev_id = best_i;
-  }
+  wave_select<NS + 1>(s, id, k, lane, base, out_s, out_i);
 }
 
 // One wave per query.  prev_* (the previous level's exact top-k, local indices) may alias out_*.  A query whose list
@@ -550,6 +568,69 @@ __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restri
   else if (n <= 512) RG_RESCORE(8);
   else RG_RESCORE(CPL);
 #undef RG_RESCORE
+}
+
+// Small batches: one WORKGROUP per query.  The narrow kernel's wave walks its lane's candidates one after the other,
+// each a latency-bound chain of row loads, and a few hundred waves do not hide that; here four waves take a quarter of
+// the list each, leave their top-k in LDS, and wave 0 merges the four (and the previous level's winners, which ride
+// with wave 0's quarter).
+template <int D>
+__global__ void __launch_bounds__(256) topk_rescore_wide_kernel(const float* __restrict__ Qn, const float* __restrict__ Kn,
+                                                                const int* __restrict__ count,
+                                                                const int* __restrict__ cand, int64_t B, int cap, int k,
+                                                                int64_t idx_base, const float* prev_s,
+                                                                const int64_t* prev_i, int final_level, float* out_s,
+                                                                int64_t* out_i, int* __restrict__ overflow,
+                                                                int64_t* __restrict__ overflow_idx,
+                                                                unsigned char* __restrict__ flag) {
+  __shared__ float4 qs[D / 4];
+  __shared__ float ps[4][32];
+  __shared__ int64_t pi[4][32];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t b = blockIdx.x;
+  if (threadIdx.x < D / 4) qs[threadIdx.x] = reinterpret_cast<const float4*>(Qn + b * D)[threadIdx.x];
+  __syncthreads();
+  int n = count[b];
+  bool over = flag[b] != 0;
+  if (n > cap) {
+    over = true;
+    n = cap;
+  }
+  if (threadIdx.x == 0) {
+    if (final_level) {
+      if (over) {
+        const int pos = atomicAdd(overflow, 1);
+        if (overflow_idx) overflow_idx[pos] = b;
+      }
+    } else if (over) {
+      flag[b] = 1;
+    }
+  }
+  const int per = (n + 3) / 4;  // <= 512
+  const int lo = w * per;
+  const int nw = lo >= n ? 0 : (n - lo < per ? n - lo : per);
+  const int* cb = cand + b * cap + lo;
+  const float* pps = (prev_s && w == 0) ? prev_s + b * k : nullptr;
+  const int64_t* ppi = (prev_i && w == 0) ? prev_i + b * k : nullptr;
+#define RG_RESCORE(NS_) rescore_query<D, NS_>(qs, Kn, cb, nw, lane, k, 0, pps, ppi, ps[w], pi[w])
+  if (nw <= 64) RG_RESCORE(1);
+  else if (nw <= 128) RG_RESCORE(2);
+  else if (nw <= 256) RG_RESCORE(4);
+  else RG_RESCORE(8);
+#undef RG_RESCORE
+  __syncthreads();
+  if (w == 0) {  // 4 k <= 128 partial winners: two per lane
+    float s[2];
+    int64_t id[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = lane + 64 * u;
+      const bool have = e < 4 * k;
+      s[u] = have ? ps[e / k][e % k] : RG_NEG_INF;
+      id[u] = have ? pi[e / k][e % k] : INT64_MAX;
+    }
+    wave_select<2>(s, id, k, lane, final_level ? idx_base : 0, out_s + b * k, out_i + b * k);
+  }
 }
 
 static int filter_device_cus() {
@@ -723,8 +804,8 @@ extern "C" size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_
 
 // One filter level: thresholds from the exact scores in out_scores, bf16 filter over keys [key0, key1), rescoring
 // (+ merge with out_* when `merge`).
-template <int D>
-static int run_filter_level(const float* Qn, const float* Kn, const uint16_t* Kb, int64_t B, int64_t key0, int64_t key1,
+template <int D, int QW>
+static int run_filter_level_qw(const float* Qn, const float* Kn, const uint16_t* Kb, int64_t B, int64_t key0, int64_t key1,
                             int k, int64_t idx_base, int first, int merge, int final_level, float* out_scores,
                             int64_t* out_idx, int* overflow, int64_t* overflow_idx, float* thr, const float* eq,
                             const unsigned* max_kerr2, int* count, unsigned char* flag, int* cand, int cap, int level,
@@ -747,7 +828,7 @@ static int run_filter_level(const float* Qn, const float* Kn, const uint16_t* Kb
   p.N = key1;
   p.cap = cap;
   p.stage_base = key0 / C::STAGE_KEYS;  // key0 is a multiple of 256
-  p.qtiles = cdiv(B, C::QT);
+  p.qtiles = cdiv(B, (int64_t)C::WAVES * QW);
   p.nstages_total = cdiv(key1 - key0, C::STAGE_KEYS);
   const int CUS = filter_device_cus();
   p.xcd_map = p.qtiles >= 64 ? 1 : 0;
@@ -760,9 +841,9 @@ static int run_filter_level(const float* Qn, const float* Kn, const uint16_t* Kb
     if (nq < 1 || (v == 1 && (!p.xcd_map || p.qtiles % 8 == 0))) continue;
     p.depth[v] = SegmentWalker::choose_depth(nq, p.nstages_total, p.wgs_per_group, p.lb_min, 0).depth;
   }
-  static bool attr_set = false;  // per D (template instance)
+  static bool attr_set = false;  // per template instance
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_filter_kernel<D>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_filter_kernel<D, QW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     if (e != hipSuccess) {
       set_error("topk_cosine_filtered: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
@@ -771,7 +852,7 @@ static int run_filter_level(const float* Qn, const float* Kn, const uint16_t* Kb
     attr_set = true;
   }
   if (g_prof_on) (void)hipEventRecord(g_prof_ev[2 * level], st);
-  hipLaunchKernelGGL(topk_filter_kernel<D>, dim3((unsigned)CUS), dim3(C::THREADS), C::LDS_BYTES, st, p);
+  hipLaunchKernelGGL((topk_filter_kernel<D, QW>), dim3((unsigned)CUS), dim3(C::THREADS), C::LDS_BYTES, st, p);
   if (g_prof_on) {
     (void)hipEventRecord(g_prof_ev[2 * level + 1], st);
     g_prof_have = level + 1;
@@ -792,13 +873,30 @@ static int run_filter_level(const float* Qn, const float* Kn, const uint16_t* Kb
   }
 #endif
   // exact rescoring (+ merge) + canonical selection
-  dim3 grid((unsigned)cdiv(B, 4)), block(256);
   const float* ps = merge ? out_scores : nullptr;
   const int64_t* pi = merge ? out_idx : nullptr;
-  hipLaunchKernelGGL((topk_rescore_kernel<D, 32>), grid, block, 0, st, Qn, Kn, count, cand, B, cap, k, idx_base, ps, pi,
-                     final_level, out_scores, out_idx, overflow, overflow_idx, flag);
+  if (B < 4096)  // too few queries to fill the chip with one wave each
+    hipLaunchKernelGGL(topk_rescore_wide_kernel<D>, dim3((unsigned)B), dim3(256), 0, st, Qn, Kn, count, cand, B, cap, k,
+                       idx_base, ps, pi, final_level, out_scores, out_idx, overflow, overflow_idx, flag);
+  else
+    hipLaunchKernelGGL((topk_rescore_kernel<D, 32>), dim3((unsigned)cdiv(B, 4)), dim3(256), 0, st, Qn, Kn, count, cand, B,
+                       cap, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, overflow_idx, flag);
   RG_CHECK_LAUNCH("topk_cosine_filtered(rescore)");
   return RAGRAPH_OK;
+}
+
+// Batches of <= 256 queries take the one-group kernel (query tile 256): half the matrix work per stage.
+template <int D>
+static int run_filter_level(const float* Qn, const float* Kn, const uint16_t* Kb, int64_t B, int64_t key0, int64_t key1,
+                            int k, int64_t idx_base, int first, int merge, int final_level, float* out_scores,
+                            int64_t* out_idx, int* overflow, int64_t* overflow_idx, float* thr, const float* eq,
+                            const unsigned* max_kerr2, int* count, unsigned char* flag, int* cand, int cap, int level,
+                            hipStream_t st) {
+  if (B <= 256)
+    return run_filter_level_qw<D, 32>(Qn, Kn, Kb, B, key0, key1, k, idx_base, first, merge, final_level, out_scores, out_idx,
+                                      overflow, overflow_idx, thr, eq, max_kerr2, count, flag, cand, cap, level, st);
+  return run_filter_level_qw<D, 64>(Qn, Kn, Kb, B, key0, key1, k, idx_base, first, merge, final_level, out_scores, out_idx,
+                                    overflow, overflow_idx, thr, eq, max_kerr2, count, flag, cand, cap, level, st);
 }
 
 template <int D>

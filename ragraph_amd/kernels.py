@@ -133,11 +133,12 @@ def keys_to_bf16(keys_normalized: torch.Tensor) -> torch.Tensor:
 
 def filter_helps(B: int, n_keys: int, D: int, k: int) -> bool:
     """True when the bf16-filtered exact top-k is the faster way to the same bits.  Measured on MI355X (ms, filtered vs
-    fp32 kernels): 64 queries x 1M keys 0.57 vs 0.75, 300 x 1M 0.67 vs 2.57, 4096 x 65536 0.83 vs 1.53, 100k x 1M 51 vs
-    366; the fp32 kernels win below ~5e7 query-key pairs (32 x 1M: 0.54 vs 0.48; 256 x 100k: 0.43 vs 0.38)."""
+    fp32 kernels, D = 256, k = 10): 16 queries x 1M keys 0.28 vs 0.32, 64 x 1M 0.33 vs 0.77, 256 x 1M 0.37 vs 1.56,
+    4096 x 1M 2.0 vs 16.0, 100k x 1M 45 vs 366; 16 x 65536 0.135 vs 0.155, 1024 x 65536 0.23 vs 0.59.  One to a dozen
+    queries stay on the streaming fp32 kernel (1 x 1M: 0.21 vs 0.25), small banks on the tile kernel."""
     if os.environ.get("RAGRAPH_EXACT_FP32") == "1":  # e.g. under HIP-graph capture: the filtered call reads a count back
         return False
-    return D in (64, 128, 256) and k <= 32 and B >= 48 and n_keys >= 65536 and B * n_keys * D >= 48_000_000 * 256
+    return D in (64, 128, 256) and k <= 32 and B >= 12 and n_keys >= 65536
 
 
 def topk_cosine_filtered(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf16: torch.Tensor, k: int,

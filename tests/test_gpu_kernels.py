@@ -413,23 +413,29 @@ def test_topk_cosine_filtered_overflow_falls_back(dev):
 
 
 def test_key_index_dispatch_same_bits(dev, monkeypatch):
-    """KeyIndex picks the kernel by shape (streaming, tile + packed copy, bf16-filtered): every choice returns the bits
-    of the oracle, and RAGRAPH_EXACT_FP32=1 keeps a call on the fp32 kernels."""
+    """KeyIndex picks the kernel by shape (streaming, tile + packed copy, bf16-filtered with one or two query groups per
+    wave and the slab or tile-kernel level 0): every choice returns the bits of the oracle, and RAGRAPH_EXACT_FP32=1
+    keeps a call on the fp32 kernels."""
     from ragraph_amd import kernels as K
 
     rng = _rng(99)
     kn = _bank(rng, 70000, 256)
     knd = _t(kn, dev)
     index = K.KeyIndex(knd)
-    for B in (3, 200, 800):  # 800 x 70000 pairs: filtered; 200: tile kernel with the packed copy; 3: streaming kernel
+    for B in (3, 40, 200, 800):  # 3: streaming fp32 kernel; the others: filtered (<= 256: one query group per wave)
         q = rng.standard_normal((B, 256), dtype=np.float32)
-        assert K.filter_helps(B, 70000, 256, 10) == (B == 800)
+        assert K.filter_helps(B, 70000, 256, 10) == (B >= 12)
         s, i = index.topk(_t(q, dev), 10, idx_base=4)
         rs, ri = cref.topk_cosine(q, kn, 10, idx_base=4)
         assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs)
-    assert index._bf16 is not None and index._packed is not None
+    assert index._bf16 is not None
     monkeypatch.setenv("RAGRAPH_EXACT_FP32", "1")
     assert not K.filter_helps(800, 70000, 256, 10)
+    q = rng.standard_normal((200, 256), dtype=np.float32)  # tile kernel with the packed copy
+    s, i = index.topk(_t(q, dev), 10, idx_base=4)
+    rs, ri = cref.topk_cosine(q, kn, 10, idx_base=4)
+    assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs)
+    assert index._packed is not None
 
 
 def test_topk_cosine_filtered_fuzz_against_oracle(dev):
@@ -439,9 +445,9 @@ def test_topk_cosine_filtered_fuzz_against_oracle(dev):
     from ragraph_amd import kernels as K
 
     rng = np.random.default_rng(4242)
-    for trial in range(14):
-        B = int(rng.choice([1, 37, 300, 513, 900, 1500]))
-        N = int(rng.choice([300, 1000, 4100, 16500, 20001, 40000, 70003]))
+    for trial in range(20):
+        B = int(rng.choice([1, 13, 37, 256, 300, 513, 900, 1500]))
+        N = int(rng.choice([300, 1000, 4100, 16500, 20001, 40000, 70003, 140001]))
         k = int(rng.choice([1, 2, 5, 10, 17, 32]))
         D = int(rng.choice([64, 128, 256, 256]))
         keys = rng.standard_normal((N, D), dtype=np.float32)

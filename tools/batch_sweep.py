@@ -41,6 +41,8 @@ print(f"bank {N} x {D}, k = {k}")
 print(f"{'B':>7} {'path':>9} {'ms':>9} {'q/s':>10} {'bank GB/s':>10} {'TFLOP/s':>8}   {'fp32 ms':>9} {'speed-up':>8}  bound (fraction)")
 for B in BS:
     q = torch.randn(B, D, device=dev)
+    if os.environ.get("SWEEP_FORCE_FILTER"):  # crossover hunting: the filtered path whatever filter_helps says
+        K.filter_helps = lambda *a, **kw: True
     filtered = K.filter_helps(B, N, D, k)
     ms = timed(lambda: index.topk(q, k), B)
     kp = index._packed if K.packed_keys_help(B, D, k) else None
