@@ -99,8 +99,9 @@ int ragraph_topk_cosine_bank_f32(const float* Q, int64_t B, const float* Kn, con
  *   |dq| max|dk| (+ rounding slack) is computed from the actual bf16 rounding errors dq of the query and dk of the bank
  *   rows (<= 2^-7, typically 0.003): by Cauchy-Schwarz no pair's dot product moves by more; (3) the survivors (~100 per query) are
  *   rescored with the natural-order fp32 fmaf chain and selected in canonical order, which gives the exact top-k of
- *   everything seen so far and a tighter bound for the next level ([0,N/32), [N/32,N/4), [N/4,N)).  The result has the
- *   same bits as ragraph_topk_cosine_f32.  D in {64,128,256}, k <= 32.
+ *   everything seen so far and a tighter bound for the next level (large batches: [0,N/32), [N/32,N/4), [N/4,N); small
+ *   ones: fewer, steeper levels -- ragraph_topk_cosine_filtered_plan).  The result has the same bits as
+ *   ragraph_topk_cosine_f32.  D in {64,128,256}, k <= 32.
  *   Kb   bf16 copy of Kn made by ragraph_keys_to_bf16 (ragraph_keys_bf16_rows(N) rows x D, uint16 storage).
  *   Kp   optional packed fp32 copy (ragraph_pack_keys_f32) for the fp32 level, or NULL.
  *   overflow  device int, set by the call: number of queries whose candidate list exceeded its capacity
@@ -113,6 +114,12 @@ int64_t ragraph_keys_bf16_rows(int64_t N);
 int ragraph_keys_to_bf16(const float* Kn, int64_t N, int D, uint16_t* Kb, void* stream);
 int ragraph_topk_cosine_filtered_cap(int k);
 size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_t N, int D, int k);
+/* The schedule the call above will follow for this shape (host-side arithmetic only, no device work):
+ * plan[0] = n0 (level 0: exact top-k over keys [0, n0)), plan[1] = 1 if level 0 is a score slab (dense kernel +
+ * row top-k) rather than the tile kernel, plan[2] = number of filter levels L (1..3), plan[3..3+L) = their ends
+ * (increasing multiples of 256, the last = N; level l filters [end[l-1], end[l]), the first starts at 0).
+ * Returns L, or a negative error code. */
+int ragraph_topk_cosine_filtered_plan(int64_t B, int64_t N, int D, int k, int64_t plan[6]);
 int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const float* Kn, const float* Kp, const uint16_t* Kb,
                                      int64_t N, int D, int k, int64_t idx_base, float* out_scores, int64_t* out_idx,
                                      int* overflow, int64_t* overflow_idx, void* ws, size_t ws_bytes, void* stream);

@@ -803,6 +803,18 @@ extern "C" size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_
          align_up((size_t)B * cap * sizeof(int), 256);
 }
 
+extern "C" int ragraph_topk_cosine_filtered_plan(int64_t B, int64_t N, int D, int k, int64_t plan[6]) {
+  RG_REQUIRE(plan, RAGRAPH_EINVAL, "topk_cosine_filtered_plan: null pointer");
+  RG_REQUIRE(filter_dim_ok(D), RAGRAPH_EUNSUPPORTED, "topk_cosine_filtered_plan: D=%d not in {64,128,256}", D);
+  RG_REQUIRE(B >= 1 && N >= 1 && k >= 1 && k <= 32 && k <= N, RAGRAPH_EINVAL, "topk_cosine_filtered_plan: bad B/N/k");
+  const FilterSchedule sc = filter_schedule(B, N, D, k);
+  plan[0] = sc.n0;
+  plan[1] = sc.slab0;
+  plan[2] = sc.nlev;
+  for (int l = 0; l < FILTER_MAX_LEVELS; ++l) plan[3 + l] = l < sc.nlev ? sc.ends[l] : 0;
+  return sc.nlev;
+}
+
 // One filter level: thresholds from the exact scores in out_scores, bf16 filter over keys [key0, key1), rescoring
 // (+ merge with out_* when `merge`).
 template <int D, int QW>

@@ -44,6 +44,43 @@ def test_pure_host_entry_points_work_without_gpu():
     assert rc == N.EINVAL and b"null" in L.ragraph_last_error()
 
 
+def test_filtered_topk_plan_is_well_formed():
+    """Schedule of the bf16-filtered exact top-k (host arithmetic, include/ragraph_hip.h): for every shape the levels
+    partition [0, N) in increasing multiples of 256 that start behind the exact sample, a level's expected candidates
+    (1.3 k x its end / the previous end) stay inside the per-query list, and the workspace covers a slab level 0."""
+    from ragraph_amd import _native as N
+
+    L = N.lib()
+    plan = (ctypes.c_int64 * 6)()
+    cap = L.ragraph_topk_cosine_filtered_cap(10)
+    seen_levels = set()
+    for B in (1, 12, 40, 256, 257, 512, 1024, 4096, 16384, 16385, 100_000):
+        for Nk in (4096, 16384, 65536, 70_003, 1_000_000, 4_000_000, 8_000_000, 100_000_000):
+            for D in (64, 256):
+                for k in (1, 10, 32):
+                    nlev = L.ragraph_topk_cosine_filtered_plan(B, Nk, D, k, plan)
+                    n0, slab0, nl = plan[0], plan[1], plan[2]
+                    ends = [plan[3 + i] for i in range(nl)]
+                    assert nlev == nl and 1 <= nl <= 3, (B, Nk, D, k)
+                    assert k <= n0 <= Nk
+                    assert ends[-1] == Nk and all(e % 256 == 0 for e in ends[:-1])
+                    assert all(a < b for a, b in zip(ends, ends[1:])) and (nl == 1 or n0 < ends[0])
+                    if Nk >= 65536:  # the shapes KeyIndex sends here
+                        prev = n0
+                        for e in ends:
+                            assert 1.3 * k * e / prev <= cap, (B, Nk, D, k, n0, ends)
+                            prev = e
+                    if slab0:
+                        assert B <= 16384
+                        assert L.ragraph_topk_cosine_filtered_workspace_bytes(B, Nk, D, k) >= B * n0 * 4 + B * cap * 4
+                    seen_levels.add(nl)
+    assert seen_levels == {1, 2, 3}
+    assert L.ragraph_topk_cosine_filtered_plan(100, 1000, 100, 3, plan) < 0  # unsupported D
+    # the bench shape keeps the three-level schedule the measurements in DESIGN.md describe
+    assert L.ragraph_topk_cosine_filtered_plan(100_000, 1_000_000, 256, 10, plan) == 3
+    assert list(plan) == [4096, 0, 3, 31488, 250112, 1_000_000]
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
 def test_no_silent_fallback_without_device():
     from ragraph_amd import kernels as K
