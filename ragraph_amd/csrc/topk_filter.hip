@@ -487,10 +487,55 @@ __device__ __forceinline__ void wave_select(const float (&s)[NSL], const int64_t
 
 // Rescoring of one query by one wave with NS candidate slots per lane (n <= 64 * NS reserved slots): exact scores (one
 // lane per candidate, the k = 0..D-1 fmaf chain from +0), merge with the previous level's winners, canonical top-k.
+constexpr int RESCORE_LD = 68;  // floats per staged row: 16-B aligned, and 16 lanes x ds_read_b128 hit 64 distinct banks
+
+// Exact scores of 64 candidates (lane l: key `key`, -1 = none) with the rows fetched COOPERATIVELY: a load instruction
+// covers four rows x 256 B (16 lanes per row, coalesced) instead of one 16-B piece of 64 different rows, which is what
+// the texture path's line rate pays for; the 64 x 64-float block goes through the wave's LDS tile and every lane then
+// runs its own candidate's fmaf chain over it in natural order -- the same chain, so the same bits.
+template <int D>
+__device__ __forceinline__ float coop_scores(const float4* __restrict__ qrow, const float* __restrict__ Kn, int key,
+                                             int lane, float* sm) {
+  float acc = 0.f;
+  const int rr = lane >> 4, cc = lane & 15;
+#pragma unroll 1
+  for (int dc = 0; dc < D / 64; ++dc) {
+    float4 v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int kr = __shfl(key, 4 * t + rr);
+      v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kr >= 0) v[t] = *reinterpret_cast<const float4*>(Kn + (int64_t)kr * D + dc * 64 + cc * 4);
+    }
+    __builtin_amdgcn_wave_barrier();  // (single wave: LDS executes its requests in order; only the compiler must not reorder)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) *reinterpret_cast<float4*>(sm + (4 * t + rr) * RESCORE_LD + cc * 4) = v[t];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int e4 = 0; e4 < 16; ++e4) {
+      const float4 kv = *reinterpret_cast<const float4*>(sm + lane * RESCORE_LD + e4 * 4);
+      const float4 qv = qrow[dc * 16 + e4];
+      acc = fmaf(qv.x, kv.x, acc);
+      acc = fmaf(qv.y, kv.y, acc);
+      acc = fmaf(qv.z, kv.z, acc);
+      acc = fmaf(qv.w, kv.w, acc);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  return acc;
+}
+
+// Rescoring of one query by one wave with NS candidate slots per lane (n <= 64 * NS reserved slots): exact scores (one
+// lane per candidate, the k = 0..D-1 fmaf chain from +0), merge with the previous level's winners, canonical top-k.
+// `sm` != nullptr: rows staged through that LDS tile (coop_scores); else every lane reads its own row.
 template <int D, int NS>
 __device__ __forceinline__ void rescore_query(const float4* __restrict__ qrow, const float* __restrict__ Kn,
                                               const int* __restrict__ cand, int n, int lane, int k, int64_t base,
-                                              const float* prev_s, const int64_t* prev_i, float* out_s, int64_t* out_i) {
+                                              const float* prev_s, const int64_t* prev_i, float* out_s, int64_t* out_i,
+                                              float* sm = nullptr) {
   float s[NS + 1];
   int64_t id[NS + 1];
   // the previous level's winners ride along as already-scored candidates (lane l holds entry l; k <= 32)
@@ -506,7 +551,15 @@ __device__ __forceinline__ void rescore_query(const float4* __restrict__ qrow, c
     s[u] = RG_NEG_INF;
     id[u] = INT64_MAX;
     const int key = c < n ? cand[c] : -1;
-    if (key >= 0) {
+    if (sm) {
+      if (64 * u < n) {  // wave-uniform
+        const float acc = coop_scores<D>(qrow, Kn, key, lane, sm);
+        if (key >= 0) {
+          s[u] = acc;
+          id[u] = key;
+        }
+      }
+    } else if (key >= 0) {
       const float4* kr = reinterpret_cast<const float4*>(Kn + (int64_t)key * D);
       float acc = 0.f;
 #pragma unroll 8
@@ -562,6 +615,52 @@ __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restri
   const int64_t* pi = prev_i ? prev_i + b * k : nullptr;
   const int* cb = cand + b * cap;
 #define RG_RESCORE(NS_) rescore_query<D, NS_>(qs[w], Kn, cb, n, lane, k, base, ps, pi, out_s + b * k, out_i + b * k)
+  if (n <= 64) RG_RESCORE(1);
+  else if (n <= 128) RG_RESCORE(2);
+  else if (n <= 256) RG_RESCORE(4);
+  else if (n <= 512) RG_RESCORE(8);
+  else RG_RESCORE(CPL);
+#undef RG_RESCORE
+}
+
+// Large batches: as topk_rescore_kernel, rows staged through LDS (coop_scores); two waves per workgroup.
+template <int D, int CPL>
+__global__ void __launch_bounds__(128) topk_rescore_coop_kernel(const float* __restrict__ Qn, const float* __restrict__ Kn,
+                                                                const int* __restrict__ count,
+                                                                const int* __restrict__ cand, int64_t B, int cap, int k,
+                                                                int64_t idx_base, const float* prev_s,
+                                                                const int64_t* prev_i, int final_level, float* out_s,
+                                                                int64_t* out_i, int* __restrict__ overflow,
+                                                                int64_t* __restrict__ overflow_idx,
+                                                                unsigned char* __restrict__ flag) {
+  __shared__ float4 qs[2][D / 4];
+  __shared__ __attribute__((aligned(16))) float tile[2][64 * RESCORE_LD];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 2 + w;
+  if (b >= B) return;  // whole wave
+  if (lane < D / 4) qs[w][lane] = reinterpret_cast<const float4*>(Qn + b * D)[lane];
+  __builtin_amdgcn_wave_barrier();
+  int n = count[b];
+  bool over = flag[b] != 0;
+  if (n > cap) {
+    over = true;
+    n = cap;
+  }
+  if (lane == 0) {
+    if (final_level) {
+      if (over) {
+        const int pos = atomicAdd(overflow, 1);
+        if (overflow_idx) overflow_idx[pos] = b;
+      }
+    } else if (over) {
+      flag[b] = 1;
+    }
+  }
+  const int64_t base = final_level ? idx_base : 0;
+  const float* ps = prev_s ? prev_s + b * k : nullptr;
+  const int64_t* pi = prev_i ? prev_i + b * k : nullptr;
+  const int* cb = cand + b * cap;
+#define RG_RESCORE(NS_) rescore_query<D, NS_>(qs[w], Kn, cb, n, lane, k, base, ps, pi, out_s + b * k, out_i + b * k, tile[w])
   if (n <= 64) RG_RESCORE(1);
   else if (n <= 128) RG_RESCORE(2);
   else if (n <= 256) RG_RESCORE(4);
@@ -631,6 +730,14 @@ __global__ void __launch_bounds__(256) topk_rescore_wide_kernel(const float* __r
     }
     wave_select<2>(s, id, k, lane, final_level ? idx_base : 0, out_s + b * k, out_i + b * k);
   }
+}
+
+static bool rescore_coop() {  // RAGRAPH_RESCORE_COOP=0: every lane reads its own row (A/B)
+  static const bool on = [] {
+    const char* e = getenv("RAGRAPH_RESCORE_COOP");
+    return !(e && atoi(e) == 0);
+  }();
+  return on;
 }
 
 static int filter_device_cus() {
@@ -891,6 +998,9 @@ static int run_filter_level_qw(const float* Qn, const float* Kn, const uint16_t*
   if (B < 4096)  // too few queries to fill the chip with one wave each
     hipLaunchKernelGGL(topk_rescore_wide_kernel<D>, dim3((unsigned)B), dim3(256), 0, st, Qn, Kn, count, cand, B, cap, k,
                        idx_base, ps, pi, final_level, out_scores, out_idx, overflow, overflow_idx, flag);
+  else if (rescore_coop())
+    hipLaunchKernelGGL((topk_rescore_coop_kernel<D, 32>), dim3((unsigned)cdiv(B, 2)), dim3(128), 0, st, Qn, Kn, count, cand,
+                       B, cap, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, overflow_idx, flag);
   else
     hipLaunchKernelGGL((topk_rescore_kernel<D, 32>), dim3((unsigned)cdiv(B, 4)), dim3(256), 0, st, Qn, Kn, count, cand, B,
                        cap, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, overflow_idx, flag);
