@@ -530,8 +530,8 @@ __device__ __forceinline__ float coop_scores(const float4* __restrict__ qrow, co
 
 // Rescoring of one query by one wave with NS candidate slots per lane (n <= 64 * NS reserved slots): exact scores (one
 // lane per candidate, the k = 0..D-1 fmaf chain from +0), merge with the previous level's winners, canonical top-k.
-// `sm` != nullptr: rows staged through that LDS tile (coop_scores); else every lane reads its own row.
-template <int D, int NS>
+// COOP: rows staged through the LDS tile `sm` (coop_scores); else every lane reads its own row.
+template <int D, int NS, bool COOP = false>
 __device__ __forceinline__ void rescore_query(const float4* __restrict__ qrow, const float* __restrict__ Kn,
                                               const int* __restrict__ cand, int n, int lane, int k, int64_t base,
                                               const float* prev_s, const int64_t* prev_i, float* out_s, int64_t* out_i,
@@ -551,7 +551,7 @@ __device__ __forceinline__ void rescore_query(const float4* __restrict__ qrow, c
     s[u] = RG_NEG_INF;
     id[u] = INT64_MAX;
     const int key = c < n ? cand[c] : -1;
-    if (sm) {
+    if constexpr (COOP) {
       if (64 * u < n) {  // wave-uniform
         const float acc = coop_scores<D>(qrow, Kn, key, lane, sm);
         if (key >= 0) {
@@ -660,12 +660,13 @@ __global__ void __launch_bounds__(128) topk_rescore_coop_kernel(const float* __r
   const float* ps = prev_s ? prev_s + b * k : nullptr;
   const int64_t* pi = prev_i ? prev_i + b * k : nullptr;
   const int* cb = cand + b * cap;
-#define RG_RESCORE(NS_) rescore_query<D, NS_>(qs[w], Kn, cb, n, lane, k, base, ps, pi, out_s + b * k, out_i + b * k, tile[w])
-  if (n <= 64) RG_RESCORE(1);
-  else if (n <= 128) RG_RESCORE(2);
-  else if (n <= 256) RG_RESCORE(4);
-  else if (n <= 512) RG_RESCORE(8);
-  else RG_RESCORE(CPL);
+#define RG_RESCORE(NS_, COOP_) \
+  rescore_query<D, NS_, COOP_>(qs[w], Kn, cb, n, lane, k, base, ps, pi, out_s + b * k, out_i + b * k, tile[w])
+  if (n <= 64) RG_RESCORE(1, true);
+  else if (n <= 128) RG_RESCORE(2, true);
+  else if (n <= 256) RG_RESCORE(4, true);
+  else if (n <= 512) RG_RESCORE(8, false);  // long lists are rare: the plain form keeps the kernel out of scratch
+  else RG_RESCORE(CPL, false);
 #undef RG_RESCORE
 }
 
