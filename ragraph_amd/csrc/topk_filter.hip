@@ -204,8 +204,8 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     // the loop around it)
     const uint64_t goff = (uint64_t)stage_abs * C::STAGE_BYTES + (uint64_t)(C::DMAS * wave * 1024);
     const char* gbase = reinterpret_cast<const char*>(p.Kb) +
-                        (((uint64_t)__builtin_amdgcn_readfirstlane((unsigned)(goff >> 32)) << 32) |
-                         (uint64_t)__builtin_amdgcn_readfirstlane((unsigned)goff));
+                        (((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(goff >> 32)) << 32) |
+                         (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)goff));  // (returns int: no sign extension)
 #pragma unroll
     for (int i = 0; i < C::DMAS; ++i) {
       const unsigned dst = lds_base + (unsigned)(slot * C::STAGE_BYTES + (C::DMAS * wave + i) * 1024);

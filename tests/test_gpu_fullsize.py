@@ -129,6 +129,33 @@ def test_filtered_topk_matches_fp32_kernel_at_full_size(dev):
     s1, i1, over = K.topk_cosine_filtered(q, kn, K.keys_to_bf16(kn), 10, idx_base=5, keys_packed=K.pack_keys(kn))
     s0, i0 = K.topk_cosine(q, kn, 10, idx_base=5)
     assert torch.equal(i0, i1) and torch.equal(s0, s1)
+    assert over == 0  # an ordinary bank never needs the overflow path
     rows = torch.arange(0, 20_000, 1250)
     rs, ri = cref.topk_cosine(q[rows].cpu().numpy(), kn.cpu().numpy(), 10, idx_base=5)
     assert np.array_equal(i1[rows].cpu().numpy(), ri) and np.array_equal(s1[rows].cpu().numpy(), rs)
+
+
+@pytest.mark.gpu
+def test_filtered_topk_beyond_2gib_of_bf16_keys(dev):
+    """4.5M x 256 keys: the bf16 copy (2.3 GB) and the fp32 / packed copies (4.6 GB each) cross the 2^31- and 2^32-byte
+    marks, where a 32-bit or sign-extended offset in a kernel's address arithmetic would read the wrong rows (seen once:
+    a readfirstlane'd low word sign-extended into the DMA base).  All three exact paths must agree bit for bit, without
+    the overflow fallback, and the winners must really come from the whole bank."""
+    from ragraph_amd import kernels as K
+
+    g = torch.Generator(device=dev).manual_seed(12)
+    n = 4_500_000
+    kn = K.normalize_rows(torch.randn(n, 256, device=dev, generator=g))
+    kb, kp = K.keys_to_bf16(kn), K.pack_keys(kn)
+    for B in (16, 300, 700):  # one query group per wave / two; streaming vs tile fp32 kernel; wide rescoring
+        q = torch.randn(B, 256, device=dev, generator=g)
+        q[0] = kn[n - 1] + 0.01 * q[0]   # its best key is the bank's last row
+        q[1] = kn[n // 2 + 77]           # ... and one just past the 2 GiB mark of the bf16 copy
+        s1, i1, over = K.topk_cosine_filtered(q, kn, kb, 10, idx_base=3)
+        s0, i0 = K.topk_cosine(q, kn, 10, idx_base=3)
+        assert over == 0
+        assert torch.equal(i0, i1) and torch.equal(s0, s1)
+        if K.packed_keys_help(B, 256, 10):
+            s2, i2 = K.topk_cosine(q, kn, 10, idx_base=3, keys_packed=kp)
+            assert torch.equal(i0, i2) and torch.equal(s0, s2)
+        assert int(i1[0, 0]) == n - 1 + 3 and int(i1[1, 0]) == n // 2 + 77 + 3
