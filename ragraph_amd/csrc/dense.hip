@@ -17,8 +17,8 @@ __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ X
                                                      const float* __restrict__ W, int64_t N,
                                                      const float* __restrict__ bias, int act, float alpha,
                                                      float* __restrict__ Y) {
-  __shared__ float As[LBM * LLD];
-  __shared__ float Bs[LBN * LLD];
+  __shared__ float As[2][LBM * LLD];
+  __shared__ float Bs[2][LBN * LLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
@@ -29,22 +29,44 @@ __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ X
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  for (int k0 = 0; k0 < K; k0 += LKC) {
-    // stage: 64 x 32 of X and of W, zero-padded outside (0*0 leaves a chain unchanged)
+  // stage: 64 x 32 of X and of W per chunk, zero-padded outside (0*0 leaves a chain unchanged).  The next chunk's 16
+  // values per thread are in flight under the current chunk's MFMAs and written to the other buffer behind them: one
+  // barrier per chunk and no exposed load latency (the GCN encode of a Cora-sized graph, K = 1433, is 45 chunks on 86
+  // workgroups -- with load, barrier, MFMA, barrier in sequence it was 223 us of a 475 us forward).
+  constexpr int PER = (LBM * LKC) / 256;
+  float ra[PER], rb[PER];
+  auto gload = [&](int k0) {
 #pragma unroll
-    for (int u = 0; u < (LBM * LKC) / 256; ++u) {
+    for (int u = 0; u < PER; ++u) {
       const int e = tid + u * 256;
       const int row = e / LKC, c = e % LKC;
       const int kk = k0 + c;
       const int64_t gm = m0 + row, gn = n0 + row;
-      As[row * LLD + c] = (gm < M && kk < K) ? X[gm * K + kk] : 0.f;
-      Bs[row * LLD + c] = (gn < N && kk < K) ? W[gn * K + kk] : 0.f;
+      ra[u] = (gm < M && kk < K) ? X[gm * K + kk] : 0.f;
+      rb[u] = (gn < N && kk < K) ? W[gn * K + kk] : 0.f;
     }
-    __syncthreads();
-    const float* a = As + (wr * 32 + j) * LLD + h;
-    const float* b = Bs + (wc * 32 + j) * LLD + h;
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + u * 256;
+      const int row = e / LKC, c = e % LKC;
+      As[buf][row * LLD + c] = ra[u];
+      Bs[buf][row * LLD + c] = rb[u];
+    }
+  };
+  const int nch = (K + LKC - 1) / LKC;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int ch = 0; ch < nch; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nch) gload((ch + 1) * LKC);
+    const float* a = As[buf] + (wr * 32 + j) * LLD + h;
+    const float* b = Bs[buf] + (wc * 32 + j) * LLD + h;
 #pragma unroll
     for (int kk = 0; kk < LKC / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * kk], b[2 * kk], acc, 0, 0, 0);
+    if (ch + 1 < nch) sstore(buf ^ 1);  // (its last readers passed the barrier that ended chunk ch - 1)
     __syncthreads();
   }
 

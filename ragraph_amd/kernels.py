@@ -136,8 +136,10 @@ def filter_helps(B: int, n_keys: int, D: int, k: int) -> bool:
     fp32 kernels, D = 256, k = 10): 16 queries x 1M keys 0.28 vs 0.32, 64 x 1M 0.33 vs 0.77, 256 x 1M 0.37 vs 1.56,
     4096 x 1M 2.0 vs 16.0, 100k x 1M 45 vs 366; 16 x 65536 0.135 vs 0.155, 1024 x 65536 0.23 vs 0.59.  One to a dozen
     queries stay on the streaming fp32 kernel (1 x 1M: 0.21 vs 0.25), small banks on the tile kernel."""
-    if os.environ.get("RAGRAPH_EXACT_FP32") == "1":  # e.g. under HIP-graph capture: the filtered call reads a count back
+    if os.environ.get("RAGRAPH_EXACT_FP32") == "1":
         return False
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return False  # the filtered call reads its overflow count back: not capturable, the fp32 kernels are
     return D in (64, 128, 256) and k <= 32 and B >= 12 and n_keys >= 65536
 
 

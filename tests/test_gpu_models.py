@@ -296,7 +296,9 @@ def test_graph_flavour_batched_equals_per_graph(dev):
 
 def test_forward_is_hip_graph_capturable(dev):
     """The C ABI allocates nothing and never synchronises, so a whole small forward (a dozen launches, launch-bound at
-    the reference's scale) can be captured once into a HIP graph and replayed."""
+    the reference's scale) can be captured once into a HIP graph and replayed.  The bank is large enough for the
+    bf16-filtered retrieval, whose wrapper reads an overflow count back: the dispatch notices the capture and stays on
+    the fp32 kernels there -- eager (filtered) and captured (fp32) results are the same bits."""
     from ragraph_amd.data import DataLoader, synthetic_tu_dataset
     from ragraph_amd.preprompt import PrePrompt
     from ragraph_amd.RAGraph import RAGraph
@@ -306,7 +308,7 @@ def test_forward_is_hip_graph_capturable(dev):
     ds = synthetic_tu_dataset(num_graphs=16, num_node_attributes=18, num_node_labels=3, seed=2)
     pre = PrePrompt(18, 256, "prelu", 1, 0.3).to(dev)
     model = RAGraph(pre, None, 18, 3, 256, device=dev).eval()
-    N = 20000
+    N = 70000
     model.toy_graph_base.add_resources(torch.nn.functional.normalize(torch.randn(N, 256, device=dev), dim=-1),
                                        torch.randn(N, 256, device=dev),
                                        torch.nn.functional.one_hot(torch.randint(0, 3, (N,), device=dev), 3).float())
