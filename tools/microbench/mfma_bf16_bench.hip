@@ -3,6 +3,8 @@
 //   MODE 0: A fragments constant in registers (pure MFMA issue rate, B operands = 128 VGPRs as in the kernel)
 //   MODE 1: A fragments from LDS, hipcc's schedule            MODE 2: + v_max epilogue per sub-tile
 //   MODE 3: A from LDS, asm reads 4 steps ahead + epilogue    MODE 4: MODE 3 with ONE wave per SIMD (256 threads)
+//   MODE 5: 2 x 2 register blocking (two 32-key sub-tiles x two query groups, four accumulators) in snake order, so that
+//           consecutive MFMAs differ in ONE operand only -- does less operand switching buy clock on random data?
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -17,7 +19,7 @@ __global__ void __launch_bounds__(512, 2) k(float* out, int iters, float a) {
   const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
   // RANDOM != 0: operands are pseudo-random bf16 in [-1, 1) (what real unit rows look like to the data path: the chip
   // holds a lower clock on random bits than on near-constant ones)
-  for (int i = threadIdx.x; i < 16384 / 2; i += blockDim.x) {
+  for (int i = threadIdx.x; i < 32768 / 2; i += blockDim.x) {
     unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
     h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
     const float v = RANDOM ? ((int)(h & 0xFFFF) - 32768) * (1.f / 32768.f) : a + i * 1e-7f;
@@ -63,7 +65,7 @@ __global__ void __launch_bounds__(512, 2) k(float* out, int iters, float a) {
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b0[t], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b1[t], acc1, 0, 0, 0);
       }
-    } else {
+    } else if (MODE < 5) {
       f32x4 fr[4];
 #define FREAD(n_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[(n_)&3]) : "v"(addr[(n_)&7]), "i"(((n_) >= 8) ? 256 : 0))
 #define FWAIT(c_, n_) asm volatile("s_waitcnt lgkmcnt(" #c_ ")" : "+v"(fr[(n_)&3]))
@@ -82,7 +84,41 @@ __global__ void __launch_bounds__(512, 2) k(float* out, int iters, float a) {
       FSTEP(0) FSTEP(1) FSTEP(2) FSTEP(3) FSTEP(4) FSTEP(5) FSTEP(6) FSTEP(7)
       FSTEP(8) FSTEP(9) FSTEP(10) FSTEP(11) FSTEP(12) FSTEP(13) FSTEP(14) FSTEP(15)
     }
-    if (MODE >= 2) {
+    if (MODE == 5) {
+      f32x16 acc2, acc3;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[r] = acc3[r] = 0.f;
+      f32x4 fa[4], fb[4];  // sub-tile 0 / sub-tile 1 fragments, two steps in flight
+#define PREAD(n_)                                                                                                  \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[(n_)&1]) : "v"(addr[(n_)&7]), "i"(((n_) >= 8) ? 256 : 0)); \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[(n_)&1]) : "v"(addr[(n_)&7]), "i"(16384 + (((n_) >= 8) ? 256 : 0)))
+#define PSTEP(n_)                                                                          \
+  {                                                                                        \
+    if constexpr ((n_) + 1 < 16) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[(n_)&1]), "+v"(fb[(n_)&1])); \
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[(n_)&1]), "+v"(fb[(n_)&1]));        \
+    const bf16x8 a0_ = __builtin_bit_cast(bf16x8, fa[(n_)&1]);                             \
+    const bf16x8 a1_ = __builtin_bit_cast(bf16x8, fb[(n_)&1]);                             \
+    if constexpr (((n_) & 1) == 0) {                                                       \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b0[n_], acc0, 0, 0, 0);           \
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b0[n_], acc2, 0, 0, 0);           \
+      acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b1[n_], acc3, 0, 0, 0);           \
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b1[n_], acc1, 0, 0, 0);           \
+    } else {                                                                               \
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b1[n_], acc1, 0, 0, 0);           \
+      acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b1[n_], acc3, 0, 0, 0);           \
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b0[n_], acc2, 0, 0, 0);           \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b0[n_], acc0, 0, 0, 0);           \
+    }                                                                                      \
+    if constexpr ((n_) + 2 < 16) { PREAD((n_) + 2); }                                      \
+  }
+      PREAD(0); PREAD(1);
+      PSTEP(0) PSTEP(1) PSTEP(2) PSTEP(3) PSTEP(4) PSTEP(5) PSTEP(6) PSTEP(7)
+      PSTEP(8) PSTEP(9) PSTEP(10) PSTEP(11) PSTEP(12) PSTEP(13) PSTEP(14) PSTEP(15)
+      float m0 = acc0[0], m1 = acc1[0], m2 = acc2[0], m3 = acc3[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) { m0 = fmaxf(m0, acc0[r]); m1 = fmaxf(m1, acc1[r]); m2 = fmaxf(m2, acc2[r]); m3 = fmaxf(m3, acc3[r]); }
+      if (__any(m0 >= 1e30f || m1 >= 1e30f || m2 >= 1e30f || m3 >= 1e30f)) keep += m0 + m1 + m2 + m3;
+    } else if (MODE >= 2) {
       float m0 = acc0[0], m1 = acc1[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) { m0 = fmaxf(m0, acc0[r]); m1 = fmaxf(m1, acc1[r]); }
@@ -113,7 +149,7 @@ void run(const char* name, int threads) {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (ms < best) best = ms;
   }
-  double flop = 256.0 * (threads / 64) * iters * 32.0 * 32768.0;
+  double flop = 256.0 * (threads / 64) * iters * (MODE == 5 ? 64.0 : 32.0) * 32768.0;
   printf("%-60s %8.3f ms  %7.1f TFLOP/s\n", name, best, flop / best / 1e9);
   hipFree(d);
 }
@@ -127,5 +163,8 @@ int main() {
   run<3, 1>("the same on RANDOM operands, 2 waves/SIMD", 512);
   run<3, 1>("the same on RANDOM operands, 1 wave/SIMD", 256);
   run<0, 1>("A in registers, RANDOM B operands, 2 waves/SIMD", 512);
+  run<5, 0>("2x2 blocking, snake order, near-constant operands", 512);
+  run<5, 1>("2x2 blocking, snake order, RANDOM operands", 512);
+  run<3, 1>("(again) 1x2 on RANDOM operands", 512);
   return 0;
 }
