@@ -1,10 +1,11 @@
-// Exact cosine top-k through a bf16 MFMA filter  (SimilarityFunctions.py:6-16 + ToyGraphBase.py:66-67, large batches;
-// D = 64 is the edge flavour's RAGraph_edge/modules/RAGraph.py:298-324).
+// Exact cosine top-k through a bf16 MFMA filter  (SimilarityFunctions.py:6-16 + ToyGraphBase.py:66-67, a dozen queries
+// and up; D = 64 is the edge flavour's RAGraph_edge/modules/RAGraph.py:298-324).
 //
 // The fp32 tile kernel (topk_cosine.hip) spends 2·B·N·D fp32 MFMA flops; the bf16 matrix cores are 16x faster.  This
 // path returns the SAME bits with most of the work on them:
-//   1. level 0 (exact, fp32 kernel): top-k of every query over the first N/256 keys.  Its k-th score theta[q] is a
-//      lower bound of the final k-th best exact score of q.
+//   1. level 0 (exact): top-k of every query over the first n0 keys (large batches: the fp32 tile kernel; up to 16384
+//      queries: a score slab by the dense kernel + topk_rows).  Its k-th score theta[q] is a lower bound of the final
+//      k-th best exact score of q.
 //   2. filter (this file, bf16 MFMA): approximate scores s~ = bf16(q)·bf16(key), fp32 accumulate, over the next, larger
 //      part of the bank.  With q^ = q + dq, k^ = k + dk: |s~ - s| <= |dq||k| + |q||dk| + |dq||dk| + accumulation error
 //      (Cauchy-Schwarz) <= eps(q), computed from the query's actual |dq| and the bank's largest |dk| (<= 2^-7 in the worst
@@ -13,18 +14,21 @@
 //   3. rescoring: the exact score of every candidate as the fp32 fmaf chain in natural k order from +0 (one lane per
 //      candidate) -- the chain the f32 MFMA and the oracle compute, so the same bits -- merged with the previous level's
 //      winners, canonical top-k (score descending, index ascending).  That is the exact top-k of everything seen so far
-//      and a tighter theta for the next level: [0, N/32), [N/32, N/4), [N/4, N).
+//      and a tighter theta for the next level.  The schedule (n0, one to three levels) depends on the batch size:
+//      filter_schedule() below, readable through ragraph_topk_cosine_filtered_plan.
 // A query whose candidate list overflows its capacity (adversarial banks: thousands of keys within eps of the k-th
 // best) is counted in *overflow and must be re-run through ragraph_topk_cosine_bank_f32 by the caller; the other
 // queries' results are exact regardless.
 //
-// Filter kernel: workgroup = 8 waves x 64 queries = 512 queries; a wave keeps its queries as the B operands of
-// v_mfma_f32_32x32x16_bf16 (two groups of 32: 2 x D/4 VGPRs) and streams the bf16 bank (2 D bytes per key) through a
-// 4-slot LDS ring of 32 KiB stages (64 / 128 / 256 keys at D = 256 / 128 / 64) filled by LDS-DMA, 1 KiB per
-// global_load_lds_dwordx4, handed over by FULL/FREE counters.  One ds_read_b128 (8 bf16 of one key row) feeds two MFMAs
-// (one per query group).  The LDS image is XOR-swizzled through the DMA's per-lane SOURCE address (16-B chunk c of row j
-// sits at chunk c ^ f(j)), which makes the ds_read_b128 of 32 rows conflict-free without padding.  Work plan:
-// segment_plan.h with zero warm-up cost (there are no lists): every workgroup gets the same number of stages.
+// Filter kernel: workgroup = 8 waves x 64 queries = 512 queries (x 32 = 256 for batches of <= 256); a wave keeps its
+// queries as the B operands of v_mfma_f32_32x32x16_bf16 (two groups of 32: 2 x D/4 VGPRs) and streams the bf16 bank
+// (2 D bytes per key) through a 4-slot LDS ring of 32 KiB stages (64 / 128 / 256 keys at D = 256 / 128 / 64) filled by
+// LDS-DMA, 1 KiB per global_load_lds_dwordx4, handed over by FULL/FREE counters.  One ds_read_b128 (8 bf16 of one key
+// row) feeds two MFMAs (one per query group).  The LDS image is XOR-swizzled through the DMA's per-lane SOURCE address
+// (16-B chunk c of row j sits at chunk c ^ f(j)), which makes the ds_read_b128 of 32 rows conflict-free without padding.
+// Candidates leave the MFMA stream through wave-private LDS buffers (branch-free pass masks, ballot + mbcnt positions)
+// and reach the per-query lists in global memory in flushes.  Work plan: segment_plan.h with zero warm-up cost (there
+// are no lists): every workgroup gets the same number of stages.
 #include "common.h"
 #include "segment_plan.h"
 #include <cmath>
@@ -51,7 +55,6 @@ template <int D_>
 struct FilterCfg {
   static constexpr int D = D_;
   static constexpr int WAVES = 8, THREADS = 512;
-  static constexpr int QT = 512;                          // queries per workgroup
   static constexpr int ROW_BYTES = D * 2;                 // one bf16 key
   static constexpr int CR = D / 8;                        // 16-B chunks per row
   static constexpr int KSTEPS = D / 16;                   // MFMA k-steps per 32-key sub-tile
