@@ -93,6 +93,8 @@ class RAGraph(nn.Module):
         out[perm] = sm
         return out
 
+    query_shard = None  # ragraph_amd.sharded.QueryShard: retrieve only this rank's rows of the node set (inference)
+
     def _make_resource_graph(self, pretrained_model):
         """modules/RAGraph.py:185-226 with num_augment_scale = num_inverse_sample = 0 (the finetune-phase settings,
         :45-50): keys = embeddings after num_layers aggregations, values = sum of the even layers."""
@@ -135,12 +137,22 @@ class RAGraph(nn.Module):
             # the fused kernel never builds that matrix, so all queries go in one launch.
             if self._index is None:
                 self._index = K.KeyIndex(self.keys_normalized)
-            _, idx = self._index.topk(res[0], k)
+            # Several GPUs (c5): the bank is replicated and the queries -- independent of one another -- are split;
+            # a rank retrieves and reduces its rows, one all_gather of the [n, D] means completes the step
+            # (ragraph_amd.sharded.QueryShard; the result does not depend on the split, bit for bit).
+            qs = self.query_shard if not self.training else None
+            queries = res[0]
+            if qs is not None:
+                lo, hi = qs.bounds(res[0].shape[0])
+                queries = res[0][lo:hi].contiguous()
+            _, idx = self._index.topk(queries, k)
             if add_noise:
                 noise = torch.randint(0, self.resource_values.shape[0], (idx.shape[0], self.noise_retrieve_num),
                                       device=idx.device)
                 idx = torch.cat([idx, noise], dim=1)
             rag, _ = K.gather_reduce(self.resource_values, None, idx, v_scale=1.0 / idx.shape[1])  # :314,321 mean
+            if qs is not None:
+                rag = qs.gather_rows(rag, res[0].shape[0])
             total = K.axpby(total, 1 - self.retrieve_weight, rag, self.retrieve_weight)        # :328
         return total.split([self.num_users, self.num_items], dim=0)
 

@@ -187,6 +187,35 @@ def test_edge_generate_g9(dev):
                                              10, float(g["retrieve_weight"]), 3)
     assert np.allclose(out, o_out, atol=1e-6)
 
+    # query sharding (c5's multi-GPU layout): every rank's slice, stitched the way QueryShard.gather_rows does, gives the
+    # unsharded result bit for bit (the collective itself is covered by tests/test_cpu_distributed.py under gloo)
+    from ragraph_amd.sharded import shard_bounds
+
+    class Rank:
+        def __init__(self, world, rank, parts):
+            self.world, self.rank, self.parts = world, rank, parts
+
+        def bounds(self, B):
+            return shard_bounds(B, self.world, self.rank)
+
+        def gather_rows(self, local, B):
+            self.parts[self.rank] = local.clone()
+            lo, hi = self.bounds(B)
+            full = local.new_zeros((B,) + tuple(local.shape[1:]))
+            full[lo:hi] = local
+            return full
+
+    parts, outs = {}, []
+    for r in range(3):
+        model.query_shard = Rank(3, r, parts)
+        outs.append(torch.cat(model.generate()))
+    model.query_shard = None
+    full = torch.cat([uo, io])
+    for r in range(3):
+        lo, hi = shard_bounds(U + I, 3, r)
+        assert torch.equal(outs[r][lo:hi], full[lo:hi])
+    assert sum(p.shape[0] for p in parts.values()) == U + I
+
 
 def test_downprompt_g10(dev):
     from ragraph_amd import downprompt as dp
