@@ -80,7 +80,7 @@ class RAGraph(nn.Module):
     def _agg(self, all_emb, edges, edge_norm):
         """modules/RAGraph.py:232-240: out[dst] += emb[src] * norm, as one CSR SpMM (no atomics)."""
         g, perm = self._csr(edges)
-        return K.spmm_csr(g.rowptr, g.col, edge_norm[perm].contiguous(), all_emb)
+        return K.spmm_csr(g.rowptr, g.col, edge_norm[perm].contiguous(), all_emb, long_rows=g.has_long_rows)
 
     def _relative_edge_time_encoding(self, edges, edge_times, max_step=None):
         """modules/RAGraph.py:250-263.  Returns the softmax in ORIGINAL edge order."""
@@ -88,7 +88,7 @@ class RAGraph(nn.Module):
         tmin = float(edge_times.min())
         tmax = float(edge_times.max()) if max_step is None else float(max_step)
         t = K.time_rescale(edge_times, tmin, tmax)
-        sm = K.segment_softmax(g.rowptr, t[perm].contiguous())
+        sm = K.segment_softmax(g.rowptr, t[perm].contiguous(), long_rows=g.has_long_rows)
         out = torch.empty_like(sm)
         out[perm] = sm
         return out
@@ -121,12 +121,12 @@ class RAGraph(nn.Module):
         g, perm = self._csr(edges)
         tmin, tmax = self._time_range(edge_times, max_time_step)
         t = K.time_rescale(edge_times[perm].contiguous(), tmin, tmax)                           # :254-257
-        time_norm = K.segment_softmax(g.rowptr, t)                                             # :266
+        time_norm = K.segment_softmax(g.rowptr, t, long_rows=g.has_long_rows)                  # :266
         norm = K.axpby(edge_norm[perm].contiguous(), 0.5, time_norm, 0.5)                      # :267
         all_emb = self.emb_gate(torch.cat([self.user_embedding, self.item_embedding], dim=0)).detach()  # :276-277
         res = [all_emb]
         for _ in range(self.num_layers):                                                       # :280-283
-            res.append(K.spmm_csr(g.rowptr, g.col, norm, res[-1]))
+            res.append(K.spmm_csr(g.rowptr, g.col, norm, res[-1], long_rows=g.has_long_rows))
         total = res[0]
         for r in res[1:]:                                                                      # :327 sum(res_emb)
             total = K.axpby(total, 1.0, r, 1.0)

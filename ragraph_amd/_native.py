@@ -51,6 +51,10 @@ SIGNATURES = {
     "ragraph_spmm_csr_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _i32, _f32, _f32, _vp, _vp, _vp]),
     "ragraph_csr_row_normalize_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "ragraph_segment_softmax_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "ragraph_segment_softmax_ws_f32": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "ragraph_sparse_workspace_bytes": (_sz, [_i64, _i32]),
+    "ragraph_spmm_csr_ws_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _i32, _f32, _f32, _vp, _vp, _i64, _vp, _sz,
+                                       _vp]),
     "ragraph_axpby_f32": (_i32, [_vp, _f32, _vp, _f32, _i64, _vp, _vp]),
     "ragraph_softmax_mix_f32": (_i32, [_vp, _vp, _i64, _i32, _f32, _i32, _vp, _vp]),
     "ragraph_segment_reduce_f32": (_i32, [_vp, _i32, _vp, _i64, _vp, _i32, _vp, _vp]),

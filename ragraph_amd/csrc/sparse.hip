@@ -16,67 +16,188 @@
 
 namespace ragraph {
 
+// Rows longer than ROW_BLOCK edges (the hubs of a power-law graph) are summed in blocks: each block of ROW_BLOCK
+// consecutive edges is its own sequential chain from +0 and the block sums are added in block order -- the order
+// oracle/ragraph_oracle.c uses (ORACLE_ROW_BLOCK).  One chain over the 3 M edges of c5's most popular item kept a
+// single lane group busy for 31 ms per layer while the chip idled; with a workspace the blocks of long rows are
+// separate tasks for the whole chip (long_rows_kernel lists them, spmm_long_blocks_kernel sums them,
+// spmm_long_finish_kernel adds a row's block sums in order and applies the epilogue).  Without a workspace the row's
+// lane group walks its blocks itself: same bits, no parallelism.
+constexpr int ROW_BLOCK = 4096;
+
 // A row's edges are consumed in chunks of CH = 16: the first lanes of the row's lane group load the chunk's (col, val)
 // pairs with ONE coalesced load each, the group broadcasts them, and all gathers of the chunk are issued back to back
 // before the first fmaf -- three dependent memory latencies per row (rowptr, edge list, X rows) instead of one pair per
-// four edges.  The sum is still the sequential fmaf chain in CSR order.
+// four edges.  The sum is the sequential fmaf chain over edges [e0, e0 + cnt_edges) in CSR order, from +0.
+template <int LPR>
+__device__ __forceinline__ float4 row_chain(const int32_t* __restrict__ col, const float* __restrict__ val, int64_t e0,
+                                            int cnt_edges, const float4* __restrict__ X4, int D4, int c4, bool colok,
+                                            int lr, int gbase) {
+  constexpr int CH = 16;  // edges per chunk (<= LPR)
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int base = 0; base < cnt_edges; base += CH) {
+    int my_c = 0;
+    float my_v = 0.f;
+    if (lr < CH && base + lr < cnt_edges) {
+      my_c = col[e0 + base + lr];
+      my_v = val[e0 + base + lr];
+    }
+    const int cnt = cnt_edges - base < CH ? cnt_edges - base : CH;
+    float4 x[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = __shfl(my_c, gbase + i);
+      x[i] = (i < cnt && colok) ? X4[(int64_t)c * D4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const float v = __shfl(my_v, gbase + i);
+      if (i < cnt) {
+        acc.x = fmaf(v, x[i].x, acc.x); acc.y = fmaf(v, x[i].y, acc.y);
+        acc.z = fmaf(v, x[i].z, acc.z); acc.w = fmaf(v, x[i].w, acc.w);
+      }
+    }
+  }
+  return acc;
+}
+
+__device__ __forceinline__ float4 add4(float4 a, float4 b) {
+  return make_float4(__fadd_rn(a.x, b.x), __fadd_rn(a.y, b.y), __fadd_rn(a.z, b.z), __fadd_rn(a.w, b.w));
+}
+
+__device__ __forceinline__ void spmm_epilogue_store(float4 acc, const float* __restrict__ bias, int act, float alpha,
+                                                    float beta, const float* __restrict__ Yin, float* __restrict__ Y,
+                                                    int64_t row, int D4, int c4) {
+  if (bias) acc = add4(acc, reinterpret_cast<const float4*>(bias)[c4]);
+  acc.x = apply_act(acc.x, act, alpha); acc.y = apply_act(acc.y, act, alpha);
+  acc.z = apply_act(acc.z, act, alpha); acc.w = apply_act(acc.w, act, alpha);
+  if (Yin) {
+    const float4 y = reinterpret_cast<const float4*>(Yin)[row * D4 + c4];
+    acc.x = fmaf(beta, y.x, acc.x); acc.y = fmaf(beta, y.y, acc.y); acc.z = fmaf(beta, y.z, acc.z); acc.w = fmaf(beta, y.w, acc.w);
+  }
+  reinterpret_cast<float4*>(Y)[row * D4 + c4] = acc;
+}
+
+// skip_long != 0: rows longer than ROW_BLOCK are left to the long-row kernels.
 template <int LPR>
 __global__ void __launch_bounds__(256) spmm_csr_kernel(const int64_t* __restrict__ rowptr,
                                                        const int32_t* __restrict__ col,
                                                        const float* __restrict__ val, int64_t n,
                                                        const float* __restrict__ X, int D,
                                                        const float* __restrict__ bias, int act, float alpha, float beta,
-                                                       const float* __restrict__ Yin, float* __restrict__ Y) {
+                                                       const float* __restrict__ Yin, float* __restrict__ Y,
+                                                       int skip_long) {
   constexpr int RPB = 256 / LPR;  // rows per block
-  constexpr int CH = 16;          // edges per chunk (<= LPR)
   const int lr = threadIdx.x % LPR;
   const int gbase = (threadIdx.x & 63) - lr;  // first lane of this row's group inside the wave
   int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
-  const bool live = row < n;  // dead groups run along with zero edges: the shuffles need every lane
+  bool live = row < n;  // dead groups run along with zero edges: the shuffles need every lane
   if (!live) row = n - 1;
   const int64_t e0 = rowptr[row];
-  const int deg = live ? (int)(rowptr[row + 1] - e0) : 0;
+  int64_t deg = live ? rowptr[row + 1] - e0 : 0;
+  if (skip_long && deg > ROW_BLOCK) {
+    live = false;
+    deg = 0;
+  }
   const int D4 = D >> 2;
   const float4* X4 = reinterpret_cast<const float4*>(X);
 
   for (int c4 = lr; c4 < ((D4 + LPR - 1) / LPR) * LPR; c4 += LPR) {  // uniform trip count: shuffles inside
     const bool colok = c4 < D4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int base = 0; base < deg; base += CH) {
-      int my_c = 0;
-      float my_v = 0.f;
-      if (lr < CH && base + lr < deg) {
-        my_c = col[e0 + base + lr];
-        my_v = val[e0 + base + lr];
-      }
-      const int cnt = deg - base < CH ? deg - base : CH;
-      float4 x[CH];
-#pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        const int c = __shfl(my_c, gbase + i);
-        x[i] = (i < cnt && colok) ? X4[(int64_t)c * D4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        const float v = __shfl(my_v, gbase + i);
-        if (i < cnt) {
-          acc.x = fmaf(v, x[i].x, acc.x); acc.y = fmaf(v, x[i].y, acc.y);
-          acc.z = fmaf(v, x[i].z, acc.z); acc.w = fmaf(v, x[i].w, acc.w);
-        }
+    float4 acc;
+    if (deg <= ROW_BLOCK) {
+      acc = row_chain<LPR>(col, val, e0, (int)deg, X4, D4, c4, colok, lr, gbase);
+    } else {  // no workspace: this group walks the row's blocks itself
+      acc = row_chain<LPR>(col, val, e0, ROW_BLOCK, X4, D4, c4, colok, lr, gbase);
+      for (int64_t b0 = ROW_BLOCK; b0 < deg; b0 += ROW_BLOCK) {
+        const int cnt = deg - b0 < ROW_BLOCK ? (int)(deg - b0) : ROW_BLOCK;
+        acc = add4(acc, row_chain<LPR>(col, val, e0 + b0, cnt, X4, D4, c4, colok, lr, gbase));
       }
     }
     if (!live || !colok) continue;
-    if (bias) {
-      const float4 b = reinterpret_cast<const float4*>(bias)[c4];
-      acc.x = __fadd_rn(acc.x, b.x); acc.y = __fadd_rn(acc.y, b.y); acc.z = __fadd_rn(acc.z, b.z); acc.w = __fadd_rn(acc.w, b.w);
-    }
-    acc.x = apply_act(acc.x, act, alpha); acc.y = apply_act(acc.y, act, alpha);
-    acc.z = apply_act(acc.z, act, alpha); acc.w = apply_act(acc.w, act, alpha);
-    if (Yin) {
-      const float4 y = reinterpret_cast<const float4*>(Yin)[row * D4 + c4];
-      acc.x = fmaf(beta, y.x, acc.x); acc.y = fmaf(beta, y.y, acc.y); acc.z = fmaf(beta, y.z, acc.z); acc.w = fmaf(beta, y.w, acc.w);
-    }
-    reinterpret_cast<float4*>(Y)[row * D4 + c4] = acc;
+    spmm_epilogue_store(acc, bias, act, alpha, beta, Yin, Y, row, D4, c4);
+  }
+}
+
+// ---- long rows, with a workspace ------------------------------------------------------------------------------------
+struct LongRows {
+  int* ctr;           // [0] number of long rows, [1] number of block tasks
+  int64_t* rows;      // [max_rows]  row index of long row i
+  int* pos;           // [max_rows]  first task / partial slot of long row i (its blocks follow in order)
+  int64_t* task_row;  // [max_tasks]
+  int* task_blk;      // [max_tasks]
+  float* partial;     // [max_tasks, D] block sums (spmm) / [max_tasks] (softmax)
+  int64_t max_rows, max_tasks;
+};
+
+// One thread per row: a long row reserves its task slots (a contiguous range, so its blocks stay in order; which range
+// is decided by atomics and does not matter) and writes its tasks.
+__global__ void __launch_bounds__(256) long_rows_kernel(const int64_t* __restrict__ rowptr, int64_t n, LongRows w) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= n) return;
+  const int64_t deg = rowptr[row + 1] - rowptr[row];
+  if (deg <= ROW_BLOCK) return;
+  const int nb = (int)((deg + ROW_BLOCK - 1) / ROW_BLOCK);
+  const int li = atomicAdd(w.ctr, 1);
+  const int p = atomicAdd(w.ctr + 1, nb);
+  w.rows[li] = row;
+  w.pos[li] = p;
+  for (int b = 0; b < nb; ++b) {
+    w.task_row[p + b] = row;
+    w.task_blk[p + b] = b;
+  }
+}
+
+// One lane group per (long row, block): the block's chain -> partial[task].
+template <int LPR>
+__global__ void __launch_bounds__(256) spmm_long_blocks_kernel(const int64_t* __restrict__ rowptr,
+                                                               const int32_t* __restrict__ col,
+                                                               const float* __restrict__ val,
+                                                               const float* __restrict__ X, int D, LongRows w) {
+  constexpr int RPB = 256 / LPR;
+  const int lr = threadIdx.x % LPR;
+  const int gbase = (threadIdx.x & 63) - lr;
+  const int64_t t = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+  const int ntask = w.ctr[1];
+  const bool live = t < ntask;
+  const int64_t tt = live ? t : 0;
+  int64_t e0 = 0;
+  int cnt = 0;
+  if (ntask > 0) {
+    const int64_t row = w.task_row[tt];
+    const int64_t r0 = rowptr[row], r1 = rowptr[row + 1];
+    e0 = r0 + (int64_t)w.task_blk[tt] * ROW_BLOCK;
+    cnt = live ? (int)(r1 - e0 < ROW_BLOCK ? r1 - e0 : ROW_BLOCK) : 0;
+  }
+  const int D4 = D >> 2;
+  const float4* X4 = reinterpret_cast<const float4*>(X);
+  for (int c4 = lr; c4 < ((D4 + LPR - 1) / LPR) * LPR; c4 += LPR) {
+    const bool colok = c4 < D4;
+    const float4 acc = row_chain<LPR>(col, val, e0, cnt, X4, D4, c4, colok, lr, gbase);
+    if (live && colok) reinterpret_cast<float4*>(w.partial)[t * D4 + c4] = acc;
+  }
+}
+
+// One lane group per long row: its block sums in block order, then the epilogue.
+template <int LPR>
+__global__ void __launch_bounds__(256) spmm_long_finish_kernel(const int64_t* __restrict__ rowptr, int D,
+                                                               const float* __restrict__ bias, int act, float alpha,
+                                                               float beta, const float* __restrict__ Yin,
+                                                               float* __restrict__ Y, LongRows w) {
+  constexpr int RPB = 256 / LPR;
+  const int lr = threadIdx.x % LPR;
+  const int64_t li = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+  if (li >= w.ctr[0]) return;
+  const int64_t row = w.rows[li];
+  const int64_t deg = rowptr[row + 1] - rowptr[row];
+  const int nb = (int)((deg + ROW_BLOCK - 1) / ROW_BLOCK);
+  const int64_t p = w.pos[li];
+  const int D4 = D >> 2;
+  const float4* P4 = reinterpret_cast<const float4*>(w.partial);
+  for (int c4 = lr; c4 < D4; c4 += LPR) {
+    float4 acc = P4[p * D4 + c4];
+    for (int b = 1; b < nb; ++b) acc = add4(acc, P4[(p + b) * D4 + c4]);
+    spmm_epilogue_store(acc, bias, act, alpha, beta, Yin, Y, row, D4, c4);
   }
 }
 
@@ -92,22 +213,76 @@ __global__ void __launch_bounds__(256) csr_row_normalize_kernel(const int64_t* _
   for (int64_t e = e0; e < e1; ++e) out[e] = val[e] / s;
 }
 
+// One thread per segment; a segment longer than ROW_BLOCK sums its exponentials in blocks (see ROW_BLOCK), itself when
+// there is no workspace, else it is left to segment_softmax_long_kernel.
 __global__ void __launch_bounds__(256) segment_softmax_kernel(const int64_t* __restrict__ rowptr,
                                                               const float* __restrict__ x, int64_t n,
-                                                              float* __restrict__ out) {
+                                                              float* __restrict__ out, int skip_long) {
   const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (row >= n) return;
   const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
   if (e0 == e1) return;
+  if (skip_long && e1 - e0 > ROW_BLOCK) return;
   float m = x[e0];
   for (int64_t e = e0 + 1; e < e1; ++e) m = fmaxf(m, x[e]);
   float s = 0.f;
-  for (int64_t e = e0; e < e1; ++e) {
-    const float ex = expf(x[e] - m);
-    out[e] = ex;
-    s = __fadd_rn(s, ex);
+  for (int64_t b0 = e0; b0 < e1; b0 += ROW_BLOCK) {
+    const int64_t b1 = b0 + ROW_BLOCK < e1 ? b0 + ROW_BLOCK : e1;
+    float sb = 0.f;
+    for (int64_t e = b0; e < b1; ++e) {
+      const float ex = expf(x[e] - m);
+      out[e] = ex;
+      sb = __fadd_rn(sb, ex);
+    }
+    s = (b0 == e0) ? sb : __fadd_rn(s, sb);
   }
   for (int64_t e = e0; e < e1; ++e) out[e] = out[e] / s;
+}
+
+// One workgroup per long segment: maximum by a tree (order-free), one thread per block for the block sums (sequential,
+// as the contract says), thread 0 adds them in block order, everybody normalises.
+__global__ void __launch_bounds__(256) segment_softmax_long_kernel(const int64_t* __restrict__ rowptr,
+                                                                   const float* __restrict__ x,
+                                                                   float* __restrict__ out, LongRows w) {
+  __shared__ float red[256];
+  const int64_t li = blockIdx.x;
+  if (li >= w.ctr[0]) return;
+  const int tid = threadIdx.x;
+  const int64_t row = w.rows[li];
+  const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
+  const int nb = (int)((e1 - e0 + ROW_BLOCK - 1) / ROW_BLOCK);
+  float m = RG_NEG_INF;
+  for (int64_t e = e0 + tid; e < e1; e += 256) m = fmaxf(m, x[e]);
+  red[tid] = m;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (tid < off) red[tid] = fmaxf(red[tid], red[tid + off]);
+    __syncthreads();
+  }
+  m = red[0];
+  __syncthreads();
+  float* psum = w.partial + w.pos[li];
+  for (int b = tid; b < nb; b += 256) {
+    const int64_t b0 = e0 + (int64_t)b * ROW_BLOCK;
+    const int64_t b1 = b0 + ROW_BLOCK < e1 ? b0 + ROW_BLOCK : e1;
+    float sb = 0.f;
+    for (int64_t e = b0; e < b1; ++e) {
+      const float ex = expf(x[e] - m);
+      out[e] = ex;
+      sb = __fadd_rn(sb, ex);
+    }
+    psum[b] = sb;
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (tid == 0) {
+    float s = psum[0];
+    for (int b = 1; b < nb; ++b) s = __fadd_rn(s, psum[b]);
+    red[0] = s;
+  }
+  __syncthreads();
+  const float s = red[0];
+  for (int64_t e = e0 + tid; e < e1; e += 256) out[e] = out[e] / s;
 }
 
 // One workgroup per segment; thread t owns float4 chunks t, t+256, ...; rows are summed sequentially (oracle order).
@@ -140,9 +315,53 @@ __global__ void __launch_bounds__(256) segment_reduce_kernel(const float* __rest
 
 using namespace ragraph;
 
-extern "C" int ragraph_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n,
-                                    const float* X, int D, const float* bias, int act, float alpha, float beta,
-                                    const float* Y_in, float* Y, void* stream) {
+// Workspace of the long-row path: counters, long-row list, block tasks, block sums.
+static size_t long_rows_layout(int64_t nnz, int D, LongRows* w, char* base) {
+  const int64_t max_rows = nnz / ROW_BLOCK + 1, max_tasks = 2 * (nnz / ROW_BLOCK) + 2;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  };
+  char* c = take(2 * sizeof(int));
+  char* r = take((size_t)max_rows * sizeof(int64_t));
+  char* ps = take((size_t)max_rows * sizeof(int));
+  char* tr = take((size_t)max_tasks * sizeof(int64_t));
+  char* tb = take((size_t)max_tasks * sizeof(int));
+  char* pa = take((size_t)max_tasks * (size_t)(D > 0 ? D : 1) * sizeof(float));
+  if (w) {
+    w->ctr = reinterpret_cast<int*>(c);
+    w->rows = reinterpret_cast<int64_t*>(r);
+    w->pos = reinterpret_cast<int*>(ps);
+    w->task_row = reinterpret_cast<int64_t*>(tr);
+    w->task_blk = reinterpret_cast<int*>(tb);
+    w->partial = reinterpret_cast<float*>(pa);
+    w->max_rows = max_rows;
+    w->max_tasks = max_tasks;
+  }
+  return off;
+}
+
+extern "C" size_t ragraph_sparse_workspace_bytes(int64_t nnz, int D) {
+  if (nnz < 0 || D < 0) return 0;
+  return long_rows_layout(nnz, D, nullptr, nullptr);
+}
+
+static int find_long_rows(const int64_t* rowptr, int64_t n, const LongRows& w, hipStream_t st) {
+  if (hipMemsetAsync(w.ctr, 0, 2 * sizeof(int), st) != hipSuccess) {
+    set_error("sparse: memset failed");
+    return RAGRAPH_EDEVICE;
+  }
+  hipLaunchKernelGGL(long_rows_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, rowptr, n, w);
+  RG_CHECK_LAUNCH("sparse(long rows)");
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_spmm_csr_ws_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n,
+                                       const float* X, int D, const float* bias, int act, float alpha, float beta,
+                                       const float* Y_in, float* Y, int64_t nnz, void* ws, size_t ws_bytes,
+                                       void* stream) {
   RG_REQUIRE(rowptr && X && Y, RAGRAPH_EINVAL, "spmm_csr: null pointer");
   RG_REQUIRE(n >= 0 && D >= 4 && (D & 3) == 0, RAGRAPH_EINVAL, "spmm_csr: D=%d must be a positive multiple of 4", D);
   RG_REQUIRE(aligned16(X) && aligned16(Y) && (!bias || aligned16(bias)) && (!Y_in || aligned16(Y_in)), RAGRAPH_EINVAL,
@@ -151,19 +370,41 @@ extern "C" int ragraph_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, c
   RG_REQUIRE(act >= RAGRAPH_ACT_NONE && act <= RAGRAPH_ACT_ELU, RAGRAPH_EINVAL, "spmm_csr: bad act %d", act);
   if (n == 0) return RAGRAPH_OK;
   hipStream_t st = as_stream(stream);
-  const int D4 = D >> 2;
-  if (D4 <= 16) {
-    hipLaunchKernelGGL(spmm_csr_kernel<16>, dim3((unsigned)cdiv(n, 16)), dim3(256), 0, st, rowptr, col, val, n, X, D,
-                       bias, act, alpha, beta, Y_in, Y);
-  } else if (D4 <= 32) {
-    hipLaunchKernelGGL(spmm_csr_kernel<32>, dim3((unsigned)cdiv(n, 8)), dim3(256), 0, st, rowptr, col, val, n, X, D,
-                       bias, act, alpha, beta, Y_in, Y);
-  } else {
-    hipLaunchKernelGGL(spmm_csr_kernel<64>, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, st, rowptr, col, val, n, X, D,
-                       bias, act, alpha, beta, Y_in, Y);
+  LongRows w{};
+  const bool par = ws != nullptr && nnz > ROW_BLOCK;  // (no row can be long otherwise)
+  if (par) {
+    RG_REQUIRE(aligned16(ws) && ws_bytes >= long_rows_layout(nnz, D, nullptr, nullptr), RAGRAPH_EWORKSPACE,
+               "spmm_csr: workspace %zu < %zu", ws_bytes, long_rows_layout(nnz, D, nullptr, nullptr));
+    long_rows_layout(nnz, D, &w, static_cast<char*>(ws));
+    const int rc = find_long_rows(rowptr, n, w, st);
+    if (rc != RAGRAPH_OK) return rc;
   }
+  const int skip = par ? 1 : 0;
+  const int D4 = D >> 2;
+#define RG_SPMM(LPR_)                                                                                                  \
+  do {                                                                                                                 \
+    constexpr int RPB_ = 256 / (LPR_);                                                                                 \
+    hipLaunchKernelGGL(spmm_csr_kernel<LPR_>, dim3((unsigned)cdiv(n, RPB_)), dim3(256), 0, st, rowptr, col, val, n, X, \
+                       D, bias, act, alpha, beta, Y_in, Y, skip);                                                      \
+    if (par) {                                                                                                         \
+      hipLaunchKernelGGL(spmm_long_blocks_kernel<LPR_>, dim3((unsigned)cdiv(w.max_tasks, RPB_)), dim3(256), 0, st,     \
+                         rowptr, col, val, X, D, w);                                                                   \
+      hipLaunchKernelGGL(spmm_long_finish_kernel<LPR_>, dim3((unsigned)cdiv(w.max_rows, RPB_)), dim3(256), 0, st,      \
+                         rowptr, D, bias, act, alpha, beta, Y_in, Y, w);                                               \
+    }                                                                                                                  \
+  } while (0)
+  if (D4 <= 16) RG_SPMM(16);
+  else if (D4 <= 32) RG_SPMM(32);
+  else RG_SPMM(64);
+#undef RG_SPMM
   RG_CHECK_LAUNCH("spmm_csr");
   return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n,
+                                    const float* X, int D, const float* bias, int act, float alpha, float beta,
+                                    const float* Y_in, float* Y, void* stream) {
+  return ragraph_spmm_csr_ws_f32(rowptr, col, val, n, X, D, bias, act, alpha, beta, Y_in, Y, 0, nullptr, 0, stream);
 }
 
 extern "C" int ragraph_csr_row_normalize_f32(const int64_t* rowptr, const float* val, int64_t n, float* val_out,
@@ -176,14 +417,31 @@ extern "C" int ragraph_csr_row_normalize_f32(const int64_t* rowptr, const float*
   return RAGRAPH_OK;
 }
 
-extern "C" int ragraph_segment_softmax_f32(const int64_t* rowptr, const float* x, int64_t n, float* out,
-                                           void* stream) {
+extern "C" int ragraph_segment_softmax_ws_f32(const int64_t* rowptr, const float* x, int64_t n, int64_t nnz, float* out,
+                                              void* ws, size_t ws_bytes, void* stream) {
   RG_REQUIRE(rowptr && x && out, RAGRAPH_EINVAL, "segment_softmax: null pointer");
   if (n <= 0) return RAGRAPH_OK;
-  hipLaunchKernelGGL(segment_softmax_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream), rowptr, x,
-                     n, out);
+  hipStream_t st = as_stream(stream);
+  LongRows w{};
+  const bool par = ws != nullptr && nnz > ROW_BLOCK;
+  if (par) {
+    RG_REQUIRE(aligned16(ws) && ws_bytes >= long_rows_layout(nnz, 0, nullptr, nullptr), RAGRAPH_EWORKSPACE,
+               "segment_softmax: workspace %zu < %zu", ws_bytes, long_rows_layout(nnz, 0, nullptr, nullptr));
+    long_rows_layout(nnz, 0, &w, static_cast<char*>(ws));
+    const int rc = find_long_rows(rowptr, n, w, st);
+    if (rc != RAGRAPH_OK) return rc;
+  }
+  hipLaunchKernelGGL(segment_softmax_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, rowptr, x, n, out,
+                     par ? 1 : 0);
+  if (par)
+    hipLaunchKernelGGL(segment_softmax_long_kernel, dim3((unsigned)w.max_rows), dim3(256), 0, st, rowptr, x, out, w);
   RG_CHECK_LAUNCH("segment_softmax");
   return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_segment_softmax_f32(const int64_t* rowptr, const float* x, int64_t n, float* out,
+                                           void* stream) {
+  return ragraph_segment_softmax_ws_f32(rowptr, x, n, 0, out, nullptr, 0, stream);
 }
 
 extern "C" int ragraph_segment_reduce_f32(const float* X, int D, const int64_t* seg_ptr, int64_t G, const float* w,

@@ -23,6 +23,7 @@ class CSRGraph:
     val: torch.Tensor     # [nnz] fp32
     n: int
     _row_normalized: torch.Tensor | None = field(default=None, repr=False)
+    _has_long_rows: bool | None = field(default=None, repr=False)
 
     @property
     def shape(self):
@@ -41,6 +42,15 @@ class CSRGraph:
 
     def cuda(self):  # reference code calls .cuda() on its inputs (layers/gcn.py:28-29)
         return self
+
+    @property
+    def has_long_rows(self) -> bool:
+        """Does a row hold more than K.ROW_BLOCK edges (a hub of a power-law graph)?  Looked up once per graph (one
+        reduction and read-back); the kernels then spread such rows over the chip instead of one lane group."""
+        if self._has_long_rows is None:
+            self._has_long_rows = bool(self.n > 0 and self.nnz > K.ROW_BLOCK and
+                                       int((self.rowptr[1:] - self.rowptr[:-1]).max()) > K.ROW_BLOCK)
+        return self._has_long_rows
 
     def row_normalized_values(self) -> torch.Tensor:
         """adj / adj.sum(1) on the non-zeros (Propagation.py:15-16), cached per graph."""

@@ -250,10 +250,15 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = No
     return y.reshape(tuple(lead) + (w.shape[0],))
 
 
+ROW_BLOCK = 4096  # rows / segments longer than this are summed in blocks (csrc/sparse.hip, oracle ORACLE_ROW_BLOCK)
+
+
 def spmm_csr(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, x: torch.Tensor,
              bias: torch.Tensor | None = None, act: int = ACT_NONE, alpha: float = 0.0, beta: float = 0.0,
-             y_in: torch.Tensor | None = None) -> torch.Tensor:
-    """act(A @ x + bias) + beta*y_in for CSR A -- layers/gcn.py:36-40, Propagation.py:22-25, edge _agg."""
+             y_in: torch.Tensor | None = None, long_rows: bool = False) -> torch.Tensor:
+    """act(A @ x + bias) + beta*y_in for CSR A -- layers/gcn.py:36-40, Propagation.py:22-25, edge _agg.
+    `long_rows`: the graph has rows of more than ROW_BLOCK edges (CSRGraph.has_long_rows): their blocks are spread over
+    the chip through a workspace -- same bits, three more launches."""
     L = _ready()
     rowptr = _idxc(rowptr, "spmm_csr.rowptr")
     col = _idxc(col, "spmm_csr.col", torch.int32)
@@ -264,6 +269,13 @@ def spmm_csr(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, x: torc
     b = None if bias is None else _f32c(bias, "spmm_csr.bias")
     yi = None if y_in is None else _f32c(y_in, "spmm_csr.y_in")
     y = torch.empty((n, D), dtype=torch.float32, device=x.device)
+    if long_rows:
+        nnz = col.numel()
+        ws = _workspace(L.ragraph_sparse_workspace_bytes(nnz, D), x.device)
+        N.check(L.ragraph_spmm_csr_ws_f32(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), n, x.data_ptr(), D, _ptr(b),
+                                          act, float(alpha), float(beta), _ptr(yi), y.data_ptr(), nnz, ws.data_ptr(),
+                                          ws.numel(), _stream()), "spmm_csr")
+        return y
     N.check(L.ragraph_spmm_csr_f32(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), n, x.data_ptr(), D, _ptr(b), act,
                                    float(alpha), float(beta), _ptr(yi), y.data_ptr(), _stream()), "spmm_csr")
     return y
@@ -280,12 +292,18 @@ def csr_row_normalize(rowptr: torch.Tensor, val: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def segment_softmax(rowptr: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """scatter_softmax over CSR rows -- RAGraph_edge/modules/RAGraph.py:261."""
+def segment_softmax(rowptr: torch.Tensor, x: torch.Tensor, long_rows: bool = False) -> torch.Tensor:
+    """scatter_softmax over CSR rows -- RAGraph_edge/modules/RAGraph.py:261 (`long_rows`: see spmm_csr)."""
     L = _ready()
     rowptr = _idxc(rowptr, "segment_softmax.rowptr")
     x = _f32c(x, "segment_softmax.x")
     out = torch.zeros_like(x)
+    if long_rows:
+        nnz = x.numel()
+        ws = _workspace(L.ragraph_sparse_workspace_bytes(nnz, 0), x.device)
+        N.check(L.ragraph_segment_softmax_ws_f32(rowptr.data_ptr(), x.data_ptr(), rowptr.numel() - 1, nnz, out.data_ptr(),
+                                                 ws.data_ptr(), ws.numel(), _stream()), "segment_softmax")
+        return out
     N.check(L.ragraph_segment_softmax_f32(rowptr.data_ptr(), x.data_ptr(), rowptr.numel() - 1, out.data_ptr(),
                                           _stream()), "segment_softmax")
     return out

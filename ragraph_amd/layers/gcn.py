@@ -33,4 +33,4 @@ class GCN(nn.Module):
         g = as_csr(adj)
         seq_fts = K.linear(seq.squeeze(0) if seq.dim() == 3 else seq, self.fc.weight)          # :32
         return K.spmm_csr(g.rowptr, g.col, g.val, seq_fts, bias=self.bias, act=K.ACT_PRELU,      # :36-40 fused
-                          alpha=self._alpha())
+                          alpha=self._alpha(), long_rows=g.has_long_rows)

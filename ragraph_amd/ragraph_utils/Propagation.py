@@ -15,5 +15,5 @@ class Propagation:
             return x
         valn = g.row_normalized_values()
         for _ in range(int(k)):
-            x = K.spmm_csr(g.rowptr, g.col, valn, x, act=K.ACT_RELU)
+            x = K.spmm_csr(g.rowptr, g.col, valn, x, act=K.ACT_RELU, long_rows=g.has_long_rows)
         return x

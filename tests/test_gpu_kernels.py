@@ -207,6 +207,46 @@ def test_csr_row_normalize_and_segment_softmax(dev):
     assert np.allclose(sums, 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize("D", [64, 256, 20])
+def test_spmm_and_softmax_hub_rows_bit_exact(dev, D):
+    """Power-law shape: a few rows hold thousands of edges (one of them most of the graph).  Rows longer than 4096 edges
+    are summed in blocks of 4096 (block chains from +0, added in block order) -- by the row's own lanes without a
+    workspace, by the whole chip with one; both must give the oracle's bits, and short rows stay single chains."""
+    from ragraph_amd import kernels as K
+    from ragraph_amd.graph import CSRGraph
+
+    rng = _rng(500 + D)
+    n, ncols = 300, 5000
+    deg = rng.integers(0, 12, n)
+    deg[7], deg[8], deg[150], deg[299] = 4096, 4097, 3 * 4096 + 5, 40_000   # at, just past and far past the block size
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(deg)
+    nnz = int(rowptr[-1])
+    col = rng.integers(0, ncols, nnz).astype(np.int32)
+    val = (rng.random(nnz, dtype=np.float32) - 0.3)
+    X = rng.standard_normal((ncols, D), dtype=np.float32)
+    b = rng.standard_normal(D, dtype=np.float32)
+    Yin = rng.standard_normal((n, D), dtype=np.float32)
+    ref = cref.spmm_csr(rowptr, col, val, X, bias=b, act=2, alpha=0.25, beta=0.5, Y_in=Yin)
+    args = (_t(rowptr, dev), _t(col, dev), _t(val, dev), _t(X, dev))
+    for long_rows in (False, True):
+        got = K.spmm_csr(*args, bias=_t(b, dev), act=2, alpha=0.25, beta=0.5, y_in=_t(Yin, dev), long_rows=long_rows)
+        assert np.array_equal(got.cpu().numpy(), ref), f"long_rows={long_rows}"
+    g = CSRGraph(_t(rowptr, dev), _t(col, dev), _t(val, dev), n)
+    assert g.has_long_rows
+    if D == 64:
+        x = rng.standard_normal(nnz).astype(np.float32)
+        sref = cref.segment_softmax(rowptr, x)
+        for long_rows in (False, True):
+            got = K.segment_softmax(_t(rowptr, dev), _t(x, dev), long_rows=long_rows).cpu().numpy()
+            assert np.allclose(got, sref, rtol=1e-6, atol=1e-9), f"long_rows={long_rows}"
+            sums = np.add.reduceat(got, rowptr[:-1][np.diff(rowptr) > 0])
+            assert np.allclose(sums, 1.0, atol=1e-4)
+        a = K.segment_softmax(_t(rowptr, dev), _t(x, dev), long_rows=False)
+        c = K.segment_softmax(_t(rowptr, dev), _t(x, dev), long_rows=True)
+        assert torch.equal(a, c)   # the two paths agree bit for bit
+
+
 def test_segment_reduce_axpby_softmax_proto(dev):
     from ragraph_amd import kernels as K
 
