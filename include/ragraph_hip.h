@@ -16,7 +16,8 @@
  * Numerics contract (what "parity" means; restated on the CPU in oracle/ragraph_oracle.c)
  *   - every dot product (cosine scores, GEMM, SpMM) is ONE fp32 fmaf chain in natural index order starting from
  *     +0 -- exactly what v_mfma_f32_32x32x2_f32 / _16x16x4_f32 compute -- so scores are bit-identical to the oracle
- *     regardless of batch size, tiling, split count or GPU count;
+ *     regardless of batch size, tiling, split count or GPU count (one exception: SpMM rows and softmax segments of more
+ *     than 4096 entries are summed in blocks of 4096, see "Hub rows" at ragraph_spmm_csr_ws_f32);
  *   - top-k order is canonical: score descending, then index ascending (torch.topk leaves ties unspecified);
  *   - row L2 norms use the fixed reduction tree documented at ragraph_normalize_rows_f32.
  */
