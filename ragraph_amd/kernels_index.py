@@ -17,6 +17,7 @@ class KeyIndex:
         self.keys_normalized = keys_normalized
         self._packed = None
         self._bf16 = None
+        self._filter_off = False  # set when this bank defeats the filter (see topk)
 
     def topk(self, q: torch.Tensor, k: int, idx_base: int = 0):
         ops, kn = self.ops, self.keys_normalized
@@ -28,10 +29,15 @@ class KeyIndex:
                 self._packed = ops.pack_keys(kn)
             kp = self._packed
         fhelps = getattr(ops, "filter_helps", None)
-        if fhelps is not None and fhelps(B, kn.shape[0], D, k):
+        if fhelps is not None and not self._filter_off and fhelps(B, kn.shape[0], D, k):
             if self._bf16 is None:
                 self._bf16 = ops.keys_to_bf16(kn)
-            s, i, _ = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base, keys_packed=kp)
+            s, i, n_over = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base, keys_packed=kp)
+            # A bank of near-duplicates (thousands of keys within the bf16 bound of a query's k-th best) overflows the
+            # candidate lists, and every such row is recomputed with the fp32 kernels: still exact, but once a quarter
+            # of a sizeable batch goes that way the filter only adds its own cost -- this bank version stays on fp32.
+            if B >= 64 and 4 * n_over > B:
+                self._filter_off = True
             return s, i
         if kp is not None:
             return ops.topk_cosine(q, kn, k, idx_base=idx_base, keys_packed=kp)

@@ -450,6 +450,16 @@ def test_topk_cosine_filtered_overflow_falls_back(dev):
     rs, ri = cref.topk_cosine(q, kn, 10)
     assert np.array_equal(i.cpu().numpy(), ri)
     assert np.array_equal(s.cpu().numpy(), rs)
+    # the bank-side dispatch notices that this bank defeats the filter and keeps it on the fp32 kernels afterwards
+    big = _t(np.concatenate([kn] * 4), dev)             # 80000 keys: large enough for the filtered path
+    index = K.KeyIndex(big)
+    qd = _t(q, dev)
+    s1, i1 = index.topk(qd, 10)
+    assert index._filter_off
+    s2, i2 = index.topk(qd, 10)
+    assert torch.equal(i1, i2) and torch.equal(s1, s2)
+    rs4, ri4 = cref.topk_cosine(q, np.concatenate([kn] * 4), 10)
+    assert np.array_equal(i1.cpu().numpy(), ri4) and np.array_equal(s1.cpu().numpy(), rs4)
 
 
 def test_key_index_dispatch_same_bits(dev, monkeypatch):
