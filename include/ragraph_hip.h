@@ -94,8 +94,9 @@ int ragraph_topk_cosine_bank_f32(const float* Q, int64_t B, const float* Kn, con
                                  void* stream);
 
 /* a1, large batches: the same result through a bf16 MFMA filter (ragraph_amd/csrc/topk_filter.hip).
- *   Exact by construction: (1) the fp32 kernel finds the top-k of every query over the first N/256 keys; its k-th score
- *   bounds the final k-th best from below; (2) a bf16 MFMA pass (16x the fp32 matrix rate) over the next, larger part of
+ *   Exact by construction: (1) a lower bound of every query's final k-th best score -- the k-th exact score over a sample
+ *   of the bank, or, for banks of >= 65536 keys, min over k parts of a prefix of the best approximate score in the part,
+ *   minus eps(q) (k distinct keys score at least that); (2) a bf16 MFMA pass (16x the fp32 matrix rate) over the next, larger part of
  *   the bank keeps every key whose approximate score is within eps(q) of that bound, where eps(q) = |dq| + max|dk| +
  *   |dq| max|dk| (+ rounding slack) is computed from the actual bf16 rounding errors dq of the query and dk of the bank
  *   rows (<= 2^-7, typically 0.003): by Cauchy-Schwarz no pair's dot product moves by more; (3) the survivors (~100 per query) are
@@ -116,11 +117,13 @@ int ragraph_keys_to_bf16(const float* Kn, int64_t N, int D, uint16_t* Kb, void* 
 int ragraph_topk_cosine_filtered_cap(int k);
 size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_t N, int D, int k);
 /* The schedule the call above will follow for this shape (host-side arithmetic only, no device work):
- * plan[0] = n0 (level 0: exact top-k over keys [0, n0)), plan[1] = 1 if level 0 is a score slab (dense kernel +
- * row top-k) rather than the tile kernel, plan[2] = number of filter levels L (1..3), plan[3..3+L) = their ends
- * (increasing multiples of 256, the last = N; level l filters [end[l-1], end[l]), the first starts at 0).
- * Returns L, or a negative error code. */
-int ragraph_topk_cosine_filtered_plan(int64_t B, int64_t N, int D, int k, int64_t plan[6]);
+ * plan[1] = how the first lower bound of a query's k-th best score is made: 2 = bound pass (banks of >= 65536 keys: a
+ * bf16 pass over keys [0, plan[6]) records the best approximate score of each of k parts; the smallest, minus eps, is
+ * the bound -- worth the exact k-th best of plan[0] keys), 1 = exact top-k over keys [0, plan[0]) as a score slab (dense
+ * kernel + row top-k), 0 = the same by the fp32 tile kernel; plan[2] = number of filter levels L (1..3),
+ * plan[3..3+L) = their ends (increasing multiples of 256, the last = N; level l filters [end[l-1], end[l]), the first
+ * starts at 0).  Returns L, or a negative error code. */
+int ragraph_topk_cosine_filtered_plan(int64_t B, int64_t N, int D, int k, int64_t plan[7]);
 int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const float* Kn, const float* Kp, const uint16_t* Kb,
                                      int64_t N, int D, int k, int64_t idx_base, float* out_scores, int64_t* out_idx,
                                      int* overflow, int64_t* overflow_idx, void* ws, size_t ws_bytes, void* stream);

@@ -84,7 +84,17 @@ struct FilterParams {
   int64_t stage_base;     // first stage of the key range this launch filters
   int64_t qtiles, nstages_total;  // nstages_total = stages in the range
   int xcd_map, wgs_per_group, lb_min, depth[2];
+  // bound pass (BOUND kernels): per query, the maxima of `ngroups` consecutive stage ranges of the launch's key range
+  int* gmax;              // [B, ngroups] as order-preserving ints (f2ord), pre-filled with f2ord(-inf)
+  int ngroups;
 };
+
+// float <-> int with the same order (for atomicMax on scores of either sign)
+__device__ __forceinline__ int f2ord(float f) {
+  const int b = __float_as_int(f);
+  return b >= 0 ? b : b ^ 0x7FFFFFFF;
+}
+__device__ __forceinline__ float ord2f(int o) { return __int_as_float(o >= 0 ? o : o ^ 0x7FFFFFFF); }
 
 __device__ __forceinline__ void fring_wait(unsigned* ctr, unsigned target) {
   while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
@@ -148,22 +158,38 @@ __global__ void __launch_bounds__(256) filter_query_err_kernel(const float* __re
   if ((threadIdx.x & (TPR - 1)) == 0 && q < B) eq[q] = sqrtf(e2);
 }
 
-// thr[q] = (k-th exact score of the previous level) - eps(q); count[q] = 0.  `first`: also clear the overflow bookkeeping.
+// thr[q] = theta[q] - eps(q); count[q] = 0.  `first`: also clear the overflow bookkeeping.  theta is the k-th exact score
+// of the previous level, or -- gmax != NULL, after the bound pass -- min over the k groups of the group's best APPROXIMATE
+// score minus eps(q): each group's best key has an exact score >= its approximate one - eps, so k distinct keys score at
+// least that, and so does the final k-th best.
 __global__ void __launch_bounds__(256) filter_prepare_kernel(const float* __restrict__ prev_scores, int64_t B, int k,
                                                              const float* __restrict__ eq,
                                                              const unsigned* __restrict__ max_kerr2,
                                                              float* __restrict__ thr, int* __restrict__ count,
                                                              int* __restrict__ overflow, unsigned char* __restrict__ flag,
-                                                             int first, int ablate) {
+                                                             int first, int ablate, const int* __restrict__ gmax) {
   const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (first && q == 0) *overflow = 0;
   if (q >= B) return;
   const float ek = sqrtf(__uint_as_float(*max_kerr2));
   const float e = eq[q];
   const float eps = fmaf(fmaf(e, ek, e + ek), 1.0009765625f, FILTER_EPS_SLACK);  // rounding direction is inside the factor
-  thr[q] = ablate ? __builtin_huge_valf() : __fsub_rn(prev_scores[q * k + k - 1], eps);
+  float theta;
+  if (gmax) {
+    int m = gmax[q * k];
+    for (int g = 1; g < k; ++g) m = min(m, gmax[q * k + g]);
+    theta = __fsub_rn(ord2f(m), eps);
+  } else {
+    theta = prev_scores[q * k + k - 1];
+  }
+  thr[q] = ablate ? __builtin_huge_valf() : __fsub_rn(theta, eps);
   count[q] = 0;
   if (first) flag[q] = 0;
+}
+
+__global__ void __launch_bounds__(256) filter_gmax_init_kernel(int* __restrict__ gmax, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) gmax[i] = f2ord(RG_NEG_INF);
 }
 
 #ifdef RG_TOPK_TIMING  // diagnostic build only: per-wave cycle totals of the ring's phases
@@ -175,7 +201,9 @@ __device__ unsigned long long g_filter_timing[8];
 
 // QW = queries per wave: 64 (two groups of 32 sharing every A fragment; query tile = 512) or 32 (one group, tile = 256:
 // batches of <= 256 queries, which would otherwise spend half their matrix work on padding).
-template <int D, int QW>
+// BOUND: no thresholds, no candidates -- the launch only records, per query, the best approximate score of each of
+// p.ngroups consecutive parts of its key range (filter_prepare_kernel turns them into the first lower bound).
+template <int D, int QW, bool BOUND = false>
 __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
   using C = FilterCfg<D>;
   static_assert(QW == 64 || QW == 32, "one or two query groups per wave");
@@ -269,8 +297,22 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
       }
     }
     // padded queries never pass: +inf threshold
-    float thr0 = q_lo < p.B ? p.thr[q_lo] : __builtin_huge_valf();
-    float thr1 = (TWO && q_hi < p.B) ? p.thr[q_hi] : __builtin_huge_valf();
+    float thr0 = (!BOUND && q_lo < p.B) ? p.thr[q_lo] : __builtin_huge_valf();
+    float thr1 = (!BOUND && TWO && q_hi < p.B) ? p.thr[q_hi] : __builtin_huge_valf();
+    // bound pass: running maxima of the current group (group g = stages [ceil(g n / G), ceil((g+1) n / G)) of the range)
+    float gm0 = RG_NEG_INF, gm1 = RG_NEG_INF;
+    int grp = 0;
+    int64_t grp_end = 0;  // first stage (range-relative) of the next group
+    auto group_of = [&](int64_t t) { return (int)(t * p.ngroups / p.nstages_total); };  // largest g with ceil(g n / G) <= t
+    auto flush_max = [&]() {
+      if (q_lo < p.B) atomicMax(p.gmax + q_lo * p.ngroups + grp, f2ord(gm0));
+      if (TWO && q_hi < p.B) atomicMax(p.gmax + q_hi * p.ngroups + grp, f2ord(gm1));
+      gm0 = gm1 = RG_NEG_INF;
+    };
+    if constexpr (BOUND) {
+      grp = group_of(st0);
+      grp_end = ((int64_t)(grp + 1) * p.nstages_total + p.ngroups - 1) / p.ngroups;
+    }
     // Candidates: a sub-tile that holds any (one wave-uniform test of the accumulators' maxima) turns each lane's 16 scores
     // per query group into a pass MASK without a branch, and the lanes with a non-zero mask push one 8-byte entry
     // {(query within the wave) << 26 | offset of the lane's key group from key_org, mask} into a wave-private LDS buffer
@@ -328,6 +370,13 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
         flush();
         key_org += 0x10000 * C::STAGE_KEYS;
       }
+      if constexpr (BOUND) {
+        if (st0 + s >= grp_end) {  // (groups hold at least one stage each: at most one boundary per stage)
+          flush_max();
+          ++grp;
+          grp_end = ((int64_t)(grp + 1) * p.nstages_total + p.ngroups - 1) / p.ngroups;
+        }
+      }
       RG_FT(t0);
       fring_wait(full + slot, (unsigned)(C::WAVES * (gen + 1)));
       RG_FT(t1);
@@ -353,7 +402,10 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
           m0 = fmaxf(m0, a0[r]);
           if constexpr (TWO) m1 = fmaxf(m1, a1[r]);
         }
-        if (__any(m0 >= thr0 || (TWO && m1 >= thr1))) {
+        if constexpr (BOUND) {
+          gm0 = fmaxf(gm0, m0);
+          if constexpr (TWO) gm1 = fmaxf(gm1, m1);
+        } else if (__any(m0 >= thr0 || (TWO && m1 >= thr1))) {
           const int stage_key0 = (int)((p.stage_base + st0 + s) * C::STAGE_KEYS);
           const int key_base = stage_key0 + 32 * u + 4 * g;  // the lane's keys: key_base + (r & 3) + 8 (r >> 2)
           unsigned k0 = pass_mask(a0, thr0), k1 = TWO ? pass_mask(a1, thr1) : 0u;
@@ -447,6 +499,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
       for (int i = 0; i < 6; ++i) atomicAdd(&g_filter_timing[i], tw[i]);
 #endif
     flush();
+    if constexpr (BOUND) flush_max();
     __syncthreads();  // flags are re-initialised by the next segment
   }
 }
@@ -809,7 +862,8 @@ constexpr int FILTER_MAX_LEVELS = 3;
 static int64_t filter_round_up(int64_t n) { return (n + FILTER_PAD_KEYS - 1) / FILTER_PAD_KEYS * FILTER_PAD_KEYS; }
 
 struct FilterSchedule {
-  int64_t n0;                       // level 0: exact top-k over keys [0, n0)
+  int64_t bound_keys;               // > 0: no exact level 0 -- the first bound comes from a bf16 pass over keys [0, bound_keys)
+  int64_t n0;                       // level 0: exact top-k over keys [0, n0)   (bound_keys == 0)
   int slab0;                        // level 0 by dense kernel + topk_rows (needs B * n0 floats of workspace)
   int nlev;                         // filter levels
   int64_t ends[FILTER_MAX_LEVELS];  // their ends (multiples of 256 except the last = N)
@@ -818,14 +872,36 @@ struct FilterSchedule {
 constexpr int64_t FILTER_SLAB_MAX_B = 16384;
 constexpr int64_t FILTER_SLAB_MAX_SCORES = (int64_t)1 << 26;  // 256 MiB of scores
 
+// Banks of >= 65536 keys (the shapes KeyIndex sends here) take their first bound from the BOUND pass instead of an
+// exact level 0: the filter kernel itself runs over the first bound_keys keys and records, per query, the best approximate
+// score of each of k consecutive parts; the smallest of the k maxima, minus eps, bounds the final k-th best from below
+// (filter_prepare_kernel).  As a bound it is worth the exact k-th best of ~bound_keys / (ln k + 1) keys, and it costs a
+// bf16 pass with no lists, no inserts and no fp32 matrix work: 0.7 ms instead of the tile kernel's 3.2 ms for the
+// bench's 100 k queries, 40 us instead of the slab's 110 us for 256.  RAGRAPH_FILTER_EXACT_LEVEL0=1 keeps the exact
+// level 0 (A/B).
+static bool filter_bound_pass_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("RAGRAPH_FILTER_EXACT_LEVEL0");
+    return !(e && atoi(e) != 0);
+  }();
+  return on;
+}
+
 static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k) {
-  FilterSchedule sc;
+  FilterSchedule sc{};
   const int cap = 2048;
+  const bool bound = N >= 65536 && filter_bound_pass_enabled();
+  const double eff_div = log((double)k) + 1.0;  // bound_keys / eff_div ~ the exact sample the bound is worth
   if (B > FILTER_SLAB_MAX_B || N < 4 * 4096) {
     int64_t n0 = N / 256;
     if (n0 < 4096) n0 = 4096;
     if (n0 > N) n0 = N;
     if (n0 < k) n0 = k < N ? k : N;
+    if (bound) {
+      int64_t nA = filter_round_up((int64_t)((double)n0 * eff_div));
+      if (nA > N / 4) nA = N / 4 / FILTER_PAD_KEYS * FILTER_PAD_KEYS;
+      sc.bound_keys = nA;
+    }
     sc.n0 = n0;
     sc.slab0 = 0;  // (measured at 100 k queries: slabs of 16384 cost 3.6 ms -- dense kernel 104 TFLOP/s, topk_rows bound
                    // by its list inserts -- against the tile kernel's 3.2 ms)
@@ -839,24 +915,39 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k) {
       prev = e;
     }
     sc.ends[sc.nlev++] = N;
+    // the k keys behind the bound must lie inside the first level (it has to find at least k candidates)
+    if (sc.bound_keys > sc.ends[0]) sc.bound_keys = sc.ends[0] / FILTER_PAD_KEYS * FILTER_PAD_KEYS;
     return sc;
   }
   double best = 1e30;
-  int64_t best_n0 = 4096;
+  int64_t best_n0 = 4096, best_nA = 0;
   int best_L = FILTER_MAX_LEVELS;
-  for (int64_t n0 = 4096; n0 * 4 <= N && B * n0 <= FILTER_SLAB_MAX_SCORES; n0 *= 2) {
-    const double slab = 30.0 + (double)B * (double)n0 * (2.0 * D / 1.0e8 + 4.0 / 3.0e6);
+  const int stage_keys = FILTER_STAGE_BYTES / (2 * D);
+  const double tiles = (double)((B + 511) / 512);
+  for (int64_t n0 = 4096; n0 * 4 <= N; n0 *= 2) {
+    double first;  // cost of the first bound, us
+    int64_t nA = 0;
+    if (bound) {
+      nA = filter_round_up((int64_t)((double)n0 * eff_div));
+      if (nA * 4 > N) break;
+      first = 35.0 + (double)nA * 2.0 * D / 3.0e6 + tiles * (double)(nA / stage_keys) * 3.1 / 256.0;
+    } else {
+      if (B * n0 > FILTER_SLAB_MAX_SCORES) break;
+      first = 30.0 + (double)B * (double)n0 * (2.0 * D / 1.0e8 + 4.0 / 3.0e6);
+    }
     for (int L = 1; L <= FILTER_MAX_LEVELS; ++L) {
       const double r = pow((double)N / (double)n0, 1.0 / L);
       if (1.3 * k * r > cap / 2) continue;
-      const double cost = slab + L * (60.0 + (double)B * 1.3 * k * r * 0.4e-3);
+      const double cost = first + L * (60.0 + (double)B * 1.3 * k * r * 0.4e-3);
       if (cost < best) {
         best = cost;
         best_n0 = n0;
+        best_nA = nA;
         best_L = L;
       }
     }
   }
+  sc.bound_keys = bound ? (best_nA ? best_nA : filter_round_up((int64_t)(4096 * eff_div))) : 0;
   sc.n0 = best_n0;
   sc.slab0 = 1;
   sc.nlev = 0;
@@ -869,11 +960,13 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k) {
     sc.ends[sc.nlev++] = ei;
   }
   sc.ends[sc.nlev++] = N;
+  if (sc.bound_keys > sc.ends[0]) sc.bound_keys = sc.ends[0] / FILTER_PAD_KEYS * FILTER_PAD_KEYS;
   return sc;
 }
 
 // workspace of level 0: the tile kernel's, or the score slab
 static size_t filter_level0_ws(const FilterSchedule& sc, int64_t B, int D, int k) {
+  if (sc.bound_keys > 0) return 0;
   return sc.slab0 ? align_up((size_t)(B < FILTER_SLAB_MAX_B ? B : FILTER_SLAB_MAX_B) * (size_t)sc.n0 * sizeof(float), 256)
                   : ragraph_topk_cosine_workspace_bytes(B, sc.n0, D, k);
 }
@@ -911,18 +1004,19 @@ extern "C" size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_
   const FilterSchedule sc = filter_schedule(B, N, D, k);
   return filter_level0_ws(sc, B, D, k) + align_up((size_t)B * D * sizeof(float), 256) +
          2 * align_up((size_t)B * sizeof(float), 256) + align_up((size_t)B * sizeof(int), 256) + align_up((size_t)B, 256) +
-         align_up((size_t)B * cap * sizeof(int), 256);
+         align_up((size_t)B * cap * sizeof(int), 256) + align_up((size_t)B * k * sizeof(int), 256);
 }
 
-extern "C" int ragraph_topk_cosine_filtered_plan(int64_t B, int64_t N, int D, int k, int64_t plan[6]) {
+extern "C" int ragraph_topk_cosine_filtered_plan(int64_t B, int64_t N, int D, int k, int64_t plan[7]) {
   RG_REQUIRE(plan, RAGRAPH_EINVAL, "topk_cosine_filtered_plan: null pointer");
   RG_REQUIRE(filter_dim_ok(D), RAGRAPH_EUNSUPPORTED, "topk_cosine_filtered_plan: D=%d not in {64,128,256}", D);
   RG_REQUIRE(B >= 1 && N >= 1 && k >= 1 && k <= 32 && k <= N, RAGRAPH_EINVAL, "topk_cosine_filtered_plan: bad B/N/k");
   const FilterSchedule sc = filter_schedule(B, N, D, k);
   plan[0] = sc.n0;
-  plan[1] = sc.slab0;
+  plan[1] = sc.bound_keys > 0 ? 2 : sc.slab0;
   plan[2] = sc.nlev;
   for (int l = 0; l < FILTER_MAX_LEVELS; ++l) plan[3 + l] = l < sc.nlev ? sc.ends[l] : 0;
+  plan[6] = sc.bound_keys;
   return sc.nlev;
 }
 
@@ -933,14 +1027,14 @@ static int run_filter_level_qw(const float* Qn, const float* Kn, const uint16_t*
                             int k, int64_t idx_base, int first, int merge, int final_level, float* out_scores,
                             int64_t* out_idx, int* overflow, int64_t* overflow_idx, float* thr, const float* eq,
                             const unsigned* max_kerr2, int* count, unsigned char* flag, int* cand, int cap, int level,
-                            hipStream_t st) {
+                            const int* gmax, hipStream_t st) {
   using C = FilterCfg<D>;
   static const int ablate = [] {  // RAGRAPH_FILTER_ABLATE=1: no key passes the filter (timing only, results invalid)
     const char* e = getenv("RAGRAPH_FILTER_ABLATE");
     return e ? atoi(e) : 0;
   }();
   hipLaunchKernelGGL(filter_prepare_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, out_scores, B, k, eq, max_kerr2,
-                     thr, count, overflow, flag, first, ablate);
+                     thr, count, overflow, flag, first, ablate, gmax);
   RG_CHECK_LAUNCH("topk_cosine_filtered(prepare)");
   FilterParams p;
   p.Qn = Qn;
@@ -948,6 +1042,8 @@ static int run_filter_level_qw(const float* Qn, const float* Kn, const uint16_t*
   p.thr = thr;
   p.count = count;
   p.cand = cand;
+  p.gmax = nullptr;
+  p.ngroups = 0;
   p.B = B;
   p.N = key1;
   p.cap = cap;
@@ -1018,12 +1114,53 @@ static int run_filter_level(const float* Qn, const float* Kn, const uint16_t* Kb
                             int k, int64_t idx_base, int first, int merge, int final_level, float* out_scores,
                             int64_t* out_idx, int* overflow, int64_t* overflow_idx, float* thr, const float* eq,
                             const unsigned* max_kerr2, int* count, unsigned char* flag, int* cand, int cap, int level,
-                            hipStream_t st) {
+                            const int* gmax, hipStream_t st) {
   if (B <= 256)
     return run_filter_level_qw<D, 32>(Qn, Kn, Kb, B, key0, key1, k, idx_base, first, merge, final_level, out_scores, out_idx,
-                                      overflow, overflow_idx, thr, eq, max_kerr2, count, flag, cand, cap, level, st);
+                                      overflow, overflow_idx, thr, eq, max_kerr2, count, flag, cand, cap, level, gmax, st);
   return run_filter_level_qw<D, 64>(Qn, Kn, Kb, B, key0, key1, k, idx_base, first, merge, final_level, out_scores, out_idx,
-                                    overflow, overflow_idx, thr, eq, max_kerr2, count, flag, cand, cap, level, st);
+                                    overflow, overflow_idx, thr, eq, max_kerr2, count, flag, cand, cap, level, gmax, st);
+}
+
+// The bound pass: group maxima of the approximate scores over keys [0, nA), nA a multiple of 256 with nA <= N.
+template <int D, int QW>
+static int run_bound_pass_qw(const float* Qn, const uint16_t* Kb, int64_t B, int64_t nA, int k, int* gmax, hipStream_t st) {
+  using C = FilterCfg<D>;
+  hipLaunchKernelGGL(filter_gmax_init_kernel, dim3((unsigned)cdiv(B * k, 256)), dim3(256), 0, st, gmax, B * k);
+  FilterParams p{};
+  p.Qn = Qn;
+  p.Kb = Kb;
+  p.gmax = gmax;
+  p.ngroups = k;
+  p.B = B;
+  p.N = nA;
+  p.stage_base = 0;
+  p.qtiles = cdiv(B, (int64_t)C::WAVES * QW);
+  p.nstages_total = nA / C::STAGE_KEYS;
+  const int CUS = filter_device_cus();
+  p.xcd_map = p.qtiles >= 64 ? 1 : 0;
+  p.wgs_per_group = CUS / (p.xcd_map ? 8 : 1);
+  p.lb_min = 8;
+  const int64_t nq0 = p.xcd_map ? (p.qtiles + 7) / 8 : p.qtiles;
+  for (int v = 0; v < 2; ++v) {
+    const int64_t nq = nq0 - v;
+    p.depth[v] = 0;
+    if (nq < 1 || (v == 1 && (!p.xcd_map || p.qtiles % 8 == 0))) continue;
+    p.depth[v] = SegmentWalker::choose_depth(nq, p.nstages_total, p.wgs_per_group, p.lb_min, 0).depth;
+  }
+  static bool attr_set = false;  // per template instance
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_filter_kernel<D, QW, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("topk_cosine_filtered: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+      return RAGRAPH_EDEVICE;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((topk_filter_kernel<D, QW, true>), dim3((unsigned)CUS), dim3(C::THREADS), C::LDS_BYTES, st, p);
+  RG_CHECK_LAUNCH("topk_cosine_filtered(bound pass)");
+  return RAGRAPH_OK;
 }
 
 template <int D>
@@ -1044,12 +1181,16 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   int* count = reinterpret_cast<int*>(reinterpret_cast<char*>(eq) + align_up((size_t)B * sizeof(float), 256));
   unsigned char* flag = reinterpret_cast<unsigned char*>(count) + align_up((size_t)B * sizeof(int), 256);
   int* cand = reinterpret_cast<int*>(flag + align_up((size_t)B, 256));
+  int* gmax = reinterpret_cast<int*>(reinterpret_cast<char*>(cand) + align_up((size_t)B * cap * sizeof(int), 256));
   const unsigned* max_kerr2 = reinterpret_cast<const unsigned*>(Kb + filter_round_up(N) * D);
 
   // level 0: exact top-k over the first n0 keys (out_scores / out_idx hold every level's running result, local indices)
   int rc = ragraph_normalize_rows_f32(Q, B, D, Qn, stream);
   if (rc != RAGRAPH_OK) return rc;
-  if (sc.slab0) {
+  if (sc.bound_keys > 0) {  // no exact level 0: group maxima of a bf16 pass bound the k-th best
+    rc = B <= 256 ? run_bound_pass_qw<D, 32>(Qn, Kb, B, sc.bound_keys, k, gmax, st)
+                  : run_bound_pass_qw<D, 64>(Qn, Kb, B, sc.bound_keys, k, gmax, st);
+  } else if (sc.slab0) {
     float* S = reinterpret_cast<float*>(w);  // one slab of scores, reused: written and read back while it is in cache
     for (int64_t b0 = 0; b0 < B && rc == RAGRAPH_OK; b0 += FILTER_SLAB_MAX_B) {
       const int64_t nb = B - b0 < FILTER_SLAB_MAX_B ? B - b0 : FILTER_SLAB_MAX_B;
@@ -1067,7 +1208,8 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   int64_t key0 = 0;
   for (int l = 0; l < nlev; ++l) {  // the first level re-reads [0, n0): its keys pass the bound and need no merge
     rc = run_filter_level<D>(Qn, Kn, Kb, B, key0, ends[l], k, idx_base, l == 0, l > 0, l == nlev - 1, out_scores, out_idx,
-                             overflow, overflow_idx, thr, eq, max_kerr2, count, flag, cand, cap, l, st);
+                             overflow, overflow_idx, thr, eq, max_kerr2, count, flag, cand, cap, l,
+                             (l == 0 && sc.bound_keys > 0) ? gmax : nullptr, st);
     if (rc != RAGRAPH_OK) return rc;
     key0 = ends[l];
   }

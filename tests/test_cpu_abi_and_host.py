@@ -51,7 +51,7 @@ def test_filtered_topk_plan_is_well_formed():
     from ragraph_amd import _native as N
 
     L = N.lib()
-    plan = (ctypes.c_int64 * 6)()
+    plan = (ctypes.c_int64 * 7)()
     cap = L.ragraph_topk_cosine_filtered_cap(10)
     seen_levels = set()
     for B in (1, 12, 40, 256, 257, 512, 1024, 4096, 16384, 16385, 100_000):
@@ -59,7 +59,8 @@ def test_filtered_topk_plan_is_well_formed():
             for D in (64, 256):
                 for k in (1, 10, 32):
                     nlev = L.ragraph_topk_cosine_filtered_plan(B, Nk, D, k, plan)
-                    n0, slab0, nl = plan[0], plan[1], plan[2]
+                    n0, mode, nl, bound_keys = plan[0], plan[1], plan[2], plan[6]
+                    slab0 = mode == 1
                     ends = [plan[3 + i] for i in range(nl)]
                     assert nlev == nl and 1 <= nl <= 3, (B, Nk, D, k)
                     assert k <= n0 <= Nk
@@ -70,6 +71,9 @@ def test_filtered_topk_plan_is_well_formed():
                         for e in ends:
                             assert 1.3 * k * e / prev <= cap, (B, Nk, D, k, n0, ends)
                             prev = e
+                    assert (mode == 2) == (Nk >= 65536) and (bound_keys > 0) == (mode == 2)
+                    if mode == 2:  # the k keys behind the bound lie inside the first level; whole stages of any D
+                        assert bound_keys % 256 == 0 and k <= bound_keys <= ends[0]
                     if slab0:
                         assert B <= 16384
                         assert L.ragraph_topk_cosine_filtered_workspace_bytes(B, Nk, D, k) >= B * n0 * 4 + B * cap * 4
@@ -78,7 +82,7 @@ def test_filtered_topk_plan_is_well_formed():
     assert L.ragraph_topk_cosine_filtered_plan(100, 1000, 100, 3, plan) < 0  # unsupported D
     # the bench shape keeps the three-level schedule the measurements in DESIGN.md describe
     assert L.ragraph_topk_cosine_filtered_plan(100_000, 1_000_000, 256, 10, plan) == 3
-    assert list(plan) == [4096, 0, 3, 31488, 250112, 1_000_000]
+    assert list(plan) == [4096, 2, 3, 31488, 250112, 1_000_000, 13568]
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
