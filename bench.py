@@ -303,9 +303,10 @@ def main():
                             "profiles/r1_pmc_traffic.json",
             "launch_ms": round(kernel_ms, 3),
             "note": "algorithmic flops 2*B*N*D of the score matrix / mean duration of the filter kernel (events "
-                    "recorded around its launches inside the library, three filter levels per call summed). The whole "
-                    f"exact retrieval call (fp32 top-k over the first N/256 keys + this kernel + exact fp32 rescoring "
-                    f"of the survivors) takes {call_ms:.2f} ms; --exact-fp32 runs the fp32 MFMA kernel alone. "
+                    "recorded around its launches inside the library: the bound pass over a prefix of the bank, "
+                    "whose flops are overhead and not counted, and the filter levels, summed per call). The whole "
+                    f"exact retrieval call (this kernel + exact fp32 rescoring of the survivors) takes "
+                    f"{call_ms:.2f} ms; --exact-fp32 runs the fp32 MFMA kernel alone. "
                     f"tools/microbench/mfma_bf16_bench.hip: this kernel's bare inner loop sustains 1.60 PFLOP/s on random "
                     f"operands (2.19 on near-constant ones): the clock held under real data bounds it well below peak",
             "retrieval_call_ms": round(call_ms, 3),

@@ -818,11 +818,11 @@ using namespace ragraph;
 
 // Optional timing of the filter kernel alone (bench.py's roofline): events recorded around its launches on the caller's
 // stream.  Off by default; enabling creates the events once.
-static hipEvent_t g_prof_ev[2 * 3];
-static int g_prof_created = 0, g_prof_on = 0, g_prof_have = 0;
+static hipEvent_t g_prof_ev[2 * 4];  // three filter levels + the bound pass (slot 3)
+static int g_prof_created = 0, g_prof_on = 0, g_prof_have = 0, g_prof_bound = 0;
 extern "C" int ragraph_profile_filter_kernel(int on) {
   if (on && !g_prof_created) {
-    for (int i = 0; i < 2 * 3; ++i)
+    for (int i = 0; i < 2 * 4; ++i)
       if (hipEventCreate(&g_prof_ev[i]) != hipSuccess) {
         set_error("profile: cannot create events");
         return RAGRAPH_EDEVICE;
@@ -830,7 +830,7 @@ extern "C" int ragraph_profile_filter_kernel(int on) {
     g_prof_created = 1;
   }
   g_prof_on = on ? 1 : 0;
-  g_prof_have = 0;
+  g_prof_have = g_prof_bound = 0;
   return RAGRAPH_OK;
 }
 // Milliseconds the filter kernel ran in the most recent call (its launches summed; synchronises with them), or a
@@ -838,6 +838,12 @@ extern "C" int ragraph_profile_filter_kernel(int on) {
 extern "C" float ragraph_profile_last_filter_ms(void) {
   if (!g_prof_on || !g_prof_have) return -1.f;
   float total = 0.f;
+  if (g_prof_bound) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_prof_ev[7]) != hipSuccess || hipEventElapsedTime(&ms, g_prof_ev[6], g_prof_ev[7]) != hipSuccess)
+      return -1.f;
+    total += ms;
+  }
   for (int l = 0; l < g_prof_have; ++l) {
     float ms = 0.f;
     if (hipEventSynchronize(g_prof_ev[2 * l + 1]) != hipSuccess ||
@@ -1158,7 +1164,12 @@ static int run_bound_pass_qw(const float* Qn, const uint16_t* Kb, int64_t B, int
     }
     attr_set = true;
   }
+  if (g_prof_on) (void)hipEventRecord(g_prof_ev[6], st);
   hipLaunchKernelGGL((topk_filter_kernel<D, QW, true>), dim3((unsigned)CUS), dim3(C::THREADS), C::LDS_BYTES, st, p);
+  if (g_prof_on) {
+    (void)hipEventRecord(g_prof_ev[7], st);
+    g_prof_bound = 1;
+  }
   RG_CHECK_LAUNCH("topk_cosine_filtered(bound pass)");
   return RAGRAPH_OK;
 }
@@ -1172,6 +1183,7 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   const FilterSchedule sc = filter_schedule(B, N, D, k);
   const int nlev = sc.nlev;
   const int64_t* ends = sc.ends;
+  if (g_prof_on) g_prof_have = g_prof_bound = 0;
 
   char* w = static_cast<char*>(ws);
   const size_t sample_ws = filter_level0_ws(sc, B, D, k);
