@@ -133,8 +133,8 @@ def keys_to_bf16(keys_normalized: torch.Tensor) -> torch.Tensor:
 
 def filter_helps(B: int, n_keys: int, D: int, k: int) -> bool:
     """True when the bf16-filtered exact top-k is the faster way to the same bits.  Measured on MI355X (ms, filtered vs
-    fp32 kernels, D = 256, k = 10): 16 queries x 1M keys 0.28 vs 0.32, 64 x 1M 0.33 vs 0.77, 256 x 1M 0.37 vs 1.56,
-    4096 x 1M 2.0 vs 16.0, 100k x 1M 45 vs 366; 16 x 65536 0.135 vs 0.155, 1024 x 65536 0.23 vs 0.59.  One to a dozen
+    fp32 kernels, D = 256, k = 10): 16 queries x 1M keys 0.30 vs 0.32, 64 x 1M 0.33 vs 0.76, 256 x 1M 0.32 vs 1.54,
+    4096 x 1M 1.9 vs 16.0, 100k x 1M 41 vs 366; 16 x 65536 0.135 vs 0.155, 1024 x 65536 0.23 vs 0.59.  One to a dozen
     queries stay on the streaming fp32 kernel (1 x 1M: 0.21 vs 0.25), small banks on the tile kernel."""
     if os.environ.get("RAGRAPH_EXACT_FP32") == "1":
         return False
