@@ -924,6 +924,7 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k) {
     sc.ends[sc.nlev++] = N;
     // the k keys behind the bound must lie inside the first level (it has to find at least k candidates)
     if (sc.bound_keys > sc.ends[0]) sc.bound_keys = sc.ends[0] / FILTER_PAD_KEYS * FILTER_PAD_KEYS;
+    if (sc.bound_keys / (FILTER_STAGE_BYTES / (2 * D)) < k) sc.bound_keys = 0;  // every part needs a stage of its own
     return sc;
   }
   double best = 1e30;
@@ -968,6 +969,8 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k) {
   }
   sc.ends[sc.nlev++] = N;
   if (sc.bound_keys > sc.ends[0]) sc.bound_keys = sc.ends[0] / FILTER_PAD_KEYS * FILTER_PAD_KEYS;
+  if (sc.bound_keys / stage_keys < k) sc.bound_keys = 0;  // every part needs a stage of its own: else the exact slab
+  if (sc.bound_keys == 0 && B * sc.n0 > FILTER_SLAB_MAX_SCORES) sc.slab0 = 0;
   return sc;
 }
 

@@ -71,9 +71,10 @@ def test_filtered_topk_plan_is_well_formed():
                         for e in ends:
                             assert 1.3 * k * e / prev <= cap, (B, Nk, D, k, n0, ends)
                             prev = e
-                    assert (mode == 2) == (Nk >= 65536) and (bound_keys > 0) == (mode == 2)
-                    if mode == 2:  # the k keys behind the bound lie inside the first level; whole stages of any D
-                        assert bound_keys % 256 == 0 and k <= bound_keys <= ends[0]
+                    assert (bound_keys > 0) == (mode == 2) and (mode != 2 or Nk >= 65536)
+                    if mode == 2:  # the k keys behind the bound lie inside the first level; a stage or more per part
+                        assert bound_keys % 256 == 0 and bound_keys <= ends[0]
+                        assert bound_keys // (32768 // (2 * D)) >= k
                     if slab0:
                         assert B <= 16384
                         assert L.ragraph_topk_cosine_filtered_workspace_bytes(B, Nk, D, k) >= B * n0 * 4 + B * cap * 4

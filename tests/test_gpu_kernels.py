@@ -462,6 +462,34 @@ def test_topk_cosine_filtered_overflow_falls_back(dev):
     assert np.array_equal(i1.cpu().numpy(), ri4) and np.array_equal(s1.cpu().numpy(), rs4)
 
 
+def test_filtered_bound_pass_shapes_match_fp32_kernels(dev):
+    """Banks of >= 65536 keys take their first bound from the bound pass (k group maxima of approximate scores over a
+    prefix).  Shapes around its edges -- the smallest such bank, one and 32 groups, every D, one / two query groups per
+    wave, the slab-sized and the large-batch schedules, a prefix clipped by the first level -- against the fp32 kernels
+    (themselves checked against the oracle above): same bits, no overflow on ordinary data."""
+    from ragraph_amd import _native as Nn
+    from ragraph_amd import kernels as K
+    import ctypes
+
+    g = torch.Generator(device=dev).manual_seed(77)
+    plan = (ctypes.c_int64 * 7)()
+    seen_modes = set()
+    for (B, N, D, k) in [(13, 65536, 64, 32), (256, 65536, 256, 1), (300, 70003, 128, 10), (513, 140001, 256, 17),
+                         (1500, 300000, 64, 32), (5000, 200000, 256, 10), (20000, 150000, 128, 5),
+                         (17000, 65536, 64, 32), (40, 1_000_000, 256, 32)]:
+        Nn.lib().ragraph_topk_cosine_filtered_plan(B, N, D, k, plan)
+        seen_modes.add(int(plan[1]))
+        kn = K.normalize_rows(torch.randn(N, D, device=dev, generator=g))
+        q = torch.randn(B, D, device=dev, generator=g)
+        q[0] = kn[N - 1]  # a winner in the bank's last row
+        s1, i1, over = K.topk_cosine_filtered(q, kn, K.keys_to_bf16(kn), k, idx_base=9)
+        s0, i0 = K.topk_cosine(q, kn, k, idx_base=9)
+        assert over == 0, (B, N, D, k)
+        assert torch.equal(i0, i1) and torch.equal(s0, s1), (B, N, D, k, list(plan))
+        assert int(i1[0, 0]) == N - 1 + 9
+    assert 2 in seen_modes
+
+
 def test_key_index_dispatch_same_bits(dev, monkeypatch):
     """KeyIndex picks the kernel by shape (streaming, tile + packed copy, bf16-filtered with one or two query groups per
     wave and the slab or tile-kernel level 0): every choice returns the bits of the oracle, and RAGRAPH_EXACT_FP32=1
