@@ -95,7 +95,7 @@ int ragraph_topk_cosine_bank_f32(const float* Q, int64_t B, const float* Kn, con
 
 /* a1, large batches: the same result through a bf16 MFMA filter (ragraph_amd/csrc/topk_filter.hip).
  *   Exact by construction: (1) a lower bound of every query's final k-th best score -- the k-th exact score over a sample
- *   of the bank, or, for banks of >= 65536 keys, min over k parts of a prefix of the best approximate score in the part,
+ *   of the bank, or, for banks of >= 8192 keys, min over k parts of a prefix of the best approximate score in the part,
  *   minus eps(q) (k distinct keys score at least that); (2) a bf16 MFMA pass (16x the fp32 matrix rate) over the next, larger part of
  *   the bank keeps every key whose approximate score is within eps(q) of that bound, where eps(q) = |dq| + max|dk| +
  *   |dq| max|dk| (+ rounding slack) is computed from the actual bf16 rounding errors dq of the query and dk of the bank
@@ -117,7 +117,7 @@ int ragraph_keys_to_bf16(const float* Kn, int64_t N, int D, uint16_t* Kb, void* 
 int ragraph_topk_cosine_filtered_cap(int k);
 size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_t N, int D, int k);
 /* The schedule the call above will follow for this shape (host-side arithmetic only, no device work):
- * plan[1] = how the first lower bound of a query's k-th best score is made: 2 = bound pass (banks of >= 65536 keys: a
+ * plan[1] = how the first lower bound of a query's k-th best score is made: 2 = bound pass (banks of >= 8192 keys: a
  * bf16 pass over keys [0, plan[6]) records the best approximate score of each of k parts; the smallest, minus eps, is
  * the bound -- worth the exact k-th best of plan[0] keys), 1 = exact top-k over keys [0, plan[0]) as a score slab (dense
  * kernel + row top-k), 0 = the same by the fp32 tile kernel; plan[2] = number of filter levels L (1..3),

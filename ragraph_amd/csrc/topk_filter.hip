@@ -3,7 +3,7 @@
 //
 // The fp32 tile kernel (topk_cosine.hip) spends 2·B·N·D fp32 MFMA flops; the bf16 matrix cores are 16x faster.  This
 // path returns the SAME bits with most of the work on them:
-//   1. a first lower bound theta[q] of the final k-th best exact score of q.  Banks of >= 65536 keys: the BOUND pass --
+//   1. a first lower bound theta[q] of the final k-th best exact score of q.  Banks of >= 8192 keys: the BOUND pass --
 //      this file's kernel over a prefix of the bank, recording per query the best approximate score of each of k parts;
 //      k distinct keys score at least (the smallest of those maxima) - eps(q).  Smaller banks: the k-th score of an exact
 //      top-k over the first n0 keys (the fp32 tile kernel, or up to 16384 queries a score slab + topk_rows).
@@ -879,7 +879,7 @@ struct FilterSchedule {
 constexpr int64_t FILTER_SLAB_MAX_B = 16384;
 constexpr int64_t FILTER_SLAB_MAX_SCORES = (int64_t)1 << 26;  // 256 MiB of scores
 
-// Banks of >= 65536 keys (the shapes KeyIndex sends here) take their first bound from the BOUND pass instead of an
+// Banks of >= 8192 keys (KeyIndex sends >= 16384) take their first bound from the BOUND pass instead of an
 // exact level 0: the filter kernel itself runs over the first bound_keys keys and records, per query, the best approximate
 // score of each of k consecutive parts; the smallest of the k maxima, minus eps, bounds the final k-th best from below
 // (filter_prepare_kernel).  As a bound it is worth the exact k-th best of ~bound_keys / (ln k + 1) keys, and it costs a
@@ -897,7 +897,7 @@ static bool filter_bound_pass_enabled() {
 static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k) {
   FilterSchedule sc{};
   const int cap = 2048;
-  const bool bound = N >= 65536 && filter_bound_pass_enabled();
+  const bool bound = N >= 8192 && filter_bound_pass_enabled();
   const double eff_div = log((double)k) + 1.0;  // bound_keys / eff_div ~ the exact sample the bound is worth
   if (B > FILTER_SLAB_MAX_B || N < 4 * 4096) {
     int64_t n0 = N / 256;

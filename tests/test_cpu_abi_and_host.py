@@ -71,7 +71,7 @@ def test_filtered_topk_plan_is_well_formed():
                         for e in ends:
                             assert 1.3 * k * e / prev <= cap, (B, Nk, D, k, n0, ends)
                             prev = e
-                    assert (bound_keys > 0) == (mode == 2) and (mode != 2 or Nk >= 65536)
+                    assert (bound_keys > 0) == (mode == 2) and (mode != 2 or Nk >= 8192)
                     if mode == 2:  # the k keys behind the bound lie inside the first level; a stage or more per part
                         assert bound_keys % 256 == 0 and bound_keys <= ends[0]
                         assert bound_keys // (32768 // (2 * D)) >= k
