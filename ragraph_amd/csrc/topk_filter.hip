@@ -409,7 +409,13 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
         } else if (__any(m0 >= thr0 || (TWO && m1 >= thr1))) {
           const int stage_key0 = (int)((p.stage_base + st0 + s) * C::STAGE_KEYS);
           const int key_base = stage_key0 + 32 * u + 4 * g;  // the lane's keys: key_base + (r & 3) + 8 (r >> 2)
-          unsigned k0 = pass_mask(a0, thr0), k1 = TWO ? pass_mask(a1, thr1) : 0u;
+          // (a group without a passing lane skips its sixteen compares: at the later levels a sub-tile that has a
+          // candidate at all usually has it in one group only)
+          unsigned k0 = 0, k1 = 0;
+          if (__any(m0 >= thr0)) k0 = pass_mask(a0, thr0);
+          if constexpr (TWO) {
+            if (__any(m1 >= thr1)) k1 = pass_mask(a1, thr1);
+          }
           if (stage_key0 + C::STAGE_KEYS > (int)p.N) {  // the range's last stage: keys >= N (padding, or the next level's)
             unsigned vm = 0;
 #pragma unroll
