@@ -22,23 +22,21 @@ class KeyIndex:
     def topk(self, q: torch.Tensor, k: int, idx_base: int = 0):
         ops, kn = self.ops, self.keys_normalized
         B, D = q.shape
-        kp = None
-        helps = getattr(ops, "packed_keys_help", None)
-        if helps is not None and helps(B, D, k):
-            if self._packed is None:
-                self._packed = ops.pack_keys(kn)
-            kp = self._packed
         fhelps = getattr(ops, "filter_helps", None)
         if fhelps is not None and not self._filter_off and fhelps(B, kn.shape[0], D, k):
             if self._bf16 is None:
                 self._bf16 = ops.keys_to_bf16(kn)
-            s, i, n_over = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base, keys_packed=kp)
+            # (the packed fp32 copy is not made for this path: its first bound comes from the bf16 copy itself)
+            s, i, n_over = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base, keys_packed=self._packed)
             # A bank of near-duplicates (thousands of keys within the bf16 bound of a query's k-th best) overflows the
             # candidate lists, and every such row is recomputed with the fp32 kernels: still exact, but once a quarter
             # of a sizeable batch goes that way the filter only adds its own cost -- this bank version stays on fp32.
             if B >= 64 and 4 * n_over > B:
                 self._filter_off = True
             return s, i
-        if kp is not None:
-            return ops.topk_cosine(q, kn, k, idx_base=idx_base, keys_packed=kp)
+        helps = getattr(ops, "packed_keys_help", None)
+        if helps is not None and helps(B, D, k):
+            if self._packed is None:
+                self._packed = ops.pack_keys(kn)
+            return ops.topk_cosine(q, kn, k, idx_base=idx_base, keys_packed=self._packed)
         return ops.topk_cosine(q, kn, k, idx_base=idx_base)
