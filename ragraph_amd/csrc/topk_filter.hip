@@ -548,8 +548,6 @@ __device__ __forceinline__ void wave_select(const float (&s)[NSL], const int64_t
   }
 }
 
-// Rescoring of one query by one wave with NS candidate slots per lane (n <= 64 * NS reserved slots): exact scores (one
-// lane per candidate, the k = 0..D-1 fmaf chain from +0), merge with the previous level's winners, canonical top-k.
 constexpr int RESCORE_LD = 68;  // floats per staged row: 16-B aligned, and 16 lanes x ds_read_b128 hit 64 distinct banks
 
 // Exact scores of 64 candidates (lane l: key `key`, -1 = none) with the rows fetched COOPERATIVELY: a load instruction
@@ -561,18 +559,30 @@ __device__ __forceinline__ float coop_scores(const float4* __restrict__ qrow, co
                                              int lane, float* sm) {
   float acc = 0.f;
   const int rr = lane >> 4, cc = lane & 15;
-#pragma unroll 1
-  for (int dc = 0; dc < D / 64; ++dc) {
-    float4 v[16];
+  constexpr int NDC = D / 64;
+  // the next 64-float block's sixteen loads are in flight while this one is staged and consumed: a wave's chain is one
+  // memory latency per list, not one per block (the kernel runs eight waves per CU and lives on latency hiding)
+  int krow[16];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int kr = __shfl(key, 4 * t + rr);
-      v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kr >= 0) v[t] = *reinterpret_cast<const float4*>(Kn + (int64_t)kr * D + dc * 64 + cc * 4);
-    }
+  for (int t = 0; t < 16; ++t) krow[t] = __shfl(key, 4 * t + rr);
+  float4 v[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (krow[t] >= 0) v[t] = *reinterpret_cast<const float4*>(Kn + (int64_t)krow[t] * D + cc * 4);
+  }
+#pragma unroll 1
+  for (int dc = 0; dc < NDC; ++dc) {
     __builtin_amdgcn_wave_barrier();  // (single wave: LDS executes its requests in order; only the compiler must not reorder)
 #pragma unroll
     for (int t = 0; t < 16; ++t) *reinterpret_cast<float4*>(sm + (4 * t + rr) * RESCORE_LD + cc * 4) = v[t];
+    if (dc + 1 < NDC) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (krow[t] >= 0) v[t] = *reinterpret_cast<const float4*>(Kn + (int64_t)krow[t] * D + cc * 4 + (dc + 1) * 64);
+      }
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -599,6 +609,7 @@ __device__ __forceinline__ void rescore_query(const float4* __restrict__ qrow, c
                                               const int* __restrict__ cand, int n, int lane, int k, int64_t base,
                                               const float* prev_s, const int64_t* prev_i, float* out_s, int64_t* out_i,
                                               float* sm = nullptr) {
+  const int first_keys = cand[lane];  // (no dependence on n: the list has >= 64 slots; issued next to the count's load)
   float s[NS + 1];
   int64_t id[NS + 1];
   // the previous level's winners ride along as already-scored candidates (lane l holds entry l; k <= 32)
@@ -613,7 +624,9 @@ __device__ __forceinline__ void rescore_query(const float4* __restrict__ qrow, c
     const int c = lane + 64 * u;
     s[u] = RG_NEG_INF;
     id[u] = INT64_MAX;
-    const int key = c < n ? cand[c] : -1;
+    int key = -1;
+    if (u == 0) key = c < n ? first_keys : -1;
+    else if (c < n) key = cand[c];
     if constexpr (COOP) {
       if (64 * u < n) {  // wave-uniform
         const float acc = coop_scores<D>(qrow, Kn, key, lane, sm);
@@ -701,10 +714,13 @@ __global__ void __launch_bounds__(128) topk_rescore_coop_kernel(const float* __r
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t b = (int64_t)blockIdx.x * 2 + w;
   if (b >= B) return;  // whole wave
-  if (lane < D / 4) qs[w][lane] = reinterpret_cast<const float4*>(Qn + b * D)[lane];
-  __builtin_amdgcn_wave_barrier();
+  // (the count, the flag and the query row are independent loads: issued together, one latency)
   int n = count[b];
   bool over = flag[b] != 0;
+  float4 qv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (lane < D / 4) qv4 = reinterpret_cast<const float4*>(Qn + b * D)[lane];
+  if (lane < D / 4) qs[w][lane] = qv4;
+  __builtin_amdgcn_wave_barrier();
   if (n > cap) {
     over = true;
     n = cap;
