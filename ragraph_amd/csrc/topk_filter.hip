@@ -1127,7 +1127,11 @@ static int run_filter_level_qw(const float* Qn, const float* Kn, const uint16_t*
   // exact rescoring (+ merge) + canonical selection
   const float* ps = merge ? out_scores : nullptr;
   const int64_t* pi = merge ? out_idx : nullptr;
-  if (B < 4096)  // too few queries to fill the chip with one wave each
+  static const int64_t wide_max_b = [] {  // RAGRAPH_RESCORE_WIDE_BELOW: A/B of the crossover
+    const char* e = getenv("RAGRAPH_RESCORE_WIDE_BELOW");
+    return e ? (int64_t)atoll(e) : (int64_t)2048;  // measured: 512 queries 0.39 (wide) vs 0.44 ms, 1024-2048 equal, 4095: 1.98 vs 1.89
+  }();
+  if (B < wide_max_b)  // too few queries to fill the chip with one wave each
     hipLaunchKernelGGL(topk_rescore_wide_kernel<D>, dim3((unsigned)B), dim3(256), 0, st, Qn, Kn, count, cand, B, cap, k,
                        idx_base, ps, pi, final_level, out_scores, out_idx, overflow, overflow_idx, flag);
   else if (rescore_coop())
