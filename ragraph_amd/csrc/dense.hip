@@ -317,7 +317,15 @@ static int launch_linear_stream(const float* X, int64_t M, const float* W, int64
   const int64_t total_stages = cdiv(M, C::STAGE_ROWS);
   const int64_t col_blocks = cdiv(N, 256);
   // ~2 workgroups per CU in flight (LDS 66 KB, <= 128 VGPRs); at least 4 stages each so the pipeline fills
-  int64_t wgs = 512 / col_blocks;
+  static const int64_t wgs_env = [] {  // RAGRAPH_LINEAR_WGS: A/B of the workgroup count
+    const char* e = getenv("RAGRAPH_LINEAR_WGS");
+    return e ? (int64_t)atoll(e) : (int64_t)0;
+  }();
+  // two workgroups per CU hide each other's latencies on long streams (1M x 128 -> 256: 639 vs 693 us); with a few
+  // stages per CU one workgroup each keeps the CUs evenly loaded (100k x 256 -> 256: 148 vs 168 us; 391 workgroups on
+  // 256 CUs left half of them with twice the work)
+  const int64_t wgs_target = wgs_env > 0 ? wgs_env : (total_stages >= 16 * 256 ? 512 : 256);
+  int64_t wgs = wgs_target / col_blocks;
   if (wgs < 1) wgs = 1;
   int64_t per = cdiv(total_stages, wgs);
   if (per < 4) per = 4;
