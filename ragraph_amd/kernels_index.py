@@ -10,6 +10,8 @@ class KeyIndex:
     `ops` supplies the kernels (default: this module); an object without the optional entries (the CPU tests' oracle
     shim) simply always takes topk_cosine."""
 
+    MAX_FILTERED_BATCH = 262144
+
     def __init__(self, keys_normalized: torch.Tensor, ops=None):
         if ops is None:
             from . import kernels as ops  # the HIP library; raises loudly without a GPU
@@ -27,6 +29,12 @@ class KeyIndex:
             if self._bf16 is None:
                 self._bf16 = ops.keys_to_bf16(kn)
             # (the packed fp32 copy is not made for this path: its first bound comes from the bf16 copy itself)
+            if B > self.MAX_FILTERED_BATCH:
+                # the candidate lists take 8 KiB per query: slabs of 256 k queries keep the workspace at 2 GiB (the edge
+                # flavour asks for all 4 M nodes at once) at the throughput of one big call
+                outs = [self.topk(q[b0:b0 + self.MAX_FILTERED_BATCH], k, idx_base)
+                        for b0 in range(0, B, self.MAX_FILTERED_BATCH)]
+                return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
             s, i, n_over = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base, keys_packed=self._packed)
             # A bank of near-duplicates (thousands of keys within the bf16 bound of a query's k-th best) overflows the
             # candidate lists, and every such row is recomputed with the fp32 kernels: still exact, but once a quarter

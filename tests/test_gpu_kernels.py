@@ -507,6 +507,12 @@ def test_key_index_dispatch_same_bits(dev, monkeypatch):
         rs, ri = cref.topk_cosine(q, kn, 10, idx_base=4)
         assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs)
     assert index._bf16 is not None
+    # batches beyond MAX_FILTERED_BATCH go through the filtered path in slabs (bounded workspace): same rows, same order
+    monkeypatch.setattr(K.KeyIndex, "MAX_FILTERED_BATCH", 300)
+    q = rng.standard_normal((800, 256), dtype=np.float32)
+    s, i = index.topk(_t(q, dev), 10, idx_base=4)
+    rs, ri = cref.topk_cosine(q, kn, 10, idx_base=4)
+    assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs)
     monkeypatch.setenv("RAGRAPH_EXACT_FP32", "1")
     assert not K.filter_helps(800, 70000, 256, 10)
     q = rng.standard_normal((200, 256), dtype=np.float32)  # tile kernel with the packed copy
