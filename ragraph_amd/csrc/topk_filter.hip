@@ -21,8 +21,9 @@
 // best) is counted in *overflow and must be re-run through ragraph_topk_cosine_bank_f32 by the caller; the other
 // queries' results are exact regardless.
 //
-// Filter kernel: workgroup = 8 waves x 64 queries = 512 queries (x 32 = 256 for batches of <= 256); a wave keeps its
-// queries as the B operands of v_mfma_f32_32x32x16_bf16 (two groups of 32: 2 x D/4 VGPRs) and streams the bf16 bank
+// Filter kernel: workgroup = 8 waves x 64 queries = 512 queries (x 32 = 256 for batches of <= 256, x 128 = 1024 at
+// D = 64); a wave keeps its queries as the B operands of v_mfma_f32_32x32x16_bf16 (groups of 32: D/4 VGPRs each) and
+// streams the bf16 bank
 // (2 D bytes per key) through a 4-slot LDS ring of 32 KiB stages (64 / 128 / 256 keys at D = 256 / 128 / 64) filled by
 // LDS-DMA, 1 KiB per global_load_lds_dwordx4, handed over by FULL/FREE counters.  One ds_read_b128 (8 bf16 of one key
 // row) feeds two MFMAs (one per query group).  The LDS image is XOR-swizzled through the DMA's per-lane SOURCE address
@@ -207,9 +208,9 @@ __device__ unsigned long long g_filter_timing[8];
 template <int D, int QW, bool BOUND = false>
 __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
   using C = FilterCfg<D>;
-  static_assert(QW == 64 || QW == 32, "one or two query groups per wave");
+  static_assert(QW == 32 || QW == 64 || QW == 128, "one, two or four query groups of 32 per wave");
   constexpr int QT = C::WAVES * QW;
-  constexpr bool TWO = (QW == 64);
+  constexpr int NG = QW / 32;  // query groups per wave: each A fragment feeds NG MFMAs
   extern __shared__ float4 fsmem4[];
   char* smem = reinterpret_cast<char*>(fsmem4);
   unsigned* full = reinterpret_cast<unsigned*>(smem + C::SLOTS * C::STAGE_BYTES);  // [SLOTS] then freec [SLOTS]
@@ -268,47 +269,47 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
   Segment seg;
   while (walker.next(seg)) {
     const int64_t qtile = p.xcd_map ? x + 8 * seg.tile : seg.tile;
-    const int64_t q_lo = qtile * QT + wave * QW + j, q_hi = q_lo + 32;
+    const int64_t q_lo = qtile * QT + wave * QW + j;  // group gq's query: q_lo + 32 gq
     const int64_t st0 = seg.st0;
     const int nstages = (int)(seg.st1 - seg.st0);
 
-    // ---- B operands: queries q_lo / q_hi, k-step t = elements 16 t + 8 g .. + 7, converted to bf16 (RNE) ----------
-    bf16x8 b0[C::KSTEPS], b1[C::KSTEPS];
-    {
-      const float* r0 = p.Qn + (q_lo < p.B ? q_lo : p.B - 1) * D + 8 * g;
-      const float* r1 = p.Qn + (q_hi < p.B ? q_hi : p.B - 1) * D + 8 * g;
+    // ---- B operands: group gq's query q_lo + 32 gq, k-step t = elements 16 t + 8 g .. + 7, converted to bf16 (RNE) ----
+    bf16x8 bq[NG][C::KSTEPS];
 #pragma unroll
-      for (int t0 = 0; t0 < C::KSTEPS; t0 += 4) {  // batches of 4 steps = 16 float4 in flight
+    for (int gq = 0; gq < NG; ++gq) {
+      const int64_t qq = q_lo + 32 * gq;
+      const float* r0 = p.Qn + (qq < p.B ? qq : p.B - 1) * D + 8 * g;
+#pragma unroll
+      for (int t0 = 0; t0 < C::KSTEPS; t0 += 4) {  // batches of 4 steps = 8 float4 in flight
 #pragma unroll
         for (int t = t0; t < t0 + 4; ++t) {
           const float4 u0 = *reinterpret_cast<const float4*>(r0 + 16 * t), u1 = *reinterpret_cast<const float4*>(r0 + 16 * t + 4);
-          float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
-          if constexpr (TWO) {
-            w0 = *reinterpret_cast<const float4*>(r1 + 16 * t);
-            w1 = *reinterpret_cast<const float4*>(r1 + 16 * t + 4);
-          }
-          b0[t][0] = (__bf16)u0.x; b0[t][1] = (__bf16)u0.y; b0[t][2] = (__bf16)u0.z; b0[t][3] = (__bf16)u0.w;
-          b0[t][4] = (__bf16)u1.x; b0[t][5] = (__bf16)u1.y; b0[t][6] = (__bf16)u1.z; b0[t][7] = (__bf16)u1.w;
-          b1[t][0] = (__bf16)w0.x; b1[t][1] = (__bf16)w0.y; b1[t][2] = (__bf16)w0.z; b1[t][3] = (__bf16)w0.w;
-          b1[t][4] = (__bf16)w1.x; b1[t][5] = (__bf16)w1.y; b1[t][6] = (__bf16)w1.z; b1[t][7] = (__bf16)w1.w;
+          bq[gq][t][0] = (__bf16)u0.x; bq[gq][t][1] = (__bf16)u0.y; bq[gq][t][2] = (__bf16)u0.z; bq[gq][t][3] = (__bf16)u0.w;
+          bq[gq][t][4] = (__bf16)u1.x; bq[gq][t][5] = (__bf16)u1.y; bq[gq][t][6] = (__bf16)u1.z; bq[gq][t][7] = (__bf16)u1.w;
         }
 #pragma unroll
-        for (int t = t0; t < t0 + 4; ++t) asm volatile("" : "+v"(b0[t]), "+v"(b1[t]));
+        for (int t = t0; t < t0 + 4; ++t) asm volatile("" : "+v"(bq[gq][t]));
         asm volatile("" ::: "memory");
       }
     }
     // padded queries never pass: +inf threshold
-    float thr0 = (!BOUND && q_lo < p.B) ? p.thr[q_lo] : __builtin_huge_valf();
-    float thr1 = (!BOUND && TWO && q_hi < p.B) ? p.thr[q_hi] : __builtin_huge_valf();
+    float thr[NG];
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq)
+      thr[gq] = (!BOUND && q_lo + 32 * gq < p.B) ? p.thr[q_lo + 32 * gq] : __builtin_huge_valf();
     // bound pass: running maxima of the current group (group g = stages [ceil(g n / G), ceil((g+1) n / G)) of the range)
-    float gm0 = RG_NEG_INF, gm1 = RG_NEG_INF;
+    float gm[NG];
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) gm[gq] = RG_NEG_INF;
     int grp = 0;
     int64_t grp_end = 0;  // first stage (range-relative) of the next group
     auto group_of = [&](int64_t t) { return (int)(t * p.ngroups / p.nstages_total); };  // largest g with ceil(g n / G) <= t
     auto flush_max = [&]() {
-      if (q_lo < p.B) atomicMax(p.gmax + q_lo * p.ngroups + grp, f2ord(gm0));
-      if (TWO && q_hi < p.B) atomicMax(p.gmax + q_hi * p.ngroups + grp, f2ord(gm1));
-      gm0 = gm1 = RG_NEG_INF;
+#pragma unroll
+      for (int gq = 0; gq < NG; ++gq) {
+        if (q_lo + 32 * gq < p.B) atomicMax(p.gmax + (q_lo + 32 * gq) * p.ngroups + grp, f2ord(gm[gq]));
+        gm[gq] = RG_NEG_INF;
+      }
     };
     if constexpr (BOUND) {
       grp = group_of(st0);
@@ -330,8 +331,8 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
         const int i = i0 + lane;
         if (i < wcnt) {
           const uint2 e = wbuf[i];
-          const int64_t q = q_wave + (e.x >> 26);
-          const int key0 = key_org + (int)(e.x & 0x3FFFFFFu);
+          const int64_t q = q_wave + (e.x >> 25);
+          const int key0 = key_org + (int)(e.x & 0x1FFFFFFu);
           unsigned mk = e.y;
           int slot = atomicAdd(p.count + q, __popc(mk));
           // retired here on every path: a return hipcc still considers pending where the flush rejoins the stage loop
@@ -350,7 +351,9 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     // hipcc does not know about the asm DMA loads, and any vmcnt(0) it emits inside the stage loop (for a global load it
     // still considers pending at the loop's back edge) would drain them every sub-tile: retire the thresholds here and
     // hand them to the loop as plain register values
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(thr0), "+v"(thr1) : : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) asm volatile("" : "+v"(thr[gq]));
 
     // ---- ring prologue ------------------------------------------------------------------------------------------
     const int pro = nstages < C::SLOTS - 1 ? nstages : C::SLOTS - 1;
@@ -367,9 +370,9 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
 #endif
     for (int s = 0; s < nstages; ++s) {
       const int slot = s & (C::SLOTS - 1), gen = s / C::SLOTS;
-      if ((s & 0xFFFF) == 0 && s > 0) {  // keep the entries' key offsets inside 26 bits
+      if ((s & 0x7FFF) == 0 && s > 0) {  // keep the entries' key offsets inside 25 bits
         flush();
-        key_org += 0x10000 * C::STAGE_KEYS;
+        key_org += 0x8000 * C::STAGE_KEYS;
       }
       if constexpr (BOUND) {
         if (st0 + s >= grp_end) {  // (groups hold at least one stage each: at most one boundary per stage)
@@ -396,37 +399,42 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
           wcnt += __popcll(m);
         }
       };
-      auto epilogue = [&](int u, const f32x16& a0, const f32x16& a1) {
-        float m0 = a0[0], m1 = TWO ? a1[0] : RG_NEG_INF;
+      auto epilogue = [&](int u, const f32x16 (&a)[NG]) {
+        float m[NG];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) {
-          m0 = fmaxf(m0, a0[r]);
-          if constexpr (TWO) m1 = fmaxf(m1, a1[r]);
+        for (int gq = 0; gq < NG; ++gq) {
+          m[gq] = a[gq][0];
+#pragma unroll
+          for (int r = 1; r < 16; ++r) m[gq] = fmaxf(m[gq], a[gq][r]);
         }
+        bool hit = false;
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) hit = hit || (m[gq] >= thr[gq]);
         if constexpr (BOUND) {
-          gm0 = fmaxf(gm0, m0);
-          if constexpr (TWO) gm1 = fmaxf(gm1, m1);
-        } else if (__any(m0 >= thr0 || (TWO && m1 >= thr1))) {
+#pragma unroll
+          for (int gq = 0; gq < NG; ++gq) gm[gq] = fmaxf(gm[gq], m[gq]);
+        } else if (__any(hit)) {
           const int stage_key0 = (int)((p.stage_base + st0 + s) * C::STAGE_KEYS);
           const int key_base = stage_key0 + 32 * u + 4 * g;  // the lane's keys: key_base + (r & 3) + 8 (r >> 2)
           // (a group without a passing lane skips its sixteen compares: at the later levels a sub-tile that has a
           // candidate at all usually has it in one group only)
-          unsigned k0 = 0, k1 = 0;
-          if (__any(m0 >= thr0)) k0 = pass_mask(a0, thr0);
-          if constexpr (TWO) {
-            if (__any(m1 >= thr1)) k1 = pass_mask(a1, thr1);
+          unsigned km[NG];
+#pragma unroll
+          for (int gq = 0; gq < NG; ++gq) {
+            km[gq] = 0;
+            if (__any(m[gq] >= thr[gq])) km[gq] = pass_mask(a[gq], thr[gq]);
           }
           if (stage_key0 + C::STAGE_KEYS > (int)p.N) {  // the range's last stage: keys >= N (padding, or the next level's)
             unsigned vm = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) vm |= (key_base + (r & 3) + 8 * (r >> 2) < (int)p.N) ? (1u << r) : 0u;
-            k0 &= vm;
-            k1 &= vm;
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) km[gq] &= vm;
           }
-          if (wcnt > C::CAND_BUF - 128) flush();  // a sub-tile pushes at most 2 x 64 entries
+          if (wcnt > C::CAND_BUF - 64 * NG) flush();  // a sub-tile pushes at most NG x 64 entries
           const unsigned off = (unsigned)(key_base - key_org);
-          push(k0, ((unsigned)j << 26) | off);
-          if constexpr (TWO) push(k1, ((unsigned)(j + 32) << 26) | off);
+#pragma unroll
+          for (int gq = 0; gq < NG; ++gq) push(km[gq], ((unsigned)(j + 32 * gq) << 25) | off);
         }
       };
       // ---- SUBS sub-tiles of 32 keys x 64 queries, KSTEPS k-steps each; one A fragment per step feeds both query groups.
@@ -437,7 +445,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
       unsigned addr[NA];
 #pragma unroll
       for (int i = 0; i < NA; ++i) addr[i] = apos[i] + (unsigned)(slot * C::STAGE_BYTES);
-      f32x16 acc0, acc1;
+      f32x16 acc[NG];
       f32x4 fr[4];
 #define RG_FREAD(n_)                                                                                       \
   asm volatile("ds_read_b128 %0, %1 offset:%2"                                                             \
@@ -448,7 +456,8 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
 #define RG_FSTEP(n_)                                                                                       \
   {                                                                                                        \
     if constexpr ((n_) % C::KSTEPS == 0) {                                                                 \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;                               \
+      _Pragma("unroll") for (int gq = 0; gq < NG; ++gq)                                                     \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[gq][r] = 0.f;                                    \
     }                                                                                                      \
     if constexpr ((n_) + 3 < C::NSTEP) RG_FWAIT(3, n_);                                                     \
     else if constexpr ((n_) + 2 < C::NSTEP) RG_FWAIT(2, n_);                                                \
@@ -456,12 +465,11 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     else RG_FWAIT(0, n_);                                                                                   \
     {                                                                                                      \
       const bf16x8 a_ = __builtin_bit_cast(bf16x8, fr[(n_)&3]);                                             \
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b0[(n_) % C::KSTEPS], acc0, 0, 0, 0);              \
-      if constexpr (TWO)                                                                                    \
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b1[(n_) % C::KSTEPS], acc1, 0, 0, 0);            \
+      _Pragma("unroll") for (int gq = 0; gq < NG; ++gq)                                                     \
+        acc[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, bq[gq][(n_) % C::KSTEPS], acc[gq], 0, 0, 0);  \
     }                                                                                                      \
     if constexpr ((n_) + 4 < C::NSTEP) RG_FREAD((n_) + 4);                                                  \
-    if constexpr ((n_) % C::KSTEPS == C::KSTEPS - 1) epilogue((n_) / C::KSTEPS, acc0, acc1);                \
+    if constexpr ((n_) % C::KSTEPS == C::KSTEPS - 1) epilogue((n_) / C::KSTEPS, acc);                       \
   }
 #define RG_FSTEP8(n_) RG_FSTEP(n_) RG_FSTEP((n_) + 1) RG_FSTEP((n_) + 2) RG_FSTEP((n_) + 3) \
     RG_FSTEP((n_) + 4) RG_FSTEP((n_) + 5) RG_FSTEP((n_) + 6) RG_FSTEP((n_) + 7)
@@ -820,6 +828,14 @@ static bool rescore_coop() {  // RAGRAPH_RESCORE_COOP=0: every lane reads its ow
   return on;
 }
 
+static bool filter_wide_waves(int64_t B) {  // RAGRAPH_FILTER_QW128=0/1: A/B; default from 1024 queries (one full tile)
+  static const int env = [] {
+    const char* e = getenv("RAGRAPH_FILTER_QW128");
+    return e ? atoi(e) : -1;
+  }();
+  return env < 0 ? B >= 1024 : env != 0;
+}
+
 static int filter_device_cus() {
   static const int cus = [] {
     if (const char* e = getenv("RAGRAPH_TOPK_CUS")) {
@@ -1154,6 +1170,13 @@ static int run_filter_level(const float* Qn, const float* Kn, const uint16_t* Kb
   if (B <= 256)
     return run_filter_level_qw<D, 32>(Qn, Kn, Kb, B, key0, key1, k, idx_base, first, merge, final_level, out_scores, out_idx,
                                       overflow, overflow_idx, thr, eq, max_kerr2, count, flag, cand, cap, level, gmax, st);
+  if constexpr (D == 64) {  // short rows leave registers for four query groups per wave: half the LDS reads and ring
+                            // hand-overs per MFMA (the edge flavour's D)
+    if (filter_wide_waves(B))
+      return run_filter_level_qw<D, 128>(Qn, Kn, Kb, B, key0, key1, k, idx_base, first, merge, final_level, out_scores,
+                                         out_idx, overflow, overflow_idx, thr, eq, max_kerr2, count, flag, cand, cap, level,
+                                         gmax, st);
+  }
   return run_filter_level_qw<D, 64>(Qn, Kn, Kb, B, key0, key1, k, idx_base, first, merge, final_level, out_scores, out_idx,
                                     overflow, overflow_idx, thr, eq, max_kerr2, count, flag, cand, cap, level, gmax, st);
 }
