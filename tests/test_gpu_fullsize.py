@@ -159,3 +159,16 @@ def test_filtered_topk_beyond_2gib_of_bf16_keys(dev):
             s2, i2 = K.topk_cosine(q, kn, 10, idx_base=3, keys_packed=kp)
             assert torch.equal(i0, i2) and torch.equal(s0, s2)
         assert int(i1[0, 0]) == n - 1 + 3 and int(i1[1, 0]) == n // 2 + 77 + 3
+    del kn, kb, kp
+    torch.cuda.empty_cache()
+    # the edge flavour's D = 64 with four query groups per wave (B >= 1024): 20M keys = 2.56 GB of bf16
+    n = 20_000_000
+    kn = K.normalize_rows(torch.randn(n, 64, device=dev, generator=g))
+    kb = K.keys_to_bf16(kn)
+    q = torch.randn(2048, 64, device=dev, generator=g)
+    q[0] = kn[n - 1]
+    q[1] = kn[n // 2 + 12345]
+    s1, i1, over = K.topk_cosine_filtered(q, kn, kb, 10, idx_base=3)
+    s0, i0 = K.topk_cosine(q, kn, 10, idx_base=3)
+    assert over == 0 and torch.equal(i0, i1) and torch.equal(s0, s1)
+    assert int(i1[0, 0]) == n - 1 + 3 and int(i1[1, 0]) == n // 2 + 12345 + 3
