@@ -153,6 +153,94 @@ void run(const char* name, int threads) {
   printf("%-60s %8.3f ms  %7.1f TFLOP/s\n", name, best, flop / best / 1e9);
   hipFree(d);
 }
+// MODE 6 (separate kernel): ONE wave per SIMD (256 threads, up to 512 registers per lane), FOUR accumulator chains sharing
+// each A fragment (B operands: 4 x 16 x 4 = 256 registers): half the LDS reads per MFMA of the product kernel.
+template <int RANDOM>
+__global__ void __launch_bounds__(256, 1) k4(float* out, int iters, float a) {
+  extern __shared__ float4 smem4[];
+  char* smem = (char*)smem4;
+  const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
+  for (int i = threadIdx.x; i < 32768 / 2; i += blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    const float v = RANDOM ? ((int)(h & 0xFFFF) - 32768) * (1.f / 32768.f) : a + i * 1e-7f;
+    ((__bf16*)smem)[i] = (__bf16)v;
+  }
+  __syncthreads();
+  bf16x8 b[4][16];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        unsigned h = (unsigned)(threadIdx.x * 131 + t * 17 + e + c * 7919) * 2654435761u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        const float v = ((int)(h & 0xFFFF) - 32768) * (1.f / 32768.f) * 0.0625f;
+        b[c][t][e] = RANDOM ? (__bf16)v : (__bf16)(a + t * 1e-3f + e * 1e-2f + lane * 1e-4f + c);
+      }
+  float keep = 0.f;
+  const unsigned lds_base = (unsigned)(size_t)(lds_void*)smem;
+  unsigned addr[8];
+  const unsigned c0 = (unsigned)(g ^ (j & 15));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) addr[i] = lds_base + (unsigned)j * 512 + (((unsigned)(2 * i) ^ c0) << 4);
+  for (int it = 0; it < iters; ++it) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    f32x4 fr[4];
+#define QREAD(n_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[(n_)&3]) : "v"(addr[(n_)&7]), "i"(((n_) >= 8) ? 256 : 0))
+#define QWAIT(c_, n_) asm volatile("s_waitcnt lgkmcnt(" #c_ ")" : "+v"(fr[(n_)&3]))
+#define QSTEP(n_)                                                                          \
+  {                                                                                        \
+    if constexpr ((n_) + 3 < 16) QWAIT(3, n_);                                             \
+    else if constexpr ((n_) + 2 < 16) QWAIT(2, n_);                                        \
+    else if constexpr ((n_) + 1 < 16) QWAIT(1, n_);                                        \
+    else QWAIT(0, n_);                                                                     \
+    const bf16x8 a_ = __builtin_bit_cast(bf16x8, fr[(n_)&3]);                              \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c)                                          \
+      acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b[c][n_], acc[c], 0, 0, 0);     \
+    if constexpr ((n_) + 4 < 16) QREAD((n_) + 4);                                          \
+  }
+    QREAD(0); QREAD(1); QREAD(2); QREAD(3);
+    QSTEP(0) QSTEP(1) QSTEP(2) QSTEP(3) QSTEP(4) QSTEP(5) QSTEP(6) QSTEP(7)
+    QSTEP(8) QSTEP(9) QSTEP(10) QSTEP(11) QSTEP(12) QSTEP(13) QSTEP(14) QSTEP(15)
+    float m = acc[0][0];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[c][r]);
+    if (__any(m >= 1e30f)) keep += m;
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = keep;
+}
+template <int RANDOM>
+void run4(const char* name) {
+  float* d;
+  hipMalloc(&d, 256 * 512 * 4);
+  hipFuncSetAttribute((const void*)k4<RANDOM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  int iters = 20000;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const size_t lds = 140 * 1024;
+  k4<RANDOM><<<256, 256, lds>>>(d, 10, 1.0f);
+  hipDeviceSynchronize();
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0);
+    k4<RANDOM><<<256, 256, lds>>>(d, iters, 1.0001f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  double flop = 256.0 * 4 * iters * 64.0 * 32768.0;
+  printf("%-60s %8.3f ms  %7.1f TFLOP/s\n", name, best, flop / best / 1e9);
+  hipFree(d);
+}
 int main() {
   run<0, 0>("A in registers, 2 waves/SIMD", 512);
   run<0, 0>("A in registers, 1 wave/SIMD", 256);
@@ -166,5 +254,8 @@ int main() {
   run<5, 0>("2x2 blocking, snake order, near-constant operands", 512);
   run<5, 1>("2x2 blocking, snake order, RANDOM operands", 512);
   run<3, 1>("(again) 1x2 on RANDOM operands", 512);
+  run4<0>("1 wave/SIMD, FOUR chains per A fragment, near-constant");
+  run4<1>("1 wave/SIMD, FOUR chains per A fragment, RANDOM operands");
+  run<3, 1>("(again) 1x2 on RANDOM operands, 2 waves/SIMD", 512);
   return 0;
 }
