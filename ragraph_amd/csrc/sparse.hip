@@ -305,6 +305,8 @@ __global__ void __launch_bounds__(256) segment_reduce_kernel(const float* __rest
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 wv = make_float4(1.f, 1.f, 1.f, 1.f);
     if (w) wv = reinterpret_cast<const float4*>(w)[c4];
+    // (eight rows' loads in flight; the additions stay in row order)
+#pragma unroll 8
     for (int64_t r = r0; r < r1; ++r) {
       float4 x = X4[r * D4 + c4];
       if (w) { x.x = __fmul_rn(wv.x, x.x); x.y = __fmul_rn(wv.y, x.y); x.z = __fmul_rn(wv.z, x.z); x.w = __fmul_rn(wv.w, x.w); }

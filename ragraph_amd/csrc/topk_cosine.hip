@@ -1054,7 +1054,8 @@ static int64_t slab_rows_for(int64_t B, int64_t N) {
 
 extern "C" size_t ragraph_topk_cosine_workspace_bytes(int64_t B, int64_t N, int D, int k) {
   if (B < 1 || N < 1 || k < 1 || (D != 64 && D != 128 && D != 256)) return 0;
-  if (k > 32) return align_up((size_t)B * D * sizeof(float), 256) + (size_t)slab_rows_for(B, N) * N * sizeof(float);
+  if (k > 32 || (B <= 128 && N <= 8192 && B * N <= ((int64_t)1 << 20)))
+    return align_up((size_t)B * D * sizeof(float), 256) + (size_t)slab_rows_for(B, N) * N * sizeof(float);
   TopkPlan pl = plan_topk(B, N, D, k);
   return pl.qn_bytes + pl.part_s_bytes + pl.part_i_bytes;
 }
@@ -1123,7 +1124,11 @@ extern "C" int ragraph_topk_cosine_bank_f32(const float* Q, int64_t B, const flo
              RAGRAPH_TOPK_MAX);
   RG_REQUIRE(N < (int64_t)INT_MAX - 1024, RAGRAPH_EUNSUPPORTED, "topk_cosine: shard rows must fit int32");
   RG_REQUIRE(aligned16(Q) && aligned16(Kn) && aligned16(ws), RAGRAPH_EINVAL, "topk_cosine: Q, Kn, ws must be 16-B aligned");
-  if (k > 32) {  // materialised slabs, see slab_rows_for()
+  // A handful of queries against a bank of a few thousand keys (graph classification: 16 graphs x the training set's
+  // 1113): every key is still a candidate for every list, and the streaming kernel's cooperative inserts -- one
+  // (query, key) at a time -- were 45 us of a 150 us forward.  The slab path (dense kernel + topk_rows) has no lists.
+  const bool tiny = B <= 128 && N <= 8192 && B * N <= ((int64_t)1 << 20);
+  if (k > 32 || tiny) {  // materialised slabs, see slab_rows_for()
     const size_t qn_bytes = align_up((size_t)B * D * sizeof(float), 256);
     const int64_t rows = slab_rows_for(B, N);
     RG_REQUIRE(ws_bytes >= qn_bytes + (size_t)rows * N * sizeof(float), RAGRAPH_EWORKSPACE, "topk_cosine: workspace too small");
