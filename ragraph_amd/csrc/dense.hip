@@ -358,7 +358,10 @@ extern "C" int ragraph_linear_f32(const float* X, int64_t M, int K, const float*
            : K == 128 ? launch_linear_stream<128>(X, M, W, N, bias, act, alpha, Y, st)
                       : launch_linear_stream<64>(X, M, W, N, bias, act, alpha, Y, st);
   }
-  if (tile_ok && M >= TBM && N >= TBN && K % 4 == 0 && aligned16(X) && aligned16(W)) {
+  // (a handful of 128 x 128 tiles leaves most of the chip idle and each workgroup alone with its latencies: the
+  // 64 x 64 kernel has four times the workgroups -- Cora-sized decoder 2708 x 128 -> 128: 30 -> 10 us)
+  if (tile_ok && M >= TBM && N >= TBN && K % 4 == 0 && aligned16(X) && aligned16(W) &&
+      cdiv(M, TBM) * cdiv(N, TBN) >= 64) {
     const size_t lds = sizeof(float) * 4 * TBM * TLD;
     static bool attr_set = false;
     if (!attr_set) {
