@@ -1046,6 +1046,19 @@ using namespace ragraph;
 // lists no longer fit next to the stages in LDS, so the scores of a slab of queries are materialised with the dense
 // kernel (the same fmaf chains, hence the same bits) and selected by topk_rows -- the reference's own slab idiom
 // (modules/RAGraph.py:298-311), kept on the device.
+// Small score matrices are cheaper to WRITE than to avoid: the dense kernel fills the whole chip whatever B is, and
+// topk_rows has no list warm-up per workgroup, while the fused kernels pay launch-sized fixed costs (query operands,
+// ring, list inserts) that only a long key stream amortises.  Measured (us, slab vs fused kernels, k = 10): 64 x 20000
+// x 256: 55 vs 209; 128 x 50000: 106 vs 341; 1500 x 10000: 170 vs 257; 2000 x 16000: 292 vs 369; 4000 x 4000 x 128:
+// 121 vs 136; not 2708 x 10000 x 128 (186 vs 168) nor one to a few queries against a long bank (the dense kernel pads
+// to 64 rows; the streaming kernel runs at HBM speed).  RAGRAPH_TOPK_SLAB=0 turns the rule off (A/B).
+static bool use_slab(int64_t B, int64_t N, int D) {
+  const char* e = getenv("RAGRAPH_TOPK_SLAB");  // (read per call: the tests switch it to reach both families of kernels)
+  if (e && atoi(e) == 0) return false;
+  if (B <= 128 && N <= 8192 && B * N <= ((int64_t)1 << 20)) return true;  // a handful of queries x a tiny bank
+  return B >= 8 && N <= 131072 && B * N <= (D == 256 ? (int64_t)1 << 25 : (int64_t)1 << 24);
+}
+
 static int64_t slab_rows_for(int64_t B, int64_t N) {
   int64_t rows = ((int64_t)1 << 30) / (4 * N);  // ~1 GiB of scores per slab
   if (rows < 64) rows = 64;
@@ -1054,7 +1067,7 @@ static int64_t slab_rows_for(int64_t B, int64_t N) {
 
 extern "C" size_t ragraph_topk_cosine_workspace_bytes(int64_t B, int64_t N, int D, int k) {
   if (B < 1 || N < 1 || k < 1 || (D != 64 && D != 128 && D != 256)) return 0;
-  if (k > 32 || (B <= 128 && N <= 8192 && B * N <= ((int64_t)1 << 20)))
+  if (k > 32 || use_slab(B, N, D))
     return align_up((size_t)B * D * sizeof(float), 256) + (size_t)slab_rows_for(B, N) * N * sizeof(float);
   TopkPlan pl = plan_topk(B, N, D, k);
   return pl.qn_bytes + pl.part_s_bytes + pl.part_i_bytes;
@@ -1127,8 +1140,7 @@ extern "C" int ragraph_topk_cosine_bank_f32(const float* Q, int64_t B, const flo
   // A handful of queries against a bank of a few thousand keys (graph classification: 16 graphs x the training set's
   // 1113): every key is still a candidate for every list, and the streaming kernel's cooperative inserts -- one
   // (query, key) at a time -- were 45 us of a 150 us forward.  The slab path (dense kernel + topk_rows) has no lists.
-  const bool tiny = B <= 128 && N <= 8192 && B * N <= ((int64_t)1 << 20);
-  if (k > 32 || tiny) {  // materialised slabs, see slab_rows_for()
+  if (k > 32 || use_slab(B, N, D)) {  // materialised slabs, see slab_rows_for()
     const size_t qn_bytes = align_up((size_t)B * D * sizeof(float), 256);
     const int64_t rows = slab_rows_for(B, N);
     RG_REQUIRE(ws_bytes >= qn_bytes + (size_t)rows * N * sizeof(float), RAGRAPH_EWORKSPACE, "topk_cosine: workspace too small");

@@ -134,13 +134,16 @@ def keys_to_bf16(keys_normalized: torch.Tensor) -> torch.Tensor:
 def filter_helps(B: int, n_keys: int, D: int, k: int) -> bool:
     """True when the bf16-filtered exact top-k is the faster way to the same bits.  Measured on MI355X (ms, filtered vs
     fp32 kernels, D = 256, k = 10): 16 queries x 1M keys 0.30 vs 0.32, 64 x 1M 0.33 vs 0.76, 256 x 1M 0.32 vs 1.54,
-    4096 x 1M 1.9 vs 16.0, 100k x 1M 41 vs 366; 16 x 65536 0.135 vs 0.155, 1024 x 65536 0.23 vs 0.59.  One to a dozen
+    4096 x 1M 1.9 vs 16.0, 100k x 1M 41 vs 366; 1024 x 65536 0.23 vs 0.59.  One to a dozen
     queries stay on the streaming fp32 kernel (1 x 1M: 0.21 vs 0.25), small banks on the tile kernel."""
     if os.environ.get("RAGRAPH_EXACT_FP32") == "1":
         return False
     if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
         return False  # the filtered call reads its overflow count back: not capturable, the fp32 kernels are
     if D not in (64, 128, 256) or k > 32:
+        return False
+    # small score matrices are cheaper materialised (the fp32 entry's slab rule: 64 x 65536: 81 vs 129 us filtered)
+    if n_keys <= 131072 and B * n_keys <= 6 * (1 << 20):
         return False
     # mid-sized banks pay off for larger batches only (8192 x 20000 x 256: 0.37 vs 1.07 ms; 545 x 20000: 0.22 vs 0.26)
     return (n_keys >= 65536 and B >= 12) or (n_keys >= 16384 and B >= 2048)

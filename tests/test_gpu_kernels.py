@@ -24,6 +24,18 @@ def _bank(rng, N, D):
     return cref.normalize_rows(rng.standard_normal((N, D), dtype=np.float32))
 
 
+@pytest.fixture(params=["fused", "slab-rule"])
+def topk_family(request, monkeypatch):
+    """Small score matrices take the slab path (dense kernel + topk_rows) by default; RAGRAPH_TOPK_SLAB=0 (read per
+    call) keeps every shape on the fused kernels.  The fp32 top-k tests run under both, so that neither family of
+    kernels loses its small-shape coverage to the dispatch rule."""
+    if request.param == "fused":
+        monkeypatch.setenv("RAGRAPH_TOPK_SLAB", "0")
+    else:
+        monkeypatch.delenv("RAGRAPH_TOPK_SLAB", raising=False)
+    return request.param
+
+
 @pytest.mark.parametrize("n,D", [(1, 1), (5, 3), (7, 64), (33, 128), (257, 256), (4, 1433), (3, 300)])
 def test_normalize_rows_bit_exact(dev, n, D):
     from ragraph_amd import kernels as K
@@ -62,7 +74,7 @@ def test_normalize_rows_bit_exact(dev, n, D):
         (40, 3000, 256, 31),     # largest k the streaming kernel's LDS holds
     ],
 )
-def test_topk_cosine_bit_exact(dev, B, N, D, k):
+def test_topk_cosine_bit_exact(dev, topk_family, B, N, D, k):
     from ragraph_amd import kernels as K
 
     rng = _rng(B * 7 + N + D + k)
@@ -74,7 +86,7 @@ def test_topk_cosine_bit_exact(dev, B, N, D, k):
     assert np.array_equal(s.cpu().numpy(), rs)
 
 
-def test_topk_cosine_duplicates_and_zero_query(dev):
+def test_topk_cosine_duplicates_and_zero_query(dev, topk_family):
     """Toy banks hold exact duplicate keys (multinomial with replacement, ToyGraphBase.py:98); torch.topk leaves the
     order of ties open, the library breaks them towards the lower index."""
     from ragraph_amd import kernels as K
@@ -301,7 +313,7 @@ def test_errors_are_loud(dev):
         (1000, 20000, 1),
     ],
 )
-def test_topk_cosine_packed_bank_bit_exact(dev, B, N, k):
+def test_topk_cosine_packed_bank_bit_exact(dev, topk_family, B, N, k):
     """LDS-DMA ring over the packed bank copy (D = 256, B > 128, k <= 14) vs the oracle, and the pack layout itself."""
     from ragraph_amd import kernels as K
 
@@ -336,7 +348,7 @@ def test_pack_keys_other_dims(dev, D):
     assert np.array_equal(kp, np.concatenate([kn[:, 0::2], kn[:, 1::2]], axis=1))
 
 
-def test_topk_cosine_fuzz_against_oracle(dev):
+def test_topk_cosine_fuzz_against_oracle(dev, topk_family):
     """60 random shapes across all kernel paths (streaming with 1-8 groups, with / without the pre-pass; tile kernel
     with 1-3 query tiles, ring and barrier variants; materialised k > 32), ragged sizes, duplicate keys, zero queries."""
     from ragraph_amd import kernels as K
@@ -500,9 +512,9 @@ def test_key_index_dispatch_same_bits(dev, monkeypatch):
     kn = _bank(rng, 70000, 256)
     knd = _t(kn, dev)
     index = K.KeyIndex(knd)
-    for B in (3, 40, 200, 800):  # 3: streaming fp32 kernel; the others: filtered (<= 256: one query group per wave)
+    for B in (3, 40, 200, 800):  # 3: streaming fp32 kernel; 40: score slab; 200, 800: filtered (<= 256: one group per wave)
         q = rng.standard_normal((B, 256), dtype=np.float32)
-        assert K.filter_helps(B, 70000, 256, 10) == (B >= 12)
+        assert K.filter_helps(B, 70000, 256, 10) == (B >= 200)
         s, i = index.topk(_t(q, dev), 10, idx_base=4)
         rs, ri = cref.topk_cosine(q, kn, 10, idx_base=4)
         assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs)
