@@ -1175,7 +1175,10 @@ static int run_filter_level(const float* Qn, const float* Kn, const uint16_t* Kb
                                       overflow, overflow_idx, thr, eq, max_kerr2, count, flag, cand, cap, level, gmax, st);
   if constexpr (D == 64) {  // short rows leave registers for four query groups per wave: half the LDS reads and ring
                             // hand-overs per MFMA (the edge flavour's D)
-    if (filter_wide_waves(B))
+    // (only where a workgroup keeps its 1024 queries for a long stream: on a short bank the larger tiles mean fewer,
+    // shorter segments, each paying the operand loads again -- 8192 x 40000 x 64: 0.58 vs 0.46 ms)
+    const int64_t nst = cdiv(key1 - key0, (int64_t)FilterCfg<D>::STAGE_KEYS);
+    if (filter_wide_waves(B) && cdiv(B, (int64_t)1024) * nst >= 32 * (int64_t)filter_device_cus())
       return run_filter_level_qw<D, 128>(Qn, Kn, Kb, B, key0, key1, k, idx_base, first, merge, final_level, out_scores,
                                          out_idx, overflow, overflow_idx, thr, eq, max_kerr2, count, flag, cand, cap, level,
                                          gmax, st);

@@ -145,6 +145,8 @@ def filter_helps(B: int, n_keys: int, D: int, k: int) -> bool:
     # small score matrices are cheaper materialised (the fp32 entry's slab rule: 64 x 65536: 81 vs 129 us filtered)
     if n_keys <= 131072 and B * n_keys <= 6 * (1 << 20):
         return False
+    if D == 64 and n_keys < 65536 and B * n_keys <= (1 << 26):  # (4096 x 16384 x 64: slab 228, filtered 317 us)
+        return False
     # mid-sized banks pay off for larger batches only (8192 x 20000 x 256: 0.37 vs 1.07 ms; 545 x 20000: 0.22 vs 0.26)
     return (n_keys >= 65536 and B >= 12) or (n_keys >= 16384 and B >= 2048)
 
