@@ -358,10 +358,11 @@ extern "C" int ragraph_linear_f32(const float* X, int64_t M, int K, const float*
            : K == 128 ? launch_linear_stream<128>(X, M, W, N, bias, act, alpha, Y, st)
                       : launch_linear_stream<64>(X, M, W, N, bias, act, alpha, Y, st);
   }
-  // (a handful of 128 x 128 tiles leaves most of the chip idle and each workgroup alone with its latencies: the
-  // 64 x 64 kernel has four times the workgroups -- Cora-sized decoder 2708 x 128 -> 128: 30 -> 10 us)
+  // (up to a few waves of 128 x 128 tiles the 64 x 64 kernel -- four times the workgroups, next chunk in flight under
+  // the MFMAs -- is as fast or faster: 2708 x 128 -> 128: 30 -> 10 us; 600 x 256 -> 20000: 124 -> 103; 300 x 256 ->
+  // 5000: 39 -> 20; equal from ~1000 tiles, and the tile kernel wins on large problems: 4096 x 256 -> 125000: 112 TF)
   if (tile_ok && M >= TBM && N >= TBN && K % 4 == 0 && aligned16(X) && aligned16(W) &&
-      cdiv(M, TBM) * cdiv(N, TBN) >= 64) {
+      cdiv(M, TBM) * cdiv(N, TBN) >= 2048) {
     const size_t lds = sizeof(float) * 4 * TBM * TLD;
     static bool attr_set = false;
     if (!attr_set) {
