@@ -424,6 +424,114 @@ def g8_fewshot_retrieve():
              k=np.int64(5), topk_idx=torch.topk(S, 5).indices, rag_embeddings=rag_e, rag_labels=rag_l)
 
 
+def g11_noise():
+    """add_noise branches of retrieve (node ToyGraphBase.py:66,73-79; graph ToyGraphBase.py:84-85,131-134; edge
+    modules/RAGraph.py:308-321) and the noisy training-mode forwards.  The reference draws its noise from torch's
+    default CPU generator (torch.randint / torch.normal without a device), so torch.manual_seed pins it."""
+    with ref_project("RAGraph_node"):
+        F_in, C, D, n, N = 18, 3, 256, 120, 1500
+        pre, model = _node_model(F_in, C, D, seed=0)
+        model.noise_finetune = True
+        adj = random_graph_adj(n, 3.7, seed=71)
+        X = torch.rand(n, F_in, generator=gen(72))
+        with torch.no_grad():
+            h = pre.inference(X, adj)
+        hn = torch.nn.functional.normalize(h, dim=-1)
+        tgb = model.toy_graph_base
+        k2 = 2 * tgb.retrieve_num
+        for bank_seed in range(73, 1073, 100):
+            K = unit_bank(N, D, bank_seed)
+            if min_topk_gap(hn @ K.t(), k2) > 1e-5:
+                break
+        else:
+            raise AssertionError("no tie-free bank seed found")
+        V = torch.randn(N, D, generator=gen(74))
+        L = torch.nn.functional.one_hot(torch.randint(0, C, (N,), generator=gen(75)), C).float()
+        tgb.resource_keys, tgb.resource_values, tgb.resource_labels = K, V, L
+        gcn = pre.gcn.convs[0]
+        with torch.no_grad():
+            torch.manual_seed(111)
+            rag_e, rag_l = tgb.retrieve(h, adj, True)
+            model.train()
+            torch.manual_seed(111)
+            logits = model(X, adj)
+            model.eval()
+        assert rag_e.shape == (n, k2 + tgb.noise_retrieve_num, D)
+        save("g11a_node_noise", X=X, adj=adj, W=gcn.fc.weight, bias=gcn.bias, alpha=gcn.act.weight, H=h, keys=K, values=V,
+             labels=L, retrieve_num=np.int64(tgb.retrieve_num), noise_retrieve_num=np.int64(tgb.noise_retrieve_num),
+             seed=np.int64(111), rag_embeddings=rag_e, rag_labels=rag_l, fc1_w=model.decoder.fc1.weight,
+             fc1_b=model.decoder.fc1.bias, fc2_w=model.decoder.fc2.weight, fc2_b=model.decoder.fc2.bias,
+             train_logits=logits)
+
+    with ref_project("RAGraph_graph"):
+        from ragraph_utils import ToyGraphBase
+
+        C, D, N = 2, 256, 900
+        tgb = ToyGraphBase(None, C, D, 1)
+        K = unit_bank(N, D, 76)
+        tgb.resource_keys = K
+        tgb.resource_values = torch.randn(N, D, generator=gen(77))
+        tgb.resource_labels = torch.nn.functional.one_hot(torch.randint(0, C, (N,), generator=gen(78)), C).float()
+        q = torch.randn(D, generator=gen(79))
+        k2 = 2 * tgb.retrieve_num
+        assert min_topk_gap((torch.nn.functional.normalize(q, dim=-1) @ K.t()).unsqueeze(0), k2) > 1e-5
+        torch.manual_seed(112)
+        rag_e, rag_l = tgb.retrieve(q, None, True)
+        save("g11b_graph_noise", Q=q, keys=K, values=tgb.resource_values, labels=tgb.resource_labels,
+             retrieve_num=np.int64(tgb.retrieve_num), noise_std=np.float32(tgb.noise_std), seed=np.int64(112),
+             rag_embeddings=rag_e, rag_labels=rag_l)
+
+    argv = ["x", "--device", "cpu", "--data_path", "dataset/amazon", "--log", "0", "--emb_dropout", "0"]
+    with ref_project("RAGraph_edge", argv=argv):
+        from modules.RAGraph import RAGraph
+
+        U, I, E, D = 150, 100, 900, 64
+        rng = np.random.default_rng(20)
+        u = np.concatenate([rng.integers(0, U, E), np.repeat(np.arange(U), 3), rng.integers(0, U, 3 * I)])
+        i = np.concatenate([rng.integers(0, I, E), rng.integers(0, I, 3 * U), np.repeat(np.arange(I), 3)])
+        pairs = np.unique(np.stack([u, i], 1), axis=0)
+        u, i = pairs[:, 0], pairs[:, 1]
+        t = rng.integers(0, 720, len(u))
+        etd = {}
+        for a, b, tt in zip(u, i, t):
+            etd.setdefault(int(a), {})[int(b) + U] = int(tt)
+            etd.setdefault(int(b) + U, {})[int(a)] = int(tt)
+
+        class DS:
+            num_users, num_items = U, I
+            edge_time_dict = etd
+
+        DS.graph = sp.coo_matrix((np.ones(len(u)), (u, i)), shape=(U, I))
+        ue = 0.1 * torch.randn(U, D, generator=gen(63))
+        ie = 0.1 * torch.randn(I, D, generator=gen(64))
+
+        class Pre:
+            def generate(self):
+                return ue.clone(), ie.clone()
+
+        torch.manual_seed(7)
+        model = RAGraph(DS, Pre(), phase="finetune", use_RAG=True, use_noise=True, use_LoRA=False)
+        model.batch_size = 100  # three slabs: the per-slab randint draws concatenate to one [n, 1] draw
+        model.retrieve_num = 10
+        model.train()
+        with torch.no_grad():
+            all_emb = model.emb_gate(torch.cat([model.user_embedding, model.item_embedding], 0))
+            S = torch.nn.functional.normalize(all_emb, dim=-1) @ torch.nn.functional.normalize(model.resource_keys, dim=-1).t()
+            top = torch.topk(S.double(), 12, dim=-1).values
+            row_gap = (top[:, :-1] - top[:, 1:]).min(dim=1).values
+            torch.manual_seed(113)
+            user_out, item_out = model.forward(model.edges, model.edge_norm, model.edge_times)
+            torch.manual_seed(113)
+            one_draw = torch.randint(0, model.resource_values.shape[0], (U + I, model.noise_retrieve_num))
+        print(f"  edge noise fixture: rows with top-12 gap > 1e-5: {100 * float((row_gap > 1e-5).double().mean()):.1f} %")
+        save("g11c_edge_noise", edges=model.edges, edge_norm=model.edge_norm, edge_times=model.edge_times,
+             num_users=np.int64(U), num_items=np.int64(I), user_embedding=model.user_embedding,
+             item_embedding=model.item_embedding, gating_weight=model.gating_weight, gating_bias=model.gating_bias,
+             resource_keys=model.resource_keys, resource_values=model.resource_values, row_gap=row_gap,
+             retrieve_num=np.int64(10), noise_retrieve_num=np.int64(model.noise_retrieve_num), seed=np.int64(113),
+             noise_idx=one_draw, retrieve_weight=np.float32(model.retrieve_weight), user_out=user_out, item_out=item_out)
+
+
 def main():
     assert os.path.isdir(REF), "the reference is only mounted in the build container"
     _install_shims()
@@ -435,6 +543,7 @@ def main():
     g10_downprompt()
     g9_edge()
     g8_fewshot_retrieve()
+    g11_noise()
 
 
 if __name__ == "__main__":

@@ -60,9 +60,7 @@ class RAGraph(nn.Module):
         if self.query_shard is not None and not self.training and self.flavour == "node":
             return self._forward_query_shard(queries, pretrain_embedddings, g)
         if add_noise:
-            rag_embeddings, rag_labels = tgb.retrieve(queries, g, True)                        # :43 (noise branch)
-            rag_label = rag_labels.mean(dim=1)
-            rag_embedding = rag_embeddings.sum(dim=1)
+            rag_embedding, rag_label = tgb.retrieve_reduced_noisy(queries)                     # :43,48-49 (noise branch)
         else:
             rag_embedding, rag_label, _ = tgb.retrieve_reduced(queries)                        # :43,48-49 fused
         if not self.finetune:

@@ -46,13 +46,15 @@ class RAGraph(nn.Module):
 
     # ---- helpers ---------------------------------------------------------------------------------------------------
     def _csr(self, edges):
-        """Destination-sorted CSR of an edge list (stable: keeps scatter_add_'s accumulation order), cached per list."""
-        key = (edges.data_ptr(), edges.shape[0])
-        if self._csr_cache is None or self._csr_cache[0] != key:
+        """Destination-sorted CSR of an edge list (stable: keeps scatter_add_'s accumulation order), cached per edge
+        tensor: the cache holds the tensor itself and its version counter, so another list of the same length at a
+        recycled address, or an in-place edit, rebuilds it."""
+        c = self._csr_cache
+        if c is None or c[0] is not edges or c[1] != edges._version:
             n = self.num_users + self.num_items
             g, perm = CSRGraph.from_coo(edges[:, 1], edges[:, 0], torch.ones(edges.shape[0], device=edges.device), n)
-            self._csr_cache = (key, g, perm)
-        return self._csr_cache[1], self._csr_cache[2]
+            self._csr_cache = c = (edges, edges._version, g, perm)
+        return c[2], c[3]
 
     def _gate_wt(self):
         """gating_weight^T (the linear kernel takes nn.Linear layout), re-made only when the parameter changes."""
@@ -70,12 +72,12 @@ class RAGraph(nn.Module):
         return K.sigmoid_gate(x, z)
 
     def _time_range(self, edge_times, max_time_step):
-        """(min, max) of the time steps as host scalars (kernel arguments), cached per edge-time tensor."""
-        tag = (edge_times.data_ptr(), edge_times.shape[0])
-        if getattr(self, "_trange", (None,))[0] != tag:
-            self._trange = (tag, float(edge_times.min()), float(edge_times.max()))
-        tmax = self._trange[2] if max_time_step is None else float(max_time_step)
-        return self._trange[1], tmax
+        """(min, max) of the time steps as host scalars (kernel arguments), cached per edge-time tensor (identity and
+        version, as _csr)."""
+        c = getattr(self, "_trange", None)
+        if c is None or c[0] is not edge_times or c[1] != edge_times._version:
+            self._trange = c = (edge_times, edge_times._version, float(edge_times.min()), float(edge_times.max()))
+        return c[2], (c[3] if max_time_step is None else float(max_time_step))
 
     def _agg(self, all_emb, edges, edge_norm):
         """modules/RAGraph.py:232-240: out[dst] += emb[src] * norm, as one CSR SpMM (no atomics)."""
@@ -85,8 +87,7 @@ class RAGraph(nn.Module):
     def _relative_edge_time_encoding(self, edges, edge_times, max_step=None):
         """modules/RAGraph.py:250-263.  Returns the softmax in ORIGINAL edge order."""
         g, perm = self._csr(edges)
-        tmin = float(edge_times.min())
-        tmax = float(edge_times.max()) if max_step is None else float(max_step)
+        tmin, tmax = self._time_range(edge_times, max_step)
         t = K.time_rescale(edge_times, tmin, tmax)
         sm = K.segment_softmax(g.rowptr, t[perm].contiguous(), long_rows=g.has_long_rows)
         out = torch.empty_like(sm)
@@ -147,8 +148,10 @@ class RAGraph(nn.Module):
                 queries = res[0][lo:hi].contiguous()
             _, idx = self._index.topk(queries, k)
             if add_noise:
-                noise = torch.randint(0, self.resource_values.shape[0], (idx.shape[0], self.noise_retrieve_num),
-                                      device=idx.device)
+                # (drawn from the default CPU generator as the reference does, :316; its per-slab draws of
+                # [batch, 1] concatenate to this one [n, 1] draw, so torch.manual_seed reproduces its rows)
+                noise = torch.randint(0, self.resource_values.shape[0], (idx.shape[0], self.noise_retrieve_num)
+                                      ).to(idx.device)
                 idx = torch.cat([idx, noise], dim=1)
             rag, _ = K.gather_reduce(self.resource_values, None, idx, v_scale=1.0 / idx.shape[1])  # :314,321 mean
             if qs is not None:

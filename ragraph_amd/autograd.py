@@ -54,11 +54,13 @@ class _SoftmaxMix(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, rag_label, lam):
-        out = K.softmax_mix(logits, rag_label, lam)
-        p = out if rag_label is None else (out - rag_label * lam) / (1.0 - lam)
+        # the plain softmax is what backward needs: computed once and mixed by the axpby kernel -- the same two
+        # multiplies and one add as the fused kernel, so training and inference outputs agree bit for bit (and
+        # label_weight = 1 needs no division by 1 - lam)
+        p = K.softmax_mix(logits, None)
         ctx.save_for_backward(p)
         ctx.lam = lam if rag_label is not None else 0.0
-        return out
+        return p if rag_label is None else K.axpby(p, 1.0 - lam, rag_label, lam)
 
     @staticmethod
     def backward(ctx, go):

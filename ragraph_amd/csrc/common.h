@@ -6,6 +6,8 @@
 #include <limits.h>
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
+#include <atomic>
 
 #include "ragraph_hip.h"
 
@@ -36,6 +38,49 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+
+// ---- per-device state ------------------------------------------------------------------------------------------
+// A process may drive several devices (hipSetDevice between calls): function attributes and the CU count belong to the
+// device that is current when a call is made, so the once-flags are kept per device and are atomic (calls may come
+// from several host threads; racing setters write the same value).
+constexpr int RG_MAX_DEVICES = 64;
+static inline int current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= RG_MAX_DEVICES) d = 0;
+  return d;
+}
+struct DeviceOnce {
+  std::atomic<unsigned char> done[RG_MAX_DEVICES];
+};
+// Raises the kernel's dynamic-LDS limit once per device.
+template <typename KernelT>
+static inline hipError_t raise_dynamic_lds(DeviceOnce& once, KernelT kernel, int bytes) {
+  const int d = current_device();
+  if (once.done[d].load(std::memory_order_acquire)) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) once.done[d].store(1, std::memory_order_release);
+  return e;
+}
+// CUs of the current device rounded down to a multiple of 8 (one persistent workgroup per CU, dealt over the 8 XCDs);
+// 256 when no device is visible (workspace / plan queries on a CPU box).  RAGRAPH_TOPK_CUS overrides it (test hook).
+static inline int device_cus_multiple_of_8() {
+  static const int env = [] {
+    const char* e = getenv("RAGRAPH_TOPK_CUS");
+    const int v = e ? atoi(e) : 0;
+    return v >= 8 ? v / 8 * 8 : 0;
+  }();
+  if (env) return env;
+  static std::atomic<int> cached[RG_MAX_DEVICES];
+  const int d = current_device();
+  int n = cached[d].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n < 8) n = 256;
+    n = n / 8 * 8;
+    cached[d].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
 
 // ---- device helpers ------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));

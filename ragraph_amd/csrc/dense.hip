@@ -304,15 +304,10 @@ template <int KD>
 static int launch_linear_stream(const float* X, int64_t M, const float* W, int64_t N, const float* bias, int act,
                                 float alpha, float* Y, hipStream_t st) {
   using C = LinStreamCfg<KD>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_stream_kernel<KD>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-    if (e != hipSuccess) {
-      set_error("linear: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
-      return RAGRAPH_EDEVICE;
-    }
-    attr_set = true;
+  static DeviceOnce lds_once;  // per device (common.h)
+  if (hipError_t e = raise_dynamic_lds(lds_once, &linear_stream_kernel<KD>, (int)C::LDS_BYTES); e != hipSuccess) {
+    set_error("linear: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+    return RAGRAPH_EDEVICE;
   }
   const int64_t total_stages = cdiv(M, C::STAGE_ROWS);
   const int64_t col_blocks = cdiv(N, 256);
@@ -364,15 +359,10 @@ extern "C" int ragraph_linear_f32(const float* X, int64_t M, int K, const float*
   if (tile_ok && M >= TBM && N >= TBN && K % 4 == 0 && aligned16(X) && aligned16(W) &&
       cdiv(M, TBM) * cdiv(N, TBN) >= 2048) {
     const size_t lds = sizeof(float) * 4 * TBM * TLD;
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tile_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) {
-        set_error("linear: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
-        return RAGRAPH_EDEVICE;
-      }
-      attr_set = true;
+    static DeviceOnce lds_once;  // per device (common.h)
+    if (hipError_t e = raise_dynamic_lds(lds_once, &linear_tile_kernel, (int)lds); e != hipSuccess) {
+      set_error("linear: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+      return RAGRAPH_EDEVICE;
     }
     dim3 grid((unsigned)cdiv(M, TBM), (unsigned)cdiv(N, TBN));
     hipLaunchKernelGGL(linear_tile_kernel, grid, dim3(256), lds, as_stream(stream), X, M, K, W, N, bias, act, alpha, Y);

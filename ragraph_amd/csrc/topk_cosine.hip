@@ -874,20 +874,7 @@ struct TopkPlan {
   size_t qn_bytes, part_s_bytes, part_i_bytes;
 };
 
-static int device_cus() {  // CUs of the current device, a multiple of 8 (one workgroup of the tile kernel per CU)
-  static const int cus = [] {
-    if (const char* e = getenv("RAGRAPH_TOPK_CUS")) {  // test hook (read once): plan for this many workgroups
-      const int v = atoi(e);
-      if (v >= 8) return v / 8 * 8;
-    }
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        n < 8)
-      n = 256;  // MI355X; also what the planner assumes when no device is visible (workspace queries on a CPU box)
-    return n / 8 * 8;
-  }();
-  return cus;
-}
+static int device_cus() { return device_cus_multiple_of_8(); }  // per device (common.h)
 
 // Up to this many queries take the wave-streaming kernel (groups of 16 queries, 16x16x4 MFMA): it fills the chip at any
 // batch size, whereas the tile kernel needs >= a few query tiles of 256 to do so (measured crossover).
@@ -971,15 +958,10 @@ template <int D, int RING>
 static int launch_topk_ring(const TopkParams& p, int64_t qtiles, hipStream_t st) {
   using C = TopkCfg<D>;
   const size_t lds = C::lds_bytes(p.k, RING);
-  static bool attr_set = false;  // raising the dynamic-LDS cap is idempotent; racing setters write the same value
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_stream_kernel<D, RING>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      set_error("topk_cosine: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
-      return RAGRAPH_EDEVICE;
-    }
-    attr_set = true;
+  static DeviceOnce lds_once;  // per device (common.h)
+  if (hipError_t e = raise_dynamic_lds(lds_once, &topk_stream_kernel<D, RING>, 160 * 1024); e != hipSuccess) {
+    set_error("topk_cosine: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+    return RAGRAPH_EDEVICE;
   }
   const int64_t grid = (int64_t)p.wgs_per_group * (p.xcd_map ? 8 : 1);  // one persistent workgroup per CU
 #ifdef RG_TOPK_TIMING
@@ -1023,15 +1005,10 @@ template <int D>
 static int launch_smallb(const TopkParams& p, hipStream_t st) {
   using C = SmallCfg<D>;
   const size_t lds = C::lds_bytes(p.k);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_smallb_kernel<D>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      set_error("topk_cosine(small batch): cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
-      return RAGRAPH_EDEVICE;
-    }
-    attr_set = true;
+  static DeviceOnce lds_once;  // per device (common.h)
+  if (hipError_t e = raise_dynamic_lds(lds_once, &topk_smallb_kernel<D>, 160 * 1024); e != hipSuccess) {
+    set_error("topk_cosine(small batch): cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+    return RAGRAPH_EDEVICE;
   }
   hipLaunchKernelGGL(topk_smallb_kernel<D>, dim3((unsigned)(p.nsplit * p.ngroups)), dim3(512), lds, st, p);
   RG_CHECK_LAUNCH("topk_cosine(small batch)");

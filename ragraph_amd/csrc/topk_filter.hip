@@ -839,20 +839,7 @@ static bool filter_wide_waves(int64_t B) {  // RAGRAPH_FILTER_QW128=0/1: A/B; de
   return env < 0 ? B >= 1024 : env != 0;
 }
 
-static int filter_device_cus() {
-  static const int cus = [] {
-    if (const char* e = getenv("RAGRAPH_TOPK_CUS")) {
-      const int v = atoi(e);
-      if (v >= 8) return v / 8 * 8;
-    }
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
-      n = 256;
-    return n / 8 * 8;
-  }();
-  return cus;
-}
+static int filter_device_cus() { return device_cus_multiple_of_8(); }  // per device (common.h)
 
 }  // namespace ragraph
 
@@ -1112,15 +1099,10 @@ static int run_filter_level_qw(const float* Qn, const float* Kn, const uint16_t*
     if (nq < 1 || (v == 1 && (!p.xcd_map || p.qtiles % 8 == 0))) continue;
     p.depth[v] = SegmentWalker::choose_depth(nq, p.nstages_total, p.wgs_per_group, p.lb_min, 0).depth;
   }
-  static bool attr_set = false;  // per template instance
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_filter_kernel<D, QW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-    if (e != hipSuccess) {
-      set_error("topk_cosine_filtered: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
-      return RAGRAPH_EDEVICE;
-    }
-    attr_set = true;
+  static DeviceOnce lds_once;  // per device (common.h)
+  if (hipError_t e = raise_dynamic_lds(lds_once, &topk_filter_kernel<D, QW>, (int)C::LDS_BYTES); e != hipSuccess) {
+    set_error("topk_cosine_filtered: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+    return RAGRAPH_EDEVICE;
   }
   if (g_prof_on) (void)hipEventRecord(g_prof_ev[2 * level], st);
   hipLaunchKernelGGL((topk_filter_kernel<D, QW>), dim3((unsigned)CUS), dim3(C::THREADS), C::LDS_BYTES, st, p);
@@ -1213,15 +1195,10 @@ static int run_bound_pass_qw(const float* Qn, const uint16_t* Kb, int64_t B, int
     if (nq < 1 || (v == 1 && (!p.xcd_map || p.qtiles % 8 == 0))) continue;
     p.depth[v] = SegmentWalker::choose_depth(nq, p.nstages_total, p.wgs_per_group, p.lb_min, 0).depth;
   }
-  static bool attr_set = false;  // per template instance
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_filter_kernel<D, QW, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-    if (e != hipSuccess) {
-      set_error("topk_cosine_filtered: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
-      return RAGRAPH_EDEVICE;
-    }
-    attr_set = true;
+  static DeviceOnce lds_once;  // per device (common.h)
+  if (hipError_t e = raise_dynamic_lds(lds_once, &topk_filter_kernel<D, QW, true>, (int)C::LDS_BYTES); e != hipSuccess) {
+    set_error("topk_cosine_filtered: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+    return RAGRAPH_EDEVICE;
   }
   if (g_prof_on) (void)hipEventRecord(g_prof_ev[6], st);
   hipLaunchKernelGGL((topk_filter_kernel<D, QW, true>), dim3((unsigned)CUS), dim3(C::THREADS), C::LDS_BYTES, st, p);

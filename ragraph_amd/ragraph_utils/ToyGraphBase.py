@@ -108,23 +108,42 @@ class ToyGraphBase:
             self._index = K.KeyIndex(self.keys_normalized)
         return self._index.topk(q, k)  # fp32 streaming / tile kernel or, for large batches, the bf16-filtered exact path
 
+    def retrieve_indices(self, search_keys: Tensor, add_noise: bool) -> Tensor:
+        """The rows retrieve() gathers: the top-k' indices (k' = 2 * retrieve_num with add_noise, :66) and, in the node
+        flavour with add_noise, noise_retrieve_num uniformly random rows behind them (:73-79).  The reference draws the
+        noise from torch's default CPU generator (no device argument) and only then moves it to the bank's device: drawn
+        the same way here, so torch.manual_seed reproduces the reference's rows."""
+        retrieve_num = 2 * self.retrieve_num if add_noise else self.retrieve_num
+        _, idx = self.topk(search_keys, retrieve_num)                              # :66-67
+        if add_noise and self.flavour == "node":
+            noise_idx = torch.randint(0, self.resource_values.shape[0], (idx.shape[0], self.noise_retrieve_num))
+            idx = torch.cat([idx, noise_idx.to(idx.device)], dim=1)
+        return idx
+
     def retrieve(self, search_keys: Tensor, search_adj, add_noise: bool):
         """ToyGraphBase.py:47-81 -> (rag_embeddings [B,k',D], rag_labels [B,k',C]).  A 1-D query (graph flavour,
         RAGraph_graph/ragraph_utils/ToyGraphBase.py:56-87) gives B = 1."""
-        retrieve_num = 2 * self.retrieve_num if add_noise else self.retrieve_num
-        _, idx = self.topk(search_keys, retrieve_num)                              # :66-67
-        rag_embeddings = K.gather_rows(self.resource_values, idx)                  # :70
-        rag_labels = K.gather_rows(self.resource_labels, idx)                      # :71
-        if add_noise:
-            if self.flavour == "node":                                             # :73-79 one random extra row
-                noise_idx = torch.randint(0, self.resource_values.shape[0], (idx.shape[0], self.noise_retrieve_num),
-                                          device=idx.device)
-                rag_embeddings = torch.cat([rag_embeddings, K.gather_rows(self.resource_values, noise_idx)], dim=1)
-                rag_labels = torch.cat([rag_labels, K.gather_rows(self.resource_labels, noise_idx)], dim=1)
-            else:                                                                  # graph :84-85,131-134
-                rag_embeddings = rag_embeddings + torch.normal(0.0, self.noise_std, size=rag_embeddings.shape,
-                                                               device=rag_embeddings.device)
+        idx = self.retrieve_indices(search_keys, add_noise)
+        rag_embeddings = K.gather_rows(self.resource_values, idx)                  # :70 (+ :76,78 noise rows)
+        rag_labels = K.gather_rows(self.resource_labels, idx)                      # :71 (+ :77,79)
+        if add_noise and self.flavour != "node":                                   # graph :84-85,131-134
+            noise = torch.normal(mean=0, std=self.noise_std, size=rag_embeddings.shape).to(rag_embeddings.device)
+            rag_embeddings = K.axpby(rag_embeddings, 1.0, noise, 1.0)
         return rag_embeddings, rag_labels
+
+    def retrieve_reduced_noisy(self, search_keys: Tensor):
+        """What RAGraph.forward consumes in noisy fine-tuning (RAGraph.py:42-49 with add_noise): (sum_k' V, mean_k' L)
+        over the top-2k rows plus the noise -- every reduction on the HIP kernels."""
+        if self.flavour == "node":   # noise = extra rows: still a gather-reduce over an index matrix
+            idx = self.retrieve_indices(search_keys, True)
+            sum_v, mean_l = K.gather_reduce(self.resource_values, self.resource_labels, idx)
+            return sum_v, mean_l
+        rag_embeddings, _ = self.retrieve(search_keys, None, True)   # noise is added to the gathered embeddings
+        B, k, D = rag_embeddings.shape
+        seg = torch.arange(0, B * k + 1, k, dtype=torch.int64, device=rag_embeddings.device)
+        sum_v = K.segment_reduce(rag_embeddings.reshape(B * k, D), seg)
+        _, mean_l = K.gather_reduce(self.resource_values, self.resource_labels, self.topk(search_keys, k)[1])
+        return sum_v, mean_l
 
     def retrieve_reduced(self, search_keys: Tensor, k: int | None = None):
         """What RAGraph.forward consumes (RAGraph.py:48-49): (sum_k V[idx] [B,D], mean_k L[idx] [B,C], idx) without
@@ -143,9 +162,9 @@ class ToyGraphBase:
         blob = torch.load(path, map_location="cpu")
         if blob.get("format") != "ragraph_amd.bank.v1":
             raise ValueError(f"{path}: not a ragraph_amd bank file")
-        if not append:
-            for b in (self._keys, self._values, self._labels):
-                b.n = 0
+        if not append:  # fresh stores: the old ones may be tensors adopted from the caller (set_resources)
+            self._keys, self._values, self._labels = (_Bank(b.buf.shape[1], self.device)
+                                                      for b in (self._keys, self._values, self._labels))
         self.add_resources(blob["keys"], blob["values"], blob["labels"])
 
     def show(self):

@@ -141,3 +141,24 @@ def test_topk_rows_matches_torch_topk_on_tie_free_rows():
     S[:, ::7] = 0.25  # ties: canonical order = lower index first
     s, i = cref.topk_rows(np.minimum(S, 0.25), 10)
     assert (s == 0.25).all() and np.array_equal(i[0], np.sort(i[0]))
+
+
+def test_g11_add_noise_branches():
+    """retrieve(add_noise=True): the deterministic prefix is the oracle's top-k' and the noise comes from torch's
+    default CPU generator (ToyGraphBase.py:66,73-79; graph flavour :84-85,131-134)."""
+    g = gold("g11a_node_noise")
+    k, nz = int(g["retrieve_num"]), int(g["noise_retrieve_num"])
+    e, l, idx = pipeline.retrieve(g["H"], g["keys"], g["values"], g["labels"], 2 * k)
+    assert np.array_equal(e, g["rag_embeddings"][:, :2 * k]) and np.array_equal(l, g["rag_labels"][:, :2 * k])
+    torch.manual_seed(int(g["seed"]))
+    noise = torch.randint(0, g["values"].shape[0], (g["H"].shape[0], nz)).numpy()
+    assert np.array_equal(g["values"][noise], g["rag_embeddings"][:, 2 * k:])
+    assert np.array_equal(g["labels"][noise], g["rag_labels"][:, 2 * k:])
+
+    g = gold("g11b_graph_noise")
+    k = int(g["retrieve_num"])
+    e, l, idx = pipeline.retrieve(g["Q"], g["keys"], g["values"], g["labels"], 2 * k)
+    assert np.array_equal(l, g["rag_labels"])
+    torch.manual_seed(int(g["seed"]))
+    noise = torch.normal(mean=0, std=float(g["noise_std"]), size=e.shape).numpy()
+    assert np.array_equal(e + noise, g["rag_embeddings"])
