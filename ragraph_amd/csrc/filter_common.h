@@ -1,0 +1,93 @@
+// Shared pieces of the bf16-filtered exact top-k (topk_filter.hip: schedule, ring kernel for many queries, rescoring;
+// topk_filter_direct.hip: the register-fed kernel for up to 256 queries).
+#pragma once
+#include "common.h"
+
+namespace ragraph {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Error bound of the bf16 scores.  The rounded rows are q + dq and k + dk, so
+//   |(q+dq).(k+dk) - q.k| <= |dq||k| + |q||dk| + |dq||dk|      (Cauchy-Schwarz, Euclidean norms)
+// bf16 keeps 8 significant bits, i.e. |dq| <= 2^-8 |q| at worst, but the actual |dq| of a query and the largest |dk| of
+// the bank are known exactly: ragraph_keys_to_bf16 leaves max_k |dk| behind the bank copy and the query side is
+// computed per call.  eps(q) = (|dq| + max|dk| + |dq| max|dk|)(1 + 2^-10) + 2^-12: the factor covers the fp32 rounding
+// of the norms and the 1e-7 by which a normalised row's norm can exceed 1, the constant the fp32 accumulation of the
+// (exact) bf16 products -- in ANY order: the bank copy is stored in MFMA fragment order and the products of a score are
+// summed in whatever order the matrix core takes them -- and the rounding of the exact chain itself (< 2^-14 each).
+// Typically eps ~ 0.003, a third of the worst case 2^-7.
+constexpr float FILTER_EPS_SLACK = 0.000244140625f;  // 2^-12
+
+constexpr int FILTER_STAGE_BYTES = 32 * 1024;  // one ring slot of the ring kernel
+constexpr int FILTER_PAD_KEYS = 256;           // bank rows are padded to whole stages of any D (256 keys at D = 64)
+
+// Layout of the bf16 bank copy (ragraph_keys_to_bf16): MFMA FRAGMENT ORDER.  Keys are taken in sub-tiles of 32; a
+// sub-tile is D/16 k-steps; k-step t of sub-tile u is one 1-KiB block at byte ((u * D/16) + t) * 1024, and inside it
+// lane l = j + 32 g of a wave owns 16 bytes at 16 l: elements 16 t + 8 g .. + 7 of key 32 u + j -- exactly the A operand
+// of v_mfma_f32_32x32x16_bf16 for that step.  A wave therefore fetches an operand with ONE fully coalesced 1-KiB load
+// (global_load_dwordx4, or global_load_lds_dwordx4 into a ring slot whose image needs no swizzle: consecutive lanes read
+// consecutive 16-B pieces), and no kernel transposes anything.  2 D bytes per key, as the row-major copy had.
+__host__ __device__ constexpr int64_t filter_block_offset(int64_t subtile, int ksteps, int t) {
+  return (subtile * ksteps + t) * 1024;
+}
+
+// float <-> int with the same order (for atomicMax on scores of either sign)
+__device__ __forceinline__ int f2ord(float f) {
+  const int b = __float_as_int(f);
+  return b >= 0 ? b : b ^ 0x7FFFFFFF;
+}
+__device__ __forceinline__ float ord2f(int o) { return __int_as_float(o >= 0 ? o : o ^ 0x7FFFFFFF); }
+
+// How a filter launch obtains a query's pass threshold thr[q] = theta[q] - eps(q), where theta[q] is a proven lower
+// bound of the query's final k-th best exact score: the k-th exact score of everything rescored so far (prev_scores),
+// or -- gmax != NULL, right after the bound pass -- the smallest of the k group maxima of approximate scores minus
+// eps(q) (each group's best key has an exact score >= its approximate one - eps, so k distinct keys score at least that).
+struct FilterThr {
+  const float* prev_scores;   // [B,k] running exact top-k (descending), or NULL
+  const int* gmax;            // [B,ngroups] order-preserving ints of the bound pass, or NULL
+  const float* eq;            // [B] |dq| of the query's bf16 rounding
+  const unsigned* max_kerr2;  // bank: max_k |dk|^2 as float bits
+  int k, ngroups;
+  int ablate;                 // timing only: nothing passes
+};
+
+__device__ __forceinline__ float filter_eps(const FilterThr& t, int64_t q) {
+  const float ek = sqrtf(__uint_as_float(*t.max_kerr2));
+  const float e = t.eq[q];
+  return fmaf(fmaf(e, ek, e + ek), 1.0009765625f, FILTER_EPS_SLACK);  // rounding direction is inside the factor
+}
+
+__device__ __forceinline__ float filter_threshold(const FilterThr& t, int64_t q) {
+  if (t.ablate) return __builtin_huge_valf();
+  const float eps = filter_eps(t, q);
+  float theta;
+  if (t.gmax) {
+    int m = t.gmax[q * t.ngroups];
+    for (int g = 1; g < t.ngroups; ++g) m = min(m, t.gmax[q * t.ngroups + g]);
+    theta = __fsub_rn(ord2f(m), eps);
+  } else {
+    theta = t.prev_scores[q * t.k + t.k - 1];
+  }
+  return __fsub_rn(theta, eps);
+}
+
+// One filter launch of the direct kernel (topk_filter_direct.hip): up to 256 queries against keys [key0, key1) of the
+// bf16 copy (key0 a multiple of 32).  bound_groups > 0: the BOUND pass -- no thresholds, no candidates, the launch
+// records per query the best approximate score of each of bound_groups consecutive parts of the range into gmax_out.
+struct DirectArgs {
+  const uint16_t* Qb;     // the normalised queries as bf16 B operands in fragment order (filter_prep_kernel):
+                          // block (gq * D/16 + t) = k-step t of queries 32 gq .. 32 gq + 31, lane j + 32 g of it
+                          // = elements 16 t + 8 g .. + 7 of query 32 gq + j; queries >= B zero
+  const uint16_t* Kb;     // fragment-order bf16 keys
+  int64_t B, key0, key1;
+  FilterThr thr;          // (filter launches)
+  int* count;             // [B] candidate slots reserved so far
+  int* cand;              // [B,cap] candidate key indices (local to this shard)
+  int cap;
+  int* gmax_out;          // (bound pass) [B,bound_groups]
+  int bound_groups;
+};
+template <int D>
+int launch_filter_direct(const DirectArgs& a, hipStream_t st);
+
+}  // namespace ragraph

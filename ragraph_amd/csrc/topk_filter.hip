@@ -31,27 +31,13 @@
 // Candidates leave the MFMA stream through wave-private LDS buffers (branch-free pass masks, ballot + mbcnt positions)
 // and reach the per-query lists in global memory in flushes.  Work plan: segment_plan.h with zero warm-up cost (there
 // are no lists): every workgroup gets the same number of stages.
-#include "common.h"
+#include "filter_common.h"
 #include "segment_plan.h"
 #include <cmath>
 
 namespace ragraph {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void_f;
-
-// Error bound of the bf16 scores.  The rounded rows are q + dq and k + dk, so
-//   |(q+dq).(k+dk) - q.k| <= |dq||k| + |q||dk| + |dq||dk|      (Cauchy-Schwarz, Euclidean norms)
-// bf16 keeps 8 significant bits, i.e. |dq| <= 2^-8 |q| at worst, but the actual |dq| of a query and the largest |dk| of
-// the bank are known exactly: ragraph_keys_to_bf16 leaves max_k |dk| behind the bank copy and the query side is
-// computed per call.  eps(q) = (|dq| + max|dk| + |dq| max|dk|)(1 + 2^-10) + 2^-12: the factor covers the fp32 rounding
-// of the norms and the 1e-7 by which a normalised row's norm can exceed 1, the constant the fp32 accumulation of the
-// (exact) bf16 products and the rounding of the exact chain itself (< 2^-14 each).  Typically eps ~ 0.003, a third of
-// the worst case 2^-7.
-constexpr float FILTER_EPS_SLACK = 0.000244140625f;  // 2^-12
-
-constexpr int FILTER_STAGE_BYTES = 32 * 1024;  // one ring slot
-constexpr int FILTER_PAD_KEYS = 256;           // bank rows are padded to whole stages of any D (256 keys at D = 64)
 
 template <int D_>
 struct FilterCfg {
@@ -69,16 +55,13 @@ struct FilterCfg {
   static constexpr int RPI = 1024 / ROW_BYTES;            // key rows per DMA instruction: 2 / 4 / 8
   static constexpr int CAND_BUF = 480;                    // entries of a wave's candidate buffer (8 B each)
   static constexpr size_t LDS_BYTES = (size_t)SLOTS * STAGE_BYTES + 64 + (size_t)WAVES * CAND_BUF * 8;
-  // swizzle f(row): rows that share a 256-B LDS bank row (16 chunks) must differ, and so must the 16 rows of a
-  // ds_read_b128 lane group
-  __host__ __device__ static constexpr int swz(int row) { return CR >= 16 ? (row & 15) : ((row / (16 / CR)) & (CR - 1)); }
 };
 static_assert(FilterCfg<256>::NSTEP == 32 && FilterCfg<128>::NSTEP == 32 && FilterCfg<64>::NSTEP == 32, "32 steps per stage");
 
 struct FilterParams {
   const float* Qn;        // [B,D] normalised queries (fp32)
-  const uint16_t* Kb;     // [round_up(N,256),D] bf16 keys, rows >= N zero
-  const float* thr;       // [B] theta[q] - eps(q)
+  const uint16_t* Kb;     // bf16 keys in MFMA fragment order (filter_common.h), rows >= N zero
+  FilterThr thr;          // how a query's pass threshold theta[q] - eps(q) is obtained (filter_common.h)
   int* count;             // [B] candidate slots reserved so far
   int* cand;              // [B,cap] candidate key indices (local to this shard)
   int64_t B, N;           // N = end of the key range (keys >= N never pass)
@@ -91,13 +74,6 @@ struct FilterParams {
   int ngroups;
 };
 
-// float <-> int with the same order (for atomicMax on scores of either sign)
-__device__ __forceinline__ int f2ord(float f) {
-  const int b = __float_as_int(f);
-  return b >= 0 ? b : b ^ 0x7FFFFFFF;
-}
-__device__ __forceinline__ float ord2f(int o) { return __int_as_float(o >= 0 ? o : o ^ 0x7FFFFFFF); }
-
 __device__ __forceinline__ void fring_wait(unsigned* ctr, unsigned target) {
   while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
 }
@@ -105,7 +81,8 @@ __device__ __forceinline__ void fring_signal(unsigned* ctr, int lane) {
   if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// fp32 -> bf16 (round to nearest even) of the bank, rows [N, Npad) zero so the stream never needs a tail clamp, and
+// fp32 -> bf16 (round to nearest even) of the bank in MFMA fragment order, rows [N, Npad) zero so the stream never needs
+// a tail clamp, and
 // max_k |dk|^2 of the bank (see FILTER_EPS_SLACK) by an integer max: non-negative floats order like their bit patterns.
 template <int D>
 __global__ void __launch_bounds__(256) keys_to_bf16_kernel(const float* __restrict__ Kn, int64_t N, int64_t Npad,
@@ -128,7 +105,12 @@ __global__ void __launch_bounds__(256) keys_to_bf16_kernel(const float* __restri
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (__bf16)0.f;
   }
-  if (i < Npad * TPR) reinterpret_cast<bf16x8*>(Kb)[i] = o;
+  if (i < Npad * TPR) {
+    // fragment order (filter_common.h): 16-B piece c = 2 t + g of key row 32 u + j goes to block (u * D/16 + t), lane j + 32 g
+    const int c = (int)(i % TPR);
+    const int64_t dst = filter_block_offset(row >> 5, D / 16, c >> 1) + (((c & 1) * 32 + (int)(row & 31)) << 4);
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(Kb) + dst) = o;
+  }
 #pragma unroll
   for (int off = TPR / 2; off >= 1; off >>= 1) e2 += __shfl_xor(e2, off);
   // (a plain read first: after the first few rows almost none beats the running maximum, so almost none pays for the
@@ -138,60 +120,61 @@ __global__ void __launch_bounds__(256) keys_to_bf16_kernel(const float* __restri
     atomicMax(max_err2, __float_as_uint(e2));
 }
 
-// |dq| per query: q - bf16(q) over the normalised row (D/8 lanes per query).
+// Everything a call needs before its first filter launch, in ONE launch (one wave per query): the normalised query row
+// (the norm tree, sqrt and divisions of normalize_rows_kernel, so the same bits), |dq| of its bf16 rounding, an empty
+// candidate list, a clear overflow flag, and -- before a bound pass -- the group maxima at -inf.
 template <int D>
-__global__ void __launch_bounds__(256) filter_query_err_kernel(const float* __restrict__ Qn, int64_t B,
-                                                               float* __restrict__ eq) {
-  constexpr int TPR = D / 8;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t q = i / TPR;
-  float e2 = 0.f;
-  if (q < B) {
-    const float4 a = reinterpret_cast<const float4*>(Qn)[2 * i], b = reinterpret_cast<const float4*>(Qn)[2 * i + 1];
-    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+__global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restrict__ Q, int64_t B, float* __restrict__ Qn,
+                                                          float* __restrict__ eq, int* __restrict__ count,
+                                                          unsigned char* __restrict__ flag, int* __restrict__ overflow,
+                                                          int* __restrict__ gmax, int ngroups,
+                                                          uint16_t* __restrict__ Qb) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q == 0 && lane == 0) *overflow = 0;
+  if (q >= (Qb ? (B + 31) / 32 * 32 : B)) return;
+  constexpr int NCH = D / 4;  // float4 chunks per row: 16 / 32 / 64 -- at most one per lane
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (lane < NCH && q < B) v = reinterpret_cast<const float4*>(Q + q * D)[lane];
+  float p = 0.f;
+  p = fmaf(v.x, v.x, p);
+  p = fmaf(v.y, v.y, p);
+  p = fmaf(v.z, v.z, p);
+  p = fmaf(v.w, v.w, p);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float d = x[e] - (float)(__bf16)x[e];
-      e2 = fmaf(d, d, e2);
+  for (int off = 32; off >= 1; off >>= 1) p = __fadd_rn(p, __shfl_xor(p, off));
+  const float d = fmaxf(sqrtf(p), 1e-12f);
+  v.x = v.x / d; v.y = v.y / d; v.z = v.z / d; v.w = v.w / d;
+  if (lane < NCH && q < B) reinterpret_cast<float4*>(Qn + q * D)[lane] = v;
+  if (Qb && lane < NCH) {
+    // the direct kernel's B operands (<= 256 queries): bf16 in fragment order (filter_common.h, DirectArgs::Qb); this
+    // lane's elements 4 l .. 4 l + 3 are half of one 16-byte piece.  (The launch covers the padding queries of the last
+    // group of 32 too: they get zero rows.)
+    const int e0 = 4 * lane, t = e0 >> 4, gg = (e0 >> 3) & 1;
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 o;
+    o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    char* base = reinterpret_cast<char*>(Qb) + ((q >> 5) * (D / 16) + t) * 1024 + (gg * 32 + (int)(q & 31)) * 16 + (e0 & 7) * 2;
+    *reinterpret_cast<bf16x4*>(base) = o;
+  }
+  float e2 = 0.f;
+  {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float dd = x[e] - (float)(__bf16)x[e];
+      e2 = fmaf(dd, dd, e2);
     }
   }
 #pragma unroll
-  for (int off = TPR / 2; off >= 1; off >>= 1) e2 += __shfl_xor(e2, off);
-  if ((threadIdx.x & (TPR - 1)) == 0 && q < B) eq[q] = sqrtf(e2);
-}
-
-// thr[q] = theta[q] - eps(q); count[q] = 0.  `first`: also clear the overflow bookkeeping.  theta is the k-th exact score
-// of the previous level, or -- gmax != NULL, after the bound pass -- min over the k groups of the group's best APPROXIMATE
-// score minus eps(q): each group's best key has an exact score >= its approximate one - eps, so k distinct keys score at
-// least that, and so does the final k-th best.
-__global__ void __launch_bounds__(256) filter_prepare_kernel(const float* __restrict__ prev_scores, int64_t B, int k,
-                                                             const float* __restrict__ eq,
-                                                             const unsigned* __restrict__ max_kerr2,
-                                                             float* __restrict__ thr, int* __restrict__ count,
-                                                             int* __restrict__ overflow, unsigned char* __restrict__ flag,
-                                                             int first, int ablate, const int* __restrict__ gmax) {
-  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (first && q == 0) *overflow = 0;
+  for (int off = 32; off >= 1; off >>= 1) e2 += __shfl_xor(e2, off);
   if (q >= B) return;
-  const float ek = sqrtf(__uint_as_float(*max_kerr2));
-  const float e = eq[q];
-  const float eps = fmaf(fmaf(e, ek, e + ek), 1.0009765625f, FILTER_EPS_SLACK);  // rounding direction is inside the factor
-  float theta;
-  if (gmax) {
-    int m = gmax[q * k];
-    for (int g = 1; g < k; ++g) m = min(m, gmax[q * k + g]);
-    theta = __fsub_rn(ord2f(m), eps);
-  } else {
-    theta = prev_scores[q * k + k - 1];
+  if (lane == 0) {
+    eq[q] = sqrtf(e2) * 1.0000002f;  // (any summation order of the squares stays below this)
+    count[q] = 0;
+    flag[q] = 0;
   }
-  thr[q] = ablate ? __builtin_huge_valf() : __fsub_rn(theta, eps);
-  count[q] = 0;
-  if (first) flag[q] = 0;
-}
-
-__global__ void __launch_bounds__(256) filter_gmax_init_kernel(int* __restrict__ gmax, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) gmax[i] = f2ord(RG_NEG_INF);
+  if (gmax && lane < ngroups) gmax[q * ngroups + lane] = f2ord(RG_NEG_INF);
 }
 
 #ifdef RG_TOPK_TIMING  // diagnostic build only: per-wave cycle totals of the ring's phases
@@ -222,16 +205,13 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, g = lane >> 5;
 
-  // DMA source offsets of this lane for the wave's DMAS instructions of a stage.  Instruction i of wave w fills LDS bytes
-  // [(DMAS w + i) KiB, + 1 KiB) of the slot = RPI consecutive rows; LDS byte 16 l of it is row l / CR of the instruction at
-  // chunk position l % CR, which holds source chunk pos ^ swz(row in stage).
+  // DMA: instruction i of wave w copies the stage's (DMAS w + i)-th 1-KiB block -- one k-step of one 32-key sub-tile in
+  // fragment order -- to the same offset of the ring slot; lane l moves bytes [16 l, 16 l + 16) of it.  The LDS image IS
+  // the HBM image, and a k-step's A operand is one ds_read_b128 at 16 l: consecutive lanes, consecutive pieces, no
+  // bank conflicts and no swizzle.
   unsigned voff[C::DMAS];
 #pragma unroll
-  for (int i = 0; i < C::DMAS; ++i) {
-    const int rin = lane / C::CR, pos = lane % C::CR;
-    const int row = (C::DMAS * wave + i) * C::RPI + rin;  // row inside the stage
-    voff[i] = (unsigned)(i * 1024 + rin * C::ROW_BYTES + ((pos ^ C::swz(row)) << 4));
-  }
+  for (int i = 0; i < C::DMAS; ++i) voff[i] = (unsigned)(i * 1024 + lane * 16);
   auto dma_stage = [&](int64_t stage_abs, int slot) {  // stage_abs: stage index over the whole bank
     // (wave-uniform by construction; the readfirstlanes keep it in SGPRs whatever hipcc's divergence analysis makes of
     // the loop around it)
@@ -250,16 +230,8 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
           : "memory");
     }
   };
-  // A fragment of lane (j, g) for k-step t of a sub-tile: row j (swz depends only on j: sub-tiles start at multiples of
-  // 32 rows), source chunk c = 2t + g, stored at position c ^ swz(j) = 2t ^ c0 with c0 = g ^ swz(j).  Eight per-lane
-  // addresses (t & 7) plus immediate offsets (256 B for t >= 8 at D = 256; the sub-tile) reach every fragment of a stage.
-  constexpr int NA = C::KSTEPS < 8 ? C::KSTEPS : 8;
-  unsigned apos[NA];
-  {
-    const unsigned c0 = (unsigned)(g ^ C::swz(j));
-#pragma unroll
-    for (int i = 0; i < NA; ++i) apos[i] = lds_base + (unsigned)j * C::ROW_BYTES + (((unsigned)(2 * i) ^ c0) << 4);
-  }
+  // A fragment of step n of a stage (sub-tile n / KSTEPS, k-step n % KSTEPS): block n of the slot, this lane's 16 bytes
+  const unsigned apos = lds_base + (unsigned)lane * 16u;
 
   const int x = p.xcd_map ? (int)(blockIdx.x & 7) : 0;
   const int64_t nq = p.xcd_map ? ((p.qtiles - x + 7) >> 3) : p.qtiles;
@@ -296,7 +268,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     float thr[NG];
 #pragma unroll
     for (int gq = 0; gq < NG; ++gq)
-      thr[gq] = (!BOUND && q_lo + 32 * gq < p.B) ? p.thr[q_lo + 32 * gq] : __builtin_huge_valf();
+      thr[gq] = (!BOUND && q_lo + 32 * gq < p.B) ? filter_threshold(p.thr, q_lo + 32 * gq) : __builtin_huge_valf();
     // bound pass: running maxima of the current group (group g = stages [ceil(g n / G), ceil((g+1) n / G)) of the range)
     float gm[NG];
 #pragma unroll
@@ -442,16 +414,13 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
       // their MFMAs (hipcc's own schedule keeps one ahead and the matrix pipe idles half the time).  They are asm
       // loads, invisible to hipcc's waitcnt bookkeeping: RG_FWAIT counts them (LDS returns in order; anything else
       // outstanding only makes the wait stricter) and names the fragment so its MFMAs stay behind the wait.
-      unsigned addr[NA];
-#pragma unroll
-      for (int i = 0; i < NA; ++i) addr[i] = apos[i] + (unsigned)(slot * C::STAGE_BYTES);
+      const unsigned addr = apos + (unsigned)(slot * C::STAGE_BYTES);
       f32x16 acc[NG];
       f32x4 fr[4];
 #define RG_FREAD(n_)                                                                                       \
   asm volatile("ds_read_b128 %0, %1 offset:%2"                                                             \
                : "=v"(fr[(n_)&3])                                                                           \
-               : "v"(addr[((n_) % C::KSTEPS) & 7]),                                                         \
-                 "i"(((n_) / C::KSTEPS) * 32 * C::ROW_BYTES + ((((n_) % C::KSTEPS) >= 8) ? 256 : 0)))
+               : "v"(addr), "i"((n_) * 1024))
 #define RG_FWAIT(c_, n_) asm volatile("s_waitcnt lgkmcnt(" #c_ ")" : "+v"(fr[(n_)&3]))
 #define RG_FSTEP(n_)                                                                                       \
   {                                                                                                        \
@@ -668,11 +637,11 @@ __device__ __forceinline__ void rescore_query(const float4* __restrict__ qrow, c
 // fewer candidates than the capacity: the slot count is a wave-uniform choice among 1, 2, 4, 8 and CPL.
 template <int D, int CPL>
 __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restrict__ Qn, const float* __restrict__ Kn,
-                                                           const int* __restrict__ count, const int* __restrict__ cand,
+                                                           int* __restrict__ count, const int* __restrict__ cand,
                                                            int64_t B, int cap, int k, int64_t idx_base,
                                                            const float* prev_s, const int64_t* prev_i, int final_level,
                                                            float* out_s, int64_t* out_i, int* __restrict__ overflow,
-                                                           int64_t* __restrict__ overflow_idx,
+                                                           int* __restrict__ overflow_list,
                                                            unsigned char* __restrict__ flag) {
   __shared__ float4 qs[4][D / 4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -682,6 +651,7 @@ __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restri
   __builtin_amdgcn_wave_barrier();
   int n = count[b];
   bool over = flag[b] != 0;
+  if (lane == 0 && n >= 0) count[b] = 0;  // the next level starts from an empty list (ordered behind the read through n)
   if (n > cap) {  // slots reserved beyond the capacity: candidates were dropped
     over = true;
     n = cap;
@@ -690,7 +660,7 @@ __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restri
     if (final_level) {
       if (over) {
         const int pos = atomicAdd(overflow, 1);
-        if (overflow_idx) overflow_idx[pos] = b;
+        overflow_list[pos] = (int)b;
       }
     } else if (over) {
       flag[b] = 1;
@@ -712,12 +682,12 @@ __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restri
 // Large batches: as topk_rescore_kernel, rows staged through LDS (coop_scores); two waves per workgroup.
 template <int D, int CPL>
 __global__ void __launch_bounds__(128) topk_rescore_coop_kernel(const float* __restrict__ Qn, const float* __restrict__ Kn,
-                                                                const int* __restrict__ count,
+                                                                int* __restrict__ count,
                                                                 const int* __restrict__ cand, int64_t B, int cap, int k,
                                                                 int64_t idx_base, const float* prev_s,
                                                                 const int64_t* prev_i, int final_level, float* out_s,
                                                                 int64_t* out_i, int* __restrict__ overflow,
-                                                                int64_t* __restrict__ overflow_idx,
+                                                                int* __restrict__ overflow_list,
                                                                 unsigned char* __restrict__ flag) {
   __shared__ float4 qs[2][D / 4];
   __shared__ __attribute__((aligned(16))) float tile[2][64 * RESCORE_LD];
@@ -731,6 +701,7 @@ __global__ void __launch_bounds__(128) topk_rescore_coop_kernel(const float* __r
   if (lane < D / 4) qv4 = reinterpret_cast<const float4*>(Qn + b * D)[lane];
   if (lane < D / 4) qs[w][lane] = qv4;
   __builtin_amdgcn_wave_barrier();
+  if (lane == 0 && n >= 0) count[b] = 0;  // the next level starts from an empty list (ordered behind the read through n)
   if (n > cap) {
     over = true;
     n = cap;
@@ -739,7 +710,7 @@ __global__ void __launch_bounds__(128) topk_rescore_coop_kernel(const float* __r
     if (final_level) {
       if (over) {
         const int pos = atomicAdd(overflow, 1);
-        if (overflow_idx) overflow_idx[pos] = b;
+        overflow_list[pos] = (int)b;
       }
     } else if (over) {
       flag[b] = 1;
@@ -763,15 +734,19 @@ __global__ void __launch_bounds__(128) topk_rescore_coop_kernel(const float* __r
 // each a latency-bound chain of row loads, and a few hundred waves do not hide that; here four waves take a quarter of
 // the list each, leave their top-k in LDS, and wave 0 merges the four (and the previous level's winners, which ride
 // with wave 0's quarter).
-template <int D>
+// SLICED (a handful of queries: gridDim.y = S workgroups per query): a workgroup rescans only slice blockIdx.y of the
+// list and leaves its k winners (local ids) in part_s / part_i [B][S][k]; topk_rescore_merge_kernel finishes the query.
+// One workgroup walking ~800 candidates of a lone query is ~30 us of dependent row gathers; eight of them take ~8.
+template <int D, bool SLICED>
 __global__ void __launch_bounds__(256) topk_rescore_wide_kernel(const float* __restrict__ Qn, const float* __restrict__ Kn,
-                                                                const int* __restrict__ count,
+                                                                int* __restrict__ count,
                                                                 const int* __restrict__ cand, int64_t B, int cap, int k,
                                                                 int64_t idx_base, const float* prev_s,
                                                                 const int64_t* prev_i, int final_level, float* out_s,
                                                                 int64_t* out_i, int* __restrict__ overflow,
-                                                                int64_t* __restrict__ overflow_idx,
-                                                                unsigned char* __restrict__ flag) {
+                                                                int* __restrict__ overflow_list,
+                                                                unsigned char* __restrict__ flag,
+                                                                float* __restrict__ part_s, int* __restrict__ part_i) {
   __shared__ float4 qs[D / 4];
   __shared__ float ps[4][32];
   __shared__ int64_t pi[4][32];
@@ -780,27 +755,37 @@ __global__ void __launch_bounds__(256) topk_rescore_wide_kernel(const float* __r
   if (threadIdx.x < D / 4) qs[threadIdx.x] = reinterpret_cast<const float4*>(Qn + b * D)[threadIdx.x];
   __syncthreads();
   int n = count[b];
-  bool over = flag[b] != 0;
+  bool over = false;
   if (n > cap) {
     over = true;
     n = cap;
   }
-  if (threadIdx.x == 0) {
-    if (final_level) {
-      if (over) {
-        const int pos = atomicAdd(overflow, 1);
-        if (overflow_idx) overflow_idx[pos] = b;
+  if constexpr (!SLICED) {
+    over = over || flag[b] != 0;
+    if (threadIdx.x == 0) {
+      if (final_level) {
+        if (over) {
+          const int pos = atomicAdd(overflow, 1);
+          overflow_list[pos] = (int)b;
+        }
+      } else if (over) {
+        flag[b] = 1;
       }
-    } else if (over) {
-      flag[b] = 1;
     }
+  }
+  int lo0 = 0;
+  if constexpr (SLICED) {  // this workgroup's slice of the list
+    const int S = (int)gridDim.y, sl = (int)blockIdx.y;
+    const int pers = (n + S - 1) / S;
+    lo0 = sl * pers;
+    n = lo0 >= n ? 0 : (n - lo0 < pers ? n - lo0 : pers);
   }
   const int per = (n + 3) / 4;  // <= 512
   const int lo = w * per;
   const int nw = lo >= n ? 0 : (n - lo < per ? n - lo : per);
-  const int* cb = cand + b * cap + lo;
-  const float* pps = (prev_s && w == 0) ? prev_s + b * k : nullptr;
-  const int64_t* ppi = (prev_i && w == 0) ? prev_i + b * k : nullptr;
+  const int* cb = cand + b * cap + lo0 + lo;
+  const float* pps = (!SLICED && prev_s && w == 0) ? prev_s + b * k : nullptr;
+  const int64_t* ppi = (!SLICED && prev_i && w == 0) ? prev_i + b * k : nullptr;
 #define RG_RESCORE(NS_) rescore_query<D, NS_>(qs, Kn, cb, nw, lane, k, 0, pps, ppi, ps[w], pi[w])
   if (nw <= 64) RG_RESCORE(1);
   else if (nw <= 128) RG_RESCORE(2);
@@ -808,6 +793,9 @@ __global__ void __launch_bounds__(256) topk_rescore_wide_kernel(const float* __r
   else RG_RESCORE(8);
 #undef RG_RESCORE
   __syncthreads();
+  if constexpr (!SLICED) {
+    if (threadIdx.x == 0) count[b] = 0;  // every wave has read it: the next level starts from an empty list
+  }
   if (w == 0) {  // 4 k <= 128 partial winners: two per lane
     float s[2];
     int id[2];
@@ -819,7 +807,141 @@ __global__ void __launch_bounds__(256) topk_rescore_wide_kernel(const float* __r
       const int64_t pv = have ? pi[e / k][e % k] : INT64_MAX;
       id[u] = pv >= INT_MAX ? INT_MAX : (int)pv;
     }
-    wave_select<2>(s, id, k, lane, final_level ? idx_base : 0, out_s + b * k, out_i + b * k);
+    if constexpr (SLICED) {
+      // (wave_select writes 64-bit ids: staged through LDS, stored as the 32-bit local ids the merge expects)
+      wave_select<2>(s, id, k, lane, 0, ps[0], pi[0]);
+      __builtin_amdgcn_wave_barrier();
+      const int64_t slot = (b * gridDim.y + blockIdx.y) * k;
+      if (lane < k) {
+        part_s[slot + lane] = ps[0][lane];
+        part_i[slot + lane] = pi[0][lane] >= INT_MAX ? INT_MAX : (int)pi[0][lane];
+      }
+    } else {
+      wave_select<2>(s, id, k, lane, final_level ? idx_base : 0, out_s + b * k, out_i + b * k);
+    }
+  }
+}
+
+// Second half of the sliced rescoring: one wave per query merges the S slices' winners (S k <= 256: four per lane) with
+// the previous level's, does the level's bookkeeping (overflow flag / list, empty list for the next level) and writes
+// the running result.
+__global__ void __launch_bounds__(256) topk_rescore_merge_kernel(int* __restrict__ count, int64_t B, int S, int cap, int k,
+                                                                 int64_t idx_base, const float* prev_s, const int64_t* prev_i,
+                                                                 int final_level, float* out_s, int64_t* out_i,
+                                                                 int* __restrict__ overflow, int* __restrict__ overflow_list,
+                                                                 unsigned char* __restrict__ flag,
+                                                                 const float* __restrict__ part_s,
+                                                                 const int* __restrict__ part_i) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;  // whole wave
+  const int n = count[b];
+  const bool over = flag[b] != 0 || n > cap;
+  if (lane == 0 && n >= 0) {
+    count[b] = 0;
+    if (final_level) {
+      if (over) {
+        const int pos = atomicAdd(overflow, 1);
+        overflow_list[pos] = (int)b;
+      }
+    } else if (over) {
+      flag[b] = 1;
+    }
+  }
+  float s[5];
+  int id[5];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = lane + 64 * u;
+    const bool have = e < S * k;
+    s[u] = have ? part_s[b * S * k + e] : RG_NEG_INF;
+    id[u] = have ? part_i[b * S * k + e] : INT_MAX;
+  }
+  s[4] = RG_NEG_INF;
+  id[4] = INT_MAX;
+  if (prev_s && lane < k) {
+    s[4] = prev_s[b * k + lane];
+    const int64_t pv = prev_i[b * k + lane];
+    id[4] = pv >= INT_MAX ? INT_MAX : (int)pv;
+  }
+  wave_select<5>(s, id, k, lane, final_level ? idx_base : 0, out_s + b * k, out_i + b * k);
+}
+
+// The exact fallback for queries whose candidate list overflowed (thousands of keys within eps of the k-th best:
+// near-duplicate banks, zero queries), ON THE DEVICE: the final rescoring kernel has listed them, and this launch -- a
+// fixed grid that finds an empty list on ordinary banks and returns -- scans the whole bank for each with the fp32 chain
+// (coop_scores: 64 rows per step through an LDS tile), one workgroup per listed query, four waves a quarter of the
+// keys each with a register-resident sorted list (lane p = entry p), merged at the end.  No host read-back, so the call
+// stays asynchronous and HIP-graph capturable; a bank that sends many queries here is slow (one full fp32 scan per
+// query and workgroup), which KeyIndex notices from the count after the fact and stops filtering that bank.
+template <int D>
+__global__ void __launch_bounds__(256) topk_overflow_fixup_kernel(const float* __restrict__ Qn, const float* __restrict__ Kn,
+                                                                  int64_t N, int k, int64_t idx_base,
+                                                                  const int* __restrict__ overflow,
+                                                                  const int* __restrict__ overflow_list,
+                                                                  int64_t* __restrict__ overflow_idx_out,
+                                                                  float* __restrict__ out_s, int64_t* __restrict__ out_i) {
+  __shared__ float4 qs[D / 4];
+  __shared__ __attribute__((aligned(16))) float tile[4][64 * RESCORE_LD];
+  __shared__ float ps[4][32];
+  __shared__ int64_t pi[4][32];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n_over = *overflow;
+  for (int o = blockIdx.x; o < n_over; o += gridDim.x) {
+    const int64_t b = overflow_list[o];
+    if (overflow_idx_out && threadIdx.x == 0) overflow_idx_out[o] = b;
+    if (threadIdx.x < D / 4) qs[threadIdx.x] = reinterpret_cast<const float4*>(Qn + b * D)[threadIdx.x];
+    __syncthreads();
+    float es = RG_NEG_INF;  // lane p < k: entry p of this wave's sorted list
+    int ei = INT_MAX;
+    float kth_s = RG_NEG_INF;
+    int kth_i = INT_MAX;
+    for (int64_t base = (int64_t)w * 64; base < N; base += 256) {
+      const int key = base + lane < N ? (int)(base + lane) : -1;
+      const float sc = coop_scores<D>(qs, Kn, key, lane, tile[w]);
+      unsigned long long pend = __ballot(key >= 0 && cand_better(sc, key, kth_s, kth_i));
+      while (pend) {
+        const int src = __ffsll((long long)pend) - 1;
+        pend &= pend - 1;
+        const float s = __shfl(sc, src);
+        const int id = __shfl(key, src);
+        const unsigned long long ahead = __ballot(lane < k && cand_better(es, ei, s, id));
+        const int pos = __popcll(ahead);
+        const float us = __shfl_up(es, 1);
+        const int ui = __shfl_up(ei, 1);
+        if (pos < k) {
+          if (lane == pos) {
+            es = s;
+            ei = id;
+          } else if (lane > pos && lane < k) {
+            es = us;
+            ei = ui;
+          }
+        }
+        kth_s = __shfl(es, k - 1);
+        kth_i = __shfl(ei, k - 1);
+        pend &= __ballot(key >= 0 && cand_better(sc, key, kth_s, kth_i));
+      }
+    }
+    if (lane < 32) {
+      ps[w][lane] = lane < k ? es : RG_NEG_INF;
+      pi[w][lane] = (lane < k && ei != INT_MAX) ? (int64_t)ei : INT64_MAX;
+    }
+    __syncthreads();
+    if (w == 0) {  // 4 k <= 128 partial winners: two per lane
+      float s2[2];
+      int id2[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = lane + 64 * u;
+        const bool have = e < 4 * k;
+        s2[u] = have ? ps[e / k][e % k] : RG_NEG_INF;
+        const int64_t pv = have ? pi[e / k][e % k] : INT64_MAX;
+        id2[u] = pv >= INT_MAX ? INT_MAX : (int)pv;
+      }
+      wave_select<2>(s2, id2, k, lane, idx_base, out_s + b * k, out_i + b * k);
+    }
+    __syncthreads();
   }
 }
 
@@ -958,9 +1080,13 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k) {
   double best = 1e30;
   int64_t best_n0 = 4096, best_nA = 0;
   int best_L = FILTER_MAX_LEVELS;
+  // RAGRAPH_FILTER_FORCE_N0 / _L: schedule experiments (n0 = the exact sample the first bound is worth, L levels)
+  static const int64_t force_n0 = [] { const char* e = getenv("RAGRAPH_FILTER_FORCE_N0"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
+  static const int force_L = [] { const char* e = getenv("RAGRAPH_FILTER_FORCE_L"); return e ? atoi(e) : 0; }();
   const int stage_keys = FILTER_STAGE_BYTES / (2 * D);
   const double tiles = (double)((B + 511) / 512);
   for (int64_t n0 = 4096; n0 * 4 <= N; n0 *= 2) {
+    if (force_n0 > 0 && n0 != force_n0) continue;
     double first;  // cost of the first bound, us
     int64_t nA = 0;
     if (bound) {
@@ -972,8 +1098,9 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k) {
       first = 30.0 + (double)B * (double)n0 * (2.0 * D / 1.0e8 + 4.0 / 3.0e6);
     }
     for (int L = 1; L <= FILTER_MAX_LEVELS; ++L) {
+      if (force_L > 0 && L != force_L) continue;
       const double r = pow((double)N / (double)n0, 1.0 / L);
-      if (1.3 * k * r > cap / 2) continue;
+      if (1.3 * k * r > cap / 2 && !(force_n0 > 0 && force_L > 0)) continue;
       const double cost = first + L * (60.0 + (double)B * 1.3 * k * r * 0.4e-3);
       if (cost < best) {
         best = cost;
@@ -1036,13 +1163,13 @@ extern "C" int64_t ragraph_keys_bf16_rows(int64_t N) { return N < 1 ? 0 : filter
 
 extern "C" int ragraph_topk_cosine_filtered_cap(int k) { return 2048; }
 
+static size_t filter_ws_carve(char* w, int64_t B, int D, int k, int cap, struct FilterWs* out);
+
 extern "C" size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_t N, int D, int k) {
   if (B < 1 || N < 1 || k < 1 || !filter_dim_ok(D)) return 0;
   const int cap = ragraph_topk_cosine_filtered_cap(k);
   const FilterSchedule sc = filter_schedule(B, N, D, k);
-  return filter_level0_ws(sc, B, D, k) + align_up((size_t)B * D * sizeof(float), 256) +
-         2 * align_up((size_t)B * sizeof(float), 256) + align_up((size_t)B * sizeof(int), 256) + align_up((size_t)B, 256) +
-         align_up((size_t)B * cap * sizeof(int), 256) + align_up((size_t)B * k * sizeof(int), 256);
+  return filter_level0_ws(sc, B, D, k) + filter_ws_carve(nullptr, B, D, k, cap, nullptr);
 }
 
 extern "C" int ragraph_topk_cosine_filtered_plan(int64_t B, int64_t N, int D, int k, int64_t plan[7]) {
@@ -1058,36 +1185,47 @@ extern "C" int ragraph_topk_cosine_filtered_plan(int64_t B, int64_t N, int D, in
   return sc.nlev;
 }
 
-// One filter level: thresholds from the exact scores in out_scores, bf16 filter over keys [key0, key1), rescoring
-// (+ merge with out_* when `merge`).
-template <int D, int QW>
-static int run_filter_level_qw(const float* Qn, const float* Kn, const uint16_t* Kb, int64_t B, int64_t key0, int64_t key1,
-                            int k, int64_t idx_base, int first, int merge, int final_level, float* out_scores,
-                            int64_t* out_idx, int* overflow, int64_t* overflow_idx, float* thr, const float* eq,
-                            const unsigned* max_kerr2, int* count, unsigned char* flag, int* cand, int cap, int level,
-                            const int* gmax, hipStream_t st) {
+// Everything one call keeps in its workspace behind level 0's scratch.
+struct FilterWs {
+  float* Qn;            // [B,D] normalised queries
+  uint16_t* Qb;         // (B <= 256) the same as bf16 B operands in fragment order, padded to whole groups of 32
+  float* eq;            // [B] |dq|
+  int* count;           // [B] candidate slots reserved in the current level
+  unsigned char* flag;  // [B] the list overflowed at an earlier level
+  int* cand;            // [B,cap] candidate keys
+  int* gmax;            // [B,k] group maxima of the bound pass
+  int* overflow_list;   // [B] queries the final level sends to the exact fallback
+  float* part_s;        // (B <= 64) sliced rescoring: [B][8][k] partial winners
+  int* part_i;
+};
+
+static size_t filter_ws_carve(char* w, int64_t B, int D, int k, int cap, FilterWs* out) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* ptr = w ? w + off : nullptr;
+    off += align_up(bytes, 256);
+    return ptr;
+  };
+  FilterWs f;
+  f.Qn = reinterpret_cast<float*>(take((size_t)B * D * sizeof(float)));
+  f.Qb = B <= 256 ? reinterpret_cast<uint16_t*>(take((size_t)((B + 31) / 32 * 32) * D * sizeof(uint16_t))) : nullptr;
+  f.eq = reinterpret_cast<float*>(take((size_t)B * sizeof(float)));
+  f.count = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
+  f.flag = reinterpret_cast<unsigned char*>(take((size_t)B));
+  f.cand = reinterpret_cast<int*>(take((size_t)B * cap * sizeof(int)));
+  f.gmax = reinterpret_cast<int*>(take((size_t)B * k * sizeof(int)));
+  f.overflow_list = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
+  f.part_s = B <= 64 ? reinterpret_cast<float*>(take((size_t)B * 8 * k * sizeof(float))) : nullptr;
+  f.part_i = B <= 64 ? reinterpret_cast<int*>(take((size_t)B * 8 * k * sizeof(int))) : nullptr;
+  if (out) *out = f;
+  return off;
+}
+
+// Ring-kernel launch shared by the filter levels and the bound pass (B > 256: the direct kernel takes smaller batches).
+template <int D, int QW, bool BOUND>
+static int launch_ring(FilterParams p, int64_t B, int prof_slot, hipStream_t st) {
   using C = FilterCfg<D>;
-  static const int ablate = [] {  // RAGRAPH_FILTER_ABLATE=1: no key passes the filter (timing only, results invalid)
-    const char* e = getenv("RAGRAPH_FILTER_ABLATE");
-    return e ? atoi(e) : 0;
-  }();
-  hipLaunchKernelGGL(filter_prepare_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, out_scores, B, k, eq, max_kerr2,
-                     thr, count, overflow, flag, first, ablate, gmax);
-  RG_CHECK_LAUNCH("topk_cosine_filtered(prepare)");
-  FilterParams p;
-  p.Qn = Qn;
-  p.Kb = Kb;
-  p.thr = thr;
-  p.count = count;
-  p.cand = cand;
-  p.gmax = nullptr;
-  p.ngroups = 0;
-  p.B = B;
-  p.N = key1;
-  p.cap = cap;
-  p.stage_base = key0 / C::STAGE_KEYS;  // key0 is a multiple of 256
   p.qtiles = cdiv(B, (int64_t)C::WAVES * QW);
-  p.nstages_total = cdiv(key1 - key0, C::STAGE_KEYS);
   const int CUS = filter_device_cus();
   p.xcd_map = p.qtiles >= 64 ? 1 : 0;
   p.wgs_per_group = CUS / (p.xcd_map ? 8 : 1);
@@ -1099,17 +1237,14 @@ static int run_filter_level_qw(const float* Qn, const float* Kn, const uint16_t*
     if (nq < 1 || (v == 1 && (!p.xcd_map || p.qtiles % 8 == 0))) continue;
     p.depth[v] = SegmentWalker::choose_depth(nq, p.nstages_total, p.wgs_per_group, p.lb_min, 0).depth;
   }
-  static DeviceOnce lds_once;  // per device (common.h)
-  if (hipError_t e = raise_dynamic_lds(lds_once, &topk_filter_kernel<D, QW>, (int)C::LDS_BYTES); e != hipSuccess) {
+  static DeviceOnce lds_once;  // per template instance and device (common.h)
+  if (hipError_t e = raise_dynamic_lds(lds_once, &topk_filter_kernel<D, QW, BOUND>, (int)C::LDS_BYTES); e != hipSuccess) {
     set_error("topk_cosine_filtered: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
     return RAGRAPH_EDEVICE;
   }
-  if (g_prof_on) (void)hipEventRecord(g_prof_ev[2 * level], st);
-  hipLaunchKernelGGL((topk_filter_kernel<D, QW>), dim3((unsigned)CUS), dim3(C::THREADS), C::LDS_BYTES, st, p);
-  if (g_prof_on) {
-    (void)hipEventRecord(g_prof_ev[2 * level + 1], st);
-    g_prof_have = level + 1;
-  }
+  if (g_prof_on) (void)hipEventRecord(g_prof_ev[2 * prof_slot], st);
+  hipLaunchKernelGGL((topk_filter_kernel<D, QW, BOUND>), dim3((unsigned)CUS), dim3(C::THREADS), C::LDS_BYTES, st, p);
+  if (g_prof_on) (void)hipEventRecord(g_prof_ev[2 * prof_slot + 1], st);
   RG_CHECK_LAUNCH("topk_cosine_filtered(filter)");
 #ifdef RG_TOPK_TIMING
   {
@@ -1118,95 +1253,102 @@ static int run_filter_level_qw(const float* Qn, const float* Kn, const uint16_t*
     (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_filter_timing), sizeof(t));
     const double n = (double)t[5];
     if (n > 0)
-      fprintf(stderr, "[filter timing] level %d D=%d wave-stages=%.0f ticks/stage: wait_full %.1f compute %.1f signal+vmcnt "
-              "%.1f wait_free %.1f dma_issue %.1f total %.1f\n", level, D, n, t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n,
+      fprintf(stderr, "[filter timing] slot %d D=%d wave-stages=%.0f ticks/stage: wait_full %.1f compute %.1f signal+vmcnt "
+              "%.1f wait_free %.1f dma_issue %.1f total %.1f\n", prof_slot, D, n, t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n,
               (t[0] + t[1] + t[2] + t[3] + t[4]) / n);
     unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_filter_timing), zero, sizeof(zero));
   }
 #endif
-  // exact rescoring (+ merge) + canonical selection
+  return RAGRAPH_OK;
+}
+
+// One bf16 pass over keys [key0, key1) of the bank copy: a filter level (bound_groups = 0: candidates of every query
+// whose threshold `thr` describes) or the bound pass (bound_groups = k group maxima into gmax).  Up to 256 queries take
+// the direct kernel (topk_filter_direct.hip: the stream, not the matrix work, is what such a call costs), more the ring
+// kernel with two -- at D = 64 and long streams four -- query groups per wave.
+template <int D>
+static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64_t key0, int64_t key1, const FilterThr& thr,
+                         int cap, int bound_groups, int prof_slot, hipStream_t st) {
+  using C = FilterCfg<D>;
+  if (B <= 256) {
+    DirectArgs a{};
+    a.Qb = f.Qb;
+    a.Kb = Kb;
+    a.B = B;
+    a.key0 = key0;
+    a.key1 = key1;
+    a.thr = thr;
+    a.count = f.count;
+    a.cand = f.cand;
+    a.cap = cap;
+    a.gmax_out = f.gmax;
+    a.bound_groups = bound_groups;
+    if (g_prof_on) (void)hipEventRecord(g_prof_ev[2 * prof_slot], st);
+    const int rc = launch_filter_direct<D>(a, st);
+    if (g_prof_on) (void)hipEventRecord(g_prof_ev[2 * prof_slot + 1], st);
+    return rc;
+  }
+  FilterParams p{};
+  p.Qn = f.Qn;
+  p.Kb = Kb;
+  p.thr = thr;
+  p.count = f.count;
+  p.cand = f.cand;
+  p.gmax = bound_groups > 0 ? f.gmax : nullptr;
+  p.ngroups = bound_groups;
+  p.B = B;
+  p.N = key1;
+  p.cap = cap;
+  p.stage_base = key0 / C::STAGE_KEYS;  // key0 is a multiple of 256
+  p.nstages_total = cdiv(key1 - key0, C::STAGE_KEYS);
+  if (bound_groups > 0) return launch_ring<D, 64, true>(p, B, prof_slot, st);
+  if constexpr (D == 64) {  // short rows leave registers for four query groups per wave: half the LDS reads and ring
+                            // hand-overs per MFMA (the edge flavour's D)
+    // (only where a workgroup keeps its 1024 queries for a long stream: on a short bank the larger tiles mean fewer,
+    // shorter segments, each paying the operand loads again -- 8192 x 40000 x 64: 0.58 vs 0.46 ms)
+    if (filter_wide_waves(B) && cdiv(B, (int64_t)1024) * p.nstages_total >= 32 * (int64_t)filter_device_cus())
+      return launch_ring<D, 128, false>(p, B, prof_slot, st);
+  }
+  return launch_ring<D, 64, false>(p, B, prof_slot, st);
+}
+
+// Exact rescoring of a level's candidates (+ merge with the running result when `merge`) and canonical selection.
+template <int D>
+static int run_rescore(const FilterWs& f, const float* Kn, int64_t B, int cap, int k, int64_t idx_base, int merge,
+                       int final_level, float* out_scores, int64_t* out_idx, int* overflow, hipStream_t st) {
   const float* ps = merge ? out_scores : nullptr;
   const int64_t* pi = merge ? out_idx : nullptr;
   static const int64_t wide_max_b = [] {  // RAGRAPH_RESCORE_WIDE_BELOW: A/B of the crossover
     const char* e = getenv("RAGRAPH_RESCORE_WIDE_BELOW");
     return e ? (int64_t)atoll(e) : (int64_t)2048;  // measured: 512 queries 0.39 (wide) vs 0.44 ms, 1024-2048 equal, 4095: 1.98 vs 1.89
   }();
-  if (B < wide_max_b)  // too few queries to fill the chip with one wave each
-    hipLaunchKernelGGL(topk_rescore_wide_kernel<D>, dim3((unsigned)B), dim3(256), 0, st, Qn, Kn, count, cand, B, cap, k,
-                       idx_base, ps, pi, final_level, out_scores, out_idx, overflow, overflow_idx, flag);
+  static const int slice_env = [] {  // RAGRAPH_RESCORE_SLICES: A/B (0 = never slice)
+    const char* e = getenv("RAGRAPH_RESCORE_SLICES");
+    return e ? atoi(e) : -1;
+  }();
+  // a handful of queries: S workgroups per query + a merge launch (S k <= 256)
+  int S = B <= 16 ? 8 : (B <= 32 ? 4 : (B <= 64 ? 2 : 1));
+  if (slice_env >= 0) S = slice_env;
+  while (S > 1 && S * k > 256) S >>= 1;
+  if (B < wide_max_b && S > 1) {
+    hipLaunchKernelGGL((topk_rescore_wide_kernel<D, true>), dim3((unsigned)B, (unsigned)S), dim3(256), 0, st, f.Qn, Kn, f.count,
+                       f.cand, B, cap, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list,
+                       f.flag, f.part_s, f.part_i);
+    RG_CHECK_LAUNCH("topk_cosine_filtered(rescore slices)");
+    hipLaunchKernelGGL(topk_rescore_merge_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, st, f.count, B, S, cap, k, idx_base,
+                       ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag, f.part_s, f.part_i);
+  } else if (B < wide_max_b)  // too few queries to fill the chip with one wave each
+    hipLaunchKernelGGL((topk_rescore_wide_kernel<D, false>), dim3((unsigned)B), dim3(256), 0, st, f.Qn, Kn, f.count, f.cand, B,
+                       cap, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag,
+                       (float*)nullptr, (int*)nullptr);
   else if (rescore_coop())
-    hipLaunchKernelGGL((topk_rescore_coop_kernel<D, 32>), dim3((unsigned)cdiv(B, 2)), dim3(128), 0, st, Qn, Kn, count, cand,
-                       B, cap, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, overflow_idx, flag);
+    hipLaunchKernelGGL((topk_rescore_coop_kernel<D, 32>), dim3((unsigned)cdiv(B, 2)), dim3(128), 0, st, f.Qn, Kn, f.count,
+                       f.cand, B, cap, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag);
   else
-    hipLaunchKernelGGL((topk_rescore_kernel<D, 32>), dim3((unsigned)cdiv(B, 4)), dim3(256), 0, st, Qn, Kn, count, cand, B,
-                       cap, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, overflow_idx, flag);
+    hipLaunchKernelGGL((topk_rescore_kernel<D, 32>), dim3((unsigned)cdiv(B, 4)), dim3(256), 0, st, f.Qn, Kn, f.count, f.cand,
+                       B, cap, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag);
   RG_CHECK_LAUNCH("topk_cosine_filtered(rescore)");
-  return RAGRAPH_OK;
-}
-
-// Batches of <= 256 queries take the one-group kernel (query tile 256): half the matrix work per stage.
-template <int D>
-static int run_filter_level(const float* Qn, const float* Kn, const uint16_t* Kb, int64_t B, int64_t key0, int64_t key1,
-                            int k, int64_t idx_base, int first, int merge, int final_level, float* out_scores,
-                            int64_t* out_idx, int* overflow, int64_t* overflow_idx, float* thr, const float* eq,
-                            const unsigned* max_kerr2, int* count, unsigned char* flag, int* cand, int cap, int level,
-                            const int* gmax, hipStream_t st) {
-  if (B <= 256)
-    return run_filter_level_qw<D, 32>(Qn, Kn, Kb, B, key0, key1, k, idx_base, first, merge, final_level, out_scores, out_idx,
-                                      overflow, overflow_idx, thr, eq, max_kerr2, count, flag, cand, cap, level, gmax, st);
-  if constexpr (D == 64) {  // short rows leave registers for four query groups per wave: half the LDS reads and ring
-                            // hand-overs per MFMA (the edge flavour's D)
-    // (only where a workgroup keeps its 1024 queries for a long stream: on a short bank the larger tiles mean fewer,
-    // shorter segments, each paying the operand loads again -- 8192 x 40000 x 64: 0.58 vs 0.46 ms)
-    const int64_t nst = cdiv(key1 - key0, (int64_t)FilterCfg<D>::STAGE_KEYS);
-    if (filter_wide_waves(B) && cdiv(B, (int64_t)1024) * nst >= 32 * (int64_t)filter_device_cus())
-      return run_filter_level_qw<D, 128>(Qn, Kn, Kb, B, key0, key1, k, idx_base, first, merge, final_level, out_scores,
-                                         out_idx, overflow, overflow_idx, thr, eq, max_kerr2, count, flag, cand, cap, level,
-                                         gmax, st);
-  }
-  return run_filter_level_qw<D, 64>(Qn, Kn, Kb, B, key0, key1, k, idx_base, first, merge, final_level, out_scores, out_idx,
-                                    overflow, overflow_idx, thr, eq, max_kerr2, count, flag, cand, cap, level, gmax, st);
-}
-
-// The bound pass: group maxima of the approximate scores over keys [0, nA), nA a multiple of 256 with nA <= N.
-template <int D, int QW>
-static int run_bound_pass_qw(const float* Qn, const uint16_t* Kb, int64_t B, int64_t nA, int k, int* gmax, hipStream_t st) {
-  using C = FilterCfg<D>;
-  hipLaunchKernelGGL(filter_gmax_init_kernel, dim3((unsigned)cdiv(B * k, 256)), dim3(256), 0, st, gmax, B * k);
-  FilterParams p{};
-  p.Qn = Qn;
-  p.Kb = Kb;
-  p.gmax = gmax;
-  p.ngroups = k;
-  p.B = B;
-  p.N = nA;
-  p.stage_base = 0;
-  p.qtiles = cdiv(B, (int64_t)C::WAVES * QW);
-  p.nstages_total = nA / C::STAGE_KEYS;
-  const int CUS = filter_device_cus();
-  p.xcd_map = p.qtiles >= 64 ? 1 : 0;
-  p.wgs_per_group = CUS / (p.xcd_map ? 8 : 1);
-  p.lb_min = 8;
-  const int64_t nq0 = p.xcd_map ? (p.qtiles + 7) / 8 : p.qtiles;
-  for (int v = 0; v < 2; ++v) {
-    const int64_t nq = nq0 - v;
-    p.depth[v] = 0;
-    if (nq < 1 || (v == 1 && (!p.xcd_map || p.qtiles % 8 == 0))) continue;
-    p.depth[v] = SegmentWalker::choose_depth(nq, p.nstages_total, p.wgs_per_group, p.lb_min, 0).depth;
-  }
-  static DeviceOnce lds_once;  // per device (common.h)
-  if (hipError_t e = raise_dynamic_lds(lds_once, &topk_filter_kernel<D, QW, true>, (int)C::LDS_BYTES); e != hipSuccess) {
-    set_error("topk_cosine_filtered: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
-    return RAGRAPH_EDEVICE;
-  }
-  if (g_prof_on) (void)hipEventRecord(g_prof_ev[6], st);
-  hipLaunchKernelGGL((topk_filter_kernel<D, QW, true>), dim3((unsigned)CUS), dim3(C::THREADS), C::LDS_BYTES, st, p);
-  if (g_prof_on) {
-    (void)hipEventRecord(g_prof_ev[7], st);
-    g_prof_bound = 1;
-  }
-  RG_CHECK_LAUNCH("topk_cosine_filtered(bound pass)");
   return RAGRAPH_OK;
 }
 
@@ -1217,32 +1359,41 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   hipStream_t st = as_stream(stream);
   const int cap = ragraph_topk_cosine_filtered_cap(k);
   const FilterSchedule sc = filter_schedule(B, N, D, k);
-  const int nlev = sc.nlev;
-  const int64_t* ends = sc.ends;
+  static const int ablate = [] {  // RAGRAPH_FILTER_ABLATE=1: no key passes the filter (timing only, results invalid)
+    const char* e = getenv("RAGRAPH_FILTER_ABLATE");
+    return e ? atoi(e) : 0;
+  }();
   if (g_prof_on) g_prof_have = g_prof_bound = 0;
 
   char* w = static_cast<char*>(ws);
   const size_t sample_ws = filter_level0_ws(sc, B, D, k);
-  float* Qn = reinterpret_cast<float*>(w + sample_ws);
-  float* thr = reinterpret_cast<float*>(reinterpret_cast<char*>(Qn) + align_up((size_t)B * D * sizeof(float), 256));
-  float* eq = reinterpret_cast<float*>(reinterpret_cast<char*>(thr) + align_up((size_t)B * sizeof(float), 256));
-  int* count = reinterpret_cast<int*>(reinterpret_cast<char*>(eq) + align_up((size_t)B * sizeof(float), 256));
-  unsigned char* flag = reinterpret_cast<unsigned char*>(count) + align_up((size_t)B * sizeof(int), 256);
-  int* cand = reinterpret_cast<int*>(flag + align_up((size_t)B, 256));
-  int* gmax = reinterpret_cast<int*>(reinterpret_cast<char*>(cand) + align_up((size_t)B * cap * sizeof(int), 256));
+  FilterWs f;
+  filter_ws_carve(w + sample_ws, B, D, k, cap, &f);
   const unsigned* max_kerr2 = reinterpret_cast<const unsigned*>(Kb + filter_round_up(N) * D);
+  const bool bound = sc.bound_keys > 0;
 
-  // level 0: exact top-k over the first n0 keys (out_scores / out_idx hold every level's running result, local indices)
-  int rc = ragraph_normalize_rows_f32(Q, B, D, Qn, stream);
-  if (rc != RAGRAPH_OK) return rc;
-  if (sc.bound_keys > 0) {  // no exact level 0: group maxima of a bf16 pass bound the k-th best
-    rc = B <= 256 ? run_bound_pass_qw<D, 32>(Qn, Kb, B, sc.bound_keys, k, gmax, st)
-                  : run_bound_pass_qw<D, 64>(Qn, Kb, B, sc.bound_keys, k, gmax, st);
+  // one launch: normalised queries, their bf16 rounding errors, empty lists, clear flags (+ group maxima at -inf)
+  hipLaunchKernelGGL(filter_prep_kernel<D>, dim3((unsigned)cdiv(B <= 256 ? (B + 31) / 32 * 32 : B, 4)), dim3(256), 0, st, Q, B,
+                     f.Qn, f.eq, f.count, f.flag, overflow, bound ? f.gmax : nullptr, k, B <= 256 ? f.Qb : nullptr);
+  RG_CHECK_LAUNCH("topk_cosine_filtered(prepare)");
+
+  FilterThr thr{};
+  thr.eq = f.eq;
+  thr.max_kerr2 = max_kerr2;
+  thr.k = k;
+  thr.ngroups = k;
+  thr.ablate = ablate;
+  int rc = RAGRAPH_OK;
+  // the first bound: group maxima of a bf16 pass over a prefix, or an exact level 0 over the first n0 keys (out_scores /
+  // out_idx hold every level's running result, local indices)
+  if (bound) {
+    rc = run_bf16_pass<D>(f, Kb, B, 0, sc.bound_keys, thr, cap, k, 3, st);
+    if (g_prof_on) g_prof_bound = 1;
   } else if (sc.slab0) {
     float* S = reinterpret_cast<float*>(w);  // one slab of scores, reused: written and read back while it is in cache
     for (int64_t b0 = 0; b0 < B && rc == RAGRAPH_OK; b0 += FILTER_SLAB_MAX_B) {
       const int64_t nb = B - b0 < FILTER_SLAB_MAX_B ? B - b0 : FILTER_SLAB_MAX_B;
-      rc = ragraph_linear_f32(Qn + b0 * D, nb, D, Kn, sc.n0, nullptr, RAGRAPH_ACT_NONE, 0.f, S, stream);
+      rc = ragraph_linear_f32(f.Qn + b0 * D, nb, D, Kn, sc.n0, nullptr, RAGRAPH_ACT_NONE, 0.f, S, stream);
       if (rc == RAGRAPH_OK)
         rc = ragraph_topk_rows_f32(S, nb, sc.n0, sc.n0, k, out_scores + b0 * k, out_idx + b0 * k, stream);
     }
@@ -1251,16 +1402,22 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
                                       stream);
   }
   if (rc != RAGRAPH_OK) return rc;
-  hipLaunchKernelGGL(filter_query_err_kernel<D>, dim3((unsigned)cdiv(B * (D / 8), 256)), dim3(256), 0, st, Qn, B, eq);
-  RG_CHECK_LAUNCH("topk_cosine_filtered(query error)");
   int64_t key0 = 0;
-  for (int l = 0; l < nlev; ++l) {  // the first level re-reads [0, n0): its keys pass the bound and need no merge
-    rc = run_filter_level<D>(Qn, Kn, Kb, B, key0, ends[l], k, idx_base, l == 0, l > 0, l == nlev - 1, out_scores, out_idx,
-                             overflow, overflow_idx, thr, eq, max_kerr2, count, flag, cand, cap, l,
-                             (l == 0 && sc.bound_keys > 0) ? gmax : nullptr, st);
+  for (int l = 0; l < sc.nlev; ++l) {  // the first level re-reads [0, n0): its keys pass the bound and need no merge
+    thr.gmax = (l == 0 && bound) ? f.gmax : nullptr;
+    thr.prev_scores = out_scores;
+    rc = run_bf16_pass<D>(f, Kb, B, key0, sc.ends[l], thr, cap, 0, l, st);
     if (rc != RAGRAPH_OK) return rc;
-    key0 = ends[l];
+    if (g_prof_on) g_prof_have = l + 1;
+    rc = run_rescore<D>(f, Kn, B, cap, k, idx_base, l > 0, l == sc.nlev - 1, out_scores, out_idx, overflow, st);
+    if (rc != RAGRAPH_OK) return rc;
+    key0 = sc.ends[l];
   }
+  // overflowed queries (none on ordinary banks): exact fp32 scan on the device -- no host read-back
+  const int fix_grid = (int)(B < 256 ? B : 256);
+  hipLaunchKernelGGL(topk_overflow_fixup_kernel<D>, dim3((unsigned)fix_grid), dim3(256), 0, st, f.Qn, Kn, N, k, idx_base,
+                     overflow, f.overflow_list, overflow_idx, out_scores, out_idx);
+  RG_CHECK_LAUNCH("topk_cosine_filtered(overflow fallback)");
   return RAGRAPH_OK;
 }
 

@@ -121,7 +121,8 @@ def topk_cosine(q: torch.Tensor, keys_normalized: torch.Tensor, k: int, idx_base
 
 
 def keys_to_bf16(keys_normalized: torch.Tensor) -> torch.Tensor:
-    """bf16 copy of the bank for topk_cosine_filtered (rows zero-padded to a multiple of 128 + one row holding the largest rounding error; int16 storage)."""
+    """bf16 copy of the bank for topk_cosine_filtered, in MFMA fragment order (csrc/filter_common.h): rows zero-padded to
+    a multiple of 256 + one row holding the largest rounding error; int16 storage, 2 D bytes per key."""
     L = _ready()
     kn = _f32c(keys_normalized, "keys_to_bf16.keys")
     rows = L.ragraph_keys_bf16_rows(kn.shape[0])
@@ -133,13 +134,10 @@ def keys_to_bf16(keys_normalized: torch.Tensor) -> torch.Tensor:
 
 def filter_helps(B: int, n_keys: int, D: int, k: int) -> bool:
     """True when the bf16-filtered exact top-k is the faster way to the same bits.  Measured on MI355X (ms, filtered vs
-    fp32 kernels, D = 256, k = 10): 16 queries x 1M keys 0.30 vs 0.32, 64 x 1M 0.33 vs 0.76, 256 x 1M 0.32 vs 1.54,
-    4096 x 1M 1.9 vs 16.0, 100k x 1M 41 vs 366; 1024 x 65536 0.23 vs 0.59.  One to a dozen
-    queries stay on the streaming fp32 kernel (1 x 1M: 0.21 vs 0.25), small banks on the tile kernel."""
+    fp32 kernels, D = 256, k = 10): see DESIGN.md section 4.0 (batch-size table).  Small score matrices stay on the
+    fp32 slab / tile kernels."""
     if os.environ.get("RAGRAPH_EXACT_FP32") == "1":
         return False
-    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-        return False  # the filtered call reads its overflow count back: not capturable, the fp32 kernels are
     if D not in (64, 128, 256) or k > 32:
         return False
     # small score matrices are cheaper materialised (the fp32 entry's slab rule: 64 x 65536: 81 vs 129 us filtered)
@@ -148,15 +146,18 @@ def filter_helps(B: int, n_keys: int, D: int, k: int) -> bool:
     if D == 64 and n_keys < 65536 and B * n_keys <= (1 << 26):  # (4096 x 16384 x 64: slab 228, filtered 317 us)
         return False
     # mid-sized banks pay off for larger batches only (8192 x 20000 x 256: 0.37 vs 1.07 ms; 545 x 20000: 0.22 vs 0.26)
-    return (n_keys >= 65536 and B >= 12) or (n_keys >= 16384 and B >= 2048)
+    return (n_keys >= 65536 and B >= FILTER_MIN_B) or (n_keys >= 16384 and B >= 2048)
+
+
+FILTER_MIN_B = int(os.environ.get("RAGRAPH_FILTER_MIN_B", "1"))  # banks of >= 64 k keys: filtered from this many queries
 
 
 def topk_cosine_filtered(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf16: torch.Tensor, k: int,
                          idx_base: int = 0, keys_packed: torch.Tensor | None = None):
-    """Exact top-k (same bits as topk_cosine) through the bf16 MFMA filter.  Returns (scores, idx, n_overflow): the few
-    queries whose candidate list overflowed (none on ordinary banks) are recomputed here with the fp32 kernel, so the
-    result is complete; `n_overflow` says how many there were.  Reading that count synchronises with the stream -- use
-    topk_cosine where a call must stay asynchronous (graph capture)."""
+    """Exact top-k (same bits as topk_cosine) through the bf16 MFMA filter.  Returns (scores, idx, overflow): `overflow`
+    is a 1-element int32 DEVICE tensor counting the queries whose candidate list overflowed (none on ordinary banks);
+    the call itself recomputed those rows with an exact fp32 scan on the device, so the result is complete and nothing
+    is read back: the call is asynchronous and HIP-graph capturable.  (`int(overflow)` synchronises.)"""
     L = _ready()
     q = _f32c(q, "topk_cosine_filtered.q")
     kn = _f32c(keys_normalized, "topk_cosine_filtered.keys")
@@ -173,24 +174,16 @@ def topk_cosine_filtered(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf
         kp = kpt.data_ptr()
     scores = torch.empty((B, k), dtype=torch.float32, device=q.device)
     idx = torch.empty((B, k), dtype=torch.int64, device=q.device)
-    overflow = torch.zeros(1, dtype=torch.int32, device=q.device)
-    overflow_idx = torch.empty(B, dtype=torch.int64, device=q.device)
+    overflow = torch.empty(1, dtype=torch.int32, device=q.device)
     nbytes = L.ragraph_topk_cosine_filtered_workspace_bytes(B, Nk, D, k)
     if nbytes == 0:
         raise RagraphNativeError(f"topk_cosine_filtered: unsupported shape B={B} N={Nk} D={D} k={k}")
     ws = _workspace(nbytes, q.device)
     N.check(L.ragraph_topk_cosine_filtered_f32(q.data_ptr(), B, kn.data_ptr(), kp, keys_bf16.data_ptr(), Nk, D, k, idx_base,
-                                               scores.data_ptr(), idx.data_ptr(), overflow.data_ptr(),
-                                               overflow_idx.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+                                               scores.data_ptr(), idx.data_ptr(), overflow.data_ptr(), None,
+                                               ws.data_ptr(), ws.numel(), _stream()),
             "topk_cosine_filtered")
-    n_over = int(overflow.item())
-    if n_over:
-        rows = overflow_idx[:n_over]
-        s2, i2 = topk_cosine(q.index_select(0, rows), kn, k, idx_base=idx_base,
-                             keys_packed=keys_packed if packed_keys_help(n_over, D, k) else None)
-        scores.index_copy_(0, rows, s2)
-        idx.index_copy_(0, rows, i2)
-    return scores, idx, n_over
+    return scores, idx, overflow
 
 
 from .kernels_index import KeyIndex  # noqa: E402,F401  (bank copies + dispatch to the fastest exact top-k)

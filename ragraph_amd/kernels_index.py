@@ -19,12 +19,30 @@ class KeyIndex:
         self.keys_normalized = keys_normalized
         self._packed = None
         self._bf16 = None
-        self._filter_off = False  # set when this bank defeats the filter (see topk)
+        self._filter_off = False  # set when this bank defeats the filter (see _poll_overflow)
+        self._pending = None      # (pinned word, event, batch) of the last filtered call's overflow count
+        self._host_word = self._event = None
+        self.overflowed_queries = 0
+
+    def _poll_overflow(self):
+        """The filtered call repairs overflowed rows on the device and reads nothing back; its count arrives here after
+        the fact (pinned host word + event, polled without waiting).  A bank of near-duplicates (thousands of keys within
+        the bf16 bound of a query's k-th best) sends its queries to the exact fallback scan: still exact, but once a
+        quarter of a sizeable batch goes that way the filter only adds cost -- this bank version stays on fp32."""
+        pend = self._pending
+        if pend is None or not pend[1].query():
+            return
+        n_over, B = int(pend[0][0]), pend[2]
+        self._pending = None
+        self.overflowed_queries += n_over
+        if B >= 64 and 4 * n_over > B:
+            self._filter_off = True
 
     def topk(self, q: torch.Tensor, k: int, idx_base: int = 0):
         ops, kn = self.ops, self.keys_normalized
         B, D = q.shape
         fhelps = getattr(ops, "filter_helps", None)
+        self._poll_overflow()
         if fhelps is not None and not self._filter_off and fhelps(B, kn.shape[0], D, k):
             if self._bf16 is None:
                 self._bf16 = ops.keys_to_bf16(kn)
@@ -35,12 +53,16 @@ class KeyIndex:
                 outs = [self.topk(q[b0:b0 + self.MAX_FILTERED_BATCH], k, idx_base)
                         for b0 in range(0, B, self.MAX_FILTERED_BATCH)]
                 return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
-            s, i, n_over = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base, keys_packed=self._packed)
-            # A bank of near-duplicates (thousands of keys within the bf16 bound of a query's k-th best) overflows the
-            # candidate lists, and every such row is recomputed with the fp32 kernels: still exact, but once a quarter
-            # of a sizeable batch goes that way the filter only adds its own cost -- this bank version stays on fp32.
-            if B >= 64 and 4 * n_over > B:
-                self._filter_off = True
+            s, i, over = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base, keys_packed=self._packed)
+            if self._pending is None and over.is_cuda and not torch.cuda.is_current_stream_capturing():
+                if self._host_word is None:
+                    self._host_word = torch.zeros(1, dtype=torch.int32).pin_memory()
+                    self._event = torch.cuda.Event()
+                self._host_word.copy_(over, non_blocking=True)
+                self._event.record()
+                self._pending = (self._host_word, self._event, B)
+            elif not over.is_cuda:  # (the CPU tests' oracle shim)
+                self.overflowed_queries += int(over)
             return s, i
         helps = getattr(ops, "packed_keys_help", None)
         if helps is not None and helps(B, D, k):

@@ -326,8 +326,7 @@ def test_graph_flavour_batched_equals_per_graph(dev):
 def test_forward_is_hip_graph_capturable(dev):
     """The C ABI allocates nothing and never synchronises, so a whole small forward (a dozen launches, launch-bound at
     the reference's scale) can be captured once into a HIP graph and replayed.  The bank is large enough for the
-    bf16-filtered retrieval, whose wrapper reads an overflow count back: the dispatch notices the capture and stays on
-    the fp32 kernels there -- eager (filtered) and captured (fp32) results are the same bits."""
+    bf16-filtered retrieval, which repairs overflowed rows on the device and reads nothing back: it is captured too."""
     from ragraph_amd.data import DataLoader, synthetic_tu_dataset
     from ragraph_amd.preprompt import PrePrompt
     from ragraph_amd.RAGraph import RAGraph
@@ -351,9 +350,17 @@ def test_forward_is_hip_graph_capturable(dev):
             for _ in range(2):
                 model(feats, adj)  # warm-up on the capture stream (workspace, LDS attributes)
         torch.cuda.current_stream().wait_stream(s)
+        from ragraph_amd import kernels as K
+        calls = []
+        orig = K.topk_cosine_filtered
+        K.topk_cosine_filtered = lambda *a, **kw: (calls.append(1), orig(*a, **kw))[1]
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            captured = model(feats, adj)
+        try:
+            with torch.cuda.graph(graph):
+                captured = model(feats, adj)
+        finally:
+            K.topk_cosine_filtered = orig
+        assert calls, "the captured forward must contain the bf16-filtered retrieval"
         feats.mul_(1.0)  # same static input buffers
         graph.replay()
         torch.cuda.synchronize()
