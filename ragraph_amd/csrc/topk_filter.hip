@@ -730,6 +730,70 @@ __global__ void __launch_bounds__(128) topk_rescore_coop_kernel(const float* __r
 #undef RG_RESCORE
 }
 
+// The exact fallback for a query whose candidate list overflowed (thousands of keys within eps of the k-th best:
+// near-duplicate banks, zero queries), ON THE DEVICE: one workgroup scans the whole bank for it with the fp32 chain
+// (coop_scores: 64 rows per step through an LDS tile), four waves a quarter of the keys each with a register-resident
+// sorted list (lane p = entry p), merged at the end.  No host read-back, so the call stays asynchronous and HIP-graph
+// capturable; a bank that sends many queries here is slow (one full fp32 scan per query and workgroup), which KeyIndex
+// notices from the count after the fact and stops filtering that bank.  All 256 threads of the workgroup must call.
+template <int D>
+__device__ __forceinline__ void exact_scan_query(const float4* qs /* LDS: the query row */, const float* __restrict__ Kn,
+                                                 int64_t N, int k, int64_t idx_base, float (*tile)[64 * RESCORE_LD],
+                                                 float (*ps)[32], int64_t (*pi)[32], float* __restrict__ out_s,
+                                                 int64_t* __restrict__ out_i) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float es = RG_NEG_INF;  // lane p < k: entry p of this wave's sorted list
+  int ei = INT_MAX;
+  float kth_s = RG_NEG_INF;
+  int kth_i = INT_MAX;
+  for (int64_t base = (int64_t)w * 64; base < N; base += 256) {
+    const int key = base + lane < N ? (int)(base + lane) : -1;
+    const float sc = coop_scores<D>(qs, Kn, key, lane, tile[w]);
+    unsigned long long pend = __ballot(key >= 0 && cand_better(sc, key, kth_s, kth_i));
+    while (pend) {
+      const int src = __ffsll((long long)pend) - 1;
+      pend &= pend - 1;
+      const float s = __shfl(sc, src);
+      const int id = __shfl(key, src);
+      const unsigned long long ahead = __ballot(lane < k && cand_better(es, ei, s, id));
+      const int pos = __popcll(ahead);
+      const float us = __shfl_up(es, 1);
+      const int ui = __shfl_up(ei, 1);
+      if (pos < k) {
+        if (lane == pos) {
+          es = s;
+          ei = id;
+        } else if (lane > pos && lane < k) {
+          es = us;
+          ei = ui;
+        }
+      }
+      kth_s = __shfl(es, k - 1);
+      kth_i = __shfl(ei, k - 1);
+      pend &= __ballot(key >= 0 && cand_better(sc, key, kth_s, kth_i));
+    }
+  }
+  if (lane < 32) {
+    ps[w][lane] = lane < k ? es : RG_NEG_INF;
+    pi[w][lane] = (lane < k && ei != INT_MAX) ? (int64_t)ei : INT64_MAX;
+  }
+  __syncthreads();
+  if (w == 0) {  // 4 k <= 128 partial winners: two per lane
+    float s2[2];
+    int id2[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = lane + 64 * u;
+      const bool have = e < 4 * k;
+      s2[u] = have ? ps[e / k][e % k] : RG_NEG_INF;
+      const int64_t pv = have ? pi[e / k][e % k] : INT64_MAX;
+      id2[u] = pv >= INT_MAX ? INT_MAX : (int)pv;
+    }
+    wave_select<2>(s2, id2, k, lane, idx_base, out_s, out_i);
+  }
+  __syncthreads();
+}
+
 // Small batches: one WORKGROUP per query.  The narrow kernel's wave walks its lane's candidates one after the other,
 // each a latency-bound chain of row loads, and a few hundred waves do not hide that; here four waves take a quarter of
 // the list each, leave their top-k in LDS, and wave 0 merges the four (and the previous level's winners, which ride
@@ -822,31 +886,40 @@ __global__ void __launch_bounds__(256) topk_rescore_wide_kernel(const float* __r
   }
 }
 
-// Second half of the sliced rescoring: one wave per query merges the S slices' winners (S k <= 256: four per lane) with
-// the previous level's, does the level's bookkeeping (overflow flag / list, empty list for the next level) and writes
-// the running result.
-__global__ void __launch_bounds__(256) topk_rescore_merge_kernel(int* __restrict__ count, int64_t B, int S, int cap, int k,
+// Second half of the sliced rescoring, one workgroup per query: wave 0 merges the S slices' winners (S k <= 256: four per
+// lane) with the previous level's, does the level's bookkeeping (overflow flag / count, empty list for the next level)
+// and writes the running result; a query that overflowed its list gets the exact scan right here on the final level,
+// so these calls need no separate fallback launch.
+template <int D>
+__global__ void __launch_bounds__(256) topk_rescore_merge_kernel(const float* __restrict__ Qn, const float* __restrict__ Kn,
+                                                                 int64_t N, int* __restrict__ count, int S, int cap, int k,
                                                                  int64_t idx_base, const float* prev_s, const int64_t* prev_i,
                                                                  int final_level, float* out_s, int64_t* out_i,
-                                                                 int* __restrict__ overflow, int* __restrict__ overflow_list,
-                                                                 unsigned char* __restrict__ flag,
+                                                                 int* __restrict__ overflow, unsigned char* __restrict__ flag,
                                                                  const float* __restrict__ part_s,
                                                                  const int* __restrict__ part_i) {
-  const int lane = threadIdx.x & 63;
-  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (b >= B) return;  // whole wave
+  __shared__ float4 qs[D / 4];
+  __shared__ __attribute__((aligned(16))) float tile[4][64 * RESCORE_LD];
+  __shared__ float ps[4][32];
+  __shared__ int64_t pi[4][32];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t b = blockIdx.x;
   const int n = count[b];
   const bool over = flag[b] != 0 || n > cap;
+  if (final_level && over) {  // (block-uniform)
+    if (threadIdx.x < D / 4) qs[threadIdx.x] = reinterpret_cast<const float4*>(Qn + b * D)[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      count[b] = 0;
+      atomicAdd(overflow, 1);
+    }
+    exact_scan_query<D>(qs, Kn, N, k, idx_base, tile, ps, pi, out_s + b * k, out_i + b * k);
+    return;
+  }
+  if (w != 0) return;
   if (lane == 0 && n >= 0) {
     count[b] = 0;
-    if (final_level) {
-      if (over) {
-        const int pos = atomicAdd(overflow, 1);
-        overflow_list[pos] = (int)b;
-      }
-    } else if (over) {
-      flag[b] = 1;
-    }
+    if (over) flag[b] = 1;
   }
   float s[5];
   int id[5];
@@ -867,13 +940,9 @@ __global__ void __launch_bounds__(256) topk_rescore_merge_kernel(int* __restrict
   wave_select<5>(s, id, k, lane, final_level ? idx_base : 0, out_s + b * k, out_i + b * k);
 }
 
-// The exact fallback for queries whose candidate list overflowed (thousands of keys within eps of the k-th best:
-// near-duplicate banks, zero queries), ON THE DEVICE: the final rescoring kernel has listed them, and this launch -- a
-// fixed grid that finds an empty list on ordinary banks and returns -- scans the whole bank for each with the fp32 chain
-// (coop_scores: 64 rows per step through an LDS tile), one workgroup per listed query, four waves a quarter of the
-// keys each with a register-resident sorted list (lane p = entry p), merged at the end.  No host read-back, so the call
-// stays asynchronous and HIP-graph capturable; a bank that sends many queries here is slow (one full fp32 scan per
-// query and workgroup), which KeyIndex notices from the count after the fact and stops filtering that bank.
+// Large batches (the one-wave-per-query rescoring kernels): the final level has listed the overflowed queries, and this
+// launch -- a fixed grid that finds an empty list on ordinary banks and returns -- runs exact_scan_query for each.
+// (Below 2048 queries the workgroup-per-query rescoring kernels call it themselves and this launch is not made.)
 template <int D>
 __global__ void __launch_bounds__(256) topk_overflow_fixup_kernel(const float* __restrict__ Qn, const float* __restrict__ Kn,
                                                                   int64_t N, int k, int64_t idx_base,
@@ -885,63 +954,13 @@ __global__ void __launch_bounds__(256) topk_overflow_fixup_kernel(const float* _
   __shared__ __attribute__((aligned(16))) float tile[4][64 * RESCORE_LD];
   __shared__ float ps[4][32];
   __shared__ int64_t pi[4][32];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int n_over = *overflow;
   for (int o = blockIdx.x; o < n_over; o += gridDim.x) {
     const int64_t b = overflow_list[o];
     if (overflow_idx_out && threadIdx.x == 0) overflow_idx_out[o] = b;
     if (threadIdx.x < D / 4) qs[threadIdx.x] = reinterpret_cast<const float4*>(Qn + b * D)[threadIdx.x];
     __syncthreads();
-    float es = RG_NEG_INF;  // lane p < k: entry p of this wave's sorted list
-    int ei = INT_MAX;
-    float kth_s = RG_NEG_INF;
-    int kth_i = INT_MAX;
-    for (int64_t base = (int64_t)w * 64; base < N; base += 256) {
-      const int key = base + lane < N ? (int)(base + lane) : -1;
-      const float sc = coop_scores<D>(qs, Kn, key, lane, tile[w]);
-      unsigned long long pend = __ballot(key >= 0 && cand_better(sc, key, kth_s, kth_i));
-      while (pend) {
-        const int src = __ffsll((long long)pend) - 1;
-        pend &= pend - 1;
-        const float s = __shfl(sc, src);
-        const int id = __shfl(key, src);
-        const unsigned long long ahead = __ballot(lane < k && cand_better(es, ei, s, id));
-        const int pos = __popcll(ahead);
-        const float us = __shfl_up(es, 1);
-        const int ui = __shfl_up(ei, 1);
-        if (pos < k) {
-          if (lane == pos) {
-            es = s;
-            ei = id;
-          } else if (lane > pos && lane < k) {
-            es = us;
-            ei = ui;
-          }
-        }
-        kth_s = __shfl(es, k - 1);
-        kth_i = __shfl(ei, k - 1);
-        pend &= __ballot(key >= 0 && cand_better(sc, key, kth_s, kth_i));
-      }
-    }
-    if (lane < 32) {
-      ps[w][lane] = lane < k ? es : RG_NEG_INF;
-      pi[w][lane] = (lane < k && ei != INT_MAX) ? (int64_t)ei : INT64_MAX;
-    }
-    __syncthreads();
-    if (w == 0) {  // 4 k <= 128 partial winners: two per lane
-      float s2[2];
-      int id2[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int e = lane + 64 * u;
-        const bool have = e < 4 * k;
-        s2[u] = have ? ps[e / k][e % k] : RG_NEG_INF;
-        const int64_t pv = have ? pi[e / k][e % k] : INT64_MAX;
-        id2[u] = pv >= INT_MAX ? INT_MAX : (int)pv;
-      }
-      wave_select<2>(s2, id2, k, lane, idx_base, out_s + b * k, out_i + b * k);
-    }
-    __syncthreads();
+    exact_scan_query<D>(qs, Kn, N, k, idx_base, tile, ps, pi, out_s + b * k, out_i + b * k);
   }
 }
 
@@ -1092,7 +1111,10 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k) {
     if (bound) {
       nA = filter_round_up((int64_t)((double)n0 * eff_div));
       if (nA * 4 > N) break;
-      first = 35.0 + (double)nA * 2.0 * D / 3.0e6 + tiles * (double)(nA / stage_keys) * 3.1 / 256.0;
+      if (B <= 256)  // direct kernel: the prefix streams at ~5 TB/s (8.7 / 22 / 40 us for 54 k / 216 k / 216 k keys x 1 / 16 / 256 queries)
+        first = 6.0 + (double)nA * 2.0 * D / 5.0e6 * (1.0 + (double)B / 320.0);
+      else
+        first = 35.0 + (double)nA * 2.0 * D / 3.0e6 + tiles * (double)(nA / stage_keys) * 3.1 / 256.0;
     } else {
       if (B * n0 > FILTER_SLAB_MAX_SCORES) break;
       first = 30.0 + (double)B * (double)n0 * (2.0 * D / 1.0e8 + 4.0 / 3.0e6);
@@ -1101,7 +1123,9 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k) {
       if (force_L > 0 && L != force_L) continue;
       const double r = pow((double)N / (double)n0, 1.0 / L);
       if (1.3 * k * r > cap / 2 && !(force_n0 > 0 && force_L > 0)) continue;
-      const double cost = first + L * (60.0 + (double)B * 1.3 * k * r * 0.4e-3);
+      // a level: launches + the rescoring kernels' latency floor, plus ~0.4 - 0.5 ns per candidate (1 KB row gather each)
+      const double cost = B <= 256 ? first + L * (25.0 + (double)B * 1.3 * k * r * 0.5e-3) + (L - 1) * 15.0  /* (a second pass start-up) */
+                                   : first + L * (60.0 + (double)B * 1.3 * k * r * 0.4e-3);
       if (cost < best) {
         best = cost;
         best_n0 = n0;
@@ -1315,8 +1339,9 @@ static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64
 
 // Exact rescoring of a level's candidates (+ merge with the running result when `merge`) and canonical selection.
 template <int D>
-static int run_rescore(const FilterWs& f, const float* Kn, int64_t B, int cap, int k, int64_t idx_base, int merge,
-                       int final_level, float* out_scores, int64_t* out_idx, int* overflow, hipStream_t st) {
+static int run_rescore(const FilterWs& f, const float* Kn, int64_t N, int64_t B, int cap, int k, int64_t idx_base, int merge,
+                       int final_level, float* out_scores, int64_t* out_idx, int* overflow, int* fallback_done,
+                       hipStream_t st) {
   const float* ps = merge ? out_scores : nullptr;
   const int64_t* pi = merge ? out_idx : nullptr;
   static const int64_t wide_max_b = [] {  // RAGRAPH_RESCORE_WIDE_BELOW: A/B of the crossover
@@ -1336,8 +1361,9 @@ static int run_rescore(const FilterWs& f, const float* Kn, int64_t B, int cap, i
                        f.cand, B, cap, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list,
                        f.flag, f.part_s, f.part_i);
     RG_CHECK_LAUNCH("topk_cosine_filtered(rescore slices)");
-    hipLaunchKernelGGL(topk_rescore_merge_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, st, f.count, B, S, cap, k, idx_base,
-                       ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag, f.part_s, f.part_i);
+    hipLaunchKernelGGL(topk_rescore_merge_kernel<D>, dim3((unsigned)B), dim3(256), 0, st, f.Qn, Kn, N, f.count, S, cap, k,
+                       idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.flag, f.part_s, f.part_i);
+    *fallback_done = 1;
   } else if (B < wide_max_b)  // too few queries to fill the chip with one wave each
     hipLaunchKernelGGL((topk_rescore_wide_kernel<D, false>), dim3((unsigned)B), dim3(256), 0, st, f.Qn, Kn, f.count, f.cand, B,
                        cap, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag,
@@ -1383,7 +1409,7 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   thr.k = k;
   thr.ngroups = k;
   thr.ablate = ablate;
-  int rc = RAGRAPH_OK;
+  int rc = RAGRAPH_OK, fallback_done = 0;
   // the first bound: group maxima of a bf16 pass over a prefix, or an exact level 0 over the first n0 keys (out_scores /
   // out_idx hold every level's running result, local indices)
   if (bound) {
@@ -1409,11 +1435,14 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
     rc = run_bf16_pass<D>(f, Kb, B, key0, sc.ends[l], thr, cap, 0, l, st);
     if (rc != RAGRAPH_OK) return rc;
     if (g_prof_on) g_prof_have = l + 1;
-    rc = run_rescore<D>(f, Kn, B, cap, k, idx_base, l > 0, l == sc.nlev - 1, out_scores, out_idx, overflow, st);
+    rc = run_rescore<D>(f, Kn, N, B, cap, k, idx_base, l > 0, l == sc.nlev - 1, out_scores, out_idx, overflow,
+                        &fallback_done, st);
     if (rc != RAGRAPH_OK) return rc;
     key0 = sc.ends[l];
   }
-  // overflowed queries (none on ordinary banks): exact fp32 scan on the device -- no host read-back
+  // overflowed queries (none on ordinary banks): exact fp32 scan on the device -- no host read-back (the sliced
+  // rescoring of a handful of queries has done it inside its merge launch)
+  if (fallback_done) return RAGRAPH_OK;
   const int fix_grid = (int)(B < 256 ? B : 256);
   hipLaunchKernelGGL(topk_overflow_fixup_kernel<D>, dim3((unsigned)fix_grid), dim3(256), 0, st, f.Qn, Kn, N, k, idx_base,
                      overflow, f.overflow_list, overflow_idx, out_scores, out_idx);

@@ -30,7 +30,9 @@ class KeyIndex:
         the bf16 bound of a query's k-th best) sends its queries to the exact fallback scan: still exact, but once a
         quarter of a sizeable batch goes that way the filter only adds cost -- this bank version stays on fp32."""
         pend = self._pending
-        if pend is None or not pend[1].query():
+        if pend is None or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+            return  # (an event query is not a capturable call)
+        if not pend[1].query():
             return
         n_over, B = int(pend[0][0]), pend[2]
         self._pending = None
