@@ -2,24 +2,32 @@
 """bench.py -- RAGraph retrieve-and-propagate hot path on MI355X.
 
 Workload (BASELINE.json configs[1]): RAGraph_node forward on a synthetic 100k-node graph (F=128, mean degree ~10)
-against a 1M-key x 256-d bank, k=10, C=3.  One step = one full forward: GCN encode -> fused cosine+top-k retrieval of
+against a 1M-key x 256-d bank, k=10, C=3.  One step = one full forward: GCN encode -> exact cosine top-k retrieval of
 every node against the bank -> winners' value-sum / label-mean -> 3-hop propagation -> fusion + decoder + softmax-mix.
-value = retrieved queries (= nodes) per second, whole job.
+value = retrieved queries (= nodes) per second, whole job; the timed region is exactly `--steps` forwards.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the 1M-key bank is row-sharded across the ranks (strong
-scaling on the metric's own bank); every rank scores all queries against its shard, one RCCL all_gather of the
-per-shard top-k + canonical merge; values / labels are replicated (1 GB) so the winners' sums are local
-(ragraph_amd/sharded.py).  The cheap GNN part is replicated.
+N > 1 (one rank per GPU; `python bench.py --gpus N` starts the ranks itself when no launcher did): strong scaling on the
+metric's own 1M-key bank.  Default layout = north_star's: the KEY BANK is row-sharded, every rank scores all queries
+against its shard with thresholds sharpened by two tiny exchanges (an all_reduce(MAX) of the per-query first bound, an
+all_gather of each rank's best few scores per level), then ONE all_gather of the per-shard top-k and a canonical merge
+(ragraph_amd/sharded.py); values / labels are replicated (1 GB), the cheap GNN part runs on every rank.  The other
+layout (bank replicated, QUERY batch split, no data-path collective) is timed right after and reported as
+`query_sharded`; `--shard queries` makes it the headline instead.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel (the fused
-top-k: fp32-MFMA-bound at this batch size) and, at N = 1, `cpu_baseline` (the torch-CPU port of the reference's op
-chain, oracle/ref_torch.py, on a bounded sample).
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` for the dominant kernel (the bf16 MFMA
+filter of the exact top-k) and, at N = 1, next to the timed region: `retrieval_small_batch` (the reference's real batch
+sizes, B = 1 / 16 / 256 / 4096, HBM-bound up to a few hundred queries), `exact_fp32` (the same step on the fp32 MFMA
+kernels alone), `gnn_fwd_nodes_per_s`, and `cpu_baseline` (the torch-CPU port of the reference's op chain,
+oracle/ref_torch.py: 3 warm-ups + 5 repetitions of a 1024-query slab, median, plus the 'fair' pre-normalised-bank row).
 """
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -29,9 +37,10 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: ~2.5 PF dense = 1024 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz
-HBM_PEAK_GBS = 8000.0          # spec; ~6300 achievable
+HBM_PEAK_GBS = 8000.0           # spec; ~6300 achievable
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
 
 
 def parse():
@@ -41,22 +50,23 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nodes", type=int, default=100_000)
     ap.add_argument("--feat", type=int, default=128)
-    ap.add_argument("--bank", type=int, default=1_000_000)
+    ap.add_argument("--bank", type=int, default=1_000_000,
+                    help="key-bank rows (BASELINE configs[1]: 1 000 000; configs[3] = 8 000 000 with --gpus 8)")
     ap.add_argument("--dim", type=int, default=256)
     ap.add_argument("--classes", type=int, default=3)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=2048, help="queries timed on the CPU baseline")
-    ap.add_argument("--small-batch", action="store_true", help="also time the HBM-bound B<=16 retrieval regime")
-    ap.add_argument("--shard", choices=("queries", "keys"), default="queries",
-                    help="N > 1: split the query batch over the GPUs with the bank replicated (default; no data-path "
-                         "collective, one all_gather of the [n, C] outputs), or row-shard the key bank with an RCCL "
-                         "all_gather of the per-shard top-k (the layout for banks that should not be replicated)")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed region (profiling runs)")
+    ap.add_argument("--cpu-slab", type=int, default=1024, help="queries per CPU-baseline repetition (one slab)")
+    ap.add_argument("--shard", choices=("keys", "queries"), default="keys",
+                    help="N > 1: row-shard the key bank (north_star's layout; default) or split the query batch over "
+                         "the GPUs with the bank replicated")
     ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="G",
-                    help="single process: time what rank 0 of a G-GPU job would compute (no collectives); an estimate "
-                         "of the per-rank step for DESIGN.md, never the bench line of a real multi-GPU run")
+                    help="single process: time what rank 0 of a G-GPU job would compute (collectives replaced by their "
+                         "local part); an estimate of the per-rank step for DESIGN.md, never the bench line of a real "
+                         "multi-GPU run")
     ap.add_argument("--exact-fp32", action="store_true",
-                    help="retrieve with the fp32 MFMA kernel only (no bf16 filter): the previous headline path")
+                    help="retrieve with the fp32 MFMA kernel only (no bf16 filter) in the timed region")
     return ap.parse_args()
 
 
@@ -83,14 +93,17 @@ class EventTimer:
     def mean_ms(self):
         return sum(a.elapsed_time(b) for a, b in self.events) / max(len(self.events), 1)
 
+    def reset(self):
+        self.events = []
 
-def build_workload(args, dev, rank, world, force_dist=False):
+
+def build_workload(args, dev, rank, world, shard, force_dist=False):
     from ragraph_amd import kernels as K
     from ragraph_amd.data import synthetic_bank, synthetic_big_graph
     from ragraph_amd.graph import CSRGraph
     from ragraph_amd.preprompt import PrePrompt
     from ragraph_amd.RAGraph import RAGraph
-    from ragraph_amd.sharded import ShardedToyGraphBase, shard_bounds
+    from ragraph_amd.sharded import QueryShard, ShardedToyGraphBase, shard_bounds
 
     torch.manual_seed(0)
     pre = PrePrompt(args.feat, args.dim, "prelu", 1, 0.3).to(dev)
@@ -103,38 +116,36 @@ def build_workload(args, dev, rank, world, force_dist=False):
     Kb, Vb, Lb = synthetic_bank(args.bank, args.dim, args.classes, device=dev)
     Kb = K.normalize_rows(Kb)  # stored unit-norm, as the reference stores keys (ToyGraphBase.py:109)
     emu = args.emulate_rank_of
-    if emu > 1 and args.shard == "queries":
-        class _Slice:  # rank 0 of `emu`, no process group
-            world, rank, collective = emu, 0, False
+    G = emu if emu > 1 else world
+    if G > 1 or force_dist:
+        if shard == "queries":
+            if emu > 1:
+                class _Slice:  # rank 0 of `emu`, no process group
+                    world, rank, collective = emu, 0, False
 
-            def bounds(self, B):
-                return shard_bounds(B, emu, 0)
+                    def bounds(self, B):
+                        return shard_bounds(B, emu, 0)
 
-            def gather_rows(self, local, B):
-                return local
-        model.query_shard = _Slice()
-        model.toy_graph_base.set_resources(Kb, Vb, Lb)
-        n_local = args.bank
-    elif emu > 1:
-        lo, hi = shard_bounds(args.bank, emu, 0)
-        model.toy_graph_base = ShardedToyGraphBase(Kb[lo:hi].contiguous(), Vb, Lb, lo, args.k, values_replicated=True)
-        n_local = hi - lo
-    elif (world > 1 or force_dist) and args.shard == "queries":
-        from ragraph_amd.sharded import QueryShard
-        model.query_shard = QueryShard(force_collectives=force_dist)
-        model.toy_graph_base.set_resources(Kb, Vb, Lb)
-        n_local = args.bank
-    elif world > 1 or force_dist:
-        lo, hi = shard_bounds(args.bank, world, rank)
-        # keys row-sharded; values / labels replicated (1 GB of 288 GB) so the top-k all_gather is the only collective
-        model.toy_graph_base = ShardedToyGraphBase(Kb[lo:hi].contiguous(), Vb, Lb, lo, args.k,
-                                                   force_collectives=force_dist, values_replicated=True)
-        del Kb
-        n_local = hi - lo
+                    def gather_rows(self, local, B):
+                        return local
+                model.query_shard = _Slice()
+            else:
+                model.query_shard = QueryShard(force_collectives=force_dist)
+            model.toy_graph_base.set_resources(Kb, Vb, Lb)
+            n_local = args.bank
+        else:
+            r = 0 if emu > 1 else rank
+            lo, hi = shard_bounds(args.bank, G, r)
+            # keys row-sharded; values / labels replicated (1 GB of 288 GB): the winners' sums are local gathers
+            model.toy_graph_base = ShardedToyGraphBase(Kb[lo:hi].contiguous(), Vb, Lb, lo, args.k,
+                                                       force_collectives=force_dist, values_replicated=True,
+                                                       emulate_world=emu if emu > 1 else 0)
+            n_local = hi - lo
     else:
         model.toy_graph_base.set_resources(Kb, Vb, Lb)
         _ = model.toy_graph_base.keys_normalized
         n_local = args.bank
+    del Kb
     torch.cuda.synchronize()
     return model, feats, adj, n_local
 
@@ -156,16 +167,20 @@ def gnn_only_rate(model, feats, adj, steps):
 
 
 def small_batch_rates(tgb, dim, k, dev):
-    """Retrieval alone against batch size through the product dispatch (KeyIndex: fp32 streaming kernel for a handful of
-    queries -- graph classification sends ONE per forward, the HBM-bound regime --, the bf16-filtered exact path from a
-    dozen up): ms per call and bank passes per second (the fp32 bank's bytes / time, whichever copy was streamed)."""
+    """Retrieval alone at the reference's real batch sizes through the product dispatch (KeyIndex): graph
+    classification sends ONE query per forward, RAGraph_node a few hundred, the edge flavour slabs of 4096.  Up to a few
+    hundred queries a call is bound by one pass over the bf16 bank copy: `streamed_GB` = the bytes the call streams from
+    HBM (the bf16 copy + the prefix its bound pass reads), `frac_hbm_peak` = that / time / 8 TB/s;
+    `algorithmic_GBps` = SURVEY section 8(d)'s byte model (the fp32 bank once, 4 N D) / time."""
     from ragraph_amd import kernels as K
 
     out = {}
     kn = tgb.keys_normalized
     index = tgb._index if tgb._index is not None else K.KeyIndex(kn)
-    for B in (1, 16, 64, 256, 4096):
-        q = torch.randn(B, dim, device=dev)
+    n_keys = kn.shape[0]
+    L = K.N.lib()
+    for B in (1, 16, 256, 4096):
+        q = torch.randn(B, dim, device=dev, generator=torch.Generator(device=dev).manual_seed(4321 + B))
         for _ in range(3):
             index.topk(q, k)
         torch.cuda.synchronize()
@@ -177,60 +192,120 @@ def small_batch_rates(tgb, dim, k, dev):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        gbs = kn.numel() * 4 / ms / 1e6
-        out[f"B{B}"] = {"ms": round(ms, 4), "queries_per_s": round(B / ms * 1e3, 1), "bank_GBps": round(gbs, 1),
-                        "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
-                        "path": "bf16-filtered" if K.filter_helps(B, kn.shape[0], dim, k) else "fp32"}
+        filtered = K.filter_helps(B, n_keys, dim, k)
+        if filtered:
+            plan = (ctypes.c_int64 * 7)()
+            L.ragraph_topk_cosine_filtered_plan(B, n_keys, dim, k, plan)
+            streamed = (n_keys + int(plan[6])) * dim * 2 + B * dim * 4
+        else:
+            streamed = n_keys * dim * 4 + B * dim * 4
+        gbs = streamed / ms / 1e6
+        flops = 2.0 * B * n_keys * dim
+        rec = {"ms": round(ms, 4), "queries_per_s": round(B / ms * 1e3, 1), "path": "bf16-filtered" if filtered else "fp32",
+               "streamed_GB": round(streamed / 1e9, 4), "GBps_streamed": round(gbs, 1),
+               "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+               "algorithmic_GBps": round(n_keys * dim * 4 / ms / 1e6, 1), "TFLOPs": round(flops / ms / 1e9, 1)}
+        # which roofline binds this batch: one pass over the streamed copy, or the score matrix on the bf16 cores
+        t_hbm, t_mfma = streamed / (HBM_PEAK_GBS * 1e9), flops / (BF16_MFMA_PEAK_TFLOPS * 1e12)
+        rec["bound"] = "hbm" if t_hbm >= t_mfma else "mfma"
+        rec["frac_of_bound"] = round(max(t_hbm, t_mfma) / (ms * 1e-3), 4)
+        out[f"B{B}"] = rec
     return out
 
 
 def cpu_baseline(args, model, feats, adj):
-    """The reference's op chain on the host cores (oracle/ref_torch.py): GNN part on the whole graph (sparse CSR: the
-    reference's dense adjacency would be 40 GB), retrieval on a bounded sample of the queries with the bank
-    re-normalised per slab as the reference does; extrapolated to the full forward."""
+    """The reference's op chain on the host cores (oracle/ref_torch.py), BASELINE.md section 3: GNN part on the whole
+    graph (sparse CSR: the reference's dense adjacency would be 40 GB); retrieval exactly as the reference computes it
+    (bank re-normalised on every call, the B x N slab materialised, torch.topk, gathers) on ONE slab of 1024 queries --
+    3 warm-ups + 5 timed repetitions, median -- extrapolated to the full forward; and the 'fair' row with the bank
+    normalised once (1 warm-up + 3 repetitions)."""
     from oracle import ref_torch
 
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     n = feats.shape[0]
-    sample = min(args.cpu_sample, n)
+    slab = min(args.cpu_slab, n)
     conv = model.pretrain_model.gcn.convs[0]
     p = {"W": conv.fc.weight.detach().cpu(), "bias": conv.bias.detach().cpu(), "alpha": conv.act.weight.detach().cpu()}
     tgb = model.toy_graph_base
     keys, vals, labs = tgb.resource_keys.cpu(), tgb.resource_values.cpu(), tgb.resource_labels.cpu()
     adj_cpu = torch.sparse_csr_tensor(adj.rowptr.cpu(), adj.col.cpu().long(), adj.val.cpu(), (n, n))
     X = feats.cpu()
+
+    def timed(fn, warm, reps):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts), ts
+
     with torch.no_grad():
         t0 = time.perf_counter()
         h = ref_torch.gcn_layer(X, adj_cpu, p["W"], p["bias"], p["alpha"])
         ref_torch.propagate(adj_cpu, h, model.query_graph_hop)
         t_gnn = time.perf_counter() - t0
-        slab = 512
-        ref_torch.retrieve(h[:slab], keys, vals, labs, args.k, slab=slab)  # warm-up slab (page-in, thread pool)
-        t0 = time.perf_counter()
-        ref_torch.retrieve(h[:sample], keys, vals, labs, args.k, slab=slab)
-        t_ret = time.perf_counter() - t0
-    est_full = t_gnn + t_ret * (n / sample)
+        q = h[:slab].contiguous()
+        t_ref, ts_ref = timed(lambda: ref_torch.retrieve(q, keys, vals, labs, args.k, slab=slab), 3, 5)
+        kn = torch.nn.functional.normalize(keys, p=2, dim=-1)
+
+        def fair():
+            S = torch.matmul(torch.nn.functional.normalize(q, p=2, dim=-1), kn.t())
+            _, idx = torch.topk(S, args.k, largest=True, sorted=True)
+            return vals[idx].sum(dim=1), labs[idx].mean(dim=1)
+        t_fair, ts_fair = timed(fair, 1, 3)
+    est_full = t_gnn + t_ref * (n / slab)
+    est_fair = t_gnn + t_fair * (n / slab)
     return {"value": round(n / est_full, 2), "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": f"GNN encode+{model.query_graph_hop}-hop on all {n} nodes ({t_gnn:.2f}s, torch sparse CSR) + retrieval "
-                      f"of {sample} of the {n} queries in slabs of {slab} vs the full {keys.shape[0]}x{keys.shape[1]} bank "
-                      f"({t_ret:.2f}s, bank re-normalised per slab as the reference does), extrapolated to {n} queries",
-            "retrieval_only_queries_per_s": round(sample / t_ret, 2)}
+            "sample": f"GNN encode+{model.query_graph_hop}-hop on all {n} nodes ({t_gnn:.2f}s, torch sparse CSR) + retrieval of "
+                      f"one slab of {slab} of the {n} queries vs the full {keys.shape[0]}x{keys.shape[1]} bank, 3 warm-ups + 5 "
+                      f"repetitions, median {t_ref:.2f}s (bank re-normalised per call as the reference does), extrapolated "
+                      f"to {n} queries",
+            "retrieval_only_queries_per_s": round(slab / t_ref, 2),
+            "retrieval_rep_seconds": [round(t, 3) for t in ts_ref],
+            "fair": {"value": round(n / est_fair, 2), "retrieval_only_queries_per_s": round(slab / t_fair, 2),
+                     "rep_seconds": [round(t, 3) for t in ts_fair],
+                     "note": "bank normalised once (ref_torch.retrieve(renormalize_bank=False) arithmetic), 1 warm-up + 3 "
+                             "repetitions, median: what the reference would do without its redundant per-call "
+                             "F.normalize(resource_keys)"}}
+
+
+def timed_steps(step, steps, world, dev, on_step=None):
+    """Exactly `steps` forwards between barrier + synchronize on both sides; MAX over ranks."""
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step()
+        if on_step:
+            on_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, out
 
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torchrun job (nothing in this
         # process has touched the GPU yet -- never re-exec after it has) and exit with its code.
-        import subprocess
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29511"),
                os.path.abspath(__file__), *sys.argv[1:]]
         raise SystemExit(subprocess.run(cmd).returncode)
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
@@ -246,11 +321,12 @@ def main():
 
     from ragraph_amd import kernels as K
 
+    real_filter_helps = K.filter_helps
     if args.exact_fp32:
         K.filter_helps = lambda *a, **kw: False
     topk_timer = EventTimer(K, "topk_cosine")             # fp32 kernel (the whole retrieval with --exact-fp32)
-    filt_timer = EventTimer(K, "topk_cosine_filtered")    # sample pass + bf16 filter + rescoring
-    model, feats, adj, n_local = build_workload(args, dev, rank, world, force_dist)
+    filt_timer = EventTimer(K, "topk_cosine_filtered")    # bound pass + bf16 filter + rescoring
+    model, feats, adj, n_local = build_workload(args, dev, rank, world, args.shard, force_dist)
     L = K.N.lib()
     L.ragraph_profile_filter_kernel(1)
     filter_ms = []
@@ -259,46 +335,38 @@ def main():
         with torch.no_grad():
             return model(feats, adj)
 
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    topk_timer.enabled = filt_timer.enabled = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-        ms = L.ragraph_profile_last_filter_ms()  # the step has already synchronised on its overflow count
+    def grab_filter_ms():
+        ms = L.ragraph_profile_last_filter_ms()  # waits for this step's filter launches (they are the step's tail)
         if ms > 0:
             filter_ms.append(ms)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+
+    for _ in range(args.warmup):
+        step()
+    topk_timer.enabled = filt_timer.enabled = True
+    elapsed, out = timed_steps(step, args.steps, world, dev, grab_filter_ms)
     topk_timer.enabled = filt_timer.enabled = False
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    L.ragraph_profile_filter_kernel(0)
     assert torch.isfinite(out).all()
 
     n = args.nodes
+    G = max(world, args.emulate_rank_of, 1)
+    shard_div = G if args.shard == "queries" else 1
+    n_q_local = -(-n // shard_div)  # queries this rank scores against its n_local keys
     traffic = None  # HBM-side GB per launch from the committed PMC run of this exact shape (cannot be sampled in-process)
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-        nq_key = -(-n // (max(world, args.emulate_rank_of, 1) if args.shard == "queries" else 1))
-        key = (f"topk_filter_kernel B={nq_key} N={n_local} D={args.dim} k={args.k}" if not args.exact_fp32 and
-               K.filter_helps(nq_key, n_local, args.dim, args.k) else
-               f"topk_stream_kernel<{args.dim}> B={nq_key} N={n_local} D={args.dim} k={args.k}")
+        prof = json.load(open(TRAFFIC_JSON))
+        filtered_shape = not args.exact_fp32 and real_filter_helps(n_q_local, n_local, args.dim, args.k)
+        key = (f"topk_filter_kernel B={n_q_local} N={n_local} D={args.dim} k={args.k}" if filtered_shape else
+               f"topk_stream_kernel<{args.dim}> B={n_q_local} N={n_local} D={args.dim} k={args.k}")
         if key in prof:
             traffic = prof[key]["hbm_side_GB"]
     except (OSError, ValueError):
         pass
     ms_step = elapsed / args.steps * 1e3
-    shard_div = max(world, args.emulate_rank_of, 1) if args.shard == "queries" else 1
-    n_q_local = -(-n // shard_div)  # queries this rank scores against its n_local keys
     flops = 2.0 * n_q_local * n_local * args.dim
     filtered = len(filt_timer.events) > 0
+    traffic_unit = ("GB per launch, HBM side = (2*FETCH_SIZE + WRITE_SIZE) from rocprofv3 --pmc (separate passes), "
+                    "profiles/r2_pmc_traffic.json")
     if filtered:
         # dominant kernel = the bf16 filter (its own events inside the library, ragraph_profile_last_filter_ms)
         kernel_ms = sum(filter_ms) / max(len(filter_ms), 1)
@@ -307,15 +375,13 @@ def main():
         roofline = {
             "kernel": "ragraph::topk_filter_kernel (bf16 MFMA filter of the exact top-k, v_mfma_f32_32x32x16_bf16)",
             "bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-            "traffic_unit": "GB per launch, HBM side = (2*FETCH_SIZE + WRITE_SIZE) from rocprofv3 --pmc, "
-                            "profiles/r1_pmc_traffic.json",
+            "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": traffic_unit,
             "launch_ms": round(kernel_ms, 3),
             "note": "algorithmic flops 2*B*N*D of the score matrix / mean duration of the filter kernel (events "
                     "recorded around its launches inside the library: the bound pass over a prefix of the bank, "
                     "whose flops are overhead and not counted, and the filter levels, summed per call). The whole "
                     f"exact retrieval call (this kernel + exact fp32 rescoring of the survivors) takes "
-                    f"{call_ms:.2f} ms; --exact-fp32 runs the fp32 MFMA kernel alone. "
+                    f"{call_ms:.2f} ms; `exact_fp32` below is the same step on the fp32 MFMA kernel alone. "
                     f"tools/microbench/mfma_bf16_bench.hip: this kernel's bare inner loop sustains 1.60 PFLOP/s on random "
                     f"operands (2.19 on near-constant ones): the clock held under real data bounds it well below peak",
             "retrieval_call_ms": round(call_ms, 3),
@@ -326,13 +392,17 @@ def main():
         roofline = {
             "kernel": "ragraph::topk_stream_kernel<256, 4> (fused cosine+top-k, v_mfma_f32_32x32x2_f32, LDS-DMA key ring)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-            "traffic_unit": "GB per launch, HBM side = (2*FETCH_SIZE + WRITE_SIZE) from rocprofv3 --pmc, "
-                            "profiles/r1_pmc_traffic.json",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": traffic_unit,
             "launch_ms": round(topk_ms, 3),
             "note": "algorithmic flops 2*B*N*D per launch / mean launch time from events on the launch stream "
                     "(includes the <0.1 % query-normalise and select kernels of the same ABI call)",
         }
+    if args.shard == "keys":
+        par = (f"key bank row-sharded x{G} (values replicated): per-query bounds sharpened by an all_reduce(MAX) and an "
+               f"all_gather of each rank's best scores per level, one RCCL all_gather of the per-shard top-k per step")
+    else:
+        par = (f"query batch split x{G}, bank replicated on every GPU (1 GB of 288 GB): no data-path collective, one RCCL "
+               f"all_gather of the [n, C] outputs per step")
     result = {
         "metric": "retrieved-queries/sec (RAGraph_node forward: GCN encode + cosine/top-k retrieval + 3-hop propagate + decode)",
         "value": round(n / (elapsed / args.steps), 1),
@@ -350,21 +420,50 @@ def main():
                                f"{args.bank}-key x {args.dim}-d bank, k={args.k}, C={args.classes} "
                                f"(BASELINE.json configs[1])",
                    "bank_rows_per_gpu": n_local,
-                   "parallelism": "single GPU" if world == 1 else
-                   (f"query batch split x{world}, bank replicated on every GPU (1 GB of 288 GB): no data-path collective, "
-                    f"one RCCL all_gather of the [n, C] outputs per step" if args.shard == "queries" else
-                    f"key bank row-sharded x{world} (values replicated), one RCCL all_gather of the per-shard top-k per "
-                    f"step")},
+                   "parallelism": "single GPU" if G == 1 else par},
         "roofline": roofline,
     }
     if args.emulate_rank_of > 1:
-        result["emulated"] = (f"rank 0 of a {args.emulate_rank_of}-GPU job ({args.shard}-sharded), no collectives: "
-                              f"value is NOT a job throughput")
-    if world == 1 and args.emulate_rank_of <= 1:
+        result["emulated"] = (f"rank 0 of a {args.emulate_rank_of}-GPU job ({args.shard}-sharded), collectives replaced by "
+                              f"their local part: value is NOT a job throughput")
+    extras = not args.no_extras and args.emulate_rank_of <= 1
+    if world > 1 and extras and args.shard == "keys":
+        # the other layout, right after: bank replicated, query batch split (every rank must take part)
+        del model
+        torch.cuda.empty_cache()
+        m2, f2, a2, _ = build_workload(args, dev, rank, world, "queries", force_dist)
+
+        def step2():
+            with torch.no_grad():
+                return m2(f2, a2)
+        for _ in range(max(args.warmup, 1)):
+            step2()
+        e2, _ = timed_steps(step2, args.steps, world, dev)
+        result["query_sharded"] = {"value": round(n / (e2 / args.steps), 1), "unit": "queries/s",
+                                   "ms_per_step": round(e2 / args.steps * 1e3, 3),
+                                   "parallelism": f"query batch split x{world}, bank replicated; same steps / warm-up"}
+    if world == 1 and extras:
         result["gnn_fwd_nodes_per_s"] = round(gnn_only_rate(model, feats, adj, max(args.steps, 3)), 1)
-        if args.small_batch:
-            result["retrieval_small_batch"] = small_batch_rates(model.toy_graph_base, args.dim, args.k, dev)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        K.filter_helps = real_filter_helps
+        result["retrieval_small_batch"] = small_batch_rates(model.toy_graph_base, args.dim, args.k, dev)
+        if not args.exact_fp32:
+            # the same step on the fp32 MFMA kernels alone (the path the bf16 filter replaces bit for bit)
+            K.filter_helps = lambda *a, **kw: False
+            topk_timer.reset()
+            step()
+            topk_timer.enabled = True
+            e32, _ = timed_steps(step, 2, 1, dev)
+            topk_timer.enabled = False
+            K.filter_helps = real_filter_helps
+            t32 = topk_timer.mean_ms()
+            a32 = flops / (t32 * 1e-3) / 1e12
+            result["exact_fp32"] = {"value": round(n / (e32 / 2), 1), "unit": "queries/s", "ms_per_step": round(e32 / 2 * 1e3, 3),
+                                    "steps": 2,
+                                    "roofline": {"kernel": "ragraph::topk_stream_kernel<256, 4> (v_mfma_f32_32x32x2_f32)",
+                                                 "bound": "mfma", "achieved": round(a32, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                                                 "unit": "TFLOP/s", "frac": round(a32 / FP32_MFMA_PEAK_TFLOPS, 4),
+                                                 "launch_ms": round(t32, 3)}}
+    if rank == 0 and world == 1 and extras and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, model, feats, adj)
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -108,9 +108,12 @@ int ragraph_topk_cosine_bank_f32(const float* Q, int64_t B, const float* Kn, con
  *   Kp   optional packed fp32 copy (ragraph_pack_keys_f32) for the fp32 level, or NULL.
  *   overflow  device int, set by the call: number of queries whose candidate list exceeded its capacity
  *        (ragraph_topk_cosine_filtered_cap(k)) at some level; only possible on banks with thousands of keys within EPS
- *        of a query's k-th best (near-duplicate banks, zero queries).  Their rows of the result are NOT valid: the
- *        caller re-runs those queries (or the batch) through ragraph_topk_cosine_bank_f32.  All other rows are exact.
- *   overflow_idx  optional device int64[B]: the first *overflow entries receive the row numbers of those queries.
+ *        of a query's k-th best (near-duplicate banks, zero queries).  The call itself recomputes those rows with an
+ *        exact fp32 scan of the bank ON THE DEVICE (its last launch; an empty list on ordinary banks), so every row of
+ *        the result is exact and nothing is read back: the call never synchronises and is HIP-graph capturable.  The
+ *        count is diagnostic (a bank that sends many queries to the scan is better served by the fp32 kernels).
+ *   overflow_idx  optional device int64[B]: the first *overflow entries receive the row numbers of those queries
+ *        (batches of 2048 queries and more; smaller ones repair inside their rescoring launch and leave it untouched).
  */
 int64_t ragraph_keys_bf16_rows(int64_t N);
 int ragraph_keys_to_bf16(const float* Kn, int64_t N, int D, uint16_t* Kb, void* stream);
@@ -127,6 +130,32 @@ int ragraph_topk_cosine_filtered_plan(int64_t B, int64_t N, int D, int k, int64_
 int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const float* Kn, const float* Kp, const uint16_t* Kb,
                                      int64_t N, int D, int k, int64_t idx_base, float* out_scores, int64_t* out_idx,
                                      int* overflow, int64_t* overflow_idx, void* ws, size_t ws_bytes, void* stream);
+
+/* a1 over a ROW-SHARDED bank (one shard per GPU; the reference is single-GPU, so no reference line beyond the retrieval
+ * itself -- SimilarityFunctions.py:6-16 + ToyGraphBase.py:66-67).  As ragraph_topk_cosine_filtered_f32 on this shard's
+ * rows, with the per-query bound theta[B] (a proven lower bound of the query's final k-th best exact score over ALL
+ * shards) exposed between the phases so that the caller can sharpen it across the shards -- what keeps a shard's
+ * candidate lists at 1/G of a single GPU's instead of the same length:
+ *   exchange(ctx, 0)      after the first bound (bound pass or exact level 0): theta = this shard's bound; the caller may
+ *                         replace theta[q] by any valid lower bound of the global k-th best (e.g. all_reduce MAX);
+ *   exchange(ctx, 1 + l)  after level l (not the last): out_scores holds this shard's running top-k (descending, -inf
+ *                         where it has fewer than k candidates) and theta = max(theta, its k-th); same contract.
+ * The callback runs on the calling host thread between launches; whatever it enqueues must be ordered on `stream` (a
+ * torch.distributed collective on the current stream is).  plan_N = the LARGEST shard's row count: the schedule (hence
+ * the number of callbacks) is computed from it, so that every rank makes the same calls; N <= plan_N <= N + 1024.
+ * The result is this shard's exact top-k among its rows that can still be in the global top-k (fewer than k entries
+ * are padded with -inf / INT64_MAX); ragraph_topk_merge_f32 over the shards' lists gives the global result, bit-identical
+ * to one GPU.  exchange = NULL: exactly ragraph_topk_cosine_filtered_f32. */
+typedef void (*ragraph_exchange_fn)(void* ctx, int phase);
+int ragraph_topk_cosine_filtered_sharded_f32(const float* Q, int64_t B, const float* Kn, const float* Kp, const uint16_t* Kb,
+                                             int64_t N, int D, int k, int64_t idx_base, float* out_scores, int64_t* out_idx,
+                                             int* overflow, int64_t* overflow_idx, void* ws, size_t ws_bytes, void* stream,
+                                             int64_t plan_N, float* theta, ragraph_exchange_fn exchange, void* ctx);
+
+/* The per-level exchange of the sharded call: theta[b] = max(theta[b], k-th largest of the G*m scores gathered for query
+ * b), gathered = the all_gather of every shard's best m exact scores, [G, B, m] as the collective leaves it; k <= G*m <= 64.
+ * (The k-th largest of a subset of all scores bounds the k-th largest of all from below.) */
+int ragraph_theta_sharpen_f32(const float* gathered, int G, int64_t B, int m, int k, float* theta, void* stream);
 
 /* Measurement hook (bench.py): when enabled, ragraph_topk_cosine_filtered_f32 brackets its bf16 filter kernel with
  * events on the caller's stream; ragraph_profile_last_filter_ms() waits for the latest one and returns its

@@ -43,6 +43,7 @@ __device__ __forceinline__ float ord2f(int o) { return __int_as_float(o >= 0 ? o
 // or -- gmax != NULL, right after the bound pass -- the smallest of the k group maxima of approximate scores minus
 // eps(q) (each group's best key has an exact score >= its approximate one - eps, so k distinct keys score at least that).
 struct FilterThr {
+  const float* theta;         // [B] the bound itself, handed in (sharded banks: sharpened across the shards), or NULL
   const float* prev_scores;   // [B,k] running exact top-k (descending), or NULL
   const int* gmax;            // [B,ngroups] order-preserving ints of the bound pass, or NULL
   const float* eq;            // [B] |dq| of the query's bf16 rounding
@@ -61,7 +62,9 @@ __device__ __forceinline__ float filter_threshold(const FilterThr& t, int64_t q)
   if (t.ablate) return __builtin_huge_valf();
   const float eps = filter_eps(t, q);
   float theta;
-  if (t.gmax) {
+  if (t.theta) {
+    theta = t.theta[q];
+  } else if (t.gmax) {
     int m = t.gmax[q * t.ngroups];
     for (int g = 1; g < t.ngroups; ++g) m = min(m, t.gmax[q * t.ngroups + g]);
     theta = __fsub_rn(ord2f(m), eps);

@@ -177,6 +177,44 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
   if (gmax && lane < ngroups) gmax[q * ngroups + lane] = f2ord(RG_NEG_INF);
 }
 
+// Sharded banks (ragraph_topk_cosine_filtered_sharded_f32): the bound a level filters with is kept in theta[B] so that
+// the caller can sharpen it across the shards between the phases.  After the bound pass: theta = min over the parts of
+// the part's best approximate score, minus eps; after an exact level 0 or a rescoring level: theta = max(theta, the
+// shard's k-th exact score so far) (-inf while the shard has fewer than k candidates).
+__global__ void __launch_bounds__(256) filter_theta_kernel(FilterThr t, int64_t B, int init, float* __restrict__ theta) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= B) return;
+  float v;
+  if (t.gmax) {
+    int m = t.gmax[q * t.ngroups];
+    for (int g = 1; g < t.ngroups; ++g) m = min(m, t.gmax[q * t.ngroups + g]);
+    v = __fsub_rn(ord2f(m), filter_eps(t, q));
+  } else {
+    v = t.prev_scores[q * t.k + t.k - 1];
+  }
+  theta[q] = init ? v : fmaxf(theta[q], v);
+}
+
+// Sharded banks, after a level: theta[b] = max(theta[b], k-th largest of the union of every shard's best m exact scores
+// of query b) -- the k-th largest of a SUBSET of all scores is a lower bound of the k-th largest of all.  `gathered` is the
+// all_gather's [G, B, m] layout as it stands; G m <= 64: one wave per query, lane l holds one score and ranks it by
+// counting (ties broken by lane, so duplicates count as many times as they occur).
+__global__ void __launch_bounds__(256) theta_sharpen_kernel(const float* __restrict__ gathered, int G, int64_t B, int m, int k,
+                                                            float* __restrict__ theta) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int n = G * m;
+  float v = RG_NEG_INF;
+  if (lane < n) v = gathered[((int64_t)(lane / m) * B + b) * m + (lane % m)];
+  int rank = 0;
+  for (int o = 0; o < n; ++o) {
+    const float u = __shfl(v, o);
+    rank += (u > v || (u == v && o < lane)) ? 1 : 0;
+  }
+  if (lane < n && rank == k - 1) theta[b] = fmaxf(theta[b], v);
+}
+
 #ifdef RG_TOPK_TIMING  // diagnostic build only: per-wave cycle totals of the ring's phases
 __device__ unsigned long long g_filter_timing[8];
 #define RG_FT(var_) const unsigned long long var_ = __builtin_amdgcn_s_memtime()
@@ -579,10 +617,55 @@ __device__ __forceinline__ float coop_scores(const float4* __restrict__ qrow, co
   return acc;
 }
 
+// The same for at most 16 candidates (lanes 0..15; sharded banks and late levels leave a query a handful): only rows
+// 0..15 exist, so ALL of a row's 64-float blocks are fetched at once -- one memory latency per query instead of one per
+// block -- and staged block by block; the chains are the same.
+template <int D>
+__device__ __forceinline__ float coop_scores_few(const float4* __restrict__ qrow, const float* __restrict__ Kn, int key,
+                                                 int lane, float* sm) {
+  const int rr = lane >> 4, cc = lane & 15;
+  constexpr int NDC = D / 64;
+  int krow[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) krow[t] = __shfl(key, 4 * t + rr);
+  float4 v[NDC][4];
+#pragma unroll
+  for (int dc = 0; dc < NDC; ++dc)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      v[dc][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (krow[t] >= 0) v[dc][t] = *reinterpret_cast<const float4*>(Kn + (int64_t)krow[t] * D + cc * 4 + dc * 64);
+    }
+  float acc = 0.f;
+#pragma unroll
+  for (int dc = 0; dc < NDC; ++dc) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) *reinterpret_cast<float4*>(sm + (4 * t + rr) * RESCORE_LD + cc * 4) = v[dc][t];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < 16) {
+#pragma unroll
+      for (int e4 = 0; e4 < 16; ++e4) {
+        const float4 kv = *reinterpret_cast<const float4*>(sm + lane * RESCORE_LD + e4 * 4);
+        const float4 qv = qrow[dc * 16 + e4];
+        acc = fmaf(qv.x, kv.x, acc);
+        acc = fmaf(qv.y, kv.y, acc);
+        acc = fmaf(qv.z, kv.z, acc);
+        acc = fmaf(qv.w, kv.w, acc);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  return acc;
+}
+
 // Rescoring of one query by one wave with NS candidate slots per lane (n <= 64 * NS reserved slots): exact scores (one
 // lane per candidate, the k = 0..D-1 fmaf chain from +0), merge with the previous level's winners, canonical top-k.
 // COOP: rows staged through the LDS tile `sm` (coop_scores); else every lane reads its own row.
-template <int D, int NS, bool COOP = false>
+template <int D, int NS, bool COOP = false, bool FEW = false>
 __device__ __forceinline__ void rescore_query(const float4* __restrict__ qrow, const float* __restrict__ Kn,
                                               const int* __restrict__ cand, int n, int lane, int k, int64_t base,
                                               const float* prev_s, const int64_t* prev_i, float* out_s, int64_t* out_i,
@@ -608,7 +691,7 @@ __device__ __forceinline__ void rescore_query(const float4* __restrict__ qrow, c
     else if (c < n) key = cand[c];
     if constexpr (COOP) {
       if (64 * u < n) {  // wave-uniform
-        const float acc = coop_scores<D>(qrow, Kn, key, lane, sm);
+        const float acc = FEW ? coop_scores_few<D>(qrow, Kn, key, lane, sm) : coop_scores<D>(qrow, Kn, key, lane, sm);
         if (key >= 0) {
           s[u] = acc;
           id[u] = key;
@@ -680,7 +763,11 @@ __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restri
 }
 
 // Large batches: as topk_rescore_kernel, rows staged through LDS (coop_scores); two waves per workgroup.
-template <int D, int CPL>
+// FEWTILE: the variant for levels that leave a query a handful of candidates (the later levels over a sharded bank,
+// whose bounds were sharpened across the shards): a 16-row tile instead of 64, so that four times as many waves fit a
+// CU -- such a level is a chain of memory latencies per query, and occupancy is what hides them; the rare longer list
+// takes the lane-private row reads.
+template <int D, int CPL, bool FEWTILE = false>
 __global__ void __launch_bounds__(128) topk_rescore_coop_kernel(const float* __restrict__ Qn, const float* __restrict__ Kn,
                                                                 int* __restrict__ count,
                                                                 const int* __restrict__ cand, int64_t B, int cap, int k,
@@ -690,7 +777,7 @@ __global__ void __launch_bounds__(128) topk_rescore_coop_kernel(const float* __r
                                                                 int* __restrict__ overflow_list,
                                                                 unsigned char* __restrict__ flag) {
   __shared__ float4 qs[2][D / 4];
-  __shared__ __attribute__((aligned(16))) float tile[2][64 * RESCORE_LD];
+  __shared__ __attribute__((aligned(16))) float tile[2][(FEWTILE ? 16 : 64) * RESCORE_LD];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t b = (int64_t)blockIdx.x * 2 + w;
   if (b >= B) return;  // whole wave
@@ -722,9 +809,11 @@ __global__ void __launch_bounds__(128) topk_rescore_coop_kernel(const float* __r
   const int* cb = cand + b * cap;
 #define RG_RESCORE(NS_, COOP_) \
   rescore_query<D, NS_, COOP_>(qs[w], Kn, cb, n, lane, k, base, ps, pi, out_s + b * k, out_i + b * k, tile[w])
-  if (n <= 64) RG_RESCORE(1, true);
-  else if (n <= 128) RG_RESCORE(2, true);
-  else if (n <= 256) RG_RESCORE(4, true);
+  if (n <= 16)
+    rescore_query<D, 1, true, true>(qs[w], Kn, cb, n, lane, k, base, ps, pi, out_s + b * k, out_i + b * k, tile[w]);
+  else if (n <= 64) RG_RESCORE(1, !FEWTILE);
+  else if (n <= 128) RG_RESCORE(2, !FEWTILE);
+  else if (n <= 256) RG_RESCORE(4, !FEWTILE);
   else if (n <= 512) RG_RESCORE(8, false);  // long lists are rare: the plain form keeps the kernel out of scratch
   else RG_RESCORE(CPL, false);
 #undef RG_RESCORE
@@ -1340,7 +1429,7 @@ static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64
 // Exact rescoring of a level's candidates (+ merge with the running result when `merge`) and canonical selection.
 template <int D>
 static int run_rescore(const FilterWs& f, const float* Kn, int64_t N, int64_t B, int cap, int k, int64_t idx_base, int merge,
-                       int final_level, float* out_scores, int64_t* out_idx, int* overflow, int* fallback_done,
+                       int final_level, float* out_scores, int64_t* out_idx, int* overflow, int* fallback_done, bool few,
                        hipStream_t st) {
   const float* ps = merge ? out_scores : nullptr;
   const int64_t* pi = merge ? out_idx : nullptr;
@@ -1368,6 +1457,9 @@ static int run_rescore(const FilterWs& f, const float* Kn, int64_t N, int64_t B,
     hipLaunchKernelGGL((topk_rescore_wide_kernel<D, false>), dim3((unsigned)B), dim3(256), 0, st, f.Qn, Kn, f.count, f.cand, B,
                        cap, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag,
                        (float*)nullptr, (int*)nullptr);
+  else if (rescore_coop() && few)
+    hipLaunchKernelGGL((topk_rescore_coop_kernel<D, 32, true>), dim3((unsigned)cdiv(B, 2)), dim3(128), 0, st, f.Qn, Kn, f.count,
+                       f.cand, B, cap, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag);
   else if (rescore_coop())
     hipLaunchKernelGGL((topk_rescore_coop_kernel<D, 32>), dim3((unsigned)cdiv(B, 2)), dim3(128), 0, st, f.Qn, Kn, f.count,
                        f.cand, B, cap, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag);
@@ -1381,10 +1473,12 @@ static int run_rescore(const FilterWs& f, const float* Kn, int64_t N, int64_t B,
 template <int D>
 static int run_filtered(const float* Q, int64_t B, const float* Kn, const float* Kp, const uint16_t* Kb, int64_t N, int k,
                         int64_t idx_base, float* out_scores, int64_t* out_idx, int* overflow, int64_t* overflow_idx,
-                        void* ws, void* stream) {
+                        void* ws, void* stream, int64_t plan_N, float* theta, ragraph_exchange_fn exchange, void* ctx) {
   hipStream_t st = as_stream(stream);
   const int cap = ragraph_topk_cosine_filtered_cap(k);
-  const FilterSchedule sc = filter_schedule(B, N, D, k);
+  FilterSchedule sc = filter_schedule(B, plan_N, D, k);  // (sharded banks: the same schedule on every shard)
+  sc.ends[sc.nlev - 1] = N;
+  if (sc.bound_keys > N / 2) sc.bound_keys = 0, sc.n0 = sc.n0 < N ? sc.n0 : N;
   static const int ablate = [] {  // RAGRAPH_FILTER_ABLATE=1: no key passes the filter (timing only, results invalid)
     const char* e = getenv("RAGRAPH_FILTER_ABLATE");
     return e ? atoi(e) : 0;
@@ -1428,17 +1522,33 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
                                       stream);
   }
   if (rc != RAGRAPH_OK) return rc;
+  if (exchange) {  // the first bound leaves through theta, and comes back as a bound on the k-th best of ALL shards
+    thr.gmax = bound ? f.gmax : nullptr;
+    thr.prev_scores = out_scores;
+    hipLaunchKernelGGL(filter_theta_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, thr, B, 1, theta);
+    RG_CHECK_LAUNCH("topk_cosine_filtered(theta)");
+    exchange(ctx, 0);
+    thr.theta = theta;
+  }
   int64_t key0 = 0;
   for (int l = 0; l < sc.nlev; ++l) {  // the first level re-reads [0, n0): its keys pass the bound and need no merge
-    thr.gmax = (l == 0 && bound) ? f.gmax : nullptr;
+    thr.gmax = (l == 0 && bound && !exchange) ? f.gmax : nullptr;
     thr.prev_scores = out_scores;
     rc = run_bf16_pass<D>(f, Kb, B, key0, sc.ends[l], thr, cap, 0, l, st);
     if (rc != RAGRAPH_OK) return rc;
     if (g_prof_on) g_prof_have = l + 1;
     rc = run_rescore<D>(f, Kn, N, B, cap, k, idx_base, l > 0, l == sc.nlev - 1, out_scores, out_idx, overflow,
-                        &fallback_done, st);
+                        &fallback_done, exchange != nullptr && l > 0, st);
     if (rc != RAGRAPH_OK) return rc;
     key0 = sc.ends[l];
+    if (exchange && l + 1 < sc.nlev) {  // this shard's k-th exact score so far sharpens theta; then the other shards'
+      FilterThr t2 = thr;
+      t2.gmax = nullptr;
+      t2.theta = nullptr;
+      hipLaunchKernelGGL(filter_theta_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, t2, B, 0, theta);
+      RG_CHECK_LAUNCH("topk_cosine_filtered(theta)");
+      exchange(ctx, 1 + l);
+    }
   }
   // overflowed queries (none on ordinary banks): exact fp32 scan on the device -- no host read-back (the sliced
   // rescoring of a handful of queries has done it inside its merge launch)
@@ -1450,21 +1560,55 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   return RAGRAPH_OK;
 }
 
-extern "C" int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const float* Kn, const float* Kp,
-                                                const uint16_t* Kb, int64_t N, int D, int k, int64_t idx_base,
-                                                float* out_scores, int64_t* out_idx, int* overflow,
-                                                int64_t* overflow_idx, void* ws, size_t ws_bytes, void* stream) {
+static int filtered_entry(const float* Q, int64_t B, const float* Kn, const float* Kp, const uint16_t* Kb, int64_t N, int D,
+                          int k, int64_t idx_base, float* out_scores, int64_t* out_idx, int* overflow, int64_t* overflow_idx,
+                          void* ws, size_t ws_bytes, void* stream, int64_t plan_N, float* theta, ragraph_exchange_fn exchange,
+                          void* ctx) {
   RG_REQUIRE(Q && Kn && Kb && out_scores && out_idx && overflow && ws, RAGRAPH_EINVAL, "topk_cosine_filtered: null pointer");
   RG_REQUIRE(filter_dim_ok(D), RAGRAPH_EUNSUPPORTED, "topk_cosine_filtered: D=%d not in {64,128,256}", D);
   RG_REQUIRE(B >= 1 && N >= 1 && k >= 1 && k <= 32 && k <= N, RAGRAPH_EINVAL, "topk_cosine_filtered: bad B/N/k");
   RG_REQUIRE(N < (int64_t)INT_MAX - 1024, RAGRAPH_EUNSUPPORTED, "topk_cosine_filtered: shard rows must fit int32");
+  RG_REQUIRE(plan_N >= N && plan_N - N <= 1024, RAGRAPH_EINVAL, "topk_cosine_filtered: plan_N must be the largest shard's size");
+  RG_REQUIRE(!exchange || theta, RAGRAPH_EINVAL, "topk_cosine_filtered: an exchange needs the theta buffer");
   RG_REQUIRE(aligned16(Q) && aligned16(Kn) && aligned16(Kb) && aligned16(ws), RAGRAPH_EINVAL,
              "topk_cosine_filtered: pointers must be 16-B aligned");
-  const size_t need = ragraph_topk_cosine_filtered_workspace_bytes(B, N, D, k);
+  const size_t need = ragraph_topk_cosine_filtered_workspace_bytes(B, plan_N, D, k);
   RG_REQUIRE(ws_bytes >= need, RAGRAPH_EWORKSPACE, "topk_cosine_filtered: workspace %zu < %zu", ws_bytes, need);
   if (D == 256)
-    return run_filtered<256>(Q, B, Kn, Kp, Kb, N, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, stream);
+    return run_filtered<256>(Q, B, Kn, Kp, Kb, N, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, stream, plan_N,
+                             theta, exchange, ctx);
   if (D == 128)
-    return run_filtered<128>(Q, B, Kn, Kp, Kb, N, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, stream);
-  return run_filtered<64>(Q, B, Kn, Kp, Kb, N, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, stream);
+    return run_filtered<128>(Q, B, Kn, Kp, Kb, N, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, stream, plan_N,
+                             theta, exchange, ctx);
+  return run_filtered<64>(Q, B, Kn, Kp, Kb, N, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, stream, plan_N,
+                          theta, exchange, ctx);
+}
+
+extern "C" int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const float* Kn, const float* Kp,
+                                                const uint16_t* Kb, int64_t N, int D, int k, int64_t idx_base,
+                                                float* out_scores, int64_t* out_idx, int* overflow,
+                                                int64_t* overflow_idx, void* ws, size_t ws_bytes, void* stream) {
+  return filtered_entry(Q, B, Kn, Kp, Kb, N, D, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, ws_bytes, stream,
+                        N, nullptr, nullptr, nullptr);
+}
+
+extern "C" int ragraph_topk_cosine_filtered_sharded_f32(const float* Q, int64_t B, const float* Kn, const float* Kp,
+                                                        const uint16_t* Kb, int64_t N, int D, int k, int64_t idx_base,
+                                                        float* out_scores, int64_t* out_idx, int* overflow,
+                                                        int64_t* overflow_idx, void* ws, size_t ws_bytes, void* stream,
+                                                        int64_t plan_N, float* theta, ragraph_exchange_fn exchange,
+                                                        void* ctx) {
+  return filtered_entry(Q, B, Kn, Kp, Kb, N, D, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, ws_bytes, stream,
+                        plan_N, theta, exchange, ctx);
+}
+
+extern "C" int ragraph_theta_sharpen_f32(const float* gathered, int G, int64_t B, int m, int k, float* theta, void* stream) {
+  RG_REQUIRE(gathered && theta, RAGRAPH_EINVAL, "theta_sharpen: null pointer");
+  RG_REQUIRE(G >= 1 && m >= 1 && k >= 1 && G * m <= 64 && G * m >= k, RAGRAPH_EINVAL,
+             "theta_sharpen: need k <= G*m <= 64 (G=%d m=%d k=%d)", G, m, k);
+  if (B <= 0) return RAGRAPH_OK;
+  hipLaunchKernelGGL(theta_sharpen_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, as_stream(stream), gathered, G, B, m, k,
+                     theta);
+  RG_CHECK_LAUNCH("theta_sharpen");
+  return RAGRAPH_OK;
 }

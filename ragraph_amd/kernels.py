@@ -5,6 +5,7 @@ All functions require CUDA(=ROCm) tensors and raise `RagraphNativeError` otherwi
 """
 from __future__ import annotations
 
+import ctypes
 import os
 
 import torch
@@ -152,12 +153,21 @@ def filter_helps(B: int, n_keys: int, D: int, k: int) -> bool:
 FILTER_MIN_B = int(os.environ.get("RAGRAPH_FILTER_MIN_B", "1"))  # banks of >= 64 k keys: filtered from this many queries
 
 
+_EXCHANGE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int)
+
+
 def topk_cosine_filtered(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf16: torch.Tensor, k: int,
-                         idx_base: int = 0, keys_packed: torch.Tensor | None = None):
+                         idx_base: int = 0, keys_packed: torch.Tensor | None = None, exchange=None, plan_n: int = 0):
     """Exact top-k (same bits as topk_cosine) through the bf16 MFMA filter.  Returns (scores, idx, overflow): `overflow`
     is a 1-element int32 DEVICE tensor counting the queries whose candidate list overflowed (none on ordinary banks);
     the call itself recomputed those rows with an exact fp32 scan on the device, so the result is complete and nothing
-    is read back: the call is asynchronous and HIP-graph capturable.  (`int(overflow)` synchronises.)"""
+    is read back: the call is asynchronous and HIP-graph capturable.  (`int(overflow)` synchronises.)
+
+    Row-sharded banks: `exchange(phase, theta, scores)` is called between the phases of the call
+    (ragraph_topk_cosine_filtered_sharded_f32) with theta [B] = this shard's lower bound of every query's final k-th
+    best score and scores [B,k] = its running top-k; it sharpens theta in place across the shards.  `plan_n` = the
+    largest shard's size (the same schedule, hence the same collectives, on every rank).  The result is then the
+    shard's list of what can still be in the global top-k (padded with -inf / INT64_MAX), to be merged by topk_merge."""
     L = _ready()
     q = _f32c(q, "topk_cosine_filtered.q")
     kn = _f32c(keys_normalized, "topk_cosine_filtered.keys")
@@ -175,15 +185,46 @@ def topk_cosine_filtered(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf
     scores = torch.empty((B, k), dtype=torch.float32, device=q.device)
     idx = torch.empty((B, k), dtype=torch.int64, device=q.device)
     overflow = torch.empty(1, dtype=torch.int32, device=q.device)
-    nbytes = L.ragraph_topk_cosine_filtered_workspace_bytes(B, Nk, D, k)
+    nbytes = L.ragraph_topk_cosine_filtered_workspace_bytes(B, max(plan_n, Nk), D, k)
     if nbytes == 0:
         raise RagraphNativeError(f"topk_cosine_filtered: unsupported shape B={B} N={Nk} D={D} k={k}")
     ws = _workspace(nbytes, q.device)
-    N.check(L.ragraph_topk_cosine_filtered_f32(q.data_ptr(), B, kn.data_ptr(), kp, keys_bf16.data_ptr(), Nk, D, k, idx_base,
-                                               scores.data_ptr(), idx.data_ptr(), overflow.data_ptr(), None,
-                                               ws.data_ptr(), ws.numel(), _stream()),
-            "topk_cosine_filtered")
+    if exchange is None:
+        N.check(L.ragraph_topk_cosine_filtered_f32(q.data_ptr(), B, kn.data_ptr(), kp, keys_bf16.data_ptr(), Nk, D, k,
+                                                   idx_base, scores.data_ptr(), idx.data_ptr(), overflow.data_ptr(), None,
+                                                   ws.data_ptr(), ws.numel(), _stream()),
+                "topk_cosine_filtered")
+        return scores, idx, overflow
+    theta = torch.empty(B, dtype=torch.float32, device=q.device)
+    errors = []
+
+    def _cb(_ctx, phase):  # runs on this thread, between the call's launches
+        try:
+            exchange(int(phase), theta, scores)
+        except BaseException as e:  # (an exception must not unwind through the C frames)
+            errors.append(e)
+
+    cb = _EXCHANGE_FN(_cb)
+    rc = L.ragraph_topk_cosine_filtered_sharded_f32(q.data_ptr(), B, kn.data_ptr(), kp, keys_bf16.data_ptr(), Nk, D, k,
+                                                    idx_base, scores.data_ptr(), idx.data_ptr(), overflow.data_ptr(), None,
+                                                    ws.data_ptr(), ws.numel(), _stream(), max(plan_n, Nk),
+                                                    theta.data_ptr(), cb, None)
+    if errors:
+        raise errors[0]
+    N.check(rc, "topk_cosine_filtered(sharded)")
     return scores, idx, overflow
+
+
+def theta_sharpen(gathered: torch.Tensor, theta: torch.Tensor, k: int) -> torch.Tensor:
+    """In place: theta[b] = max(theta[b], k-th largest of gathered[:, b, :]) -- the per-level exchange of a filtered
+    retrieval over a row-sharded bank (gathered = all_gather of every shard's best m exact scores, [G, B, m])."""
+    L = _ready()
+    g = _f32c(gathered, "theta_sharpen.gathered")
+    G, B, m = g.shape
+    if theta.dtype != torch.float32 or not theta.is_contiguous() or theta.numel() != B:
+        raise RagraphNativeError("theta_sharpen: theta must be a contiguous fp32 [B] tensor")
+    N.check(L.ragraph_theta_sharpen_f32(g.data_ptr(), G, B, m, k, theta.data_ptr(), _stream()), "theta_sharpen")
+    return theta
 
 
 from .kernels_index import KeyIndex  # noqa: E402,F401  (bank copies + dispatch to the fastest exact top-k)

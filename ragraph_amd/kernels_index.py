@@ -40,10 +40,22 @@ class KeyIndex:
         if B >= 64 and 4 * n_over > B:
             self._filter_off = True
 
-    def topk(self, q: torch.Tensor, k: int, idx_base: int = 0):
+    def topk(self, q: torch.Tensor, k: int, idx_base: int = 0, exchange=None, plan_n: int = 0):
+        """exchange / plan_n: this index holds one shard of a row-sharded bank (ShardedToyGraphBase): the filtered path
+        sharpens its per-query bounds across the shards through `exchange` (kernels.topk_cosine_filtered), and every
+        decision that changes which collectives run is taken from plan_n -- the largest shard's size -- so that all
+        ranks take it alike."""
         ops, kn = self.ops, self.keys_normalized
         B, D = q.shape
         fhelps = getattr(ops, "filter_helps", None)
+        if exchange is not None:
+            if fhelps is not None and fhelps(B, max(plan_n, kn.shape[0]), D, k) and B <= self.MAX_FILTERED_BATCH:
+                if self._bf16 is None:
+                    self._bf16 = ops.keys_to_bf16(kn)
+                s, i, _ = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base, exchange=exchange,
+                                                   plan_n=plan_n)
+                return s, i
+            fhelps = None  # (fp32 kernels: the shard's own exact top-k, no exchange needed)
         self._poll_overflow()
         if fhelps is not None and not self._filter_off and fhelps(B, kn.shape[0], D, k):
             if self._bf16 is None:

@@ -68,9 +68,12 @@ class ShardedToyGraphBase:
     library); the CPU tests inject an oracle-backed object to exercise the collective logic under gloo."""
 
     def __init__(self, keys, values, labels, idx_base: int, retrieve_num: int, group=None, ops=None,
-                 force_collectives: bool = False, values_replicated: bool = False):
+                 force_collectives: bool = False, values_replicated: bool = False, emulate_world: int = 0,
+                 plan_n: int = 0):
         """keys: this rank's key rows.  values/labels: this rank's rows (values_replicated=False) or the WHOLE bank's
-        (values_replicated=True)."""
+        (values_replicated=True).  plan_n: the largest shard's row count (default: all_reduce MAX of the shard sizes).
+        emulate_world = G (single process, TIMING ONLY): behave as rank 0 of a G-rank job whose other shards look like
+        this one -- the exchanges use this shard's numbers G times; results are not the global top-k."""
         if ops is None:
             from . import kernels as ops  # the HIP library; raises loudly without a GPU
         self.ops = ops
@@ -86,6 +89,43 @@ class ShardedToyGraphBase:
         self.keys_normalized = ops.normalize_rows(keys)
         from .kernels_index import KeyIndex  # torch-only helper: copies for the faster kernels, made on first use
         self._index = KeyIndex(self.keys_normalized, ops)
+        self.emulate_world = int(emulate_world)
+        n_local = int(keys.shape[0])
+        if plan_n:
+            self.plan_n = int(plan_n)
+        elif self.collective:
+            t = torch.tensor([n_local], dtype=torch.int64, device=keys.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            self.plan_n = int(t.item())
+        else:
+            self.plan_n = n_local
+
+    # ---- the exchanges of a filtered retrieval over the sharded bank (kernels.topk_cosine_filtered) ---------------------
+    def _exchange(self, phase: int, theta, scores):
+        """theta [B]: this shard's lower bound of every query's final k-th best score -> a bound over ALL shards.
+        phase 0 (first bound): the best shard's bound holds globally: all_reduce(MAX), 4 B per query.
+        phase 1 + l (after level l): the k-th largest of the union of every shard's best m = 2 ceil(k / G) exact scores
+        is a lower bound of the global k-th best (k-th of a subset): one all_gather of [B, m] scores, 4 m B per query
+        and rank, + a k-th selection over [B, G m] (topk_rows)."""
+        G = self.emulate_world if self.emulate_world > 1 else self.world
+        if G <= 1 and not self.collective:
+            return
+        k = scores.shape[1]
+        if phase == 0:
+            if self.collective:
+                dist.all_reduce(theta, op=dist.ReduceOp.MAX, group=self.group)
+            return
+        m = min(k, 2 * (-(-k // G)))
+        while G * m > 64 and m > -(-k // G):
+            m -= 1
+        local = scores[:, :m].contiguous()
+        B = local.shape[0]
+        if self.emulate_world > 1:
+            gathered = local.unsqueeze(0).expand(G, B, m).contiguous()
+        else:
+            gathered = torch.empty((G, B, m), dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(gathered.view(G * B, m), local, group=self.group)
+        self.ops.theta_sharpen(gathered, theta, k)
 
     def topk(self, search_keys, k=None):
         """Global canonical top-k: (scores [B,k], idx [B,k]) identical on every rank."""
@@ -93,13 +133,20 @@ class ShardedToyGraphBase:
         q = search_keys.reshape(1, -1) if search_keys.dim() == 1 else search_keys
         n_local = self.keys_normalized.shape[0]
         kl = min(k, n_local)
-        s, i = self._index.topk(q, kl, idx_base=self.idx_base)
+        sharded = self.collective or self.emulate_world > 1
+        s, i = self._index.topk(q, kl, idx_base=self.idx_base, exchange=self._exchange if sharded and kl == k else None,
+                                plan_n=self.plan_n)
         if kl < k:  # a shard smaller than k: pad with sentinels that lose every comparison
             pad_s = torch.full((q.shape[0], k - kl), float("-inf"), dtype=s.dtype, device=s.device)
             pad_i = torch.full((q.shape[0], k - kl), torch.iinfo(torch.int64).max, dtype=i.dtype, device=i.device)
             s, i = torch.cat([s, pad_s], 1), torch.cat([i, pad_i], 1)
+        if self.emulate_world > 1:  # (timing only) the merge launch a real rank would run over the G gathered lists
+            G = self.emulate_world
+            self.ops.topk_merge(s.unsqueeze(0).expand(G, *s.shape).contiguous(), i.unsqueeze(0).expand(G, *i.shape).contiguous())
+            return s, i
         if not self.collective:
             return s, i
+        # shards that cannot hold k winners of a query pad with sentinels that lose every comparison (-inf, INT64_MAX)
         B = s.shape[0]
         gs = torch.empty((self.world * B, k), dtype=s.dtype, device=s.device)   # rank-major concatenation
         gi = torch.empty((self.world * B, k), dtype=i.dtype, device=i.device)

@@ -39,6 +39,65 @@ class OracleOps:
     def gather_rows(v, idx, idx_base=0):
         return torch.from_numpy(cref.gather_rows(v.numpy(), idx.numpy(), idx_base))
 
+    @staticmethod
+    def theta_sharpen(gathered, theta, k):
+        G, B, m = gathered.shape
+        union = gathered.permute(1, 0, 2).reshape(B, G * m)
+        kth = torch.sort(union, dim=1, descending=True).values[:, k - 1]
+        torch.maximum(theta, kth, out=theta)
+        return theta
+
+
+class FilteredOracleOps(OracleOps):
+    """+ the phased (bound -> level 0 -> level 1) structure of ragraph_topk_cosine_filtered_sharded_f32, restated with
+    exact scores: a shard's list holds only what passes the bound the EXCHANGE left in theta.  If an exchange produced an
+    invalid (too high) bound, winners would be dropped and the merged result would differ from the single-GPU one."""
+
+    calls = 0
+
+    @staticmethod
+    def filter_helps(B, n_keys, D, k):
+        return True
+
+    @staticmethod
+    def keys_to_bf16(kn):
+        return kn
+
+    @classmethod
+    def topk_cosine_filtered(cls, q, kn, kb, k, idx_base=0, keys_packed=None, exchange=None, plan_n=0):
+        cls.calls += 1
+        qn = cref.normalize_rows(q.numpy())
+        S = cref.cosine_scores(qn, kn.numpy())                       # [B, n_local] exact scores
+        B, n = S.shape
+        ninf = np.float32(-np.inf)
+
+        def local_topk(lo, hi, theta, prev):
+            out_s = np.full((B, k), ninf, np.float32)
+            out_i = np.full((B, k), np.iinfo(np.int64).max, np.int64)
+            for b in range(B):
+                cand = [(S[b, j], j) for j in range(lo, hi) if S[b, j] >= theta[b]]
+                if prev is not None:
+                    cand += [(prev[0][b, r], int(prev[1][b, r])) for r in range(k) if prev[1][b, r] != np.iinfo(np.int64).max]
+                cand.sort(key=lambda t: (-t[0], t[1]))
+                for r, (sc, j) in enumerate(cand[:k]):
+                    out_s[b, r], out_i[b, r] = sc, j
+            return out_s, out_i
+
+        n0 = min(n, max(k, n // 8))
+        theta = torch.from_numpy(np.sort(S[:, :n0], axis=1)[:, ::-1][:, k - 1].copy() if n0 >= k else np.full(B, ninf, np.float32))
+        scores = torch.full((B, k), float("-inf"))
+        if exchange is not None:
+            exchange(0, theta, scores)
+        e1 = n // 2
+        s0, i0 = local_topk(0, e1, theta.numpy(), None)
+        scores.copy_(torch.from_numpy(s0))
+        torch.maximum(theta, scores[:, k - 1], out=theta)
+        if exchange is not None:
+            exchange(1, theta, scores)
+        s1, i1 = local_topk(e1, n, theta.numpy(), (s0, i0))
+        i1 = np.where(i1 == np.iinfo(np.int64).max, i1, i1 + idx_base)
+        return torch.from_numpy(s1), torch.from_numpy(i1), torch.zeros(1, dtype=torch.int32)
+
 
 def _free_port():
     with socket.socket() as s:
@@ -117,3 +176,45 @@ def test_query_shard_gather_world2(tmp_path, B):
     r0, r1 = (dict(np.load(tmp_path / f"q{r}.npz")) for r in range(world))
     assert np.array_equal(r0["got"], want) and np.array_equal(r1["got"], want)
     assert r0["lo"] == 0 and r0["hi"] == r1["lo"] and r1["hi"] == B
+
+
+def _theta_worker(rank, world, port, N, D, B, k, skew, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ragraph_amd.sharded import ShardedToyGraphBase, shard_bounds
+
+        rng = np.random.default_rng(5)
+        keys = cref.normalize_rows(rng.standard_normal((N, D), dtype=np.float32))
+        q = rng.standard_normal((B, D), dtype=np.float32)
+        if skew:  # every winner of the first queries lives in shard 1: shard 0's lists come back empty
+            keys[N - 3 * k:] = cref.normalize_rows(q[0:1] + 0.05 * rng.standard_normal((3 * k, D), dtype=np.float32))
+        lo, hi = shard_bounds(N, world, rank)
+        vals = torch.from_numpy(rng.standard_normal((N, D), dtype=np.float32))
+        labs = torch.from_numpy(np.eye(3, dtype=np.float32)[rng.integers(0, 3, N)])
+        tgb = ShardedToyGraphBase(torch.from_numpy(keys[lo:hi]), vals, labs, lo, k, ops=FilteredOracleOps,
+                                  values_replicated=True)
+        assert tgb.plan_n == max(shard_bounds(N, world, r)[1] - shard_bounds(N, world, r)[0] for r in range(world))
+        s, i = tgb.topk(torch.from_numpy(q))
+        assert FilteredOracleOps.calls == 1
+        np.savez(os.path.join(out_dir, f"t{rank}.npz"), s=s.numpy(), i=i.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("skew", [False, True])
+def test_sharded_theta_exchange_world2(tmp_path, skew):
+    """Key sharding with bounds sharpened across the shards (all_reduce MAX of the first bound, all_gather of each
+    shard's best scores per level): the merged result is the single-GPU one bit for bit, also when one shard holds every
+    winner and the other's lists are empty."""
+    N, D, B, k, world = 1501, 64, 23, 10, 2
+    mp.spawn(_theta_worker, args=(world, _free_port(), N, D, B, k, skew, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(5)
+    keys = cref.normalize_rows(rng.standard_normal((N, D), dtype=np.float32))
+    q = rng.standard_normal((B, D), dtype=np.float32)
+    if skew:
+        keys[N - 3 * k:] = cref.normalize_rows(q[0:1] + 0.05 * rng.standard_normal((3 * k, D), dtype=np.float32))
+    rs, ri = cref.topk_cosine(q, cref.normalize_rows(keys), k)
+    for r in range(world):
+        got = dict(np.load(tmp_path / f"t{r}.npz"))
+        assert np.array_equal(got["i"], ri) and np.array_equal(got["s"], rs)

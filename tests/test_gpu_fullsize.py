@@ -172,3 +172,70 @@ def test_filtered_topk_beyond_2gib_of_bf16_keys(dev):
     s0, i0 = K.topk_cosine(q, kn, 10, idx_base=3)
     assert over == 0 and torch.equal(i0, i1) and torch.equal(s0, s1)
     assert int(i1[0, 0]) == n - 1 + 3 and int(i1[1, 0]) == n // 2 + 12345 + 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G,B", [(2, 3000), (4, 20000), (3, 200)])
+def test_sharded_filtered_exchange_matches_single_gpu(dev, G, B):
+    """ragraph_topk_cosine_filtered_sharded_f32 on G row shards of a 1M x 256 bank, one host thread and one stream per
+    shard on this one GPU, the per-phase exchanges done through a thread barrier exactly as ShardedToyGraphBase does
+    them with RCCL (all_reduce MAX of the first bound, k-th of the union of every shard's best m scores per level):
+    merged lists == the unsharded call, bit for bit; and the shards' candidate work shrinks (lists padded with -inf)."""
+    import threading
+
+    from ragraph_amd import kernels as K
+    from ragraph_amd.sharded import shard_bounds
+
+    g = torch.Generator(device=dev).manual_seed(21)
+    N, D, k = 1_000_000, 256, 10
+    kn = K.normalize_rows(torch.randn(N, D, device=dev, generator=g))
+    q = torch.randn(B, D, device=dev, generator=g)
+    q[0] = kn[N - 1]                       # a winner in the last shard's last row
+    q[1] = kn[5] + 0.02 * q[1]             # all of this query's best keys near one row of shard 0
+    full_s, full_i = K.topk_cosine(q, kn, k)
+    bounds = [shard_bounds(N, G, r) for r in range(G)]
+    plan_n = max(hi - lo for lo, hi in bounds)
+    shards = [kn[lo:hi].contiguous() for lo, hi in bounds]
+    copies = [K.keys_to_bf16(s) for s in shards]
+    torch.cuda.synchronize()
+    barrier = threading.Barrier(G)
+    slots = [None] * G
+    out, errs, phases = [None] * G, [], []
+    m = min(k, 2 * (-(-k // G)))
+
+    def exchange_for(r):
+        def exchange(phase, theta, scores):
+            phases.append(phase)
+            torch.cuda.current_stream().synchronize()          # this shard's numbers are final
+            slots[r] = theta.clone() if phase == 0 else scores[:, :m].clone()
+            torch.cuda.current_stream().synchronize()
+            barrier.wait()
+            if phase == 0:
+                theta.copy_(torch.stack(slots).max(dim=0).values)
+            else:
+                K.theta_sharpen(torch.stack(slots).contiguous(), theta, k)   # [G, B, m], as an all_gather leaves it
+            torch.cuda.current_stream().synchronize()
+            barrier.wait()
+        return exchange
+
+    def run(r):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                s, i, over = K.topk_cosine_filtered(q, shards[r], copies[r], k, idx_base=bounds[r][0],
+                                                    exchange=exchange_for(r), plan_n=plan_n)
+                torch.cuda.current_stream().synchronize()
+                out[r] = (s, i, int(over))
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    ms, mi = K.topk_merge(torch.stack([o[0] for o in out]), torch.stack([o[1] for o in out]))
+    assert torch.equal(mi, full_i) and torch.equal(ms, full_s)
+    assert all(o[2] == 0 for o in out)
+    assert phases and all(p0 == 0 for p0 in phases[:G])   # every shard went through the first-bound exchange
