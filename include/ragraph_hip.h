@@ -67,7 +67,7 @@ int ragraph_normalize_rows_f32(const float* X, int64_t n, int D, float* out, voi
  *   Q   [B,D] raw (un-normalised) queries; normalised inside (a1) into the workspace.
  *   Kn  [N,D] key bank ALREADY row-normalised by ragraph_normalize_rows_f32 (done once per bank version; the
  *       reference re-normalises its stored keys on every call, SimilarityFunctions.py:11).
- *   k   1 <= k <= min(N, RAGRAPH_TOPK_MAX).  D in {64,128,256}.  B,N >= 1.  B <= 128 takes the wave-streaming
+ *   k   1 <= k <= min(N, RAGRAPH_TOPK_MAX) (larger k: ragraph_topk_select_rows_f32 over score slabs).  D in {64,128,256}.  B,N >= 1.  B <= 128 takes the wave-streaming
  *       kernel (groups of 16 queries on 16x16x4 MFMA; HBM-bound up to 16 queries), larger B the MFMA-bound tile
  *       kernel (256 queries per workgroup on 32x32x2); same numerics, so B never changes a bit of the result.
  *       32 < k <= 64 materialises ~1 GiB slabs of scores in the workspace (dense kernel + row top-k), same bits.
@@ -270,6 +270,16 @@ int ragraph_time_rescale_f32(const int64_t* t, int64_t n, float t_min, float t_m
  * out_scores [B,k], out_idx [B,k] int64. */
 int ragraph_topk_rows_f32(const float* S, int64_t B, int64_t N, int64_t ld, int k, float* out_scores,
                           int64_t* out_idx, void* stream);
+
+/* Large k: the canonical top-k SET of each row of a materialised score matrix -- the edge flavour's vanilla phase retrieves
+ * with retrieve_num = 50 ... 100000 and consumes only the MEAN of the winners' values
+ * (RAGraph_edge/modules/RAGraph.py:57,73 retrieve_num; :308-321 topk -> resource_values[idx] -> .mean(dim=1)).
+ * S [B, ld] with N <= ld valid columns; any 1 <= k <= N.  out_kth [B] = the k-th largest score; out_idx [B,k] int64 = the
+ * indices of the k winners under the canonical order (score descending, index ascending: of the scores equal to the
+ * k-th, the lowest indices), written in ASCENDING index order (the winners' mean is then summed in a fixed order).
+ * Exact radix select + ordered compaction, one workgroup per row, deterministic. */
+int ragraph_topk_select_rows_f32(const float* S, int64_t B, int64_t N, int64_t ld, int64_t k, float* out_kth,
+                                 int64_t* out_idx, void* stream);
 
 /* batch_pred[i, pos_list] = value  -- RAGraph_edge/utils/metrics.py:210-214 (_mask_history_pos, value = -1e8).
  * CSR (rowptr [B+1], col [nnz], both int64) lists the columns to overwrite in each row of S [B, ld]. */

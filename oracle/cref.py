@@ -240,3 +240,18 @@ def position_code(dist, anchors, dis_q=10.0):
     out = np.empty((n, A), dtype=np.float32)
     lib().oracle_position_code(_p(dist), _ci(n), _p(anchors), _ci(A), _cf(dis_q), _p(out))
     return out
+
+
+def topk_select_rows(S, k):
+    """Large k (RAGraph_edge/modules/RAGraph.py:57,73,308-321): the canonical top-k SET of every row -- score descending,
+    index ascending; of the scores equal to the k-th the lowest indices -- returned in ASCENDING index order, with the
+    k-th largest score.  numpy restatement (byte/index work): a stable sort by descending score IS the canonical order."""
+    S = _f32(S)
+    B, N = S.shape
+    kth = np.empty(B, dtype=np.float32)
+    idx = np.empty((B, k), dtype=np.int64)
+    for b in range(B):
+        order = np.argsort(-S[b], kind="stable")[:k]
+        kth[b] = S[b, order[-1]]
+        idx[b] = np.sort(order)
+    return kth, idx

@@ -532,6 +532,61 @@ def g11_noise():
              noise_idx=one_draw, retrieve_weight=np.float32(model.retrieve_weight), user_out=user_out, item_out=item_out)
 
 
+def g12_edge_large_k():
+    """RAGraph_edge vanilla phase with retrieve_num = 1000 over a 5000-row bank (modules/RAGraph.py:57,73: the koubei /
+    taobao settings retrieve 100000 neighbours; :308-321: only the mean of their values is consumed)."""
+    argv = ["x", "--device", "cpu", "--data_path", "dataset/amazon", "--log", "0", "--emb_dropout", "0"]
+    with ref_project("RAGraph_edge", argv=argv):
+        from modules.RAGraph import RAGraph
+
+        U, I, E, D, NB, K_ = 120, 80, 700, 64, 5000, 1000
+        rng = np.random.default_rng(30)
+        u = np.concatenate([rng.integers(0, U, E), np.repeat(np.arange(U), 2), rng.integers(0, U, 2 * I)])
+        i = np.concatenate([rng.integers(0, I, E), rng.integers(0, I, 2 * U), np.repeat(np.arange(I), 2)])
+        pairs = np.unique(np.stack([u, i], 1), axis=0)
+        u, i = pairs[:, 0], pairs[:, 1]
+        t = rng.integers(0, 720, len(u))
+        etd = {}
+        for a, b, tt in zip(u, i, t):
+            etd.setdefault(int(a), {})[int(b) + U] = int(tt)
+            etd.setdefault(int(b) + U, {})[int(a)] = int(tt)
+
+        class DS:
+            num_users, num_items = U, I
+            edge_time_dict = etd
+
+        DS.graph = sp.coo_matrix((np.ones(len(u)), (u, i)), shape=(U, I))
+        ue = 0.1 * torch.randn(U, D, generator=gen(65))
+        ie = 0.1 * torch.randn(I, D, generator=gen(66))
+
+        class Pre:
+            def generate(self):
+                return ue.clone(), ie.clone()
+
+        torch.manual_seed(8)
+        model = RAGraph(DS, Pre(), phase="vanilla", use_RAG=True, use_noise=False, use_LoRA=False)
+        model.eval()
+        # the bank proper is injected (the vanilla phase samples its own stochastically, :185-226): 5000 rows near the
+        # propagated embeddings, so that thousands of keys score alike -- the regime where a set, not a list, is wanted
+        with torch.no_grad():
+            all_emb = torch.cat([model.user_embedding, model.item_embedding], 0)
+        base = all_emb[torch.randint(0, U + I, (NB,), generator=gen(67))]
+        model.resource_keys = base + 0.05 * torch.randn(NB, D, generator=gen(68))
+        model.resource_values = torch.randn(NB, D, generator=gen(69))
+        model.retrieve_num, model.batch_size = K_, 64
+        with torch.no_grad():
+            S = torch.nn.functional.normalize(all_emb, dim=-1) @ torch.nn.functional.normalize(model.resource_keys, dim=-1).t()
+            top = torch.topk(S.double(), K_ + 1, dim=-1).values
+            boundary_gap = top[:, K_ - 1] - top[:, K_]       # the set is well defined where the k-th and (k+1)-th differ
+            user_out, item_out = model.generate()
+        print(f"  large-k fixture: rows with boundary gap > 1e-6: {100 * float((boundary_gap > 1e-6).double().mean()):.1f} %")
+        save("g12_edge_large_k", edges=model.edges, edge_norm=model.edge_norm, edge_times=model.edge_times,
+             num_users=np.int64(U), num_items=np.int64(I), user_embedding=model.user_embedding,
+             item_embedding=model.item_embedding, resource_keys=model.resource_keys, resource_values=model.resource_values,
+             retrieve_num=np.int64(K_), retrieve_weight=np.float32(model.retrieve_weight), boundary_gap=boundary_gap,
+             num_layers=np.int64(3), user_out=user_out, item_out=item_out)
+
+
 def main():
     assert os.path.isdir(REF), "the reference is only mounted in the build container"
     _install_shims()
@@ -544,6 +599,7 @@ def main():
     g9_edge()
     g8_fewshot_retrieve()
     g11_noise()
+    g12_edge_large_k()
 
 
 if __name__ == "__main__":

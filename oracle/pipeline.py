@@ -92,7 +92,10 @@ def edge_forward(edges, edge_norm, edge_times, gated_emb, resource_keys, resourc
     for _ in range(int(num_layers)):                                           # :280-283
         layers.append(cref.spmm_csr(rowptr, col, norm, layers[-1]))
     kn = cref.normalize_rows(resource_keys)
-    _, idx = cref.topk_cosine(layers[0], kn, int(k))                           # :298-311 (slabs do not change results)
+    if int(k) <= 64:
+        _, idx = cref.topk_cosine(layers[0], kn, int(k))                       # :298-311 (slabs do not change results)
+    else:  # vanilla phase: retrieve_num in the thousands (:57,73) -- only the winners' mean is consumed: the SET suffices
+        _, idx = cref.topk_select_rows(cref.linear(cref.normalize_rows(layers[0]), kn), int(k))
     rag, _ = cref.gather_reduce(resource_values, None, idx, v_scale=np.float32(1.0 / k))  # :314,321 mean over k
     acc = layers[0]
     for l in layers[1:]:                                                       # :327 sum(res_emb)

@@ -146,6 +146,14 @@ class RAGraph(nn.Module):
             if qs is not None:
                 lo, hi = qs.bounds(res[0].shape[0])
                 queries = res[0][lo:hi].contiguous()
+            if k > K.N.TOPK_MAX:
+                # vanilla phase (:57,73: retrieve_num = 50 ... 100000): only the winners' MEAN is consumed (:321), so the
+                # top-k SET is selected from score slabs (radix select) instead of sorted lists
+                rag = K.retrieve_mean_large_k(queries, self.keys_normalized, self.resource_values, k)
+                if qs is not None:
+                    rag = qs.gather_rows(rag, res[0].shape[0])
+                total = K.axpby(total, 1 - self.retrieve_weight, rag, self.retrieve_weight)    # :328
+                return total.split([self.num_users, self.num_items], dim=0)
             _, idx = self._index.topk(queries, k)
             if add_noise:
                 # (drawn from the default CPU generator as the reference does, :316; its per-slab draws of

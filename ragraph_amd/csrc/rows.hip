@@ -4,6 +4,8 @@
 //                                                             (RAGraph_node_fewshot/ragraph_utils/ToyGraphBase.py:58-64);
 //                                                             edge evaluation: top-20 of user x item ratings
 //                                                             (RAGraph_edge/utils/metrics.py:112-118)
+//   topk_select_rows the canonical top-k SET for large k       RAGraph_edge/modules/RAGraph.py:57,73,308-321 (vanilla phase:
+//                                                             retrieve_num in the thousands, only the winners' mean is used)
 //   scatter_fill     batch_pred[i, pos_list] = -1e8           RAGraph_edge/utils/metrics.py:210-214 (_mask_history_pos)
 //   floyd_warshall   min-plus all-pairs closure               ragraph_utils/PositionAwareEncoder.py:27-48
 //   position_code    1/(d+1) if d < dis_q else 0 to anchors   PositionAwareEncoder.py:6-24
@@ -131,6 +133,111 @@ __global__ void __launch_bounds__(256) topk_rows_kernel(const float* __restrict_
   }
 }
 
+// ---- large k: the canonical top-k SET of a materialised score row (k up to N) --------------------------------------
+// The edge flavour's vanilla phase retrieves with retrieve_num in the thousands and consumes only the MEAN of the
+// winners' values (RAGraph_edge/modules/RAGraph.py:57,73,308-321): sorted lists are not needed, the set is.  One
+// workgroup per row: an exact radix select of the k-th largest score (four 8-bit passes over an order-preserving
+// integer image of the floats, 256-bin histograms in LDS), then one ordered pass that writes the indices of every score
+// above it and of the first (k - #above) scores equal to it -- the canonical tie rule (score descending, index
+// ascending) -- in ASCENDING index order.  Deterministic: no atomics on global memory, positions by prefix sums.
+__device__ __forceinline__ unsigned select_key(float f) {  // larger float -> larger unsigned
+  unsigned b = __float_as_uint(f);
+  if (b == 0x80000000u) b = 0;  // -0 and +0 are one score (they compare equal: a tie, broken by index)
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ void __launch_bounds__(256) topk_select_rows_kernel(const float* __restrict__ S, int64_t N, int64_t ld, int64_t k,
+                                                               float* __restrict__ out_kth, int64_t* __restrict__ out_idx) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned sh_prefix, sh_need;
+  __shared__ unsigned wsum_gt[4], wsum_eq[4];
+  __shared__ unsigned long long sh_sel_before;
+  __shared__ unsigned sh_eq_before;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = S + (int64_t)blockIdx.x * ld;
+  // ---- radix select: after the pass over digit d (most significant first), `prefix` holds the top digits of the k-th
+  // largest key and `need` how many keys with that prefix are still to be taken
+  unsigned prefix = 0, mask = 0;
+  unsigned need = (unsigned)k;  // k <= N < 2^31
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    hist[tid] = 0;
+    __syncthreads();
+    for (int64_t e = tid; e < N; e += 256) {
+      const unsigned key = select_key(row[e]);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned acc = 0;
+      int d = 255;
+      for (; d > 0; --d) {
+        if (acc + hist[d] >= need) break;
+        acc += hist[d];
+      }
+      sh_prefix = prefix | ((unsigned)d << shift);
+      sh_need = need - acc;
+    }
+    __syncthreads();
+    prefix = sh_prefix;
+    need = sh_need;
+    mask |= 255u << shift;
+    __syncthreads();
+  }
+  const unsigned kth_key = prefix;  // the k-th largest key; `need` of the keys equal to it are taken (lowest indices)
+  if (tid == 0) {
+    const unsigned b = (kth_key & 0x80000000u) ? (kth_key & 0x7FFFFFFFu) : ~kth_key;
+    out_kth[blockIdx.x] = __uint_as_float(b);
+    sh_sel_before = 0;
+    sh_eq_before = 0;
+  }
+  __syncthreads();
+  // ---- ordered compaction, 256 scores per round
+  int64_t* out = out_idx + (int64_t)blockIdx.x * k;
+  for (int64_t e0 = 0; e0 < N; e0 += 256) {
+    const int64_t e = e0 + tid;
+    unsigned key = 0;
+    bool gt = false, eq = false;
+    if (e < N) {
+      key = select_key(row[e]);
+      gt = key > kth_key;
+      eq = key == kth_key;
+    }
+    const unsigned long long bg = __ballot(gt), be = __ballot(eq);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (lane == 0) {
+      wsum_gt[wave] = (unsigned)__popcll(bg);
+      wsum_eq[wave] = (unsigned)__popcll(be);
+    }
+    __syncthreads();
+    unsigned gt_before = 0, eq_before_w = 0;
+    for (int w = 0; w < wave; ++w) {
+      gt_before += wsum_gt[w];
+      eq_before_w += wsum_eq[w];
+    }
+    const unsigned eq_rank = sh_eq_before + eq_before_w + (unsigned)__popcll(be & below);  // among ALL equals so far
+    const bool sel = gt || (eq && eq_rank < need);
+    // selected equals before this element (in this round) = equals before it whose rank < need
+    const unsigned eq_taken_before_round = sh_eq_before < need ? sh_eq_before : need;
+    const unsigned eq_before_here = sh_eq_before + eq_before_w + (unsigned)__popcll(be & below);
+    const unsigned eq_taken_before_here = (eq_before_here < need ? eq_before_here : need) - eq_taken_before_round;
+    const unsigned long long pos = sh_sel_before + gt_before + (unsigned)__popcll(bg & below) + eq_taken_before_here;
+    if (sel) out[pos] = e;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned tg = 0, te = 0;
+      for (int w = 0; w < 4; ++w) {
+        tg += wsum_gt[w];
+        te += wsum_eq[w];
+      }
+      const unsigned eq_after = sh_eq_before + te;
+      const unsigned taken = (eq_after < need ? eq_after : need) - eq_taken_before_round;
+      sh_sel_before += tg + taken;
+      sh_eq_before = eq_after;
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void __launch_bounds__(256) scatter_fill_kernel(float* __restrict__ S, int64_t ld,
                                                            const int64_t* __restrict__ rowptr,
                                                            const int64_t* __restrict__ col, float value) {
@@ -183,6 +290,19 @@ extern "C" int ragraph_topk_rows_f32(const float* S, int64_t B, int64_t N, int64
   hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)B), dim3(256), 0, as_stream(stream), S, N, ld, k, out_scores,
                      out_idx);
   RG_CHECK_LAUNCH("topk_rows");
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_topk_select_rows_f32(const float* S, int64_t B, int64_t N, int64_t ld, int64_t k, float* out_kth,
+                                            int64_t* out_idx, void* stream) {
+  RG_REQUIRE(S && out_kth && out_idx, RAGRAPH_EINVAL, "topk_select_rows: null pointer");
+  RG_REQUIRE(B >= 0 && N >= 1 && ld >= N, RAGRAPH_EINVAL, "topk_select_rows: bad shape");
+  RG_REQUIRE(k >= 1 && k <= N, RAGRAPH_EINVAL, "topk_select_rows: k=%lld out of range for N=%lld", (long long)k, (long long)N);
+  RG_REQUIRE(N < (int64_t)INT_MAX, RAGRAPH_EUNSUPPORTED, "topk_select_rows: N must fit int32");
+  if (B == 0) return RAGRAPH_OK;
+  hipLaunchKernelGGL(topk_select_rows_kernel, dim3((unsigned)B), dim3(256), 0, as_stream(stream), S, N, ld, k, out_kth,
+                     out_idx);
+  RG_CHECK_LAUNCH("topk_select_rows");
   return RAGRAPH_OK;
 }
 

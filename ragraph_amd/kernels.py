@@ -419,6 +419,39 @@ def topk_rows(scores: torch.Tensor, k: int):
     return out_s, out_i
 
 
+def topk_select_rows(scores: torch.Tensor, k: int):
+    """The canonical top-k SET of every row for any k <= N: (kth [B], idx [B,k] in ascending index order) -- the edge
+    flavour's vanilla-phase retrieval (RAGraph_edge/modules/RAGraph.py:57,73,308-321), which only averages the winners."""
+    L = _ready()
+    s = _f32c(scores, "topk_select_rows.scores")
+    if s.dim() != 2:
+        raise RagraphNativeError(f"topk_select_rows: expected [B,N], got {tuple(s.shape)}")
+    B, Nn = s.shape
+    kth = torch.empty(B, dtype=torch.float32, device=s.device)
+    idx = torch.empty((B, k), dtype=torch.int64, device=s.device)
+    N.check(L.ragraph_topk_select_rows_f32(s.data_ptr(), B, Nn, Nn, k, kth.data_ptr(), idx.data_ptr(), _stream()),
+            "topk_select_rows")
+    return kth, idx
+
+
+def retrieve_mean_large_k(q: torch.Tensor, keys_normalized: torch.Tensor, values: torch.Tensor, k: int,
+                          slab_bytes: int = 1 << 30) -> torch.Tensor:
+    """mean_k V[top-k(q)] for k beyond the fused kernels' lists (k > 64): score slabs by the dense kernel (the same
+    fmaf chains as every other path), topk_select_rows, gather_reduce with v_scale = 1/k in ascending index order.
+    RAGraph_edge/modules/RAGraph.py:298-324 with retrieve_num = 50 ... 100000."""
+    q = _f32c(q, "retrieve_mean_large_k.q")
+    kn = _f32c(keys_normalized, "retrieve_mean_large_k.keys")
+    B, Nk = q.shape[0], kn.shape[0]
+    qn = normalize_rows(q)
+    rows = max(1, min(B, slab_bytes // (4 * Nk)))
+    out = torch.empty((B, values.shape[1]), dtype=torch.float32, device=q.device)
+    for b0 in range(0, B, rows):
+        S = linear(qn[b0:b0 + rows], kn)
+        _, idx = topk_select_rows(S, k)
+        out[b0:b0 + rows], _ = gather_reduce(values, None, idx, v_scale=1.0 / k)
+    return out
+
+
 def scatter_fill_(scores: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, value: float) -> torch.Tensor:
     """In place: scores[b, col[rowptr[b]:rowptr[b+1]]] = value -- metrics.py:210-214 (_mask_history_pos)."""
     L = _ready()

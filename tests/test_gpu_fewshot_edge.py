@@ -16,6 +16,10 @@ def T(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
+def gold(name):
+    return dict(np.load(os.path.join(GOLD, name + ".npz")))
+
+
 @pytest.mark.parametrize("B,N,k", [(1, 10, 10), (5, 1000, 20), (64, 107029, 20), (7, 4099, 64), (3, 257, 1)])
 def test_topk_rows_bit_exact(dev, B, N, k):
     from ragraph_amd import kernels as K
@@ -138,3 +142,53 @@ def test_edge_eval_topk_items(dev):
     truth = [set(rng.choice(I, 5, replace=False).tolist()) for _ in users]
     rec, ndcg = edge_eval.recall_ndcg(idx.cpu().numpy(), truth, k)
     assert 0.0 <= rec <= 1.0 and 0.0 <= ndcg <= 1.0
+
+
+def test_topk_select_rows_matches_oracle(dev):
+    """The canonical top-k SET for large k: ties at the k-th place (duplicates, constant rows), k = 1, k = N, negative and
+    zero scores, row strides that are not multiples of 256 -- index sets bit-exact vs the oracle."""
+    from ragraph_amd import kernels as K
+
+    rng = np.random.default_rng(12)
+    for (B, N, k) in [(5, 1000, 1), (7, 1000, 1000), (9, 5000, 1000), (3, 70001, 33333), (4, 513, 257), (2, 100, 64)]:
+        S = rng.standard_normal((B, N)).astype(np.float32)
+        S[0, : N // 2] = S[0, N // 2: 2 * (N // 2)]        # exact duplicates: ties everywhere
+        S[1] = 0.25                                          # a constant row: the first k indices win
+        if B > 2:
+            S[2, ::3] = 0.0
+            S[2, 1::3] = -0.0
+        kth, idx = K.topk_select_rows(torch.from_numpy(S).to(dev), k)
+        rk, ri = cref.topk_select_rows(S, k)
+        assert np.array_equal(idx.cpu().numpy(), ri), (B, N, k)
+        assert np.array_equal(kth.cpu().numpy(), rk), (B, N, k)
+
+
+def test_edge_vanilla_large_k_g12(dev):
+    """RAGraph_edge vanilla phase, retrieve_num = 1000 over a 5000-row bank: the reference's generate() (golden g12) and
+    the oracle composition (retrieval part bit for bit: test_topk_select_rows_matches_oracle)."""
+    from ragraph_amd.RAGraph_edge import RAGraph as RAGraphEdge
+
+    g = gold("g12_edge_large_k")
+    U, I = int(g["num_users"]), int(g["num_items"])
+
+    class DS:
+        num_users, num_items = U, I
+        edges, edge_norm, edge_times = T(g["edges"], dev), T(g["edge_norm"], dev), T(g["edge_times"], dev)
+
+    class Pre:
+        def generate(self):
+            return T(g["user_embedding"], dev), T(g["item_embedding"], dev)
+
+    m = RAGraphEdge(DS, Pre(), phase="vanilla", use_RAG=False, retrieve_num=int(g["retrieve_num"]),
+                    retrieve_weight=float(g["retrieve_weight"]), device=dev).eval()
+    m.use_RAG = True
+    m.resource_keys, m.resource_values = T(g["resource_keys"], dev), T(g["resource_values"], dev)
+    uo, io = m.generate()
+    out = torch.cat([uo, io]).cpu().numpy()
+    ref = np.concatenate([g["user_out"], g["item_out"]])
+    ok = g["boundary_gap"] > 1e-6
+    assert np.allclose(out[ok], ref[ok], atol=2e-5)
+    all_emb = np.concatenate([g["user_embedding"], g["item_embedding"]])
+    o, _, _, _, _ = pipeline.edge_forward(g["edges"], g["edge_norm"], g["edge_times"], all_emb, g["resource_keys"],
+                                          g["resource_values"], int(g["retrieve_num"]), float(g["retrieve_weight"]), 3)
+    assert np.allclose(out, o, atol=1e-6)   # (the time softmax calls expf: oracle and device libm agree to 1e-6)

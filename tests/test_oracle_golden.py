@@ -162,3 +162,23 @@ def test_g11_add_noise_branches():
     torch.manual_seed(int(g["seed"]))
     noise = torch.normal(mean=0, std=float(g["noise_std"]), size=e.shape).numpy()
     assert np.array_equal(e + noise, g["rag_embeddings"])
+
+
+def test_g12_edge_large_k():
+    """Vanilla-phase retrieval with retrieve_num = 1000 (modules/RAGraph.py:57,73,308-321): the oracle's top-k SET +
+    mean against the reference's generate() on the rows whose k-th / (k+1)-th scores differ."""
+    g = gold("g12_edge_large_k")
+    all_emb = np.concatenate([g["user_embedding"], g["item_embedding"]])
+    out, idx, layers, tn, csr = pipeline.edge_forward(g["edges"], g["edge_norm"], g["edge_times"], all_emb, g["resource_keys"],
+                                                      g["resource_values"], int(g["retrieve_num"]), float(g["retrieve_weight"]),
+                                                      int(g["num_layers"]))
+    ref = np.concatenate([g["user_out"], g["item_out"]])
+    ok = g["boundary_gap"] > 1e-6
+    assert ok.mean() > 0.95
+    assert np.allclose(out[ok], ref[ok], atol=2e-5)
+    assert idx.shape == (all_emb.shape[0], int(g["retrieve_num"])) and (np.diff(idx, axis=1) > 0).all()
+    # the set is the canonical one: k-th score = the k-th largest, every member scores >= it
+    S = cref.linear(cref.normalize_rows(all_emb), cref.normalize_rows(g["resource_keys"]))
+    kth, idx2 = cref.topk_select_rows(S[:7], 1000)
+    for b in range(7):
+        assert kth[b] == np.sort(S[b])[::-1][999] and S[b, idx2[b]].min() == kth[b]
