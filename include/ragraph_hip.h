@@ -296,6 +296,37 @@ int ragraph_floyd_warshall_f32(const float* adj, int n, float* dist, void* strea
 int ragraph_position_code_f32(const float* dist, int n, const int64_t* anchors, int A, float dis_q, float* out,
                               void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Toy-bank construction (the step before the hot path), batched over resource graphs.
+ *
+ * InverseSampling.pagerank_algorithm  -- RAGraph_node/ragraph_utils/InverseSampling.py:22-47 (dense);
+ *   RAGraph_edge/modules/ragraph_utils/InverseSampling.py:22-60 (sparse): p = 1/N; repeat new_p = (1-d)/N + d (P^T p +
+ *   dangling mass / N) until ||new_p - p||_1 < eps, returning the iterate BEFORE the converged step (break precedes the
+ *   assignment, :41-43).  The batch is one block-diagonal matrix: graph g owns nodes [graph_ptr[g], graph_ptr[g+1]),
+ *   graph_of[i] = g; a single big graph is G = 1.  (rowptrT, colT, valT) = CSR of the TRANSPOSED adjacency (row j lists
+ *   the i with adj[i][j] != 0, valT = adj[i][j]); out_deg[i] = sum_j adj[i][j] (ragraph_csr_row_sums_f32 of the
+ *   adjacency).  max_iter power iterations are enqueued back to back (converged graphs skip theirs on the device; d = 0.85
+ *   and eps = 1e-6 converge within ~90); iters[g] = iterations graph g took, max_iter if it did not converge.
+ *   No host synchronisation.  ws: ragraph_pagerank_workspace_bytes(n, G). */
+size_t ragraph_pagerank_workspace_bytes(int64_t n, int64_t G);
+int ragraph_pagerank_f32(const int64_t* rowptrT, const int32_t* colT, const float* valT, const float* out_deg,
+                         const int64_t* graph_ptr, const int32_t* graph_of, int64_t G, int64_t n, float d, float eps,
+                         int max_iter, float* p, int* iters, void* ws, size_t ws_bytes, void* stream);
+/* InverseSampling.compute_sample_prob (:6-19) with degree_centrality_algorithm (:50-56): importance = alpha * pagerank +
+ * (1 - alpha) * col_sum / (N_g - 1); prob = (1 / (importance + eps)) / (sum over graph g).  col_sum = column sums of the
+ * adjacency (ragraph_csr_row_sums_f32 of its transposed CSR). */
+int ragraph_sample_prob_f32(const float* pagerank, const float* col_sum, const int64_t* graph_ptr, int64_t G, float alpha,
+                            float eps, float* prob, void* stream);
+/* out[r] = sum of row r of a CSR matrix, sequential fp32 adds in CSR order (torch.sum(adj, dim=1) / dim=0 on the
+ * transposed CSR: InverseSampling.py:25,53). */
+int ragraph_csr_row_sums_f32(const int64_t* rowptr, const float* val, int64_t n, float* out, void* stream);
+/* PositionAwareEncoder.encode_position_aware_code (PositionAwareEncoder.py:6-24) for G graphs of n <= 64 nodes at once
+ * (the sampled toy graphs, ToyGraphBase.py:114: n = num_inverse_sample = 10): adj [G,n,n] dense, anchors [G,A] int64
+ * (drawn by the caller: the reference uses torch.randint), codes [G,n,A]; dist_out [G,n,n] optional (the Floyd-Warshall
+ * closure of :27-48). */
+int ragraph_position_codes_batch_f32(const float* adj, int64_t G, int n, const int64_t* anchors, int A, float dis_q,
+                                     float* dist_out, float* codes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -255,3 +255,53 @@ def topk_select_rows(S, k):
         kth[b] = S[b, order[-1]]
         idx[b] = np.sort(order)
     return kth, idx
+
+
+# ---- toy-bank construction --------------------------------------------------------------
+def csr_row_sums(rowptr, val):
+    rowptr, val = _i64(rowptr), _f32(val)
+    out = np.empty(rowptr.shape[0] - 1, dtype=np.float32)
+    lib().oracle_csr_row_sums(_p(rowptr), _p(val), _c64(out.shape[0]), _p(out))
+    return out
+
+
+def pagerank(rowptr_t, col_t, val_t, out_deg, graph_ptr, d=0.85, eps=1e-6, max_iter=128):
+    """InverseSampling.pagerank_algorithm over a batch of graphs (transposed CSR, see ragraph_hip.h) -> (p, iters)."""
+    rowptr_t, col_t, val_t, out_deg, graph_ptr = _i64(rowptr_t), _i32(col_t), _f32(val_t), _f32(out_deg), _i64(graph_ptr)
+    p = np.empty(out_deg.shape[0], dtype=np.float32)
+    iters = np.empty(graph_ptr.shape[0] - 1, dtype=np.int32)
+    lib().oracle_pagerank(_p(rowptr_t), _p(col_t), _p(val_t), _p(out_deg), _p(graph_ptr), _c64(iters.shape[0]), _cf(d), _cf(eps),
+                          _ci(max_iter), _p(p), _p(iters))
+    return p, iters
+
+
+def sample_prob(pagerank_p, col_sum, graph_ptr, alpha=0.5, eps=1e-6):
+    pr, cs, graph_ptr = _f32(pagerank_p), _f32(col_sum), _i64(graph_ptr)
+    out = np.empty_like(pr)
+    lib().oracle_sample_prob(_p(pr), _p(cs), _p(graph_ptr), _c64(graph_ptr.shape[0] - 1), _cf(alpha), _cf(eps), _p(out))
+    return out
+
+
+def dense_to_csr_t(adj):
+    """CSR of the TRANSPOSED dense matrix (row j lists the i with adj[i][j] != 0, ascending i) + the row sums of adj."""
+    a = _f32(adj)
+    rowptr, col, val = dense_to_csr(np.ascontiguousarray(a.T))
+    return rowptr, col, val
+
+
+def compute_sample_prob_dense(adj):
+    """InverseSampling.compute_sample_prob(adj) for one dense adjacency: (prob, pagerank, iters)."""
+    a = _f32(adj)
+    n = a.shape[0]
+    rowptr, col, val = dense_to_csr(a)
+    rt, ct, vt = dense_to_csr_t(a)
+    gp = np.array([0, n], dtype=np.int64)
+    out_deg = csr_row_sums(rowptr, val)
+    p, it = pagerank(rt, ct, vt, out_deg, gp)
+    return sample_prob(p, csr_row_sums(rt, vt), gp), p, it
+
+
+def position_codes_batch(adj, anchors, dis_q=10.0):
+    """PositionAwareEncoder.encode_position_aware_code for G small graphs: adj [G,n,n], anchors [G,A] -> [G,n,A]."""
+    adj, anchors = _f32(adj), _i64(anchors)
+    return np.stack([position_code(floyd_warshall(adj[g]), anchors[g], dis_q) for g in range(adj.shape[0])])

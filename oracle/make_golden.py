@@ -587,6 +587,59 @@ def g12_edge_large_k():
              num_layers=np.int64(3), user_out=user_out, item_out=item_out)
 
 
+def g13_bank_build():
+    """The deterministic parts of the toy-bank construction: InverseSampling (dense node flavour + sparse edge flavour) and
+    the position-aware codes of a sampled toy graph with the randint anchors pinned by torch.manual_seed."""
+    out = {}
+    with ref_project("RAGraph_node"):
+        from ragraph_utils.InverseSampling import InverseSampling
+        from ragraph_utils.PositionAwareEncoder import PositionAwareEncoder
+
+        adj = random_graph_adj(41, 3.2, seed=91)                       # D^-1/2 (A+I) D^-1/2, as process_tu_dataset makes it
+        out["adj_norm"] = adj
+        out["adj_norm_pagerank"] = InverseSampling.pagerank_algorithm(adj.clone())
+        out["adj_norm_degree_centrality"] = InverseSampling.degree_centrality_algorithm(adj)
+        out["adj_norm_sample_prob"] = InverseSampling.compute_sample_prob(adj.clone())
+        # an augmented adjacency as Augmentation.augment_adj leaves it: 0/1, asymmetric, with rows that have no out-edge
+        rw = (torch.rand(33, 33, generator=gen(92)) < 0.08).float()
+        rw[4] = 0
+        rw[17] = 0
+        out["adj_rewired"] = rw
+        out["adj_rewired_pagerank"] = InverseSampling.pagerank_algorithm(rw.clone())
+        out["adj_rewired_sample_prob"] = InverseSampling.compute_sample_prob(rw.clone())
+        # position codes of a sampled 10-node toy graph (ToyGraphBase.py:98-100,114: adj[mask][:, mask], repeats allowed)
+        mask = torch.randint(0, 41, (10,), generator=gen(93))
+        sample_adj = adj[mask, :][:, mask]
+        torch.manual_seed(777)
+        anchors = torch.randint(low=0, high=10, size=(10,))
+        torch.manual_seed(777)
+        out["sample_mask"], out["sample_adj"], out["anchors"] = mask, sample_adj, anchors
+        out["position_codes"] = PositionAwareEncoder.encode_position_aware_code(sample_adj, 10, 10)
+        out["sample_dist"] = PositionAwareEncoder.floyd_warshall(sample_adj)
+    argv = ["x", "--device", "cpu", "--data_path", "dataset/amazon", "--log", "0", "--emb_dropout", "0"]
+    with ref_project("RAGraph_edge", argv=argv):
+        from modules.base_model import BaseModel
+        from modules.ragraph_utils.InverseSampling import InverseSampling as EdgeIS
+
+        U, I = 50, 30
+        rng = np.random.default_rng(94)
+        u, i = rng.integers(0, U, 260), rng.integers(0, I, 260)
+        u[u == 7] = 8                                                    # user 7 has no interaction: a zero row
+        graph = sp.coo_matrix((np.ones(len(u)), (u, i)), shape=(U, I))
+
+        class DL:
+            num_users, num_items = U, I
+
+        bm = BaseModel(DL)
+        adj = bm._make_binorm_adj(graph).coalesce()
+        out["edge_u"], out["edge_i"] = u, i
+        out["edge_adj_indices"], out["edge_adj_values"] = adj.indices(), adj.values()
+        out["edge_pagerank"] = EdgeIS.pagerank_algorithm(adj)
+        out["edge_degree_centrality"] = EdgeIS.degree_centrality_algorithm(adj)
+        out["edge_sample_prob"] = EdgeIS.compute_sample_prob(adj)
+    save("g13_bank_build", **out)
+
+
 def main():
     assert os.path.isdir(REF), "the reference is only mounted in the build container"
     _install_shims()
@@ -600,6 +653,7 @@ def main():
     g8_fewshot_retrieve()
     g11_noise()
     g12_edge_large_k()
+    g13_bank_build()
 
 
 if __name__ == "__main__":

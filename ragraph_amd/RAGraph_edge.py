@@ -14,7 +14,7 @@ from .graph import CSRGraph
 class RAGraph(nn.Module):
     def __init__(self, dataset, pretrained_model=None, phase="finetune", use_RAG=True, use_noise=False,
                  use_LoRA=False, LoRA_rank=16, emb_size=64, num_layers=3, retrieve_num=10, retrieve_weight=0.3,
-                 batch_size=4096, device="cuda"):
+                 batch_size=4096, device="cuda", num_augment_scale=0, num_inverse_sample=0):
         """dataset: .num_users, .num_items, .edges [2E,2] int64 (src,dst, both directions), .edge_norm [2E] fp32,
         .edge_times [2E] int64 (the tensors modules/RAGraph.py:22-27 derives from the scipy graph).
         pretrained_model: .generate() -> (user_emb, item_emb)."""
@@ -30,6 +30,9 @@ class RAGraph(nn.Module):
         self.use_noise = use_noise and phase == "finetune"
         self.retrieve_weight, self.retrieve_num, self.batch_size = retrieve_weight, retrieve_num, batch_size  # :33-85
         self.noise_retrieve_num = 1
+        # bank construction (modules/RAGraph.py:38-44,56-62): the vanilla phase keeps an inverse-importance SAMPLE of the
+        # nodes (round(0.01 n) draws) of the original and of num_augment_scale feature-augmented copies
+        self.num_augment_scale, self.num_inverse_sample = num_augment_scale, num_inverse_sample
         self.resource_keys = self.resource_values = None
         self._keys_normalized = self._index = None
         self._csr_cache = None
@@ -107,8 +110,39 @@ class RAGraph(nn.Module):
         vals = res[0]
         for r in res[2::2]:
             vals = K.axpby(vals, 1.0, r, 1.0)
-        self.resource_keys, self.resource_values = res[-1], vals
+        keys = res[-1]
+        if self.num_inverse_sample > 0 or self.num_augment_scale > 0:
+            keys, vals = self._sample_bank(keys, vals)
+        self.resource_keys, self.resource_values = keys, vals
         self._keys_normalized = self._index = None
+
+    def sample_prob(self):
+        """InverseSampling.compute_sample_prob(self.adj) (modules/ragraph_utils/InverseSampling.py:6-19) on the
+        bi-normalised bipartite adjacency: sparse PageRank + degree centrality on the HIP kernels, no host round trip."""
+        from .bank_build import compute_sample_prob
+        n = self.num_users + self.num_items
+        g, _ = CSRGraph.from_coo(self.edges[:, 0], self.edges[:, 1], self.edge_norm, n, sort_cols=True)
+        return compute_sample_prob(g)
+
+    def _sample_bank(self, all_emb, all_logits):
+        """modules/RAGraph.py:199-226: the original embeddings and num_augment_scale noisy / dropped copies
+        (Augmentation.augment_features, modules/ragraph_utils/Augmentation.py:8-22), each cut down to num_inverse_sample
+        rows drawn with replacement by inverse importance.  The draws come from torch's RNG (as the reference's)."""
+        prob = self.sample_prob()                                                  # :201
+        keys_out, vals_out = [], []
+        for i in range(1 + self.num_augment_scale):                                # :203-204
+            k, v = all_emb, all_logits
+            if i > 0:                                                              # :206-208
+                def aug(x):
+                    noisy = x + torch.randn_like(x) * 0.1
+                    return noisy * torch.bernoulli(prob * 0.01).unsqueeze(-1)
+                k, v = aug(all_emb), aug(all_logits)
+            if self.num_inverse_sample > 0:                                        # :214-218
+                mask = torch.multinomial(prob, num_samples=self.num_inverse_sample, replacement=True)
+                k, v = K.gather_rows(k, mask), K.gather_rows(v, mask)
+            keys_out.append(k)
+            vals_out.append(v)
+        return torch.cat(keys_out, 0), torch.cat(vals_out, 0)                      # :220-226
 
     @property
     def keys_normalized(self):

@@ -504,3 +504,65 @@ def time_rescale(t: torch.Tensor, t_min: float, t_max: float) -> torch.Tensor:
     N.check(L.ragraph_time_rescale_f32(t.data_ptr(), t.numel(), float(t_min), float(t_max), out.data_ptr(), _stream()),
             "time_rescale")
     return out
+
+
+# ---- toy-bank construction --------------------------------------------------------------
+def csr_row_sums(rowptr: torch.Tensor, val: torch.Tensor) -> torch.Tensor:
+    """Row sums of a CSR matrix (torch.sum(adj, dim=1); dim=0 on the transposed CSR) -- InverseSampling.py:25,53."""
+    L = _ready()
+    rowptr = _idxc(rowptr, "csr_row_sums.rowptr")
+    val = _f32c(val, "csr_row_sums.val")
+    out = torch.empty(rowptr.numel() - 1, dtype=torch.float32, device=val.device)
+    N.check(L.ragraph_csr_row_sums_f32(rowptr.data_ptr(), val.data_ptr(), out.numel(), out.data_ptr(), _stream()),
+            "csr_row_sums")
+    return out
+
+
+def pagerank(rowptr_t: torch.Tensor, col_t: torch.Tensor, val_t: torch.Tensor, out_deg: torch.Tensor,
+             graph_ptr: torch.Tensor, d: float = 0.85, eps: float = 1e-6, max_iter: int = 128):
+    """InverseSampling.pagerank_algorithm for a batch of graphs (segments of one block-diagonal transposed CSR), all
+    power iterations enqueued without a host round trip.  Returns (p [n], iters [G] int32)."""
+    L = _ready()
+    rowptr_t = _idxc(rowptr_t, "pagerank.rowptr")
+    col_t = _idxc(col_t, "pagerank.col", torch.int32)
+    val_t = _f32c(val_t, "pagerank.val")
+    out_deg = _f32c(out_deg, "pagerank.out_deg")
+    graph_ptr = _idxc(graph_ptr, "pagerank.graph_ptr")
+    n, G = out_deg.numel(), graph_ptr.numel() - 1
+    sizes = graph_ptr[1:] - graph_ptr[:-1]
+    graph_of = torch.repeat_interleave(torch.arange(G, device=out_deg.device, dtype=torch.int32), sizes)
+    p = torch.empty(n, dtype=torch.float32, device=out_deg.device)
+    iters = torch.empty(G, dtype=torch.int32, device=out_deg.device)
+    ws = _workspace(L.ragraph_pagerank_workspace_bytes(n, G), out_deg.device)
+    N.check(L.ragraph_pagerank_f32(rowptr_t.data_ptr(), col_t.data_ptr(), val_t.data_ptr(), out_deg.data_ptr(),
+                                   graph_ptr.data_ptr(), graph_of.data_ptr(), G, n, float(d), float(eps), int(max_iter),
+                                   p.data_ptr(), iters.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "pagerank")
+    return p, iters
+
+
+def sample_prob(pagerank_p: torch.Tensor, col_sum: torch.Tensor, graph_ptr: torch.Tensor, alpha: float = 0.5,
+                eps: float = 1e-6) -> torch.Tensor:
+    """InverseSampling.compute_sample_prob (:6-19): inverse-importance sampling probabilities per graph."""
+    L = _ready()
+    pr = _f32c(pagerank_p, "sample_prob.pagerank")
+    cs = _f32c(col_sum, "sample_prob.col_sum")
+    graph_ptr = _idxc(graph_ptr, "sample_prob.graph_ptr")
+    out = torch.empty_like(pr)
+    N.check(L.ragraph_sample_prob_f32(pr.data_ptr(), cs.data_ptr(), graph_ptr.data_ptr(), graph_ptr.numel() - 1, float(alpha),
+                                      float(eps), out.data_ptr(), _stream()), "sample_prob")
+    return out
+
+
+def position_codes_batch(adj: torch.Tensor, anchors: torch.Tensor, dis_q: float = 10.0, return_dist: bool = False):
+    """PositionAwareEncoder.encode_position_aware_code for G graphs of n <= 64 nodes: adj [G,n,n], anchors [G,A] ->
+    codes [G,n,A] (and the all-pairs distances [G,n,n])."""
+    L = _ready()
+    a = _f32c(adj, "position_codes_batch.adj")
+    anchors = _idxc(anchors, "position_codes_batch.anchors")
+    G, n, _ = a.shape
+    A = anchors.shape[1]
+    codes = torch.empty((G, n, A), dtype=torch.float32, device=a.device)
+    dist = torch.empty_like(a) if return_dist else None
+    N.check(L.ragraph_position_codes_batch_f32(a.data_ptr(), G, n, anchors.data_ptr(), A, float(dis_q), _ptr(dist),
+                                               codes.data_ptr(), _stream()), "position_codes_batch")
+    return (codes, dist) if return_dist else codes

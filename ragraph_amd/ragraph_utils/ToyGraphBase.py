@@ -55,6 +55,8 @@ class ToyGraphBase:
         self._keys = _Bank(emb_size, self.device)
         self._values = _Bank(emb_size, self.device)
         self._labels = _Bank(num_class, self.device)
+        self.num_anchors, self.dis_q = 10, 10             # ToyGraphBase.py:27-28
+        self._positions = _Bank(self.num_anchors, self.device)   # position-aware codes of the sampled toy graphs (:114,119)
         self._keys_normalized = None  # cache, invalidated by every append
         self._index = None            # K.KeyIndex of this bank version (packed / bf16 copies made on first use)
 
@@ -71,12 +73,19 @@ class ToyGraphBase:
     def resource_labels(self) -> Tensor:
         return self._labels.view()
 
-    def add_resources(self, keys: Tensor, values: Tensor, labels: Tensor) -> None:
+    @property
+    def resource_positions(self) -> Tensor:
+        return self._positions.view()
+
+    def add_resources(self, keys: Tensor, values: Tensor, labels: Tensor, positions: Tensor | None = None) -> None:
         """Append rows to the bank (what ToyGraphBase.py:116-119 does with torch.cat)."""
         assert keys.shape[0] == values.shape[0] == labels.shape[0]
         self._keys.append(keys)
         self._values.append(values)
         self._labels.append(labels)
+        if positions is not None:
+            assert positions.shape[0] == keys.shape[0]
+            self._positions.append(positions)
         self._keys_normalized = self._index = None
 
     def set_resources(self, keys: Tensor, values: Tensor, labels: Tensor) -> None:
@@ -171,4 +180,5 @@ class ToyGraphBase:
         print("resource_keys", self.resource_keys.shape)
         print("resource_values", self.resource_values.shape)
         print("resource_labels", self.resource_labels.shape)
+        print("resource positions", self.resource_positions.shape)
         print("label count distribution", torch.sum(self.resource_labels, dim=0))

@@ -182,3 +182,26 @@ def test_g12_edge_large_k():
     kth, idx2 = cref.topk_select_rows(S[:7], 1000)
     for b in range(7):
         assert kth[b] == np.sort(S[b])[::-1][999] and S[b, idx2[b]].min() == kth[b]
+
+
+def test_g13_bank_build_deterministic_parts():
+    """InverseSampling (dense + sparse) and the position codes of a sampled toy graph: oracle vs the reference."""
+    g = gold("g13_bank_build")
+    for tag in ("adj_norm", "adj_rewired"):
+        prob, p, it = cref.compute_sample_prob_dense(g[tag])
+        assert np.allclose(p, g[tag + "_pagerank"], atol=2e-6) and 1 <= int(it[0]) < 128
+        assert np.allclose(prob, g[tag + "_sample_prob"], rtol=2e-5, atol=1e-7)
+    rt, ct, vt = cref.dense_to_csr_t(g["adj_norm"])
+    assert np.allclose(cref.csr_row_sums(rt, vt) / np.float32(g["adj_norm"].shape[0] - 1), g["adj_norm_degree_centrality"], atol=1e-7)
+    # sparse (edge) flavour: the bi-normalised bipartite adjacency as a COO list
+    n = 80
+    r, c = g["edge_adj_indices"]
+    dense = np.zeros((n, n), np.float32)
+    dense[r, c] = g["edge_adj_values"]
+    prob, p, it = cref.compute_sample_prob_dense(dense)
+    assert np.allclose(p, g["edge_pagerank"], atol=2e-6)
+    assert np.allclose(prob, g["edge_sample_prob"], rtol=2e-5, atol=1e-7)
+    # position codes
+    codes = cref.position_codes_batch(g["sample_adj"][None], g["anchors"][None])[0]
+    assert np.allclose(codes, g["position_codes"], atol=1e-6)
+    assert np.array_equal(np.isinf(cref.floyd_warshall(g["sample_adj"])), np.isinf(g["sample_dist"]))
