@@ -327,6 +327,29 @@ int ragraph_csr_row_sums_f32(const int64_t* rowptr, const float* val, int64_t n,
 int ragraph_position_codes_batch_f32(const float* adj, int64_t G, int n, const int64_t* anchors, int A, float dis_q,
                                      float* dist_out, float* codes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Graph ingestion (the step before the path on the data side).
+ *
+ * utility.py:19-26,45-66 (normalize_adj of the batch's block-diagonal adjacency + I, built densely through scipy):
+ *   D^-1/2 (A + I) D^-1/2 directly as CSR from an edge list.  row/col [E] int64 (batch-global node ids; duplicate edges
+ *   SUM, as sp.coo_matrix(...).todense() does); n nodes.  Outputs: rowptr [n+1] int64, out_col / out_val with capacity
+ *   E + n, *nnz (device) = number of stored entries.  normalize_adj returns (A D)^T D, i.e. entry (i,j) = d_i A[j][i] d_j
+ *   with d from A's ROW sums: the transposed pattern is emitted, so a directed edge list gives the reference's matrix
+ *   too.  Values are computed in float64 and cast to fp32 last (scipy float64 -> torch.FloatTensor).  Columns ascend
+ *   within a row.  ws: ragraph_ingest_workspace_bytes(E + n, n). */
+size_t ragraph_ingest_workspace_bytes(int64_t max_keys, int64_t n);
+int ragraph_csr_sym_normalized_f32(const int64_t* row, const int64_t* col, int64_t E, int64_t n, int64_t* rowptr,
+                                   int32_t* out_col, float* out_val, int64_t* nnz, void* ws, size_t ws_bytes, void* stream);
+/* base_model.py:34-52 (_make_binorm_adj) + dataloader.py:94,108-113: interactions (users[e], items[e], step[e]) ->
+ *   the symmetric, binarised, bi-normalised bipartite adjacency as a COO edge list over the joint id space (items offset
+ *   by num_users), both directions, ordered by (destination, source) -- the order (A D)^T D .tocoo() leaves --, with
+ *   norm = d^-1/2[src] d^-1/2[dst] (float64 product cast to fp32) and, per edge, the time step of the LAST occurrence of
+ *   its (user, item) pair.  edges [2E,2] / norm [2E] / times [2E] have capacity 2E; *nedges (device) = edges written.
+ *   ws: ragraph_ingest_workspace_bytes(2E, num_users + num_items). */
+int ragraph_binorm_edges_f32(const int64_t* users, const int64_t* items, const int64_t* step, int64_t E, int64_t num_users,
+                             int64_t num_items, int64_t* edges, float* norm, int64_t* times, int64_t* nedges, void* ws,
+                             size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -640,6 +640,79 @@ def g13_bank_build():
     save("g13_bank_build", **out)
 
 
+def g14_ingestion():
+    """Graph ingestion as the reference does it: process_tu_dataset / normalize_adj (ragraph_utils/utility.py:19-72) on a
+    batch of three TU-style graphs (with a duplicated and a one-directional edge), and the edge flavour's loader + adjacency
+    (utils/dataloader.py:47-124,186-196; modules/base_model.py:34-52; modules/RAGraph.py:22-27) on a small TSV."""
+    out = {}
+    with ref_project("RAGraph_node"):
+        from ragraph_utils.utility import process_tu_dataset
+
+        rng = np.random.default_rng(95)
+
+        class G:
+            pass
+
+        graphs, F_attr, C = [], 4, 3
+        for n in (7, 12, 5):
+            m = 2 * n
+            src, dst = rng.integers(0, n, m), rng.integers(0, n, m)
+            keep = src != dst
+            ei = np.concatenate([np.stack([src[keep], dst[keep]]), np.stack([dst[keep], src[keep]])], axis=1)
+            ei = np.concatenate([ei, ei[:, :2], np.array([[0], [n - 1]])], axis=1)   # two duplicated edges, one directed edge
+            g = G()
+            g.x = torch.tensor(np.concatenate([rng.random((n, F_attr), dtype=np.float32),
+                                               np.eye(C, dtype=np.float32)[rng.integers(0, C, n)]], 1))
+            g.edge_index = torch.tensor(ei, dtype=torch.long)
+            graphs.append(g)
+
+        class Batch(list):
+            num_graphs = 3
+            num_features = F_attr + C
+
+        feats, adj, labels = process_tu_dataset(Batch(graphs), F_attr)
+        off, eis, xs = 0, [], []
+        for g in graphs:
+            eis.append(g.edge_index + off)
+            xs.append(g.x)
+            off += g.x.shape[0]
+        out.update(tu_x=torch.cat(xs), tu_edge_index=torch.cat(eis, dim=1), tu_num_node_attributes=np.int64(F_attr),
+                   tu_features=feats, tu_adj=adj, tu_node_labels=labels)
+    import tempfile
+    argv = ["x", "--device", "cpu", "--data_path", "dataset/amazon", "--log", "0", "--emb_dropout", "0"]
+    with ref_project("RAGraph_edge", argv=argv):
+        from modules.RAGraph import RAGraph
+        from utils.dataloader import EdgeListData
+        from utils.parse_args import args as ref_args
+
+        rng = np.random.default_rng(96)
+        U, I = 40, 25
+        lines = []
+        for u in range(U):
+            if u in (3, 17):
+                continue                                          # users without any interaction
+            k = int(rng.integers(1, 7))
+            items = rng.integers(0, I, k)
+            if u == 5:
+                items = np.array([2, 9, 2, 2])                    # a repeated (user, item) pair: the LAST time wins
+            times = 1_600_000_000 + rng.integers(0, 40 * 3600, len(items))
+            lines.append(f"{u}\t{' '.join(map(str, items))}\t{' '.join(map(str, times))}")
+        train_txt = "\n".join(lines) + "\n"
+        test_txt = "0\t1 2\n39\t24\n"
+        with tempfile.TemporaryDirectory() as d:
+            tr, te = os.path.join(d, "train.txt"), os.path.join(d, "test.txt")
+            open(tr, "w").write(train_txt)
+            open(te, "w").write(test_txt)
+            with contextlib.redirect_stdout(open(os.devnull, "w")):
+                ds = EdgeListData(tr, te, phase="pretrain")
+        model = RAGraph(ds, None, phase="pretrain", use_RAG=False)
+        out.update(edge_train_txt=np.array(train_txt), edge_test_txt=np.array(test_txt),
+                   edge_hour_interval=np.int64(ref_args.hour_interval_pre), edge_num_users=np.int64(ds.num_users),
+                   edge_num_items=np.int64(ds.num_items), edge_edges=model.edges, edge_norm=model.edge_norm,
+                   edge_times=model.edge_times)
+    save("g14_ingestion", **out)
+
+
 def main():
     assert os.path.isdir(REF), "the reference is only mounted in the build container"
     _install_shims()
@@ -654,6 +727,7 @@ def main():
     g11_noise()
     g12_edge_large_k()
     g13_bank_build()
+    g14_ingestion()
 
 
 if __name__ == "__main__":

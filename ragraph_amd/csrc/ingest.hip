@@ -1,0 +1,254 @@
+// Graph ingestion on the device: edge lists -> the hot path's input formats.
+//
+//   csr_sym_normalized   D^-1/2 (A + I) D^-1/2 as CSR                  RAGraph_node/ragraph_utils/utility.py:19-26 (normalize_adj),
+//                                                                       :45-66 (coo_matrix of ones -> dense: duplicate edges SUM;
+//                                                                       + eye; torch.FloatTensor)
+//   binorm_edges         bipartite D^-1/2 A D^-1/2 as a sorted edge list RAGraph_edge/modules/base_model.py:34-52 (_make_binorm_adj:
+//                                                                       binarised, symmetric, .tocoo() order), edge times of
+//                                                                       utils/dataloader.py:94,108-113 (the LAST time of a
+//                                                                       repeated (user, item) pair wins: dict assignment)
+//
+// The reference builds both on the host (a numpy row_stack loop that densifies the block-diagonal adjacency -- quadratic
+// in the batch's node count and the reason a 100k-node graph cannot be ingested at all -- and Python loops over every
+// edge).  Here: 64-bit keys, device radix sort (rocPRIM through hipCUB: integer bookkeeping), run-length heads, a prefix
+// sum, and kernels that count multiplicities, accumulate integer degrees (exact whatever the atomic order) and emit the
+// normalised values in double precision cast to fp32 last -- as scipy (float64) followed by torch.FloatTensor does.
+#include "common.h"
+#include <hipcub/hipcub.hpp>
+
+namespace ragraph {
+
+__global__ void __launch_bounds__(256) sym_keys_kernel(const int64_t* __restrict__ row, const int64_t* __restrict__ col,
+                                                       int64_t E, int64_t n, uint64_t* __restrict__ keys) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < E) keys[e] = (uint64_t)col[e] * (uint64_t)n + (uint64_t)row[e];  // normalize_adj returns (A D)^T D: transposed pattern
+  else if (e < E + n) keys[e] = (uint64_t)(e - E) * (uint64_t)n + (uint64_t)(e - E);  // + sp.eye(n)
+}
+
+// head[s] = 1 where a run of equal keys starts (LAST = 0) or ends (LAST = 1)
+template <bool LAST>
+__global__ void __launch_bounds__(256) run_flags_kernel(const uint64_t* __restrict__ keys, int64_t M, int* __restrict__ flag) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= M) return;
+  if (LAST) flag[s] = (s == M - 1 || keys[s] != keys[s + 1]) ? 1 : 0;
+  else flag[s] = (s == 0 || keys[s] != keys[s - 1]) ? 1 : 0;
+}
+
+// pos[u] = sorted position of the u-th flagged element; count = number of flagged elements; pos[count] = M
+__global__ void __launch_bounds__(256) run_positions_kernel(const int* __restrict__ flag, const int* __restrict__ slot, int64_t M,
+                                                            int64_t* __restrict__ pos, int64_t* __restrict__ count) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= M) return;
+  if (flag[s]) pos[slot[s]] = s;
+  if (s == M - 1) {
+    const int64_t c = (int64_t)slot[s] + flag[s];
+    *count = c;
+    pos[c] = M;
+  }
+}
+
+// unique (out_row = original col, out_col = original row) entries with multiplicities; integer degrees of the ORIGINAL rows
+__global__ void __launch_bounds__(256) sym_entries_kernel(const uint64_t* __restrict__ keys, const int64_t* __restrict__ pos,
+                                                          const int64_t* __restrict__ nnz, int64_t n,
+                                                          int64_t* __restrict__ rowptr, int32_t* __restrict__ out_col,
+                                                          unsigned* __restrict__ cnt, unsigned* __restrict__ deg) {
+  const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t nn = *nnz;
+  if (u == 0) rowptr[n] = nn;
+  if (u >= nn) return;
+  const uint64_t key = keys[pos[u]];
+  const int64_t orow = (int64_t)(key / (uint64_t)n), r = (int64_t)(key % (uint64_t)n);
+  const unsigned c = (unsigned)(pos[u + 1] - pos[u]);
+  out_col[u] = (int32_t)r;
+  cnt[u] = c;
+  atomicAdd(deg + r, c);  // row sum of A + I over the original row r (integers: exact in any order)
+  if (u == 0 || (int64_t)(keys[pos[u - 1]] / (uint64_t)n) != orow) rowptr[orow] = u;  // every row holds its self loop
+}
+
+__global__ void __launch_bounds__(256) sym_values_kernel(const uint64_t* __restrict__ keys, const int64_t* __restrict__ pos,
+                                                         const int64_t* __restrict__ nnz, int64_t n,
+                                                         const unsigned* __restrict__ cnt, const unsigned* __restrict__ deg,
+                                                         float* __restrict__ val) {
+  const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (u >= *nnz) return;
+  const uint64_t key = keys[pos[u]];
+  const int64_t c = (int64_t)(key / (uint64_t)n), r = (int64_t)(key % (uint64_t)n);
+  const double dr = deg[r] ? pow((double)deg[r], -0.5) : 0.0, dc = deg[c] ? pow((double)deg[c], -0.5) : 0.0;
+  val[u] = (float)(((double)cnt[u] * dr) * dc);  // (A[r][c] * d_r) * d_c in float64, cast last
+}
+
+// ---- bipartite ----------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pair_keys_kernel(const int64_t* __restrict__ u, const int64_t* __restrict__ it, int64_t E,
+                                                        int64_t num_items, uint64_t* __restrict__ keys, int64_t* __restrict__ idx) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  keys[e] = (uint64_t)u[e] * (uint64_t)num_items + (uint64_t)it[e];
+  idx[e] = e;
+}
+
+// unique (user, item) pairs: the time of the LAST occurrence; both directed edges' keys (dst * n + src) and degrees
+__global__ void __launch_bounds__(256) pair_edges_kernel(const uint64_t* __restrict__ keys, const int64_t* __restrict__ idx,
+                                                         const int64_t* __restrict__ pos /* last positions */,
+                                                         const int64_t* __restrict__ npairs, const int64_t* __restrict__ step,
+                                                         int64_t num_users, int64_t num_items, uint64_t* __restrict__ ekeys,
+                                                         int64_t* __restrict__ etime, unsigned* __restrict__ deg) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t np_ = *npairs;
+  if (p >= np_) return;
+  const int64_t s = pos[p];
+  const uint64_t key = keys[s];
+  const int64_t uu = (int64_t)(key / (uint64_t)num_items), ii = (int64_t)(key % (uint64_t)num_items) + num_users;
+  const uint64_t n = (uint64_t)(num_users + num_items);
+  const int64_t t = step[idx[s]];
+  ekeys[p] = (uint64_t)ii * n + (uint64_t)uu;        // edge uu -> ii, ordered by (dst, src)
+  ekeys[np_ + p] = (uint64_t)uu * n + (uint64_t)ii;  // edge ii -> uu
+  etime[p] = t;
+  etime[np_ + p] = t;
+  atomicAdd(deg + uu, 1u);
+  atomicAdd(deg + ii, 1u);
+}
+
+__global__ void __launch_bounds__(256) pair_emit_kernel(const uint64_t* __restrict__ ekeys_sorted, const int64_t* __restrict__ etime_sorted,
+                                                        const int64_t* __restrict__ npairs, int64_t n,
+                                                        const unsigned* __restrict__ deg, int64_t* __restrict__ edges,
+                                                        float* __restrict__ norm, int64_t* __restrict__ times,
+                                                        int64_t* __restrict__ nedges) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t ne = 2 * *npairs;
+  if (e == 0) *nedges = ne;
+  if (e >= ne) return;
+  const uint64_t key = ekeys_sorted[e];
+  const int64_t dst = (int64_t)(key / (uint64_t)n), src = (int64_t)(key % (uint64_t)n);
+  edges[2 * e] = src;
+  edges[2 * e + 1] = dst;
+  const double ds = deg[src] ? pow((double)deg[src], -0.5) : 0.0, dd = deg[dst] ? pow((double)deg[dst], -0.5) : 0.0;
+  norm[e] = (float)(ds * dd);  // mat.data.astype(np.float32) of the float64 product
+  times[e] = etime_sorted[e];
+}
+
+static int key_bits(uint64_t max_key) {
+  int b = 1;
+  while (b < 64 && (max_key >> b) != 0) ++b;
+  return b;
+}
+
+struct IngestWs {
+  uint64_t *keys_a, *keys_b;
+  int64_t *vals_a, *vals_b, *pos, *count;
+  int *flag, *slot;
+  unsigned *cnt, *deg;
+  void* temp;
+  size_t temp_bytes;
+};
+
+static size_t ingest_carve(char* w, int64_t M, int64_t n, IngestWs* out) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = w ? w + off : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  };
+  IngestWs f;
+  f.keys_a = reinterpret_cast<uint64_t*>(take((size_t)M * 8));
+  f.keys_b = reinterpret_cast<uint64_t*>(take((size_t)M * 8));
+  f.vals_a = reinterpret_cast<int64_t*>(take((size_t)M * 8));
+  f.vals_b = reinterpret_cast<int64_t*>(take((size_t)M * 8));
+  f.pos = reinterpret_cast<int64_t*>(take((size_t)(M + 1) * 8));
+  f.count = reinterpret_cast<int64_t*>(take(8));
+  f.flag = reinterpret_cast<int*>(take((size_t)M * 4));
+  f.slot = reinterpret_cast<int*>(take((size_t)M * 4));
+  f.cnt = reinterpret_cast<unsigned*>(take((size_t)M * 4));
+  f.deg = reinterpret_cast<unsigned*>(take((size_t)n * 4));
+  size_t t1 = 0, t2 = 0, t3 = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t1, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int64_t*)nullptr,
+                                           (int64_t*)nullptr, (int)M, 0, 64, (hipStream_t)0);
+  (void)hipcub::DeviceRadixSort::SortKeys(nullptr, t2, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)M, 0, 64, (hipStream_t)0);
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t3, (const int*)nullptr, (int*)nullptr, (int)M, (hipStream_t)0);
+  f.temp_bytes = t1 > t2 ? (t1 > t3 ? t1 : t3) : (t2 > t3 ? t2 : t3);
+  f.temp = take(f.temp_bytes + 256);
+  if (out) *out = f;
+  return off;
+}
+
+}  // namespace ragraph
+
+using namespace ragraph;
+
+extern "C" size_t ragraph_ingest_workspace_bytes(int64_t max_keys, int64_t n) {
+  if (max_keys < 1 || max_keys >= (int64_t)INT_MAX || n < 1) return 0;
+  return ingest_carve(nullptr, max_keys, n, nullptr);
+}
+
+#define RG_HIPCUB(call, what)                                                  \
+  do {                                                                         \
+    hipError_t e__ = (call);                                                   \
+    if (e__ != hipSuccess) {                                                   \
+      set_error("%s: %s", (what), hipGetErrorString(e__));                     \
+      return RAGRAPH_EDEVICE;                                                  \
+    }                                                                          \
+  } while (0)
+
+extern "C" int ragraph_csr_sym_normalized_f32(const int64_t* row, const int64_t* col, int64_t E, int64_t n, int64_t* rowptr,
+                                              int32_t* out_col, float* out_val, int64_t* nnz, void* ws, size_t ws_bytes,
+                                              void* stream) {
+  RG_REQUIRE((row && col) || E == 0, RAGRAPH_EINVAL, "csr_sym_normalized: null edge list");
+  RG_REQUIRE(rowptr && out_col && out_val && nnz && ws, RAGRAPH_EINVAL, "csr_sym_normalized: null pointer");
+  RG_REQUIRE(E >= 0 && n >= 1 && n < ((int64_t)1 << 31), RAGRAPH_EINVAL, "csr_sym_normalized: bad E/n");
+  const int64_t M = E + n;
+  RG_REQUIRE(M < (int64_t)INT_MAX, RAGRAPH_EUNSUPPORTED, "csr_sym_normalized: E + n must fit int32");
+  RG_REQUIRE(ws_bytes >= ragraph_ingest_workspace_bytes(M, n), RAGRAPH_EWORKSPACE, "csr_sym_normalized: workspace too small");
+  hipStream_t st = as_stream(stream);
+  IngestWs f;
+  ingest_carve(static_cast<char*>(ws), M, n, &f);
+  const unsigned g = (unsigned)cdiv(M, 256);
+  RG_HIPCUB(hipMemsetAsync(f.deg, 0, (size_t)n * 4, st), "csr_sym_normalized(memset)");
+  hipLaunchKernelGGL(sym_keys_kernel, dim3(g), dim3(256), 0, st, row, col, E, n, f.keys_a);
+  size_t tb = f.temp_bytes;
+  RG_HIPCUB(hipcub::DeviceRadixSort::SortKeys(f.temp, tb, f.keys_a, f.keys_b, (int)M, 0, key_bits((uint64_t)n * (uint64_t)n), st),
+            "csr_sym_normalized(sort)");
+  hipLaunchKernelGGL(run_flags_kernel<false>, dim3(g), dim3(256), 0, st, f.keys_b, M, f.flag);
+  tb = f.temp_bytes;
+  RG_HIPCUB(hipcub::DeviceScan::ExclusiveSum(f.temp, tb, f.flag, f.slot, (int)M, st), "csr_sym_normalized(scan)");
+  hipLaunchKernelGGL(run_positions_kernel, dim3(g), dim3(256), 0, st, f.flag, f.slot, M, f.pos, nnz);
+  hipLaunchKernelGGL(sym_entries_kernel, dim3(g), dim3(256), 0, st, f.keys_b, f.pos, nnz, n, rowptr, out_col, f.cnt, f.deg);
+  hipLaunchKernelGGL(sym_values_kernel, dim3(g), dim3(256), 0, st, f.keys_b, f.pos, nnz, n, f.cnt, f.deg, out_val);
+  RG_CHECK_LAUNCH("csr_sym_normalized");
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_binorm_edges_f32(const int64_t* users, const int64_t* items, const int64_t* step, int64_t E,
+                                        int64_t num_users, int64_t num_items, int64_t* edges, float* norm, int64_t* times,
+                                        int64_t* nedges, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(users && items && step && edges && norm && times && nedges && ws, RAGRAPH_EINVAL, "binorm_edges: null pointer");
+  RG_REQUIRE(E >= 1 && num_users >= 1 && num_items >= 1, RAGRAPH_EINVAL, "binorm_edges: bad sizes");
+  const int64_t n = num_users + num_items, M = 2 * E;
+  RG_REQUIRE(M < (int64_t)INT_MAX && n < ((int64_t)1 << 31), RAGRAPH_EUNSUPPORTED, "binorm_edges: 2E and n must fit int32");
+  RG_REQUIRE(ws_bytes >= ragraph_ingest_workspace_bytes(M, n), RAGRAPH_EWORKSPACE, "binorm_edges: workspace too small");
+  hipStream_t st = as_stream(stream);
+  IngestWs f;
+  ingest_carve(static_cast<char*>(ws), M, n, &f);
+  const unsigned gE = (unsigned)cdiv(E, 256), gM = (unsigned)cdiv(M, 256);
+  RG_HIPCUB(hipMemsetAsync(f.deg, 0, (size_t)n * 4, st), "binorm_edges(memset)");
+  hipLaunchKernelGGL(pair_keys_kernel, dim3(gE), dim3(256), 0, st, users, items, E, num_items, f.keys_a, f.vals_a);
+  size_t tb = f.temp_bytes;
+  // (radix sort is stable: among equal (user, item) pairs the original order survives, so a run's last element is the
+  // pair's last occurrence)
+  RG_HIPCUB(hipcub::DeviceRadixSort::SortPairs(f.temp, tb, f.keys_a, f.keys_b, f.vals_a, f.vals_b, (int)E, 0,
+                                               key_bits((uint64_t)num_users * (uint64_t)num_items), st), "binorm_edges(sort pairs)");
+  hipLaunchKernelGGL(run_flags_kernel<true>, dim3(gE), dim3(256), 0, st, f.keys_b, E, f.flag);
+  tb = f.temp_bytes;
+  RG_HIPCUB(hipcub::DeviceScan::ExclusiveSum(f.temp, tb, f.flag, f.slot, (int)E, st), "binorm_edges(scan)");
+  hipLaunchKernelGGL(run_positions_kernel, dim3(gE), dim3(256), 0, st, f.flag, f.slot, E, f.pos, f.count);
+  // directed edges keyed by (dst, src); keys_a / vals_a are free again
+  RG_HIPCUB(hipMemsetAsync(f.keys_a, 0xFF, (size_t)M * 8, st), "binorm_edges(memset keys)");  // unused tail sorts last
+  hipLaunchKernelGGL(pair_edges_kernel, dim3(gE), dim3(256), 0, st, f.keys_b, f.vals_b, f.pos, f.count, step, num_users, num_items,
+                     f.keys_a, f.vals_a, f.deg);
+  // (vals_a beyond 2 * npairs is garbage paired with 0xFF.. keys: sorted behind every real edge)
+  tb = f.temp_bytes;
+  RG_HIPCUB(hipcub::DeviceRadixSort::SortPairs(f.temp, tb, f.keys_a, f.keys_b, f.vals_a, f.vals_b, (int)M, 0, 64, st),
+            "binorm_edges(sort edges)");
+  hipLaunchKernelGGL(pair_emit_kernel, dim3(gM), dim3(256), 0, st, f.keys_b, f.vals_b, f.count, n, f.deg, edges, norm, times,
+                     nedges);
+  RG_CHECK_LAUNCH("binorm_edges");
+  return RAGRAPH_OK;
+}

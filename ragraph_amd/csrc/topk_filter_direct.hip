@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
   // as asm loads with counted lgkmcnt waits (hipcc's own schedule keeps one read ahead and idles the matrix pipe).
   const unsigned qaddr0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)qlds + lane16;
   auto process = [&](f32x4 (&A)[16], int64_t unit, auto next_tag) {
-    constexpr int BEHIND = decltype(next_tag)::value ? 16 : 0;
+    [[maybe_unused]] constexpr int BEHIND = decltype(next_tag)::value ? 16 : 0;
     int part0 = 0;
     if constexpr (BOUND) part0 = (int)(((unit - p.unit0) * C::SUBS) * p.ngroups / (p.nunits * C::SUBS));
     // (sub-tiles of one unit lie in one part or in two neighbouring ones: the division is per unit, not per sub-tile)

@@ -46,10 +46,16 @@ class EdgeListData:
         self.num_edges = int(u.shape[0])
         step = 1 + (t - t.min()) // int(hour_interval * 3600)            # :94,186-196 (0 is the self-loop padding)
         self.user_hist_dict = {uu: self.train_user_dict.get(uu, []) for uu in range(self.num_users)}
-        edges, norm, times = binorm_edges(self.num_users, self.num_items, u, i, step)
-        self.edges = torch.from_numpy(edges).to(device)
-        self.edge_norm = torch.from_numpy(norm).to(device)
-        self.edge_times = torch.from_numpy(times).to(device)
+        if torch.device(device).type == "cuda":   # the product path: sorts, degrees and norms on the device (csrc/ingest.hip)
+            from . import kernels as K
+            self.edges, self.edge_norm, self.edge_times = K.binorm_edges(
+                torch.from_numpy(u).to(device), torch.from_numpy(i).to(device), torch.from_numpy(step.astype(np.int64)).to(device),
+                self.num_users, self.num_items)
+        else:                                      # host tensors (the CPU host-logic test): the numpy restatement below
+            edges, norm, times = binorm_edges(self.num_users, self.num_items, u, i, step)
+            self.edges = torch.from_numpy(edges).to(device)
+            self.edge_norm = torch.from_numpy(norm).to(device)
+            self.edge_times = torch.from_numpy(times).to(device)
 
     def history_csr(self, users, device="cuda"):
         """CSR of training-history items for `users` (the mask of metrics.py:210-214)."""

@@ -88,6 +88,10 @@ class CSRGraph:
         scipy (coo_matrix of ones -> todense sums duplicate edges; + eye; normalize_adj).  The normalisation is done
         in float64 and cast to fp32 last, as scipy + torch.FloatTensor do."""
         dev = edge_index.device
+        if dev.type == "cuda":  # the product path: one sort + a few kernels on the device (csrc/ingest.hip)
+            rowptr, col, val = K.csr_sym_normalized_from_edges(edge_index, n)
+            return CSRGraph(rowptr, col, val, n)
+        # host tensors (the CPU host-logic tests): the same construction with torch ops
         loops = torch.arange(n, device=dev, dtype=torch.int64)
         r = torch.cat([edge_index[0].to(torch.int64), loops])
         c = torch.cat([edge_index[1].to(torch.int64), loops])

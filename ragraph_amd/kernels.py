@@ -566,3 +566,44 @@ def position_codes_batch(adj: torch.Tensor, anchors: torch.Tensor, dis_q: float 
     N.check(L.ragraph_position_codes_batch_f32(a.data_ptr(), G, n, anchors.data_ptr(), A, float(dis_q), _ptr(dist),
                                                codes.data_ptr(), _stream()), "position_codes_batch")
     return (codes, dist) if return_dist else codes
+
+
+# ---- graph ingestion --------------------------------------------------------------------
+def csr_sym_normalized_from_edges(edge_index: torch.Tensor, n: int):
+    """D^-1/2 (A + I) D^-1/2 as CSR from an edge list [2,E] -- ragraph_utils/utility.py:19-26,45-66.  Returns (rowptr
+    int64 [n+1], col int32 [nnz], val fp32 [nnz]).  Reads the entry count back (one synchronisation: ingestion is a
+    per-graph step, not part of the captured forward)."""
+    L = _ready()
+    ei = _idxc(edge_index, "csr_sym_normalized.edge_index")
+    E = ei.shape[1]
+    dev = ei.device
+    rowptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    col = torch.empty(E + n, dtype=torch.int32, device=dev)
+    val = torch.empty(E + n, dtype=torch.float32, device=dev)
+    nnz = torch.empty(1, dtype=torch.int64, device=dev)
+    ws = _workspace(L.ragraph_ingest_workspace_bytes(E + n, n), dev)
+    N.check(L.ragraph_csr_sym_normalized_f32(ei[0].data_ptr() if E else None, ei[1].data_ptr() if E else None, E, n,
+                                             rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), nnz.data_ptr(), ws.data_ptr(),
+                                             ws.numel(), _stream()), "csr_sym_normalized")
+    m = int(nnz.item())
+    return rowptr, col[:m].contiguous(), val[:m].contiguous()
+
+
+def binorm_edges(users: torch.Tensor, items: torch.Tensor, step: torch.Tensor, num_users: int, num_items: int):
+    """Bi-normalised bipartite adjacency as a (dst, src)-sorted edge list with per-edge time steps --
+    RAGraph_edge/modules/base_model.py:34-52 + utils/dataloader.py:94,108-113.  Returns (edges [M,2] int64, norm [M],
+    times [M] int64)."""
+    L = _ready()
+    u, i, t = (_idxc(x, "binorm_edges") for x in (users, items, step))
+    E = u.numel()
+    dev = u.device
+    edges = torch.empty((2 * E, 2), dtype=torch.int64, device=dev)
+    norm = torch.empty(2 * E, dtype=torch.float32, device=dev)
+    times = torch.empty(2 * E, dtype=torch.int64, device=dev)
+    ne = torch.empty(1, dtype=torch.int64, device=dev)
+    ws = _workspace(L.ragraph_ingest_workspace_bytes(2 * E, num_users + num_items), dev)
+    N.check(L.ragraph_binorm_edges_f32(u.data_ptr(), i.data_ptr(), t.data_ptr(), E, num_users, num_items, edges.data_ptr(),
+                                       norm.data_ptr(), times.data_ptr(), ne.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+            "binorm_edges")
+    m = int(ne.item())
+    return edges[:m].contiguous(), norm[:m].contiguous(), times[:m].contiguous()

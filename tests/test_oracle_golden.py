@@ -205,3 +205,27 @@ def test_g13_bank_build_deterministic_parts():
     codes = cref.position_codes_batch(g["sample_adj"][None], g["anchors"][None])[0]
     assert np.allclose(codes, g["position_codes"], atol=1e-6)
     assert np.array_equal(np.isinf(cref.floyd_warshall(g["sample_adj"])), np.isinf(g["sample_dist"]))
+
+
+def test_g14_ingestion_host_restatement(tmp_path):
+    """The host-side restatements of the ingestion (the checkers of the HIP ingestion kernels) against the reference's own
+    process_tu_dataset / EdgeListData + _make_binorm_adj outputs."""
+    from ragraph_amd.edge_data import EdgeListData
+    from ragraph_amd.graph import CSRGraph
+
+    g = gold("g14_ingestion")
+    n = g["tu_x"].shape[0]
+    csr = CSRGraph.from_edge_index_sym_normalized(torch.from_numpy(g["tu_edge_index"]), n)   # CPU tensors: torch restatement
+    dense = np.zeros((n, n), np.float32)
+    rows = np.repeat(np.arange(n), np.diff(csr.rowptr.numpy()))
+    dense[rows, csr.col.numpy()] = csr.val.numpy()
+    assert np.allclose(dense, g["tu_adj"], atol=1e-7) and np.array_equal(dense != 0, g["tu_adj"] != 0)
+    F = int(g["tu_num_node_attributes"])
+    assert np.array_equal(g["tu_x"][:, :F], g["tu_features"]) and np.array_equal(g["tu_x"][:, F:], g["tu_node_labels"])
+    tr, te = tmp_path / "train.txt", tmp_path / "test.txt"
+    tr.write_text(str(g["edge_train_txt"]))
+    te.write_text(str(g["edge_test_txt"]))
+    ds = EdgeListData(str(tr), str(te), hour_interval=int(g["edge_hour_interval"]), device="cpu")
+    assert ds.num_users == int(g["edge_num_users"]) and ds.num_items == int(g["edge_num_items"])
+    assert np.array_equal(ds.edges.numpy(), g["edge_edges"]) and np.array_equal(ds.edge_times.numpy(), g["edge_times"])
+    assert np.allclose(ds.edge_norm.numpy(), g["edge_norm"], atol=1e-7)
