@@ -297,6 +297,23 @@ int ragraph_position_code_f32(const float* dist, int n, const int64_t* anchors, 
                               void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Fine-tuning backward (section 7.3 hard part 4).  The matrix parts of a backward pass are the
+ * forward entry points again (ragraph_linear_f32 on transposed operands; ragraph_spmm_csr_f32 on the TRANSPOSED CSR: the
+ * few-shot flavour trains its decode layer through the SpMM, RAGraph_node_fewshot/RAGraph.py:69; the edge flavour trains
+ * embeddings and gate through three propagation layers, RAGraph_edge/modules/RAGraph.py:280-283,335-355); these are the
+ * element-wise derivatives of the fused epilogues.
+ *   act_grad:  gz = gy * act'(z) written through the OUTPUT y (sign(y) = sign(z) for ReLU / PReLU / LeakyReLU); for PReLU
+ *     alpha_terms (optional) receives gy * z on z < 0 (z = y / alpha): its sum is the slope's gradient (layers/gcn.py:9).
+ *   sigmoid_gate_grad:  out = x * sigmoid(z) (modules/RAGraph.py:168): gx = g * s, gz = g * x * s * (1 - s).
+ *   softmax_grad:  RAGraph_node/RAGraph.py:55-57: out = p * (g - sum_c g_c p_c), g = go * scale (scale = 1 - label_weight).
+ *   mul_cols:  out[r,:] = x[r,:] * w  -- downstreamprompt.forward (RAGraph_graph/downprompt.py:164-168); its own backward. */
+int ragraph_act_grad_f32(const float* y, const float* gy, int64_t n, int act, float alpha, float* gz, float* alpha_terms,
+                         void* stream);
+int ragraph_sigmoid_gate_grad_f32(const float* x, const float* z, const float* g, int64_t n, float* gx, float* gz, void* stream);
+int ragraph_softmax_grad_f32(const float* p, const float* go, int64_t B, int C, float scale, float* out, void* stream);
+int ragraph_mul_cols_f32(const float* x, const float* w, int64_t n, int D, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Toy-bank construction (the step before the hot path), batched over resource graphs.
  *
  * InverseSampling.pagerank_algorithm  -- RAGraph_node/ragraph_utils/InverseSampling.py:22-47 (dense);

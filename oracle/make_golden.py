@@ -713,6 +713,74 @@ def g14_ingestion():
     save("g14_ingestion", **out)
 
 
+def g15_graph_fewshot():
+    """RAGraph_graph_fewshot forward (RAGraph.py:46-91): every node of one query graph against a bank holding every node of
+    every resource graph (ragraph_utils/ToyGraphBase.py:118-126), prototype-logit labels, the second GCN layer as decoder,
+    mean over the nodes."""
+    fs = types.ModuleType("ragraph_utils.fewshot_utility")   # ragraph_utils/__init__.py:7 imports a module that is not shipped
+    for name in ("fewshot_predict_labels_by_mean", "fewshot_mean_logits", "fewshot_predict_logits", "fewshot_predict_labels"):
+        setattr(fs, name, None)
+    with ref_project("RAGraph_graph_fewshot"):
+        sys.modules["ragraph_utils.fewshot_utility"] = fs
+        from preprompt import PrePrompt
+        from RAGraph import RAGraph
+        from ragraph_utils import ToyGraphBase
+
+        F_in, C, D, n = 4, 2, 256, 31
+        torch.manual_seed(9)
+        pre = PrePrompt(F_in, D, "prelu", 2, 0.3)
+        pre.eval()
+        with torch.no_grad():
+            for conv in pre.gcn.convs:
+                conv.bias.copy_(0.05 * torch.randn(D, generator=gen(101)))
+        model = RAGraph.__new__(RAGraph)                      # __init__ needs dataset blobs that are not shipped (FewShotBase)
+        nn.Module.__init__(model)
+        model.emb_size, model.num_class, model.pretrain_model = D, C, pre
+        model.retrieve_weight, model.label_weight = 0.5, 0.5  # RAGraph.py:22-23 (PROTEINS)
+        model.finetune, model.noise_finetune, model.query_graph_hop = True, False, 1
+        model.toy_graph_base = ToyGraphBase(pre, C, D, model.query_graph_hop)
+        model.eval()
+        tgb = model.toy_graph_base
+        # the bank: two resource graphs built by the reference's own _build_toy_graph_base (deterministic here: the
+        # graph_fewshot flavour neither augments nor samples, ToyGraphBase.py:21-27) + random filler rows
+        res = []
+        for gi, (nn_, label) in enumerate(((17, 0), (23, 1))):
+            radj = random_graph_adj(nn_, 3.0, seed=110 + gi)
+            rx = torch.rand(nn_, F_in, generator=gen(120 + gi))
+            with torch.no_grad():
+                tgb._build_toy_graph_base(rx, radj, torch.tensor([label]))
+            res.append((rx, radj, label))
+        built_keys, built_values, built_labels = tgb.resource_keys.clone(), tgb.resource_values.clone(), tgb.resource_labels.clone()
+        N = 1500
+        for bank_seed in range(130, 2130, 100):
+            Kf = unit_bank(N, D, bank_seed)
+            adj = random_graph_adj(n, 3.3, seed=102)
+            X = torch.rand(n, F_in, generator=gen(103))
+            with torch.no_grad():
+                h = pre.encode(X, adj)
+            keys_all = torch.cat([built_keys, Kf])
+            if min_topk_gap(torch.nn.functional.normalize(h, dim=-1) @ torch.nn.functional.normalize(keys_all, dim=-1).t(),
+                            tgb.retrieve_num) > 1e-5:
+                break
+        else:
+            raise AssertionError("no tie-free bank seed found")
+        Vf = torch.randn(N, D, generator=gen(104))
+        Lf = torch.nn.functional.one_hot(torch.randint(0, C, (N,), generator=gen(105)), C).float()
+        tgb.resource_keys, tgb.resource_values = keys_all, torch.cat([built_values, Vf])
+        tgb.resource_labels = torch.cat([built_labels.float(), Lf])
+        mean_fewshot_logits = torch.randn(C, D, generator=gen(106))
+        with torch.no_grad():
+            logits = model(X, adj, mean_fewshot_logits)
+            dec = pre.decode(h, adj)
+        c0, c1 = pre.gcn.convs
+        save("g15_graph_fewshot", X=X, adj=adj, W0=c0.fc.weight, b0=c0.bias, a0=c0.act.weight, W1=c1.fc.weight, b1=c1.bias,
+             a1=c1.act.weight, H=h, decode_H=dec, keys=tgb.resource_keys, values=tgb.resource_values, labels=tgb.resource_labels,
+             k=np.int64(tgb.retrieve_num), mean_fewshot_logits=mean_fewshot_logits, retrieve_weight=np.float32(0.5),
+             label_weight=np.float32(0.5), logits=logits,
+             res0_x=res[0][0], res0_adj=res[0][1], res1_x=res[1][0], res1_adj=res[1][1], built_keys=built_keys,
+             built_values=built_values, built_labels=built_labels)
+
+
 def main():
     assert os.path.isdir(REF), "the reference is only mounted in the build container"
     _install_shims()
@@ -728,6 +796,7 @@ def main():
     g12_edge_large_k()
     g13_bank_build()
     g14_ingestion()
+    g15_graph_fewshot()
 
 
 if __name__ == "__main__":

@@ -133,3 +133,20 @@ def edge_topk_items(user_emb, item_emb, users, hist, k=20):
     for r, items in enumerate(hist):
         rating[r, list(items)] = np.float32(-1e8)
     return cref.topk_rows(rating, k)[1]
+
+
+def graph_fewshot_forward(X, csr, p, keys, values, labels, mean_fewshot_logits, k, retrieve_weight, label_weight, hops=1):
+    """RAGraph_graph_fewshot/RAGraph.py:46-86 (finetune branch, no noise).  p: W0,b0,a0 (encode = layer 0), W1,b1,a1
+    (decode = layer 1)."""
+    h = gcn_layer(X, csr, p["W0"], p["b0"], p["a0"])                              # :47 encode
+    kn = cref.normalize_rows(keys)
+    _, idx = cref.topk_cosine(h, kn, int(k))                                       # :51
+    label_ids = np.argmax(cref.gather_rows(labels, idx), axis=-1).astype(np.int64)  # :55
+    rag_logits, _ = cref.gather_reduce(mean_fewshot_logits, None, label_ids, v_scale=np.float32(1.0 / k))   # :56,68
+    rag_emb, _ = cref.gather_reduce(values, None, idx)                             # :69
+    q = propagate(csr, h, hops)                                                    # :71
+    hidden = cref.axpby(q, np.float32(1.0 - retrieve_weight), rag_emb, np.float32(retrieve_weight))          # :75
+    dec = gcn_layer(hidden, csr, p["W1"], p["b1"], p["a1"])                        # :79 decode
+    mix = cref.axpby(dec, np.float32(1.0 - label_weight), rag_logits, np.float32(label_weight))              # :82
+    seg = np.array([0, mix.shape[0]], dtype=np.int64)
+    return cref.segment_reduce(mix, seg, mean_mode=True), idx, h                   # :84

@@ -1,12 +1,15 @@
-"""Mirror of RAGraph_edge/modules/RAGraph.py (inference side): LightGCN-style propagation with time-softmax edge
-weights, retrieval over all users+items, fusion.  Training-side pieces (LoRA, BPR loss, edge dropout) are out of scope
-(SURVEY.md section 2 row 9); the gating layer is kept because generate() applies it.
+"""Mirror of RAGraph_edge/modules/RAGraph.py: LightGCN-style propagation with time-softmax edge weights, retrieval
+over all users+items, fusion -- and its fine-tuning step (cal_loss: edge dropout, the forward with gradients through
+gate / LoRA factors / three propagation layers, BPR + L2; modules/RAGraph.py:121-171,335-376), every product of forward
+AND backward on the HIP kernels (ragraph_amd.autograd).  Retrieval is not differentiated (the bank carries no gradient
+and torch.topk's indices have none); the trainers, metrics and loggers around cal_loss stay out of scope.
 """
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
 
+from . import autograd as A
 from . import kernels as K
 from .graph import CSRGraph
 
@@ -19,8 +22,8 @@ class RAGraph(nn.Module):
         .edge_times [2E] int64 (the tensors modules/RAGraph.py:22-27 derives from the scipy graph).
         pretrained_model: .generate() -> (user_emb, item_emb)."""
         super().__init__()
-        if use_LoRA:
-            raise NotImplementedError("LoRA fine-tuning (modules/RAGraph.py:121-160) is training-side; out of scope")
+        self.use_LoRA = bool(use_LoRA) and phase == "finetune"
+        self.edge_dropout, self.weight_decay, self.emb_dropout = 0.5, 1e-4, 0.0   # utils/parse_args.py:22,27,35 defaults
         self.num_users, self.num_items = dataset.num_users, dataset.num_items
         self.emb_size, self.num_layers = emb_size, num_layers
         self.edges = dataset.edges.to(device)
@@ -44,6 +47,11 @@ class RAGraph(nn.Module):
             self.gating_bias = nn.Parameter(nn.init.xavier_uniform_(torch.empty(1, emb_size, device=device)))
         else:
             self.gating_weight = self.gating_bias = None
+        if self.use_LoRA:   # :121-160: rank-r factors of the pretrained tables (U_r S_r, V_r^T), trained next to them
+            for name, emb in (("user", self.user_embedding), ("item", self.item_embedding)):
+                U, S, V = torch.svd(emb.detach())
+                setattr(self, f"{name}_embedding_A", nn.Parameter((U[:, :LoRA_rank] @ torch.diag(S[:LoRA_rank])).contiguous()))
+                setattr(self, f"{name}_embedding_B", nn.Parameter(V[:, :LoRA_rank].t().contiguous()))
         if use_RAG:
             self._make_resource_graph(pretrained_model)
 
@@ -68,11 +76,23 @@ class RAGraph(nn.Module):
         return self._gate_cache[1]
 
     def emb_gate(self, x):
-        """modules/RAGraph.py:168: x * sigmoid(x @ W + b) (dropout p = 0 at inference)."""
+        """modules/RAGraph.py:168: x * sigmoid(x @ W + b) (emb_dropout p = 0 by default)."""
         if self.gating_weight is None:
             return x
+        if torch.is_grad_enabled() and (x.requires_grad or self.gating_weight.requires_grad):
+            z = A.linear(x, self.gating_weight.t().contiguous(), self.gating_bias.reshape(-1))
+            out = A.sigmoid_gate(x, z)
+            return torch.nn.functional.dropout(out, self.emb_dropout, self.training) if self.emb_dropout > 0 else out
         z = K.linear(x, self._gate_wt(), self.gating_bias.reshape(-1))
         return K.sigmoid_gate(x, z)
+
+    def _embeddings(self):
+        """:269-275: the tables, plus the LoRA product A @ B when fine-tuning with LoRA."""
+        ue, ie = self.user_embedding, self.item_embedding
+        if self.use_LoRA:
+            ue = ue + A.linear(self.user_embedding_A, self.user_embedding_B.t().contiguous())
+            ie = ie + A.linear(self.item_embedding_A, self.item_embedding_B.t().contiguous())
+        return ue, ie
 
     def _time_range(self, edge_times, max_time_step):
         """(min, max) of the time steps as host scalars (kernel arguments), cached per edge-time tensor (identity and
@@ -158,13 +178,19 @@ class RAGraph(nn.Module):
         t = K.time_rescale(edge_times[perm].contiguous(), tmin, tmax)                           # :254-257
         time_norm = K.segment_softmax(g.rowptr, t, long_rows=g.has_long_rows)                  # :266
         norm = K.axpby(edge_norm[perm].contiguous(), 0.5, time_norm, 0.5)                      # :267
-        all_emb = self.emb_gate(torch.cat([self.user_embedding, self.item_embedding], dim=0)).detach()  # :276-277
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        ue, ie = self._embeddings()
+        all_emb = self.emb_gate(torch.cat([ue, ie], dim=0))                                     # :276-277
+        if not train:
+            all_emb = all_emb.detach()
         res = [all_emb]
+        gw = CSRGraph(g.rowptr, g.col, norm, g.n) if train else None   # (this step's weights; its transpose serves backward)
         for _ in range(self.num_layers):                                                       # :280-283
-            res.append(K.spmm_csr(g.rowptr, g.col, norm, res[-1], long_rows=g.has_long_rows))
+            res.append(A.spmm_csr(gw, res[-1]) if train else
+                       K.spmm_csr(g.rowptr, g.col, norm, res[-1], long_rows=g.has_long_rows))
         total = res[0]
         for r in res[1:]:                                                                      # :327 sum(res_emb)
-            total = K.axpby(total, 1.0, r, 1.0)
+            total = A.axpby(total, 1.0, r, 1.0)
         if self.use_RAG and self.phase in ("vanilla", "finetune"):
             add_noise = self.use_noise and self.training
             k = self.retrieve_num + (self.noise_retrieve_num if add_noise else 0)             # :308
@@ -176,7 +202,7 @@ class RAGraph(nn.Module):
             # a rank retrieves and reduces its rows, one all_gather of the [n, D] means completes the step
             # (ragraph_amd.sharded.QueryShard; the result does not depend on the split, bit for bit).
             qs = self.query_shard if not self.training else None
-            queries = res[0]
+            queries = res[0].detach()
             if qs is not None:
                 lo, hi = qs.bounds(res[0].shape[0])
                 queries = res[0][lo:hi].contiguous()
@@ -186,7 +212,7 @@ class RAGraph(nn.Module):
                 rag = K.retrieve_mean_large_k(queries, self.keys_normalized, self.resource_values, k)
                 if qs is not None:
                     rag = qs.gather_rows(rag, res[0].shape[0])
-                total = K.axpby(total, 1 - self.retrieve_weight, rag, self.retrieve_weight)    # :328
+                total = A.axpby(total, 1 - self.retrieve_weight, rag, self.retrieve_weight)    # :328
                 return total.split([self.num_users, self.num_items], dim=0)
             _, idx = self._index.topk(queries, k)
             if add_noise:
@@ -198,7 +224,7 @@ class RAGraph(nn.Module):
             rag, _ = K.gather_reduce(self.resource_values, None, idx, v_scale=1.0 / idx.shape[1])  # :314,321 mean
             if qs is not None:
                 rag = qs.gather_rows(rag, res[0].shape[0])
-            total = K.axpby(total, 1 - self.retrieve_weight, rag, self.retrieve_weight)        # :328
+            total = A.axpby(total, 1 - self.retrieve_weight, rag, self.retrieve_weight)        # :328
         return total.split([self.num_users, self.num_items], dim=0)
 
     @torch.no_grad()
@@ -208,3 +234,27 @@ class RAGraph(nn.Module):
     @torch.no_grad()
     def rating(self, user_emb, item_emb):
         return K.linear(user_emb, item_emb)   # modules/RAGraph.py:362-364: user_emb @ item_emb.T
+
+    # ---- fine-tuning step --------------------------------------------------------------------------------------------
+    def cal_loss(self, batch_data):
+        """modules/RAGraph.py:335-355: edge dropout (keep 1 - edge_dropout; the reference draws the mask with torch.rand on
+        the CPU generator, utils.py:46), forward on the kept edges, BPR loss on (user, positive, negative) triples + L2 on
+        the batch's table rows.  Returns (loss, {"rec_loss", "reg_loss"})."""
+        keep = 1.0 - self.edge_dropout
+        n_e = self.edges.shape[0]
+        mask = (torch.rand(n_e) + keep).floor().bool().to(self.edges.device) if keep < 1.0 else \
+            torch.ones(n_e, dtype=torch.bool, device=self.edges.device)
+        edges, norm, times = self.edges[mask], self.edge_norm[mask], self.edge_times[mask]
+        users, pos_items, neg_items = (t.to(self.edges.device).long() for t in batch_data)
+        user_emb, item_emb = self.forward(edges, norm, times)
+        u = A.gather_rows(user_emb.contiguous(), users)                                        # :343-345
+        p = A.gather_rows(item_emb.contiguous(), pos_items)
+        q = A.gather_rows(item_emb.contiguous(), neg_items)
+        # base_model.py:81-86 (the loss itself: a few thousand scalars -- trainer-side bookkeeping in torch)
+        pos_score, neg_score = (u * p).sum(dim=1), (u * q).sum(dim=1)
+        rec = (-torch.log(1e-10 + torch.sigmoid(pos_score - neg_score))).mean()
+        ue, ie = self._embeddings()                                                            # :365-376
+        ru, rp, rq = A.gather_rows(ue, users), A.gather_rows(ie, pos_items), A.gather_rows(ie, neg_items)
+        reg = 0.5 * (ru.norm(2).pow(2) + rp.norm(2).pow(2) + rq.norm(2).pow(2)) / float(len(users))
+        loss = rec + self.weight_decay * reg
+        return loss, {"rec_loss": float(rec), "reg_loss": float(self.weight_decay * reg)}

@@ -124,3 +124,55 @@ class RAGraph(nn.Module):
         hidden = K.axpby(query, 1 - self.retrieve_weight, rag_embedding, self.retrieve_weight)   # :67
         decode_logits = self.pretrain_model.decode(hidden, g)                                    # :69
         return K.axpby(decode_logits, 1 - self.label_weight, rag_logits, self.label_weight)      # :77
+
+
+class RAGraphGraphFewShot(nn.Module):
+    """RAGraph_graph_fewshot/RAGraph.py:7-91: graph classification, few-shot.  EVERY node of the one query graph is a query
+    against a bank that holds every node of every resource graph with its graph's label
+    (ragraph_utils/ToyGraphBase.py:118-126); the label term is a prototype-logit lookup, the decoder is the encoder's
+    second GCN layer (trained through decode(): ragraph_amd.autograd.spmm_csr), and the node logits are averaged into one
+    row (:86).  FewShotBase (RAGraph.py:43) only loads blobs that forward never reads and is not reproduced."""
+
+    def __init__(self, pretrain_model, resource_dataset, feture_size, num_class, emb_size, finetune=True,
+                 noise_finetune=False, device="cuda", dataset_name=None):
+        super().__init__()
+        self.emb_size, self.num_class, self.pretrain_model = emb_size, num_class, pretrain_model
+        name = dataset_name or getattr(resource_dataset, "name", "PROTEINS")
+        weights = {"ENZYMES": (0.3, 0.8), "PROTEINS": (0.5, 0.5), "COX2": (0.3, 0.6), "BZR": (0.1, 0.5)}   # RAGraph.py:16-30
+        if name not in weights:
+            raise NotImplementedError(name)
+        self.retrieve_weight, self.label_weight = weights[name]
+        self.finetune, self.noise_finetune = finetune, noise_finetune
+        if noise_finetune:
+            assert finetune
+        self.query_graph_hop = 1                                                               # :38
+        self.toy_graph_base = ToyGraphBase(pretrain_model, num_class, emb_size, self.query_graph_hop, device=device,
+                                           flavour="graph_fewshot")
+        if resource_dataset is not None:
+            self.toy_graph_base.build_toy_graph(resource_dataset)
+        self.to(device)
+
+    def forward(self, features, adj, mean_fewshot_logits):
+        from . import autograd as A
+        g = as_csr(adj)
+        tgb = self.toy_graph_base
+        emb = self.pretrain_model.encode(features, g)                                            # :47
+        add_noise = self.training and self.noise_finetune
+        idx = tgb.retrieve_indices(emb, add_noise)                                               # :51 (k' = 2k with noise)
+        k = idx.shape[1]
+        label_ids = torch.argmax(K.gather_rows(tgb.resource_labels, idx), dim=-1)                # :55 (integer lookup)
+        rag_logits, _ = K.gather_reduce(mean_fewshot_logits, None, label_ids, v_scale=1.0 / k)   # :56,68 mean over k
+        if not self.finetune:
+            return rag_logits                                                                    # :88-91
+        if add_noise:                                                                            # graph noise: on the embeddings
+            rag_embedding, _ = tgb.retrieve_reduced_noisy(emb)
+        else:
+            rag_embedding, _ = K.gather_reduce(tgb.resource_values, None, idx)                   # :69 sum over k
+        query = Propagation.aggregate_k_hop_features(g, emb, self.query_graph_hop)               # :71
+        hidden = K.axpby(query, 1 - self.retrieve_weight, rag_embedding, self.retrieve_weight)   # :75
+        decode_logits = self.pretrain_model.decode(hidden, g)                                    # :79
+        label_logits = A.axpby(decode_logits, 1 - self.label_weight, rag_logits, self.label_weight)   # :82
+        if label_logits.requires_grad:   # training: the mean over the nodes through torch (one reduction of [n, D])
+            return label_logits.mean(dim=0).unsqueeze(0)                                         # :84
+        seg = torch.tensor([0, label_logits.shape[0]], dtype=torch.int64, device=label_logits.device)
+        return K.segment_reduce(label_logits, seg, mean_mode=True)                               # :84

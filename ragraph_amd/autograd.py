@@ -1,8 +1,15 @@
-"""Autograd wrappers for the only trainable part of the path: the decoder head (TaskDecoder, fusion, softmax-mix).
+"""Autograd wrappers of the trainable parts of the path.
 
-In the reference the encoder output is detached (preprompt.py:62) and the bank carries no gradient, so fine-tuning
-(finetune-rag.py:81-84) back-propagates through RAGraph.py:53-57 only.  Forward AND backward GEMMs run on the HIP
-linear kernel; the element-wise derivative masks are plain tensor ops on the device (training-side bookkeeping).
+  * node / graph flavours: the encoder output is detached (preprompt.py:62) and the bank carries no gradient, so
+    fine-tuning (finetune-rag.py:81-84) back-propagates through the decoder head only (RAGraph.py:53-57): linear,
+    axpby, softmax-mix.
+  * few-shot flavours train the SECOND GCN layer through decode() (RAGraph_node_fewshot/RAGraph.py:69,
+    RAGraph_graph_fewshot/RAGraph.py:77): spmm_csr (backward = the SpMM over the transposed CSR) with its fused
+    bias / PReLU epilogue, slope and bias gradients included.
+  * edge flavour (RAGraph_edge/modules/RAGraph.py:265-355): embeddings, gate and LoRA factors through the gate, three
+    propagation layers and the batch gathers: sigmoid_gate, spmm_csr, gather_rows.
+Every forward AND backward product runs on the HIP kernels (the matrix parts of a backward pass are the forward entry
+points on transposed operands; the element-wise derivatives are csrc/rowops.hip's *_grad kernels).
 """
 from __future__ import annotations
 
@@ -25,10 +32,8 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
         gy = gy.contiguous()
-        if ctx.act in (K.ACT_LEAKY, K.ACT_PRELU):
-            gy = torch.where(y >= 0, gy, gy * ctx.alpha)  # sign(y) == sign(pre-activation) for alpha > 0
-        elif ctx.act == K.ACT_RELU:
-            gy = torch.where(y > 0, gy, torch.zeros_like(gy))
+        if ctx.act != K.ACT_NONE:
+            gy = K.act_grad(y, gy, ctx.act, ctx.alpha)  # sign(y) == sign(pre-activation) for alpha > 0
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = K.linear(gy, w.t().contiguous())                      # gy @ W
@@ -65,8 +70,7 @@ class _SoftmaxMix(torch.autograd.Function):
     @staticmethod
     def backward(ctx, go):
         (p,) = ctx.saved_tensors
-        g = go * (1.0 - ctx.lam)
-        return p * (g - (g * p).sum(dim=-1, keepdim=True)), None, None
+        return K.softmax_grad(p, go.contiguous(), 1.0 - ctx.lam), None, None
 
 
 def softmax_mix(logits, rag_label, lam):
@@ -83,11 +87,111 @@ class _Axpby(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, go):
-        return (go * ctx.wa if ctx.needs_input_grad[0] else None, None,
-                go * ctx.wb if ctx.needs_input_grad[2] else None, None)
+        go = go.contiguous()
+        zero = 0.0
+        return (K.axpby(go, ctx.wa, go, zero) if ctx.needs_input_grad[0] else None, None,
+                K.axpby(go, ctx.wb, go, zero) if ctx.needs_input_grad[2] else None, None)
 
 
 def axpby(a, wa, b, wb):
     if torch.is_grad_enabled() and (a.requires_grad or b.requires_grad):
         return _Axpby.apply(a, wa, b, wb)
     return K.axpby(a, wa, b, wb)
+
+
+class _SpmmCsr(torch.autograd.Function):
+    """y = act(A @ x + bias) for a CSRGraph A -- layers/gcn.py:36-40, Propagation.py:22-25, edge _agg (:232-240).
+    Backward: gz = gy * act'(z); gx = A^T gz (the same kernel over the transposed CSR, cached on the graph); gbias =
+    column sums of gz; PReLU slope: sum of gy * z over z < 0."""
+
+    @staticmethod
+    def forward(ctx, g, x, bias, act, alpha_t, alpha):
+        y = K.spmm_csr(g.rowptr, g.col, g.val, x, bias=bias, act=act, alpha=alpha, long_rows=g.has_long_rows)
+        ctx.g, ctx.act, ctx.alpha = g, act, alpha
+        ctx.has_bias, ctx.has_alpha = bias is not None, alpha_t is not None
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        galpha = None
+        if ctx.act != K.ACT_NONE:
+            if ctx.has_alpha and ctx.needs_input_grad[4]:
+                gz, terms = K.act_grad(y, gy, ctx.act, ctx.alpha, want_alpha_terms=True)
+                seg = torch.tensor([0, terms.shape[0]], dtype=torch.int64, device=gy.device)
+                galpha = K.segment_reduce(terms, seg).sum().reshape(1)   # (the last 256 -> 1 is bookkeeping)
+            else:
+                gz = K.act_grad(y, gy, ctx.act, ctx.alpha)
+        else:
+            gz = gy
+        gx = gb = None
+        if ctx.needs_input_grad[1]:
+            gt = ctx.g.transposed()
+            gx = K.spmm_csr(gt.rowptr, gt.col, gt.val, gz, long_rows=gt.has_long_rows)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            seg = torch.tensor([0, gz.shape[0]], dtype=torch.int64, device=gz.device)
+            gb = K.segment_reduce(gz, seg).reshape(-1)
+        return None, gx, gb, None, galpha, None
+
+
+def spmm_csr(g, x, bias=None, act=K.ACT_NONE, alpha_param=None, alpha=0.0):
+    """Differentiable act(A @ x + bias); alpha_param = the PReLU weight tensor (its gradient is produced when it requires
+    one), alpha = its value as a host scalar."""
+    need = torch.is_grad_enabled() and (x.requires_grad or (bias is not None and bias.requires_grad) or
+                                        (alpha_param is not None and alpha_param.requires_grad))
+    if need:
+        return _SpmmCsr.apply(g, x, bias, act, alpha_param, alpha)
+    return K.spmm_csr(g.rowptr, g.col, g.val, x, bias=bias, act=act, alpha=alpha, long_rows=g.has_long_rows)
+
+
+class _SigmoidGate(torch.autograd.Function):
+    """x * sigmoid(z) -- RAGraph_edge/modules/RAGraph.py:168."""
+
+    @staticmethod
+    def forward(ctx, x, z):
+        ctx.save_for_backward(x, z)
+        return K.sigmoid_gate(x, z)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, z = ctx.saved_tensors
+        return K.sigmoid_gate_grad(x, z, g.contiguous())
+
+
+def sigmoid_gate(x, z):
+    if torch.is_grad_enabled() and (x.requires_grad or z.requires_grad):
+        return _SigmoidGate.apply(x, z)
+    return K.sigmoid_gate(x, z)
+
+
+class _GatherRows(torch.autograd.Function):
+    """v[idx] for a 1-D index -- batch_user_emb = user_emb[users] (modules/RAGraph.py:343-345).  Backward scatters the
+    row gradients back: rows hit several times are summed by a CSR SpMM (rows = bank rows, one unit entry per hit),
+    deterministic -- no atomics."""
+
+    @staticmethod
+    def forward(ctx, v, idx):
+        ctx.n = v.shape[0]
+        ctx.save_for_backward(idx)
+        return K.gather_rows(v, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        from .graph import CSRGraph
+        m = idx.numel()
+        hits, _ = CSRGraph.from_coo(idx.reshape(-1), torch.arange(m, device=idx.device), torch.ones(m, device=idx.device), ctx.n)
+        hits.n_cols = m
+        return K.spmm_csr(hits.rowptr, hits.col, hits.val, g.contiguous().reshape(m, -1)), None
+
+
+def gather_rows(v, idx):
+    if torch.is_grad_enabled() and v.requires_grad:
+        return _GatherRows.apply(v, idx)
+    return K.gather_rows(v, idx)
+
+
+def mul_cols(x, w):
+    return K.mul_cols(x, w)

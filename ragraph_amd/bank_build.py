@@ -31,13 +31,6 @@ from .ragraph_utils.utility import process_tu_dataset
 NUM_ANCHORS, DIS_Q = 10, 10.0   # ToyGraphBase.py:27-28 (num_anchors, dis_q)
 
 
-def _transpose(g: CSRGraph) -> CSRGraph:
-    """CSR of the transposed matrix (row j lists the i with adj[i][j] != 0, ascending i)."""
-    rows = torch.repeat_interleave(torch.arange(g.n, device=g.device), g.rowptr[1:] - g.rowptr[:-1])
-    gt, _ = CSRGraph.from_coo(g.col.long(), rows, g.val, g.n, sort_cols=True)
-    return gt
-
-
 def compute_sample_prob(adj, graph_ptr: torch.Tensor | None = None) -> torch.Tensor:
     """InverseSampling.compute_sample_prob (InverseSampling.py:6-19) for every graph of a block-diagonal batch at once:
     p ~ 1 / (0.5 * PageRank + 0.5 * degree centrality + 1e-6), normalised per graph.  `adj`: CSRGraph (or a dense
@@ -45,7 +38,7 @@ def compute_sample_prob(adj, graph_ptr: torch.Tensor | None = None) -> torch.Ten
     g = adj if isinstance(adj, CSRGraph) else CSRGraph.from_dense(adj)
     if graph_ptr is None:
         graph_ptr = torch.tensor([0, g.n], dtype=torch.int64, device=g.device)
-    gt = _transpose(g)
+    gt = g.transposed()
     out_deg = K.csr_row_sums(g.rowptr, g.val)                    # :25 torch.sum(adj, dim=1)
     p, _ = K.pagerank(gt.rowptr, gt.col, gt.val, out_deg, graph_ptr)   # :22-47
     col_sum = K.csr_row_sums(gt.rowptr, gt.val)                  # :53 torch.sum(adj, dim=0)
@@ -94,7 +87,7 @@ def build_toy_graph(tgb, resource_dataset, batch_size: int = 4096) -> None:
         features, adj, node_labels = process_tu_dataset(data, resource_dataset.num_node_attributes, device=dev)
         graph_ptr = data.ptr.to(dev, torch.int64)
         graph_labels = None
-        if tgb.flavour == "graph":
+        if tgb.flavour in ("graph", "graph_fewshot"):
             graph_labels = torch.nn.functional.one_hot(data.y.reshape(-1).to(dev).long(),
                                                        tgb.resource_labels.shape[1]).float()
         _build_batch(tgb, features, adj, node_labels, graph_ptr, graph_labels)
@@ -108,8 +101,9 @@ def _build_batch(tgb, features, adj: CSRGraph, node_labels, graph_ptr, graph_lab
     if tgb.num_augment_scale > 0:                                               # Augmentation.augment_graph :51-64
         prob0 = compute_sample_prob(adj, graph_ptr)
         variants += [augment_batch(features, prob0, graph_ptr) for _ in range(tgb.num_augment_scale)]
+    embed = tgb.pretrain_model.encode if tgb.flavour == "graph_fewshot" else tgb.pretrain_model.inference
     for aug_features, aug_adj in variants:
-        emb = tgb.pretrain_model.inference(aug_features, aug_adj)               # :93
+        emb = embed(aug_features, aug_adj)                                      # :93 (graph_fewshot :120 encode)
         if S > 0:
             prob = compute_sample_prob(aug_adj, graph_ptr)                      # :97
             sizes = graph_ptr[1:] - graph_ptr[:-1]
@@ -136,6 +130,10 @@ def _build_batch(tgb, features, adj: CSRGraph, node_labels, graph_ptr, graph_lab
             keys = K.segment_reduce(keys, seg_ptr, mean_mode=True)
             values = K.segment_reduce(values, seg_ptr, mean_mode=True)
             labels, positions = graph_labels, None
+        elif tgb.flavour == "graph_fewshot":   # RAGraph_graph_fewshot/.../ToyGraphBase.py:118-126: every node, its graph's label
+            rows = seg_ptr[1:] - seg_ptr[:-1]
+            labels, positions = K.gather_rows(graph_labels, torch.repeat_interleave(
+                torch.arange(rows.numel(), device=rows.device), rows)), None
         tgb.add_resources(keys, values, labels, positions=positions)            # :116-119
 
 

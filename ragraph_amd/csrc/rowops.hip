@@ -156,6 +156,53 @@ __global__ void __launch_bounds__(256) sigmoid_gate_kernel(const float* __restri
     out[i] = __fmul_rn(x[i], 1.f / (1.f + expf(-z[i])));
 }
 
+// ---- backward of the fused epilogues (fine-tuning: RAGraph_node_fewshot/RAGraph.py:69 trains the decode layer through
+// its SpMM; RAGraph_edge/modules/RAGraph.py:335-355 trains embeddings / gate through the propagation) -------------------
+// gz = gy * act'(z) expressed through the OUTPUT y (sign(y) = sign(z) for the leaky family; ELU: y + alpha for y < 0);
+// t (optional, PReLU): the slope's gradient terms gy * z for z < 0, z = y / alpha.
+__global__ void __launch_bounds__(256) act_grad_kernel(const float* __restrict__ y, const float* __restrict__ gy, int64_t n,
+                                                       int act, float alpha, float* __restrict__ gz, float* __restrict__ t) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float yv = y[i], g = gy[i];
+    float d = 1.f;
+    if (act == RAGRAPH_ACT_RELU) d = yv > 0.f ? 1.f : 0.f;
+    else if (act == RAGRAPH_ACT_PRELU || act == RAGRAPH_ACT_LEAKY) d = yv >= 0.f ? 1.f : alpha;
+    else if (act == RAGRAPH_ACT_ELU) d = yv > 0.f ? 1.f : yv + alpha;
+    gz[i] = g * d;
+    if (t) t[i] = (yv < 0.f && alpha != 0.f) ? g * (yv / alpha) : 0.f;
+  }
+}
+
+// emb_gate backward: out = x * s, s = sigmoid(z):  gx = g * s,  gz = g * x * s * (1 - s)
+__global__ void __launch_bounds__(256) sigmoid_gate_grad_kernel(const float* __restrict__ x, const float* __restrict__ z,
+                                                                const float* __restrict__ g, int64_t n, float* __restrict__ gx,
+                                                                float* __restrict__ gz) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float sg = 1.f / (1.f + expf(-z[i]));
+    gx[i] = g[i] * sg;
+    gz[i] = g[i] * x[i] * sg * (1.f - sg);
+  }
+}
+
+// softmax backward (RAGraph.py:55-57): out = p * (g - sum_c g p), g = go * scale; one thread per row
+__global__ void __launch_bounds__(256) softmax_grad_kernel(const float* __restrict__ p, const float* __restrict__ go, int64_t B,
+                                                           int C, float scale, float* __restrict__ out) {
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  float dot = 0.f;
+  for (int c = 0; c < C; ++c) dot = fmaf(go[b * C + c] * scale, p[b * C + c], dot);
+  for (int c = 0; c < C; ++c) out[b * C + c] = p[b * C + c] * (go[b * C + c] * scale - dot);
+}
+
+// downstreamprompt.forward (RAGraph_graph/downprompt.py:164-168): out[r,:] = x[r,:] * w[:]
+__global__ void __launch_bounds__(256) mul_cols_kernel(const float* __restrict__ x, const float* __restrict__ w, int64_t n, int D,
+                                                       float* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n * D; i += stride) out[i] = __fmul_rn(x[i], w[i % D]);
+}
+
 // ---- a12: (t - t_min) / (t_max - t_min) on int64 time steps (RAGraph_edge/modules/RAGraph.py:254-257) ----------------
 __global__ void __launch_bounds__(256) time_rescale_kernel(const int64_t* __restrict__ t, int64_t n, float tmin,
                                                            float tmax, float* __restrict__ out) {
@@ -358,5 +405,46 @@ extern "C" int ragraph_time_rescale_f32(const int64_t* t, int64_t n, float t_min
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(time_rescale_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), t, n, t_min, t_max, out);
   RG_CHECK_LAUNCH("time_rescale");
+  return RAGRAPH_OK;
+}
+
+static unsigned ew_blocks(int64_t n) {
+  int64_t b = cdiv(n, 256);
+  return (unsigned)(b > 2048 ? 2048 : b);
+}
+
+extern "C" int ragraph_act_grad_f32(const float* y, const float* gy, int64_t n, int act, float alpha, float* gz,
+                                    float* alpha_terms, void* stream) {
+  RG_REQUIRE(y && gy && gz, RAGRAPH_EINVAL, "act_grad: null pointer");
+  if (n <= 0) return RAGRAPH_OK;
+  hipLaunchKernelGGL(act_grad_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), y, gy, n, act, alpha, gz,
+                     alpha_terms);
+  RG_CHECK_LAUNCH("act_grad");
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_sigmoid_gate_grad_f32(const float* x, const float* z, const float* g, int64_t n, float* gx, float* gz,
+                                             void* stream) {
+  RG_REQUIRE(x && z && g && gx && gz, RAGRAPH_EINVAL, "sigmoid_gate_grad: null pointer");
+  if (n <= 0) return RAGRAPH_OK;
+  hipLaunchKernelGGL(sigmoid_gate_grad_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), x, z, g, n, gx, gz);
+  RG_CHECK_LAUNCH("sigmoid_gate_grad");
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_softmax_grad_f32(const float* p, const float* go, int64_t B, int C, float scale, float* out,
+                                        void* stream) {
+  RG_REQUIRE(p && go && out, RAGRAPH_EINVAL, "softmax_grad: null pointer");
+  if (B <= 0) return RAGRAPH_OK;
+  hipLaunchKernelGGL(softmax_grad_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, as_stream(stream), p, go, B, C, scale, out);
+  RG_CHECK_LAUNCH("softmax_grad");
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_mul_cols_f32(const float* x, const float* w, int64_t n, int D, float* out, void* stream) {
+  RG_REQUIRE(x && w && out && D >= 1, RAGRAPH_EINVAL, "mul_cols: bad argument");
+  if (n <= 0) return RAGRAPH_OK;
+  hipLaunchKernelGGL(mul_cols_kernel, dim3(ew_blocks(n * D)), dim3(256), 0, as_stream(stream), x, w, n, D, out);
+  RG_CHECK_LAUNCH("mul_cols");
   return RAGRAPH_OK;
 }

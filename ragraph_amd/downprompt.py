@@ -14,7 +14,7 @@ class downstreamprompt(nn.Module):
         torch.nn.init.xavier_uniform_(self.weight)     # downprompt.py:160-161
 
     def forward(self, graph_embedding):                # downprompt.py:164-168: weight * h
-        return graph_embedding * self.weight           # element-wise; the fused form is split_and_batchify(..., weight)
+        return K.mul_cols(graph_embedding, self.weight)   # (the fused form is split_and_batchify(..., weight))
 
 
 def split_and_batchify_graph_feats(batched_graph_feats, graph_sizes, weight=None):

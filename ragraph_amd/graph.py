@@ -24,6 +24,7 @@ class CSRGraph:
     n: int
     _row_normalized: torch.Tensor | None = field(default=None, repr=False)
     _has_long_rows: bool | None = field(default=None, repr=False)
+    _transposed: "CSRGraph | None" = field(default=None, repr=False)
 
     @property
     def shape(self):
@@ -57,6 +58,14 @@ class CSRGraph:
         if self._row_normalized is None:
             self._row_normalized = K.csr_row_normalize(self.rowptr, self.val)
         return self._row_normalized
+
+    def transposed(self) -> "CSRGraph":
+        """CSR of A^T (row j lists the i with A[i][j] != 0, ascending i), cached: what a backward pass through the SpMM
+        multiplies by, and what PageRank pulls along."""
+        if self._transposed is None:
+            rows = torch.repeat_interleave(torch.arange(self.n, device=self.device), self.rowptr[1:] - self.rowptr[:-1])
+            self._transposed, _ = CSRGraph.from_coo(self.col.long(), rows, self.val, self.n, sort_cols=True)
+        return self._transposed
 
     # ---- constructors ------------------------------------------------------------------------------------------
     @staticmethod

@@ -607,3 +607,45 @@ def binorm_edges(users: torch.Tensor, items: torch.Tensor, step: torch.Tensor, n
             "binorm_edges")
     m = int(ne.item())
     return edges[:m].contiguous(), norm[:m].contiguous(), times[:m].contiguous()
+
+
+# ---- element-wise derivatives of the fused epilogues (fine-tuning backward) -------------------------------------------
+def act_grad(y: torch.Tensor, gy: torch.Tensor, act: int, alpha: float = 0.0, want_alpha_terms: bool = False):
+    """gz = gy * act'(z) through the output y; with want_alpha_terms also gy * z on z < 0 (PReLU slope gradient terms)."""
+    L = _ready()
+    y, gy = _f32c(y, "act_grad.y"), _f32c(gy, "act_grad.gy")
+    gz = torch.empty_like(y)
+    t = torch.empty_like(y) if want_alpha_terms else None
+    N.check(L.ragraph_act_grad_f32(y.data_ptr(), gy.data_ptr(), y.numel(), act, float(alpha), gz.data_ptr(), _ptr(t), _stream()),
+            "act_grad")
+    return (gz, t) if want_alpha_terms else gz
+
+
+def sigmoid_gate_grad(x: torch.Tensor, z: torch.Tensor, g: torch.Tensor):
+    L = _ready()
+    x, z, g = _f32c(x, "sigmoid_gate_grad.x"), _f32c(z, "sigmoid_gate_grad.z"), _f32c(g, "sigmoid_gate_grad.g")
+    gx, gz = torch.empty_like(x), torch.empty_like(x)
+    N.check(L.ragraph_sigmoid_gate_grad_f32(x.data_ptr(), z.data_ptr(), g.data_ptr(), x.numel(), gx.data_ptr(), gz.data_ptr(),
+                                            _stream()), "sigmoid_gate_grad")
+    return gx, gz
+
+
+def softmax_grad(p: torch.Tensor, go: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    L = _ready()
+    p, go = _f32c(p, "softmax_grad.p"), _f32c(go, "softmax_grad.go")
+    p2 = p.reshape(-1, p.shape[-1])
+    out = torch.empty_like(p2)
+    N.check(L.ragraph_softmax_grad_f32(p2.data_ptr(), go.reshape(p2.shape).data_ptr(), p2.shape[0], p2.shape[1], float(scale),
+                                       out.data_ptr(), _stream()), "softmax_grad")
+    return out.reshape(p.shape)
+
+
+def mul_cols(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """x[r,:] * w -- downstreamprompt.forward (RAGraph_graph/downprompt.py:164-168)."""
+    L = _ready()
+    x = _f32c(x, "mul_cols.x")
+    w = _f32c(w, "mul_cols.w").reshape(-1)
+    x2 = x.reshape(-1, x.shape[-1])
+    out = torch.empty_like(x2)
+    N.check(L.ragraph_mul_cols_f32(x2.data_ptr(), w.data_ptr(), x2.shape[0], x2.shape[1], out.data_ptr(), _stream()), "mul_cols")
+    return out.reshape(x.shape)

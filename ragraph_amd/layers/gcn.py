@@ -31,6 +31,12 @@ class GCN(nn.Module):
         flag is accepted for signature compatibility; aggregation is always the CSR SpMM kernel."""
         seq, adj = input[0], input[1]
         g = as_csr(adj)
-        seq_fts = K.linear(seq.squeeze(0) if seq.dim() == 3 else seq, self.fc.weight)          # :32
+        x = seq.squeeze(0) if seq.dim() == 3 else seq
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # fine-tuning (the few-shot flavours train this layer through decode()): the same kernels, with backward
+            from .. import autograd as A
+            seq_fts = A.linear(x, self.fc.weight)
+            return A.spmm_csr(g, seq_fts, self.bias, K.ACT_PRELU, self.act.weight, self._alpha())
+        seq_fts = K.linear(x, self.fc.weight)                                                    # :32
         return K.spmm_csr(g.rowptr, g.col, g.val, seq_fts, bias=self.bias, act=K.ACT_PRELU,      # :36-40 fused
                           alpha=self._alpha(), long_rows=g.has_long_rows)

@@ -43,7 +43,7 @@ class ToyGraphBase:
             self.num_inverse_sample = 10
             self.num_augment_scale = 3
             self.retrieve_num = num_class + 1
-        else:                   # RAGraph_graph/ragraph_utils/ToyGraphBase.py:21-27
+        else:                   # RAGraph_graph/ragraph_utils/ToyGraphBase.py:21-27 (graph_fewshot: the same constants)
             self.num_inverse_sample = 0
             self.num_augment_scale = 0
             self.retrieve_num = min(3, num_class + 1)

@@ -173,7 +173,8 @@ def test_edge_generate_g9(dev):
     assert np.allclose(model.resource_values.cpu().numpy(), g["resource_values"], atol=1e-6)
     tn = model._relative_edge_time_encoding(model.edges, model.edge_times)
     assert np.allclose(tn.cpu().numpy(), g["time_norm"], atol=1e-6)
-    gated = model.emb_gate(torch.cat([model.user_embedding, model.item_embedding]).detach())
+    with torch.no_grad():   # (outside no_grad the gate is on the autograd tape: the fine-tuning path)
+        gated = model.emb_gate(torch.cat([model.user_embedding, model.item_embedding]).detach())
     assert np.allclose(gated.cpu().numpy(), g["gated_emb"], atol=1e-6)
     uo, io = model.generate()
     out = torch.cat([uo, io]).cpu().numpy()

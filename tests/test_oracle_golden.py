@@ -229,3 +229,19 @@ def test_g14_ingestion_host_restatement(tmp_path):
     assert ds.num_users == int(g["edge_num_users"]) and ds.num_items == int(g["edge_num_items"])
     assert np.array_equal(ds.edges.numpy(), g["edge_edges"]) and np.array_equal(ds.edge_times.numpy(), g["edge_times"])
     assert np.allclose(ds.edge_norm.numpy(), g["edge_norm"], atol=1e-7)
+
+
+def test_g15_graph_fewshot_forward():
+    g = gold("g15_graph_fewshot")
+    p = {k: g[k] for k in ("W0", "b0", "W1", "b1")}
+    p["a0"], p["a1"] = float(g["a0"][0]), float(g["a1"][0])
+    csr = cref.dense_to_csr(g["adj"])
+    out, idx, h = pipeline.graph_fewshot_forward(g["X"], csr, p, g["keys"], g["values"], g["labels"], g["mean_fewshot_logits"],
+                                                 int(g["k"]), float(g["retrieve_weight"]), float(g["label_weight"]))
+    assert np.allclose(h, g["H"], atol=1e-5)
+    assert np.allclose(out, g["logits"], atol=2e-5)
+    # the bank rows the reference built from two resource graphs: every node, normalised keys, its graph's label
+    for tag, lo, hi, lab in (("res0", 0, 17, 0), ("res1", 17, 40, 1)):
+        hk = pipeline.gcn_layer(g[tag + "_x"], cref.dense_to_csr(g[tag + "_adj"]), p["W0"], p["b0"], p["a0"])
+        assert np.allclose(cref.normalize_rows(hk), g["built_keys"][lo:hi], atol=1e-5)
+        assert (g["built_labels"][lo:hi].argmax(1) == lab).all()
