@@ -59,7 +59,7 @@ __device__ __forceinline__ float filter_eps(const FilterThr& t, int64_t q) {
 }
 
 __device__ __forceinline__ float filter_threshold(const FilterThr& t, int64_t q) {
-  if (t.ablate) return __builtin_huge_valf();
+  if (t.ablate == 1) return __builtin_huge_valf();
   const float eps = filter_eps(t, q);
   float theta;
   if (t.theta) {
@@ -74,6 +74,15 @@ __device__ __forceinline__ float filter_threshold(const FilterThr& t, int64_t q)
   return __fsub_rn(theta, eps);
 }
 
+// Candidate counters of a call of up to 256 queries.  A returning atomicAdd costs ~11 ns per operation on ONE address
+// and ~1.8 ns on one 128-byte line chip-wide (tools/microbench/atomic_contention_bench.hip): 16 queries x 800
+// candidates on sixteen neighbouring ints were 25 us of serialised atomics behind a 75 us stream.  So every query's
+// counters sit on their own line (FILTER_COUNT_STRIDE ints apart), and a query of a very small batch -- whose list the
+// sliced rescoring cuts into S parts anyway -- gets S sub-lists with a counter each, the waves spread over them.
+constexpr int FILTER_COUNT_STRIDE = 32;
+constexpr int FILTER_TICKET_SLOT = 16;  // int of a query's line that counts its finished rescoring workgroups
+__host__ __device__ constexpr int filter_count_stride(int64_t B) { return B <= 256 ? FILTER_COUNT_STRIDE : 1; }
+
 // One filter launch of the direct kernel (topk_filter_direct.hip): up to 256 queries against keys [key0, key1) of the
 // bf16 copy (key0 a multiple of 32).  bound_groups > 0: the BOUND pass -- no thresholds, no candidates, the launch
 // records per query the best approximate score of each of bound_groups consecutive parts of the range into gmax_out.
@@ -84,9 +93,10 @@ struct DirectArgs {
   const uint16_t* Kb;     // fragment-order bf16 keys
   int64_t B, key0, key1;
   FilterThr thr;          // (filter launches)
-  int* count;             // [B] candidate slots reserved so far
-  int* cand;              // [B,cap] candidate key indices (local to this shard)
+  int* count;             // [B][FILTER_COUNT_STRIDE] candidate slots reserved so far, per sub-list
+  int* cand;              // [B,cap] candidate key indices (local to this shard): nsub sub-lists of cap / nsub slots
   int cap;
+  int nsub;               // sub-lists per query (a power of two <= FILTER_COUNT_STRIDE; wave w appends to w % nsub)
   int* gmax_out;          // (bound pass) [B,bound_groups]
   int bound_groups;
 };

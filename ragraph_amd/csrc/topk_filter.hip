@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
                                                           float* __restrict__ eq, int* __restrict__ count,
                                                           unsigned char* __restrict__ flag, int* __restrict__ overflow,
                                                           int* __restrict__ gmax, int ngroups,
-                                                          uint16_t* __restrict__ Qb) {
+                                                          uint16_t* __restrict__ Qb, int cstride) {
   const int lane = threadIdx.x & 63;
   const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q == 0 && lane == 0) *overflow = 0;
@@ -171,9 +171,9 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
   if (q >= B) return;
   if (lane == 0) {
     eq[q] = sqrtf(e2) * 1.0000002f;  // (any summation order of the squares stays below this)
-    count[q] = 0;
     flag[q] = 0;
   }
+  if (lane < cstride) count[q * cstride + lane] = 0;
   if (gmax && lane < ngroups) gmax[q * ngroups + lane] = f2ord(RG_NEG_INF);
 }
 
@@ -529,38 +529,78 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
 // Canonical top-k (score descending, index ascending) of the 64 x NSL (score, id) pairs a wave holds in registers:
 // k rounds of wave argmax over what comes after the previous winner.  Lane 0 writes the result (ids + base).  Ids are
 // shard-local key indices (32 bits; INT_MAX = none, written out as INT64_MAX): a third less to shuffle than 64-bit ones.
+// ---- canonical top-k of a wave's 64 NSL (score, id) pairs (score descending, id ascending; k <= 32) -------------------
+// A pair travels as one 64-bit key whose unsigned order is the canonical order: the score's bits made monotone in the
+// upper word, ~id in the lower; an empty slot (-inf, INT_MAX) and a pair already taken are key 0, which decodes to
+// (-inf, INT64_MAX).  Round r: every lane's best remaining key, the wave's maximum of those -- four DPP steps inside
+// each row of 16 lanes (quad_perm / row_half_mirror / row_mirror: no LDS traffic) and the four row maxima through
+// v_readlane, i.e. a wave-uniform value -- which lane r keeps and every lane strikes from its slots.  (The __shfl_xor
+// butterfly this replaces was twelve dependent ds_bpermute per round: ~0.8 us a round, 8 us a call at k = 10, three
+// such calls in a row in the rescoring of a small batch.)
+__device__ __forceinline__ unsigned select_ord(float f) {
+  unsigned u = __float_as_uint(f);
+  if (u == 0x80000000u) u = 0u;  // -0 == +0
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float select_unord(unsigned o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o); }
+
+template <int CTRL>
+__device__ __forceinline__ void select_dpp_max(unsigned& hi, unsigned& lo) {
+  const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xF, 0xF, false);
+  const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xF, 0xF, false);
+  const bool take = ohi > hi || (ohi == hi && olo > lo);
+  hi = take ? ohi : hi;
+  lo = take ? olo : lo;
+}
+
 template <int NSL>
 __device__ __forceinline__ void wave_select(const float (&s)[NSL], const int (&id)[NSL], int k, int lane, int64_t base,
                                             float* out_s, int64_t* out_i) {
-  float prev_sc = __builtin_huge_valf();
-  int prev_id = -1;  // everything is worse than (+inf, -1)
+  unsigned khi[NSL], klo[NSL];
+#pragma unroll
+  for (int u = 0; u < NSL; ++u) {
+    const bool empty = id[u] == INT_MAX;
+    khi[u] = empty ? 0u : select_ord(s[u]);
+    klo[u] = empty ? 0u : ~(unsigned)id[u];
+  }
+  unsigned my_hi = 0u, my_lo = 0u;  // lane r: the r-th winner
   for (int r = 0; r < k; ++r) {
-    float best_s = RG_NEG_INF;
-    int best_i = INT_MAX;
+    unsigned bh = khi[0], bl = klo[0];
+#pragma unroll
+    for (int u = 1; u < NSL; ++u) {
+      const bool take = khi[u] > bh || (khi[u] == bh && klo[u] > bl);
+      bh = take ? khi[u] : bh;
+      bl = take ? klo[u] : bl;
+    }
+    select_dpp_max<0xB1>(bh, bl);   // quad_perm [1,0,3,2]: lane ^ 1
+    select_dpp_max<0x4E>(bh, bl);   // quad_perm [2,3,0,1]: lane ^ 2
+    select_dpp_max<0x141>(bh, bl);  // row_half_mirror: the other quad of the 8
+    select_dpp_max<0x140>(bh, bl);  // row_mirror: the other half of the 16
+    unsigned mh = (unsigned)__builtin_amdgcn_readlane((int)bh, 0), ml = (unsigned)__builtin_amdgcn_readlane((int)bl, 0);
+#pragma unroll
+    for (int row = 1; row < 4; ++row) {
+      const unsigned h = (unsigned)__builtin_amdgcn_readlane((int)bh, 16 * row);
+      const unsigned l = (unsigned)__builtin_amdgcn_readlane((int)bl, 16 * row);
+      const bool take = h > mh || (h == mh && l > ml);
+      mh = take ? h : mh;
+      ml = take ? l : ml;
+    }
+    if (lane == r) {
+      my_hi = mh;
+      my_lo = ml;
+    }
+    if ((mh | ml) == 0u) break;  // nothing left: the remaining winners stay empty
 #pragma unroll
     for (int u = 0; u < NSL; ++u) {
-      const bool after_prev = (s[u] < prev_sc) || (s[u] == prev_sc && id[u] > prev_id);
-      const bool beats = (s[u] > best_s) || (s[u] == best_s && id[u] < best_i);
-      if (after_prev && beats) {
-        best_s = s[u];
-        best_i = id[u];
-      }
+      const bool hit = khi[u] == mh && klo[u] == ml;
+      khi[u] = hit ? 0u : khi[u];
+      klo[u] = hit ? 0u : klo[u];
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const float os = __shfl_xor(best_s, off);
-      const int oi = __shfl_xor(best_i, off);
-      if ((os > best_s) || (os == best_s && oi < best_i)) {
-        best_s = os;
-        best_i = oi;
-      }
-    }
-    if (lane == 0) {
-      out_s[r] = best_s;
-      out_i[r] = best_i == INT_MAX ? INT64_MAX : (int64_t)best_i + base;
-    }
-    prev_sc = best_s;
-    prev_id = best_i;
+  }
+  if (lane < k) {
+    const bool empty = (my_hi | my_lo) == 0u;
+    out_s[lane] = empty ? RG_NEG_INF : select_unord(my_hi);
+    out_i[lane] = empty ? INT64_MAX : (int64_t)(int)~my_lo + base;
   }
 }
 
@@ -887,14 +927,21 @@ __device__ __forceinline__ void exact_scan_query(const float4* qs /* LDS: the qu
 // each a latency-bound chain of row loads, and a few hundred waves do not hide that; here four waves take a quarter of
 // the list each, leave their top-k in LDS, and wave 0 merges the four (and the previous level's winners, which ride
 // with wave 0's quarter).
-// SLICED (a handful of queries: gridDim.y = S workgroups per query): a workgroup rescans only slice blockIdx.y of the
-// list and leaves its k winners (local ids) in part_s / part_i [B][S][k]; topk_rescore_merge_kernel finishes the query.
+// SLICED (a handful of queries: gridDim.y = S workgroups per query): a workgroup rescans only sub-list blockIdx.y of
+// the query (the direct kernel filled S of them) and leaves its k winners (local ids) in part_s / part_i [B][S][k]; the
+// query's last workgroup to finish (a ticket in the query's counter line) merges them -- no second launch.
 // One workgroup walking ~800 candidates of a lone query is ~30 us of dependent row gathers; eight of them take ~8.
-template <int D, bool SLICED>
+#ifdef RG_WIDE_TIMING
+__device__ unsigned long long g_wide_t[16];
+#define RG_WSTAMP(i_) if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_wide_t[i_] = wall_clock64()
+#else
+#define RG_WSTAMP(i_)
+#endif
+template <int D, bool SLICED, bool COOP>
 __global__ void __launch_bounds__(256) topk_rescore_wide_kernel(const float* __restrict__ Qn, const float* __restrict__ Kn,
                                                                 int* __restrict__ count,
-                                                                const int* __restrict__ cand, int64_t B, int cap, int k,
-                                                                int64_t idx_base, const float* prev_s,
+                                                                const int* __restrict__ cand, int64_t B, int64_t N, int cap,
+                                                                int cs, int k, int64_t idx_base, const float* prev_s,
                                                                 const int64_t* prev_i, int final_level, float* out_s,
                                                                 int64_t* out_i, int* __restrict__ overflow,
                                                                 int* __restrict__ overflow_list,
@@ -903,15 +950,23 @@ __global__ void __launch_bounds__(256) topk_rescore_wide_kernel(const float* __r
   __shared__ float4 qs[D / 4];
   __shared__ float ps[4][32];
   __shared__ int64_t pi[4][32];
+  // COOP (up to 256 queries): rows fetched cooperatively through a per-wave LDS tile (coop_scores) -- a lane walking its
+  // own 1-KiB row is a chain of ~8 memory latencies; SLICED also scans the bank through it when a list overflowed
+  __shared__ __attribute__((aligned(16))) float tile[(COOP || SLICED) ? 4 : 1][(COOP || SLICED) ? 64 * RESCORE_LD : 4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t b = blockIdx.x;
+  RG_WSTAMP(0);
   if (threadIdx.x < D / 4) qs[threadIdx.x] = reinterpret_cast<const float4*>(Qn + b * D)[threadIdx.x];
   __syncthreads();
-  int n = count[b];
+  RG_WSTAMP(1);
+  // SLICED: sub-list blockIdx.y of the query (the direct kernel filled gridDim.y of them, cap / gridDim.y slots each);
+  // the merge launch looks after overflow and empties the counters
+  const int subcap = SLICED ? cap / (int)gridDim.y : cap;
+  int n = count[b * cs + (SLICED ? (int)blockIdx.y : 0)];
   bool over = false;
-  if (n > cap) {
+  if (n > subcap) {
     over = true;
-    n = cap;
+    n = subcap;
   }
   if constexpr (!SLICED) {
     over = over || flag[b] != 0;
@@ -926,28 +981,25 @@ __global__ void __launch_bounds__(256) topk_rescore_wide_kernel(const float* __r
       }
     }
   }
-  int lo0 = 0;
-  if constexpr (SLICED) {  // this workgroup's slice of the list
-    const int S = (int)gridDim.y, sl = (int)blockIdx.y;
-    const int pers = (n + S - 1) / S;
-    lo0 = sl * pers;
-    n = lo0 >= n ? 0 : (n - lo0 < pers ? n - lo0 : pers);
-  }
+  const int lo0 = SLICED ? (int)blockIdx.y * subcap : 0;
   const int per = (n + 3) / 4;  // <= 512
   const int lo = w * per;
   const int nw = lo >= n ? 0 : (n - lo < per ? n - lo : per);
   const int* cb = cand + b * cap + lo0 + lo;
   const float* pps = (!SLICED && prev_s && w == 0) ? prev_s + b * k : nullptr;
   const int64_t* ppi = (!SLICED && prev_i && w == 0) ? prev_i + b * k : nullptr;
-#define RG_RESCORE(NS_) rescore_query<D, NS_>(qs, Kn, cb, nw, lane, k, 0, pps, ppi, ps[w], pi[w])
-  if (nw <= 64) RG_RESCORE(1);
+#define RG_RESCORE(NS_) rescore_query<D, NS_, COOP>(qs, Kn, cb, nw, lane, k, 0, pps, ppi, ps[w], pi[w], tile[w])
+  if (COOP && nw <= 16) rescore_query<D, 1, true, true>(qs, Kn, cb, nw, lane, k, 0, pps, ppi, ps[w], pi[w], tile[w]);
+  else if (nw <= 64) RG_RESCORE(1);
   else if (nw <= 128) RG_RESCORE(2);
   else if (nw <= 256) RG_RESCORE(4);
   else RG_RESCORE(8);
 #undef RG_RESCORE
+  RG_WSTAMP(2);
   __syncthreads();
+  RG_WSTAMP(3);
   if constexpr (!SLICED) {
-    if (threadIdx.x == 0) count[b] = 0;  // every wave has read it: the next level starts from an empty list
+    if (threadIdx.x == 0) count[b * cs] = 0;  // every wave has read it: the next level starts from an empty list
   }
   if (w == 0) {  // 4 k <= 128 partial winners: two per lane
     float s[2];
@@ -973,60 +1025,58 @@ __global__ void __launch_bounds__(256) topk_rescore_wide_kernel(const float* __r
       wave_select<2>(s, id, k, lane, final_level ? idx_base : 0, out_s + b * k, out_i + b * k);
     }
   }
-}
-
-// Second half of the sliced rescoring, one workgroup per query: wave 0 merges the S slices' winners (S k <= 256: four per
-// lane) with the previous level's, does the level's bookkeeping (overflow flag / count, empty list for the next level)
-// and writes the running result; a query that overflowed its list gets the exact scan right here on the final level,
-// so these calls need no separate fallback launch.
-template <int D>
-__global__ void __launch_bounds__(256) topk_rescore_merge_kernel(const float* __restrict__ Qn, const float* __restrict__ Kn,
-                                                                 int64_t N, int* __restrict__ count, int S, int cap, int k,
-                                                                 int64_t idx_base, const float* prev_s, const int64_t* prev_i,
-                                                                 int final_level, float* out_s, int64_t* out_i,
-                                                                 int* __restrict__ overflow, unsigned char* __restrict__ flag,
-                                                                 const float* __restrict__ part_s,
-                                                                 const int* __restrict__ part_i) {
-  __shared__ float4 qs[D / 4];
-  __shared__ __attribute__((aligned(16))) float tile[4][64 * RESCORE_LD];
-  __shared__ float ps[4][32];
-  __shared__ int64_t pi[4][32];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t b = blockIdx.x;
-  const int n = count[b];
-  const bool over = flag[b] != 0 || n > cap;
-  if (final_level && over) {  // (block-uniform)
-    if (threadIdx.x < D / 4) qs[threadIdx.x] = reinterpret_cast<const float4*>(Qn + b * D)[threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      count[b] = 0;
-      atomicAdd(overflow, 1);
+  if constexpr (SLICED) {
+    // ---- the query's LAST workgroup to get here merges the S slices' winners (S k <= 256: four per lane) with the
+    // previous level's, does the level's bookkeeping (overflow flag / count, empty lists for the next level) and writes
+    // the running result; a query that overflowed a sub-list gets the exact scan right here on the final level, so
+    // these calls need no merge launch and no separate fallback launch.
+    __shared__ int last_sh;
+    const int S = (int)gridDim.y;
+    int* cnt = count + b * cs;  // [0, S): the sub-lists' counters; [FILTER_TICKET_SLOT]: workgroups done
+    RG_WSTAMP(4);
+    if (w == 0) {
+      __threadfence();  // this slice's winners are visible device-wide before its ticket
+      RG_WSTAMP(5);
+      if (lane == 0) last_sh = atomicAdd(cnt + FILTER_TICKET_SLOT, 1) == S - 1;
     }
-    exact_scan_query<D>(qs, Kn, N, k, idx_base, tile, ps, pi, out_s + b * k, out_i + b * k);
-    return;
-  }
-  if (w != 0) return;
-  if (lane == 0 && n >= 0) {
-    count[b] = 0;
-    if (over) flag[b] = 1;
-  }
-  float s[5];
-  int id[5];
+    __syncthreads();
+    RG_WSTAMP(6);
+    if (!last_sh) return;
+    __threadfence();
+    RG_WSTAMP(7);
+    int nmax = 0;
+    for (int s_ = 0; s_ < S; ++s_) nmax = max(nmax, cnt[s_]);
+    const bool over_q = flag[b] != 0 || nmax > subcap;
+    __syncthreads();  // every thread has read the counters
+    if (threadIdx.x < S) cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) cnt[FILTER_TICKET_SLOT] = 0;
+    if (final_level && over_q) {  // (block-uniform)
+      if (threadIdx.x == 0) atomicAdd(overflow, 1);
+      exact_scan_query<D>(qs, Kn, N, k, idx_base, tile, ps, pi, out_s + b * k, out_i + b * k);
+      return;
+    }
+    if (w != 0) return;
+    if (lane == 0 && over_q) flag[b] = 1;
+    float s[5];
+    int id[5];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int e = lane + 64 * u;
-    const bool have = e < S * k;
-    s[u] = have ? part_s[b * S * k + e] : RG_NEG_INF;
-    id[u] = have ? part_i[b * S * k + e] : INT_MAX;
+    for (int u = 0; u < 4; ++u) {  // (the other workgroups' stores: read past this CU's and XCD's caches)
+      const int e = lane + 64 * u;
+      const bool have = e < S * k;
+      s[u] = have ? __hip_atomic_load(part_s + b * S * k + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : RG_NEG_INF;
+      id[u] = have ? __hip_atomic_load(part_i + b * S * k + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INT_MAX;
+    }
+    s[4] = RG_NEG_INF;
+    id[4] = INT_MAX;
+    if (prev_s && lane < k) {
+      s[4] = prev_s[b * k + lane];
+      const int64_t pv = prev_i[b * k + lane];
+      id[4] = pv >= INT_MAX ? INT_MAX : (int)pv;
+    }
+    RG_WSTAMP(8);
+    wave_select<5>(s, id, k, lane, final_level ? idx_base : 0, out_s + b * k, out_i + b * k);
+    RG_WSTAMP(9);
   }
-  s[4] = RG_NEG_INF;
-  id[4] = INT_MAX;
-  if (prev_s && lane < k) {
-    s[4] = prev_s[b * k + lane];
-    const int64_t pv = prev_i[b * k + lane];
-    id[4] = pv >= INT_MAX ? INT_MAX : (int)pv;
-  }
-  wave_select<5>(s, id, k, lane, final_level ? idx_base : 0, out_s + b * k, out_i + b * k);
 }
 
 // Large batches (the one-wave-per-query rescoring kernels): the final level has listed the overflowed queries, and this
@@ -1275,12 +1325,15 @@ extern "C" int ragraph_keys_to_bf16(const float* Kn, int64_t N, int D, uint16_t*
 extern "C" int64_t ragraph_keys_bf16_rows(int64_t N) { return N < 1 ? 0 : filter_round_up(N) + 1; }
 
 extern "C" int ragraph_topk_cosine_filtered_cap(int k) { return 2048; }
+static int rescore_slices(int64_t B, int k);
+// slots of a query's candidate region: one list, or (<= 64 queries) one full-size list per rescoring slice
+static int filter_cap(int64_t B, int k) { return ragraph_topk_cosine_filtered_cap(k) * (B <= 64 ? rescore_slices(B, k) : 1); }
 
 static size_t filter_ws_carve(char* w, int64_t B, int D, int k, int cap, struct FilterWs* out);
 
 extern "C" size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_t N, int D, int k) {
   if (B < 1 || N < 1 || k < 1 || !filter_dim_ok(D)) return 0;
-  const int cap = ragraph_topk_cosine_filtered_cap(k);
+  const int cap = filter_cap(B, k);
   const FilterSchedule sc = filter_schedule(B, N, D, k);
   return filter_level0_ws(sc, B, D, k) + filter_ws_carve(nullptr, B, D, k, cap, nullptr);
 }
@@ -1303,7 +1356,7 @@ struct FilterWs {
   float* Qn;            // [B,D] normalised queries
   uint16_t* Qb;         // (B <= 256) the same as bf16 B operands in fragment order, padded to whole groups of 32
   float* eq;            // [B] |dq|
-  int* count;           // [B] candidate slots reserved in the current level
+  int* count;           // [B][filter_count_stride(B)] candidate slots reserved in the current level (per sub-list)
   unsigned char* flag;  // [B] the list overflowed at an earlier level
   int* cand;            // [B,cap] candidate keys
   int* gmax;            // [B,k] group maxima of the bound pass
@@ -1323,7 +1376,7 @@ static size_t filter_ws_carve(char* w, int64_t B, int D, int k, int cap, FilterW
   f.Qn = reinterpret_cast<float*>(take((size_t)B * D * sizeof(float)));
   f.Qb = B <= 256 ? reinterpret_cast<uint16_t*>(take((size_t)((B + 31) / 32 * 32) * D * sizeof(uint16_t))) : nullptr;
   f.eq = reinterpret_cast<float*>(take((size_t)B * sizeof(float)));
-  f.count = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
+  f.count = reinterpret_cast<int*>(take((size_t)B * filter_count_stride(B) * sizeof(int)));
   f.flag = reinterpret_cast<unsigned char*>(take((size_t)B));
   f.cand = reinterpret_cast<int*>(take((size_t)B * cap * sizeof(int)));
   f.gmax = reinterpret_cast<int*>(take((size_t)B * k * sizeof(int)));
@@ -1332,6 +1385,20 @@ static size_t filter_ws_carve(char* w, int64_t B, int D, int k, int cap, FilterW
   f.part_i = B <= 64 ? reinterpret_cast<int*>(take((size_t)B * 8 * k * sizeof(int))) : nullptr;
   if (out) *out = f;
   return off;
+}
+
+// A handful of queries: S workgroups rescore a query (S k <= 256 partial winners for the merge launch), and the direct
+// kernel keeps S sub-lists per query, one per rescoring workgroup (filter_common.h: FILTER_COUNT_STRIDE).
+static int rescore_slices(int64_t B, int k) {
+  static const int slice_env = [] {  // RAGRAPH_RESCORE_SLICES: A/B (0 or 1 = never slice; a power of two <= 8)
+    const char* e = getenv("RAGRAPH_RESCORE_SLICES");
+    return e ? atoi(e) : -1;
+  }();
+  int S = B <= 16 ? 8 : (B <= 32 ? 4 : (B <= 64 ? 2 : 1));
+  if (slice_env >= 0) S = slice_env >= 8 ? 8 : (slice_env >= 4 ? 4 : (slice_env >= 2 ? 2 : 1));
+  if (B > 64) S = 1;  // (part_s / part_i exist up to 64 queries)
+  while (S > 1 && S * k > 256) S >>= 1;
+  return S;
 }
 
 // Ring-kernel launch shared by the filter levels and the bound pass (B > 256: the direct kernel takes smaller batches).
@@ -1395,6 +1462,7 @@ static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64
     a.count = f.count;
     a.cand = f.cand;
     a.cap = cap;
+    a.nsub = rescore_slices(B, thr.k);
     a.gmax_out = f.gmax;
     a.bound_groups = bound_groups;
     if (g_prof_on) (void)hipEventRecord(g_prof_ev[2 * prof_slot], st);
@@ -1437,25 +1505,35 @@ static int run_rescore(const FilterWs& f, const float* Kn, int64_t N, int64_t B,
     const char* e = getenv("RAGRAPH_RESCORE_WIDE_BELOW");
     return e ? (int64_t)atoll(e) : (int64_t)2048;  // measured: 512 queries 0.39 (wide) vs 0.44 ms, 1024-2048 equal, 4095: 1.98 vs 1.89
   }();
-  static const int slice_env = [] {  // RAGRAPH_RESCORE_SLICES: A/B (0 = never slice)
-    const char* e = getenv("RAGRAPH_RESCORE_SLICES");
-    return e ? atoi(e) : -1;
+  static const int64_t wide_coop_max_b = [] {  // RAGRAPH_RESCORE_WIDE_COOP_MAX: A/B
+    const char* e = getenv("RAGRAPH_RESCORE_WIDE_COOP_MAX");
+    return e ? (int64_t)atoll(e) : (int64_t)256;
   }();
-  // a handful of queries: S workgroups per query + a merge launch (S k <= 256)
-  int S = B <= 16 ? 8 : (B <= 32 ? 4 : (B <= 64 ? 2 : 1));
-  if (slice_env >= 0) S = slice_env;
-  while (S > 1 && S * k > 256) S >>= 1;
+  // a handful of queries: S workgroups per query, each with its sub-list
+  const int S = B <= 256 ? rescore_slices(B, k) : 1;
+  const int cs = filter_count_stride(B);
   if (B < wide_max_b && S > 1) {
-    hipLaunchKernelGGL((topk_rescore_wide_kernel<D, true>), dim3((unsigned)B, (unsigned)S), dim3(256), 0, st, f.Qn, Kn, f.count,
-                       f.cand, B, cap, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list,
+    hipLaunchKernelGGL((topk_rescore_wide_kernel<D, true, true>), dim3((unsigned)B, (unsigned)S), dim3(256), 0, st, f.Qn, Kn, f.count,
+                       f.cand, B, N, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list,
                        f.flag, f.part_s, f.part_i);
-    RG_CHECK_LAUNCH("topk_cosine_filtered(rescore slices)");
-    hipLaunchKernelGGL(topk_rescore_merge_kernel<D>, dim3((unsigned)B), dim3(256), 0, st, f.Qn, Kn, N, f.count, S, cap, k,
-                       idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.flag, f.part_s, f.part_i);
     *fallback_done = 1;
-  } else if (B < wide_max_b)  // too few queries to fill the chip with one wave each
-    hipLaunchKernelGGL((topk_rescore_wide_kernel<D, false>), dim3((unsigned)B), dim3(256), 0, st, f.Qn, Kn, f.count, f.cand, B,
-                       cap, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag,
+#ifdef RG_WIDE_TIMING
+    {
+      (void)hipDeviceSynchronize();
+      unsigned long long t[16];
+      (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_wide_t), sizeof(t));
+      fprintf(stderr, "[wide timing, block 0, 10 ns ticks]");
+      for (int i = 1; i < 10; ++i) fprintf(stderr, " %d:%lld", i, (long long)(t[i] - t[0]));
+      fprintf(stderr, "\n");
+    }
+#endif
+  } else if (B <= wide_coop_max_b)  // one workgroup per CU: its 70 KB of tiles cost no occupancy
+    hipLaunchKernelGGL((topk_rescore_wide_kernel<D, false, true>), dim3((unsigned)B), dim3(256), 0, st, f.Qn, Kn, f.count, f.cand,
+                       B, N, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag,
+                       (float*)nullptr, (int*)nullptr);
+  else if (B < wide_max_b)  // too few queries to fill the chip with one wave each
+    hipLaunchKernelGGL((topk_rescore_wide_kernel<D, false, false>), dim3((unsigned)B), dim3(256), 0, st, f.Qn, Kn, f.count, f.cand,
+                       B, N, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag,
                        (float*)nullptr, (int*)nullptr);
   else if (rescore_coop() && few)
     hipLaunchKernelGGL((topk_rescore_coop_kernel<D, 32, true>), dim3((unsigned)cdiv(B, 2)), dim3(128), 0, st, f.Qn, Kn, f.count,
@@ -1475,7 +1553,7 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
                         int64_t idx_base, float* out_scores, int64_t* out_idx, int* overflow, int64_t* overflow_idx,
                         void* ws, void* stream, int64_t plan_N, float* theta, ragraph_exchange_fn exchange, void* ctx) {
   hipStream_t st = as_stream(stream);
-  const int cap = ragraph_topk_cosine_filtered_cap(k);
+  const int cap = filter_cap(B, k);
   FilterSchedule sc = filter_schedule(B, plan_N, D, k);  // (sharded banks: the same schedule on every shard)
   sc.ends[sc.nlev - 1] = N;
   if (sc.bound_keys > N / 2) sc.bound_keys = 0, sc.n0 = sc.n0 < N ? sc.n0 : N;
@@ -1494,7 +1572,8 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
 
   // one launch: normalised queries, their bf16 rounding errors, empty lists, clear flags (+ group maxima at -inf)
   hipLaunchKernelGGL(filter_prep_kernel<D>, dim3((unsigned)cdiv(B <= 256 ? (B + 31) / 32 * 32 : B, 4)), dim3(256), 0, st, Q, B,
-                     f.Qn, f.eq, f.count, f.flag, overflow, bound ? f.gmax : nullptr, k, B <= 256 ? f.Qb : nullptr);
+                     f.Qn, f.eq, f.count, f.flag, overflow, bound ? f.gmax : nullptr, k, B <= 256 ? f.Qb : nullptr,
+                     filter_count_stride(B));
   RG_CHECK_LAUNCH("topk_cosine_filtered(prepare)");
 
   FilterThr thr{};

@@ -50,9 +50,9 @@ struct DirectParams {
   int64_t unit0, nunits;  // units [unit0, unit0 + nunits) of the bank copy
   int64_t key_end;        // keys >= key_end never pass (padding, or the next level's)
   FilterThr thr;
-  int* count;
+  int* count;             // [B][FILTER_COUNT_STRIDE]
   int* cand;
-  int cap;
+  int cap, nsub, subcap;  // nsub sub-lists of subcap = cap / nsub slots per query
   int* gmax;              // BOUND
   int ngroups;            // BOUND: parts of the range
   int qgroups;            // groups of 32 queries (1..8)
@@ -129,6 +129,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
   int wcnt = 0;  // wave-uniform
   const unsigned lane16 = (unsigned)lane * 16u;
 
+  const int sub = (int)(gw & (p.nsub - 1));  // this wave's sub-list of every query
   auto flush = [&]() {
     for (int i0 = 0; i0 < wcnt; i0 += 64) {
       const int i = i0 + lane;
@@ -136,14 +137,14 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
         const uint2 e = wbuf[i];
         const int64_t q = e.y >> 16;
         unsigned mk = e.y & 0xFFFFu;
-        int slot = atomicAdd(p.count + q, __popc(mk));
+        int slot = atomicAdd(p.count + q * FILTER_COUNT_STRIDE + sub, __popc(mk));
         // retired here on every path: a returning atomic hipcc still considers pending where the flush rejoins the
         // unit loop would put its vmcnt(0) -- which also drains the prefetched unit -- in front of every group pass
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(slot) : : "memory");
         while (mk) {
           const int r = __ffs(mk) - 1;
           mk &= mk - 1;
-          if (slot < p.cap) p.cand[q * p.cap + slot] = (int)e.x + (r & 3) + 8 * (r >> 2);
+          if (slot < p.subcap) p.cand[q * p.cap + sub * p.subcap + slot] = (int)e.x + (r & 3) + 8 * (r >> 2);
           ++slot;
         }
       }
@@ -187,6 +188,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
           for (int r = 0; r < 16; ++r) vm |= (key_base + (r & 3) + 8 * (r >> 2) < p.key_end) ? (1u << r) : 0u;
           mk &= vm;
         }
+        if (p.thr.ablate == 2) mk = 0;  // (timing only: masks computed, candidates dropped)
         const unsigned long long bal = __ballot(mk != 0);
         if (bal) {
           const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
@@ -358,6 +360,9 @@ int launch_filter_direct(const DirectArgs& a, hipStream_t st) {
   p.count = a.count;
   p.cand = a.cand;
   p.cap = a.cap;
+  p.nsub = a.nsub < 1 ? 1 : a.nsub;
+  RG_REQUIRE((p.nsub & (p.nsub - 1)) == 0 && p.nsub <= FILTER_COUNT_STRIDE, RAGRAPH_EINVAL, "filter(direct): nsub=%d", p.nsub);
+  p.subcap = a.cap / p.nsub;
   p.gmax = a.gmax_out;
   p.ngroups = a.bound_groups;
   p.qgroups = (int)cdiv(a.B, 32);
