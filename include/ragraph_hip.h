@@ -235,6 +235,18 @@ int ragraph_segment_softmax_ws_f32(const int64_t* rowptr, const float* x, int64_
  *     NOT contracted to an fma, matching the eager reference).  a,b,out [n] elementwise; in-place allowed. */
 int ragraph_axpby_f32(const float* a, float wa, const float* b, float wb, int64_t n, float* out, void* stream);
 
+/* a8  K5 + K6 of an inference forward in ONE launch  -- RAGraph_node/RAGraph.py:53-57 + ragraph_utils/TaskDecoder.py:14-17:
+ *       hidden = query * wq + rag * wr;  logits = fc2(LeakyReLU_slope(fc1(hidden)));
+ *       out = softmax(logits) * (1 - lambda) + rag_label * lambda        (rag_label NULL: plain softmax)
+ *     query, rag [n,D]; W1 [H,D], b1 [H] or NULL; W2 [C,H], b2 [C] or NULL; rag_label, out [n,C].  Same bits as
+ *     ragraph_axpby_f32 -> ragraph_linear_f32 (LEAKY) -> ragraph_linear_f32 -> ragraph_softmax_mix_f32 (same chains, same
+ *     order); meant for the launch-bound small forwards (Cora, PROTEINS batches) -- one workgroup per 4 rows, scalar
+ *     fp32 -- while large batches are faster through the separate entries (MFMA tile kernel for fc1).
+ *     4 (D + H + C) floats must fit 64 KB of LDS. */
+int ragraph_fuse_decode_f32(const float* query, const float* rag, int64_t n, int D, float wq, float wr, const float* W1,
+                            const float* b1, int H, float slope, const float* W2, const float* b2, int C,
+                            const float* rag_label, float lambda, float* out, void* stream);
+
 /* a8  torch.softmax(decode_label, dim=1) * (1-lambda) + rag_label * lambda  -- RAGraph_node/RAGraph.py:55-57.
  *     logits [B,C], rag_label [B,C] or NULL (then plain softmax; log_mode=1 gives log_softmax, downprompt.py:54).
  *     C <= 1024. */

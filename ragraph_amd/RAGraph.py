@@ -67,6 +67,19 @@ class RAGraph(nn.Module):
             return rag_label                                                                   # :60-63
         query_embeddings = self._pool(
             Propagation.aggregate_k_hop_features(g, pretrain_embedddings, self.query_graph_hop), g)  # :51
+        return self._fuse_decode(query_embeddings, rag_embedding, rag_label)                   # :53-57
+
+    def _fuse_decode(self, query_embeddings, rag_embedding, rag_label):
+        """RAGraph.py:53-57: prompt fusion -> task decoder -> label mix.  An inference forward of a small batch (Cora,
+        PROTEINS: launch-bound) takes the single fused launch; training and large batches the separate differentiable
+        entries (MFMA fc1).  Same bits either way."""
+        fc1, fc2 = self.decoder.layers()
+        trains = torch.is_grad_enabled() and (query_embeddings.requires_grad or rag_embedding.requires_grad or
+                                              any(p.requires_grad for p in self.decoder.parameters()))
+        if not trains and K.fuse_decode_fits(query_embeddings.shape[0], fc1.in_features, fc1.out_features, fc2.out_features):
+            return K.fuse_decode(query_embeddings, rag_embedding, 1 - self.retrieve_weight, self.retrieve_weight,
+                                 fc1.weight, fc1.bias, self.decoder.NEGATIVE_SLOPE, fc2.weight, fc2.bias, rag_label,
+                                 self.label_weight)
         hidden = A.axpby(query_embeddings, 1 - self.retrieve_weight, rag_embedding, self.retrieve_weight)  # :53
         decode_label = self.decoder(hidden)                                                    # :54
         return A.softmax_mix(decode_label, rag_label, self.label_weight)                       # :55-57
@@ -83,9 +96,7 @@ class RAGraph(nn.Module):
         if not self.finetune:
             return qs.gather_rows(rag_label, n)
         query_embeddings = Propagation.aggregate_k_hop_features(g, emb, self.query_graph_hop)[lo:hi].contiguous()
-        hidden = A.axpby(query_embeddings, 1 - self.retrieve_weight, rag_embedding, self.retrieve_weight)
-        out = A.softmax_mix(self.decoder(hidden), rag_label, self.label_weight)
-        return qs.gather_rows(out, n)
+        return qs.gather_rows(self._fuse_decode(query_embeddings, rag_embedding, rag_label), n)
 
 
 class RAGraphGraph(RAGraph):
@@ -121,5 +132,4 @@ class RAGraphGraph(RAGraph):
             return rag_label
         query = K.segment_reduce(Propagation.aggregate_k_hop_features(g, emb, self.query_graph_hop), seg,
                                  mean_mode=True)                                                 # :62-63
-        hidden = K.axpby(query, 1 - self.retrieve_weight, rag_embedding, self.retrieve_weight)   # :65
-        return K.softmax_mix(self.decoder(hidden), rag_label, self.label_weight)                 # :66-69
+        return self._fuse_decode(query, rag_embedding, rag_label)                                # :65-69

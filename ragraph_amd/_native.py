@@ -60,6 +60,8 @@ SIGNATURES = {
                                        _vp]),
     "ragraph_axpby_f32": (_i32, [_vp, _f32, _vp, _f32, _i64, _vp, _vp]),
     "ragraph_softmax_mix_f32": (_i32, [_vp, _vp, _i64, _i32, _f32, _i32, _vp, _vp]),
+    "ragraph_fuse_decode_f32": (_i32, [_vp, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _i32, _f32, _vp, _vp, _i32, _vp, _f32,
+                                       _vp, _vp]),
     "ragraph_segment_reduce_f32": (_i32, [_vp, _i32, _vp, _i64, _vp, _i32, _vp, _vp]),
     "ragraph_proto_cosine_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp]),
     "ragraph_sigmoid_gate_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),

@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256) spmm_csr_kernel(const int64_t* __restrict
                                                        const float* __restrict__ X, int D,
                                                        const float* __restrict__ bias, int act, float alpha, float beta,
                                                        const float* __restrict__ Yin, float* __restrict__ Y,
-                                                       int skip_long) {
+                                                       int skip_long, unsigned RUN) {
   constexpr int RPB = 256 / LPR;  // rows per block
   const int lr = threadIdx.x % LPR;
   const int gbase = (threadIdx.x & 63) - lr;  // first lane of this row's group inside the wave
@@ -94,7 +94,12 @@ __global__ void __launch_bounds__(256) spmm_csr_kernel(const int64_t* __restrict
   // a CONTIGUOUS run of 32 (128 rows at D = 256) instead of every eighth, so that rows which share neighbours (self
   // loops, ring / community structure, any locality in the node numbering) share an L2; the groups keep the XCDs'
   // loads interleaved (one contiguous eighth per XCD was 60 % slower on c5's bipartite graph: users and items differ).
-  constexpr unsigned RUN = 32;
+  // RUN = 32 by default (RAGRAPH_SPMM_XCD_RUN).  Measured on c2's shape (tools/spmm_locality.py, profiles/
+  // r2_spmm_locality.txt): the kernel moves nnz x 1 KiB = 1.1 GB of gathers through the L2s per hop whatever the node
+  // order, ~11 TB/s at 100 us -- with a community-ordered graph and RUN = 256 the L2 MISSES fall to 124 MB (ideal 111)
+  // and the hop still takes 100 us; on c2's Erdos-Renyi graph 440 MB miss and it takes 133 us.  Two restructurings that
+  // attack the per-row dependent chain instead (rows of a run as one edge stream; row pointers and edge pairs fetched
+  // one and two tiles ahead) were 10 - 50 % slower: latency is not what bounds it.
   const unsigned grp = blockIdx.x / (8 * RUN), in = blockIdx.x % (8 * RUN);
   const unsigned blk = (grp + 1) * (8 * RUN) <= gridDim.x ? grp * (8 * RUN) + (in % 8) * RUN + in / 8 : blockIdx.x;
   int64_t row = (int64_t)blk * RPB + threadIdx.x / LPR;
@@ -390,11 +395,16 @@ extern "C" int ragraph_spmm_csr_ws_f32(const int64_t* rowptr, const int32_t* col
   }
   const int skip = par ? 1 : 0;
   const int D4 = D >> 2;
+  static const unsigned xcd_run = [] {  // workgroups of one XCD's contiguous run (see spmm_csr_kernel)
+    const char* e = getenv("RAGRAPH_SPMM_XCD_RUN");
+    const int v = e ? atoi(e) : 32;
+    return (unsigned)(v < 1 ? 1 : v);
+  }();
 #define RG_SPMM(LPR_)                                                                                                  \
   do {                                                                                                                 \
     constexpr int RPB_ = 256 / (LPR_);                                                                                 \
     hipLaunchKernelGGL(spmm_csr_kernel<LPR_>, dim3((unsigned)cdiv(n, RPB_)), dim3(256), 0, st, rowptr, col, val, n, X, \
-                       D, bias, act, alpha, beta, Y_in, Y, skip);                                                      \
+                       D, bias, act, alpha, beta, Y_in, Y, skip, xcd_run);                                             \
     if (par) {                                                                                                         \
       hipLaunchKernelGGL(spmm_long_blocks_kernel<LPR_>, dim3((unsigned)cdiv(w.max_tasks, RPB_)), dim3(256), 0, st,     \
                          rowptr, col, val, X, D, w);                                                                   \

@@ -117,6 +117,31 @@ def synthetic_big_graph(n=100_000, mean_degree=10, seed=8, device="cuda"):
     return torch.stack([torch.cat([src, dst]), torch.cat([dst, src])]).to(device)
 
 
+def synthetic_community_graph(n=100_000, mean_degree=10, community=512, p_intra=0.9, seed=9, shuffle=True, device="cuda"):
+    """A graph WITH structure (the c2 graph above is Erdos-Renyi: nothing to reorder): communities of `community` nodes,
+    a fraction p_intra of every node's edges inside its community, node ids shuffled so that the given numbering hides
+    the communities (real datasets arrive like that).  Returns (edge_index [2,E] on `device`, membership [n] on the host:
+    the community of every node in the RETURNED numbering -- the oracle ordering a reordering is measured against)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    half = n * mean_degree // 2
+    src = torch.randint(0, n, (half,), generator=g)
+    intra = torch.rand(half, generator=g) < p_intra
+    base = src // community * community
+    size = torch.full_like(base, community).minimum(n - base)   # (the last community may be short)
+    dst_in = base + (torch.rand(half, generator=g) * size).long().minimum(size - 1)
+    dst = torch.where(intra, dst_in, torch.randint(0, n, (half,), generator=g))
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    member = torch.arange(n) // community
+    if shuffle:
+        perm = torch.randperm(n, generator=g)   # old id -> new id
+        src, dst = perm[src], perm[dst]
+        m2 = torch.empty_like(member)
+        m2[perm] = member
+        member = m2
+    return torch.stack([torch.cat([src, dst]), torch.cat([dst, src])]).to(device), member
+
+
 def synthetic_bank(N, D, C, device="cuda", seeds=(1234, 1235, 1236)):
     """K = normalize(randn), V = randn, L = one_hot(randint).  Generated on the device in slabs
     (a 1M x 256 fp32 host tensor would be a 1 GB PCIe copy)."""

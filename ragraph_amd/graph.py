@@ -67,6 +67,30 @@ class CSRGraph:
             self._transposed, _ = CSRGraph.from_coo(self.col.long(), rows, self.val, self.n, sort_cols=True)
         return self._transposed
 
+    # ---- locality ----------------------------------------------------------------------------------------------
+    def permuted(self, order: torch.Tensor) -> "CSRGraph":
+        """P A P^T: node order[i] of this graph becomes node i (rows AND columns), columns ascending within a row again.
+        The SpMM over it gathers rows of X[order] -- neighbours that are close in `order` are close in memory, so a
+        community-aware order (locality_order) turns Infinity-Cache gathers into L2 hits.  A row's terms are then summed
+        in the NEW column order: the result equals the unpermuted one up to fp32 summation order (not bit for bit),
+        which is why no forward applies this by itself -- the caller opts in, permutes X once and inverts at the end."""
+        order = order.to(self.device, torch.int64)
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(self.n, device=self.device)
+        rows = torch.repeat_interleave(torch.arange(self.n, device=self.device), self.rowptr[1:] - self.rowptr[:-1])
+        g, _ = CSRGraph.from_coo(inv[rows], inv[self.col.long()], self.val, self.n, sort_cols=True)
+        return g
+
+    def locality_order(self) -> torch.Tensor:
+        """Reverse Cuthill-McKee order of the (symmetrised) pattern -- structure-only bookkeeping, once per graph, on the
+        host (scipy.sparse.csgraph): order[i] = the node that should be stored i-th."""
+        import numpy as np
+        import scipy.sparse as sp
+        from scipy.sparse.csgraph import reverse_cuthill_mckee
+        rp = self.rowptr.cpu().numpy()
+        a = sp.csr_matrix((np.ones(self.nnz, dtype=np.int8), self.col.cpu().numpy(), rp), shape=(self.n, self.n))
+        return torch.from_numpy(np.ascontiguousarray(reverse_cuthill_mckee(a, symmetric_mode=False)).astype(np.int64)).to(self.device)
+
     # ---- constructors ------------------------------------------------------------------------------------------
     @staticmethod
     def from_dense(adj: torch.Tensor) -> "CSRGraph":

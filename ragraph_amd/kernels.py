@@ -377,6 +377,39 @@ def softmax_mix(logits: torch.Tensor, rag_label: torch.Tensor | None, lam: float
     return out.reshape(logits.shape)
 
 
+FUSE_DECODE_MAX_ROWS = 8192   # beyond: fc1 is faster on the MFMA tile kernel than in the fused launch's scalar chains
+FUSE_DECODE_LDS = 64 * 1024
+
+
+def fuse_decode_fits(n: int, D: int, H: int, C: int) -> bool:
+    """Does ragraph_fuse_decode_f32 take this shape (and is it the faster form)?"""
+    return 0 < n <= FUSE_DECODE_MAX_ROWS and 4 * 4 * ((D + 3) // 4 * 4 + (H + 3) // 4 * 4 + C) <= FUSE_DECODE_LDS
+
+
+def fuse_decode(query: torch.Tensor, rag: torch.Tensor, wq: float, wr: float, W1: torch.Tensor, b1: torch.Tensor | None,
+                slope: float, W2: torch.Tensor, b2: torch.Tensor | None, rag_label: torch.Tensor | None,
+                lam: float) -> torch.Tensor:
+    """K5 + K6 in one launch -- RAGraph_node/RAGraph.py:53-57 + TaskDecoder.py:14-17:
+    softmax(fc2(LeakyReLU(fc1(query*wq + rag*wr)))) * (1-lam) + rag_label*lam.  Same bits as axpby -> linear(LEAKY) ->
+    linear -> softmax_mix."""
+    L = _ready()
+    query, rag = _f32c(query, "fuse_decode.query"), _f32c(rag, "fuse_decode.rag")
+    W1, W2 = _f32c(W1, "fuse_decode.W1"), _f32c(W2, "fuse_decode.W2")
+    b1 = None if b1 is None else _f32c(b1, "fuse_decode.b1")
+    b2 = None if b2 is None else _f32c(b2, "fuse_decode.b2")
+    n, D = query.shape
+    H, C = W1.shape[0], W2.shape[0]
+    if rag.shape != query.shape or W1.shape[1] != D or W2.shape[1] != H:
+        raise ValueError(f"fuse_decode: shapes query {tuple(query.shape)} rag {tuple(rag.shape)} W1 {tuple(W1.shape)} "
+                         f"W2 {tuple(W2.shape)}")
+    rl = None if rag_label is None else _f32c(rag_label, "fuse_decode.rag_label").reshape(n, C)
+    out = torch.empty((n, C), dtype=torch.float32, device=query.device)
+    N.check(L.ragraph_fuse_decode_f32(query.data_ptr(), rag.data_ptr(), n, D, float(wq), float(wr), W1.data_ptr(),
+                                      _ptr(b1), H, float(slope), W2.data_ptr(), _ptr(b2), C, _ptr(rl), float(lam),
+                                      out.data_ptr(), _stream()), "fuse_decode")
+    return out
+
+
 def segment_reduce(x: torch.Tensor, seg_ptr: torch.Tensor, w: torch.Tensor | None = None,
                    mean_mode: bool = False) -> torch.Tensor:
     """Per-segment sum (or mean) of rows, optionally of w*x -- RAGraph_graph/RAGraph.py:50,63; downprompt.py:98-112."""

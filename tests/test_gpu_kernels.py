@@ -289,6 +289,35 @@ def test_segment_reduce_axpby_softmax_proto(dev):
             assert np.allclose(got, cref.proto_cosine(emb, proto, mode), atol=1e-5)
 
 
+@pytest.mark.parametrize("n,D,H,C", [(1, 128, 128, 7), (16, 256, 256, 2), (2708, 128, 128, 7), (333, 96, 50, 3),
+                                      (1000, 130, 67, 5)])
+def test_fuse_decode_same_bits_as_separate_entries(dev, n, D, H, C):
+    """K5 + K6 in one launch (RAGraph.py:53-57 + TaskDecoder.py:14-17): same bits as axpby -> linear(LeakyReLU) -> linear
+    -> softmax_mix on the HIP path, logits chain bit-identical to the oracle's (softmax within 1e-6: expf)."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(n + D + H + C)
+    q = rng.standard_normal((n, D), dtype=np.float32)
+    r = rng.standard_normal((n, D), dtype=np.float32)
+    W1 = (rng.standard_normal((H, D), dtype=np.float32) / np.sqrt(D)).astype(np.float32)
+    b1 = rng.standard_normal(H, dtype=np.float32)
+    W2 = (rng.standard_normal((C, H), dtype=np.float32) / np.sqrt(H)).astype(np.float32)
+    b2 = rng.standard_normal(C, dtype=np.float32)
+    rl = np.eye(C, dtype=np.float32)[rng.integers(0, C, n)]
+    d = lambda a: _t(a, dev)
+    got = K.fuse_decode(d(q), d(r), 0.7, 0.3, d(W1), d(b1), 0.01, d(W2), d(b2), d(rl), 0.4)
+    hid = K.axpby(d(q), 0.7, d(r), 0.3)
+    sep = K.softmax_mix(K.linear(K.linear(hid, d(W1), d(b1), act=K.ACT_LEAKY, alpha=0.01), d(W2), d(b2)), d(rl), 0.4)
+    assert torch.equal(got, sep)
+    ref = cref.softmax_mix(cref.linear(cref.linear(cref.axpby(q, 0.7, r, 0.3), W1, b1, act=cref.ACT_LEAKY, alpha=0.01),
+                                       W2, b2), rl, 0.4)
+    assert np.allclose(got.cpu().numpy(), ref, atol=1e-6)
+    # no biases, no label term
+    got = K.fuse_decode(d(q), d(r), 0.5, 0.5, d(W1), None, 0.01, d(W2), None, None, 0.0)
+    sep = K.softmax_mix(K.linear(K.linear(K.axpby(d(q), 0.5, d(r), 0.5), d(W1), act=K.ACT_LEAKY, alpha=0.01), d(W2)), None, 0.0)
+    assert torch.equal(got, sep)
+
+
 def test_errors_are_loud(dev):
     from ragraph_amd import kernels as K
 
