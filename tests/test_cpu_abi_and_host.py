@@ -145,6 +145,38 @@ def test_data_standins_and_csr_normalisation_match_scipy():
     assert torch.equal(g2.rowptr, g.rowptr) and torch.equal(g2.col, g.col) and torch.equal(g2.val, g.val)
 
 
+def test_csr_permuted_and_locality_order_host_logic():
+    """CSRGraph.permuted(order) is P A P^T with ascending columns, and locality_order() is a permutation that shrinks the
+    mean |row - col| of a shuffled community graph (the structure-only bookkeeping behind tools/spmm_locality.py)."""
+    import torch
+
+    from ragraph_amd.data import synthetic_community_graph
+    from ragraph_amd.graph import CSRGraph
+
+    n = 600
+    ei, member = synthetic_community_graph(n, 8, 50, 0.9, seed=3, device="cpu")
+    g = CSRGraph.from_edge_index_sym_normalized(ei, n)
+    dense = torch.zeros(n, n)
+    rows = torch.repeat_interleave(torch.arange(n), g.rowptr[1:] - g.rowptr[:-1])
+    dense[rows, g.col.long()] = g.val
+    order = g.locality_order()
+    assert sorted(order.tolist()) == list(range(n))
+    gp = g.permuted(order)
+    dp = torch.zeros(n, n)
+    prow = torch.repeat_interleave(torch.arange(n), gp.rowptr[1:] - gp.rowptr[:-1])
+    dp[prow, gp.col.long()] = gp.val
+    assert torch.equal(dp, dense[order][:, order])
+    for r in range(n):  # columns ascending inside every row
+        c = gp.col[gp.rowptr[r]:gp.rowptr[r + 1]]
+        assert torch.all(c[1:] > c[:-1])
+    span = lambda gg, rr: (rr - gg.col.long()).abs().float().mean().item()
+    assert span(gp, prow) < 0.6 * span(g, rows)
+    truth = torch.sort(member, stable=True).indices
+    gt = g.permuted(truth)
+    trow = torch.repeat_interleave(torch.arange(n), gt.rowptr[1:] - gt.rowptr[:-1])
+    assert span(gt, trow) < 0.3 * span(g, rows)
+
+
 def test_edge_list_ingestion_matches_reference_recipe(tmp_path):
     """ragraph_amd.edge_data vs a literal restatement of the reference's loader (dict-of-dicts edge times,
     dataloader.py:47-113; scipy bi-normalised adjacency, base_model.py:34-52) on a small TSV in the reference's format."""

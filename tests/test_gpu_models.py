@@ -368,6 +368,37 @@ def test_forward_is_hip_graph_capturable(dev):
     assert torch.equal(captured, eager)
 
 
+def test_captured_forward_helper_replays_new_inputs(dev):
+    """ragraph_amd.capture.CapturedForward: capture a batched graph-classification forward once, replay it on OTHER
+    features of the same shape -- the replayed output equals the eager forward on those features, bit for bit."""
+    from ragraph_amd.capture import CapturedForward
+    from ragraph_amd.data import DataLoader, synthetic_tu_dataset
+    from ragraph_amd.preprompt import PrePrompt
+    from ragraph_amd.RAGraph import RAGraphGraph
+    from ragraph_amd.ragraph_utils import process_tu_dataset
+
+    torch.manual_seed(1)
+    ds = synthetic_tu_dataset(num_graphs=16, num_node_attributes=18, num_node_labels=3, seed=4)
+    model = RAGraphGraph(PrePrompt(18, 128, "prelu", 1, 0.3).to(dev), None, 18, 2, 128, device=dev).eval()
+    model.toy_graph_base.add_resources(torch.nn.functional.normalize(torch.randn(1113, 128, device=dev), dim=-1),
+                                       torch.randn(1113, 128, device=dev),
+                                       torch.nn.functional.one_hot(torch.randint(0, 2, (1113,), device=dev), 2).float())
+    data = next(iter(DataLoader(ds, batch_size=16)))
+    feats, adj, _ = process_tu_dataset(data, 18, device=dev)
+    ptr = data.ptr.to(dev)
+    _ = adj.row_normalized_values()
+    fwd = CapturedForward(lambda x: model.forward_batch(x, adj, ptr), feats)
+    other = torch.rand_like(feats)
+    with torch.no_grad():
+        want = model.forward_batch(other, adj, ptr)
+        want0 = model.forward_batch(feats, adj, ptr)
+    got = fwd(other).clone()
+    assert torch.equal(got, want)
+    assert torch.equal(fwd(feats), want0)
+    with pytest.raises(ValueError):
+        fwd(other[:-1])
+
+
 def test_bank_save_load_roundtrip(dev, tmp_path):
     from ragraph_amd.ragraph_utils import ToyGraphBase
 
