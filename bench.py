@@ -373,7 +373,7 @@ def main():
         call_ms = filt_timer.mean_ms()
         achieved = flops / (kernel_ms * 1e-3) / 1e12
         roofline = {
-            "kernel": "ragraph::topk_filter_kernel (bf16 MFMA filter of the exact top-k, v_mfma_f32_32x32x16_bf16)",
+            "kernel": "ragraph::topk_filter_kernel (bf16 MFMA filter of the exact top-k, v_mfma_f32_16x16x32_bf16)",
             "bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": traffic_unit,
             "launch_ms": round(kernel_ms, 3),

@@ -21,14 +21,20 @@ constexpr float FILTER_EPS_SLACK = 0.000244140625f;  // 2^-12
 constexpr int FILTER_STAGE_BYTES = 32 * 1024;  // one ring slot of the ring kernel
 constexpr int FILTER_PAD_KEYS = 256;           // bank rows are padded to whole stages of any D (256 keys at D = 64)
 
-// Layout of the bf16 bank copy (ragraph_keys_to_bf16): MFMA FRAGMENT ORDER.  Keys are taken in sub-tiles of 32; a
-// sub-tile is D/16 k-steps; k-step t of sub-tile u is one 1-KiB block at byte ((u * D/16) + t) * 1024, and inside it
-// lane l = j + 32 g of a wave owns 16 bytes at 16 l: elements 16 t + 8 g .. + 7 of key 32 u + j -- exactly the A operand
-// of v_mfma_f32_32x32x16_bf16 for that step.  A wave therefore fetches an operand with ONE fully coalesced 1-KiB load
+// Layout of the bf16 bank copy (ragraph_keys_to_bf16): MFMA FRAGMENT ORDER of v_mfma_f32_16x16x32_bf16 (keys = the A
+// operand's 16 rows, 32 elements per k-step).  Keys are taken in sub-tiles of 32 = two halves of 16; a sub-tile is
+// D/32 k-steps x 2 halves = D/16 blocks of 1 KiB; block 2 t + h of sub-tile u (byte ((u * D/16) + 2 t + h) * 1024) is the
+// A operand of k-step t for half h: lane l = j + 16 g (j < 16, g < 4) owns 16 bytes at 16 l -- elements 32 t + 8 g .. + 7
+// of key 32 u + 16 h + j.  A wave therefore fetches an operand with ONE fully coalesced 1-KiB load
 // (global_load_dwordx4, or global_load_lds_dwordx4 into a ring slot whose image needs no swizzle: consecutive lanes read
-// consecutive 16-B pieces), and no kernel transposes anything.  2 D bytes per key, as the row-major copy had.
-__host__ __device__ constexpr int64_t filter_block_offset(int64_t subtile, int ksteps, int t) {
-  return (subtile * ksteps + t) * 1024;
+// consecutive 16-B pieces), and no kernel transposes anything.  2 D bytes per key, as a row-major copy has.  The blocks
+// of a sub-tile are k-step major (both halves of step 0, then of step 1, ...): the order the kernels consume them in.
+// Why this shape and not 32x32x16 (round 1): on random operands the chip holds a higher clock under it -- 1.71 vs 1.61
+// PFLOP/s sustained in the filter's own inner loop (tools/microbench/mfma_bf16_shape_bench.hip) -- at the same LDS
+// traffic per flop (one 1-KiB fragment read feeds 64 MFMA cycles either way).
+// The result of one MFMA: lane j + 16 g holds scores of query column j against keys 4 g + r (r < 4) of the half.
+__host__ __device__ constexpr int64_t filter_block_offset(int64_t subtile, int D, int t, int h) {
+  return (subtile * (D / 16) + 2 * t + h) * 1024;
 }
 
 // float <-> int with the same order (for atomicMax on scores of either sign)
@@ -88,8 +94,8 @@ __host__ __device__ constexpr int filter_count_stride(int64_t B) { return B <= 2
 // records per query the best approximate score of each of bound_groups consecutive parts of the range into gmax_out.
 struct DirectArgs {
   const uint16_t* Qb;     // the normalised queries as bf16 B operands in fragment order (filter_prep_kernel):
-                          // block (gq * D/16 + t) = k-step t of queries 32 gq .. 32 gq + 31, lane j + 32 g of it
-                          // = elements 16 t + 8 g .. + 7 of query 32 gq + j; queries >= B zero
+                          // block (qg * D/32 + t) = k-step t of queries 16 qg .. 16 qg + 15, lane j + 16 g of it
+                          // = elements 32 t + 8 g .. + 7 of query 16 qg + j; padded to whole groups of 32 queries, zeros
   const uint16_t* Kb;     // fragment-order bf16 keys
   int64_t B, key0, key1;
   FilterThr thr;          // (filter launches)

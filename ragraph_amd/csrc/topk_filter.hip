@@ -45,11 +45,12 @@ struct FilterCfg {
   static constexpr int WAVES = 8, THREADS = 512;
   static constexpr int ROW_BYTES = D * 2;                 // one bf16 key
   static constexpr int CR = D / 8;                        // 16-B chunks per row
-  static constexpr int KSTEPS = D / 16;                   // MFMA k-steps per 32-key sub-tile
+  static constexpr int KSTEPS = D / 16;                   // 1-KiB blocks (A fragments) per 32-key sub-tile: 2 halves x KS32
+  static constexpr int KS32 = D / 32;                     // MFMA k-steps (32 elements) per sub-tile: 8 / 4 / 2
   static constexpr int STAGE_BYTES = FILTER_STAGE_BYTES;
   static constexpr int STAGE_KEYS = STAGE_BYTES / ROW_BYTES;  // 64 / 128 / 256
   static constexpr int SUBS = STAGE_KEYS / 32;            // 32-key MFMA sub-tiles per stage: 2 / 4 / 8
-  static constexpr int NSTEP = SUBS * KSTEPS;             // = 32 MFMA steps (x 2 query groups) per stage for every D
+  static constexpr int NSTEP = SUBS * KSTEPS;             // = 32 fragment steps (x QW/16 query groups) per stage for every D
   static constexpr int SLOTS = 4;                         // 128 KiB of ring; the hand-over protocol needs >= 3 slots
   static constexpr int DMAS = STAGE_BYTES / 1024 / WAVES; // 1 KiB DMA instructions per wave and stage = 4
   static constexpr int RPI = 1024 / ROW_BYTES;            // key rows per DMA instruction: 2 / 4 / 8
@@ -106,9 +107,10 @@ __global__ void __launch_bounds__(256) keys_to_bf16_kernel(const float* __restri
     for (int e = 0; e < 8; ++e) o[e] = (__bf16)0.f;
   }
   if (i < Npad * TPR) {
-    // fragment order (filter_common.h): 16-B piece c = 2 t + g of key row 32 u + j goes to block (u * D/16 + t), lane j + 32 g
+    // fragment order (filter_common.h): 16-B piece c = 4 t + g of key row 32 u + 16 h + j goes to block 2 t + h of
+    // sub-tile u, lane j + 16 g
     const int c = (int)(i % TPR);
-    const int64_t dst = filter_block_offset(row >> 5, D / 16, c >> 1) + (((c & 1) * 32 + (int)(row & 31)) << 4);
+    const int64_t dst = filter_block_offset(row >> 5, D, c >> 2, (int)(row >> 4) & 1) + (((c & 3) * 16 + (int)(row & 15)) << 4);
     *reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(Kb) + dst) = o;
   }
 #pragma unroll
@@ -150,11 +152,11 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
     // the direct kernel's B operands (<= 256 queries): bf16 in fragment order (filter_common.h, DirectArgs::Qb); this
     // lane's elements 4 l .. 4 l + 3 are half of one 16-byte piece.  (The launch covers the padding queries of the last
     // group of 32 too: they get zero rows.)
-    const int e0 = 4 * lane, t = e0 >> 4, gg = (e0 >> 3) & 1;
+    const int e0 = 4 * lane, t = e0 >> 5, gg = (e0 >> 3) & 3;
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
     bf16x4 o;
     o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
-    char* base = reinterpret_cast<char*>(Qb) + ((q >> 5) * (D / 16) + t) * 1024 + (gg * 32 + (int)(q & 31)) * 16 + (e0 & 7) * 2;
+    char* base = reinterpret_cast<char*>(Qb) + ((q >> 4) * (D / 32) + t) * 1024 + (gg * 16 + (int)(q & 15)) * 16 + (e0 & 7) * 2;
     *reinterpret_cast<bf16x4*>(base) = o;
   }
   float e2 = 0.f;
@@ -222,16 +224,16 @@ __device__ unsigned long long g_filter_timing[8];
 #define RG_FT(var_)
 #endif
 
-// QW = queries per wave: 64 (two groups of 32 sharing every A fragment; query tile = 512) or 32 (one group, tile = 256:
-// batches of <= 256 queries, which would otherwise spend half their matrix work on padding).
+// QW = queries per wave: 64 (four groups of 16 sharing every A fragment; query tile = 512), 32 (tile = 256) or 128
+// (D = 64, long streams: tile = 1024).
 // BOUND: no thresholds, no candidates -- the launch only records, per query, the best approximate score of each of
 // p.ngroups consecutive parts of its key range (filter_prepare_kernel turns them into the first lower bound).
 template <int D, int QW, bool BOUND = false>
 __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
   using C = FilterCfg<D>;
-  static_assert(QW == 32 || QW == 64 || QW == 128, "one, two or four query groups of 32 per wave");
+  static_assert(QW == 32 || QW == 64 || QW == 128, "two, four or eight query groups of 16 per wave");
   constexpr int QT = C::WAVES * QW;
-  constexpr int NG = QW / 32;  // query groups per wave: each A fragment feeds NG MFMAs
+  constexpr int NG = QW / 16;  // query groups per wave: each A fragment (16 keys x 32 elements) feeds NG MFMAs
   extern __shared__ float4 fsmem4[];
   char* smem = reinterpret_cast<char*>(fsmem4);
   unsigned* full = reinterpret_cast<unsigned*>(smem + C::SLOTS * C::STAGE_BYTES);  // [SLOTS] then freec [SLOTS]
@@ -241,9 +243,9 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31, g = lane >> 5;
+  const int j = lane & 15, g = lane >> 4;
 
-  // DMA: instruction i of wave w copies the stage's (DMAS w + i)-th 1-KiB block -- one k-step of one 32-key sub-tile in
+  // DMA: instruction i of wave w copies the stage's (DMAS w + i)-th 1-KiB block -- one k-step of half a 32-key sub-tile in
   // fragment order -- to the same offset of the ring slot; lane l moves bytes [16 l, 16 l + 16) of it.  The LDS image IS
   // the HBM image, and a k-step's A operand is one ds_read_b128 at 16 l: consecutive lanes, consecutive pieces, no
   // bank conflicts and no swizzle.
@@ -279,26 +281,27 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
   Segment seg;
   while (walker.next(seg)) {
     const int64_t qtile = p.xcd_map ? x + 8 * seg.tile : seg.tile;
-    const int64_t q_lo = qtile * QT + wave * QW + j;  // group gq's query: q_lo + 32 gq
+    const int64_t q_lo = qtile * QT + wave * QW + j;  // group gq's query: q_lo + 16 gq
     const int64_t st0 = seg.st0;
     const int nstages = (int)(seg.st1 - seg.st0);
 
-    // ---- B operands: group gq's query q_lo + 32 gq, k-step t = elements 16 t + 8 g .. + 7, converted to bf16 (RNE) ----
-    bf16x8 bq[NG][C::KSTEPS];
+    // ---- B operands: group gq's query q_lo + 16 gq, k-step t = elements 32 t + 8 g .. + 7, converted to bf16 (RNE) ----
+    bf16x8 bq[NG][C::KS32];
+    constexpr int TB = C::KS32 < 4 ? C::KS32 : 4;
 #pragma unroll
     for (int gq = 0; gq < NG; ++gq) {
-      const int64_t qq = q_lo + 32 * gq;
+      const int64_t qq = q_lo + 16 * gq;
       const float* r0 = p.Qn + (qq < p.B ? qq : p.B - 1) * D + 8 * g;
 #pragma unroll
-      for (int t0 = 0; t0 < C::KSTEPS; t0 += 4) {  // batches of 4 steps = 8 float4 in flight
+      for (int t0 = 0; t0 < C::KS32; t0 += TB) {  // batches of (up to) 4 steps = 8 float4 in flight
 #pragma unroll
-        for (int t = t0; t < t0 + 4; ++t) {
-          const float4 u0 = *reinterpret_cast<const float4*>(r0 + 16 * t), u1 = *reinterpret_cast<const float4*>(r0 + 16 * t + 4);
+        for (int t = t0; t < t0 + TB; ++t) {
+          const float4 u0 = *reinterpret_cast<const float4*>(r0 + 32 * t), u1 = *reinterpret_cast<const float4*>(r0 + 32 * t + 4);
           bq[gq][t][0] = (__bf16)u0.x; bq[gq][t][1] = (__bf16)u0.y; bq[gq][t][2] = (__bf16)u0.z; bq[gq][t][3] = (__bf16)u0.w;
           bq[gq][t][4] = (__bf16)u1.x; bq[gq][t][5] = (__bf16)u1.y; bq[gq][t][6] = (__bf16)u1.z; bq[gq][t][7] = (__bf16)u1.w;
         }
 #pragma unroll
-        for (int t = t0; t < t0 + 4; ++t) asm volatile("" : "+v"(bq[gq][t]));
+        for (int t = t0; t < t0 + TB; ++t) asm volatile("" : "+v"(bq[gq][t]));
         asm volatile("" ::: "memory");
       }
     }
@@ -306,7 +309,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     float thr[NG];
 #pragma unroll
     for (int gq = 0; gq < NG; ++gq)
-      thr[gq] = (!BOUND && q_lo + 32 * gq < p.B) ? filter_threshold(p.thr, q_lo + 32 * gq) : __builtin_huge_valf();
+      thr[gq] = (!BOUND && q_lo + 16 * gq < p.B) ? filter_threshold(p.thr, q_lo + 16 * gq) : __builtin_huge_valf();
     // bound pass: running maxima of the current group (group g = stages [ceil(g n / G), ceil((g+1) n / G)) of the range)
     float gm[NG];
 #pragma unroll
@@ -317,7 +320,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     auto flush_max = [&]() {
 #pragma unroll
       for (int gq = 0; gq < NG; ++gq) {
-        if (q_lo + 32 * gq < p.B) atomicMax(p.gmax + (q_lo + 32 * gq) * p.ngroups + grp, f2ord(gm[gq]));
+        if (q_lo + 16 * gq < p.B) atomicMax(p.gmax + (q_lo + 16 * gq) * p.ngroups + grp, f2ord(gm[gq]));
         gm[gq] = RG_NEG_INF;
       }
     };
@@ -325,8 +328,8 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
       grp = group_of(st0);
       grp_end = ((int64_t)(grp + 1) * p.nstages_total + p.ngroups - 1) / p.ngroups;
     }
-    // Candidates: a sub-tile that holds any (one wave-uniform test of the accumulators' maxima) turns each lane's 16 scores
-    // per query group into a pass MASK without a branch, and the lanes with a non-zero mask push one 8-byte entry
+    // Candidates: a sub-tile that holds any (one wave-uniform test of the accumulators' maxima) turns each lane's 8 scores
+    // per query group (keys 4 g + r of both halves against query j of the group) into a pass MASK without a branch, and the lanes with a non-zero mask push one 8-byte entry
     // {(query within the wave) << 26 | offset of the lane's key group from key_org, mask} into a wave-private LDS buffer
     // (position by ballot + mbcnt).  No atomics and no memory wait inside the MFMA stream, ~100 VALU instructions that
     // fit under the other wave's MFMAs.  A full buffer, and the end of the segment, flush the entries to the queries'
@@ -351,7 +354,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
           while (mk) {
             const int r = __ffs(mk) - 1;
             mk &= mk - 1;
-            if (slot < p.cap) p.cand[q * p.cap + slot] = key0 + (r & 3) + 8 * (r >> 2);
+            if (slot < p.cap) p.cand[q * p.cap + slot] = key0 + (r & 3) + 16 * (r >> 2);
             ++slot;
           }
         }
@@ -394,29 +397,30 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
       RG_FT(t0);
       fring_wait(full + slot, (unsigned)(C::WAVES * (gen + 1)));
       RG_FT(t1);
-      // epilogue of sub-tile u: acc[r] = approximate score of key row (r&3) + 8 (r>>2) + 4 g of the sub-tile
-      auto pass_mask = [&](const f32x16& a, float thr) {
+      // epilogue of sub-tile u: a[h][gq][r] = approximate score of key 16 h + 4 g + r of the sub-tile for query j of group gq
+      auto pass_mask = [&](const f32x4 (&a)[2][NG], int gq, float thr) {
         unsigned mk = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mk |= (a[r] >= thr) ? (1u << r) : 0u;
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mk |= (a[h][gq][r] >= thr) ? (1u << (4 * h + r)) : 0u;
         return mk;
       };
       auto push = [&](unsigned mk, unsigned word0) {
         const unsigned long long m = __ballot(mk != 0);
         if (m) {
+          if (wcnt > C::CAND_BUF - 64) flush();  // (a push adds at most 64 entries)
           const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
           if (mk) wbuf[pos] = make_uint2(word0, mk);
           wcnt += __popcll(m);
         }
       };
-      auto epilogue = [&](int u, const f32x16 (&a)[NG]) {
+      auto epilogue = [&](int u, const f32x4 (&a)[2][NG]) {
         float m[NG];
 #pragma unroll
-        for (int gq = 0; gq < NG; ++gq) {
-          m[gq] = a[gq][0];
-#pragma unroll
-          for (int r = 1; r < 16; ++r) m[gq] = fmaxf(m[gq], a[gq][r]);
-        }
+        for (int gq = 0; gq < NG; ++gq)
+          m[gq] = fmaxf(fmaxf(fmaxf(a[0][gq][0], a[0][gq][1]), fmaxf(a[0][gq][2], a[0][gq][3])),
+                        fmaxf(fmaxf(a[1][gq][0], a[1][gq][1]), fmaxf(a[1][gq][2], a[1][gq][3])));
         bool hit = false;
 #pragma unroll
         for (int gq = 0; gq < NG; ++gq) hit = hit || (m[gq] >= thr[gq]);
@@ -425,35 +429,35 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
           for (int gq = 0; gq < NG; ++gq) gm[gq] = fmaxf(gm[gq], m[gq]);
         } else if (__any(hit)) {
           const int stage_key0 = (int)((p.stage_base + st0 + s) * C::STAGE_KEYS);
-          const int key_base = stage_key0 + 32 * u + 4 * g;  // the lane's keys: key_base + (r & 3) + 8 (r >> 2)
-          // (a group without a passing lane skips its sixteen compares: at the later levels a sub-tile that has a
-          // candidate at all usually has it in one group only)
+          const int key_base = stage_key0 + 32 * u + 4 * g;  // the lane's keys: key_base + r + 16 h  (mask bit 4 h + r)
+          // (a group without a passing lane skips its compares: at the later levels a sub-tile that has a candidate at
+          // all usually has it in one group only)
           unsigned km[NG];
 #pragma unroll
           for (int gq = 0; gq < NG; ++gq) {
             km[gq] = 0;
-            if (__any(m[gq] >= thr[gq])) km[gq] = pass_mask(a[gq], thr[gq]);
+            if (__any(m[gq] >= thr[gq])) km[gq] = pass_mask(a, gq, thr[gq]);
           }
           if (stage_key0 + C::STAGE_KEYS > (int)p.N) {  // the range's last stage: keys >= N (padding, or the next level's)
             unsigned vm = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) vm |= (key_base + (r & 3) + 8 * (r >> 2) < (int)p.N) ? (1u << r) : 0u;
+            for (int r = 0; r < 8; ++r) vm |= (key_base + (r & 3) + 16 * (r >> 2) < (int)p.N) ? (1u << r) : 0u;
 #pragma unroll
             for (int gq = 0; gq < NG; ++gq) km[gq] &= vm;
           }
-          if (wcnt > C::CAND_BUF - 64 * NG) flush();  // a sub-tile pushes at most NG x 64 entries
           const unsigned off = (unsigned)(key_base - key_org);
 #pragma unroll
-          for (int gq = 0; gq < NG; ++gq) push(km[gq], ((unsigned)(j + 32 * gq) << 25) | off);
+          for (int gq = 0; gq < NG; ++gq) push(km[gq], ((unsigned)(j + 16 * gq) << 25) | off);
         }
       };
-      // ---- SUBS sub-tiles of 32 keys x 64 queries, KSTEPS k-steps each; one A fragment per step feeds both query groups.
+      // ---- SUBS sub-tiles of 32 keys x QW queries, KSTEPS fragments each (k-step major: both 16-key halves of a step);
+      // one A fragment feeds all NG query groups.
       // A step is only 64 cycles of MFMA, less than an LDS round trip, so the fragment reads run FOUR steps ahead of
       // their MFMAs (hipcc's own schedule keeps one ahead and the matrix pipe idles half the time).  They are asm
       // loads, invisible to hipcc's waitcnt bookkeeping: RG_FWAIT counts them (LDS returns in order; anything else
       // outstanding only makes the wait stricter) and names the fragment so its MFMAs stay behind the wait.
       const unsigned addr = apos + (unsigned)(slot * C::STAGE_BYTES);
-      f32x16 acc[NG];
+      f32x4 acc[2][NG];
       f32x4 fr[4];
 #define RG_FREAD(n_)                                                                                       \
   asm volatile("ds_read_b128 %0, %1 offset:%2"                                                             \
@@ -463,8 +467,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
 #define RG_FSTEP(n_)                                                                                       \
   {                                                                                                        \
     if constexpr ((n_) % C::KSTEPS == 0) {                                                                 \
-      _Pragma("unroll") for (int gq = 0; gq < NG; ++gq)                                                     \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[gq][r] = 0.f;                                    \
+      _Pragma("unroll") for (int gq = 0; gq < NG; ++gq) acc[0][gq] = acc[1][gq] = f32x4{0.f, 0.f, 0.f, 0.f}; \
     }                                                                                                      \
     if constexpr ((n_) + 3 < C::NSTEP) RG_FWAIT(3, n_);                                                     \
     else if constexpr ((n_) + 2 < C::NSTEP) RG_FWAIT(2, n_);                                                \
@@ -473,7 +476,8 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     {                                                                                                      \
       const bf16x8 a_ = __builtin_bit_cast(bf16x8, fr[(n_)&3]);                                             \
       _Pragma("unroll") for (int gq = 0; gq < NG; ++gq)                                                     \
-        acc[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, bq[gq][(n_) % C::KSTEPS], acc[gq], 0, 0, 0);  \
+        acc[(n_) & 1][gq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, bq[gq][((n_) >> 1) % C::KS32],      \
+                                                                    acc[(n_) & 1][gq], 0, 0, 0);          \
     }                                                                                                      \
     if constexpr ((n_) + 4 < C::NSTEP) RG_FREAD((n_) + 4);                                                  \
     if constexpr ((n_) % C::KSTEPS == C::KSTEPS - 1) epilogue((n_) / C::KSTEPS, acc);                       \

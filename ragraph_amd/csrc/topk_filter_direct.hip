@@ -4,24 +4,27 @@
 // With so few queries the score matrix is cheap (2 * 256 * N * D flops = 52 us of bf16 MFMA at N = 1M, D = 256) and the call
 // is bound by ONE pass over the bf16 bank copy (2 N D bytes): the kernel is built around that stream, not around the
 // matrix cores.
-//   * The bank copy is stored in MFMA fragment order (filter_common.h): a wave fetches the A operand of a k-step with one
-//     coalesced 1-KiB global_load_dwordx4 straight into the registers the MFMA reads.  No LDS staging, no ring, no
+//   * The bank copy is stored in MFMA fragment order (filter_common.h: v_mfma_f32_16x16x32_bf16, 16 keys x 32 elements
+//     per 1-KiB block): a wave fetches an A operand with one coalesced 1-KiB global_load_dwordx4 straight into the
+//     registers the MFMA reads.  No LDS staging, no ring, no
 //     barrier, no hand-over between waves: every wave streams its own 16-KiB units (512 key-elements x 16 blocks), the
 //     next unit's sixteen loads in flight while the current one is multiplied -- 8 waves x 16 KiB = 128 KiB in flight per
 //     CU.  Units are dealt round-robin over all waves of the grid, so neighbouring waves read neighbouring 16 KiB.
 //   * The queries are the B operands, converted once per call to bf16 in fragment order too (1 KiB per k-step and group
-//     of 32; filter_prep_kernel).  Up to 32 of them live in registers (D/4 VGPRs); 33..256 are copied into LDS: every
-//     unit is multiplied with each group in turn, one conflict-free ds_read_b128 per MFMA (128 B/clk/CU, half the LDS
-//     rate).  The key stream is thus read ONCE for all groups.
+//     of 16; filter_prep_kernel).  Up to 32 of them live in registers (D/4 VGPRs); 33..256 are copied into LDS: every
+//     unit is multiplied with each group in turn, one conflict-free ds_read_b128 per k-step feeding the MFMAs of BOTH
+//     16-key halves of every sub-tile of the unit (32 SUBS cycles of MFMA per KiB read).  The key stream is thus read
+//     ONCE for all groups.
 //   * Epilogue as in the ring kernel: one wave-uniform test of the accumulators' maxima per 32 keys x 32 queries; passing
 //     keys leave through a wave-private LDS buffer and reach the per-query candidate lists in flushes.
 //   * BOUND mode: no thresholds, no candidates -- per query the best approximate score of each of `ngroups` consecutive
 //     parts of the key range (atomicMax on order-preserving ints), from which the first lower bound of the k-th best
 //     score is made (filter_threshold).
-// The loads are inline asm (hipcc would otherwise serialise them behind its own waitcnt bookkeeping) and are waited for
-// with counted s_waitcnt vmcnt: block i of the current unit is needed when (15 - i) younger loads of the unit and, if a
-// next unit exists, its 16 loads may still be outstanding.  Any other vector-memory operation the compiler issues in
-// between is younger than the awaited load or older than all of them, so it can only make a wait stricter.
+// The key loads are plain (nontemporal) loads: hipcc counts its own vmcnt waits -- block i of the current unit is needed
+// when the unit's younger loads and the next unit's sixteen are still outstanding -- which it gets right as long as no
+// asm statement claims the registers in between (an earlier version with asm loads and tied asm waits made the register
+// allocator copy registers whose loads had not landed).  The B-operand reads from LDS are asm, run ahead of the MFMAs
+// and are counted with lgkmcnt by hand.
 #include "filter_common.h"
 #include <type_traits>
 
@@ -31,13 +34,15 @@ template <int D_>
 struct DirectCfg {
   static constexpr int D = D_;
   static constexpr int WAVES = 8, THREADS = 512;
-  static constexpr int KSTEPS = D / 16;              // MFMA k-steps (1-KiB blocks) per 32-key sub-tile: 16 / 8 / 4
+  static constexpr int KSTEPS = D / 16;              // 1-KiB blocks per 32-key sub-tile (2 halves x KS32): 16 / 8 / 4
+  static constexpr int KS32 = D / 32;                // MFMA k-steps (32 elements) per sub-tile: 8 / 4 / 2
   static constexpr int UNIT_BLOCKS = 16;             // blocks per unit = 16 KiB in flight per wave and buffer
   static constexpr int SUBS = UNIT_BLOCKS / KSTEPS;  // sub-tiles per unit: 1 / 2 / 4
   static constexpr int UNIT_KEYS = 32 * SUBS;        // 32 / 64 / 128
   static constexpr int CAND_BUF = SUBS == 1 ? 256 : 512;  // entries (8 B) of a wave's candidate buffer; one group pass
                                                          // over a unit pushes at most 64 SUBS of them
-  static constexpr int GROUP_BYTES = KSTEPS * 1024;  // one group of 32 queries as bf16 B operands
+  static constexpr int GROUP_BYTES = KS32 * 1024;    // one group of 16 queries as bf16 B operands
+  static constexpr int LA = KS32 < 4 ? KS32 : 4;     // B-operand reads in flight ahead of their MFMAs
   static constexpr size_t lds_bytes(int groups_in_lds) {
     return (size_t)groups_in_lds * GROUP_BYTES + (size_t)WAVES * CAND_BUF * 8 + 256 * sizeof(float) + WAVES * sizeof(int);
   }
@@ -55,7 +60,7 @@ struct DirectParams {
   int cap, nsub, subcap;  // nsub sub-lists of subcap = cap / nsub slots per query
   int* gmax;              // BOUND
   int ngroups;            // BOUND: parts of the range
-  int qgroups;            // groups of 32 queries (1..8)
+  int qgroups;            // groups of 16 queries (2..16, even: the query image is padded to whole 32s)
 };
 
 // QREG: <= 32 queries, B operands in registers; else `qgroups` groups in LDS.
@@ -65,14 +70,14 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
   extern __shared__ float4 dsmem4[];
   char* smem = reinterpret_cast<char*>(dsmem4);
   const int ngl = QREG ? 0 : p.qgroups;
-  char* qlds = smem;                                                             // [ngl][KSTEPS][64] x 16 B
+  char* qlds = smem;                                                             // [ngl][KS32][64] x 16 B
   uint2* wbuf_all = reinterpret_cast<uint2*>(smem + (size_t)ngl * C::GROUP_BYTES);  // [WAVES][CAND_BUF]
   float* thr_lds = reinterpret_cast<float*>(wbuf_all + C::WAVES * C::CAND_BUF);     // [256]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31, g = lane >> 5;
+  const int j = lane & 15, g = lane >> 4;
 
   // ---- thresholds (one per query of the tile) and, beyond 32 queries, the B operands in LDS -------------------------
   if (tid < 256) {
@@ -83,7 +88,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
   // the B operands: filter_prep_kernel left them in HBM as bf16 in fragment order, so a workgroup copies its image
   // into LDS linearly (33..256 queries) or a wave takes its 64 VGPRs straight from it (<= 32 queries)
   if constexpr (!QREG) {
-    const int pieces = ngl * C::KSTEPS * 64;
+    const int pieces = ngl * C::KS32 * 64;
     for (int i = tid; i < pieces; i += C::THREADS)
       *reinterpret_cast<f32x4*>(qlds + (size_t)i * 16) = reinterpret_cast<const f32x4*>(p.Qb)[i];
   }
@@ -144,7 +149,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
         while (mk) {
           const int r = __ffs(mk) - 1;
           mk &= mk - 1;
-          if (slot < p.subcap) p.cand[q * p.cap + sub * p.subcap + slot] = (int)e.x + (r & 3) + 8 * (r >> 2);
+          if (slot < p.subcap) p.cand[q * p.cap + sub * p.subcap + slot] = (int)e.x + (r & 3) + 16 * (r >> 2);
           ++slot;
         }
       }
@@ -163,50 +168,53 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
   }
 #define RG_DWAIT(cnt_, reg_)
 
-  // epilogue of a 32-key sub-tile against one query group: acc[r] = approximate score of key row (r & 3) + 8 (r >> 2) + 4 g
-  auto epilogue = [&](const f32x16& acc, int gq, int64_t unit, int sub, int part) {
-    float m = acc[0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+  // epilogue of a 32-key sub-tile against one group of 16 queries: a[h][r] = approximate score of key 16 h + 4 g + r of the
+  // sub-tile for query 16 gq + j
+  auto epilogue = [&](const f32x4 (&a)[2], int gq, int64_t unit, int sub, int part) {
+    float m = fmaxf(fmaxf(fmaxf(a[0][0], a[0][1]), fmaxf(a[0][2], a[0][3])), fmaxf(fmaxf(a[1][0], a[1][1]), fmaxf(a[1][2], a[1][3])));
     if constexpr (BOUND) {
       if (part != cur_part) {  // wave-uniform: the run crossed into the next part
         flush_max();
         cur_part = part;
       }
+      m = fmaxf(m, __shfl_xor(m, 16));
       m = fmaxf(m, __shfl_xor(m, 32));
-      if (g == 0) gm_lds[32 * gq + j] = fmaxf(gm_lds[32 * gq + j], m);
+      if (g == 0) gm_lds[16 * gq + j] = fmaxf(gm_lds[16 * gq + j], m);
     } else {
-      const float th = thr_lds[32 * gq + j];
+      const float th = thr_lds[16 * gq + j];
       if (__any(m >= th)) {
         unsigned mk = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mk |= (acc[r] >= th) ? (1u << r) : 0u;
-        const int64_t key_base = (unit * C::SUBS + sub) * 32 + 4 * g;  // the lane's keys: + (r & 3) + 8 (r >> 2)
-        if (key_base + 28 >= p.key_end) {
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mk |= (a[h][r] >= th) ? (1u << (4 * h + r)) : 0u;
+        const int64_t key_base = (unit * C::SUBS + sub) * 32 + 4 * g;  // the lane's keys: + r + 16 h  (mask bit 4 h + r)
+        if (key_base + 32 > p.key_end) {
           unsigned vm = 0;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) vm |= (key_base + (r & 3) + 8 * (r >> 2) < p.key_end) ? (1u << r) : 0u;
+          for (int r = 0; r < 8; ++r) vm |= (key_base + (r & 3) + 16 * (r >> 2) < p.key_end) ? (1u << r) : 0u;
           mk &= vm;
         }
         if (p.thr.ablate == 2) mk = 0;  // (timing only: masks computed, candidates dropped)
         const unsigned long long bal = __ballot(mk != 0);
         if (bal) {
           const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-          if (mk) wbuf[pos] = make_uint2((unsigned)key_base, ((unsigned)(32 * gq + j) << 16) | mk);
+          if (mk) wbuf[pos] = make_uint2((unsigned)key_base, ((unsigned)(16 * gq + j) << 16) | mk);
           wcnt += __popcll(bal);
         }
       }
     }
   };
 
-  // One unit against every query group.  The first group's pass carries the counted vmcnt waits: block i is needed
-  // when the unit's 15 - i younger loads and, if a next unit is in flight, its 16 may still be outstanding; the other
-  // groups find the unit in registers.  Beyond 32 queries the B operands come from LDS, and a k-step is only 32 cycles
-  // of MFMA -- less than an LDS round trip -- so their reads run FOUR steps ahead of the MFMAs, across group boundaries,
-  // as asm loads with counted lgkmcnt waits (hipcc's own schedule keeps one read ahead and idles the matrix pipe).
+  // One unit against every query group.  The unit's sixteen blocks are k-step major (filter_common.h): block
+  // (sub * KS32 + t) * 2 + h = k-step t of half h of sub-tile sub.  Up to 32 queries: the B operands are registers.
+  // Beyond: they come from LDS, one 1-KiB fragment per (group, k-step) that feeds the 2 SUBS MFMAs of every half of the
+  // unit -- 32 SUBS cycles of MFMA, less than an LDS round trip at D = 256 -- so the reads run LA steps ahead of the
+  // MFMAs, across group boundaries (the groups are contiguous in LDS: read number r is simply KiB r of the image; the
+  // last LA reads run past it into the candidate buffers and are never used), as asm loads with counted lgkmcnt waits
+  // (hipcc's own schedule keeps one read ahead and idles the matrix pipe).
   const unsigned qaddr0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)qlds + lane16;
   auto process = [&](f32x4 (&A)[16], int64_t unit, auto next_tag) {
-    [[maybe_unused]] constexpr int BEHIND = decltype(next_tag)::value ? 16 : 0;
     int part0 = 0;
     if constexpr (BOUND) part0 = (int)(((unit - p.unit0) * C::SUBS) * p.ngroups / (p.nunits * C::SUBS));
     // (sub-tiles of one unit lie in one part or in two neighbouring ones: the division is per unit, not per sub-tile)
@@ -215,72 +223,62 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
       if (C::SUBS == 1 || sub == 0) return part0;
       return (int)(((unit - p.unit0) * C::SUBS + sub) * p.ngroups / (p.nunits * C::SUBS));
     };
-    f32x16 acc;
     if constexpr (QREG) {
-#define RG_STEP(i_)                                                                                             \
-  {                                                                                                             \
-    if constexpr ((i_) % C::KSTEPS == 0) {                                                                      \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] = 0.f;                                              \
-    }                                                                                                           \
-    RG_DWAIT(BEHIND + 15 - (i_), A[i_]);                                                                        \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[i_]), bq[(i_) % C::KSTEPS], acc, 0, 0, 0); \
-    if constexpr ((i_) % C::KSTEPS == C::KSTEPS - 1) epilogue(acc, 0, unit, (i_) / C::KSTEPS, part_of((i_) / C::KSTEPS)); \
-  }
       if constexpr (!BOUND) {
-        if (wcnt > C::CAND_BUF - 64 * C::SUBS) flush();
+        if (wcnt > C::CAND_BUF - 128 * C::SUBS) flush();  // two groups x SUBS sub-tiles x <= 64 entries
       }
-      RG_STEP(0) RG_STEP(1) RG_STEP(2) RG_STEP(3) RG_STEP(4) RG_STEP(5) RG_STEP(6) RG_STEP(7)
-      RG_STEP(8) RG_STEP(9) RG_STEP(10) RG_STEP(11) RG_STEP(12) RG_STEP(13) RG_STEP(14) RG_STEP(15)
-#undef RG_STEP
+#pragma unroll
+      for (int sub = 0; sub < C::SUBS; ++sub) {
+        f32x4 acc[2][2];  // [group][half]
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq) acc[gq][0] = acc[gq][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < C::KS32; ++t)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const bf16x8 a_ = __builtin_bit_cast(bf16x8, A[(sub * C::KS32 + t) * 2 + h]);
+#pragma unroll
+            for (int gq = 0; gq < 2; ++gq)
+              acc[gq][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, bq[gq * C::KS32 + t], acc[gq][h], 0, 0, 0);
+          }
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq) epilogue(acc[gq], gq, unit, sub, part_of(sub));
+      }
     } else {
-      f32x4 fr[4];
-      // step i of a group pass reads B block i % KSTEPS of the group; the read of step i + 4 is issued behind MFMA i --
-      // for the last four steps that is the NEXT group's block (the last group reads group 0's again: unused)
+      f32x4 fr[C::LA];
 #define RG_BREAD(slot_, addr_, blk_) \
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[(slot_)&3]) : "v"(addr_), "n"(((blk_) % C::KSTEPS) * 1024))
-#define RG_BWAIT(cnt_, slot_) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fr[(slot_)&3]) : "n"(cnt_))
-#define RG_GSTEP(i_, FIRST_)                                                                                    \
-  {                                                                                                             \
-    if constexpr ((i_) % C::KSTEPS == 0) {                                                                      \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] = 0.f;                                              \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[(slot_) % C::LA]) : "v"(addr_), "n"((blk_) * 1024))
+#define RG_BWAIT(slot_) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fr[(slot_) % C::LA]) : "n"(C::LA - 1))
+#pragma unroll
+      for (int t = 0; t < C::LA; ++t) RG_BREAD(t, qaddr0, t);
+      for (int gq = 0; gq < ngl; ++gq) {
+        if constexpr (!BOUND) {
+          if (wcnt > C::CAND_BUF - 64 * C::SUBS) flush();
+        }
+        const unsigned cur = qaddr0 + (unsigned)gq * C::GROUP_BYTES;
+        f32x4 acc[C::SUBS][2];
+#pragma unroll
+        for (int sub = 0; sub < C::SUBS; ++sub) acc[sub][0] = acc[sub][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define RG_GSTEP(t_)                                                                                            \
+  if constexpr ((t_) < C::KS32) {                                                                               \
+    RG_BWAIT(t_);                                                                                               \
+    {                                                                                                           \
+      const bf16x8 b_ = __builtin_bit_cast(bf16x8, fr[(t_) % C::LA]);                                           \
+      _Pragma("unroll") for (int sub = 0; sub < C::SUBS; ++sub)                                                 \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                           \
+          acc[sub][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                                \
+              __builtin_bit_cast(bf16x8, A[(sub * C::KS32 + (t_)) * 2 + h]), b_, acc[sub][h], 0, 0, 0);         \
     }                                                                                                           \
-    RG_BWAIT(3, i_);                                                                                            \
-    if constexpr (FIRST_) RG_DWAIT(BEHIND + 15 - (i_), A[i_]);                                                  \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[i_]),                            \
-                                                  __builtin_bit_cast(bf16x8, fr[(i_)&3]), acc, 0, 0, 0);        \
-    if constexpr ((i_) + 4 < 16) RG_BREAD(i_, cur, (i_) + 4);                                                   \
-    else RG_BREAD(i_, nxt, (i_) + 4 - 16);                                                                      \
-    if constexpr ((i_) % C::KSTEPS == C::KSTEPS - 1) epilogue(acc, gq, unit, (i_) / C::KSTEPS, part_of((i_) / C::KSTEPS)); \
+    RG_BREAD(t_, cur, (t_) + C::LA);                                                                            \
   }
-#define RG_GPASS(FIRST_)                                                                                        \
-  RG_GSTEP(0, FIRST_) RG_GSTEP(1, FIRST_) RG_GSTEP(2, FIRST_) RG_GSTEP(3, FIRST_) RG_GSTEP(4, FIRST_)           \
-  RG_GSTEP(5, FIRST_) RG_GSTEP(6, FIRST_) RG_GSTEP(7, FIRST_) RG_GSTEP(8, FIRST_) RG_GSTEP(9, FIRST_)           \
-  RG_GSTEP(10, FIRST_) RG_GSTEP(11, FIRST_) RG_GSTEP(12, FIRST_) RG_GSTEP(13, FIRST_) RG_GSTEP(14, FIRST_)      \
-  RG_GSTEP(15, FIRST_)
-      unsigned cur = qaddr0, nxt = ngl > 1 ? qaddr0 + C::GROUP_BYTES : qaddr0;
-      RG_BREAD(0, cur, 0);
-      RG_BREAD(1, cur, 1);
-      RG_BREAD(2, cur, 2);
-      RG_BREAD(3, cur, 3);
-      {
-        const int gq = 0;
-        if constexpr (!BOUND) {
-          if (wcnt > C::CAND_BUF - 64 * C::SUBS) flush();
-        }
-        RG_GPASS(true)
-      }
-      for (int gq = 1; gq < ngl; ++gq) {
-        cur = nxt;
-        nxt = gq + 1 < ngl ? cur + C::GROUP_BYTES : qaddr0;
-        if constexpr (!BOUND) {
-          if (wcnt > C::CAND_BUF - 64 * C::SUBS) flush();
-        }
-        RG_GPASS(false)
-      }
-      // the four reads issued past the last step land in registers nobody uses: retire them
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[0]), "+v"(fr[1]), "+v"(fr[2]), "+v"(fr[3]));
-#undef RG_GPASS
+        RG_GSTEP(0) RG_GSTEP(1) RG_GSTEP(2) RG_GSTEP(3) RG_GSTEP(4) RG_GSTEP(5) RG_GSTEP(6) RG_GSTEP(7)
 #undef RG_GSTEP
+#pragma unroll
+        for (int sub = 0; sub < C::SUBS; ++sub) epilogue(acc[sub], gq, unit, sub, part_of(sub));
+      }
+      // the LA reads issued past the last step land in registers nobody uses: retire them
+#pragma unroll
+      for (int t = 0; t < C::LA; ++t) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[t]));
 #undef RG_BWAIT
 #undef RG_BREAD
     }
@@ -365,7 +363,7 @@ int launch_filter_direct(const DirectArgs& a, hipStream_t st) {
   p.subcap = a.cap / p.nsub;
   p.gmax = a.gmax_out;
   p.ngroups = a.bound_groups;
-  p.qgroups = (int)cdiv(a.B, 32);
+  p.qgroups = 2 * (int)cdiv(a.B, 32);
   const bool bound = a.bound_groups > 0;
   if (bound)
     RG_REQUIRE(p.nunits * C::SUBS >= a.bound_groups, RAGRAPH_EINVAL, "filter(direct): bound range shorter than its parts");
