@@ -382,8 +382,9 @@ def main():
                     "whose flops are overhead and not counted, and the filter levels, summed per call). The whole "
                     f"exact retrieval call (this kernel + exact fp32 rescoring of the survivors) takes "
                     f"{call_ms:.2f} ms; `exact_fp32` below is the same step on the fp32 MFMA kernel alone. "
-                    f"tools/microbench/mfma_bf16_bench.hip: this kernel's bare inner loop sustains 1.60 PFLOP/s on random "
-                    f"operands (2.19 on near-constant ones): the clock held under real data bounds it well below peak",
+                    f"tools/microbench/mfma_bf16_shape_bench.hip: this kernel's bare inner loop sustains 1.71 PFLOP/s on random "
+                    f"operands (1.61 with the 32x32x16 shape of round 1; 2.2 on near-constant operands): the clock "
+                    f"the chip holds under real data bounds it well below the nominal peak",
             "retrieval_call_ms": round(call_ms, 3),
         }
     else:

@@ -9,7 +9,9 @@
  *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host; row-major, contiguous, fp32;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous on it;
  *   - no allocation, no synchronisation and no global state inside a call (graph-capturable, thread-safe per
- *     stream); scratch comes from the caller via (ws, ws_bytes) sized by the matching *_workspace_bytes();
+ *     stream); scratch comes from the caller via (ws, ws_bytes) sized by the matching *_workspace_bytes().  The one
+ *     exception is the measurement hook ragraph_profile_filter_kernel(): while it is ON the filtered top-k records
+ *     events into process-global slots (one measuring thread at a time, not capturable); it is OFF by default;
  *   - return 0 on success, a negative RAGRAPH_E* code otherwise; ragraph_last_error() gives the thread's last
  *     message.  There is NO CPU fallback: without a gfx950 device every compute entry returns RAGRAPH_EDEVICE.
  *
@@ -190,7 +192,9 @@ int ragraph_gather_reduce_f32(const float* V, int D, const float* L, int C, int6
 /* ------------------------------------------------------------------------------------------------------------
  * a4/a9/a1  dense  Y = act(X @ W^T + b)   -- layers/gcn.py:32 (self.fc, no bias), TaskDecoder.py:15-16
  *           (fc1+LeakyReLU, fc2), and the materialised score matrix of SimilarityFunctions.py:14 (X=Qn, W=Kn).
- *     X [M,K], W [N,K] (nn.Linear weight layout), bias [N] or NULL, Y [M,N].  Any M,N,K >= 1.
+ *     X [M,K], W [N,K] (nn.Linear weight layout), bias [N] or NULL, Y [M,N].  Any M,K >= 1; 1 <= N <= 65535 * 64
+ *     (= 4 194 240 output columns per launch, RAGRAPH_EUNSUPPORTED beyond: callers that materialise scores against a
+ *     longer bank -- the k > 64 slab path -- cut the bank into column slabs).
  *     Each Y[m,n] is one fmaf chain over k = 0..K-1 from +0; then + bias (one fp32 add); then act.
  */
 int ragraph_linear_f32(const float* X, int64_t M, int K, const float* W, int64_t N, const float* bias, int act,

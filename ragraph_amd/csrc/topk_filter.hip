@@ -406,21 +406,41 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
           for (int r = 0; r < 4; ++r) mk |= (a[h][gq][r] >= thr) ? (1u << (4 * h + r)) : 0u;
         return mk;
       };
-      auto push = [&](unsigned mk, unsigned word0) {
-        const unsigned long long m = __ballot(mk != 0);
-        if (m) {
-          if (wcnt > C::CAND_BUF - 64) flush();  // (a push adds at most 64 entries)
-          const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-          if (mk) wbuf[pos] = make_uint2(word0, mk);
-          wcnt += __popcll(m);
+      // the groups' entries of one sub-tile: ballots first, ONE buffer check per (up to) four groups -- a flush is ~60
+      // instructions and every copy of it sits in the stage loop's instruction stream
+      auto push_groups = [&](const unsigned (&km)[NG], unsigned off) {
+        constexpr int GB = NG < 4 ? NG : 4;  // groups per check: at most 64 GB = 256 entries < CAND_BUF
+#pragma unroll
+        for (int g0 = 0; g0 < NG; g0 += GB) {
+          unsigned long long bm[GB];
+          int tot = 0;
+#pragma unroll
+          for (int i = 0; i < GB; ++i) {
+            bm[i] = __ballot(km[g0 + i] != 0);
+            tot += __popcll(bm[i]);
+          }
+          if (tot == 0) continue;
+          if (wcnt + tot > C::CAND_BUF) flush();
+#pragma unroll
+          for (int i = 0; i < GB; ++i) {
+            if (bm[i]) {
+              const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm[i] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm[i], 0u));
+              if (km[g0 + i]) wbuf[pos] = make_uint2(((unsigned)(j + 16 * (g0 + i)) << 25) | off, km[g0 + i]);
+              wcnt += __popcll(bm[i]);
+            }
+          }
         }
       };
       auto epilogue = [&](int u, const f32x4 (&a)[2][NG]) {
         float m[NG];
 #pragma unroll
-        for (int gq = 0; gq < NG; ++gq)
-          m[gq] = fmaxf(fmaxf(fmaxf(a[0][gq][0], a[0][gq][1]), fmaxf(a[0][gq][2], a[0][gq][3])),
-                        fmaxf(fmaxf(a[1][gq][0], a[1][gq][1]), fmaxf(a[1][gq][2], a[1][gq][3])));
+        for (int gq = 0; gq < NG; ++gq) {  // (a chain, not a tree: hipcc folds it into v_max3_f32 -- 4 instructions, not 7)
+          m[gq] = a[0][gq][0];
+#pragma unroll
+          for (int r = 1; r < 4; ++r) m[gq] = fmaxf(m[gq], a[0][gq][r]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) m[gq] = fmaxf(m[gq], a[1][gq][r]);
+        }
         bool hit = false;
 #pragma unroll
         for (int gq = 0; gq < NG; ++gq) hit = hit || (m[gq] >= thr[gq]);
@@ -445,9 +465,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
 #pragma unroll
             for (int gq = 0; gq < NG; ++gq) km[gq] &= vm;
           }
-          const unsigned off = (unsigned)(key_base - key_org);
-#pragma unroll
-          for (int gq = 0; gq < NG; ++gq) push(km[gq], ((unsigned)(j + 16 * gq) << 25) | off);
+          push_groups(km, (unsigned)(key_base - key_org));
         }
       };
       // ---- SUBS sub-tiles of 32 keys x QW queries, KSTEPS fragments each (k-step major: both 16-key halves of a step);

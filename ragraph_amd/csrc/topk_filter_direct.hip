@@ -171,7 +171,11 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
   // epilogue of a 32-key sub-tile against one group of 16 queries: a[h][r] = approximate score of key 16 h + 4 g + r of the
   // sub-tile for query 16 gq + j
   auto epilogue = [&](const f32x4 (&a)[2], int gq, int64_t unit, int sub, int part) {
-    float m = fmaxf(fmaxf(fmaxf(a[0][0], a[0][1]), fmaxf(a[0][2], a[0][3])), fmaxf(fmaxf(a[1][0], a[1][1]), fmaxf(a[1][2], a[1][3])));
+    float m = a[0][0];  // (a chain, not a tree: hipcc folds it into v_max3_f32)
+#pragma unroll
+    for (int r = 1; r < 4; ++r) m = fmaxf(m, a[0][r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m = fmaxf(m, a[1][r]);
     if constexpr (BOUND) {
       if (part != cur_part) {  // wave-uniform: the run crossed into the next part
         flush_max();
