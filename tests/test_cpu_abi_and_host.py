@@ -87,6 +87,25 @@ def test_filtered_topk_plan_is_well_formed():
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_filtered_dispatch_rule():
+    """kernels.filter_helps (pure host arithmetic): which shapes take the bf16-filtered exact top-k.  Long banks at any
+    batch size; mid-sized banks (>= 8192 keys) from 2048 queries up (D >= 128) or 8192 (D = 64); small score matrices
+    never (they are cheaper materialised); unsupported D / k never; RAGRAPH_EXACT_FP32=1 never."""
+    import os
+
+    from ragraph_amd import kernels as K
+
+    assert os.environ.get("RAGRAPH_EXACT_FP32") != "1"
+    yes = [(1, 1_000_000, 256, 10), (16, 262144, 64, 3), (2708, 10_000, 128, 5), (8192, 8192, 128, 5),
+           (2708, 10_000, 256, 10), (8192, 10_000, 64, 10), (4096, 16384, 256, 10), (100_000, 1_000_000, 256, 32)]
+    no = [(1024, 10_000, 128, 5), (2708, 10_000, 64, 10), (2708, 4096, 128, 5), (64, 65536, 256, 10),
+          (1, 1_000_000, 96, 10), (1, 1_000_000, 256, 33), (40, 70_000, 256, 10)]
+    for B, N, D, k in yes:
+        assert K.filter_helps(B, N, D, k), (B, N, D, k)
+    for B, N, D, k in no:
+        assert not K.filter_helps(B, N, D, k), (B, N, D, k)
+
+
 def test_no_silent_fallback_without_device():
     from ragraph_amd import kernels as K
     from ragraph_amd.ragraph_utils import Propagation, SimilarityFunctions
