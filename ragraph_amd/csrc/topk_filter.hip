@@ -1,5 +1,5 @@
-// Exact cosine top-k through a bf16 MFMA filter  (SimilarityFunctions.py:6-16 + ToyGraphBase.py:66-67, a dozen queries
-// and up; D = 64 is the edge flavour's RAGraph_edge/modules/RAGraph.py:298-324).
+// Exact cosine top-k through a bf16 MFMA filter  (SimilarityFunctions.py:6-16 + ToyGraphBase.py:66-67, any batch size
+// against banks of >= 64 k keys; D = 64 is the edge flavour's RAGraph_edge/modules/RAGraph.py:298-324).
 //
 // The fp32 tile kernel (topk_cosine.hip) spends 2·B·N·D fp32 MFMA flops; the bf16 matrix cores are 16x faster.  This
 // path returns the SAME bits with most of the work on them:
@@ -18,19 +18,19 @@
 //      and a tighter theta for the next level.  The schedule (n0, one to three levels) depends on the batch size:
 //      filter_schedule() below, readable through ragraph_topk_cosine_filtered_plan.
 // A query whose candidate list overflows its capacity (adversarial banks: thousands of keys within eps of the k-th
-// best) is counted in *overflow and must be re-run through ragraph_topk_cosine_bank_f32 by the caller; the other
-// queries' results are exact regardless.
+// best) is recomputed by an exact fp32 scan of the bank ON THE DEVICE (exact_scan_query: inside the sliced rescoring
+// launch for <= 64 queries, topk_overflow_fixup_kernel otherwise); *overflow only counts those rows.  The call never
+// synchronises and reads nothing back.
 //
-// Filter kernel: workgroup = 8 waves x 64 queries = 512 queries (x 32 = 256 for batches of <= 256, x 128 = 1024 at
-// D = 64); a wave keeps its queries as the B operands of v_mfma_f32_32x32x16_bf16 (groups of 32: D/4 VGPRs each) and
-// streams the bf16 bank
-// (2 D bytes per key) through a 4-slot LDS ring of 32 KiB stages (64 / 128 / 256 keys at D = 256 / 128 / 64) filled by
-// LDS-DMA, 1 KiB per global_load_lds_dwordx4, handed over by FULL/FREE counters.  One ds_read_b128 (8 bf16 of one key
-// row) feeds two MFMAs (one per query group).  The LDS image is XOR-swizzled through the DMA's per-lane SOURCE address
-// (16-B chunk c of row j sits at chunk c ^ f(j)), which makes the ds_read_b128 of 32 rows conflict-free without padding.
-// Candidates leave the MFMA stream through wave-private LDS buffers (branch-free pass masks, ballot + mbcnt positions)
-// and reach the per-query lists in global memory in flushes.  Work plan: segment_plan.h with zero warm-up cost (there
-// are no lists): every workgroup gets the same number of stages.
+// Two filter kernels share one bank layout (filter_common.h: MFMA fragment order of v_mfma_f32_16x16x32_bf16):
+// topk_filter_direct_kernel (topk_filter_direct.hip) for up to 256 queries, and this file's RING kernel above that:
+// workgroup = 8 waves x 64 queries = 512 queries (x 32 = 256, x 128 = 1024 at D = 64 on long streams); a wave keeps its
+// queries as QW/16 groups of B operands (D/8 VGPRs each) and streams the bf16 bank (2 D bytes per key) through a 4-slot
+// LDS ring of 32 KiB stages (64 / 128 / 256 keys at D = 256 / 128 / 64) filled by LDS-DMA, one 1-KiB block per
+// global_load_lds_dwordx4 -- the LDS image is the HBM image, conflict-free for the lanes' ds_read_b128 -- handed over by
+// FULL/FREE counters.  One fragment read feeds QW/16 MFMAs.  Candidates leave the MFMA stream through wave-private LDS
+// buffers (branch-free pass masks, ballot + mbcnt positions) and reach the per-query lists in global memory in flushes.
+// Work plan: segment_plan.h with zero warm-up cost (there are no lists): every workgroup gets the same number of stages.
 #include "filter_common.h"
 #include "segment_plan.h"
 #include <cmath>
@@ -548,9 +548,6 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
   }
 }
 
-// Canonical top-k (score descending, index ascending) of the 64 x NSL (score, id) pairs a wave holds in registers:
-// k rounds of wave argmax over what comes after the previous winner.  Lane 0 writes the result (ids + base).  Ids are
-// shard-local key indices (32 bits; INT_MAX = none, written out as INT64_MAX): a third less to shuffle than 64-bit ones.
 // ---- canonical top-k of a wave's 64 NSL (score, id) pairs (score descending, id ascending; k <= 32) -------------------
 // A pair travels as one 64-bit key whose unsigned order is the canonical order: the score's bits made monotone in the
 // upper word, ~id in the lower; an empty slot (-inf, INT_MAX) and a pair already taken are key 0, which decodes to
