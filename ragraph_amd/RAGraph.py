@@ -59,6 +59,9 @@ class RAGraph(nn.Module):
         queries = self._queries(pretrain_embedddings, g)
         if self.query_shard is not None and not self.training and self.flavour == "node":
             return self._forward_query_shard(queries, pretrain_embedddings, g)
+        if (not self.training and self.flavour == "node" and getattr(tgb, "values_replicated", False)
+                and hasattr(tgb, "retrieve_reduced_rows") and (tgb.collective or tgb.emulate_world > 1)):
+            return self._forward_key_shard(queries, pretrain_embedddings, g)
         if add_noise:
             rag_embedding, rag_label = tgb.retrieve_reduced_noisy(queries)                     # :43,48-49 (noise branch)
         else:
@@ -97,6 +100,22 @@ class RAGraph(nn.Module):
             return qs.gather_rows(rag_label, n)
         query_embeddings = Propagation.aggregate_k_hop_features(g, emb, self.query_graph_hop)[lo:hi].contiguous()
         return qs.gather_rows(self._fuse_decode(query_embeddings, rag_embedding, rag_label), n)
+
+
+    def _forward_key_shard(self, queries, emb, g):
+        """Multi-GPU inference with a row-sharded KEY bank (ragraph_amd.sharded.ShardedToyGraphBase, values replicated):
+        every rank filters ALL queries against its shard; everything behind that is per query and runs on the rank's
+        slice of the nodes only -- merge of the per-shard lists (one all_to_all), value / label gather, the last
+        propagation hop, fusion + decoder -- and one all_gather of the [n, C] outputs completes the step.  Row for row
+        the arithmetic of forward()."""
+        tgb = self.toy_graph_base
+        n = queries.shape[0]
+        lo, hi = tgb.tail_bounds(n)
+        rag_embedding, rag_label, _ = tgb.retrieve_reduced_rows(queries)
+        if not self.finetune:
+            return tgb.gather_output_rows(rag_label, n)
+        query_embeddings = Propagation.aggregate_k_hop_features(g, emb, self.query_graph_hop, rows=(lo, hi))
+        return tgb.gather_output_rows(self._fuse_decode(query_embeddings, rag_embedding, rag_label), n)
 
 
 class RAGraphGraph(RAGraph):

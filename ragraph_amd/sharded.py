@@ -90,6 +90,7 @@ class ShardedToyGraphBase:
         from .kernels_index import KeyIndex  # torch-only helper: copies for the faster kernels, made on first use
         self._index = KeyIndex(self.keys_normalized, ops)
         self.emulate_world = int(emulate_world)
+        self._out_shard = None
         n_local = int(keys.shape[0])
         if plan_n:
             self.plan_n = int(plan_n)
@@ -153,6 +154,59 @@ class ShardedToyGraphBase:
         dist.all_gather_into_tensor(gs, s.contiguous(), group=self.group)
         dist.all_gather_into_tensor(gi, i.contiguous(), group=self.group)
         return self.ops.topk_merge(gs.view(self.world, B, k), gi.view(self.world, B, k))
+
+    # ---- key-sharded bank, query-sharded tail -----------------------------------------------------------------------
+    # Everything behind the per-shard filter is per query: merge, value / label gather, fusion, decoder.  With the
+    # values replicated, rank r finishes only rows shard_bounds(B, G, r) of the batch: the per-shard lists travel by ONE
+    # all_to_all (a rank receives its rows' lists from every shard: B k 12 (G - 1) / G bytes instead of the all_gather's
+    # B k 12 (G - 1)), the merge, the gathers and the decoder run on B / G rows, and one all_gather of the [B, C] outputs
+    # (RAGraph.forward) completes the step.  Same bits as the replicated tail: every step is per row.
+    def tail_bounds(self, B: int):
+        G = self.emulate_world if self.emulate_world > 1 else self.world
+        return shard_bounds(B, G, 0 if self.emulate_world > 1 else self.rank)
+
+    def topk_rows(self, search_keys, k=None):
+        """Global canonical top-k of THIS RANK'S rows of the batch: (scores, idx) [hi - lo, k], (lo, hi) = tail_bounds."""
+        k = self.retrieve_num if k is None else k
+        q = search_keys.reshape(1, -1) if search_keys.dim() == 1 else search_keys
+        B = q.shape[0]
+        lo, hi = self.tail_bounds(B)
+        n_local = self.keys_normalized.shape[0]
+        sharded = self.collective or self.emulate_world > 1
+        if not sharded or min(k, n_local) < k:
+            s, i = self.topk(q, k)
+            return s[lo:hi].contiguous(), i[lo:hi].contiguous()
+        s, i = self._index.topk(q, k, idx_base=self.idx_base, exchange=self._exchange, plan_n=self.plan_n)
+        if self.emulate_world > 1:  # (timing only) the merge a real rank runs over the G lists of its rows
+            G = self.emulate_world
+            ss, ii = s[lo:hi], i[lo:hi]
+            self.ops.topk_merge(ss.unsqueeze(0).expand(G, *ss.shape).contiguous(), ii.unsqueeze(0).expand(G, *ii.shape).contiguous())
+            return ss.contiguous(), ii.contiguous()
+        G = self.world
+        bounds = [shard_bounds(B, G, r) for r in range(G)]
+        send = [b - a for a, b in bounds]                    # rows of my lists that go to rank r (its slice of the batch)
+        recv = [hi - lo] * G                                 # every shard sends me its lists for my rows
+        gs = torch.empty((G * (hi - lo), k), dtype=s.dtype, device=s.device)   # shard-major
+        gi = torch.empty((G * (hi - lo), k), dtype=i.dtype, device=i.device)
+        dist.all_to_all_single(gs, s.contiguous(), recv, send, group=self.group)
+        dist.all_to_all_single(gi, i.contiguous(), recv, send, group=self.group)
+        return self.ops.topk_merge(gs.view(G, hi - lo, k), gi.view(G, hi - lo, k))
+
+    def retrieve_reduced_rows(self, search_keys, k=None):
+        """(sum_k V[idx], mean_k L[idx], idx) for this rank's rows of the batch (values replicated)."""
+        if not self.values_replicated:
+            raise ValueError("retrieve_reduced_rows: needs the values / labels replicated on every rank")
+        _, idx = self.topk_rows(search_keys, k)
+        sum_v, mean_l = self.ops.gather_reduce(self.resource_values, self.resource_labels, idx)
+        return sum_v, mean_l, idx
+
+    def gather_output_rows(self, local: torch.Tensor, B: int) -> torch.Tensor:
+        """[hi - lo, C] per rank -> [B, C] on every rank (QueryShard.gather_rows over this bank's group)."""
+        if self.emulate_world > 1 or not self.collective:
+            return local
+        if self._out_shard is None:
+            self._out_shard = QueryShard(self.group, force_collectives=True)
+        return self._out_shard.gather_rows(local, B)
 
     def retrieve_reduced(self, search_keys, k=None):
         """(sum_k V[idx], mean_k L[idx], idx) over the whole bank."""

@@ -197,7 +197,13 @@ def _theta_worker(rank, world, port, N, D, B, k, skew, out_dir):
         assert tgb.plan_n == max(shard_bounds(N, world, r)[1] - shard_bounds(N, world, r)[0] for r in range(world))
         s, i = tgb.topk(torch.from_numpy(q))
         assert FilteredOracleOps.calls == 1
-        np.savez(os.path.join(out_dir, f"t{rank}.npz"), s=s.numpy(), i=i.numpy())
+        # the query-sharded tail: this rank's rows only (lists by all_to_all, merge, gathers), then the output all_gather
+        tlo, thi = tgb.tail_bounds(B)
+        assert (tlo, thi) == shard_bounds(B, world, rank)
+        sv, ml, ti = tgb.retrieve_reduced_rows(torch.from_numpy(q))
+        full_ml = tgb.gather_output_rows(ml, B)
+        np.savez(os.path.join(out_dir, f"t{rank}.npz"), s=s.numpy(), i=i.numpy(), sv=sv.numpy(), ml=ml.numpy(), ti=ti.numpy(),
+                 full_ml=full_ml.numpy(), tlo=tlo, thi=thi)
     finally:
         dist.destroy_process_group()
 
@@ -215,6 +221,14 @@ def test_sharded_theta_exchange_world2(tmp_path, skew):
     if skew:
         keys[N - 3 * k:] = cref.normalize_rows(q[0:1] + 0.05 * rng.standard_normal((3 * k, D), dtype=np.float32))
     rs, ri = cref.topk_cosine(q, cref.normalize_rows(keys), k)
+    vals = rng.standard_normal((N, D), dtype=np.float32)
+    labs = np.eye(3, dtype=np.float32)[rng.integers(0, 3, N)]
+    rsv, rml = cref.gather_reduce(vals, labs, ri)
     for r in range(world):
         got = dict(np.load(tmp_path / f"t{r}.npz"))
         assert np.array_equal(got["i"], ri) and np.array_equal(got["s"], rs)
+        # query-sharded tail (RAGraph._forward_key_shard): the rank's rows of the single-GPU result, bit for bit, and the
+        # gathered [B, C] output in query order on every rank
+        lo, hi = int(got["tlo"]), int(got["thi"])
+        assert np.array_equal(got["ti"], ri[lo:hi]) and np.array_equal(got["sv"], rsv[lo:hi])
+        assert np.array_equal(got["ml"], rml[lo:hi]) and np.array_equal(got["full_ml"], rml)

@@ -399,6 +399,50 @@ def test_captured_forward_helper_replays_new_inputs(dev):
         fwd(other[:-1])
 
 
+def test_key_sharded_forward_with_query_sharded_tail_one_rank_rccl(dev):
+    """RAGraph._forward_key_shard under a 1-rank RCCL group (the collectives run: all_reduce / all_gather of the theta
+    exchange, all_to_all of the lists, all_gather of the outputs): bit-identical to the plain forward."""
+    import socket
+
+    import torch.distributed as dist
+
+    from ragraph_amd.data import synthetic_big_graph
+    from ragraph_amd.graph import CSRGraph
+    from ragraph_amd.preprompt import PrePrompt
+    from ragraph_amd.RAGraph import RAGraph
+    from ragraph_amd.sharded import ShardedToyGraphBase
+
+    torch.manual_seed(3)
+    n, F, D, C, N, k = 3000, 32, 128, 3, 70000, 10
+    model = RAGraph(PrePrompt(F, D, "prelu", 1, 0.3).to(dev), None, F, C, D, device=dev).eval()
+    model.toy_graph_base.retrieve_num = k
+    keys = torch.nn.functional.normalize(torch.randn(N, D, device=dev), dim=-1)
+    vals = torch.randn(N, D, device=dev)
+    labs = torch.nn.functional.one_hot(torch.randint(0, C, (N,), device=dev), C).float()
+    model.toy_graph_base.add_resources(keys, vals, labs)
+    adj = CSRGraph.from_edge_index_sym_normalized(synthetic_big_graph(n, 6, seed=2, device=dev), n)
+    X = torch.randn(n, F, device=dev)
+    with torch.no_grad():
+        want = model(X, adj)
+    with socket.socket() as sck:
+        sck.bind(("127.0.0.1", 0))
+        port = sck.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        plain = model.toy_graph_base
+        model.toy_graph_base = ShardedToyGraphBase(keys, vals, labs, 0, k, force_collectives=True, values_replicated=True)
+        calls = []
+        orig = model._forward_key_shard
+        model._forward_key_shard = lambda *a: (calls.append(1), orig(*a))[1]
+        with torch.no_grad():
+            got = model(X, adj)
+        assert calls, "the sharded bank must take the key-shard forward"
+        model.toy_graph_base = plain
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(got, want)
+
+
 def test_bank_save_load_roundtrip(dev, tmp_path):
     from ragraph_amd.ragraph_utils import ToyGraphBase
 
