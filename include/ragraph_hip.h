@@ -139,10 +139,16 @@ int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const float* Kn,
  * rows, with the per-query bound theta[B] (a proven lower bound of the query's final k-th best exact score over ALL
  * shards) exposed between the phases so that the caller can sharpen it across the shards -- what keeps a shard's
  * candidate lists at 1/G of a single GPU's instead of the same length:
- *   exchange(ctx, 0)      after the first bound (bound pass or exact level 0): theta = this shard's bound; the caller may
- *                         replace theta[q] by any valid lower bound of the global k-th best (e.g. all_reduce MAX);
+ *   exchange(ctx, 0)      after the first bound: theta = this shard's bound, and out_scores[q, 0..k) = k lower bounds
+ *                         (descending) of the exact scores of k DISTINCT keys of this shard -- after a bound pass the
+ *                         parts' best approximate scores minus eps(q), after an exact level 0 its exact top-k.  The
+ *                         caller may replace theta[q] by any valid lower bound of the global k-th best: all_reduce MAX of
+ *                         theta, or (stronger) the k-th largest of the union of every shard's best m of those values
+ *                         (all_gather + ragraph_theta_sharpen_f32);
  *   exchange(ctx, 1 + l)  after level l (not the last): out_scores holds this shard's running top-k (descending, -inf
  *                         where it has fewer than k candidates) and theta = max(theta, its k-th); same contract.
+ * n_shards = G >= 1: the shards pool their first samples through exchange 0, so each scans 1/G of the prefix a single
+ * bank would (pass 1 if the callback does not combine the shards' out_scores).
  * The callback runs on the calling host thread between launches; whatever it enqueues must be ordered on `stream` (a
  * torch.distributed collective on the current stream is).  plan_N = the LARGEST shard's row count: the schedule (hence
  * the number of callbacks) is computed from it, so that every rank makes the same calls; N <= plan_N <= N + 1024.
@@ -153,7 +159,8 @@ typedef void (*ragraph_exchange_fn)(void* ctx, int phase);
 int ragraph_topk_cosine_filtered_sharded_f32(const float* Q, int64_t B, const float* Kn, const float* Kp, const uint16_t* Kb,
                                              int64_t N, int D, int k, int64_t idx_base, float* out_scores, int64_t* out_idx,
                                              int* overflow, int64_t* overflow_idx, void* ws, size_t ws_bytes, void* stream,
-                                             int64_t plan_N, float* theta, ragraph_exchange_fn exchange, void* ctx);
+                                             int64_t plan_N, float* theta, ragraph_exchange_fn exchange, void* ctx,
+                                             int n_shards);
 
 /* The per-level exchange of the sharded call: theta[b] = max(theta[b], k-th largest of the G*m scores gathered for query
  * b), gathered = the all_gather of every shard's best m exact scores, [G, B, m] as the collective leaves it; k <= G*m <= 64.

@@ -197,6 +197,30 @@ __global__ void __launch_bounds__(256) filter_theta_kernel(FilterThr t, int64_t 
   theta[q] = init ? v : fmaxf(theta[q], v);
 }
 
+// Sharded banks, after the bound pass: the k group maxima of a query, each minus eps(q), are lower bounds of the exact
+// scores of k DISTINCT keys of this shard.  Sorted (descending) into scores[B,k] they travel through the same exchange as
+// a level's exact scores (the k-th largest of the union of all shards' values bounds the global k-th best);
+// theta = the smallest of them = this shard's own bound.
+__global__ void __launch_bounds__(256) filter_bound_scores_kernel(FilterThr t, int64_t B, float* __restrict__ scores,
+                                                                  float* __restrict__ theta) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= B) return;
+  const float eps = filter_eps(t, q);
+  float v[32];
+#pragma unroll 1
+  for (int g = 0; g < t.ngroups; ++g) {  // insertion sort, k <= 32
+    const float x = __fsub_rn(ord2f(t.gmax[q * t.ngroups + g]), eps);
+    int pos = g;
+    while (pos > 0 && v[pos - 1] < x) {
+      v[pos] = v[pos - 1];
+      --pos;
+    }
+    v[pos] = x;
+  }
+  for (int g = 0; g < t.ngroups; ++g) scores[q * t.ngroups + g] = v[g];
+  theta[q] = v[t.ngroups - 1];
+}
+
 // Sharded banks, after a level: theta[b] = max(theta[b], k-th largest of the union of every shard's best m exact scores
 // of query b) -- the k-th largest of a SUBSET of all scores is a lower bound of the k-th largest of all.  `gathered` is the
 // all_gather's [G, B, m] layout as it stands; G m <= 64: one wave per query, lane l holds one score and ranks it by
@@ -1570,12 +1594,20 @@ static int run_rescore(const FilterWs& f, const float* Kn, int64_t N, int64_t B,
 template <int D>
 static int run_filtered(const float* Q, int64_t B, const float* Kn, const float* Kp, const uint16_t* Kb, int64_t N, int k,
                         int64_t idx_base, float* out_scores, int64_t* out_idx, int* overflow, int64_t* overflow_idx,
-                        void* ws, void* stream, int64_t plan_N, float* theta, ragraph_exchange_fn exchange, void* ctx) {
+                        void* ws, void* stream, int64_t plan_N, float* theta, ragraph_exchange_fn exchange, void* ctx,
+                        int n_shards) {
   hipStream_t st = as_stream(stream);
   const int cap = filter_cap(B, k);
   FilterSchedule sc = filter_schedule(B, plan_N, D, k);  // (sharded banks: the same schedule on every shard)
   sc.ends[sc.nlev - 1] = N;
   if (sc.bound_keys > N / 2) sc.bound_keys = 0, sc.n0 = sc.n0 < N ? sc.n0 : N;
+  if (exchange && n_shards > 1 && sc.bound_keys > 0) {
+    // G shards pool their samples through the exchange (the k-th largest of the union of every shard's best group
+    // maxima): each scans 1/G of the prefix one bank would -- at least one stage per part
+    const int64_t min_keys = filter_round_up((int64_t)k * (FILTER_STAGE_BYTES / (2 * D)));
+    int64_t bk = filter_round_up(sc.bound_keys / n_shards);
+    sc.bound_keys = bk < min_keys ? (min_keys < sc.bound_keys ? min_keys : sc.bound_keys) : bk;
+  }
   static const int ablate = [] {  // RAGRAPH_FILTER_ABLATE=1: no key passes the filter (timing only, results invalid)
     const char* e = getenv("RAGRAPH_FILTER_ABLATE");
     return e ? atoi(e) : 0;
@@ -1620,10 +1652,13 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
                                       stream);
   }
   if (rc != RAGRAPH_OK) return rc;
-  if (exchange) {  // the first bound leaves through theta, and comes back as a bound on the k-th best of ALL shards
+  if (exchange) {  // the first bound leaves through theta / out_scores, and comes back as a bound on the k-th best of ALL shards
     thr.gmax = bound ? f.gmax : nullptr;
     thr.prev_scores = out_scores;
-    hipLaunchKernelGGL(filter_theta_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, thr, B, 1, theta);
+    if (bound)  // k lower bounds of distinct keys' exact scores, descending, where a level leaves its exact top-k
+      hipLaunchKernelGGL(filter_bound_scores_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, thr, B, out_scores, theta);
+    else
+      hipLaunchKernelGGL(filter_theta_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, thr, B, 1, theta);
     RG_CHECK_LAUNCH("topk_cosine_filtered(theta)");
     exchange(ctx, 0);
     thr.theta = theta;
@@ -1661,8 +1696,9 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
 static int filtered_entry(const float* Q, int64_t B, const float* Kn, const float* Kp, const uint16_t* Kb, int64_t N, int D,
                           int k, int64_t idx_base, float* out_scores, int64_t* out_idx, int* overflow, int64_t* overflow_idx,
                           void* ws, size_t ws_bytes, void* stream, int64_t plan_N, float* theta, ragraph_exchange_fn exchange,
-                          void* ctx) {
+                          void* ctx, int n_shards) {
   RG_REQUIRE(Q && Kn && Kb && out_scores && out_idx && overflow && ws, RAGRAPH_EINVAL, "topk_cosine_filtered: null pointer");
+  RG_REQUIRE(n_shards >= 1, RAGRAPH_EINVAL, "topk_cosine_filtered: n_shards=%d", n_shards);
   RG_REQUIRE(filter_dim_ok(D), RAGRAPH_EUNSUPPORTED, "topk_cosine_filtered: D=%d not in {64,128,256}", D);
   RG_REQUIRE(B >= 1 && N >= 1 && k >= 1 && k <= 32 && k <= N, RAGRAPH_EINVAL, "topk_cosine_filtered: bad B/N/k");
   RG_REQUIRE(N < (int64_t)INT_MAX - 1024, RAGRAPH_EUNSUPPORTED, "topk_cosine_filtered: shard rows must fit int32");
@@ -1674,12 +1710,12 @@ static int filtered_entry(const float* Q, int64_t B, const float* Kn, const floa
   RG_REQUIRE(ws_bytes >= need, RAGRAPH_EWORKSPACE, "topk_cosine_filtered: workspace %zu < %zu", ws_bytes, need);
   if (D == 256)
     return run_filtered<256>(Q, B, Kn, Kp, Kb, N, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, stream, plan_N,
-                             theta, exchange, ctx);
+                             theta, exchange, ctx, n_shards);
   if (D == 128)
     return run_filtered<128>(Q, B, Kn, Kp, Kb, N, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, stream, plan_N,
-                             theta, exchange, ctx);
+                             theta, exchange, ctx, n_shards);
   return run_filtered<64>(Q, B, Kn, Kp, Kb, N, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, stream, plan_N,
-                          theta, exchange, ctx);
+                          theta, exchange, ctx, n_shards);
 }
 
 extern "C" int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const float* Kn, const float* Kp,
@@ -1687,7 +1723,7 @@ extern "C" int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const
                                                 float* out_scores, int64_t* out_idx, int* overflow,
                                                 int64_t* overflow_idx, void* ws, size_t ws_bytes, void* stream) {
   return filtered_entry(Q, B, Kn, Kp, Kb, N, D, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, ws_bytes, stream,
-                        N, nullptr, nullptr, nullptr);
+                        N, nullptr, nullptr, nullptr, 1);
 }
 
 extern "C" int ragraph_topk_cosine_filtered_sharded_f32(const float* Q, int64_t B, const float* Kn, const float* Kp,
@@ -1695,9 +1731,9 @@ extern "C" int ragraph_topk_cosine_filtered_sharded_f32(const float* Q, int64_t 
                                                         float* out_scores, int64_t* out_idx, int* overflow,
                                                         int64_t* overflow_idx, void* ws, size_t ws_bytes, void* stream,
                                                         int64_t plan_N, float* theta, ragraph_exchange_fn exchange,
-                                                        void* ctx) {
+                                                        void* ctx, int n_shards) {
   return filtered_entry(Q, B, Kn, Kp, Kb, N, D, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, ws_bytes, stream,
-                        plan_N, theta, exchange, ctx);
+                        plan_N, theta, exchange, ctx, n_shards);
 }
 
 extern "C" int ragraph_theta_sharpen_f32(const float* gathered, int G, int64_t B, int m, int k, float* theta, void* stream) {

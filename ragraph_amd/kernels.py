@@ -170,8 +170,11 @@ def topk_cosine_filtered(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf
     Row-sharded banks: `exchange(phase, theta, scores)` is called between the phases of the call
     (ragraph_topk_cosine_filtered_sharded_f32) with theta [B] = this shard's lower bound of every query's final k-th
     best score and scores [B,k] = its running top-k; it sharpens theta in place across the shards.  `plan_n` = the
-    largest shard's size (the same schedule, hence the same collectives, on every rank).  The result is then the
-    shard's list of what can still be in the global top-k (padded with -inf / INT64_MAX), to be merged by topk_merge."""
+    largest shard's size (the same schedule, hence the same collectives, on every rank).  At phase 0 `scores` holds k
+    lower bounds of distinct keys' exact scores (the bound pass's group maxima minus eps, or an exact level 0's top-k):
+    an exchange that pools them across the shards announces the shard count as `exchange.n_shards` (default 1), and
+    every shard then scans 1 / n_shards of the first sample.  The result is then the shard's list of what can still be
+    in the global top-k (padded with -inf / INT64_MAX), to be merged by topk_merge."""
     L = _ready()
     q = _f32c(q, "topk_cosine_filtered.q")
     kn = _f32c(keys_normalized, "topk_cosine_filtered.keys")
@@ -212,7 +215,7 @@ def topk_cosine_filtered(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf
     rc = L.ragraph_topk_cosine_filtered_sharded_f32(q.data_ptr(), B, kn.data_ptr(), kp, keys_bf16.data_ptr(), Nk, D, k,
                                                     idx_base, scores.data_ptr(), idx.data_ptr(), overflow.data_ptr(), None,
                                                     ws.data_ptr(), ws.numel(), _stream(), max(plan_n, Nk),
-                                                    theta.data_ptr(), cb, None)
+                                                    theta.data_ptr(), cb, None, int(getattr(exchange, "n_shards", 1)))
     if errors:
         raise errors[0]
     N.check(rc, "topk_cosine_filtered(sharded)")

@@ -91,6 +91,12 @@ class ShardedToyGraphBase:
         self._index = KeyIndex(self.keys_normalized, ops)
         self.emulate_world = int(emulate_world)
         self._out_shard = None
+
+        def exchange_fn(phase, theta, scores):
+            return self._exchange(phase, theta, scores)
+
+        exchange_fn.n_shards = self.emulate_world if self.emulate_world > 1 else self.world
+        self._exchange_fn = exchange_fn
         n_local = int(keys.shape[0])
         if plan_n:
             self.plan_n = int(plan_n)
@@ -104,18 +110,16 @@ class ShardedToyGraphBase:
     # ---- the exchanges of a filtered retrieval over the sharded bank (kernels.topk_cosine_filtered) ---------------------
     def _exchange(self, phase: int, theta, scores):
         """theta [B]: this shard's lower bound of every query's final k-th best score -> a bound over ALL shards.
-        phase 0 (first bound): the best shard's bound holds globally: all_reduce(MAX), 4 B per query.
-        phase 1 + l (after level l): the k-th largest of the union of every shard's best m = 2 ceil(k / G) exact scores
-        is a lower bound of the global k-th best (k-th of a subset): one all_gather of [B, m] scores, 4 m B per query
-        and rank, + a k-th selection over [B, G m] (topk_rows)."""
+        Every phase alike: `scores` [B, k] holds (descending) lower bounds of the exact scores of k distinct keys of this
+        shard -- after the bound pass the parts' best approximate scores minus eps, after a level the running exact
+        top-k -- and the k-th largest of the union of every shard's best m = 2 ceil(k / G) of them is a lower bound of
+        the global k-th best (k-th of a subset): one all_gather of [B, m] scores, 4 m B per query and rank, + a k-th
+        selection over [B, G m] (theta_sharpen).  Because phase 0 pools the shards' samples, each shard scans only 1 / G
+        of the prefix (n_shards below)."""
         G = self.emulate_world if self.emulate_world > 1 else self.world
         if G <= 1 and not self.collective:
             return
         k = scores.shape[1]
-        if phase == 0:
-            if self.collective:
-                dist.all_reduce(theta, op=dist.ReduceOp.MAX, group=self.group)
-            return
         m = min(k, 2 * (-(-k // G)))
         while G * m > 64 and m > -(-k // G):
             m -= 1
@@ -135,7 +139,7 @@ class ShardedToyGraphBase:
         n_local = self.keys_normalized.shape[0]
         kl = min(k, n_local)
         sharded = self.collective or self.emulate_world > 1
-        s, i = self._index.topk(q, kl, idx_base=self.idx_base, exchange=self._exchange if sharded and kl == k else None,
+        s, i = self._index.topk(q, kl, idx_base=self.idx_base, exchange=self._exchange_fn if sharded and kl == k else None,
                                 plan_n=self.plan_n)
         if kl < k:  # a shard smaller than k: pad with sentinels that lose every comparison
             pad_s = torch.full((q.shape[0], k - kl), float("-inf"), dtype=s.dtype, device=s.device)
@@ -176,7 +180,7 @@ class ShardedToyGraphBase:
         if not sharded or min(k, n_local) < k:
             s, i = self.topk(q, k)
             return s[lo:hi].contiguous(), i[lo:hi].contiguous()
-        s, i = self._index.topk(q, k, idx_base=self.idx_base, exchange=self._exchange, plan_n=self.plan_n)
+        s, i = self._index.topk(q, k, idx_base=self.idx_base, exchange=self._exchange_fn, plan_n=self.plan_n)
         if self.emulate_world > 1:  # (timing only) the merge a real rank runs over the G lists of its rows
             G = self.emulate_world
             ss, ii = s[lo:hi], i[lo:hi]

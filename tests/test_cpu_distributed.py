@@ -86,6 +86,8 @@ class FilteredOracleOps(OracleOps):
         n0 = min(n, max(k, n // 8))
         theta = torch.from_numpy(np.sort(S[:, :n0], axis=1)[:, ::-1][:, k - 1].copy() if n0 >= k else np.full(B, ninf, np.float32))
         scores = torch.full((B, k), float("-inf"))
+        if n0 >= k:  # phase 0: k lower bounds of distinct keys' exact scores (here: the sample's exact top-k)
+            scores.copy_(torch.from_numpy(np.sort(S[:, :n0], axis=1)[:, ::-1][:, :k].copy()))
         if exchange is not None:
             exchange(0, theta, scores)
         e1 = n // 2

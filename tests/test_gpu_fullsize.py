@@ -175,11 +175,12 @@ def test_filtered_topk_beyond_2gib_of_bf16_keys(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("G,B", [(2, 3000), (4, 20000), (3, 200)])
-def test_sharded_filtered_exchange_matches_single_gpu(dev, G, B):
+@pytest.mark.parametrize("G,B,pool", [(2, 3000, True), (4, 20000, True), (3, 200, True), (4, 3000, False)])
+def test_sharded_filtered_exchange_matches_single_gpu(dev, G, B, pool):
     """ragraph_topk_cosine_filtered_sharded_f32 on G row shards of a 1M x 256 bank, one host thread and one stream per
     shard on this one GPU, the per-phase exchanges done through a thread barrier exactly as ShardedToyGraphBase does
-    them with RCCL (all_reduce MAX of the first bound, k-th of the union of every shard's best m scores per level):
+    them with RCCL (k-th of the union of every shard's best m values at every phase; pool = False: the weaker contract
+    of the header -- all_reduce MAX of the first bound, n_shards = 1, every shard scanning the whole first sample):
     merged lists == the unsharded call, bit for bit; and the shards' candidate work shrinks (lists padded with -inf)."""
     import threading
 
@@ -207,15 +208,16 @@ def test_sharded_filtered_exchange_matches_single_gpu(dev, G, B):
         def exchange(phase, theta, scores):
             phases.append(phase)
             torch.cuda.current_stream().synchronize()          # this shard's numbers are final
-            slots[r] = theta.clone() if phase == 0 else scores[:, :m].clone()
+            slots[r] = theta.clone() if (phase == 0 and not pool) else scores[:, :m].clone()
             torch.cuda.current_stream().synchronize()
             barrier.wait()
-            if phase == 0:
+            if phase == 0 and not pool:
                 theta.copy_(torch.stack(slots).max(dim=0).values)
             else:
                 K.theta_sharpen(torch.stack(slots).contiguous(), theta, k)   # [G, B, m], as an all_gather leaves it
             torch.cuda.current_stream().synchronize()
             barrier.wait()
+        exchange.n_shards = G if pool else 1
         return exchange
 
     def run(r):
