@@ -391,6 +391,9 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
 #pragma unroll
     for (int gq = 0; gq < NG; ++gq) asm volatile("" : "+v"(thr[gq]));
+    int thr_i[NG];
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) thr_i[gq] = thr[gq] >= 0.f ? __float_as_int(thr[gq]) : INT_MIN;
 
     // ---- ring prologue ------------------------------------------------------------------------------------------
     const int pro = nstages < C::SLOTS - 1 ? nstages : C::SLOTS - 1;
@@ -456,21 +459,36 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
         }
       };
       auto epilogue = [&](int u, const f32x4 (&a)[2][NG]) {
+        // Filter levels test "does any of the lane's 8 scores reach the threshold" on the scores' BIT PATTERNS as signed
+        // integers: for a threshold >= +0 that is the float comparison (negative scores are negative integers, the MFMA
+        // never produces -0 or NaN from finite operands), v_max3_i32 needs none of the canonicalising v_max x, x that
+        // fmaxf puts in front of accumulator values, and a false positive would only send the sub-tile through the exact
+        // float masks below.  (thr_i = INT_MIN for a negative threshold: always the exact path.)
         float m[NG];
-#pragma unroll
-        for (int gq = 0; gq < NG; ++gq) {  // (a chain, not a tree: hipcc folds it into v_max3_f32 -- 4 instructions, not 7)
-          m[gq] = a[0][gq][0];
-#pragma unroll
-          for (int r = 1; r < 4; ++r) m[gq] = fmaxf(m[gq], a[0][gq][r]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) m[gq] = fmaxf(m[gq], a[1][gq][r]);
-        }
+        int mi[NG];
         bool hit = false;
-#pragma unroll
-        for (int gq = 0; gq < NG; ++gq) hit = hit || (m[gq] >= thr[gq]);
         if constexpr (BOUND) {
 #pragma unroll
-          for (int gq = 0; gq < NG; ++gq) gm[gq] = fmaxf(gm[gq], m[gq]);
+          for (int gq = 0; gq < NG; ++gq) {  // (a chain, not a tree: hipcc folds it into v_max3_f32 -- 4 instructions, not 7)
+            m[gq] = a[0][gq][0];
+#pragma unroll
+            for (int r = 1; r < 4; ++r) m[gq] = fmaxf(m[gq], a[0][gq][r]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m[gq] = fmaxf(m[gq], a[1][gq][r]);
+            gm[gq] = fmaxf(gm[gq], m[gq]);
+          }
+        } else {
+#pragma unroll
+          for (int gq = 0; gq < NG; ++gq) {
+            mi[gq] = __float_as_int(a[0][gq][0]);
+#pragma unroll
+            for (int r = 1; r < 4; ++r) mi[gq] = max(mi[gq], __float_as_int(a[0][gq][r]));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mi[gq] = max(mi[gq], __float_as_int(a[1][gq][r]));
+            hit = hit || (mi[gq] >= thr_i[gq]);
+          }
+        }
+        if constexpr (BOUND) {
         } else if (__any(hit)) {
           const int stage_key0 = (int)((p.stage_base + st0 + s) * C::STAGE_KEYS);
           const int key_base = stage_key0 + 32 * u + 4 * g;  // the lane's keys: key_base + r + 16 h  (mask bit 4 h + r)
@@ -480,7 +498,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
 #pragma unroll
           for (int gq = 0; gq < NG; ++gq) {
             km[gq] = 0;
-            if (__any(m[gq] >= thr[gq])) km[gq] = pass_mask(a, gq, thr[gq]);
+            if (__any(mi[gq] >= thr_i[gq])) km[gq] = pass_mask(a, gq, thr[gq]);
           }
           if (stage_key0 + C::STAGE_KEYS > (int)p.N) {  // the range's last stage: keys >= N (padding, or the next level's)
             unsigned vm = 0;
