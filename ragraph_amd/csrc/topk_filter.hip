@@ -624,6 +624,44 @@ __device__ __forceinline__ void wave_select(const float (&s)[NSL], const int (&i
     khi[u] = empty ? 0u : select_ord(s[u]);
     klo[u] = empty ? 0u : ~(unsigned)id[u];
   }
+  if constexpr (NSL <= 2) {
+    // Up to 128 pairs: RANK BY COUNTING instead of k rounds.  Every key is broadcast once (v_readlane, a wave-uniform
+    // value) and each lane counts the keys greater than its own: 64 NSL x NSL 64-bit compares, ~1 us at NSL = 2 whatever
+    // k is, where the rounds take ~0.35 us each.  A pair with rank r < k is winner r.  Distinct non-empty pairs have
+    // distinct keys (a key index enters a query's lists once per call), so ranks are unique; empty slots (key 0) fill
+    // the places behind the last real pair.
+    unsigned long long mine[NSL];
+    int rank[NSL];
+    int n_real = 0;
+#pragma unroll
+    for (int u = 0; u < NSL; ++u) {
+      mine[u] = ((unsigned long long)khi[u] << 32) | klo[u];
+      rank[u] = 0;
+      n_real += __popcll(__ballot(mine[u] != 0ull));
+    }
+#pragma unroll
+    for (int v = 0; v < NSL; ++v) {
+#pragma unroll 8
+      for (int o = 0; o < 64; ++o) {
+        const unsigned long long src = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)khi[v], o) << 32) |
+                                       (unsigned)__builtin_amdgcn_readlane((int)klo[v], o);
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) rank[u] += src > mine[u] ? 1 : 0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NSL; ++u) {
+      if (mine[u] != 0ull && rank[u] < k) {
+        out_s[rank[u]] = select_unord(khi[u]);
+        out_i[rank[u]] = (int64_t)(int)~klo[u] + base;
+      }
+    }
+    if (lane < k && lane >= n_real) {
+      out_s[lane] = RG_NEG_INF;
+      out_i[lane] = INT64_MAX;
+    }
+    return;
+  }
   unsigned my_hi = 0u, my_lo = 0u;  // lane r: the r-th winner
   for (int r = 0; r < k; ++r) {
     unsigned bh = khi[0], bl = klo[0];
@@ -1118,24 +1156,32 @@ __global__ void __launch_bounds__(256) topk_rescore_wide_kernel(const float* __r
     }
     if (w != 0) return;
     if (lane == 0 && over_q) flag[b] = 1;
-    float s[5];
-    int id[5];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {  // (the other workgroups' stores: read past this CU's and XCD's caches)
-      const int e = lane + 64 * u;
-      const bool have = e < S * k;
-      s[u] = have ? __hip_atomic_load(part_s + b * S * k + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : RG_NEG_INF;
-      id[u] = have ? __hip_atomic_load(part_i + b * S * k + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INT_MAX;
-    }
-    s[4] = RG_NEG_INF;
-    id[4] = INT_MAX;
-    if (prev_s && lane < k) {
-      s[4] = prev_s[b * k + lane];
-      const int64_t pv = prev_i[b * k + lane];
-      id[4] = pv >= INT_MAX ? INT_MAX : (int)pv;
-    }
+    auto part_entry = [&](int e, float& sv, int& iv) {  // entries [0, S k): the slices' winners; [S k, S k + k): the previous level's
+      sv = RG_NEG_INF;
+      iv = INT_MAX;
+      if (e < S * k) {  // (the other workgroups' stores: read past this CU's and XCD's caches)
+        sv = __hip_atomic_load(part_s + b * S * k + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        iv = __hip_atomic_load(part_i + b * S * k + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (prev_s && e < S * k + k) {
+        sv = prev_s[b * k + e - S * k];
+        const int64_t pv = prev_i[b * k + e - S * k];
+        iv = pv >= INT_MAX ? INT_MAX : (int)pv;
+      }
+    };
     RG_WSTAMP(8);
-    wave_select<5>(s, id, k, lane, final_level ? idx_base : 0, out_s + b * k, out_i + b * k);
+    if (S * k + k <= 128) {  // (wave-uniform) two slots per lane: the rank-by-counting selection
+      float s[2];
+      int id[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) part_entry(lane + 64 * u, s[u], id[u]);
+      wave_select<2>(s, id, k, lane, final_level ? idx_base : 0, out_s + b * k, out_i + b * k);
+    } else {
+      float s[5];
+      int id[5];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) part_entry(lane + 64 * u, s[u], id[u]);
+      wave_select<5>(s, id, k, lane, final_level ? idx_base : 0, out_s + b * k, out_i + b * k);
+    }
     RG_WSTAMP(9);
   }
 }
