@@ -80,14 +80,14 @@ __device__ __forceinline__ float filter_threshold(const FilterThr& t, int64_t q)
   return __fsub_rn(theta, eps);
 }
 
-// Candidate counters of a call of up to 256 queries.  A returning atomicAdd costs ~11 ns per operation on ONE address
+// Candidate counters of a call of fewer than 2048 queries.  A returning atomicAdd costs ~11 ns per operation on ONE address
 // and ~1.8 ns on one 128-byte line chip-wide (tools/microbench/atomic_contention_bench.hip): 16 queries x 800
 // candidates on sixteen neighbouring ints were 25 us of serialised atomics behind a 75 us stream.  So every query's
 // counters sit on their own line (FILTER_COUNT_STRIDE ints apart), and a query of a very small batch -- whose list the
 // sliced rescoring cuts into S parts anyway -- gets S sub-lists with a counter each, the waves spread over them.
 constexpr int FILTER_COUNT_STRIDE = 32;
 constexpr int FILTER_TICKET_SLOT = 16;  // int of a query's line that counts its finished rescoring workgroups
-__host__ __device__ constexpr int filter_count_stride(int64_t B) { return B <= 256 ? FILTER_COUNT_STRIDE : 1; }
+__host__ __device__ constexpr int filter_count_stride(int64_t B) { return B < 2048 ? FILTER_COUNT_STRIDE : 1; }
 
 // One filter launch of the direct kernel (topk_filter_direct.hip): up to 256 queries against keys [key0, key1) of the
 // bf16 copy (key0 a multiple of 32).  bound_groups > 0: the BOUND pass -- no thresholds, no candidates, the launch

@@ -63,7 +63,8 @@ struct FilterParams {
   const float* Qn;        // [B,D] normalised queries (fp32)
   const uint16_t* Kb;     // bf16 keys in MFMA fragment order (filter_common.h), rows >= N zero
   FilterThr thr;          // how a query's pass threshold theta[q] - eps(q) is obtained (filter_common.h)
-  int* count;             // [B] candidate slots reserved so far
+  int* count;             // [B][cstride] candidate slots reserved so far (filter_count_stride)
+  int cstride;
   int* cand;              // [B,cap] candidate key indices (local to this shard)
   int64_t B, N;           // N = end of the key range (keys >= N never pass)
   int cap;
@@ -371,7 +372,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
           const int64_t q = q_wave + (e.x >> 25);
           const int key0 = key_org + (int)(e.x & 0x1FFFFFFu);
           unsigned mk = e.y;
-          int slot = atomicAdd(p.count + q, __popc(mk));
+          int slot = atomicAdd(p.count + q * p.cstride, __popc(mk));
           // retired here on every path: a return hipcc still considers pending where the flush rejoins the stage loop
           // would put its vmcnt(0) -- which also drains the DMA ring -- in front of every sub-tile
           asm volatile("s_waitcnt vmcnt(0)" : "+v"(slot) : : "memory");
@@ -860,7 +861,7 @@ __device__ __forceinline__ void rescore_query(const float4* __restrict__ qrow, c
 template <int D, int CPL>
 __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restrict__ Qn, const float* __restrict__ Kn,
                                                            int* __restrict__ count, const int* __restrict__ cand,
-                                                           int64_t B, int cap, int k, int64_t idx_base,
+                                                           int64_t B, int cap, int cs, int k, int64_t idx_base,
                                                            const float* prev_s, const int64_t* prev_i, int final_level,
                                                            float* out_s, int64_t* out_i, int* __restrict__ overflow,
                                                            int* __restrict__ overflow_list,
@@ -871,9 +872,9 @@ __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restri
   if (b >= B) return;  // whole wave
   if (lane < D / 4) qs[w][lane] = reinterpret_cast<const float4*>(Qn + b * D)[lane];  // the query row
   __builtin_amdgcn_wave_barrier();
-  int n = count[b];
+  int n = count[b * cs];
   bool over = flag[b] != 0;
-  if (lane == 0 && n >= 0) count[b] = 0;  // the next level starts from an empty list (ordered behind the read through n)
+  if (lane == 0 && n >= 0) count[b * cs] = 0;  // the next level starts from an empty list (ordered behind the read through n)
   if (n > cap) {  // slots reserved beyond the capacity: candidates were dropped
     over = true;
     n = cap;
@@ -909,7 +910,7 @@ __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restri
 template <int D, int CPL, bool FEWTILE = false>
 __global__ void __launch_bounds__(128) topk_rescore_coop_kernel(const float* __restrict__ Qn, const float* __restrict__ Kn,
                                                                 int* __restrict__ count,
-                                                                const int* __restrict__ cand, int64_t B, int cap, int k,
+                                                                const int* __restrict__ cand, int64_t B, int cap, int cs, int k,
                                                                 int64_t idx_base, const float* prev_s,
                                                                 const int64_t* prev_i, int final_level, float* out_s,
                                                                 int64_t* out_i, int* __restrict__ overflow,
@@ -921,13 +922,13 @@ __global__ void __launch_bounds__(128) topk_rescore_coop_kernel(const float* __r
   const int64_t b = (int64_t)blockIdx.x * 2 + w;
   if (b >= B) return;  // whole wave
   // (the count, the flag and the query row are independent loads: issued together, one latency)
-  int n = count[b];
+  int n = count[b * cs];
   bool over = flag[b] != 0;
   float4 qv4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (lane < D / 4) qv4 = reinterpret_cast<const float4*>(Qn + b * D)[lane];
   if (lane < D / 4) qs[w][lane] = qv4;
   __builtin_amdgcn_wave_barrier();
-  if (lane == 0 && n >= 0) count[b] = 0;  // the next level starts from an empty list (ordered behind the read through n)
+  if (lane == 0 && n >= 0) count[b * cs] = 0;  // the next level starts from an empty list (ordered behind the read through n)
   if (n > cap) {
     over = true;
     n = cap;
@@ -1582,6 +1583,7 @@ static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64
   p.Kb = Kb;
   p.thr = thr;
   p.count = f.count;
+  p.cstride = filter_count_stride(B);
   p.cand = f.cand;
   p.gmax = bound_groups > 0 ? f.gmax : nullptr;
   p.ngroups = bound_groups;
@@ -1644,13 +1646,13 @@ static int run_rescore(const FilterWs& f, const float* Kn, int64_t N, int64_t B,
                        (float*)nullptr, (int*)nullptr);
   else if (rescore_coop() && few)
     hipLaunchKernelGGL((topk_rescore_coop_kernel<D, 32, true>), dim3((unsigned)cdiv(B, 2)), dim3(128), 0, st, f.Qn, Kn, f.count,
-                       f.cand, B, cap, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag);
+                       f.cand, B, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag);
   else if (rescore_coop())
     hipLaunchKernelGGL((topk_rescore_coop_kernel<D, 32>), dim3((unsigned)cdiv(B, 2)), dim3(128), 0, st, f.Qn, Kn, f.count,
-                       f.cand, B, cap, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag);
+                       f.cand, B, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag);
   else
     hipLaunchKernelGGL((topk_rescore_kernel<D, 32>), dim3((unsigned)cdiv(B, 4)), dim3(256), 0, st, f.Qn, Kn, f.count, f.cand,
-                       B, cap, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag);
+                       B, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag);
   RG_CHECK_LAUNCH("topk_cosine_filtered(rescore)");
   return RAGRAPH_OK;
 }
