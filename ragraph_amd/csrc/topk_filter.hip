@@ -362,6 +362,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     // key_org moves up (after a flush) every 2^16 stages so that offsets stay inside 26 bits.
     uint2* wbuf = reinterpret_cast<uint2*>(smem + C::SLOTS * C::STAGE_BYTES + 64) + wave * C::CAND_BUF;
     const int64_t q_wave = qtile * QT + wave * QW;
+    const bool wave_live = q_wave < p.B;  // (wave-uniform)
     int wcnt = 0;  // wave-uniform
     int key_org = (int)((p.stage_base + st0) * C::STAGE_KEYS);
     auto flush = [&]() {
@@ -545,11 +546,15 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
   }
 #define RG_FSTEP8(n_) RG_FSTEP(n_) RG_FSTEP((n_) + 1) RG_FSTEP((n_) + 2) RG_FSTEP((n_) + 3) \
     RG_FSTEP((n_) + 4) RG_FSTEP((n_) + 5) RG_FSTEP((n_) + 6) RG_FSTEP((n_) + 7)
-      RG_FREAD(0);
-      RG_FREAD(1);
-      RG_FREAD(2);
-      RG_FREAD(3);
-      RG_FSTEP8(0) RG_FSTEP8(8) RG_FSTEP8(16) RG_FSTEP8(24)
+      // (a wave whose 64 queries all lie beyond the batch -- the tail of a ragged last tile: 300 queries fill 4.7 of a
+      // tile's 8 waves -- only takes part in the ring: no fragment reads, no MFMAs, the SIMD to its partner)
+      if (wave_live) {
+        RG_FREAD(0);
+        RG_FREAD(1);
+        RG_FREAD(2);
+        RG_FREAD(3);
+        RG_FSTEP8(0) RG_FSTEP8(8) RG_FSTEP8(16) RG_FSTEP8(24)
+      }
 #undef RG_FSTEP8
 #undef RG_FSTEP
 #undef RG_FWAIT
