@@ -304,6 +304,13 @@ int ragraph_topk_rows_f32(const float* S, int64_t B, int64_t N, int64_t ld, int 
  * Exact radix select + ordered compaction, one workgroup per row, deterministic. */
 int ragraph_topk_select_rows_f32(const float* S, int64_t B, int64_t N, int64_t ld, int64_t k, float* out_kth,
                                  int64_t* out_idx, void* stream);
+/* The same with a workspace (ragraph_topk_select_rows_workspace_bytes(B, N)): rows of >= 65536 scores are cut into chunks
+ * of 16384 and every pass of the selection is a launch over (chunk, row) -- integer histograms, a prefix over the chunks,
+ * ordered compaction per chunk -- instead of one workgroup walking a 4 M-score row five times alone (64 x 4 M: 41 -> ~2 ms).
+ * Same result, bit for bit.  B <= 65535 rows per call.  ws = NULL or short rows: ragraph_topk_select_rows_f32. */
+size_t ragraph_topk_select_rows_workspace_bytes(int64_t B, int64_t N);
+int ragraph_topk_select_rows_ws_f32(const float* S, int64_t B, int64_t N, int64_t ld, int64_t k, float* out_kth,
+                                    int64_t* out_idx, void* ws, size_t ws_bytes, void* stream);
 
 /* batch_pred[i, pos_list] = value  -- RAGraph_edge/utils/metrics.py:210-214 (_mask_history_pos, value = -1e8).
  * CSR (rowptr [B+1], col [nnz], both int64) lists the columns to overwrite in each row of S [B, ld]. */

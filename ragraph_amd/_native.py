@@ -68,6 +68,8 @@ SIGNATURES = {
     "ragraph_time_rescale_f32": (_i32, [_vp, _i64, _f32, _f32, _vp, _vp]),
     "ragraph_topk_rows_f32": (_i32, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp]),
     "ragraph_topk_select_rows_f32": (_i32, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "ragraph_topk_select_rows_workspace_bytes": (_sz, [_i64, _i64]),
+    "ragraph_topk_select_rows_ws_f32": (_i32, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "ragraph_scatter_fill_f32": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _f32, _vp]),
     "ragraph_floyd_warshall_f32": (_i32, [_vp, _i32, _vp, _vp]),
     "ragraph_position_code_f32": (_i32, [_vp, _i32, _vp, _i32, _f32, _vp, _vp]),

@@ -238,6 +238,180 @@ __global__ void __launch_bounds__(256) topk_select_rows_kernel(const float* __re
   }
 }
 
+// ---- the same selection for LONG rows (N >= SELECT_CHUNK * 4), with a workspace: one workgroup per row walks 4 M
+// scores five times alone (41 ms for 64 rows of a 4 M-key bank: 64 of 256 CUs busy, and 15 000 barrier rounds of
+// compaction each).  Here a row is cut into chunks of SELECT_CHUNK scores and every pass is a launch over (chunk, row):
+//   4 x { select_hist: LDS histogram of the chunk's keys that match the prefix found so far, integer atomicAdd into the
+//         row's 256 global bins (exact whatever the order);  select_pick: the digit that holds the k-th largest }
+//   select_count: per chunk, how many keys are above / equal to the k-th largest
+//   select_scan:  exclusive prefix over the chunks -> every chunk's first output position and its share of the ties
+//   select_compact: every chunk writes its winners in ascending index order at its offset.
+// Same result as topk_select_rows_kernel, bit for bit (the canonical set, ascending indices).
+constexpr int SELECT_CHUNK = 16384;
+
+struct SelectState {  // per row
+  unsigned prefix, mask, need, kth_key;
+};
+
+__global__ void __launch_bounds__(256) select_init_kernel(SelectState* __restrict__ st, unsigned* __restrict__ hist, int64_t B,
+                                                          int64_t k) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < B) st[i] = SelectState{0u, 0u, (unsigned)k, 0u};
+  if (i < B * 256) hist[i] = 0u;
+}
+
+__global__ void __launch_bounds__(256) select_hist_kernel(const float* __restrict__ S, int64_t N, int64_t ld, int shift,
+                                                          const SelectState* __restrict__ st, unsigned* __restrict__ hist) {
+  __shared__ unsigned h[256];
+  const int tid = threadIdx.x;
+  const int64_t b = blockIdx.y;
+  const unsigned prefix = st[b].prefix, mask = st[b].mask;
+  h[tid] = 0;
+  __syncthreads();
+  const float* row = S + b * ld;
+  const int64_t e0 = (int64_t)blockIdx.x * SELECT_CHUNK;
+  const int64_t e1 = e0 + SELECT_CHUNK < N ? e0 + SELECT_CHUNK : N;
+  for (int64_t e = e0 + tid; e < e1; e += 256) {
+    const unsigned key = select_key(row[e]);
+    if ((key & mask) == prefix) atomicAdd(&h[(key >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  if (h[tid]) atomicAdd(hist + b * 256 + tid, h[tid]);
+}
+
+__global__ void __launch_bounds__(256) select_pick_kernel(SelectState* __restrict__ st, unsigned* __restrict__ hist, int shift) {
+  __shared__ unsigned h[256];
+  const int64_t b = blockIdx.x;
+  h[threadIdx.x] = hist[b * 256 + threadIdx.x];
+  hist[b * 256 + threadIdx.x] = 0u;  // ready for the next pass
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    SelectState s = st[b];
+    unsigned acc = 0;
+    int d = 255;
+    for (; d > 0; --d) {
+      if (acc + h[d] >= s.need) break;
+      acc += h[d];
+    }
+    s.prefix |= (unsigned)d << shift;
+    s.need -= acc;
+    s.mask |= 255u << shift;
+    if (shift == 0) s.kth_key = s.prefix;
+    st[b] = s;
+  }
+}
+
+__global__ void __launch_bounds__(256) select_count_kernel(const float* __restrict__ S, int64_t N, int64_t ld,
+                                                           const SelectState* __restrict__ st, unsigned* __restrict__ counts,
+                                                           int nchunks) {
+  __shared__ unsigned wg[4], we[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t b = blockIdx.y;
+  const unsigned kth = st[b].kth_key;
+  const float* row = S + b * ld;
+  const int64_t e0 = (int64_t)blockIdx.x * SELECT_CHUNK;
+  const int64_t e1 = e0 + SELECT_CHUNK < N ? e0 + SELECT_CHUNK : N;
+  unsigned g = 0, q = 0;
+  for (int64_t e = e0 + tid; e < e1; e += 256) {
+    const unsigned key = select_key(row[e]);
+    g += key > kth;
+    q += key == kth;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    g += __shfl_xor(g, off);
+    q += __shfl_xor(q, off);
+  }
+  if (lane == 0) {
+    wg[wave] = g;
+    we[wave] = q;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    counts[(b * nchunks + blockIdx.x) * 2] = wg[0] + wg[1] + wg[2] + wg[3];
+    counts[(b * nchunks + blockIdx.x) * 2 + 1] = we[0] + we[1] + we[2] + we[3];
+  }
+}
+
+// counts[b][c] = (above, equal) of chunk c  ->  (first output position of the chunk, equals before the chunk)
+__global__ void __launch_bounds__(64) select_scan_kernel(const SelectState* __restrict__ st, unsigned* __restrict__ counts,
+                                                         int nchunks, float* __restrict__ out_kth, int64_t B) {
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const unsigned need = st[b].need, kth_key = st[b].kth_key;
+  out_kth[b] = __uint_as_float((kth_key & 0x80000000u) ? (kth_key & 0x7FFFFFFFu) : ~kth_key);
+  unsigned pos = 0, eq_before = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    unsigned* p = counts + (b * nchunks + c) * 2;
+    const unsigned g = p[0], q = p[1];
+    p[0] = pos;
+    p[1] = eq_before;
+    const unsigned taken_before = eq_before < need ? eq_before : need;
+    const unsigned eq_after = eq_before + q;
+    pos += g + ((eq_after < need ? eq_after : need) - taken_before);
+    eq_before = eq_after;
+  }
+}
+
+__global__ void __launch_bounds__(256) select_compact_kernel(const float* __restrict__ S, int64_t N, int64_t ld, int64_t k,
+                                                             const SelectState* __restrict__ st,
+                                                             const unsigned* __restrict__ counts, int nchunks,
+                                                             int64_t* __restrict__ out_idx) {
+  __shared__ unsigned wsum_gt[4], wsum_eq[4];
+  __shared__ unsigned sh_sel_before, sh_eq_before;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t b = blockIdx.y;
+  const unsigned kth_key = st[b].kth_key, need = st[b].need;
+  const float* row = S + b * ld;
+  int64_t* out = out_idx + b * k;
+  const int64_t c0 = (int64_t)blockIdx.x * SELECT_CHUNK;
+  const int64_t c1 = c0 + SELECT_CHUNK < N ? c0 + SELECT_CHUNK : N;
+  if (tid == 0) {
+    sh_sel_before = counts[(b * nchunks + blockIdx.x) * 2];
+    sh_eq_before = counts[(b * nchunks + blockIdx.x) * 2 + 1];
+  }
+  __syncthreads();
+  for (int64_t e0 = c0; e0 < c1; e0 += 256) {  // (the ordered compaction of topk_select_rows_kernel, from the chunk's offsets)
+    const int64_t e = e0 + tid;
+    bool gt = false, eq = false;
+    if (e < c1) {
+      const unsigned key = select_key(row[e]);
+      gt = key > kth_key;
+      eq = key == kth_key;
+    }
+    const unsigned long long bg = __ballot(gt), be = __ballot(eq);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (lane == 0) {
+      wsum_gt[wave] = (unsigned)__popcll(bg);
+      wsum_eq[wave] = (unsigned)__popcll(be);
+    }
+    __syncthreads();
+    unsigned gt_before = 0, eq_before_w = 0;
+    for (int w = 0; w < wave; ++w) {
+      gt_before += wsum_gt[w];
+      eq_before_w += wsum_eq[w];
+    }
+    const unsigned eq_before_here = sh_eq_before + eq_before_w + (unsigned)__popcll(be & below);
+    const bool sel = gt || (eq && eq_before_here < need);
+    const unsigned eq_taken_before_round = sh_eq_before < need ? sh_eq_before : need;
+    const unsigned eq_taken_before_here = (eq_before_here < need ? eq_before_here : need) - eq_taken_before_round;
+    const unsigned pos = sh_sel_before + gt_before + (unsigned)__popcll(bg & below) + eq_taken_before_here;
+    if (sel) out[pos] = e;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned tg = 0, te = 0;
+      for (int w = 0; w < 4; ++w) {
+        tg += wsum_gt[w];
+        te += wsum_eq[w];
+      }
+      const unsigned eq_after = sh_eq_before + te;
+      sh_sel_before += tg + ((eq_after < need ? eq_after : need) - eq_taken_before_round);
+      sh_eq_before = eq_after;
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void __launch_bounds__(256) scatter_fill_kernel(float* __restrict__ S, int64_t ld,
                                                            const int64_t* __restrict__ rowptr,
                                                            const int64_t* __restrict__ col, float value) {
@@ -303,6 +477,45 @@ extern "C" int ragraph_topk_select_rows_f32(const float* S, int64_t B, int64_t N
   hipLaunchKernelGGL(topk_select_rows_kernel, dim3((unsigned)B), dim3(256), 0, as_stream(stream), S, N, ld, k, out_kth,
                      out_idx);
   RG_CHECK_LAUNCH("topk_select_rows");
+  return RAGRAPH_OK;
+}
+
+extern "C" size_t ragraph_topk_select_rows_workspace_bytes(int64_t B, int64_t N) {
+  if (B < 1 || N < 1) return 0;
+  const int64_t nchunks = cdiv(N, (int64_t)SELECT_CHUNK);
+  return align_up((size_t)B * sizeof(SelectState), 256) + align_up((size_t)B * 256 * sizeof(unsigned), 256) +
+         align_up((size_t)B * nchunks * 2 * sizeof(unsigned), 256);
+}
+
+extern "C" int ragraph_topk_select_rows_ws_f32(const float* S, int64_t B, int64_t N, int64_t ld, int64_t k, float* out_kth,
+                                               int64_t* out_idx, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(S && out_kth && out_idx, RAGRAPH_EINVAL, "topk_select_rows: null pointer");
+  RG_REQUIRE(B >= 0 && N >= 1 && ld >= N, RAGRAPH_EINVAL, "topk_select_rows: bad shape");
+  RG_REQUIRE(k >= 1 && k <= N, RAGRAPH_EINVAL, "topk_select_rows: k=%lld out of range for N=%lld", (long long)k, (long long)N);
+  RG_REQUIRE(N < (int64_t)INT_MAX, RAGRAPH_EUNSUPPORTED, "topk_select_rows: N must fit int32");
+  if (B == 0) return RAGRAPH_OK;
+  const int64_t nchunks = cdiv(N, (int64_t)SELECT_CHUNK);
+  if (!ws || nchunks < 4)  // short rows: one workgroup per row does it all
+    return ragraph_topk_select_rows_f32(S, B, N, ld, k, out_kth, out_idx, stream);
+  RG_REQUIRE(ws_bytes >= ragraph_topk_select_rows_workspace_bytes(B, N), RAGRAPH_EWORKSPACE, "topk_select_rows: workspace too small");
+  RG_REQUIRE(B <= 65535, RAGRAPH_EUNSUPPORTED, "topk_select_rows(ws): B=%lld rows per call", (long long)B);
+  char* w = static_cast<char*>(ws);
+  SelectState* st = reinterpret_cast<SelectState*>(w);
+  w += align_up((size_t)B * sizeof(SelectState), 256);
+  unsigned* hist = reinterpret_cast<unsigned*>(w);
+  w += align_up((size_t)B * 256 * sizeof(unsigned), 256);
+  unsigned* counts = reinterpret_cast<unsigned*>(w);
+  hipStream_t sm = as_stream(stream);
+  const dim3 grid((unsigned)nchunks, (unsigned)B);
+  hipLaunchKernelGGL(select_init_kernel, dim3((unsigned)cdiv(B * 256, 256)), dim3(256), 0, sm, st, hist, B, k);
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    hipLaunchKernelGGL(select_hist_kernel, grid, dim3(256), 0, sm, S, N, ld, shift, st, hist);
+    hipLaunchKernelGGL(select_pick_kernel, dim3((unsigned)B), dim3(256), 0, sm, st, hist, shift);
+  }
+  hipLaunchKernelGGL(select_count_kernel, grid, dim3(256), 0, sm, S, N, ld, st, counts, (int)nchunks);
+  hipLaunchKernelGGL(select_scan_kernel, dim3((unsigned)cdiv(B, 64)), dim3(64), 0, sm, st, counts, (int)nchunks, out_kth, B);
+  hipLaunchKernelGGL(select_compact_kernel, grid, dim3(256), 0, sm, S, N, ld, k, st, counts, (int)nchunks, out_idx);
+  RG_CHECK_LAUNCH("topk_select_rows(ws)");
   return RAGRAPH_OK;
 }
 

@@ -469,6 +469,11 @@ def topk_select_rows(scores: torch.Tensor, k: int):
     B, Nn = s.shape
     kth = torch.empty(B, dtype=torch.float32, device=s.device)
     idx = torch.empty((B, k), dtype=torch.int64, device=s.device)
+    if Nn >= 65536 and B <= 65535:  # long rows: every pass of the selection spread over (chunk, row) workgroups
+        ws = _workspace(L.ragraph_topk_select_rows_workspace_bytes(B, Nn), s.device)
+        N.check(L.ragraph_topk_select_rows_ws_f32(s.data_ptr(), B, Nn, Nn, k, kth.data_ptr(), idx.data_ptr(), ws.data_ptr(),
+                                                  ws.numel(), _stream()), "topk_select_rows")
+        return kth, idx
     N.check(L.ragraph_topk_select_rows_f32(s.data_ptr(), B, Nn, Nn, k, kth.data_ptr(), idx.data_ptr(), _stream()),
             "topk_select_rows")
     return kth, idx
@@ -477,18 +482,32 @@ def topk_select_rows(scores: torch.Tensor, k: int):
 def retrieve_mean_large_k(q: torch.Tensor, keys_normalized: torch.Tensor, values: torch.Tensor, k: int,
                           slab_bytes: int = 1 << 30) -> torch.Tensor:
     """mean_k V[top-k(q)] for k beyond the fused kernels' lists (k > 64): score slabs by the dense kernel (the same
-    fmaf chains as every other path), topk_select_rows, gather_reduce with v_scale = 1/k in ascending index order.
-    RAGraph_edge/modules/RAGraph.py:298-324 with retrieve_num = 50 ... 100000."""
+    fmaf chains as every other path), topk_select_rows, and the winners' sum in ascending index order times 1/k.
+    RAGraph_edge/modules/RAGraph.py:298-324 with retrieve_num = 50 ... 100000.
+    Up to ROW_BLOCK winners the sum is gather_reduce's sequential chain.  Beyond (retrieve_num = 100000: one lane group
+    walking 100 k rows one after the other took 87 ms per 64 queries) the winners of a query are a CSR row of ones and the
+    sum is the SpMM's hub-row path: blocks of ROW_BLOCK consecutive winners, each its own chain, spread over the chip,
+    the block sums added in order -- the blocked order of oracle_spmm_csr, deterministic."""
     q = _f32c(q, "retrieve_mean_large_k.q")
     kn = _f32c(keys_normalized, "retrieve_mean_large_k.keys")
+    values = _f32c(values, "retrieve_mean_large_k.values")
     B, Nk = q.shape[0], kn.shape[0]
     qn = normalize_rows(q)
     rows = max(1, min(B, slab_bytes // (4 * Nk)))
     out = torch.empty((B, values.shape[1]), dtype=torch.float32, device=q.device)
+    ones = rowptr = None
     for b0 in range(0, B, rows):
         S = linear(qn[b0:b0 + rows], kn)
         _, idx = topk_select_rows(S, k)
-        out[b0:b0 + rows], _ = gather_reduce(values, None, idx, v_scale=1.0 / k)
+        nb = idx.shape[0]
+        if k <= ROW_BLOCK:
+            out[b0:b0 + nb], _ = gather_reduce(values, None, idx, v_scale=1.0 / k)
+            continue
+        if ones is None or ones.numel() != nb * k:
+            ones = torch.ones(nb * k, dtype=torch.float32, device=q.device)
+            rowptr = torch.arange(0, (nb + 1) * k, k, dtype=torch.int64, device=q.device)
+        total = spmm_csr(rowptr, idx.reshape(-1).to(torch.int32), ones, values, long_rows=True)
+        out[b0:b0 + nb] = axpby(total, 1.0 / k, total, 0.0)
     return out
 
 

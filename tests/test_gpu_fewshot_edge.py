@@ -150,7 +150,7 @@ def test_topk_select_rows_matches_oracle(dev):
     from ragraph_amd import kernels as K
 
     rng = np.random.default_rng(12)
-    for (B, N, k) in [(5, 1000, 1), (7, 1000, 1000), (9, 5000, 1000), (3, 70001, 33333), (4, 513, 257), (2, 100, 64)]:
+    for (B, N, k) in [(5, 1000, 1), (7, 1000, 1000), (9, 5000, 1000), (3, 70001, 33333), (4, 513, 257), (2, 100, 64), (3, 300001, 100000), (2, 65536, 1), (2, 131072, 131072)]:
         S = rng.standard_normal((B, N)).astype(np.float32)
         S[0, : N // 2] = S[0, N // 2: 2 * (N // 2)]        # exact duplicates: ties everywhere
         S[1] = 0.25                                          # a constant row: the first k indices win
@@ -161,6 +161,27 @@ def test_topk_select_rows_matches_oracle(dev):
         rk, ri = cref.topk_select_rows(S, k)
         assert np.array_equal(idx.cpu().numpy(), ri), (B, N, k)
         assert np.array_equal(kth.cpu().numpy(), rk), (B, N, k)
+
+
+def test_retrieve_mean_very_large_k_blocked_sum(dev):
+    """retrieve_num beyond ROW_BLOCK (the reference's amazon setting is 100000): the winners' sum takes the SpMM hub-row
+    path -- blocks of 4096 winners in ascending index order, block sums added in order.  Bit-identical to the oracle's
+    blocked SpMM over the oracle's canonical top-k set, and the plain mean to 1e-5."""
+    from ragraph_amd import kernels as K
+
+    rng = np.random.default_rng(31)
+    B, N, D, k = 6, 30000, 64, 10000
+    kn = cref.normalize_rows(rng.standard_normal((N, D), dtype=np.float32))
+    v = rng.standard_normal((N, D), dtype=np.float32)
+    q = rng.standard_normal((B, D), dtype=np.float32)
+    got = K.retrieve_mean_large_k(T(q, dev), T(kn, dev), T(v, dev), k).cpu().numpy()
+    S = cref.linear(cref.normalize_rows(q), kn)
+    _, idx = cref.topk_select_rows(S, k)
+    rowptr = np.arange(0, (B + 1) * k, k, dtype=np.int64)
+    total = cref.spmm_csr(rowptr, idx.reshape(-1).astype(np.int32), np.ones(B * k, np.float32), v)
+    want = cref.axpby(total, 1.0 / k, total, 0.0)
+    assert np.array_equal(got, want)
+    assert np.allclose(got, np.stack([v[idx[b]].astype(np.float64).mean(0) for b in range(B)]), atol=1e-5)
 
 
 def test_edge_vanilla_large_k_g12(dev):
