@@ -177,7 +177,8 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
     flag[q] = 0;
   }
   if (lane < cstride) count[q * cstride + lane] = 0;
-  if (gmax && lane < ngroups) gmax[q * ngroups + lane] = f2ord(RG_NEG_INF);
+  if (gmax)
+    for (int gi = lane; gi < ngroups; gi += 64) gmax[q * ngroups + gi] = f2ord(RG_NEG_INF);
 }
 
 // Sharded banks (ragraph_topk_cosine_filtered_sharded_f32): the bound a level filters with is kept in theta[B] so that
@@ -198,28 +199,45 @@ __global__ void __launch_bounds__(256) filter_theta_kernel(FilterThr t, int64_t 
   theta[q] = init ? v : fmaxf(theta[q], v);
 }
 
-// Sharded banks, after the bound pass: the k group maxima of a query, each minus eps(q), are lower bounds of the exact
-// scores of k DISTINCT keys of this shard.  Sorted (descending) into scores[B,k] they travel through the same exchange as
-// a level's exact scores (the k-th largest of the union of all shards' values bounds the global k-th best);
-// theta = the smallest of them = this shard's own bound.
+// After the bound pass: the G >= k part maxima of a query, each minus eps(q), are lower bounds of the exact scores of G
+// DISTINCT keys (one per part).  The k-th largest of them is therefore a lower bound of the final k-th best score:
+// theta.  With G = 4 k parts it is worth the exact k-th best of ~ 0.85 of the prefix (two of the sample's best k keys
+// share a part k^2 / 2G ~ 1.2 times on average); with G = k parts (round 1: the minimum of k maxima) only of
+// prefix / (ln k + 1).  Sharded banks: the k largest, descending, also go to scores[B,k] and travel through the same
+// exchange as a level's exact scores (the k-th largest of the union of all shards' values bounds the global k-th best).
 __global__ void __launch_bounds__(256) filter_bound_scores_kernel(FilterThr t, int64_t B, float* __restrict__ scores,
                                                                   float* __restrict__ theta) {
-  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // one wave per query: lane l holds parts l and l + 64 (G <= 128) and ranks them by counting (ties by part index)
+  const int lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= B) return;
   const float eps = filter_eps(t, q);
-  float v[32];
-#pragma unroll 1
-  for (int g = 0; g < t.ngroups; ++g) {  // insertion sort, k <= 32
-    const float x = __fsub_rn(ord2f(t.gmax[q * t.ngroups + g]), eps);
-    int pos = g;
-    while (pos > 0 && v[pos - 1] < x) {
-      v[pos] = v[pos - 1];
-      --pos;
-    }
-    v[pos] = x;
+  const int G = t.ngroups;
+  float v[2];
+  int rank[2] = {0, 0};
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int g = lane + 64 * u;
+    v[u] = g < G ? __fsub_rn(ord2f(t.gmax[q * G + g]), eps) : RG_NEG_INF;
   }
-  for (int g = 0; g < t.ngroups; ++g) scores[q * t.ngroups + g] = v[g];
-  theta[q] = v[t.ngroups - 1];
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    if (64 * w >= G) break;  // (wave-uniform)
+    const int on = G - 64 * w < 64 ? G - 64 * w : 64;
+    for (int o = 0; o < on; ++o) {
+      const float x = __shfl(v[w], o);
+      const int xi = o + 64 * w;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) rank[u] += (x > v[u] || (x == v[u] && xi < lane + 64 * u)) ? 1 : 0;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (lane + 64 * u < G && rank[u] < t.k) {
+      if (scores) scores[q * t.k + rank[u]] = v[u];
+      if (rank[u] == t.k - 1) theta[q] = v[u];
+    }
+  }
 }
 
 // Sharded banks, after a level: theta[b] = max(theta[b], k-th largest of the union of every shard's best m exact scores
@@ -1315,18 +1333,57 @@ static bool filter_bound_pass_enabled() {
   return on;
 }
 
-static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k) {
+// Parts of the bound pass's prefix: 4 k (at most 128), as many as the prefix has stages (a part is at least one ring stage;
+// sub-tiles of the direct kernel are finer), never fewer than k.
+static int filter_bound_parts(int k, int64_t bound_keys, int D, int64_t B = 1 << 20, int n_shards = 1) {
+  if (B <= 64) return k;  // a handful of queries: the minimum of k part maxima, taken inside the filter launch's prologue
+                          // (filter_threshold) -- the extra selection launch would cost more than the shorter prefix saves
+  int64_t g = 4 * (int64_t)k;
+  if (g > 128) g = 128;
+  if (n_shards > 1) g = (g + n_shards - 1) / n_shards;  // (pooled through the exchange: 4 k parts over all shards)
+  const int64_t avail = bound_keys == INT64_MAX ? g : bound_keys / (FILTER_STAGE_BYTES / (2 * D));
+  if (g > avail) g = avail;
+  return (int)(g < k ? k : g);
+}
+// prefix keys per key of exact sample the bound is worth (see filter_bound_scores_kernel)
+static double filter_bound_eff(int k, int parts) {
+  if (parts >= 4 * k || parts >= 128) return 1.2;
+  if (parts >= 2 * k) return 1.5;
+  return log((double)k) + 1.0;
+}
+
+// n_shards > 1 (row-sharded bank, N = the largest shard): the shards pool their first samples through the exchange, so
+// the sample is planned for the WHOLE bank and every shard scans its share of the prefix.
+static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_shards = 1) {
   FilterSchedule sc{};
   const int cap = 2048;
   const bool bound = N >= 8192 && filter_bound_pass_enabled();
-  const double eff_div = log((double)k) + 1.0;  // bound_keys / eff_div ~ the exact sample the bound is worth
+  // bound_keys / eff_div ~ the exact sample the bound is worth: planned for 4 k parts, corrected below if the prefix is
+  // too short for that many
+  const double eff_div = filter_bound_eff(k, B <= 64 ? k : 4 * k);
+  auto prefix_for = [&](int64_t n0) {  // prefix whose bound is worth the exact k-th best of n0 keys
+    int64_t nA = filter_round_up((int64_t)((double)n0 * eff_div));
+    const int parts = filter_bound_parts(k, nA, D, B);
+    if (parts < 4 * k && parts < 128) nA = filter_round_up((int64_t)((double)n0 * filter_bound_eff(k, parts)));
+    return nA;
+  };
   if (B > FILTER_SLAB_MAX_B || N < 4 * 4096) {
-    int64_t n0 = N / 256;
+    // (the first sample: with 4 k parts the bound pass is cheap enough for N / 64 -- fewer candidates at the first level,
+    // whose sub-tiles otherwise nearly all take the candidate path: 100k x 1M: 38.0 -> 36.5 ms against N / 256;
+    // RAGRAPH_FILTER_N0DIV: A/B)
+    static const int64_t n0div = [] { const char* e = getenv("RAGRAPH_FILTER_N0DIV"); return e ? (int64_t)atoll(e) : (int64_t)64; }();
+    int64_t n0 = N * n_shards / n0div;  // (over all shards)
     if (n0 < 4096) n0 = 4096;
+    int64_t nA = bound ? prefix_for(n0) : 0;
+    if (n_shards > 1) {  // this shard's share
+      n0 /= n_shards;
+      nA = filter_round_up(nA / n_shards);
+      const int64_t min_keys = filter_round_up((int64_t)k * (FILTER_STAGE_BYTES / (2 * D)));
+      if (nA < min_keys) nA = min_keys;
+    }
     if (n0 > N) n0 = N;
     if (n0 < k) n0 = k < N ? k : N;
     if (bound) {
-      int64_t nA = filter_round_up((int64_t)((double)n0 * eff_div));
       if (nA > N / 4) nA = N / 4 / FILTER_PAD_KEYS * FILTER_PAD_KEYS;
       sc.bound_keys = nA;
     }
@@ -1361,7 +1418,7 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k) {
     double first;  // cost of the first bound, us
     int64_t nA = 0;
     if (bound) {
-      nA = filter_round_up((int64_t)((double)n0 * eff_div));
+      nA = prefix_for(n0);
       if (nA * 4 > N) break;
       if (B <= 256)  // direct kernel: the prefix streams at ~5 TB/s (8.7 / 22 / 40 us for 54 k / 216 k / 216 k keys x 1 / 16 / 256 queries)
         first = 6.0 + (double)nA * 2.0 * D / 5.0e6 * (1.0 + (double)B / 320.0);
@@ -1386,7 +1443,7 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k) {
       }
     }
   }
-  sc.bound_keys = bound ? (best_nA ? best_nA : filter_round_up((int64_t)(4096 * eff_div))) : 0;
+  sc.bound_keys = bound ? (best_nA ? best_nA : prefix_for(4096)) : 0;
   sc.n0 = best_n0;
   sc.slab0 = 1;
   sc.nlev = 0;
@@ -1472,7 +1529,8 @@ struct FilterWs {
   int* count;           // [B][filter_count_stride(B)] candidate slots reserved in the current level (per sub-list)
   unsigned char* flag;  // [B] the list overflowed at an earlier level
   int* cand;            // [B,cap] candidate keys
-  int* gmax;            // [B,k] group maxima of the bound pass
+  int* gmax;            // [B, FILTER_BOUND_PARTS_MAX] part maxima of the bound pass
+  float* theta;         // [B] the first bound
   int* overflow_list;   // [B] queries the final level sends to the exact fallback
   float* part_s;        // (B <= 64) sliced rescoring: [B][8][k] partial winners
   int* part_i;
@@ -1492,7 +1550,8 @@ static size_t filter_ws_carve(char* w, int64_t B, int D, int k, int cap, FilterW
   f.count = reinterpret_cast<int*>(take((size_t)B * filter_count_stride(B) * sizeof(int)));
   f.flag = reinterpret_cast<unsigned char*>(take((size_t)B));
   f.cand = reinterpret_cast<int*>(take((size_t)B * cap * sizeof(int)));
-  f.gmax = reinterpret_cast<int*>(take((size_t)B * k * sizeof(int)));
+  f.gmax = reinterpret_cast<int*>(take((size_t)B * filter_bound_parts(k, INT64_MAX, 256) * sizeof(int)));
+  f.theta = reinterpret_cast<float*>(take((size_t)B * sizeof(float)));
   f.overflow_list = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   f.part_s = B <= 64 ? reinterpret_cast<float*>(take((size_t)B * 8 * k * sizeof(float))) : nullptr;
   f.part_i = B <= 64 ? reinterpret_cast<int*>(take((size_t)B * 8 * k * sizeof(int))) : nullptr;
@@ -1669,10 +1728,10 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
                         int n_shards) {
   hipStream_t st = as_stream(stream);
   const int cap = filter_cap(B, k);
-  FilterSchedule sc = filter_schedule(B, plan_N, D, k);  // (sharded banks: the same schedule on every shard)
+  FilterSchedule sc = filter_schedule(B, plan_N, D, k, exchange ? n_shards : 1);  // (sharded banks: the same schedule on every shard)
   sc.ends[sc.nlev - 1] = N;
   if (sc.bound_keys > N / 2) sc.bound_keys = 0, sc.n0 = sc.n0 < N ? sc.n0 : N;
-  if (exchange && n_shards > 1 && sc.bound_keys > 0) {
+  if (exchange && n_shards > 1 && sc.bound_keys > 0 && B <= FILTER_SLAB_MAX_B && plan_N >= 4 * 4096) {  // (the cost-model branch)
     // G shards pool their samples through the exchange (the k-th largest of the union of every shard's best group
     // maxima): each scans 1/G of the prefix one bank would -- at least one stage per part
     const int64_t min_keys = filter_round_up((int64_t)k * (FILTER_STAGE_BYTES / (2 * D)));
@@ -1694,7 +1753,8 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
 
   // one launch: normalised queries, their bf16 rounding errors, empty lists, clear flags (+ group maxima at -inf)
   hipLaunchKernelGGL(filter_prep_kernel<D>, dim3((unsigned)cdiv(B <= 256 ? (B + 31) / 32 * 32 : B, 4)), dim3(256), 0, st, Q, B,
-                     f.Qn, f.eq, f.count, f.flag, overflow, bound ? f.gmax : nullptr, k, B <= 256 ? f.Qb : nullptr,
+                     f.Qn, f.eq, f.count, f.flag, overflow, bound ? f.gmax : nullptr, bound ? filter_bound_parts(k, sc.bound_keys, D, B, exchange ? n_shards : 1) : k,
+                     B <= 256 ? f.Qb : nullptr,
                      filter_count_stride(B));
   RG_CHECK_LAUNCH("topk_cosine_filtered(prepare)");
 
@@ -1702,13 +1762,14 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   thr.eq = f.eq;
   thr.max_kerr2 = max_kerr2;
   thr.k = k;
-  thr.ngroups = k;
+  const int parts = bound ? filter_bound_parts(k, sc.bound_keys, D, B, exchange ? n_shards : 1) : k;
+  thr.ngroups = parts;
   thr.ablate = ablate;
   int rc = RAGRAPH_OK, fallback_done = 0;
   // the first bound: group maxima of a bf16 pass over a prefix, or an exact level 0 over the first n0 keys (out_scores /
   // out_idx hold every level's running result, local indices)
   if (bound) {
-    rc = run_bf16_pass<D>(f, Kb, B, 0, sc.bound_keys, thr, cap, k, 3, st);
+    rc = run_bf16_pass<D>(f, Kb, B, 0, sc.bound_keys, thr, cap, parts, 3, st);
     if (g_prof_on) g_prof_bound = 1;
   } else if (sc.slab0) {
     float* S = reinterpret_cast<float*>(w);  // one slab of scores, reused: written and read back while it is in cache
@@ -1727,16 +1788,21 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
     thr.gmax = bound ? f.gmax : nullptr;
     thr.prev_scores = out_scores;
     if (bound)  // k lower bounds of distinct keys' exact scores, descending, where a level leaves its exact top-k
-      hipLaunchKernelGGL(filter_bound_scores_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, thr, B, out_scores, theta);
+      hipLaunchKernelGGL(filter_bound_scores_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, st, thr, B, out_scores, theta);
     else
       hipLaunchKernelGGL(filter_theta_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, thr, B, 1, theta);
     RG_CHECK_LAUNCH("topk_cosine_filtered(theta)");
     exchange(ctx, 0);
     thr.theta = theta;
+  } else if (bound && parts > k) {  // theta = the k-th largest of the part maxima, minus eps
+    thr.gmax = f.gmax;
+    hipLaunchKernelGGL(filter_bound_scores_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, st, thr, B, (float*)nullptr, f.theta);
+    RG_CHECK_LAUNCH("topk_cosine_filtered(theta)");
   }
   int64_t key0 = 0;
   for (int l = 0; l < sc.nlev; ++l) {  // the first level re-reads [0, n0): its keys pass the bound and need no merge
-    thr.gmax = (l == 0 && bound && !exchange) ? f.gmax : nullptr;
+    thr.gmax = (l == 0 && bound && !exchange && parts == k) ? f.gmax : nullptr;  // (k parts: the minimum, inline)
+    if (!exchange) thr.theta = (l == 0 && bound && parts > k) ? f.theta : nullptr;
     thr.prev_scores = out_scores;
     rc = run_bf16_pass<D>(f, Kb, B, key0, sc.ends[l], thr, cap, 0, l, st);
     if (rc != RAGRAPH_OK) return rc;
