@@ -46,8 +46,9 @@ __device__ __forceinline__ float ord2f(int o) { return __int_as_float(o >= 0 ? o
 
 // How a filter launch obtains a query's pass threshold thr[q] = theta[q] - eps(q), where theta[q] is a proven lower
 // bound of the query's final k-th best exact score: the k-th exact score of everything rescored so far (prev_scores),
-// or -- gmax != NULL, right after the bound pass -- the smallest of the k group maxima of approximate scores minus
-// eps(q) (each group's best key has an exact score >= its approximate one - eps, so k distinct keys score at least that).
+// or -- gmax != NULL, right after the bound pass of a handful of queries -- the smallest of the k part maxima of approximate
+// scores minus eps(q) (each part's best key has an exact score >= its approximate one - eps, so k distinct keys score at
+// least that); larger batches record 4 k parts and pass theta = the k-th largest of them (filter_bound_scores_kernel).
 struct FilterThr {
   const float* theta;         // [B] the bound itself, handed in (sharded banks: sharpened across the shards), or NULL
   const float* prev_scores;   // [B,k] running exact top-k (descending), or NULL

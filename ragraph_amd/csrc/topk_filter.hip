@@ -4,9 +4,10 @@
 // The fp32 tile kernel (topk_cosine.hip) spends 2·B·N·D fp32 MFMA flops; the bf16 matrix cores are 16x faster.  This
 // path returns the SAME bits with most of the work on them:
 //   1. a first lower bound theta[q] of the final k-th best exact score of q.  Banks of >= 8192 keys: the BOUND pass --
-//      this file's kernel over a prefix of the bank, recording per query the best approximate score of each of k parts;
-//      k distinct keys score at least (the smallest of those maxima) - eps(q).  Smaller banks: the k-th score of an exact
-//      top-k over the first n0 keys (the fp32 tile kernel, or up to 16384 queries a score slab + topk_rows).
+//      this file's kernel over a prefix of the bank, recording per query the best approximate score of each of G = 4 k
+//      parts (a handful of queries: k); the parts' best keys are distinct, so k keys score at least (the k-th largest of
+//      those maxima) - eps(q).  Smaller banks: the k-th score of an exact top-k over the first n0 keys (the fp32 tile
+//      kernel, or up to 16384 queries a score slab + topk_rows).
 //   2. filter (this file, bf16 MFMA): approximate scores s~ = bf16(q)·bf16(key), fp32 accumulate, over the next, larger
 //      part of the bank.  With q^ = q + dq, k^ = k + dk: |s~ - s| <= |dq||k| + |q||dk| + |dq||dk| + accumulation error
 //      (Cauchy-Schwarz) <= eps(q), computed from the query's actual |dq| and the bank's largest |dk| (<= 2^-7 in the worst
