@@ -66,6 +66,7 @@ struct FilterParams {
   FilterThr thr;          // how a query's pass threshold theta[q] - eps(q) is obtained (filter_common.h)
   int* count;             // [B][cstride] candidate slots reserved so far (filter_count_stride)
   int cstride;
+  const uint16_t* Qb;     // queries as bf16 B operands in fragment order (padded to 32s), or NULL: convert from Qn
   int* cand;              // [B,cap] candidate key indices (local to this shard)
   int64_t B, N;           // N = end of the key range (keys >= N never pass)
   int cap;
@@ -332,6 +333,22 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     // ---- B operands: group gq's query q_lo + 16 gq, k-step t = elements 32 t + 8 g .. + 7, converted to bf16 (RNE) ----
     bf16x8 bq[NG][C::KS32];
     constexpr int TB = C::KS32 < 4 ? C::KS32 : 4;
+    if (p.Qb) {  // prepared image: block (group * KS32 + t), this lane's 16 bytes; groups beyond the padded batch: zeros
+      const int64_t qg0 = (qtile * QT + wave * QW) >> 4;
+      const int64_t ngroups16 = ((p.B + 31) / 32 * 32) >> 4;
+#pragma unroll
+      for (int gq = 0; gq < NG; ++gq) {
+        const bool have = qg0 + gq < ngroups16;  // (wave-uniform)
+        const bf16x8* src = reinterpret_cast<const bf16x8*>(p.Qb) + ((qg0 + gq) * C::KS32) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < C::KS32; ++t) {
+          bf16x8 z;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+          bq[gq][t] = have ? src[t * 64] : z;
+        }
+      }
+    } else
 #pragma unroll
     for (int gq = 0; gq < NG; ++gq) {
       const int64_t qq = q_lo + 16 * gq;
@@ -1317,6 +1334,10 @@ struct FilterSchedule {
 };
 
 constexpr int64_t FILTER_SLAB_MAX_B = 16384;
+// up to this many queries the prepare launch also leaves the queries as bf16 B operands in fragment order: the direct
+// kernel's image (<= 256), and the ring kernel's operand load -- 32 independent 16-byte loads per lane instead of eight
+// dependent batches of fp32 loads + conversions (13 us per segment at D = 256), which short launches cannot amortise
+constexpr int64_t FILTER_QB_MAX_B = 16384;
 constexpr int64_t FILTER_SLAB_MAX_SCORES = (int64_t)1 << 26;  // 256 MiB of scores
 
 // Banks of >= 8192 keys (KeyIndex sends >= 16384) take their first bound from the BOUND pass instead of an
@@ -1525,7 +1546,7 @@ extern "C" int ragraph_topk_cosine_filtered_plan(int64_t B, int64_t N, int D, in
 // Everything one call keeps in its workspace behind level 0's scratch.
 struct FilterWs {
   float* Qn;            // [B,D] normalised queries
-  uint16_t* Qb;         // (B <= 256) the same as bf16 B operands in fragment order, padded to whole groups of 32
+  uint16_t* Qb;         // (B <= FILTER_QB_MAX_B) the same as bf16 B operands in fragment order, padded to whole groups of 32
   float* eq;            // [B] |dq|
   int* count;           // [B][filter_count_stride(B)] candidate slots reserved in the current level (per sub-list)
   unsigned char* flag;  // [B] the list overflowed at an earlier level
@@ -1546,7 +1567,7 @@ static size_t filter_ws_carve(char* w, int64_t B, int D, int k, int cap, FilterW
   };
   FilterWs f;
   f.Qn = reinterpret_cast<float*>(take((size_t)B * D * sizeof(float)));
-  f.Qb = B <= 256 ? reinterpret_cast<uint16_t*>(take((size_t)((B + 31) / 32 * 32) * D * sizeof(uint16_t))) : nullptr;
+  f.Qb = B <= FILTER_QB_MAX_B ? reinterpret_cast<uint16_t*>(take((size_t)((B + 31) / 32 * 32) * D * sizeof(uint16_t))) : nullptr;
   f.eq = reinterpret_cast<float*>(take((size_t)B * sizeof(float)));
   f.count = reinterpret_cast<int*>(take((size_t)B * filter_count_stride(B) * sizeof(int)));
   f.flag = reinterpret_cast<unsigned char*>(take((size_t)B));
@@ -1582,7 +1603,13 @@ static int launch_ring(FilterParams p, int64_t B, int prof_slot, hipStream_t st)
   const int CUS = filter_device_cus();
   p.xcd_map = p.qtiles >= 64 ? 1 : 0;
   p.wgs_per_group = CUS / (p.xcd_map ? 8 : 1);
-  p.lb_min = 8;
+  // shortest piece of a key stream a workgroup takes: 8 stages when there is work for everybody, fewer on short launches
+  // (a bound pass of 18 stages x 6 query tiles gave 14 workgroups 8 stages each and 242 nothing: 19 us of stage loop where
+  // 108 workgroups need 2.5; tools/check_segment_plan.cpp covers lb_min = 1)
+  {
+    const int64_t per_wg = p.qtiles * p.nstages_total / CUS;
+    p.lb_min = per_wg >= 16 ? 8 : (per_wg >= 8 ? 4 : (per_wg >= 3 ? 2 : 1));
+  }
   const int64_t nq0 = p.xcd_map ? (p.qtiles + 7) / 8 : p.qtiles;
   for (int v = 0; v < 2; ++v) {
     const int64_t nq = nq0 - v;
@@ -1649,6 +1676,7 @@ static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64
   p.thr = thr;
   p.count = f.count;
   p.cstride = filter_count_stride(B);
+  p.Qb = f.Qb;
   p.cand = f.cand;
   p.gmax = bound_groups > 0 ? f.gmax : nullptr;
   p.ngroups = bound_groups;
@@ -1753,9 +1781,9 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   const bool bound = sc.bound_keys > 0;
 
   // one launch: normalised queries, their bf16 rounding errors, empty lists, clear flags (+ group maxima at -inf)
-  hipLaunchKernelGGL(filter_prep_kernel<D>, dim3((unsigned)cdiv(B <= 256 ? (B + 31) / 32 * 32 : B, 4)), dim3(256), 0, st, Q, B,
+  hipLaunchKernelGGL(filter_prep_kernel<D>, dim3((unsigned)cdiv(B <= FILTER_QB_MAX_B ? (B + 31) / 32 * 32 : B, 4)), dim3(256), 0, st, Q, B,
                      f.Qn, f.eq, f.count, f.flag, overflow, bound ? f.gmax : nullptr, bound ? filter_bound_parts(k, sc.bound_keys, D, B, exchange ? n_shards : 1) : k,
-                     B <= 256 ? f.Qb : nullptr,
+                     B <= FILTER_QB_MAX_B ? f.Qb : nullptr,
                      filter_count_stride(B));
   RG_CHECK_LAUNCH("topk_cosine_filtered(prepare)");
 
