@@ -156,7 +156,7 @@ def filter_helps(B: int, n_keys: int, D: int, k: int) -> bool:
     if D == 64 and n_keys < 65536 and B * n_keys <= (1 << 26):  # (4096 x 16384 x 64: slab 228, filtered 317 us)
         return False
     # mid-sized banks pay off for larger batches only (ms, filtered vs fp32 kernels, r2: 2708 x 10000 x 128 (Cora-sized)
-    # 0.123 vs 0.171; 8192 x 8192 x 128: 0.152 vs 0.299; 2708 x 10000 x 256: 0.202 vs 0.253; 2708 x 16384 x 128: 0.164 vs
+    # 0.089 vs 0.171; 8192 x 8192 x 128: 0.152 vs 0.299; 2708 x 10000 x 256: 0.202 vs 0.253; 2708 x 16384 x 128: 0.164 vs
     # 0.240 -- but 1024 x 10000 x 128: 0.125 vs 0.075, and at D = 64 2708 x 10000: 0.185 vs 0.137, 8192 x 10000: 0.310 vs 0.414)
     if n_keys >= 65536:
         return B >= FILTER_MIN_B
