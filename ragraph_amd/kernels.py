@@ -150,17 +150,22 @@ def filter_helps(B: int, n_keys: int, D: int, k: int) -> bool:
         return False
     if D not in (64, 128, 256) or k > 32:
         return False
-    # small score matrices are cheaper materialised (the fp32 entry's slab rule: 64 x 65536: 81 vs 129 us filtered)
-    if n_keys <= 131072 and B * n_keys <= 6 * (1 << 20):
-        return False
-    if D == 64 and n_keys < 65536 and B * n_keys <= (1 << 26):  # (4096 x 16384 x 64: slab 228, filtered 317 us)
-        return False
-    # mid-sized banks pay off for larger batches only (ms, filtered vs fp32 kernels, r2: 2708 x 10000 x 128 (Cora-sized)
-    # 0.089 vs 0.171; 8192 x 8192 x 128: 0.152 vs 0.299; 2708 x 10000 x 256: 0.202 vs 0.253; 2708 x 16384 x 128: 0.164 vs
-    # 0.240 -- but 1024 x 10000 x 128: 0.125 vs 0.075, and at D = 64 2708 x 10000: 0.185 vs 0.137, 8192 x 10000: 0.310 vs 0.414)
+    # Measured on MI355X after the round-2 kernels (ms, filtered vs the fp32 dispatch; tools/quick_topk_bench.py):
+    #   N >= 65536: filtered at every batch size (1 x 65536 x 256: 0.036 vs 0.055; 64 x 65536: 0.048 vs 0.080; D = 64,
+    #     16 x 65536: 0.036 vs 0.056);
+    #   32768 <= N < 65536: from 128 queries (128 x 32768 x 256: 0.046 vs 0.076; 64 x 32768: 0.068 vs 0.058);
+    #   8192 <= N < 32768: D >= 128 from 512 queries (512 x 10000 x 128: 0.049 vs 0.056; 1024 x 10000 x 256: 0.075 vs
+    #     0.114; 256 x 10000 x 128: 0.048 vs 0.042); D = 64 from 2048 (N >= 16384: 1024 x 16384: 0.089 vs 0.085) or 8192
+    #     queries (2708 x 10000 x 64: 0.155 vs 0.138; 8192 x 10000: 0.284 vs 0.418).
     if n_keys >= 65536:
         return B >= FILTER_MIN_B
-    return n_keys >= 8192 and (B >= 8192 or (B >= 2048 and D >= 128))
+    if n_keys >= 32768:
+        return B >= 128
+    if n_keys < 8192:
+        return False
+    if D >= 128:
+        return B >= 512
+    return B >= (2048 if n_keys >= 16384 else 8192)
 
 
 FILTER_MIN_B = int(os.environ.get("RAGRAPH_FILTER_MIN_B", "1"))  # banks of >= 64 k keys: filtered from this many queries

@@ -87,18 +87,19 @@ def test_filtered_topk_plan_is_well_formed():
 
 
 def test_filtered_dispatch_rule():
-    """kernels.filter_helps (pure host arithmetic): which shapes take the bf16-filtered exact top-k.  Long banks at any
-    batch size; mid-sized banks (>= 8192 keys) from 2048 queries up (D >= 128) or 8192 (D = 64); small score matrices
-    never (they are cheaper materialised); unsupported D / k never; RAGRAPH_EXACT_FP32=1 never."""
+    """kernels.filter_helps (pure host arithmetic): which shapes take the bf16-filtered exact top-k.  Banks of >= 65536
+    keys at any batch size; >= 32768 keys from 128 queries; >= 8192 keys from 512 queries (D >= 128) or 2048 / 8192
+    (D = 64); smaller banks, unsupported D / k and RAGRAPH_EXACT_FP32=1 never."""
     import os
 
     from ragraph_amd import kernels as K
 
     assert os.environ.get("RAGRAPH_EXACT_FP32") != "1"
-    yes = [(1, 1_000_000, 256, 10), (16, 262144, 64, 3), (2708, 10_000, 128, 5), (8192, 8192, 128, 5),
-           (2708, 10_000, 256, 10), (8192, 10_000, 64, 10), (4096, 16384, 256, 10), (100_000, 1_000_000, 256, 32)]
-    no = [(1024, 10_000, 128, 5), (2708, 10_000, 64, 10), (2708, 4096, 128, 5), (64, 65536, 256, 10),
-          (1, 1_000_000, 96, 10), (1, 1_000_000, 256, 33), (40, 70_000, 256, 10)]
+    yes = [(1, 1_000_000, 256, 10), (1, 65536, 256, 10), (40, 70_000, 256, 10), (16, 262144, 64, 3), (128, 32768, 128, 5),
+           (512, 10_000, 128, 5), (2708, 10_000, 128, 5), (8192, 8192, 128, 5), (1024, 10_000, 256, 10),
+           (8192, 10_000, 64, 10), (2048, 16384, 64, 10), (100_000, 1_000_000, 256, 32)]
+    no = [(256, 10_000, 128, 5), (64, 32768, 256, 10), (2708, 10_000, 64, 10), (1024, 16384, 64, 10), (2708, 4096, 128, 5),
+          (100_000, 8191, 256, 10), (1, 1_000_000, 96, 10), (1, 1_000_000, 256, 33)]
     for B, N, D, k in yes:
         assert K.filter_helps(B, N, D, k), (B, N, D, k)
     for B, N, D, k in no:

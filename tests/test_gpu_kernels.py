@@ -543,13 +543,20 @@ def test_key_index_dispatch_same_bits(dev, monkeypatch):
     kn = _bank(rng, 70000, 256)
     knd = _t(kn, dev)
     index = K.KeyIndex(knd)
-    for B in (3, 40, 200, 800):  # 3: streaming fp32 kernel; 40: score slab; 200, 800: filtered (<= 256: one group per wave)
+    for B in (3, 40, 200, 800):  # >= 65536 keys: filtered at every batch size (direct kernel up to 256, ring kernel beyond)
         q = rng.standard_normal((B, 256), dtype=np.float32)
-        assert K.filter_helps(B, 70000, 256, 10) == (B >= 200)
+        assert K.filter_helps(B, 70000, 256, 10)
         s, i = index.topk(_t(q, dev), 10, idx_base=4)
         rs, ri = cref.topk_cosine(q, kn, 10, idx_base=4)
         assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs)
     assert index._bf16 is not None
+    small = K.KeyIndex(_t(kn[:20000], dev))  # a bank below 32768 keys: streaming fp32 kernel, score slab, tile kernel; 600: filtered
+    for B in (3, 40, 300, 600):
+        q = rng.standard_normal((B, 256), dtype=np.float32)
+        assert K.filter_helps(B, 20000, 256, 10) == (B >= 512)
+        s, i = small.topk(_t(q, dev), 10, idx_base=4)
+        rs, ri = cref.topk_cosine(q, kn[:20000], 10, idx_base=4)
+        assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs)
     # batches beyond MAX_FILTERED_BATCH go through the filtered path in slabs (bounded workspace): same rows, same order
     monkeypatch.setattr(K.KeyIndex, "MAX_FILTERED_BATCH", 300)
     q = rng.standard_normal((800, 256), dtype=np.float32)
