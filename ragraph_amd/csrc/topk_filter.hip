@@ -381,7 +381,12 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     auto flush_max = [&]() {
 #pragma unroll
       for (int gq = 0; gq < NG; ++gq) {
-        if (q_lo + 16 * gq < p.B) atomicMax(p.gmax + (q_lo + 16 * gq) * p.ngroups + grp, f2ord(gm[gq]));
+        // the four lanes j + 16 g of a query hold the maxima of its keys 4 g .. 4 g + 3 (mod 16): one atomic per query,
+        // not four on one address in one instruction
+        float v = gm[gq];
+        v = fmaxf(v, __shfl_xor(v, 16));
+        v = fmaxf(v, __shfl_xor(v, 32));
+        if (g == 0 && q_lo + 16 * gq < p.B) atomicMax(p.gmax + (q_lo + 16 * gq) * p.ngroups + grp, f2ord(v));
         gm[gq] = RG_NEG_INF;
       }
     };
