@@ -34,39 +34,53 @@ __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ X
   // barrier per chunk and no exposed load latency (the GCN encode of a Cora-sized graph, K = 1433, is 45 chunks on 86
   // workgroups -- with load, barrier, MFMA, barrier in sequence it was 223 us of a 475 us forward).
   constexpr int PER = (LBM * LKC) / 256;
-  float ra[PER], rb[PER];
-  auto gload = [&](int k0) {
+  // TWO register sets: chunk c travels in set c & 1, loaded two chunks ahead of its MFMAs -- with one set (loaded one
+  // chunk ahead) an iteration cost a memory latency, ~1.1 us for 0.5 us of MFMA: the Cora-sized encode (K = 1433: 45
+  // chunks on 86 workgroups) 52.6 us
+  float ra[2][PER], rb[2][PER];
+  auto gload = [&](int k0, float (&pa)[PER], float (&pb)[PER]) {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int e = tid + u * 256;
       const int row = e / LKC, c = e % LKC;
       const int kk = k0 + c;
       const int64_t gm = m0 + row, gn = n0 + row;
-      ra[u] = (gm < M && kk < K) ? X[gm * K + kk] : 0.f;
-      rb[u] = (gn < N && kk < K) ? W[gn * K + kk] : 0.f;
+      pa[u] = (gm < M && kk < K) ? X[gm * K + kk] : 0.f;
+      pb[u] = (gn < N && kk < K) ? W[gn * K + kk] : 0.f;
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, const float (&pa)[PER], const float (&pb)[PER]) {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int e = tid + u * 256;
       const int row = e / LKC, c = e % LKC;
-      As[buf][row * LLD + c] = ra[u];
-      Bs[buf][row * LLD + c] = rb[u];
+      As[buf][row * LLD + c] = pa[u];
+      Bs[buf][row * LLD + c] = pb[u];
     }
   };
-  const int nch = (K + LKC - 1) / LKC;
-  gload(0);
-  sstore(0);
-  __syncthreads();
-  for (int ch = 0; ch < nch; ++ch) {
-    const int buf = ch & 1;
-    if (ch + 1 < nch) gload((ch + 1) * LKC);
+  auto compute = [&](int buf) {
     const float* a = As[buf] + (wr * 32 + j) * LLD + h;
     const float* b = Bs[buf] + (wc * 32 + j) * LLD + h;
 #pragma unroll
     for (int kk = 0; kk < LKC / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * kk], b[2 * kk], acc, 0, 0, 0);
-    if (ch + 1 < nch) sstore(buf ^ 1);  // (its last readers passed the barrier that ended chunk ch - 1)
+  };
+  const int nch = (K + LKC - 1) / LKC;
+  gload(0, ra[0], rb[0]);
+  sstore(0, ra[0], rb[0]);
+  if (nch > 1) gload(LKC, ra[1], rb[1]);
+  if (nch > 2) gload(2 * LKC, ra[0], rb[0]);
+  __syncthreads();
+  // iteration ch: MFMAs of chunk ch (LDS buffer ch & 1); chunk ch + 1 (set (ch + 1) & 1, loaded two iterations ago) goes
+  // to the other buffer -- whose last readers passed the barrier that ended chunk ch - 1 --, chunk ch + 3 into its set
+  for (int ch = 0; ch < nch; ch += 2) {
+    compute(0);
+    if (ch + 1 < nch) sstore(1, ra[1], rb[1]);
+    if (ch + 3 < nch) gload((ch + 3) * LKC, ra[1], rb[1]);
+    __syncthreads();
+    if (ch + 1 >= nch) break;
+    compute(1);
+    if (ch + 2 < nch) sstore(0, ra[0], rb[0]);
+    if (ch + 4 < nch) gload((ch + 4) * LKC, ra[0], rb[0]);
     __syncthreads();
   }
 
