@@ -99,6 +99,87 @@ __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ X
   }
 }
 
+// ---- few output tiles, long K: 32 x 32 block tile, one 16 x 16 MFMA tile per wave -----------------------------------
+// A 64 x 64 block of linear_kernel is a chain of K/2 dependent v_mfma_f32_32x32x2_f32 per wave (64 cycles each): the GCN
+// encode of a Cora-sized graph (2708 x 1433 -> 128: 86 blocks on 256 CUs, 717 dependent MFMAs) took 50 us with two
+// thirds of the chip idle.  v_mfma_f32_16x16x4_f32 walks four k-steps in 32 cycles -- the same fmaf chain per output, so
+// the same bits -- and a 16 x 16 tile per wave spreads the same outputs over four times the waves.
+constexpr int SBM = 32, SBN = 32;
+
+__global__ void __launch_bounds__(256) linear_small_kernel(const float* __restrict__ X, int64_t M, int K,
+                                                           const float* __restrict__ W, int64_t N,
+                                                           const float* __restrict__ bias, int act, float alpha,
+                                                           float* __restrict__ Y) {
+  __shared__ float As[2][SBM * LLD];
+  __shared__ float Bs[2][SBN * LLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.x * SBM;
+  const int64_t n0 = (int64_t)blockIdx.y * SBN;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // stage: 32 x 32 of X and of W per chunk (4 + 4 values per thread), two register sets as in linear_kernel
+  constexpr int PER = (SBM * LKC) / 256;
+  float ra[2][PER], rb[2][PER];
+  auto gload = [&](int k0, float (&pa)[PER], float (&pb)[PER]) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + u * 256;
+      const int row = e / LKC, c = e % LKC;
+      const int kk = k0 + c;
+      const int64_t gm = m0 + row, gn = n0 + row;
+      pa[u] = (gm < M && kk < K) ? X[gm * K + kk] : 0.f;
+      pb[u] = (gn < N && kk < K) ? W[gn * K + kk] : 0.f;
+    }
+  };
+  auto sstore = [&](int buf, const float (&pa)[PER], const float (&pb)[PER]) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + u * 256;
+      const int row = e / LKC, c = e % LKC;
+      As[buf][row * LLD + c] = pa[u];
+      Bs[buf][row * LLD + c] = pb[u];
+    }
+  };
+  auto compute = [&](int buf) {  // lane (i, kq): A[i][4 s + kq], B[4 s + kq][j]: k-step s of the chunk
+    const float* a = As[buf] + (wr * 16 + i16) * LLD + kq;
+    const float* b = Bs[buf] + (wc * 16 + i16) * LLD + kq;
+#pragma unroll
+    for (int s4 = 0; s4 < LKC / 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * s4], b[4 * s4], acc, 0, 0, 0);
+  };
+  const int nch = (K + LKC - 1) / LKC;
+  gload(0, ra[0], rb[0]);
+  sstore(0, ra[0], rb[0]);
+  if (nch > 1) gload(LKC, ra[1], rb[1]);
+  if (nch > 2) gload(2 * LKC, ra[0], rb[0]);
+  __syncthreads();
+  for (int ch = 0; ch < nch; ch += 2) {
+    compute(0);
+    if (ch + 1 < nch) sstore(1, ra[1], rb[1]);
+    if (ch + 3 < nch) gload((ch + 3) * LKC, ra[1], rb[1]);
+    __syncthreads();
+    if (ch + 1 >= nch) break;
+    compute(1);
+    if (ch + 2 < nch) sstore(0, ra[0], rb[0]);
+    if (ch + 4 < nch) gload((ch + 4) * LKC, ra[0], rb[0]);
+    __syncthreads();
+  }
+  // result: lane (j = lane % 16, kq): rows 4 kq + r of the wave's tile, column j
+  const int64_t n = n0 + wc * 16 + i16;
+  if (n < N) {
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t m = m0 + wr * 16 + 4 * kq + r;
+      if (m < M) {
+        float v = acc[r];
+        if (bias) v = __fadd_rn(v, bv);
+        Y[m * N + n] = apply_act(v, act, alpha);
+      }
+    }
+  }
+}
+
 // ---- large shapes: 128 x 128 block tile, 4 waves x (64 x 64), K chunks of 32 double-buffered through LDS -----------
 // Used when M >= 128, N >= 128, K % 4 == 0 and the rows are 16-B aligned (the GCN encode of c2: 100k x 128 -> 256).
 // Same numerics as linear_kernel (every output is the k = 0..K-1 fmaf chain the MFMA computes, bias added after), so
@@ -381,6 +462,13 @@ extern "C" int ragraph_linear_f32(const float* X, int64_t M, int K, const float*
     dim3 grid((unsigned)cdiv(M, TBM), (unsigned)cdiv(N, TBN));
     hipLaunchKernelGGL(linear_tile_kernel, grid, dim3(256), lds, as_stream(stream), X, M, K, W, N, bias, act, alpha, Y);
     RG_CHECK_LAUNCH("linear(tile)");
+    return RAGRAPH_OK;
+  }
+  // few 64 x 64 blocks and a long K: the chain of dependent MFMAs per wave is what the launch costs -- quarter-size tiles
+  if (cdiv(M, LBM) * cdiv(N, LBN) <= 192 && K >= 256 && cdiv(N, SBN) <= 65535) {
+    dim3 grid((unsigned)cdiv(M, SBM), (unsigned)cdiv(N, SBN));
+    hipLaunchKernelGGL(linear_small_kernel, grid, dim3(256), 0, as_stream(stream), X, M, K, W, N, bias, act, alpha, Y);
+    RG_CHECK_LAUNCH("linear(small)");
     return RAGRAPH_OK;
   }
   dim3 grid((unsigned)cdiv(M, LBM), (unsigned)cdiv(N, LBN));

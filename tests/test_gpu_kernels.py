@@ -156,7 +156,7 @@ def test_gather_rows_and_reduce(dev):
                                          # the 128 x 128 tile kernel (M, N >= 128, K % 4 == 0): ragged tiles, K not a
                                          # multiple of the 32-wide chunk, one chunk, many chunks
                                          (300, 128, 256, 2), (129, 36, 130, 1), (128, 4, 128, 0), (1000, 260, 384, 3),
-                                         (257, 1000, 129, 0),
+                                         (257, 1000, 129, 0), (2708, 1433, 128, 2), (31, 257, 17, 3),
                                          # the streaming kernel (M >= 4096, K in {64,128,256}, N in (192,256] per block)
                                          (4096, 128, 256, 2), (4133, 256, 250, 3), (5000, 64, 512, 0), (4100, 128, 700, 1),
                                          (9000, 128, 193, 2)])
