@@ -268,7 +268,8 @@ int ragraph_softmax_mix_f32(const float* logits, const float* rag_label, int64_t
  *     split_and_batchify_graph_feats  -- RAGraph_graph/downprompt.py:98-112, with downstreamprompt's w * h
  *     (downprompt.py:154-168) fused into the pass.
  *     out[g,:] = scale_g * sum_{r in [seg_ptr[g], seg_ptr[g+1])} (w ? w[:] * X[r,:] : X[r,:]),  sequential r, fp32 adds.
- *     mean_mode=1: scale_g = 1/len_g (a division), else 1.  w [D] or NULL.  D % 4 == 0; X, out, w 16-byte aligned. */
+ *     mean_mode=1: scale_g = 1/len_g (a division), else 1.  w [D] or NULL.  Any D >= 1 (float4 lanes when D % 4 == 0 and
+ *     X, out, w are 16-byte aligned, scalar lanes otherwise: same additions in the same order). */
 int ragraph_segment_reduce_f32(const float* X, int D, const int64_t* seg_ptr, int64_t G, const float* w, int mean_mode,
                                float* out, void* stream);
 
@@ -337,12 +338,22 @@ int ragraph_position_code_f32(const float* dist, int n, const int64_t* anchors, 
  *     alpha_terms (optional) receives gy * z on z < 0 (z = y / alpha): its sum is the slope's gradient (layers/gcn.py:9).
  *   sigmoid_gate_grad:  out = x * sigmoid(z) (modules/RAGraph.py:168): gx = g * s, gz = g * x * s * (1 - s).
  *   softmax_grad:  RAGraph_node/RAGraph.py:55-57: out = p * (g - sum_c g_c p_c), g = go * scale (scale = 1 - label_weight).
- *   mul_cols:  out[r,:] = x[r,:] * w  -- downstreamprompt.forward (RAGraph_graph/downprompt.py:164-168); its own backward. */
+ *   mul_cols:  out[r,:] = x[r,:] * w  -- downstreamprompt.forward (RAGraph_graph/downprompt.py:164-168); its own backward.
+ *   mul_cols_act:  out[r,:] = act(x[r,:] * w), act one of RAGRAPH_ACT_* -- the node flavour's downstreamprompt.forward,
+ *     ELU(weight * h) (RAGraph_node/downprompt.py:118-130; alpha = 1); backward = act_grad through the output + mul_cols.
+ *   mul:  out = a * b elementwise -- the prompt weight's gradient is the column sum of g * x (mul + segment_reduce). */
 int ragraph_act_grad_f32(const float* y, const float* gy, int64_t n, int act, float alpha, float* gz, float* alpha_terms,
                          void* stream);
 int ragraph_sigmoid_gate_grad_f32(const float* x, const float* z, const float* g, int64_t n, float* gx, float* gz, void* stream);
 int ragraph_softmax_grad_f32(const float* p, const float* go, int64_t B, int C, float scale, float* out, void* stream);
 int ragraph_mul_cols_f32(const float* x, const float* w, int64_t n, int D, float* out, void* stream);
+int ragraph_mul_cols_act_f32(const float* x, const float* w, int64_t n, int D, int act, float alpha, float* out, void* stream);
+int ragraph_mul_f32(const float* a, const float* b, int64_t n, float* out, void* stream);
+/*   proto_cosine_grad:  gradient of ragraph_proto_cosine_f32 with respect to the embeddings (the prototypes are constants
+ *     of a forward: RAGraph_node/downprompt.py:24,41-46, RAGraph_graph/downprompt.py:41-56).  out = the forward's output
+ *     in the same mode, gout [G,C] -> gemb [G,D]. */
+int ragraph_proto_cosine_grad_f32(const float* emb, int64_t G, int D, const float* proto, int C, int mode, const float* out,
+                                  const float* gout, float* gemb, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Toy-bank construction (the step before the hot path), batched over resource graphs.

@@ -168,6 +168,13 @@ def segment_reduce(X, seg_ptr, w=None, mean_mode=False):
     return out
 
 
+def mul_cols(x, w, act=ACT_NONE, alpha=0.0):
+    x, w = _f32(x), _f32(w).reshape(-1)
+    out = np.empty_like(x)
+    lib().oracle_mul_cols_act(_p(x), _p(w), _c64(x.shape[0]), _ci(x.shape[1]), _ci(act), _cf(alpha), _p(out))
+    return out
+
+
 def axpby(a, wa, b, wb):
     a, b = _f32(a), _f32(b)
     out = np.empty_like(a)

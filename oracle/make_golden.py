@@ -781,6 +781,44 @@ def g15_graph_fewshot():
              built_values=built_values, built_labels=built_labels)
 
 
+def g16_downprompt_node():
+    """Node flavour of the downstream prompt (RAGraph_node/downprompt.py): ELU(w*h), cosine to 3 prototypes, softmax.
+    `averageemb` (downprompt.py:59-78) fills a `torch.FloatTensor(3, n/2, D)` -- UNINITIALISED memory -- and averages
+    over all n/2 slots; the fixture runs it with that constructor returning zeros (the only state in which its result
+    is defined): class sum / floor(n/2)."""
+    with ref_project("RAGraph_node"):
+        import downprompt as dp
+
+        real_ft = torch.FloatTensor
+
+        def zero_ft(*shape):
+            return torch.zeros(*shape, dtype=torch.float32) if all(isinstance(v, int) for v in shape) else real_ft(*shape)
+
+        D, n = 256, 120
+        torch.manual_seed(16)
+        labels = torch.randint(0, 3, (n,), generator=gen(161))
+        feature = torch.randn(1, n, D, generator=gen(162))
+        h = torch.randn(n, D, generator=gen(163))
+        prompts = [torch.randn(1, D, generator=gen(164 + i)) for i in range(3)]
+        torch.FloatTensor = zero_ft
+        try:
+            with torch.no_grad():
+                model = dp.downprompt(prompts[0], prompts[1], prompts[2], D, 3, feature, labels)
+                out = {"h": h, "labels": labels, "feature": feature.squeeze(), "w": model.downprompt.weight,
+                       "ave_init": model.ave, "elu_wh": model.downprompt(h), "probs": model(h, train=0)}
+                ave_inj = torch.randn(3, D, generator=gen(170))
+                model.ave = ave_inj
+                out["ave_injected"], out["probs_injected"] = ave_inj, model(h, train=0)
+                out["probs_train"] = model(h, train=1)
+                out["ave_train"] = model.ave
+                out["weighted_prompt"] = model.nodelabelprompt(model.prompt)
+                out["weighted_feature"] = model.dffprompt(h, feature.squeeze())
+                out["prompt"] = model.prompt
+        finally:
+            torch.FloatTensor = real_ft
+        save("g16_downprompt_node", **out)
+
+
 def main():
     assert os.path.isdir(REF), "the reference is only mounted in the build container"
     _install_shims()
@@ -797,6 +835,7 @@ def main():
     g13_bank_build()
     g14_ingestion()
     g15_graph_fewshot()
+    g16_downprompt_node()
 
 
 if __name__ == "__main__":

@@ -111,6 +111,23 @@ def downprompt_logits(h, w, graph_len, proto, log_softmax=True):
     return cref.proto_cosine(emb, proto, mode=2 if log_softmax else 0), emb
 
 
+def downprompt_node_averageemb(labels, rawret):
+    """RAGraph_node/downprompt.py:59-78 with a zero-filled buffer: class sums (rows in index order) / floor(n/2)."""
+    labels = np.asarray(labels).reshape(-1)
+    rawret = np.asarray(rawret, dtype=np.float32)
+    order = np.concatenate([np.nonzero(labels == c)[0] for c in range(3)])
+    seg = np.concatenate([[0], np.cumsum([(labels == c).sum() for c in range(3)])]).astype(np.int64)
+    sums = cref.segment_reduce(rawret[order], seg)
+    half = int(rawret.shape[0] / 2)
+    return cref.mul_cols(sums, np.full(rawret.shape[1], np.float32(1.0) / np.float32(half), dtype=np.float32))
+
+
+def downprompt_node_forward(h, w, ave):
+    """RAGraph_node/downprompt.py:25-46: ELU(w * h) (:118-130) -> cosine to ave[0..2] -> softmax(dim=1)."""
+    rawret = cref.mul_cols(h, w, cref.ACT_ELU, 1.0)
+    return cref.proto_cosine(rawret, ave, mode=1), rawret
+
+
 def fewshot_scores(search_keys, adj_dense, anchors, keys, positions, structure_weight=0.001, semantic_weight=0.999,
                    dis_q=10.0):
     """RAGraph_node_fewshot/ragraph_utils/ToyGraphBase.py:47-61: w_s * cos(position codes) + w_m * cos(embeddings)."""

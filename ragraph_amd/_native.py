@@ -77,6 +77,9 @@ SIGNATURES = {
     "ragraph_sigmoid_gate_grad_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "ragraph_softmax_grad_f32": (_i32, [_vp, _vp, _i64, _i32, _f32, _vp, _vp]),
     "ragraph_mul_cols_f32": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "ragraph_mul_cols_act_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp]),
+    "ragraph_mul_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "ragraph_proto_cosine_grad_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ragraph_ingest_workspace_bytes": (_sz, [_i64, _i64]),
     "ragraph_csr_sym_normalized_f32": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ragraph_binorm_edges_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -41,10 +41,7 @@ class _Linear(torch.autograd.Function):
             gw = K.linear(gy.t().contiguous(), x.t().contiguous())     # gy^T @ x
         if ctx.has_bias and ctx.needs_input_grad[2]:
             seg = torch.tensor([0, gy.shape[0]], dtype=torch.int64, device=gy.device)
-            if gy.shape[1] % 4 == 0:
-                gb = K.segment_reduce(gy, seg).reshape(-1)
-            else:
-                gb = gy.sum(0)
+            gb = K.segment_reduce(gy, seg).reshape(-1)
         return gx, gw, gb, None, None
 
 
@@ -193,5 +190,60 @@ def gather_rows(v, idx):
     return K.gather_rows(v, idx)
 
 
-def mul_cols(x, w):
-    return K.mul_cols(x, w)
+class _MulCols(torch.autograd.Function):
+    """y = act(x * w), w one weight per column -- downstreamprompt.forward (RAGraph_graph/downprompt.py:164-168; ELU in
+    RAGraph_node/downprompt.py:118-130).  gz = gy * act'(z) through the output (ELU: y > 0 ? 1 : y + alpha);
+    gx = gz * w; gw = column sums of gz * x, rows added in order (segment_reduce: deterministic)."""
+
+    @staticmethod
+    def forward(ctx, x, w, act, alpha):
+        y = K.mul_cols(x, w, act, alpha)
+        ctx.save_for_backward(x, w, y)
+        ctx.act, ctx.alpha = act, alpha
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        gz = gy.contiguous()
+        if ctx.act != K.ACT_NONE:
+            gz = K.act_grad(y, gz, ctx.act, ctx.alpha)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = K.mul_cols(gz, w)
+        if ctx.needs_input_grad[1]:
+            D = x.shape[-1]
+            prod = K.mul(gz.reshape(-1, D), x.reshape(-1, D))
+            seg = torch.tensor([0, prod.shape[0]], dtype=torch.int64, device=prod.device)
+            gw = K.segment_reduce(prod, seg).reshape(w.shape)
+        return gx, gw, None, None
+
+
+def mul_cols(x, w, act=K.ACT_NONE, alpha=0.0):
+    if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+        return _MulCols.apply(x, w, act, alpha)
+    return K.mul_cols(x, w, act, alpha)
+
+
+
+class _ProtoCosine(torch.autograd.Function):
+    """f(cosine(emb_g, proto_c)), f = identity / softmax / log_softmax (downprompt.py:41-56 graph flavour,
+    RAGraph_node/downprompt.py:41-46).  The prototypes are constants of a forward; the gradient goes to the embeddings."""
+
+    @staticmethod
+    def forward(ctx, emb, proto, mode):
+        out = K.proto_cosine(emb, proto, mode)
+        ctx.save_for_backward(emb, proto, out)
+        ctx.mode = mode
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        emb, proto, out = ctx.saved_tensors
+        return K.proto_cosine_grad(emb, proto, ctx.mode, out, go.contiguous()), None, None
+
+
+def proto_cosine(emb, proto, mode=0):
+    if torch.is_grad_enabled() and emb.requires_grad:
+        return _ProtoCosine.apply(emb, proto.detach(), mode)
+    return K.proto_cosine(emb, proto, mode)

@@ -196,11 +196,20 @@ __global__ void __launch_bounds__(256) softmax_grad_kernel(const float* __restri
   for (int c = 0; c < C; ++c) out[b * C + c] = p[b * C + c] * (go[b * C + c] * scale - dot);
 }
 
-// downstreamprompt.forward (RAGraph_graph/downprompt.py:164-168): out[r,:] = x[r,:] * w[:]
+// downstreamprompt.forward: out[r,:] = act(x[r,:] * w[:]) -- act none in the graph flavour (RAGraph_graph/downprompt.py:
+// 164-168), ELU in the node flavour (RAGraph_node/downprompt.py:118-130)
 __global__ void __launch_bounds__(256) mul_cols_kernel(const float* __restrict__ x, const float* __restrict__ w, int64_t n, int D,
-                                                       float* __restrict__ out) {
+                                                       int act, float alpha, float* __restrict__ out) {
   const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n * D; i += stride) out[i] = __fmul_rn(x[i], w[i % D]);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n * D; i += stride)
+    out[i] = apply_act(__fmul_rn(x[i], w[i % D]), act, alpha);
+}
+
+// elementwise product (the prompt weight's gradient = column sums of g * x: mul + segment_reduce)
+__global__ void __launch_bounds__(256) mul_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                  float* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = __fmul_rn(a[i], b[i]);
 }
 
 // ---- a12: (t - t_min) / (t_max - t_min) on int64 time steps (RAGraph_edge/modules/RAGraph.py:254-257) ----------------
@@ -276,6 +285,67 @@ __global__ void __launch_bounds__(256) proto_cosine_kernel(const float* __restri
     myv = (mode == 1) ? ex / s : (v - m) - logf(s);
   }
   if (lane < C) out[g * C + lane] = myv;
+}
+
+// Backward of proto_cosine with respect to the EMBEDDINGS (the prototypes are constants of a forward,
+// RAGraph_node/downprompt.py:24,41-46): out = f(cos), f = identity / softmax / log_softmax;
+//   gcos_c = go_c                          (mode 0)
+//          = p_c (go_c - sum_j go_j p_j)   (mode 1, p = out)
+//          = go_c - exp(out_c) sum_j go_j  (mode 2)
+//   gemb[e] = sum_c gcos_c (p_c[e] / (|x| |p_c|) - cos_c x[e] / |x|^2).   One wave per embedding.
+__global__ void __launch_bounds__(256) proto_cosine_grad_kernel(const float* __restrict__ emb, int64_t G, int D,
+                                                                const float* __restrict__ proto, int C, int mode,
+                                                                const float* __restrict__ out,
+                                                                const float* __restrict__ gout,
+                                                                float* __restrict__ gemb) {
+  const int lane = threadIdx.x & 63;
+  const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= G) return;
+  const float* x = emb + g * D;
+  float xx = 0.f;
+  for (int e = lane; e < D; e += 64) xx = fmaf(x[e], x[e], xx);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) xx = __fadd_rn(xx, __shfl_xor(xx, off));
+  const float nx = fmaxf(sqrtf(xx), 1e-8f);
+  const float o = (lane < C) ? out[g * C + lane] : 0.f;
+  const float go = (lane < C) ? gout[g * C + lane] : 0.f;
+  float gc = go;
+  if (mode == 1) {
+    float dot = go * o;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) dot += __shfl_xor(dot, off);
+    gc = o * (go - dot);
+  } else if (mode == 2) {
+    float sum = go;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    gc = go - expf(o) * sum;
+  }
+  float sx = 0.f;  // sum_c gcos_c cos_c / |x|^2
+  for (int e0 = 0; e0 < D; e0 += 64) {
+    const int e = e0 + lane;
+    if (e < D) gemb[g * D + e] = 0.f;
+  }
+  for (int c = 0; c < C; ++c) {
+    const float* pc = proto + (int64_t)c * D;
+    float xy = 0.f, yy = 0.f;
+    for (int e = lane; e < D; e += 64) {
+      xy = fmaf(x[e], pc[e], xy);
+      yy = fmaf(pc[e], pc[e], yy);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      xy = __fadd_rn(xy, __shfl_xor(xy, off));
+      yy = __fadd_rn(yy, __shfl_xor(yy, off));
+    }
+    const float np = fmaxf(sqrtf(yy), 1e-8f);
+    const float cs = xy / (nx * np);
+    const float gcc = __shfl(gc, c);
+    sx += gcc * cs / (nx * nx);
+    const float a = gcc / (nx * np);
+    for (int e = lane; e < D; e += 64) gemb[g * D + e] += a * pc[e];
+  }
+  for (int e = lane; e < D; e += 64) gemb[g * D + e] -= sx * x[e];
 }
 
 }  // namespace ragraph
@@ -387,6 +457,18 @@ extern "C" int ragraph_proto_cosine_f32(const float* emb, int64_t G, int D, cons
   return RAGRAPH_OK;
 }
 
+extern "C" int ragraph_proto_cosine_grad_f32(const float* emb, int64_t G, int D, const float* proto, int C, int mode,
+                                             const float* out, const float* gout, float* gemb, void* stream) {
+  RG_REQUIRE(emb && proto && out && gout && gemb, RAGRAPH_EINVAL, "proto_cosine_grad: null pointer");
+  RG_REQUIRE(C >= 1 && C <= 64, RAGRAPH_EUNSUPPORTED, "proto_cosine_grad: C=%d not in [1,64]", C);
+  RG_REQUIRE(D >= 1 && mode >= 0 && mode <= 2, RAGRAPH_EINVAL, "proto_cosine_grad: bad D/mode");
+  if (G <= 0) return RAGRAPH_OK;
+  hipLaunchKernelGGL(proto_cosine_grad_kernel, dim3((unsigned)cdiv(G, 4)), dim3(256), 0, as_stream(stream), emb, G, D,
+                     proto, C, mode, out, gout, gemb);
+  RG_CHECK_LAUNCH("proto_cosine_grad");
+  return RAGRAPH_OK;
+}
+
 extern "C" int ragraph_sigmoid_gate_f32(const float* x, const float* z, int64_t n, float* out, void* stream) {
   RG_REQUIRE(x && z && out, RAGRAPH_EINVAL, "sigmoid_gate: null pointer");
   if (n <= 0) return RAGRAPH_OK;
@@ -441,10 +523,24 @@ extern "C" int ragraph_softmax_grad_f32(const float* p, const float* go, int64_t
   return RAGRAPH_OK;
 }
 
-extern "C" int ragraph_mul_cols_f32(const float* x, const float* w, int64_t n, int D, float* out, void* stream) {
+extern "C" int ragraph_mul_cols_act_f32(const float* x, const float* w, int64_t n, int D, int act, float alpha, float* out,
+                                        void* stream) {
   RG_REQUIRE(x && w && out && D >= 1, RAGRAPH_EINVAL, "mul_cols: bad argument");
+  RG_REQUIRE(act >= RAGRAPH_ACT_NONE && act <= RAGRAPH_ACT_ELU, RAGRAPH_EINVAL, "mul_cols: unknown activation %d", act);
   if (n <= 0) return RAGRAPH_OK;
-  hipLaunchKernelGGL(mul_cols_kernel, dim3(ew_blocks(n * D)), dim3(256), 0, as_stream(stream), x, w, n, D, out);
+  hipLaunchKernelGGL(mul_cols_kernel, dim3(ew_blocks(n * D)), dim3(256), 0, as_stream(stream), x, w, n, D, act, alpha, out);
   RG_CHECK_LAUNCH("mul_cols");
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_mul_cols_f32(const float* x, const float* w, int64_t n, int D, float* out, void* stream) {
+  return ragraph_mul_cols_act_f32(x, w, n, D, RAGRAPH_ACT_NONE, 0.f, out, stream);
+}
+
+extern "C" int ragraph_mul_f32(const float* a, const float* b, int64_t n, float* out, void* stream) {
+  RG_REQUIRE(a && b && out, RAGRAPH_EINVAL, "mul: null pointer");
+  if (n <= 0) return RAGRAPH_OK;
+  hipLaunchKernelGGL(mul_kernel, dim3(ew_blocks(n)), dim3(256), 0, as_stream(stream), a, b, n, out);
+  RG_CHECK_LAUNCH("mul");
   return RAGRAPH_OK;
 }

@@ -325,6 +325,27 @@ __global__ void __launch_bounds__(256) segment_reduce_kernel(const float* __rest
   }
 }
 
+// The same for any D / alignment: thread t owns columns t, t+256, ...; identical additions in identical order.
+__global__ void __launch_bounds__(256) segment_reduce_scalar_kernel(const float* __restrict__ X, int D,
+                                                                    const int64_t* __restrict__ seg_ptr,
+                                                                    const float* __restrict__ w, int mean_mode,
+                                                                    float* __restrict__ out) {
+  const int64_t g = blockIdx.x;
+  const int64_t r0 = seg_ptr[g], r1 = seg_ptr[g + 1];
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float acc = 0.f;
+    const float wv = w ? w[c] : 1.f;
+#pragma unroll 8
+    for (int64_t r = r0; r < r1; ++r) {
+      float x = X[r * D + c];
+      if (w) x = __fmul_rn(wv, x);
+      acc = __fadd_rn(acc, x);
+    }
+    if (mean_mode) acc = acc / (float)(r1 - r0);
+    out[g * D + c] = acc;
+  }
+}
+
 }  // namespace ragraph
 
 using namespace ragraph;
@@ -466,11 +487,14 @@ extern "C" int ragraph_segment_softmax_f32(const int64_t* rowptr, const float* x
 extern "C" int ragraph_segment_reduce_f32(const float* X, int D, const int64_t* seg_ptr, int64_t G, const float* w,
                                           int mean_mode, float* out, void* stream) {
   RG_REQUIRE(X && seg_ptr && out, RAGRAPH_EINVAL, "segment_reduce: null pointer");
-  RG_REQUIRE(D >= 4 && (D & 3) == 0, RAGRAPH_EINVAL, "segment_reduce: D=%d must be a positive multiple of 4", D);
-  RG_REQUIRE(aligned16(X) && aligned16(out) && (!w || aligned16(w)), RAGRAPH_EINVAL, "segment_reduce: 16-B alignment");
+  RG_REQUIRE(D >= 1, RAGRAPH_EINVAL, "segment_reduce: D=%d must be positive", D);
   if (G <= 0) return RAGRAPH_OK;
-  hipLaunchKernelGGL(segment_reduce_kernel, dim3((unsigned)G), dim3(256), 0, as_stream(stream), X, D, seg_ptr, w,
-                     mean_mode, out);
+  if ((D & 3) == 0 && aligned16(X) && aligned16(out) && (!w || aligned16(w)))
+    hipLaunchKernelGGL(segment_reduce_kernel, dim3((unsigned)G), dim3(256), 0, as_stream(stream), X, D, seg_ptr, w,
+                       mean_mode, out);
+  else
+    hipLaunchKernelGGL(segment_reduce_scalar_kernel, dim3((unsigned)G), dim3(256), 0, as_stream(stream), X, D, seg_ptr, w,
+                       mean_mode, out);
   RG_CHECK_LAUNCH("segment_reduce");
   return RAGRAPH_OK;
 }

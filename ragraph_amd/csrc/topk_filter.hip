@@ -1531,8 +1531,17 @@ static size_t filter_ws_carve(char* w, int64_t B, int D, int k, int cap, struct 
 extern "C" size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_t N, int D, int k) {
   if (B < 1 || N < 1 || k < 1 || !filter_dim_ok(D)) return 0;
   const int cap = filter_cap(B, k);
-  const FilterSchedule sc = filter_schedule(B, N, D, k);
-  return filter_level0_ws(sc, B, D, k) + filter_ws_carve(nullptr, B, D, k, cap, nullptr);
+  // run_filtered may turn the planned bound pass into an exact level 0 (a shard shorter than twice the prefix, a shard's
+  // share of a pooled sample, the schedule switches): size for whichever of the two needs more, and run_filtered checks
+  // the schedule it really runs against ws_bytes before carving
+  FilterSchedule sc = filter_schedule(B, N, D, k);
+  size_t level0 = filter_level0_ws(sc, B, D, k);
+  if (sc.bound_keys > 0) {
+    sc.bound_keys = 0;
+    const size_t exact0 = filter_level0_ws(sc, B, D, k);
+    if (exact0 > level0) level0 = exact0;
+  }
+  return level0 + filter_ws_carve(nullptr, B, D, k, cap, nullptr);
 }
 
 extern "C" int ragraph_topk_cosine_filtered_plan(int64_t B, int64_t N, int D, int k, int64_t plan[7]) {
@@ -1758,8 +1767,8 @@ static int run_rescore(const FilterWs& f, const float* Kn, int64_t N, int64_t B,
 template <int D>
 static int run_filtered(const float* Q, int64_t B, const float* Kn, const float* Kp, const uint16_t* Kb, int64_t N, int k,
                         int64_t idx_base, float* out_scores, int64_t* out_idx, int* overflow, int64_t* overflow_idx,
-                        void* ws, void* stream, int64_t plan_N, float* theta, ragraph_exchange_fn exchange, void* ctx,
-                        int n_shards) {
+                        void* ws, size_t ws_bytes, void* stream, int64_t plan_N, float* theta, ragraph_exchange_fn exchange,
+                        void* ctx, int n_shards) {
   hipStream_t st = as_stream(stream);
   const int cap = filter_cap(B, k);
   FilterSchedule sc = filter_schedule(B, plan_N, D, k, exchange ? n_shards : 1);  // (sharded banks: the same schedule on every shard)
@@ -1781,7 +1790,9 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   char* w = static_cast<char*>(ws);
   const size_t sample_ws = filter_level0_ws(sc, B, D, k);
   FilterWs f;
-  filter_ws_carve(w + sample_ws, B, D, k, cap, &f);
+  const size_t used = sample_ws + filter_ws_carve(w + sample_ws, B, D, k, cap, &f);
+  RG_REQUIRE(used <= ws_bytes, RAGRAPH_EWORKSPACE, "topk_cosine_filtered: the schedule of this call needs %zu bytes of workspace, "
+             "%zu given", used, ws_bytes);
   const unsigned* max_kerr2 = reinterpret_cast<const unsigned*>(Kb + filter_round_up(N) * D);
   const bool bound = sc.bound_keys > 0;
 
@@ -1880,13 +1891,13 @@ static int filtered_entry(const float* Q, int64_t B, const float* Kn, const floa
   const size_t need = ragraph_topk_cosine_filtered_workspace_bytes(B, plan_N, D, k);
   RG_REQUIRE(ws_bytes >= need, RAGRAPH_EWORKSPACE, "topk_cosine_filtered: workspace %zu < %zu", ws_bytes, need);
   if (D == 256)
-    return run_filtered<256>(Q, B, Kn, Kp, Kb, N, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, stream, plan_N,
-                             theta, exchange, ctx, n_shards);
+    return run_filtered<256>(Q, B, Kn, Kp, Kb, N, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, ws_bytes, stream,
+                             plan_N, theta, exchange, ctx, n_shards);
   if (D == 128)
-    return run_filtered<128>(Q, B, Kn, Kp, Kb, N, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, stream, plan_N,
-                             theta, exchange, ctx, n_shards);
-  return run_filtered<64>(Q, B, Kn, Kp, Kb, N, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, stream, plan_N,
-                          theta, exchange, ctx, n_shards);
+    return run_filtered<128>(Q, B, Kn, Kp, Kb, N, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, ws_bytes, stream,
+                             plan_N, theta, exchange, ctx, n_shards);
+  return run_filtered<64>(Q, B, Kn, Kp, Kb, N, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, ws_bytes, stream,
+                          plan_N, theta, exchange, ctx, n_shards);
 }
 
 extern "C" int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const float* Kn, const float* Kp,

@@ -4,6 +4,7 @@ become two kernels: segment_reduce (prompt multiply fused into the sum) and prot
 import torch
 import torch.nn as nn
 
+from . import autograd as AG
 from . import kernels as K
 
 
@@ -14,7 +15,7 @@ class downstreamprompt(nn.Module):
         torch.nn.init.xavier_uniform_(self.weight)     # downprompt.py:160-161
 
     def forward(self, graph_embedding):                # downprompt.py:164-168: weight * h
-        return K.mul_cols(graph_embedding, self.weight)   # (the fused form is split_and_batchify(..., weight))
+        return AG.mul_cols(graph_embedding, self.weight)  # (inference's fused form: split_and_batchify(..., weight))
 
 
 def split_and_batchify_graph_feats(batched_graph_feats, graph_sizes, weight=None):
@@ -33,15 +34,13 @@ def predict(graphnum, nb_classes, rawret, ave):
 def averageemb(labels, rawret, nb_class):
     """Class-mean prototypes.  The reference (downprompt.py:59-94) averages over an UNINITIALISED [C, n, D] buffer, so
     its result is garbage-dependent; this is the evident intent: mean of the rows of each class."""
-    out = torch.zeros(nb_class, rawret.shape[1], device=rawret.device)
     lab = labels.reshape(-1).long().to(rawret.device)
     order = torch.sort(lab, stable=True).indices
     counts = torch.bincount(lab, minlength=nb_class)
     seg = torch.zeros(nb_class + 1, dtype=torch.int64, device=rawret.device)
     seg[1:] = torch.cumsum(counts, 0)
-    if rawret.shape[1] % 4 == 0:
-        out = K.segment_reduce(K.gather_rows(rawret, order), seg, mean_mode=True)
-        out[counts == 0] = 0
+    out = K.segment_reduce(K.gather_rows(rawret, order), seg, mean_mode=True)    # any D
+    out[counts == 0] = 0                                                          # (0 / 0 of an empty class)
     return out
 
 

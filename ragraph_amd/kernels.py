@@ -70,16 +70,23 @@ def normalize_rows(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Te
     return out.reshape(x.shape)
 
 
-_ws_cache: dict = {}
+_ws_cache: dict = {}      # insertion-ordered: least recently used first
+_WS_CACHE_MAX = 8
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
-    """One grow-only scratch buffer per (device, stream): calls on a stream are ordered, so reuse is safe."""
-    key = (device, _stream())
-    ws = _ws_cache.get(key)
+    """One grow-only scratch buffer per (device index, current stream OF THAT DEVICE): calls on a stream are ordered, so
+    reuse is safe.  The cache is bounded (least recently used entry dropped; torch's allocator keeps a dropped buffer
+    alive until the work already enqueued on its stream has used it)."""
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    stream = _raw_stream(dev) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream
+    key = (dev, stream)
+    ws = _ws_cache.pop(key, None)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _ws_cache[key] = ws
+    _ws_cache[key] = ws
+    while len(_ws_cache) > _WS_CACHE_MAX:
+        _ws_cache.pop(next(iter(_ws_cache)))
     return ws
 
 
@@ -458,6 +465,18 @@ def proto_cosine(emb: torch.Tensor, proto: torch.Tensor, mode: int = 0) -> torch
     return out
 
 
+def proto_cosine_grad(emb: torch.Tensor, proto: torch.Tensor, mode: int, out: torch.Tensor, gout: torch.Tensor):
+    """Gradient of proto_cosine with respect to `emb` (prototypes constant)."""
+    L = _ready()
+    emb, proto = _f32c(emb, "proto_cosine_grad.emb"), _f32c(proto, "proto_cosine_grad.proto")
+    out, gout = _f32c(out, "proto_cosine_grad.out"), _f32c(gout, "proto_cosine_grad.gout")
+    G, D = emb.shape
+    gemb = torch.empty_like(emb)
+    N.check(L.ragraph_proto_cosine_grad_f32(emb.data_ptr(), G, D, proto.data_ptr(), proto.shape[0], mode, out.data_ptr(),
+                                            gout.data_ptr(), gemb.data_ptr(), _stream()), "proto_cosine_grad")
+    return gemb
+
+
 def topk_rows(scores: torch.Tensor, k: int):
     """torch.topk(scores, k) over a materialised [B,N] matrix, canonical tie order -- few-shot retrieve
     (RAGraph_node_fewshot/.../ToyGraphBase.py:64), edge evaluation (RAGraph_edge/utils/metrics.py:116)."""
@@ -713,12 +732,27 @@ def softmax_grad(p: torch.Tensor, go: torch.Tensor, scale: float = 1.0) -> torch
     return out.reshape(p.shape)
 
 
-def mul_cols(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    """x[r,:] * w -- downstreamprompt.forward (RAGraph_graph/downprompt.py:164-168)."""
+def mul_cols(x: torch.Tensor, w: torch.Tensor, act: int = ACT_NONE, alpha: float = 0.0) -> torch.Tensor:
+    """act(x[r,:] * w) -- downstreamprompt.forward: plain in the graph flavour (RAGraph_graph/downprompt.py:164-168), ELU
+    in the node flavour (RAGraph_node/downprompt.py:118-130)."""
     L = _ready()
     x = _f32c(x, "mul_cols.x")
     w = _f32c(w, "mul_cols.w").reshape(-1)
+    if w.numel() != x.shape[-1]:
+        raise RagraphNativeError(f"mul_cols: weight of {w.numel()} values for rows of {x.shape[-1]}")
     x2 = x.reshape(-1, x.shape[-1])
     out = torch.empty_like(x2)
-    N.check(L.ragraph_mul_cols_f32(x2.data_ptr(), w.data_ptr(), x2.shape[0], x2.shape[1], out.data_ptr(), _stream()), "mul_cols")
+    N.check(L.ragraph_mul_cols_act_f32(x2.data_ptr(), w.data_ptr(), x2.shape[0], x2.shape[1], int(act), float(alpha),
+                                       out.data_ptr(), _stream()), "mul_cols")
     return out.reshape(x.shape)
+
+
+def mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a * b elementwise (same shape)."""
+    L = _ready()
+    a, b = _f32c(a, "mul.a"), _f32c(b, "mul.b")
+    if a.shape != b.shape:
+        raise RagraphNativeError(f"mul: shapes {tuple(a.shape)} and {tuple(b.shape)} differ")
+    out = torch.empty_like(a)
+    N.check(L.ragraph_mul_f32(a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), _stream()), "mul")
+    return out

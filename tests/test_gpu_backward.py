@@ -225,3 +225,40 @@ def test_edge_cal_loss_gradients_match_torch(dev):
     assert abs(float(loss) - float(ref)) < 1e-5
     for k in names:
         assert close(got[k], P[k].grad, 2e-4), k
+
+
+
+@pytest.mark.parametrize("flavour", ["node", "graph"])
+def test_downprompt_weight_gradients_match_torch(dev, flavour):
+    """The prompt weight is the trainable parameter of downstreamprompt (RAGraph_node/downprompt.py:118-130 with ELU,
+    RAGraph_graph/downprompt.py:154-168 without): its gradient through the cosine-to-prototype head, against torch
+    autograd of the reference's formula."""
+    import torch.nn.functional as F
+    from ragraph_amd import autograd as AG
+    from ragraph_amd import downprompt as dpg
+    from ragraph_amd import downprompt_node as dpn
+
+    torch.manual_seed(3)
+    n, D = 83, 256 if flavour == "node" else 30
+    h = torch.randn(n, D, device=dev)
+    ave = torch.randn(3, D, device=dev)
+    tgt = torch.randint(0, 3, (n,), device=dev)
+    mod = (dpn.downstreamprompt(D) if flavour == "node" else dpg.downstreamprompt(D)).to(dev)
+    hq = h.clone().requires_grad_(True)
+    raw = mod(hq)
+    assert raw.grad_fn is not None
+    mode = 1 if flavour == "node" else 2
+    out = AG.proto_cosine(raw, ave, mode)
+    loss = F.nll_loss(torch.log(out) if mode == 1 else out, tgt)
+    loss.backward()
+    w_ref = mod.weight.detach().clone().requires_grad_(True)
+    h_ref = h.clone().requires_grad_(True)
+    z = w_ref * h_ref
+    raw_ref = F.elu(z) if flavour == "node" else z
+    cos = F.cosine_similarity(raw_ref[:, None, :], ave[None, :, :], dim=-1, eps=1e-8)
+    out_ref = F.softmax(cos, 1) if mode == 1 else F.log_softmax(cos, 1)
+    loss_ref = F.nll_loss(torch.log(out_ref) if mode == 1 else out_ref, tgt)
+    loss_ref.backward()
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    assert torch.allclose(mod.weight.grad, w_ref.grad, atol=1e-5), (mod.weight.grad - w_ref.grad).abs().max()
+    assert torch.allclose(hq.grad, h_ref.grad, atol=1e-5)

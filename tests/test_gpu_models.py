@@ -232,6 +232,62 @@ def test_downprompt_g10(dev):
         assert np.allclose(lp.cpu().numpy(), g[f"logp_c{C}"], atol=1e-5)
 
 
+def test_downprompt_node_g16(dev):
+    """Node flavour (RAGraph_node/downprompt.py:6-48,59-78,80-130) against the reference's own outputs and the oracle."""
+    from ragraph_amd import downprompt_node as dpn
+    from ragraph_amd import kernels as K
+
+    g = gold("g16_downprompt_node")
+    pr = T(g["prompt"], dev)
+    m = dpn.downprompt(pr[0:1], pr[1:2], pr[2:3], 256, 3, T(g["feature"], dev).unsqueeze(0), T(g["labels"], dev)).to(dev)
+    with torch.no_grad():
+        m.downprompt.weight.copy_(T(g["w"], dev))
+    h = T(g["h"], dev)
+    o_ave = pipeline.downprompt_node_averageemb(g["labels"], g["feature"])
+    assert np.array_equal(m.ave.cpu().numpy(), o_ave)                           # bit-exact vs the oracle
+    assert np.allclose(m.ave.cpu().numpy(), g["ave_init"], rtol=1e-5, atol=1e-6)
+    with torch.no_grad():
+        raw = m.downprompt(h)
+        probs = m(h, train=0)
+    o_probs, o_raw = pipeline.downprompt_node_forward(g["h"], g["w"], o_ave)
+    assert np.allclose(raw.cpu().numpy(), o_raw, atol=1e-6) and np.allclose(raw.cpu().numpy(), g["elu_wh"], atol=1e-6)
+    assert np.array_equal(np.maximum(raw.cpu().numpy(), 0), np.maximum(o_raw, 0))   # positive side: no expm1, same bits
+    assert np.allclose(probs.cpu().numpy(), o_probs, atol=1e-6)
+    assert np.allclose(probs.cpu().numpy(), g["probs"], atol=1e-6)
+    m.ave = T(g["ave_injected"], dev)
+    with torch.no_grad():
+        assert np.allclose(m(h, train=0).cpu().numpy(), g["probs_injected"], atol=1e-6)
+        assert np.allclose(m(h, train=1).cpu().numpy(), g["probs_train"], atol=1e-6)
+    assert np.allclose(m.ave.cpu().numpy(), g["ave_train"], rtol=1e-5, atol=1e-6)
+    with torch.no_grad():
+        assert np.allclose(m.nodelabelprompt(m.prompt).cpu().numpy(), g["weighted_prompt"], atol=1e-6)
+        assert np.allclose(m.dffprompt(h, T(g["feature"], dev)).cpu().numpy(), g["weighted_feature"], atol=1e-6)
+    # a class that does not fit the reference's [3, n/2, D] buffer: IndexError there, IndexError here
+    with pytest.raises(IndexError):
+        dpn.averageemb(torch.zeros(10, dtype=torch.int64, device=dev), h[:10])
+
+
+@pytest.mark.parametrize("D", [256, 30, 7])
+def test_averageemb_any_width(dev, D):
+    """Graph flavour's class means for embedding widths that are not multiples of 4 (round 2 returned zeros)."""
+    from ragraph_amd import downprompt as dp
+
+    rng = np.random.default_rng(D)
+    x = rng.standard_normal((57, D)).astype(np.float32)
+    lab = rng.integers(0, 4, 57)
+    lab[lab == 2] = 3                                                          # class 2 is empty
+    out = dp.averageemb(T(lab, dev), T(x, dev), 5).cpu().numpy()
+    for c in range(5):
+        rows = x[lab == c]
+        if len(rows) == 0:
+            assert not out[c].any()
+            continue
+        acc = np.zeros(D, dtype=np.float32)
+        for r in rows:
+            acc = acc + r
+        assert np.array_equal(out[c], acc / np.float32(len(rows)))
+
+
 def test_bank_build_and_finetune_step(dev):
     """The reference's driver loop in miniature (finetune-rag.py:57-84): build the bank from a resource dataset, one
     Adam step on the decoder, loss decreases; retrieving a stored key returns that key first."""

@@ -122,6 +122,19 @@ def test_g10_downprompt():
         assert np.allclose(logp, g[f"logp_c{C}"], atol=1e-5)
 
 
+def test_g16_downprompt_node():
+    g = gold("g16_downprompt_node")
+    ave = pipeline.downprompt_node_averageemb(g["labels"], g["feature"])
+    assert np.allclose(ave, g["ave_init"], rtol=1e-5, atol=1e-6)
+    probs, rawret = pipeline.downprompt_node_forward(g["h"], g["w"], g["ave_init"])
+    assert np.allclose(rawret, g["elu_wh"], atol=1e-6)
+    assert np.allclose(probs, g["probs"], atol=1e-6)
+    assert np.allclose(pipeline.downprompt_node_forward(g["h"], g["w"], g["ave_injected"])[0], g["probs_injected"], atol=1e-6)
+    ave_t = pipeline.downprompt_node_averageemb(g["labels"], rawret)           # train=1: prototypes from this batch
+    assert np.allclose(ave_t, g["ave_train"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(cref.proto_cosine(rawret, ave_t, mode=1), g["probs_train"], atol=1e-6)
+
+
 def test_g8_fewshot_structural_retrieve():
     g = gold("g8_fewshot_retrieve")
     assert np.array_equal(cref.floyd_warshall(g["adj"]), g["dist"])          # min-plus closure: exact
