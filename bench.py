@@ -8,17 +8,24 @@ value = retrieved queries (= nodes) per second, whole job; the timed region is e
 
 N > 1 (one rank per GPU; `python bench.py --gpus N` starts the ranks itself when no launcher did): strong scaling on the
 metric's own 1M-key bank.  Default layout = north_star's: the KEY BANK is row-sharded, every rank scores all queries
-against its shard with thresholds sharpened by two tiny exchanges (an all_reduce(MAX) of the per-query first bound, an
-all_gather of each rank's best few scores per level), then ONE all_gather of the per-shard top-k and a canonical merge
-(ragraph_amd/sharded.py); values / labels are replicated (1 GB), the cheap GNN part runs on every rank.  The other
+against its shard, and between the phases of that call (first bound, every filter level) the ranks pool their bounds: an
+all_gather of each rank's best m = 2 ceil(k/G) lower bounds per query + the k-th largest of the union
+(ragraph_theta_sharpen_f32), so a shard filters with (nearly) the global threshold.  The tail is query-sharded: ONE
+all_to_all carries the per-shard lists of a rank's rows to it, the canonical merge, value gathers, last hop and decoder
+run on B/G rows, and one all_gather of the [n, C] outputs completes the step (ragraph_amd/sharded.py,
+RAGraph._forward_key_shard); values / labels are replicated (1 GB), the cheap GNN part runs on every rank.  The other
 layout (bank replicated, QUERY batch split, no data-path collective) is timed right after and reported as
-`query_sharded`; `--shard queries` makes it the headline instead.
+`query_sharded`; `--shard queries` makes it the headline instead.  `--backend gloo` runs the same job over gloo (device
+tensors staged through the host: two ranks on ONE GPU, tests/test_gpu_two_rank.py).
+
+After the timed region (outside it) the step's retrieval is CHECKED: a fixed sample of 64 of the queries is re-scored on
+the exact fp32 kernel (same indices and score bits required) and 4 of them against the CPU oracle (`verified`).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` for the dominant kernel (the bf16 MFMA
 filter of the exact top-k) and, at N = 1, next to the timed region: `retrieval_small_batch` (the reference's real batch
-sizes, B = 1 / 16 / 256 / 4096, HBM-bound up to a few hundred queries), `exact_fp32` (the same step on the fp32 MFMA
-kernels alone), `gnn_fwd_nodes_per_s`, and `cpu_baseline` (the torch-CPU port of the reference's op chain,
-oracle/ref_torch.py: 3 warm-ups + 5 repetitions of a 1024-query slab, median, plus the 'fair' pre-normalised-bank row).
+sizes, B = 1 / 16 / 256 / 512 / 4096, HBM-bound up to a few hundred queries), `exact_fp32` (the same step on the fp32
+MFMA kernels alone), `gnn_fwd_nodes_per_s`, and `cpu_baseline` (the torch-CPU port of the reference's op chain,
+oracle/ref_torch.py: 1 warm-up + 3 repetitions of a 1024-query slab, median, plus the 'fair' pre-normalised-bank row).
 """
 from __future__ import annotations
 
@@ -65,6 +72,9 @@ def parse():
                     help="single process: time what rank 0 of a G-GPU job would compute (collectives replaced by their "
                          "local part); an estimate of the per-rank step for DESIGN.md, never the bench line of a real "
                          "multi-GPU run")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="process-group backend for N > 1: nccl (= RCCL over xGMI) or gloo (device tensors staged through "
+                         "the host; lets several ranks share one GPU for a functional check)")
     ap.add_argument("--exact-fp32", action="store_true",
                     help="retrieve with the fp32 MFMA kernel only (no bf16 filter) in the timed region")
     return ap.parse_args()
@@ -179,7 +189,7 @@ def small_batch_rates(tgb, dim, k, dev):
     index = tgb._index if tgb._index is not None else K.KeyIndex(kn)
     n_keys = kn.shape[0]
     L = K.N.lib()
-    for B in (1, 16, 256, 4096):
+    for B in (1, 16, 256, 512, 4096):
         q = torch.randn(B, dim, device=dev, generator=torch.Generator(device=dev).manual_seed(4321 + B))
         for _ in range(3):
             index.topk(q, k)
@@ -217,8 +227,9 @@ def cpu_baseline(args, model, feats, adj):
     """The reference's op chain on the host cores (oracle/ref_torch.py), BASELINE.md section 3: GNN part on the whole
     graph (sparse CSR: the reference's dense adjacency would be 40 GB); retrieval exactly as the reference computes it
     (bank re-normalised on every call, the B x N slab materialised, torch.topk, gathers) on ONE slab of 1024 queries --
-    3 warm-ups + 5 timed repetitions, median -- extrapolated to the full forward; and the 'fair' row with the bank
-    normalised once (1 warm-up + 3 repetitions)."""
+    1 warm-up + 3 timed repetitions, median -- extrapolated to the full forward; and the 'fair' row with the bank
+    normalised once (1 warm-up + 3 repetitions).  (Round 2 ran 3 + 5 repetitions: 95 % of the command's wall time, with a
+    spread of a few per cent between repetitions.)"""
     from oracle import ref_torch
 
     cores = os.cpu_count() or 1
@@ -248,7 +259,7 @@ def cpu_baseline(args, model, feats, adj):
         ref_torch.propagate(adj_cpu, h, model.query_graph_hop)
         t_gnn = time.perf_counter() - t0
         q = h[:slab].contiguous()
-        t_ref, ts_ref = timed(lambda: ref_torch.retrieve(q, keys, vals, labs, args.k, slab=slab), 3, 5)
+        t_ref, ts_ref = timed(lambda: ref_torch.retrieve(q, keys, vals, labs, args.k, slab=slab), 1, 3)
         kn = torch.nn.functional.normalize(keys, p=2, dim=-1)
 
         def fair():
@@ -260,7 +271,7 @@ def cpu_baseline(args, model, feats, adj):
     est_fair = t_gnn + t_fair * (n / slab)
     return {"value": round(n / est_full, 2), "unit": "queries/s", "cores": cores, "kind": "port",
             "sample": f"GNN encode+{model.query_graph_hop}-hop on all {n} nodes ({t_gnn:.2f}s, torch sparse CSR) + retrieval of "
-                      f"one slab of {slab} of the {n} queries vs the full {keys.shape[0]}x{keys.shape[1]} bank, 3 warm-ups + 5 "
+                      f"one slab of {slab} of the {n} queries vs the full {keys.shape[0]}x{keys.shape[1]} bank, 1 warm-up + 3 "
                       f"repetitions, median {t_ref:.2f}s (bank re-normalised per call as the reference does), extrapolated "
                       f"to {n} queries",
             "retrieval_only_queries_per_s": round(slab / t_ref, 2),
@@ -270,6 +281,50 @@ def cpu_baseline(args, model, feats, adj):
                      "note": "bank normalised once (ref_torch.retrieve(renormalize_bank=False) arithmetic), 1 warm-up + 3 "
                              "repetitions, median: what the reference would do without its redundant per-call "
                              "F.normalize(resource_keys)"}}
+
+
+def verify_retrieval(model, feats, adj, args, world, with_oracle):
+    """Outside the timed region: the retrieval the step just timed (product dispatch: bf16-filtered at this shape), ALL
+    queries again, and a fixed sample of 64 of its rows against (a) the exact fp32 kernel -- identical indices and score
+    bits required -- and (b), 4 rows, the CPU oracle (oracle/cref.py; N = 1 only: it needs the whole bank on the host).
+    Key-sharded runs compare the merged global lists with the merge of per-shard fp32 lists.  Raises on any difference."""
+    from ragraph_amd import kernels as K
+    from ragraph_amd.sharded import all_gather_into
+
+    k = args.k
+    tgb = model.toy_graph_base
+    with torch.no_grad():
+        h = model.pretrain_model.inference(feats, adj)
+        n = h.shape[0]
+        rows = torch.linspace(0, n - 1, 64, device=h.device).long()
+        s_all, i_all = tgb.topk(h, k)                                  # the timed path, every query
+        hs = h[rows].contiguous()
+        sharded = hasattr(tgb, "idx_base") and getattr(tgb, "collective", False)
+        if sharded:
+            s32, i32 = K.topk_cosine(hs, tgb.keys_normalized, k, idx_base=tgb.idx_base)
+            gs = torch.empty((world * 64, k), dtype=s32.dtype, device=s32.device)
+            gi = torch.empty((world * 64, k), dtype=i32.dtype, device=i32.device)
+            all_gather_into(gs, s32.contiguous(), tgb.group)
+            all_gather_into(gi, i32.contiguous(), tgb.group)
+            s32, i32 = K.topk_merge(gs.view(world, 64, k), gi.view(world, 64, k))
+        else:
+            s32, i32 = K.topk_cosine(hs, tgb.keys_normalized, k)
+    ok_i, ok_s = torch.equal(i_all[rows], i32), torch.equal(s_all[rows], s32)
+    if not (ok_i and ok_s):
+        raise SystemExit(f"bench.py: the timed retrieval path differs from the exact fp32 kernel on the verification sample "
+                         f"(indices equal: {ok_i}, scores equal: {ok_s})")
+    rec = {"rows": 64, "of_queries": n, "vs": ["fp32_kernel"], "identical": True,
+           "what": "top-k indices and score bits of the timed (bf16-filtered) retrieval, re-run on all queries after the "
+                   "timed region; 64 evenly spaced rows against ragraph_topk_cosine_f32"}
+    if with_oracle and not sharded:
+        from oracle import cref
+
+        os_, oi = cref.topk_cosine(hs[:4].cpu().numpy(), tgb.keys_normalized.cpu().numpy(), k)
+        if not ((i_all[rows[:4]].cpu().numpy() == oi).all() and (s_all[rows[:4]].cpu().numpy() == os_).all()):
+            raise SystemExit("bench.py: the timed retrieval path differs from the CPU oracle on the verification sample")
+        rec["vs"].append("oracle")
+        rec["oracle_rows"] = 4
+    return rec
 
 
 def timed_steps(step, steps, world, dev, on_step=None):
@@ -311,13 +366,18 @@ def main():
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in ragraph_amd)")
+    if args.backend == "gloo":  # (functional check: the ranks may share a device)
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     force_dist = os.environ.get("RAGRAPH_FORCE_DIST") == "1"  # 1-rank RCCL group: exercises the sharded path on one GPU
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from ragraph_amd import kernels as K
 
@@ -347,6 +407,11 @@ def main():
     topk_timer.enabled = filt_timer.enabled = False
     L.ragraph_profile_filter_kernel(0)
     assert torch.isfinite(out).all()
+    verified = None
+    if args.emulate_rank_of <= 1 and not args.exact_fp32 and not args.no_extras:
+        # (every rank: the sharded check has collectives; profiling runs -- --no-extras -- keep their kernel lists clean)
+        verified = verify_retrieval(model, feats, adj, args, world,
+                                    with_oracle=(rank == 0 and world == 1 and not args.no_cpu_baseline))
 
     n = args.nodes
     G = max(world, args.emulate_rank_of, 1)
@@ -399,8 +464,10 @@ def main():
                     "(includes the <0.1 % query-normalise and select kernels of the same ABI call)",
         }
     if args.shard == "keys":
-        par = (f"key bank row-sharded x{G} (values replicated): per-query bounds sharpened by an all_reduce(MAX) and an "
-               f"all_gather of each rank's best scores per level, one RCCL all_gather of the per-shard top-k per step")
+        par = (f"key bank row-sharded x{G} (values replicated): per-query bounds pooled at every phase of the filtered call "
+               f"(all_gather of each rank's best 2*ceil(k/G) lower bounds + k-th of the union), one all_to_all of the "
+               f"per-shard lists to the rank that owns the rows, query-sharded tail, one all_gather of the [n, C] outputs "
+               f"({args.backend})")
     else:
         par = (f"query batch split x{G}, bank replicated on every GPU (1 GB of 288 GB): no data-path collective, one RCCL "
                f"all_gather of the [n, C] outputs per step")
@@ -464,6 +531,8 @@ def main():
                                                  "bound": "mfma", "achieved": round(a32, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                                  "unit": "TFLOP/s", "frac": round(a32 / FP32_MFMA_PEAK_TFLOPS, 4),
                                                  "launch_ms": round(t32, 3)}}
+    if verified is not None:
+        result["verified"] = verified
     if rank == 0 and world == 1 and extras and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, model, feats, adj)
     if rank == 0:

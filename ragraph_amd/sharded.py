@@ -19,6 +19,42 @@ import torch
 import torch.distributed as dist
 
 
+# ---- collectives ------------------------------------------------------------------------------------------------------
+# RCCL ("nccl") moves device tensors directly.  Under "gloo" (CPU tests; two ranks sharing ONE GPU in
+# tests/test_gpu_two_rank.py -- RCCL refuses two ranks on one device) device tensors are staged through the host: the
+# collective itself then runs on CPU copies, and the device work enqueued before it has completed (the copy to the host
+# synchronises the stream), which is exactly the ordering the exchange callback of the filtered call relies on.
+def _staged(group, *tensors) -> bool:
+    return dist.get_backend(group) == "gloo" and any(t.is_cuda for t in tensors)
+
+
+def all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None) -> None:
+    if _staged(group, out, inp):
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, inp.cpu().contiguous(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
+def all_to_all_single(out: torch.Tensor, inp: torch.Tensor, recv, send, group=None) -> None:
+    if _staged(group, out, inp):
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(host, inp.cpu().contiguous(), recv, send, group=group)
+        out.copy_(host)
+    else:
+        dist.all_to_all_single(out, inp, recv, send, group=group)
+
+
+def all_reduce(t: torch.Tensor, op, group=None) -> None:
+    if _staged(group, t):
+        host = t.cpu()
+        dist.all_reduce(host, op=op, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
 def shard_bounds(N: int, world: int, rank: int):
     """Contiguous, balanced row ranges: the first N % world ranks hold one extra row."""
     q, r = divmod(N, world)
@@ -53,7 +89,7 @@ class QueryShard:
         if hi - lo < per:
             buf = torch.cat([local, local.new_zeros((per - (hi - lo),) + tuple(local.shape[1:]))], 0)
         out = local.new_empty((self.world * per,) + tuple(local.shape[1:]))
-        dist.all_gather_into_tensor(out, buf.contiguous(), group=self.group)
+        all_gather_into(out, buf.contiguous(), self.group)
         if self.world * per == B:
             return out
         parts = []
@@ -91,6 +127,7 @@ class ShardedToyGraphBase:
         self._index = KeyIndex(self.keys_normalized, ops)
         self.emulate_world = int(emulate_world)
         self._out_shard = None
+        self.exchange_count = {}   # phase -> how many exchanges of that phase this rank has taken part in (diagnostic)
 
         def exchange_fn(phase, theta, scores):
             return self._exchange(phase, theta, scores)
@@ -102,7 +139,7 @@ class ShardedToyGraphBase:
             self.plan_n = int(plan_n)
         elif self.collective:
             t = torch.tensor([n_local], dtype=torch.int64, device=keys.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            all_reduce(t, dist.ReduceOp.MAX, group)
             self.plan_n = int(t.item())
         else:
             self.plan_n = n_local
@@ -119,6 +156,7 @@ class ShardedToyGraphBase:
         G = self.emulate_world if self.emulate_world > 1 else self.world
         if G <= 1 and not self.collective:
             return
+        self.exchange_count[phase] = self.exchange_count.get(phase, 0) + 1
         k = scores.shape[1]
         m = min(k, 2 * (-(-k // G)))
         while G * m > 64 and m > -(-k // G):
@@ -129,7 +167,7 @@ class ShardedToyGraphBase:
             gathered = local.unsqueeze(0).expand(G, B, m).contiguous()
         else:
             gathered = torch.empty((G, B, m), dtype=local.dtype, device=local.device)
-            dist.all_gather_into_tensor(gathered.view(G * B, m), local, group=self.group)
+            all_gather_into(gathered.view(G * B, m), local, self.group)
         self.ops.theta_sharpen(gathered, theta, k)
 
     def topk(self, search_keys, k=None):
@@ -155,8 +193,8 @@ class ShardedToyGraphBase:
         B = s.shape[0]
         gs = torch.empty((self.world * B, k), dtype=s.dtype, device=s.device)   # rank-major concatenation
         gi = torch.empty((self.world * B, k), dtype=i.dtype, device=i.device)
-        dist.all_gather_into_tensor(gs, s.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(gi, i.contiguous(), group=self.group)
+        all_gather_into(gs, s.contiguous(), self.group)
+        all_gather_into(gi, i.contiguous(), self.group)
         return self.ops.topk_merge(gs.view(self.world, B, k), gi.view(self.world, B, k))
 
     # ---- key-sharded bank, query-sharded tail -----------------------------------------------------------------------
@@ -192,8 +230,8 @@ class ShardedToyGraphBase:
         recv = [hi - lo] * G                                 # every shard sends me its lists for my rows
         gs = torch.empty((G * (hi - lo), k), dtype=s.dtype, device=s.device)   # shard-major
         gi = torch.empty((G * (hi - lo), k), dtype=i.dtype, device=i.device)
-        dist.all_to_all_single(gs, s.contiguous(), recv, send, group=self.group)
-        dist.all_to_all_single(gi, i.contiguous(), recv, send, group=self.group)
+        all_to_all_single(gs, s.contiguous(), recv, send, self.group)
+        all_to_all_single(gi, i.contiguous(), recv, send, self.group)
         return self.ops.topk_merge(gs.view(G, hi - lo, k), gi.view(G, hi - lo, k))
 
     def retrieve_reduced_rows(self, search_keys, k=None):
@@ -223,7 +261,7 @@ class ShardedToyGraphBase:
         sum_l, _ = self.ops.gather_reduce(self.resource_labels, None, idx, idx_base=self.idx_base)
         if self.collective:
             packed = torch.cat([sum_v, sum_l], dim=1)
-            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
+            all_reduce(packed, dist.ReduceOp.SUM, self.group)
             sum_v, sum_l = packed[:, :sum_v.shape[1]].contiguous(), packed[:, sum_v.shape[1]:].contiguous()
         return sum_v, sum_l / float(k), idx  # label counts are small integers: exact sums, one rounded division
 
@@ -235,6 +273,6 @@ class ShardedToyGraphBase:
         e = self.ops.gather_rows(self.resource_values, idx, idx_base=self.idx_base)
         l = self.ops.gather_rows(self.resource_labels, idx, idx_base=self.idx_base)
         if self.collective:
-            dist.all_reduce(e, op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_reduce(l, op=dist.ReduceOp.SUM, group=self.group)
+            all_reduce(e, dist.ReduceOp.SUM, self.group)
+            all_reduce(l, dist.ReduceOp.SUM, self.group)
         return e, l

@@ -12,6 +12,51 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+_two_rank = None
+
+
+def pytest_sessionstart(session):
+    """tests/test_gpu_two_rank.py: its two worker processes must be started before THIS process initialises the GPU
+    (torch.cuda.device_count() does not; any test's first kernel does).  Only when GPU tests are selected and a device
+    exists; the workers run beside the other tests and the test collects their reports."""
+    global _two_rank
+    expr = session.config.getoption("markexpr", "") or ""
+    if "not gpu" in expr or os.environ.get("RAGRAPH_SKIP_TWO_RANK") == "1":
+        return
+    try:
+        import torch
+        if torch.cuda.device_count() < 1:
+            return
+    except Exception:
+        return
+    import socket
+    import subprocess
+    import tempfile
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tempfile.mkdtemp(prefix="ragraph_two_rank_")
+    worker = os.path.join(ROOT, "tests", "two_rank_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), out], env=env,
+                              stdout=open(os.path.join(out, f"rank{r}.log"), "w"), stderr=subprocess.STDOUT)
+             for r in range(2)]
+    _two_rank = (procs, out)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if _two_rank is not None:
+        for p in _two_rank[0]:
+            if p.poll() is None:
+                p.kill()
+
+
+@pytest.fixture(scope="session")
+def two_rank_job():
+    return _two_rank
+
+
 @pytest.fixture(scope="session")
 def dev():
     import torch

@@ -1,0 +1,28 @@
+"""Two real processes on the real HIP library (-m gpu): the key-sharded and the query-sharded forward of RAGraph_node
+under a world-size-2 process group, bit for bit against the single-process result.  The ranks are started by
+tests/conftest.py at session start -- before this pytest process has made any GPU call (a process that has initialised
+the GPU must not fork + exec on the GPU pool) -- and run beside the other tests; this test collects their reports."""
+import json
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_ranks_on_the_hip_library_match_single_process(dev, two_rank_job):
+    assert two_rank_job is not None, "conftest did not start the two-rank job (no ROCm device at session start?)"
+    procs, out = two_rank_job
+    for p in procs:
+        p.wait(timeout=900)
+    reports = []
+    for r in range(len(procs)):
+        path = os.path.join(out, f"rank{r}.json")
+        assert os.path.exists(path), f"rank {r} left no report (exit code {procs[r].returncode})"
+        reports.append(json.load(open(path)))
+    for rep in reports:
+        assert rep["ok"], rep.get("error")
+        assert rep["world"] == 2
+        assert rep["filtered_path"]                          # the shard goes through the bf16-filtered sharded entry
+        assert rep["key_shard_forward_equal"] and rep["key_shard_topk_equal"] and rep["query_shard_forward_equal"], rep
+        assert rep["exchange_count"].get("0", 0) >= 2, rep   # phase-0 exchange: once per key-sharded retrieval
