@@ -328,6 +328,15 @@ int ragraph_floyd_warshall_f32(const float* adj, int n, float* dist, void* strea
 int ragraph_position_code_f32(const float* dist, int n, const int64_t* anchors, int A, float dis_q, float* out,
                               void* stream);
 
+/* The same codes WITHOUT the all-pairs matrix: distances to the A anchors only, on the CSR of the (block-diagonal) query
+ * batch -- what RAGraph_node_fewshot/ragraph_utils/ToyGraphBase.py:49-50 needs on every forward from
+ * PositionAwareEncoder.py:6-24.  One workgroup per anchor relaxes d[u] = min(d[u], val[u,v] + d[v]) over the rows to its
+ * fixpoint (the minimum over all walks u -> anchor of w1 + (w2 + (...)) in fp32; Floyd-Warshall associates the same sums
+ * differently: equal to ~1 ulp).  val == 0 entries are no edges (the reference's `dist[adj == 0] = inf`), diagonal 0.
+ * codes [n,A]; dist [n,A] or NULL receives the distances (inf = unreachable).  n <= 40000 (one anchor's vector in LDS). */
+int ragraph_position_codes_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n,
+                                   const int64_t* anchors, int A, float dis_q, float* codes, float* dist, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Fine-tuning backward (section 7.3 hard part 4).  The matrix parts of a backward pass are the
  * forward entry points again (ragraph_linear_f32 on transposed operands; ragraph_spmm_csr_f32 on the TRANSPOSED CSR: the

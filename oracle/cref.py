@@ -168,6 +168,16 @@ def segment_reduce(X, seg_ptr, w=None, mean_mode=False):
     return out
 
 
+def position_codes_csr(rowptr, col, val, anchors, dis_q=10.0):
+    """(codes [n,A], dist [n,A]) from distances to the anchors only (oracle_position_codes_csr)."""
+    rowptr, col, val, anchors = _i64(rowptr), _i32(col), _f32(val), _i64(anchors).reshape(-1)
+    n, A = rowptr.shape[0] - 1, anchors.shape[0]
+    codes = np.empty((n, A), dtype=np.float32)
+    dist = np.empty((n, A), dtype=np.float32)
+    lib().oracle_position_codes_csr(_p(rowptr), _p(col), _p(val), _c64(n), _p(anchors), _ci(A), _cf(dis_q), _p(codes), _p(dist))
+    return codes, dist
+
+
 def mul_cols(x, w, act=ACT_NONE, alpha=0.0):
     x, w = _f32(x), _f32(w).reshape(-1)
     out = np.empty_like(x)

@@ -129,9 +129,15 @@ def downprompt_node_forward(h, w, ave):
 
 
 def fewshot_scores(search_keys, adj_dense, anchors, keys, positions, structure_weight=0.001, semantic_weight=0.999,
-                   dis_q=10.0):
-    """RAGraph_node_fewshot/ragraph_utils/ToyGraphBase.py:47-61: w_s * cos(position codes) + w_m * cos(embeddings)."""
-    pos = cref.position_code(cref.floyd_warshall(adj_dense), anchors, dis_q)          # PositionAwareEncoder.py:6-24
+                   dis_q=10.0, all_pairs=False):
+    """RAGraph_node_fewshot/ragraph_utils/ToyGraphBase.py:47-61: w_s * cos(position codes) + w_m * cos(embeddings).
+    Codes (PositionAwareEncoder.py:6-24): all_pairs=True through the reference's Floyd-Warshall matrix; default through
+    the distances to the anchors only (oracle_position_codes_csr: what the product computes per forward; the two agree
+    to ~1 ulp of a path sum -- tests/test_oracle_golden.py pins both against the reference's codes)."""
+    if all_pairs:
+        pos = cref.position_code(cref.floyd_warshall(adj_dense), anchors, dis_q)
+    else:
+        pos, _ = cref.position_codes_csr(*cref.dense_to_csr(adj_dense), anchors, dis_q)
     s_struct = cref.linear(cref.normalize_rows(pos), cref.normalize_rows(positions))
     s_sem = cref.linear(cref.normalize_rows(search_keys), cref.normalize_rows(keys))
     return cref.axpby(s_struct, structure_weight, s_sem, semantic_weight), pos

@@ -28,8 +28,11 @@ def _dense(adj) -> torch.Tensor:
 
 
 class PositionAwareEncoder:
-    """ragraph_utils/PositionAwareEncoder.py: distance-to-anchor codes.  The reference runs Floyd-Warshall as n dense
-    torch.min broadcasts and fills the code matrix in a Python double loop; here both are HIP kernels."""
+    """ragraph_utils/PositionAwareEncoder.py: distance-to-anchor codes.  The reference runs an all-pairs Floyd-Warshall as
+    n dense torch.min broadcasts and fills the code matrix in a Python double loop -- to use 10 columns of the n x n
+    matrix.  The codes here come from the distances to the anchors ONLY, relaxed on the CSR of the (block-diagonal)
+    batch in one launch (K.position_codes_csr: no n x n allocation, no n dependent launches); `floyd_warshall` keeps the
+    reference's all-pairs entry for callers that want the matrix."""
 
     @staticmethod
     def floyd_warshall(adj) -> torch.Tensor:
@@ -37,11 +40,11 @@ class PositionAwareEncoder:
 
     @staticmethod
     def encode_position_aware_code(adj, num_anchors: int, dis_q: int = 10, anchors: torch.Tensor | None = None):
-        dense = _dense(adj)
-        dist = K.floyd_warshall(dense)
+        g: CSRGraph = as_csr(adj.squeeze(0) if isinstance(adj, torch.Tensor) and adj.layout == torch.strided
+                             and adj.dim() == 3 else adj)
         if anchors is None:  # PositionAwareEncoder.py:11 draws them from torch's global CPU generator
-            anchors = torch.randint(low=0, high=dense.shape[0], size=(int(num_anchors),))
-        return K.position_code(dist, anchors.to(dense.device), float(dis_q))
+            anchors = torch.randint(low=0, high=g.n, size=(int(num_anchors),))
+        return K.position_codes_csr(g.rowptr, g.col, g.val, anchors.to(g.device), float(dis_q))
 
 
 class ToyGraphBaseFewShot(ToyGraphBase):
@@ -110,7 +113,7 @@ class RAGraph(nn.Module):
         g = as_csr(adj)
         emb = self.pretrain_model.encode(features, g)                                           # :48
         add_noise = self.training and self.noise_finetune
-        rag_embeddings, rag_labels = self.toy_graph_base.retrieve(emb, adj, add_noise, anchors)  # :51
+        rag_embeddings, rag_labels = self.toy_graph_base.retrieve(emb, g, add_noise, anchors)    # :51
         label_ids = torch.argmax(rag_labels, dim=-1)                                             # :54 (integer lookup)
         k = label_ids.shape[1]
         rag_logits, _ = K.gather_reduce(mean_fewshot_logits, None, label_ids, v_scale=1.0 / k)   # :55,62 mean over k
@@ -165,7 +168,7 @@ class RAGraphGraphFewShot(nn.Module):
         if not self.finetune:
             return rag_logits                                                                    # :88-91
         if add_noise:                                                                            # graph noise: on the embeddings
-            rag_embedding, _ = tgb.retrieve_reduced_noisy(emb)
+            rag_embedding, _ = tgb.retrieve_reduced_noisy(emb, idx=idx, want_labels=False)
         else:
             rag_embedding, _ = K.gather_reduce(tgb.resource_values, None, idx)                   # :69 sum over k
         query = Propagation.aggregate_k_hop_features(g, emb, self.query_graph_hop)               # :71

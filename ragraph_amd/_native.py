@@ -73,6 +73,7 @@ SIGNATURES = {
     "ragraph_scatter_fill_f32": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _f32, _vp]),
     "ragraph_floyd_warshall_f32": (_i32, [_vp, _i32, _vp, _vp]),
     "ragraph_position_code_f32": (_i32, [_vp, _i32, _vp, _i32, _f32, _vp, _vp]),
+    "ragraph_position_codes_csr_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _f32, _vp, _vp, _vp]),
     "ragraph_act_grad_f32": (_i32, [_vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp]),
     "ragraph_sigmoid_gate_grad_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "ragraph_softmax_grad_f32": (_i32, [_vp, _vp, _i64, _i32, _f32, _vp, _vp]),

@@ -449,6 +449,54 @@ __global__ void __launch_bounds__(256) position_code_kernel(const float* __restr
   out[e] = (dist < dis_q) ? 1.f / (dist + 1.f) : 0.f;
 }
 
+// ---- distances to the anchors only, on the CSR (few-shot query graphs, per forward) ---------------------------------------
+// PositionAwareEncoder.py:6-24 needs dist[u, anchor] for 10 anchors; its all-pairs Floyd-Warshall (:27-48) over the dense
+// block-diagonal batch adjacency is O(n^3) in n dependent steps.  Here: one workgroup per anchor keeps d[0..n) in LDS and
+// relaxes every row against its out-edges, d[u] = min(d[u], val[u,v] + d[v]), until a round changes nothing (<= n rounds).
+// fp32 addition and min are monotone, so the rounds converge to ONE fixpoint whatever the order in which rows see each
+// other's updates: per node the minimum over all walks to the anchor of the sum w1 + (w2 + (w3 + ...)) -- the value
+// oracle/ragraph_oracle.c computes sequentially, bit for bit.  (Floyd-Warshall associates a path's sum differently:
+// equal to ~1 ulp, pinned at 1e-6 on the codes against the reference's golden vectors.)  Entries with val == 0 are "no
+// edge", as the reference's `dist[adj == 0] = inf`; the diagonal is 0.
+__global__ void __launch_bounds__(1024) anchor_dist_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                           const float* __restrict__ val, int n,
+                                                           const int64_t* __restrict__ anchors, int A, float dis_q,
+                                                           float* __restrict__ codes, float* __restrict__ dist_out) {
+  extern __shared__ float anchor_d[];
+  __shared__ int changed;
+  const int a = blockIdx.x, tid = threadIdx.x;
+  const int src = (int)anchors[a];
+  for (int u = tid; u < n; u += 1024) anchor_d[u] = (u == src) ? 0.f : __builtin_huge_valf();
+  __syncthreads();
+  for (int round = 0; round < n; ++round) {
+    if (tid == 0) changed = 0;
+    __syncthreads();
+    for (int u = tid; u < n; u += 1024) {
+      const float cur = anchor_d[u];
+      float best = cur;
+      const int64_t e1 = rowptr[u + 1];
+      for (int64_t e = rowptr[u]; e < e1; ++e) {
+        const float w = val[e];
+        const int v = col[e];
+        if (w != 0.f && v != u) best = fminf(best, __fadd_rn(w, anchor_d[v]));
+      }
+      if (best < cur) {
+        anchor_d[u] = best;
+        changed = 1;
+      }
+    }
+    __syncthreads();
+    const int again = changed;
+    __syncthreads();
+    if (!again) break;
+  }
+  for (int u = tid; u < n; u += 1024) {
+    const float d = anchor_d[u];
+    if (dist_out) dist_out[(int64_t)u * A + a] = d;
+    codes[(int64_t)u * A + a] = (d < dis_q) ? 1.f / (d + 1.f) : 0.f;
+  }
+}
+
 }  // namespace ragraph
 
 using namespace ragraph;
@@ -537,6 +585,25 @@ extern "C" int ragraph_floyd_warshall_f32(const float* adj, int n, float* dist, 
   for (int kk = 0; kk < n; ++kk)
     hipLaunchKernelGGL(fw_step_kernel, dim3((unsigned)cdiv(n, 256), (unsigned)n), dim3(256), 0, st, dist, n, kk);
   RG_CHECK_LAUNCH("floyd_warshall");
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_position_codes_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n,
+                                              const int64_t* anchors, int A, float dis_q, float* codes, float* dist,
+                                              void* stream) {
+  RG_REQUIRE(rowptr && anchors && codes, RAGRAPH_EINVAL, "position_codes_csr: null pointer");
+  RG_REQUIRE(n >= 1 && A >= 1, RAGRAPH_EINVAL, "position_codes_csr: bad shape");
+  RG_REQUIRE(n <= 40000, RAGRAPH_EUNSUPPORTED, "position_codes_csr: n=%lld: the distance vector of one anchor must fit the "
+             "160 KB of LDS (few-shot query batches have a few hundred nodes)", (long long)n);
+  const size_t lds = (size_t)n * sizeof(float);
+  static DeviceOnce lds_once;
+  if (hipError_t e = raise_dynamic_lds(lds_once, &anchor_dist_kernel, 160 * 1024 - 64); e != hipSuccess) {
+    set_error("position_codes_csr: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+    return RAGRAPH_EDEVICE;
+  }
+  hipLaunchKernelGGL(anchor_dist_kernel, dim3((unsigned)A), dim3(1024), lds, as_stream(stream), rowptr, col, val, (int)n, anchors,
+                     A, dis_q, codes, dist);
+  RG_CHECK_LAUNCH("position_codes_csr");
   return RAGRAPH_OK;
 }
 

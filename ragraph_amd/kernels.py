@@ -578,6 +578,24 @@ def position_code(dist: torch.Tensor, anchors: torch.Tensor, dis_q: float = 10.0
     return out
 
 
+def position_codes_csr(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, anchors: torch.Tensor,
+                       dis_q: float = 10.0, return_dist: bool = False):
+    """Position-aware codes [n, A] from the CSR of the query batch: shortest-path distances to the A anchors only (one
+    workgroup per anchor, no n x n matrix, one launch) -- PositionAwareEncoder.py:6-24 as the few-shot retrieve uses it
+    on every forward (RAGraph_node_fewshot/ragraph_utils/ToyGraphBase.py:49-50)."""
+    L = _ready()
+    rowptr = _idxc(rowptr, "position_codes_csr.rowptr")
+    col = _idxc(col, "position_codes_csr.col", torch.int32)
+    val = _f32c(val, "position_codes_csr.val")
+    anchors = _idxc(anchors, "position_codes_csr.anchors").reshape(-1)
+    n, A = rowptr.numel() - 1, anchors.numel()
+    codes = torch.empty((n, A), dtype=torch.float32, device=val.device)
+    dist = torch.empty((n, A), dtype=torch.float32, device=val.device) if return_dist else None
+    N.check(L.ragraph_position_codes_csr_f32(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), n, anchors.data_ptr(), A,
+                                             float(dis_q), codes.data_ptr(), _ptr(dist), _stream()), "position_codes_csr")
+    return (codes, dist) if return_dist else codes
+
+
 def sigmoid_gate(x: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
     """x * sigmoid(z) -- the embedding gate of RAGraph_edge/modules/RAGraph.py:168."""
     L = _ready()

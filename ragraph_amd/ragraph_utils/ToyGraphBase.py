@@ -129,10 +129,12 @@ class ToyGraphBase:
             idx = torch.cat([idx, noise_idx.to(idx.device)], dim=1)
         return idx
 
-    def retrieve(self, search_keys: Tensor, search_adj, add_noise: bool):
+    def retrieve(self, search_keys: Tensor, search_adj, add_noise: bool, idx: Tensor | None = None):
         """ToyGraphBase.py:47-81 -> (rag_embeddings [B,k',D], rag_labels [B,k',C]).  A 1-D query (graph flavour,
-        RAGraph_graph/ragraph_utils/ToyGraphBase.py:56-87) gives B = 1."""
-        idx = self.retrieve_indices(search_keys, add_noise)
+        RAGraph_graph/ragraph_utils/ToyGraphBase.py:56-87) gives B = 1.  `idx`: the rows, when the caller already
+        holds retrieve_indices(search_keys, add_noise) (one top-k per forward instead of two)."""
+        if idx is None:
+            idx = self.retrieve_indices(search_keys, add_noise)
         rag_embeddings = K.gather_rows(self.resource_values, idx)                  # :70 (+ :76,78 noise rows)
         rag_labels = K.gather_rows(self.resource_labels, idx)                      # :71 (+ :77,79)
         if add_noise and self.flavour != "node":                                   # graph :84-85,131-134
@@ -140,18 +142,19 @@ class ToyGraphBase:
             rag_embeddings = K.axpby(rag_embeddings, 1.0, noise, 1.0)
         return rag_embeddings, rag_labels
 
-    def retrieve_reduced_noisy(self, search_keys: Tensor):
+    def retrieve_reduced_noisy(self, search_keys: Tensor, idx: Tensor | None = None, want_labels: bool = True):
         """What RAGraph.forward consumes in noisy fine-tuning (RAGraph.py:42-49 with add_noise): (sum_k' V, mean_k' L)
-        over the top-2k rows plus the noise -- every reduction on the HIP kernels."""
-        if self.flavour == "node":   # noise = extra rows: still a gather-reduce over an index matrix
+        over the top-2k rows plus the noise -- every reduction on the HIP kernels, ONE top-k per call (`idx`: the rows
+        when the caller already holds retrieve_indices(search_keys, True); want_labels=False skips the label means)."""
+        if idx is None:
             idx = self.retrieve_indices(search_keys, True)
-            sum_v, mean_l = K.gather_reduce(self.resource_values, self.resource_labels, idx)
-            return sum_v, mean_l
-        rag_embeddings, _ = self.retrieve(search_keys, None, True)   # noise is added to the gathered embeddings
+        if self.flavour == "node":   # noise = extra rows: still a gather-reduce over an index matrix
+            return K.gather_reduce(self.resource_values, self.resource_labels, idx)
+        rag_embeddings, _ = self.retrieve(search_keys, None, True, idx=idx)   # noise is added to the gathered embeddings
         B, k, D = rag_embeddings.shape
         seg = torch.arange(0, B * k + 1, k, dtype=torch.int64, device=rag_embeddings.device)
         sum_v = K.segment_reduce(rag_embeddings.reshape(B * k, D), seg)
-        _, mean_l = K.gather_reduce(self.resource_values, self.resource_labels, self.topk(search_keys, k)[1])
+        mean_l = K.gather_reduce(self.resource_values, self.resource_labels, idx)[1] if want_labels else None
         return sum_v, mean_l
 
     def retrieve_reduced(self, search_keys: Tensor, k: int | None = None):

@@ -66,6 +66,40 @@ def test_floyd_warshall_and_position_code(dev):
     assert np.array_equal(pc.cpu().numpy(), cref.position_code(rd, anchors, 10.0))
 
 
+@pytest.mark.parametrize("n,deg", [(97, 0.05), (528, 0.01), (3000, 0.002)])
+def test_position_codes_csr_bit_exact_vs_oracle(dev, n, deg):
+    """Distances to the anchors only (the few-shot flavour's per-forward path): HIP == oracle bit for bit on graphs with
+    unreachable nodes, explicit zero entries and duplicate anchors; within 1e-6 of the all-pairs route."""
+    from ragraph_amd import kernels as K
+    from ragraph_amd.graph import CSRGraph
+
+    rng = np.random.default_rng(n)
+    a = (rng.random((n, n)) < deg).astype(np.float32) * rng.random((n, n)).astype(np.float32)
+    a = np.maximum(a, a.T)
+    np.fill_diagonal(a, 0.3)
+    a[n // 2:, : n // 2] = 0                      # two halves: one direction cut, nodes that cannot reach some anchors
+    rowptr, col, val = cref.dense_to_csr(a)
+    val = val.copy()
+    val[::17] = 0.0                               # explicit zeros in the CSR are "no edge" (dist[adj == 0] = inf)
+    anchors = rng.integers(0, n, 10)
+    anchors[3] = anchors[2]
+    oc, od = cref.position_codes_csr(rowptr, col, val, anchors, 10.0)
+    codes, dist = K.position_codes_csr(T(rowptr, dev), T(col, dev), T(val, dev), T(anchors, dev), 10.0, return_dist=True)
+    assert np.array_equal(dist.cpu().numpy(), od) and np.array_equal(codes.cpu().numpy(), oc)
+    assert np.isinf(od).any() and np.isfinite(od).any()
+    if n <= 600:                                  # the reference's all-pairs route on the same (zero-cleaned) matrix
+        dense = np.zeros((n, n), dtype=np.float32)
+        rows = np.repeat(np.arange(n), np.diff(rowptr))
+        dense[rows, col] = val
+        fw = cref.floyd_warshall(dense)[:, anchors]
+        assert np.array_equal(np.isinf(fw), np.isinf(od))
+        assert np.allclose(od[np.isfinite(fw)], fw[np.isfinite(fw)], rtol=1e-6, atol=0)
+        assert np.allclose(oc, cref.position_code(cref.floyd_warshall(dense), anchors, 10.0), atol=1e-6)
+    g = CSRGraph(T(rowptr, dev), T(col, dev).to(torch.int32), T(val, dev), n)
+    from ragraph_amd.RAGraph_fewshot import PositionAwareEncoder
+    assert torch.equal(PositionAwareEncoder.encode_position_aware_code(g, 10, 10, anchors=T(anchors, dev)), codes)
+
+
 def test_fewshot_retrieve_g8(dev):
     from ragraph_amd.RAGraph_fewshot import PositionAwareEncoder, ToyGraphBaseFewShot
 
@@ -75,7 +109,7 @@ def test_fewshot_retrieve_g8(dev):
     adj = T(g["adj"], dev)
     assert np.array_equal(PositionAwareEncoder.floyd_warshall(adj).cpu().numpy(), g["dist"])
     pos = PositionAwareEncoder.encode_position_aware_code(adj, 10, 10, anchors=T(g["anchors"], dev))
-    assert np.allclose(pos.cpu().numpy(), g["pos_codes"], atol=1e-7)
+    assert np.allclose(pos.cpu().numpy(), g["pos_codes"], atol=1e-6)    # anchors-only distances: ~1 ulp from the all-pairs sums
     e, l = tgb.retrieve(T(g["Q"], dev), adj, False, anchors=T(g["anchors"], dev))
     assert np.array_equal(e.cpu().numpy(), g["rag_embeddings"]) and np.array_equal(l.cpu().numpy(), g["rag_labels"])
     # bit-exact vs the oracle's restatement of the mixed score

@@ -137,10 +137,22 @@ def test_g16_downprompt_node():
 
 def test_g8_fewshot_structural_retrieve():
     g = gold("g8_fewshot_retrieve")
-    assert np.array_equal(cref.floyd_warshall(g["adj"]), g["dist"])          # min-plus closure: exact
+    fw = cref.floyd_warshall(g["adj"])
+    assert np.array_equal(fw, g["dist"])                                     # min-plus closure: exact
+    # the reference's route (all-pairs matrix) and the product's per-forward route (distances to the anchors only):
+    # the same paths, sums associated differently -- both within 1e-6 of the reference's codes, identical indices
+    pos_fw = cref.position_code(fw, g["anchors"], 10.0)
+    pos_a, dist_a = cref.position_codes_csr(*cref.dense_to_csr(g["adj"]), g["anchors"], 10.0)
+    assert np.allclose(pos_fw, g["pos_codes"], atol=1e-7) and np.allclose(pos_a, g["pos_codes"], atol=1e-6)
+    ref_d = g["dist"][:, g["anchors"]]
+    assert np.array_equal(np.isinf(dist_a), np.isinf(ref_d))
+    assert np.allclose(dist_a[np.isfinite(ref_d)], ref_d[np.isfinite(ref_d)], rtol=1e-6, atol=0)
+    for all_pairs in (False, True):
+        sc, pos = pipeline.fewshot_scores(g["Q"], g["adj"], g["anchors"], g["keys"], g["positions"], all_pairs=all_pairs)
+        assert np.array_equal(cref.topk_rows(sc, int(g["k"]))[1], g["topk_idx"])
     e, l, idx, pos = pipeline.fewshot_retrieve(g["Q"], g["adj"], g["anchors"], g["keys"], g["values"], g["labels"],
                                                g["positions"], int(g["k"]))
-    assert np.allclose(pos, g["pos_codes"], atol=1e-7)
+    assert np.allclose(pos, g["pos_codes"], atol=1e-6)
     assert np.array_equal(idx, g["topk_idx"])
     assert np.array_equal(e, g["rag_embeddings"]) and np.array_equal(l, g["rag_labels"])
 

@@ -76,6 +76,27 @@ with torch.no_grad():
     print(json.dumps({"config": "c3 RAGraph_graph 16 PROTEINS-style graphs per pass (%d nodes), 1113-key bank, k=3" % Xb.shape[0],
                       "eager_ms": round(te * 1e3, 3), "hipgraph_replay_ms": round(tg * 1e3, 3),
                       "graphs_per_s_replay": round(16 / tg)}), flush=True)
+    # ---- few-shot node flavour: structural + semantic retrieval on a batch of 16 graphs (n ~ 528) ------------------
+    from ragraph_amd.RAGraph_fewshot import RAGraph as RAGraphFewShot, _dense
+    bf = next(iter(DataLoader(synthetic_tu_dataset(num_graphs=64, num_node_attributes=18, num_node_labels=3, seed=11), batch_size=16)))
+    Xf = torch.rand(bf.x.shape[0], 18, device=dev)
+    af = CSRGraph.from_edge_index_sym_normalized(bf.edge_index.to(dev), Xf.shape[0])
+    logits = torch.randn(3, 256, device=dev)
+    mf = RAGraphFewShot(PrePrompt(18, 256, "prelu", 2, 0.3).to(dev), None, logits, 256, device=dev, dataset_name="ENZYMES").eval()
+    Nf = 20_000
+    mf.toy_graph_base.add_resources(torch.nn.functional.normalize(torch.randn(Nf, 256, device=dev), dim=-1),
+                                    torch.randn(Nf, 256, device=dev),
+                                    torch.nn.functional.one_hot(torch.randint(0, 3, (Nf,), device=dev), 3).float(),
+                                    torch.rand(Nf, 10, device=dev))
+    anchors = torch.randint(0, Xf.shape[0], (10,), device=dev)
+    _ = af.row_normalized_values()
+    tf = timeit(lambda: mf(Xf, af, logits, anchors=anchors), reps=20)
+    tc = timeit(lambda: K.position_codes_csr(af.rowptr, af.col, af.val, anchors, 10.0), reps=20)
+    tfw = timeit(lambda: K.position_code(K.floyd_warshall(_dense(af)), anchors, 10.0), reps=5)   # round 2's per-forward path
+    print(json.dumps({"config": "few-shot RAGraph_node forward, 16 graphs per pass (%d nodes), 20k x 256 bank + 10-d position "
+                                "codes, k=5" % Xf.shape[0], "forward_ms": round(tf * 1e3, 3),
+                      "position_codes_csr_ms": round(tc * 1e3, 3), "all_pairs_floyd_warshall_codes_ms": round(tfw * 1e3, 3),
+                      "forward_ms_with_all_pairs_codes": round((tf - tc + tfw) * 1e3, 3)}), flush=True)
     # ---- c5 --------------------------------------------------------------------------------------------------
     from ragraph_amd.RAGraph_edge import RAGraph as RAGraphEdge
     U, I = 2_200_000, 1_800_000
