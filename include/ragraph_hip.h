@@ -162,6 +162,18 @@ int ragraph_topk_cosine_filtered_sharded_f32(const float* Q, int64_t B, const fl
                                              int64_t plan_N, float* theta, ragraph_exchange_fn exchange, void* ctx,
                                              int n_shards);
 
+/* a1 + a2 in ONE launch for small banks  -- SimilarityFunctions.py:6-16 + ToyGraphBase.py:66-67 at the reference's own sizes
+ * (BASELINE config 1: 2708 queries x a 10 000 x 128 toy bank, k = 5).  Same result, bit for bit, as
+ * ragraph_topk_cosine_f32 / _filtered_f32: a workgroup takes 32 queries through all phases of the filtered path (query
+ * normalisation, bf16 bound over a prefix, bf16 filter over the whole bank, exact fp32 rescoring, canonical selection,
+ * exact scan of a query whose 512-slot candidate list overflows) against the WHOLE bank, so nothing crosses workgroups
+ * and no workspace is needed.  Q [B,D] raw queries; Kn [N,D] unit rows; Kb = ragraph_keys_to_bf16(Kn).  D in {64,128,256},
+ * k <= 16, N >= 128 k (ragraph_topk_cosine_fused_ok: 1 if the shape is supported).  Every workgroup streams the whole bf16
+ * copy (2 N D bytes) from L2: meant for banks whose copy is a few MB (ragraph_amd/kernels_index.py decides). */
+int ragraph_topk_cosine_fused_ok(int64_t B, int64_t N, int D, int k);
+int ragraph_topk_cosine_fused_f32(const float* Q, int64_t B, const float* Kn, const uint16_t* Kb, int64_t N, int D, int k,
+                                  int64_t idx_base, float* out_scores, int64_t* out_idx, void* stream);
+
 /* The per-level exchange of the sharded call: theta[b] = max(theta[b], k-th largest of the G*m scores gathered for query
  * b), gathered = the all_gather of every shard's best m exact scores, [G, B, m] as the collective leaves it; k <= G*m <= 64.
  * (The k-th largest of a subset of all scores bounds the k-th largest of all from below.) */

@@ -1,0 +1,362 @@
+// Exact cosine top-k in ONE launch for SMALL banks  (SimilarityFunctions.py:6-16 + ToyGraphBase.py:66-67 at the reference's
+// own operating point: BASELINE config 1's 10 000 x 128 toy bank against the 2708 nodes of a Cora-sized forward, a few
+// hundred to a few thousand queries against a bank whose bf16 copy is a few MB).
+//
+// The filtered path of topk_filter.hip is six dependent launches (prepare, bound pass, bound selection, filter level,
+// rescoring, overflow check): 5 - 25 us each whatever the size, ~90 us for 7 GFLOP of scores.  Its phases only need to
+// agree on a query's bound, and when ONE workgroup sees the whole bank for its queries nothing has to cross workgroups:
+//   workgroup = 32 queries (two groups of 16 = the B operands of v_mfma_f32_16x16x32_bf16, in registers) x 8 waves, the
+//   waves taking the bank's 16-KiB units (fragment order, filter_common.h) round-robin from the L2;
+//   phase 0  normalise the 32 queries (normalize_rows' tree: same bits), |dq| of their bf16 rounding, B operands;
+//   phase A  bound: best approximate score of each of G = 4 k parts of a prefix (N/8 of the bank; N/4 for k > 8) in LDS,
+//            theta[q] = k-th largest of the G part maxima - eps(q)           (the proof of topk_filter.hip, step 1);
+//   phase B  filter: every key with s~ >= theta - eps goes to the query's candidate list in LDS (step 2);
+//   phase C  exact fp32 rescoring of the candidates (the k = 0..D-1 fmaf chain from +0) and canonical selection
+//            (rescore_common.h: the code the multi-launch path runs), a wave per query;
+//   a list that overflows (near-duplicate banks) is answered by an exact scan of the bank by the query's wave.
+// Same bits as every other path (tests/test_gpu_kernels.py: against the oracle and the fp32 kernels).
+// Cost model: every workgroup streams the whole bf16 copy from its XCD's L2 (64 B/clk per CU: 2.5 MB in ~16 us), so the
+// path is for banks whose copy stays L2-resident; kernels_index.KeyIndex decides.
+#include "rescore_common.h"
+#include <type_traits>
+
+namespace ragraph {
+
+template <int D_>
+struct FusedCfg {
+  static constexpr int D = D_;
+  static constexpr int WAVES = 8, THREADS = 512, QT = 32;
+  static constexpr int KSTEPS = D / 16;              // 1-KiB blocks per 32-key sub-tile
+  static constexpr int KS32 = D / 32;                // MFMA k-steps per sub-tile
+  static constexpr int UNIT_BLOCKS = 16;
+  static constexpr int SUBS = UNIT_BLOCKS / KSTEPS;  // sub-tiles per 16-KiB unit: 1 / 2 / 4
+  static constexpr int UNIT_KEYS = 32 * SUBS;
+  static constexpr int CAP = 512;                    // candidate slots per query (expected: ~100)
+  static constexpr int GMAX = 64;                    // parts of the bound's prefix (4 k, k <= 16)
+  static constexpr size_t QN_BYTES = (size_t)QT * D * 4, QB_BYTES = (size_t)QT * D * 2;
+  static constexpr size_t LDS_BYTES = QN_BYTES + QB_BYTES + (size_t)QT * GMAX * 4 + (size_t)QT * CAP * 4 + 3 * QT * 4;
+};
+
+struct FusedParams {
+  const float* Q;        // [B,D] raw queries
+  const float* Kn;       // [N,D] normalised keys (fp32: the exact rescoring)
+  const uint16_t* Kb;    // bf16 copy in fragment order, padded, + the max |dk|^2 word (ragraph_keys_to_bf16)
+  int64_t B, N;
+  int k, G, psubs;       // parts and 32-key sub-tiles of the bound's prefix (32 psubs <= N)
+  int64_t nunits;        // 16-KiB units that hold keys < N
+  int64_t idx_base;
+  float* out_s;
+  int64_t* out_i;
+};
+
+// The exact fallback for one query by ONE wave: every lane scores its own key per step (the fp32 chain), the wave keeps
+// the sorted list (lane p = entry p) exactly as exact_scan_query does.
+template <int D>
+__device__ __forceinline__ void exact_scan_wave(const float4* qrow, const float* __restrict__ Kn, int64_t N, int k,
+                                                int64_t idx_base, int lane, float* __restrict__ out_s,
+                                                int64_t* __restrict__ out_i) {
+  float es = RG_NEG_INF;
+  int ei = INT_MAX;
+  float kth_s = RG_NEG_INF;
+  int kth_i = INT_MAX;
+  for (int64_t base = 0; base < N; base += 64) {
+    const int key = base + lane < N ? (int)(base + lane) : -1;
+    float sc = 0.f;
+    if (key >= 0) {
+      const float4* kr = reinterpret_cast<const float4*>(Kn + (int64_t)key * D);
+#pragma unroll 8
+      for (int d4 = 0; d4 < D / 4; ++d4) {
+        const float4 kv = kr[d4], qv = qrow[d4];
+        sc = fmaf(qv.x, kv.x, sc);
+        sc = fmaf(qv.y, kv.y, sc);
+        sc = fmaf(qv.z, kv.z, sc);
+        sc = fmaf(qv.w, kv.w, sc);
+      }
+    }
+    unsigned long long pend = __ballot(key >= 0 && cand_better(sc, key, kth_s, kth_i));
+    while (pend) {
+      const int src = __ffsll((long long)pend) - 1;
+      pend &= pend - 1;
+      const float s = __shfl(sc, src);
+      const int id = __shfl(key, src);
+      const unsigned long long ahead = __ballot(lane < k && cand_better(es, ei, s, id));
+      const int pos = __popcll(ahead);
+      const float us = __shfl_up(es, 1);
+      const int ui = __shfl_up(ei, 1);
+      if (pos < k) {
+        if (lane == pos) {
+          es = s;
+          ei = id;
+        } else if (lane > pos && lane < k) {
+          es = us;
+          ei = ui;
+        }
+      }
+      kth_s = __shfl(es, k - 1);
+      kth_i = __shfl(ei, k - 1);
+      pend &= __ballot(key >= 0 && cand_better(sc, key, kth_s, kth_i));
+    }
+  }
+  if (lane < k) {
+    out_s[lane] = es;
+    out_i[lane] = ei == INT_MAX ? INT64_MAX : (int64_t)ei + idx_base;
+  }
+}
+
+template <int D>
+__global__ void __launch_bounds__(512, 2) topk_fused_kernel(FusedParams p) {
+  using C = FusedCfg<D>;
+  extern __shared__ float4 fused_smem4[];
+  char* smem = reinterpret_cast<char*>(fused_smem4);
+  float* qn = reinterpret_cast<float*>(smem);                                    // [QT][D]
+  char* qb = smem + C::QN_BYTES;                                                 // [QT/16][KS32][64] x 16 B
+  int* partmax = reinterpret_cast<int*>(qb + C::QB_BYTES);                       // [QT][GMAX]
+  int* cand = partmax + C::QT * C::GMAX;                                         // [QT][CAP]
+  int* cnt = cand + C::QT * C::CAP;                                              // [QT]
+  float* thr = reinterpret_cast<float*>(cnt + C::QT);                            // [QT]
+  float* epsq = thr + C::QT;                                                     // [QT]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int64_t q0 = (int64_t)blockIdx.x * C::QT;
+  const unsigned* max_kerr2 = reinterpret_cast<const unsigned*>(p.Kb + ((p.N + FILTER_PAD_KEYS - 1) / FILTER_PAD_KEYS) * FILTER_PAD_KEYS * D);
+
+  // ---- phase 0: this wave's four queries (filter_prep_kernel's arithmetic, into LDS) ---------------------------------------
+  {
+    constexpr int NCH = D / 4;
+    const float ek = sqrtf(__uint_as_float(*max_kerr2));
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+      const int ql = 4 * wave + i;
+      const int64_t q = q0 + ql;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lane < NCH && q < p.B) v = reinterpret_cast<const float4*>(p.Q + q * D)[lane];
+      float pn = 0.f;
+      pn = fmaf(v.x, v.x, pn);
+      pn = fmaf(v.y, v.y, pn);
+      pn = fmaf(v.z, v.z, pn);
+      pn = fmaf(v.w, v.w, pn);
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) pn = __fadd_rn(pn, __shfl_xor(pn, off));
+      const float d = fmaxf(sqrtf(pn), 1e-12f);
+      v.x = v.x / d; v.y = v.y / d; v.z = v.z / d; v.w = v.w / d;
+      float e2 = 0.f;
+      if (lane < NCH) {
+        reinterpret_cast<float4*>(qn + ql * D)[lane] = v;
+        const int e0 = 4 * lane, t = e0 >> 5, gg = (e0 >> 3) & 3;
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x4 o;
+        o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4*>(qb + ((ql >> 4) * C::KS32 + t) * 1024 + (gg * 16 + (ql & 15)) * 16 + (e0 & 7) * 2) = o;
+        const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dd = x[e] - (float)(__bf16)x[e];
+          e2 = fmaf(dd, dd, e2);
+        }
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) e2 += __shfl_xor(e2, off);
+      const float e = sqrtf(e2) * 1.0000002f;
+      if (lane == 0) {
+        epsq[ql] = fmaf(fmaf(e, ek, e + ek), 1.0009765625f, FILTER_EPS_SLACK);   // filter_eps
+        cnt[ql] = 0;
+      }
+      partmax[ql * C::GMAX + lane] = f2ord(RG_NEG_INF);
+    }
+  }
+  __syncthreads();
+  bf16x8 bq[2 * C::KS32];  // [group][k-step]
+#pragma unroll
+  for (int t = 0; t < 2 * C::KS32; ++t) bq[t] = reinterpret_cast<const bf16x8*>(qb)[t * 64 + lane];
+
+  f32x4 A0[16], A1[16];
+#define RG_ULOAD(buf_, u_)                                                                                         \
+  {                                                                                                                \
+    const char* ub_ = reinterpret_cast<const char*>(p.Kb) + (uint64_t)(u_) * (C::UNIT_BLOCKS * 1024) + lane * 16;  \
+    _Pragma("unroll") for (int b_ = 0; b_ < 16; ++b_) buf_[b_] = *reinterpret_cast<const f32x4*>(ub_ + b_ * 1024); \
+  }
+  float my_thr[2] = {0.f, 0.f};  // (phase B) the thresholds of this lane's two query columns
+  // one unit against the two query groups; BOUND_: part maxima of the prefix, else candidates
+  auto process = [&](f32x4 (&A)[16], int64_t unit, auto bound_tag) {
+    constexpr bool BOUND_ = decltype(bound_tag)::value;
+#pragma unroll
+    for (int sub = 0; sub < C::SUBS; ++sub) {
+      const int64_t st = unit * C::SUBS + sub;  // sub-tile index over the bank
+      if (BOUND_ && st >= p.psubs) break;       // (wave-uniform)
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq) acc[gq][0] = acc[gq][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < C::KS32; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bf16x8 a_ = __builtin_bit_cast(bf16x8, A[(sub * C::KS32 + t) * 2 + h]);
+#pragma unroll
+          for (int gq = 0; gq < 2; ++gq)
+            acc[gq][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, bq[gq * C::KS32 + t], acc[gq][h], 0, 0, 0);
+        }
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq) {
+        float m = acc[gq][0][0];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) m = fmaxf(m, acc[gq][0][r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[gq][1][r]);
+        if constexpr (BOUND_) {
+          m = fmaxf(m, __shfl_xor(m, 16));
+          m = fmaxf(m, __shfl_xor(m, 32));
+          const int part = (int)(st * p.G / p.psubs);
+          if (g == 0) atomicMax(partmax + (16 * gq + j) * C::GMAX + part, f2ord(m));
+        } else {
+          const float th = my_thr[gq];
+          if (__any(m >= th)) {
+            unsigned mk = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) mk |= (acc[gq][h][r] >= th) ? (1u << (4 * h + r)) : 0u;
+            const int64_t key_base = st * 32 + 4 * g;  // the lane's keys: + r + 16 h  (mask bit 4 h + r)
+            const int ql = 16 * gq + j;
+            while (mk) {
+              const int r = __ffs(mk) - 1;
+              mk &= mk - 1;
+              const int64_t key = key_base + (r & 3) + 16 * (r >> 2);
+              if (key < p.N) {
+                const int slot = atomicAdd(cnt + ql, 1);
+                if (slot < C::CAP) cand[ql * C::CAP + slot] = (int)key;
+              }
+            }
+          }
+        }
+      }
+    }
+  };
+
+  // ---- phase A: the bound from the prefix's part maxima --------------------------------------------------------------------
+  {
+    const int64_t punits = (p.psubs + C::SUBS - 1) / C::SUBS;
+    for (int64_t u = wave; u < punits; u += C::WAVES) {
+      RG_ULOAD(A0, u);
+      process(A0, u, std::true_type{});
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i) {  // theta = k-th largest of the G part maxima - eps: lane l holds part l, ranked by counting
+    const int ql = 4 * wave + i;
+    const float eps = epsq[ql];
+    const float v = lane < p.G ? __fsub_rn(ord2f(partmax[ql * C::GMAX + lane]), eps) : RG_NEG_INF;
+    int rank = 0;
+    for (int o = 0; o < p.G; ++o) {
+      const float x = __shfl(v, o);
+      rank += (x > v || (x == v && o < lane)) ? 1 : 0;
+    }
+    // (the padding queries of the last tile -- zero rows, every score 0 -- must not pass anything)
+    if (lane < p.G && rank == p.k - 1) thr[ql] = q0 + ql < p.B ? __fsub_rn(v, eps) : __builtin_huge_valf();
+  }
+  __syncthreads();
+  my_thr[0] = thr[j];
+  my_thr[1] = thr[16 + j];
+
+  // ---- phase B: the filter over the whole bank, this wave's units double-buffered ---------------------------------------------
+  {
+    const int64_t n_mine = wave < p.nunits ? (p.nunits - wave + C::WAVES - 1) / C::WAVES : 0;
+    if (n_mine > 0) {
+      RG_ULOAD(A0, wave);
+      int64_t i = 0;
+      for (; i + 2 <= n_mine; i += 2) {
+        RG_ULOAD(A1, wave + (i + 1) * C::WAVES);
+        process(A0, wave + i * C::WAVES, std::false_type{});
+        if (i + 2 < n_mine) RG_ULOAD(A0, wave + (i + 2) * C::WAVES);
+        process(A1, wave + (i + 1) * C::WAVES, std::false_type{});
+      }
+      if (i < n_mine) process(A0, wave + i * C::WAVES, std::false_type{});
+    }
+  }
+#undef RG_ULOAD
+  __syncthreads();
+
+  // ---- phase C: exact rescoring + canonical selection, a wave per query ---------------------------------------------------------
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i) {
+    const int ql = 4 * wave + i;
+    const int64_t q = q0 + ql;
+    if (q >= p.B) break;  // (wave-uniform)
+    const int n = cnt[ql];
+    const float4* qrow = reinterpret_cast<const float4*>(qn + ql * D);
+    const int* cb = cand + ql * C::CAP;
+    float* os = p.out_s + q * p.k;
+    int64_t* oi = p.out_i + q * p.k;
+#define RG_RESCORE(NS_) rescore_query<D, NS_>(qrow, p.Kn, cb, n, lane, p.k, p.idx_base, nullptr, nullptr, os, oi)
+    if (n > C::CAP) exact_scan_wave<D>(qrow, p.Kn, p.N, p.k, p.idx_base, lane, os, oi);
+    else if (n <= 64) RG_RESCORE(1);
+    else if (n <= 128) RG_RESCORE(2);
+    else if (n <= 256) RG_RESCORE(4);
+    else RG_RESCORE(8);
+#undef RG_RESCORE
+  }
+}
+
+}  // namespace ragraph
+
+using namespace ragraph;
+
+static bool fused_shape_ok(int64_t B, int64_t N, int D, int k) {
+  return B >= 1 && (D == 64 || D == 128 || D == 256) && k >= 1 && k <= 16 && N >= 32 * 4 * (int64_t)k &&
+         N < (int64_t)INT_MAX - 1024;
+}
+
+extern "C" int ragraph_topk_cosine_fused_ok(int64_t B, int64_t N, int D, int k) { return fused_shape_ok(B, N, D, k) ? 1 : 0; }
+
+template <int D>
+static int launch_fused(const FusedParams& p, hipStream_t st) {
+  using C = FusedCfg<D>;
+  static DeviceOnce lds_once;
+  if (hipError_t e = raise_dynamic_lds(lds_once, &topk_fused_kernel<D>, (int)C::LDS_BYTES); e != hipSuccess) {
+    set_error("topk_cosine_fused: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+    return RAGRAPH_EDEVICE;
+  }
+  hipLaunchKernelGGL(topk_fused_kernel<D>, dim3((unsigned)cdiv(p.B, (int64_t)C::QT)), dim3(C::THREADS), C::LDS_BYTES, st, p);
+  RG_CHECK_LAUNCH("topk_cosine_fused");
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_topk_cosine_fused_f32(const float* Q, int64_t B, const float* Kn, const uint16_t* Kb, int64_t N, int D,
+                                             int k, int64_t idx_base, float* out_scores, int64_t* out_idx, void* stream) {
+  RG_REQUIRE(Q && Kn && Kb && out_scores && out_idx, RAGRAPH_EINVAL, "topk_cosine_fused: null pointer");
+  RG_REQUIRE(fused_shape_ok(B, N, D, k), RAGRAPH_EUNSUPPORTED,
+             "topk_cosine_fused: needs D in {64,128,256}, k <= 16 and N >= 128 k (B=%lld N=%lld D=%d k=%d)", (long long)B,
+             (long long)N, D, k);
+  RG_REQUIRE(aligned16(Q) && aligned16(Kn) && aligned16(Kb), RAGRAPH_EINVAL, "topk_cosine_fused: pointers must be 16-B aligned");
+  FusedParams p{};
+  p.Q = Q;
+  p.Kn = Kn;
+  p.Kb = Kb;
+  p.B = B;
+  p.N = N;
+  p.k = k;
+  p.G = 4 * k;
+  // the bound's prefix: N/8 of the bank (N/4 for k > 8: ~100 expected candidates per query either way), at least one
+  // 32-key sub-tile per part, whole sub-tiles of REAL keys only (the copy's padding rows would score 0)
+  int64_t psubs = N / (k > 8 ? 4 : 8) / 32;
+  if (psubs < p.G) psubs = p.G;
+  if (psubs > N / 32) psubs = N / 32;
+  p.psubs = (int)psubs;
+  p.idx_base = idx_base;
+  p.out_s = out_scores;
+  p.out_i = out_idx;
+  hipStream_t st = as_stream(stream);
+  if (D == 256) {
+    p.nunits = cdiv(N, (int64_t)FusedCfg<256>::UNIT_KEYS);
+    return launch_fused<256>(p, st);
+  }
+  if (D == 128) {
+    p.nunits = cdiv(N, (int64_t)FusedCfg<128>::UNIT_KEYS);
+    return launch_fused<128>(p, st);
+  }
+  p.nunits = cdiv(N, (int64_t)FusedCfg<64>::UNIT_KEYS);
+  return launch_fused<64>(p, st);
+}

@@ -243,6 +243,39 @@ def topk_cosine_filtered(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf
     return scores, idx, overflow
 
 
+def fused_helps(B: int, n_keys: int, D: int, k: int) -> bool:
+    """True when the single-launch small-bank kernel (csrc/topk_fused.hip) is the fastest way to the exact top-k: every
+    workgroup of 32 queries streams the whole bf16 copy from L2, so the copy must stay L2-resident (<= 3 MB) and there
+    must be queries enough for the launch to beat the score-slab path of a handful of queries."""
+    if os.environ.get("RAGRAPH_EXACT_FP32") == "1" or os.environ.get("RAGRAPH_TOPK_FUSED", "1") == "0":
+        return False
+    if D not in (64, 128, 256) or k > 16 or n_keys < 128 * k:
+        return False
+    return 2 * n_keys * D <= FUSED_MAX_COPY_BYTES and B >= FUSED_MIN_B
+
+
+FUSED_MAX_COPY_BYTES = int(os.environ.get("RAGRAPH_FUSED_MAX_COPY", str(3 << 20)))
+FUSED_MIN_B = int(os.environ.get("RAGRAPH_FUSED_MIN_B", "32"))
+
+
+def topk_cosine_fused(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf16: torch.Tensor, k: int, idx_base: int = 0):
+    """Exact top-k (same bits as topk_cosine) in ONE launch: small banks (ragraph_topk_cosine_fused_f32)."""
+    L = _ready()
+    q = _f32c(q, "topk_cosine_fused.q")
+    kn = _f32c(keys_normalized, "topk_cosine_fused.keys")
+    B, D = q.shape
+    Nk = kn.shape[0]
+    if keys_bf16.dtype != torch.int16 or not keys_bf16.is_contiguous() or keys_bf16.shape[1] != D or \
+            keys_bf16.shape[0] != L.ragraph_keys_bf16_rows(Nk):
+        raise RagraphNativeError("topk_cosine_fused: keys_bf16 must come from keys_to_bf16(keys_normalized)")
+    scores = torch.empty((B, k), dtype=torch.float32, device=q.device)
+    idx = torch.empty((B, k), dtype=torch.int64, device=q.device)
+    if B:
+        N.check(L.ragraph_topk_cosine_fused_f32(q.data_ptr(), B, kn.data_ptr(), keys_bf16.data_ptr(), Nk, D, k, idx_base,
+                                                scores.data_ptr(), idx.data_ptr(), _stream()), "topk_cosine_fused")
+    return scores, idx
+
+
 def theta_sharpen(gathered: torch.Tensor, theta: torch.Tensor, k: int) -> torch.Tensor:
     """In place: theta[b] = max(theta[b], k-th largest of gathered[:, b, :]) -- the per-level exchange of a filtered
     retrieval over a row-sharded bank (gathered = all_gather of every shard's best m exact scores, [G, B, m])."""

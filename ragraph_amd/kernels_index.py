@@ -57,6 +57,11 @@ class KeyIndex:
                 return s, i
             fhelps = None  # (fp32 kernels: the shard's own exact top-k, no exchange needed)
         self._poll_overflow()
+        fused = getattr(ops, "fused_helps", None)
+        if fused is not None and fused(B, kn.shape[0], D, k):  # small bank: every phase in one launch
+            if self._bf16 is None:
+                self._bf16 = ops.keys_to_bf16(kn)
+            return ops.topk_cosine_fused(q, kn, self._bf16, k, idx_base=idx_base)
         if fhelps is not None and not self._filter_off and fhelps(B, kn.shape[0], D, k):
             if self._bf16 is None:
                 self._bf16 = ops.keys_to_bf16(kn)

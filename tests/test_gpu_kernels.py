@@ -637,3 +637,54 @@ def test_topk_cosine_filtered_adversarial_rounding(dev):
     drop = rs[:, 0] - (qb * kb).sum(1)
     assert drop.min() > 0.002, drop.min()                      # aligned errors: an order of magnitude above random
     assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs)
+
+
+@pytest.mark.parametrize("D,B,N,k", [(128, 2708, 10000, 5), (256, 33, 1113, 3), (64, 1, 640, 1), (128, 100, 5003, 8),
+                                     (256, 300, 4100, 16), (64, 777, 20000, 10), (256, 64, 2048, 4)])
+def test_topk_cosine_fused_bit_exact(dev, D, B, N, k):
+    """The single-launch small-bank kernel (csrc/topk_fused.hip: normalise, bf16 bound, bf16 filter, exact rescoring and
+    canonical selection in one workgroup per 32 queries) against the oracle: indices and score bits, ragged tiles and
+    banks, exact duplicate keys (ties at the k-th place), an index base."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(D + B + N + k)
+    kn = _bank(rng, N, D)
+    kn[N // 2:N // 2 + 40] = kn[:40]                      # exact duplicates -> ties, canonical order decides
+    q = rng.standard_normal((B, D), dtype=np.float32)
+    q[B // 2] = 3.0 * kn[7]                               # a query that IS a stored key (score 1, two copies)
+    knd = _t(kn, dev)
+    s, i = K.topk_cosine_fused(_t(q, dev), knd, K.keys_to_bf16(knd), k, idx_base=11)
+    rs, ri = cref.topk_cosine(q, kn, k, idx_base=11)
+    assert np.array_equal(i.cpu().numpy(), ri)
+    assert np.array_equal(s.cpu().numpy(), rs)
+
+
+def test_topk_cosine_fused_overflow_zero_queries_and_dispatch(dev, monkeypatch):
+    """Near-duplicate bank: thousands of keys within eps of the k-th best overflow the 512-slot candidate list, a zero
+    query ties every key at 0 -- the query's wave answers with an exact scan, still the oracle's bits.  And KeyIndex sends
+    a Cora-sized call to this kernel (and nothing else), same bits as the fp32 kernels."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(17)
+    base = rng.standard_normal((1, 128), dtype=np.float32)
+    kn = cref.normalize_rows(base + 1e-3 * rng.standard_normal((6000, 128), dtype=np.float32))
+    q = np.concatenate([base + 1e-3 * rng.standard_normal((40, 128), dtype=np.float32), np.zeros((1, 128), dtype=np.float32),
+                        rng.standard_normal((30, 128), dtype=np.float32)]).astype(np.float32)
+    knd = _t(kn, dev)
+    s, i = K.topk_cosine_fused(_t(q, dev), knd, K.keys_to_bf16(knd), 10)
+    rs, ri = cref.topk_cosine(q, kn, 10)
+    assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs)
+    # dispatch: 2708 x 10000 x 128 (BASELINE config 1's retrieval)
+    kn2 = _bank(rng, 10000, 128)
+    q2 = rng.standard_normal((2708, 128), dtype=np.float32)
+    index = K.KeyIndex(_t(kn2, dev))
+    calls = []
+    real = K.topk_cosine_fused
+    monkeypatch.setattr(K, "topk_cosine_fused", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
+    assert K.fused_helps(2708, 10000, 128, 5) and not K.fused_helps(2708, 1_000_000, 256, 10)
+    s2, i2 = index.topk(_t(q2, dev), 5)
+    assert calls == [1]
+    s3, i3 = K.topk_cosine(_t(q2, dev), _t(kn2, dev), 5)
+    assert torch.equal(i2, i3) and torch.equal(s2, s3)
+    rs2, ri2 = cref.topk_cosine(q2, kn2, 5)
+    assert np.array_equal(i2.cpu().numpy(), ri2) and np.array_equal(s2.cpu().numpy(), rs2)
