@@ -166,13 +166,18 @@ int ragraph_topk_cosine_filtered_sharded_f32(const float* Q, int64_t B, const fl
  * (BASELINE config 1: 2708 queries x a 10 000 x 128 toy bank, k = 5).  Same result, bit for bit, as
  * ragraph_topk_cosine_f32 / _filtered_f32: a workgroup takes 32 queries through all phases of the filtered path (query
  * normalisation, bf16 bound over a prefix, bf16 filter over the whole bank, exact fp32 rescoring, canonical selection,
- * exact scan of a query whose 512-slot candidate list overflows) against the WHOLE bank, so nothing crosses workgroups
- * and no workspace is needed.  Q [B,D] raw queries; Kn [N,D] unit rows; Kb = ragraph_keys_to_bf16(Kn).  D in {64,128,256},
- * k <= 16, N >= 128 k (ragraph_topk_cosine_fused_ok: 1 if the shape is supported).  Every workgroup streams the whole bf16
- * copy (2 N D bytes) from L2: meant for banks whose copy is a few MB (ragraph_amd/kernels_index.py decides). */
+ * exact scan of a query whose candidate list overflows); the bank is split over up to 8 workgroups per tile, whose
+ * per-query lists the tile's last workgroup merges (a ticket), so nothing crosses tiles and there is no second launch.
+ * Q [B,D] raw queries; Kn [N,D] unit rows; Kb = ragraph_keys_to_bf16(Kn).  D in {64,128,256}, k <= 16, N >= 128 k
+ * (ragraph_topk_cosine_fused_ok: 1 if the shape is supported).  tickets: ceil(B/32) ints, ZERO before the first call; every
+ * call leaves them zero (keep one buffer per stream).  ws: ragraph_topk_cosine_fused_workspace_bytes (the splits' lists).
+ * Every tile streams the whole bf16 copy (2 N D bytes) from L2: meant for banks whose copy is a few MB
+ * (ragraph_amd/kernels_index.py decides). */
 int ragraph_topk_cosine_fused_ok(int64_t B, int64_t N, int D, int k);
+size_t ragraph_topk_cosine_fused_workspace_bytes(int64_t B, int64_t N, int D, int k);
 int ragraph_topk_cosine_fused_f32(const float* Q, int64_t B, const float* Kn, const uint16_t* Kb, int64_t N, int D, int k,
-                                  int64_t idx_base, float* out_scores, int64_t* out_idx, void* stream);
+                                  int64_t idx_base, float* out_scores, int64_t* out_idx, int* tickets, void* ws,
+                                  size_t ws_bytes, void* stream);
 
 /* The per-level exchange of the sharded call: theta[b] = max(theta[b], k-th largest of the G*m scores gathered for query
  * b), gathered = the all_gather of every shard's best m exact scores, [G, B, m] as the collective leaves it; k <= G*m <= 64.

@@ -46,7 +46,8 @@ SIGNATURES = {
     "ragraph_topk_cosine_filtered_sharded_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp,
                                                         _vp, _sz, _vp, _i64, _vp, _vp, _vp, _i32]),
     "ragraph_topk_cosine_fused_ok": (_i32, [_i64, _i64, _i32, _i32]),
-    "ragraph_topk_cosine_fused_f32": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp]),
+    "ragraph_topk_cosine_fused_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
+    "ragraph_topk_cosine_fused_f32": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ragraph_theta_sharpen_f32": (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "ragraph_topk_cosine_bank_f32": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _sz, _vp]),
     "ragraph_topk_merge_f32": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),

@@ -244,18 +244,40 @@ def topk_cosine_filtered(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf
 
 
 def fused_helps(B: int, n_keys: int, D: int, k: int) -> bool:
-    """True when the single-launch small-bank kernel (csrc/topk_fused.hip) is the fastest way to the exact top-k: every
-    workgroup of 32 queries streams the whole bf16 copy from L2, so the copy must stay L2-resident (<= 3 MB) and there
-    must be queries enough for the launch to beat the score-slab path of a handful of queries."""
+    """True when the single-launch small-bank kernel (csrc/topk_fused.hip) is the fastest way to the exact top-k.  Its time
+    is nearly flat in the batch size (38 - 95 us: a chain of per-workgroup phases, every tile streaming the L2-resident
+    bf16 copy), while the score-slab / fp32 paths that small banks otherwise take grow with B.  Measured on MI355X
+    (us, this kernel vs the dispatch without it; tools/quick_fused_bench.py, profiles/r3_fused_sweep.txt):
+      8192 x 2000 x 64: 38 vs 136;  8192 x 5000 x 128: 76 vs 210;  8192 x 5000 x 256: 135 vs 290;  2708 x 5000 x 64: 69 vs 89;
+      2708 x 20000 x 64: 83 vs 120;  1024 x 20000 x 64: 68 vs 92;  2708 x 5000 x 256: 96 vs 140;
+      not: 1024 x 5000 x 128: 63 vs 52;  256 x 2000 x 64: 38 vs 25;  and banks of >= 8192 keys at D >= 128, where the
+      multi-launch filtered path is as fast (2708 x 10000 x 128 -- BASELINE config 1 -- 89 vs 87; 8192 x 10000 x 128: 105 vs 107)."""
     if os.environ.get("RAGRAPH_EXACT_FP32") == "1" or os.environ.get("RAGRAPH_TOPK_FUSED", "1") == "0":
         return False
     if D not in (64, 128, 256) or k > 16 or n_keys < 128 * k:
         return False
-    return 2 * n_keys * D <= FUSED_MAX_COPY_BYTES and B >= FUSED_MIN_B
+    if 2 * n_keys * D > FUSED_MAX_COPY_BYTES or (D >= 128 and n_keys >= 8192):
+        return False
+    return B * n_keys >= FUSED_MIN_SCORES
 
 
 FUSED_MAX_COPY_BYTES = int(os.environ.get("RAGRAPH_FUSED_MAX_COPY", str(3 << 20)))
-FUSED_MIN_B = int(os.environ.get("RAGRAPH_FUSED_MIN_B", "32"))
+FUSED_MIN_SCORES = int(os.environ.get("RAGRAPH_FUSED_MIN_SCORES", "12000000"))
+
+
+_fused_tickets: dict = {}
+
+
+def _tickets(n: int, device) -> torch.Tensor:
+    """The fused kernel's per-tile tickets: zero before the first call, left zero by every call; one buffer per
+    (device, stream) -- calls on a stream are ordered."""
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    key = (dev, _raw_stream(dev) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream)
+    t = _fused_tickets.get(key)
+    if t is None or t.numel() < n:
+        t = torch.zeros(max(n, 1024), dtype=torch.int32, device=device)
+        _fused_tickets[key] = t
+    return t
 
 
 def topk_cosine_fused(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf16: torch.Tensor, k: int, idx_base: int = 0):
@@ -271,8 +293,13 @@ def topk_cosine_fused(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf16:
     scores = torch.empty((B, k), dtype=torch.float32, device=q.device)
     idx = torch.empty((B, k), dtype=torch.int64, device=q.device)
     if B:
+        nbytes = L.ragraph_topk_cosine_fused_workspace_bytes(B, Nk, D, k)
+        if nbytes == 0:
+            raise RagraphNativeError(f"topk_cosine_fused: unsupported shape B={B} N={Nk} D={D} k={k}")
+        ws = _workspace(nbytes, q.device)
         N.check(L.ragraph_topk_cosine_fused_f32(q.data_ptr(), B, kn.data_ptr(), keys_bf16.data_ptr(), Nk, D, k, idx_base,
-                                                scores.data_ptr(), idx.data_ptr(), _stream()), "topk_cosine_fused")
+                                                scores.data_ptr(), idx.data_ptr(), _tickets((B + 31) // 32, q.device).data_ptr(),
+                                                ws.data_ptr(), ws.numel(), _stream()), "topk_cosine_fused")
     return scores, idx
 
 

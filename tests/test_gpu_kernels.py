@@ -662,7 +662,7 @@ def test_topk_cosine_fused_bit_exact(dev, D, B, N, k):
 def test_topk_cosine_fused_overflow_zero_queries_and_dispatch(dev, monkeypatch):
     """Near-duplicate bank: thousands of keys within eps of the k-th best overflow the 512-slot candidate list, a zero
     query ties every key at 0 -- the query's wave answers with an exact scan, still the oracle's bits.  And KeyIndex sends
-    a Cora-sized call to this kernel (and nothing else), same bits as the fp32 kernels."""
+    a many-queries-small-bank call to this kernel (and nothing else), same bits as the fp32 kernels."""
     from ragraph_amd import kernels as K
 
     rng = _rng(17)
@@ -674,14 +674,15 @@ def test_topk_cosine_fused_overflow_zero_queries_and_dispatch(dev, monkeypatch):
     s, i = K.topk_cosine_fused(_t(q, dev), knd, K.keys_to_bf16(knd), 10)
     rs, ri = cref.topk_cosine(q, kn, 10)
     assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs)
-    # dispatch: 2708 x 10000 x 128 (BASELINE config 1's retrieval)
-    kn2 = _bank(rng, 10000, 128)
-    q2 = rng.standard_normal((2708, 128), dtype=np.float32)
+    # dispatch: 2708 x 10000 x 64 (a Cora-sized batch against a 10k bank at the edge flavour's width)
+    kn2 = _bank(rng, 10000, 64)
+    q2 = rng.standard_normal((2708, 64), dtype=np.float32)
     index = K.KeyIndex(_t(kn2, dev))
     calls = []
     real = K.topk_cosine_fused
     monkeypatch.setattr(K, "topk_cosine_fused", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
-    assert K.fused_helps(2708, 10000, 128, 5) and not K.fused_helps(2708, 1_000_000, 256, 10)
+    assert K.fused_helps(2708, 10000, 64, 5) and not K.fused_helps(2708, 1_000_000, 256, 10)
+    assert not K.fused_helps(2708, 10000, 128, 5) and not K.fused_helps(256, 2000, 64, 5)
     s2, i2 = index.topk(_t(q2, dev), 5)
     assert calls == [1]
     s3, i3 = K.topk_cosine(_t(q2, dev), _t(kn2, dev), 5)
