@@ -853,16 +853,20 @@ __global__ void __launch_bounds__(256) topk_rescore_wide_kernel(const float* __r
   }
   if constexpr (!SLICED) {
     over = over || flag[b] != 0;
-    if (threadIdx.x == 0) {
-      if (final_level) {
-        if (over) {
-          const int pos = atomicAdd(overflow, 1);
-          overflow_list[pos] = (int)b;
-        }
-      } else if (over) {
-        flag[b] = 1;
+    if (final_level && over) {  // (block-uniform) the exact scan right here: these calls need no fallback launch
+      __syncthreads();          // every wave has read the counter
+      if (threadIdx.x == 0) {
+        atomicAdd(overflow, 1);
+        count[b * cs] = 0;
       }
+      if constexpr (COOP) {
+        exact_scan_query<D>(qs, Kn, N, k, idx_base, tile, ps, pi, out_s + b * k, out_i + b * k);
+      } else {
+        if (w == 0) exact_scan_wave<D>(qs, Kn, N, k, idx_base, lane, out_s + b * k, out_i + b * k);
+      }
+      return;
     }
+    if (threadIdx.x == 0 && over) flag[b] = 1;
   }
   const int lo0 = SLICED ? (int)blockIdx.y * subcap : 0;
   const int per = (n + 3) / 4;  // <= 512
@@ -1480,15 +1484,17 @@ static int run_rescore(const FilterWs& f, const float* Kn, int64_t N, int64_t B,
       fprintf(stderr, "\n");
     }
 #endif
-  } else if (B <= wide_coop_max_b)  // one workgroup per CU: its 70 KB of tiles cost no occupancy
+  } else if (B <= wide_coop_max_b) {  // one workgroup per CU: its 70 KB of tiles cost no occupancy
+    *fallback_done = 1;  // (the wide kernels answer an overflowed query themselves on the final level)
     hipLaunchKernelGGL((topk_rescore_wide_kernel<D, false, true>), dim3((unsigned)B), dim3(256), 0, st, f.Qn, Kn, f.count, f.cand,
                        B, N, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag,
                        (float*)nullptr, (int*)nullptr);
-  else if (B < wide_max_b)  // too few queries to fill the chip with one wave each
+  } else if (B < wide_max_b) {  // too few queries to fill the chip with one wave each
+    *fallback_done = 1;
     hipLaunchKernelGGL((topk_rescore_wide_kernel<D, false, false>), dim3((unsigned)B), dim3(256), 0, st, f.Qn, Kn, f.count, f.cand,
                        B, N, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag,
                        (float*)nullptr, (int*)nullptr);
-  else if (rescore_coop() && few)
+  } else if (rescore_coop() && few)
     hipLaunchKernelGGL((topk_rescore_coop_kernel<D, 32, true>), dim3((unsigned)cdiv(B, 2)), dim3(128), 0, st, f.Qn, Kn, f.count,
                        f.cand, B, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag);
   else if (rescore_coop())

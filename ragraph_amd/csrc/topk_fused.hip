@@ -61,60 +61,6 @@ struct FusedParams {
   int* part_over;        // [tiles][S][QT] this split's candidate list of the query overflowed
 };
 
-// The exact fallback for one query by ONE wave: every lane scores its own key per step (the fp32 chain), the wave keeps
-// the sorted list (lane p = entry p) exactly as exact_scan_query does.
-template <int D>
-__device__ __forceinline__ void exact_scan_wave(const float4* qrow, const float* __restrict__ Kn, int64_t N, int k,
-                                                int64_t idx_base, int lane, float* __restrict__ out_s,
-                                                int64_t* __restrict__ out_i) {
-  float es = RG_NEG_INF;
-  int ei = INT_MAX;
-  float kth_s = RG_NEG_INF;
-  int kth_i = INT_MAX;
-  for (int64_t base = 0; base < N; base += 64) {
-    const int key = base + lane < N ? (int)(base + lane) : -1;
-    float sc = 0.f;
-    if (key >= 0) {
-      const float4* kr = reinterpret_cast<const float4*>(Kn + (int64_t)key * D);
-#pragma unroll 8
-      for (int d4 = 0; d4 < D / 4; ++d4) {
-        const float4 kv = kr[d4], qv = qrow[d4];
-        sc = fmaf(qv.x, kv.x, sc);
-        sc = fmaf(qv.y, kv.y, sc);
-        sc = fmaf(qv.z, kv.z, sc);
-        sc = fmaf(qv.w, kv.w, sc);
-      }
-    }
-    unsigned long long pend = __ballot(key >= 0 && cand_better(sc, key, kth_s, kth_i));
-    while (pend) {
-      const int src = __ffsll((long long)pend) - 1;
-      pend &= pend - 1;
-      const float s = __shfl(sc, src);
-      const int id = __shfl(key, src);
-      const unsigned long long ahead = __ballot(lane < k && cand_better(es, ei, s, id));
-      const int pos = __popcll(ahead);
-      const float us = __shfl_up(es, 1);
-      const int ui = __shfl_up(ei, 1);
-      if (pos < k) {
-        if (lane == pos) {
-          es = s;
-          ei = id;
-        } else if (lane > pos && lane < k) {
-          es = us;
-          ei = ui;
-        }
-      }
-      kth_s = __shfl(es, k - 1);
-      kth_i = __shfl(ei, k - 1);
-      pend &= __ballot(key >= 0 && cand_better(sc, key, kth_s, kth_i));
-    }
-  }
-  if (lane < k) {
-    out_s[lane] = es;
-    out_i[lane] = ei == INT_MAX ? INT64_MAX : (int64_t)ei + idx_base;
-  }
-}
-
 #ifdef RG_FUSED_TIMING  // diagnostic build: wall-clock stamps (10 ns ticks) of workgroup 0 / wave 0 and of the last block
 __device__ unsigned long long g_fused_t[2][16];
 #define RG_FSTAMP(i_)                                                                                     \
