@@ -99,28 +99,43 @@ def axpby(a, wa, b, wb):
 class _SpmmCsr(torch.autograd.Function):
     """y = act(A @ x + bias) for a CSRGraph A -- layers/gcn.py:36-40, Propagation.py:22-25, edge _agg (:232-240).
     Backward: gz = gy * act'(z); gx = A^T gz (the same kernel over the transposed CSR, cached on the graph); gbias =
-    column sums of gz; PReLU slope: sum of gy * z over z < 0."""
+    column sums of gz; PReLU slope: sum of gy * z over z < 0.  The fused epilogue keeps only y, from which the
+    pre-activation's sign and value follow while the slope is positive (sign(y) = sign(z), z = y / alpha on the negative
+    side).  A trained PReLU slope is unconstrained: for alpha <= 0 the forward runs unfused and keeps z itself."""
 
     @staticmethod
     def forward(ctx, g, x, bias, act, alpha_t, alpha):
-        y = K.spmm_csr(g.rowptr, g.col, g.val, x, bias=bias, act=act, alpha=alpha, long_rows=g.has_long_rows)
+        ctx.keeps_z = act == K.ACT_PRELU and alpha <= 0.0
+        if ctx.keeps_z:
+            z = K.spmm_csr(g.rowptr, g.col, g.val, x, bias=bias, act=K.ACT_NONE, long_rows=g.has_long_rows)
+            y = K.mul_cols(z, torch.ones(z.shape[-1], device=z.device), act, alpha)    # act(z * 1)
+            ctx.save_for_backward(z)
+        else:
+            y = K.spmm_csr(g.rowptr, g.col, g.val, x, bias=bias, act=act, alpha=alpha, long_rows=g.has_long_rows)
+            ctx.save_for_backward(y)
         ctx.g, ctx.act, ctx.alpha = g, act, alpha
         ctx.has_bias, ctx.has_alpha = bias is not None, alpha_t is not None
-        ctx.save_for_backward(y)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        (y,) = ctx.saved_tensors
+        (y,) = ctx.saved_tensors          # (z itself when keeps_z: act_grad's sign test is then on the pre-activation)
         gy = gy.contiguous()
         galpha = None
         if ctx.act != K.ACT_NONE:
-            if ctx.has_alpha and ctx.needs_input_grad[4]:
+            want_alpha = ctx.has_alpha and ctx.needs_input_grad[4]
+            if ctx.keeps_z:
+                gz = K.act_grad(y, gy, ctx.act, ctx.alpha)
+                if want_alpha:             # sum of gy * min(z, 0): min(z, 0) = z - relu(z)
+                    neg = K.axpby(y, 1.0, K.mul_cols(y, torch.ones(y.shape[-1], device=y.device), K.ACT_RELU), -1.0)
+                    terms = K.mul(gy, neg)
+            elif want_alpha:
                 gz, terms = K.act_grad(y, gy, ctx.act, ctx.alpha, want_alpha_terms=True)
-                seg = torch.tensor([0, terms.shape[0]], dtype=torch.int64, device=gy.device)
-                galpha = K.segment_reduce(terms, seg).sum().reshape(1)   # (the last 256 -> 1 is bookkeeping)
             else:
                 gz = K.act_grad(y, gy, ctx.act, ctx.alpha)
+            if want_alpha:
+                seg = torch.tensor([0, terms.shape[0]], dtype=torch.int64, device=gy.device)
+                galpha = K.segment_reduce(terms, seg).sum().reshape(1)   # (the last 256 -> 1 is bookkeeping)
         else:
             gz = gy
         gx = gb = None

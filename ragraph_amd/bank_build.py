@@ -31,18 +31,29 @@ from .ragraph_utils.utility import process_tu_dataset
 NUM_ANCHORS, DIS_Q = 10, 10.0   # ToyGraphBase.py:27-28 (num_anchors, dis_q)
 
 
-def compute_sample_prob(adj, graph_ptr: torch.Tensor | None = None) -> torch.Tensor:
+PAGERANK_MAX_ITER = 128   # d = 0.85, eps = 1e-6 converge within ~90 power iterations
+
+
+def compute_sample_prob(adj, graph_ptr: torch.Tensor | None = None, check: bool = True) -> torch.Tensor:
     """InverseSampling.compute_sample_prob (InverseSampling.py:6-19) for every graph of a block-diagonal batch at once:
     p ~ 1 / (0.5 * PageRank + 0.5 * degree centrality + 1e-6), normalised per graph.  `adj`: CSRGraph (or a dense
-    tensor); graph_ptr [G+1] node offsets (default: one graph).  No host synchronisation."""
+    tensor); graph_ptr [G+1] node offsets (default: one graph).  The reference iterates PageRank until it converges
+    (`while True`, InverseSampling.py:38-44); here PAGERANK_MAX_ITER iterations are enqueued up front, and `check` reads
+    the per-graph iteration counts back (one synchronisation: bank construction, not the hot path) and raises if a graph
+    used them all -- an unconverged iterate is never returned silently.  check=False: no host synchronisation."""
     g = adj if isinstance(adj, CSRGraph) else CSRGraph.from_dense(adj)
     if graph_ptr is None:
         graph_ptr = torch.tensor([0, g.n], dtype=torch.int64, device=g.device)
     gt = g.transposed()
     out_deg = K.csr_row_sums(g.rowptr, g.val)                    # :25 torch.sum(adj, dim=1)
-    p, _ = K.pagerank(gt.rowptr, gt.col, gt.val, out_deg, graph_ptr)   # :22-47
+    p, iters = K.pagerank(gt.rowptr, gt.col, gt.val, out_deg, graph_ptr, max_iter=PAGERANK_MAX_ITER)   # :22-47
     col_sum = K.csr_row_sums(gt.rowptr, gt.val)                  # :53 torch.sum(adj, dim=0)
-    return K.sample_prob(p, col_sum, graph_ptr)                  # :10-17
+    prob = K.sample_prob(p, col_sum, graph_ptr)                  # :10-17
+    if check and int(iters.max()) >= PAGERANK_MAX_ITER:
+        raise RuntimeError(f"PageRank did not converge within {PAGERANK_MAX_ITER} iterations for "
+                           f"{int((iters >= PAGERANK_MAX_ITER).sum())} of {iters.numel()} graphs (the reference iterates "
+                           f"until ||dp||_1 < 1e-6, InverseSampling.py:38-44)")
+    return prob
 
 
 def _intra_graph_pairs(graph_ptr: torch.Tensor):

@@ -95,11 +95,13 @@ __global__ void __launch_bounds__(256) spmm_csr_kernel(const int64_t* __restrict
   // loops, ring / community structure, any locality in the node numbering) share an L2; the groups keep the XCDs'
   // loads interleaved (one contiguous eighth per XCD was 60 % slower on c5's bipartite graph: users and items differ).
   // RUN = 32 by default (RAGRAPH_SPMM_XCD_RUN).  Measured on c2's shape (tools/spmm_locality.py, profiles/
-  // r2_spmm_locality.txt): the kernel moves nnz x 1 KiB = 1.1 GB of gathers through the L2s per hop whatever the node
-  // order, ~11 TB/s at 100 us -- with a community-ordered graph and RUN = 256 the L2 MISSES fall to 124 MB (ideal 111)
-  // and the hop still takes 100 us; on c2's Erdos-Renyi graph 440 MB miss and it takes 133 us.  Two restructurings that
-  // attack the per-row dependent chain instead (rows of a run as one edge stream; row pointers and edge pairs fetched
-  // one and two tiles ahead) were 10 - 50 % slower: latency is not what bounds it.
+  // r2_spmm_locality.txt, restated in DESIGN.md section 4.3 with FETCH_SIZE doubled as gfx950 requires): on c2's
+  // Erdos-Renyi graph an XCD's L2 hits 15 - 20 % of the row gathers and the hop moves 0.98 GB over the fabric in 133 us --
+  // 7.3 TB/s, the chip's ceiling for random row gathers from a 100 MB table; a community-ordered graph with RUN = 256
+  // misses 0.35 GB and takes 100 us.  Column panels of one 128-byte line per row and XCD (profiles/r3_spmm_panel.txt)
+  // raise the hit rate to 34 % and take 12 % off; narrower panels move more requests than they save.  Two restructurings
+  // that attack the per-row dependent chain instead (rows of a run as one edge stream; row pointers and edge pairs
+  // fetched one and two tiles ahead) were 10 - 50 % slower: latency is not what bounds it.
   const unsigned grp = blockIdx.x / (8 * RUN), in = blockIdx.x % (8 * RUN);
   const unsigned blk = (grp + 1) * (8 * RUN) <= gridDim.x ? grp * (8 * RUN) + (in % 8) * RUN + in / 8 : blockIdx.x;
   int64_t row = (int64_t)blk * RPB + threadIdx.x / LPR;

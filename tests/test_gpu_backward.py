@@ -62,8 +62,11 @@ def test_spmm_autograd_matches_torch(dev):
             assert close(alpha.grad, a2.grad)
 
 
-def test_gcn_decode_layer_trains_like_torch(dev):
-    """The few-shot flavours' trainable layer (RAGraph_node_fewshot/RAGraph.py:69): fc weight, bias and PReLU slope."""
+@pytest.mark.parametrize("slope", [0.25, 0.0, -0.3])
+def test_gcn_decode_layer_trains_like_torch(dev, slope):
+    """The few-shot flavours' trainable layer (RAGraph_node_fewshot/RAGraph.py:69): fc weight, bias and PReLU slope -- also
+    for a slope that training has driven to zero or below (nn.PReLU is unconstrained): the fused epilogue's output no
+    longer determines the pre-activation there, and the layer keeps it instead."""
     from ragraph_amd.gcnlayers import GcnLayers
     from ragraph_amd.graph import CSRGraph
 
@@ -75,6 +78,7 @@ def test_gcn_decode_layer_trains_like_torch(dev):
     net = GcnLayers(18, D, 2, 0.3).to(dev)
     with torch.no_grad():
         net.convs[1].bias.normal_(0, 0.1)
+        net.convs[1].act.weight.fill_(slope)
     h = torch.randn(n, D, device=dev)
     w = torch.randn(n, D, device=dev)
     out = net.decode(h, g)

@@ -160,3 +160,22 @@ def test_edge_vanilla_phase_sampled_bank(dev):
     assert bool(same.any(dim=1).all())
     uo, io = m.generate()
     assert torch.isfinite(uo).all() and torch.isfinite(io).all() and uo.shape == (U, 64)
+
+
+
+def test_sample_prob_raises_when_pagerank_does_not_converge(dev, monkeypatch):
+    """The reference iterates PageRank until convergence (InverseSampling.py:38-44); the batched form enqueues a fixed
+    number of iterations and must not hand back an unconverged iterate silently."""
+    from ragraph_amd import bank_build
+    from ragraph_amd.graph import CSRGraph
+
+    rng = np.random.default_rng(3)
+    a = (rng.random((60, 60)) < 0.1).astype(np.float32)
+    a = np.maximum(a, a.T)
+    g = CSRGraph.from_dense(T(a, dev))
+    p = bank_build.compute_sample_prob(g)                       # converges well inside the default budget
+    assert torch.isfinite(p).all() and abs(float(p.sum()) - 1.0) < 1e-5
+    monkeypatch.setattr(bank_build, "PAGERANK_MAX_ITER", 3)
+    with pytest.raises(RuntimeError, match="did not converge"):
+        bank_build.compute_sample_prob(g)
+    assert torch.isfinite(bank_build.compute_sample_prob(g, check=False)).all()
