@@ -698,7 +698,7 @@ __global__ void __launch_bounds__(128) topk_rescore_coop_kernel(const float* __r
                                                                 const int64_t* prev_i, int final_level, float* out_s,
                                                                 int64_t* out_i, int* __restrict__ overflow,
                                                                 int* __restrict__ overflow_list,
-                                                                unsigned char* __restrict__ flag) {
+                                                                unsigned char* __restrict__ flag, int64_t scan_n) {
   __shared__ float4 qs[2][D / 4];
   __shared__ __attribute__((aligned(16))) float tile[2][(FEWTILE ? 16 : 64) * RESCORE_LD];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -715,6 +715,11 @@ __global__ void __launch_bounds__(128) topk_rescore_coop_kernel(const float* __r
   if (n > cap) {
     over = true;
     n = cap;
+  }
+  if (final_level && over && scan_n > 0) {  // (wave-uniform) calls of up to 16384 queries: the query's wave scans the bank
+    if (lane == 0) atomicAdd(overflow, 1);  // itself, and the call needs no fallback launch
+    exact_scan_wave<D>(qs[w], Kn, scan_n, k, idx_base, lane, out_s + b * k, out_i + b * k);
+    return;
   }
   if (lane == 0) {
     if (final_level) {
@@ -1469,6 +1474,9 @@ static int run_rescore(const FilterWs& f, const float* Kn, int64_t N, int64_t B,
   // a handful of queries: S workgroups per query, each with its sub-list
   const int S = B <= 256 ? rescore_slices(B, k) : 1;
   const int cs = filter_count_stride(B);
+  // mid-sized calls: an overflowed query is scanned by its own rescoring wave (no fallback launch); large batches keep
+  // the dedicated launch, whose four-wave workgroups scan a bank faster when MANY queries overflow
+  const int64_t scan_n = B <= FILTER_SLAB_MAX_B ? N : 0;
   if (B < wide_max_b && S > 1) {
     hipLaunchKernelGGL((topk_rescore_wide_kernel<D, true, true>), dim3((unsigned)B, (unsigned)S), dim3(256), 0, st, f.Qn, Kn, f.count,
                        f.cand, B, N, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list,
@@ -1494,13 +1502,17 @@ static int run_rescore(const FilterWs& f, const float* Kn, int64_t N, int64_t B,
     hipLaunchKernelGGL((topk_rescore_wide_kernel<D, false, false>), dim3((unsigned)B), dim3(256), 0, st, f.Qn, Kn, f.count, f.cand,
                        B, N, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag,
                        (float*)nullptr, (int*)nullptr);
-  } else if (rescore_coop() && few)
+  } else if (rescore_coop() && few) {
+    *fallback_done = scan_n > 0;
     hipLaunchKernelGGL((topk_rescore_coop_kernel<D, 32, true>), dim3((unsigned)cdiv(B, 2)), dim3(128), 0, st, f.Qn, Kn, f.count,
-                       f.cand, B, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag);
-  else if (rescore_coop())
+                       f.cand, B, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag,
+                       scan_n);
+  } else if (rescore_coop()) {
+    *fallback_done = scan_n > 0;
     hipLaunchKernelGGL((topk_rescore_coop_kernel<D, 32>), dim3((unsigned)cdiv(B, 2)), dim3(128), 0, st, f.Qn, Kn, f.count,
-                       f.cand, B, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag);
-  else
+                       f.cand, B, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag,
+                       scan_n);
+  } else
     hipLaunchKernelGGL((topk_rescore_kernel<D, 32>), dim3((unsigned)cdiv(B, 4)), dim3(256), 0, st, f.Qn, Kn, f.count, f.cand,
                        B, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag);
   RG_CHECK_LAUNCH("topk_cosine_filtered(rescore)");

@@ -505,6 +505,26 @@ def test_topk_cosine_filtered_overflow_falls_back(dev):
     assert np.array_equal(i1.cpu().numpy(), ri4) and np.array_equal(s1.cpu().numpy(), rs4)
 
 
+def test_topk_cosine_filtered_overflow_mid_batch_scans_in_the_rescoring_wave(dev):
+    """2048..16384 queries (one wave per query in the rescoring kernel): an overflowed query is answered by that wave's own
+    exact scan on the final level -- no fallback launch -- still the oracle's bits; ordinary queries beside it unaffected."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(23)
+    base = rng.standard_normal((1, 128), dtype=np.float32)
+    kn = cref.normalize_rows(np.concatenate([base + 1e-3 * rng.standard_normal((9000, 128), dtype=np.float32),
+                                             rng.standard_normal((3000, 128), dtype=np.float32)]))
+    q = rng.standard_normal((2600, 128), dtype=np.float32)
+    q[5] = base[0]
+    q[77] = 0.0
+    q[2599] = base[0] + 1e-3 * rng.standard_normal(128, dtype=np.float32)
+    knd = _t(kn, dev)
+    s, i, over = K.topk_cosine_filtered(_t(q, dev), knd, K.keys_to_bf16(knd), 10, idx_base=3)
+    assert int(over) >= 3
+    rs, ri = cref.topk_cosine(q, kn, 10, idx_base=3)
+    assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs)
+
+
 def test_filtered_bound_pass_shapes_match_fp32_kernels(dev):
     """Banks of >= 65536 keys take their first bound from the bound pass (k group maxima of approximate scores over a
     prefix).  Shapes around its edges -- the smallest such bank, one and 32 groups, every D, one / two query groups per
