@@ -66,10 +66,20 @@ struct DirectParams {
   int qgroups;            // groups of 16 queries (2..16, even: the query image is padded to whole 32s)
 };
 
+#ifdef RG_DIRECT_TIMING  // diagnostic build: wall-clock stamps (10 ns ticks) of the first and the last workgroup's thread 0
+__device__ unsigned long long g_direct_t[2][2][8];
+#define RG_DSTAMP(i_)                                                                       \
+  if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))                \
+  g_direct_t[BOUND][blockIdx.x != 0][i_] = wall_clock64()
+#else
+#define RG_DSTAMP(i_)
+#endif
+
 // QREG: <= 32 queries, B operands in registers; else `qgroups` groups in LDS.
 template <int D, bool QREG, bool BOUND>
 __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams p) {
   using C = DirectCfg<D>;
+  RG_DSTAMP(0);
   extern __shared__ float4 dsmem4[];
   char* smem = reinterpret_cast<char*>(dsmem4);
   const int ngl = QREG ? 0 : p.qgroups;
@@ -103,6 +113,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
   __syncthreads();
   // everything the prologue loaded is retired before the first counted wait (see the header comment)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  RG_DSTAMP(1);
 
   // ---- this wave's units: gw, gw + W, gw + 2 W, ... (filter: neighbouring waves read neighbouring 16 KiB), or -- the
   // bound pass -- one contiguous run, so that a wave stays inside one part of the range and keeps that part's running
@@ -318,6 +329,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
     }
     if (i < n_mine) process(A0, u0 + i * ustride, std::false_type{});  // odd count: the last unit, nothing behind it
   }
+  RG_DSTAMP(2);
   if constexpr (BOUND) {
     // The waves of a workgroup run through neighbouring units, so most of them end in the same part: their maxima are
     // combined in LDS and leave as ONE atomic per query and part -- a few hundred waves updating the same k words of a
@@ -344,6 +356,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
   } else {
     flush();
   }
+  RG_DSTAMP(3);
 #undef RG_DWAIT
 #undef RG_DLOAD
 }
@@ -357,6 +370,18 @@ static int launch_direct(const DirectParams& p, int grid, size_t lds, hipStream_
   }
   hipLaunchKernelGGL((topk_filter_direct_kernel<D, QREG, BOUND>), dim3((unsigned)grid), dim3(512), lds, st, p);
   RG_CHECK_LAUNCH("topk_cosine_filtered(direct filter)");
+#ifdef RG_DIRECT_TIMING
+  {
+    (void)hipDeviceSynchronize();
+    unsigned long long t[2][2][8];
+    (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_direct_t), sizeof(t));
+    for (int b = 0; b < 2; ++b)
+      fprintf(stderr, "[direct timing, %s pass, %s block of %d, 10 ns ticks] prologue %lld units %lld tail %lld (started %lld after block 0)\n",
+              BOUND ? "bound" : "filter", b ? "last" : "first", grid, (long long)(t[BOUND][b][1] - t[BOUND][b][0]),
+              (long long)(t[BOUND][b][2] - t[BOUND][b][1]), (long long)(t[BOUND][b][3] - t[BOUND][b][2]),
+              (long long)(t[BOUND][b][0] - t[BOUND][0][0]));
+  }
+#endif
   return RAGRAPH_OK;
 }
 
