@@ -2,6 +2,7 @@
 // topk_filter_direct.hip: the register-fed kernel for up to 256 queries).
 #pragma once
 #include "common.h"
+#include <climits>
 
 namespace ragraph {
 
@@ -37,6 +38,28 @@ __host__ __device__ constexpr int64_t filter_block_offset(int64_t subtile, int D
   return (subtile * (D / 16) + 2 * t + h) * 1024;
 }
 
+// The INT8 copy behind the bf16 copy (ragraph_keys_to_bf16 makes both).  v_mfma_i32_16x16x64_i8 issues at the cycles of the
+// bf16 MFMA with twice the K: in the filter's own inner loop it sustains 3.29 - 3.53 Pop/s where bf16 sustains 1.68 PFLOP/s
+// (tools/microbench/mfma_i8_bench.hip) -- twice the (query, key) pairs per second -- and a key is 1 byte per element.
+//   * keys: ONE scale for the bank, s_k = max |k_i| / 127 (a per-key scale would have to be applied to every score before
+//     the threshold test; the bound below only depends on the LARGEST key error anyway), ki = rint(k / s_k);
+//   * queries: a scale per query, s_q = max |q_i| / 127, qi = rint(q / s_q) (a query's scale folds into its threshold);
+//   * the approximate score is s~ = s_q s_k I with I = sum qi ki an EXACT integer (|I| <= 127^2 D < 2^23), and with
+//     q^ = s_q qi = q + dq, k^ = s_k ki = k + dk:  |s~ - s| <= |q^||dk| + |dq||k| <= |dq| + max|dk| + |dq| max|dk| (+ the
+//     2e-7 by which a normalised row's norm can exceed 1): filter_eps' formula with the int8 errors, ~0.02 on Gaussian
+//     rows where bf16 gives 0.004.  A key of the exact top-k has I >= (theta - eps) / (s_q s_k): the test runs on the
+//     integers, against T = floor of that quotient - 2 (the quotient's fp32 rounding is < 1 unit at |I| < 2^23).
+//   A wider eps lets ~3x as many keys through (150 instead of 50 per query at the last level of the bench shape), so int8
+//   serves the LATE levels of large batches, where the threshold is high and the matrix work is what costs.
+// Layout: the geometry of the bf16 copy at half the row bytes -- sub-tiles of 32 keys = D/64 k-steps x 2 halves = D/32
+// blocks of 1 KiB; block 2 t + h of sub-tile u: lane j + 16 g owns the 16 bytes holding elements 64 t + 16 g .. + 15 of
+// key 32 u + 16 h + j (A operand of v_mfma_i32_16x16x64_i8; any fixed assignment of the 64 elements to the four lane
+// groups is right as long as the query operand uses the same one: the integer sum does not depend on the order).
+// Tail of the int8 copy (one row): [0] max_k |dk|^2 (float bits), [1] s_k (float), [2] max |k_i| (float bits, >= 0).
+__host__ __device__ constexpr int64_t filter_i8_block_offset(int64_t subtile, int D, int t, int h) {
+  return (subtile * (D / 32) + 2 * t + h) * 1024;
+}
+
 // float <-> int with the same order (for atomicMax on scores of either sign)
 __device__ __forceinline__ int f2ord(float f) {
   const int b = __float_as_int(f);
@@ -57,6 +80,10 @@ struct FilterThr {
   const unsigned* max_kerr2;  // bank: max_k |dk|^2 as float bits
   int k, ngroups;
   int ablate;                 // timing only: nothing passes
+  // int8 levels: [B] |dq| of the query's int8 rounding, [B] its scale s_q, the int8 copy's tail (max |dk|^2, s_k)
+  const float* eq8;
+  const float* qscale;
+  const unsigned* tail8;
 };
 
 __device__ __forceinline__ float filter_eps(const FilterThr& t, int64_t q) {
@@ -65,20 +92,35 @@ __device__ __forceinline__ float filter_eps(const FilterThr& t, int64_t q) {
   return fmaf(fmaf(e, ek, e + ek), 1.0009765625f, FILTER_EPS_SLACK);  // rounding direction is inside the factor
 }
 
-__device__ __forceinline__ float filter_threshold(const FilterThr& t, int64_t q) {
-  if (t.ablate == 1) return __builtin_huge_valf();
-  const float eps = filter_eps(t, q);
-  float theta;
-  if (t.theta) {
-    theta = t.theta[q];
-  } else if (t.gmax) {
+// theta[q]: the proven lower bound of the query's final k-th best exact score a level filters with
+__device__ __forceinline__ float filter_theta(const FilterThr& t, int64_t q) {
+  if (t.theta) return t.theta[q];
+  if (t.gmax) {
     int m = t.gmax[q * t.ngroups];
     for (int g = 1; g < t.ngroups; ++g) m = min(m, t.gmax[q * t.ngroups + g]);
-    theta = __fsub_rn(ord2f(m), eps);
-  } else {
-    theta = t.prev_scores[q * t.k + t.k - 1];
+    return __fsub_rn(ord2f(m), filter_eps(t, q));   // (the bound pass ran on the bf16 copy)
   }
-  return __fsub_rn(theta, eps);
+  return t.prev_scores[q * t.k + t.k - 1];
+}
+
+__device__ __forceinline__ float filter_threshold(const FilterThr& t, int64_t q) {
+  if (t.ablate == 1) return __builtin_huge_valf();
+  return __fsub_rn(filter_theta(t, q), filter_eps(t, q));
+}
+
+// The int8 levels' integer threshold: a key can only belong to the exact top-k if I = sum qi ki >= the result (see the
+// layout comment above).  INT_MIN: everything passes (zero queries / banks, whose scales are 0).
+__device__ __forceinline__ int filter_threshold_i8(const FilterThr& t, int64_t q) {
+  if (t.ablate == 1) return INT_MAX;
+  const float ek = sqrtf(__uint_as_float(t.tail8[0]));
+  const float e = t.eq8[q];
+  const float eps = fmaf(fmaf(e, ek, e + ek), 1.0009765625f, FILTER_EPS_SLACK);
+  const float sc = t.qscale[q] * __uint_as_float(t.tail8[1]);
+  if (!(sc > 0.f)) return INT_MIN;
+  const float x = __fsub_rn(filter_theta(t, q), eps) / sc;
+  if (!(x > -8.4e6f)) return INT_MIN;   // (also NaN)
+  if (x > 8.4e6f) return INT_MAX;       // beyond any |I| <= 127^2 * 256: nothing can pass
+  return (int)floorf(x) - 2;
 }
 
 // Candidate counters of a call of fewer than 2048 queries.  A returning atomicAdd costs ~11 ns per operation on ONE address

@@ -36,10 +36,12 @@
 #include "rescore_common.h"
 #include "segment_plan.h"
 #include <cmath>
+#include <type_traits>
 
 namespace ragraph {
 
 typedef __attribute__((address_space(3))) void lds_void_f;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 template <int D_>
 struct FilterCfg {
@@ -126,6 +128,60 @@ __global__ void __launch_bounds__(256) keys_to_bf16_kernel(const float* __restri
     atomicMax(max_err2, __float_as_uint(e2));
 }
 
+// The int8 copy (filter_common.h): the bank's largest |k_i| first (the one scale), then quantise + lay out + the largest
+// |dk|^2.  tail8: [0] max |dk|^2, [1] s_k, [2] max |k_i| -- zeroed by the caller before the first kernel.
+__global__ void __launch_bounds__(256) bank_absmax_kernel(const float* __restrict__ Kn, int64_t n4, unsigned* __restrict__ tail8) {
+  unsigned m = 0u;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(Kn)[i];
+    m = max(max(m, __float_as_uint(fabsf(v.x))), max(__float_as_uint(fabsf(v.y)), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w)))));
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+  if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(tail8 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(tail8 + 2, m);
+}
+
+__device__ __forceinline__ int quantize_i8(float x, float scale) {  // rint(x / scale) clamped to [-127, 127]; scale > 0
+  return (int)fminf(fmaxf(__builtin_rintf(x / scale), -127.f), 127.f);
+}
+
+template <int D>
+__global__ void __launch_bounds__(256) keys_to_i8_kernel(const float* __restrict__ Kn, int64_t N, int64_t Npad,
+                                                         signed char* __restrict__ Kb8, unsigned* __restrict__ tail8) {
+  constexpr int TPR = D / 16;  // threads per row (one thread = 16 elements = one lane's piece of a block): 4 / 8 / 16
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = i / TPR;
+  const float sk = __uint_as_float(tail8[2]) / 127.f;
+  if (i == 0) tail8[1] = __float_as_uint(sk);
+  unsigned w[4] = {0u, 0u, 0u, 0u};
+  float e2 = 0.f;
+  if (i < Npad * TPR && row < N && sk > 0.f) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 a = reinterpret_cast<const float4*>(Kn)[4 * i + c];
+      const float x[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int qi = quantize_i8(x[e], sk);
+        w[c] |= ((unsigned)qi & 0xFFu) << (8 * e);
+        const float d = fmaf(sk, (float)qi, -x[e]);
+        e2 = fmaf(d, d, e2);
+      }
+    }
+  } else if (i < Npad * TPR && row < N) {  // an all-zero bank: the copy is zero, the error is the row itself (0)
+  }
+  if (i < Npad * TPR) {
+    const int c = (int)(i % TPR);  // piece c = 4 t + g of the row
+    const int64_t dst = filter_i8_block_offset(row >> 5, D, c >> 2, (int)(row >> 4) & 1) + (((c & 3) * 16 + (int)(row & 15)) << 4);
+    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Kb8) + dst) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+#pragma unroll
+  for (int off = TPR / 2; off >= 1; off >>= 1) e2 += __shfl_xor(e2, off);
+  e2 *= 1.000001f;  // (the fmaf's rounding of each difference)
+  if ((threadIdx.x & (TPR - 1)) == 0 && __float_as_uint(e2) > __hip_atomic_load(tail8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(tail8, __float_as_uint(e2));
+}
+
 // Everything a call needs before its first filter launch, in ONE launch (one wave per query): the normalised query row
 // (the norm tree, sqrt and divisions of normalize_rows_kernel, so the same bits), |dq| of its bf16 rounding, an empty
 // candidate list, a clear overflow flag, and -- before a bound pass -- the group maxima at -inf.
@@ -134,7 +190,8 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
                                                           float* __restrict__ eq, int* __restrict__ count,
                                                           unsigned char* __restrict__ flag, int* __restrict__ overflow,
                                                           int* __restrict__ gmax, int ngroups,
-                                                          uint16_t* __restrict__ Qb, int cstride) {
+                                                          uint16_t* __restrict__ Qb, int cstride,
+                                                          float* __restrict__ eq8, float* __restrict__ qscale) {
   const int lane = threadIdx.x & 63;
   const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q == 0 && lane == 0) *overflow = 0;
@@ -174,10 +231,32 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) e2 += __shfl_xor(e2, off);
+  float e8 = 0.f, sq = 0.f;
+  if (eq8) {  // (kernel-uniform) the query's int8 scale and rounding error (filter_common.h; the ring kernel re-quantises
+              // the row with the SAME expression, so this is the error of the operands it multiplies)
+    unsigned am = max(max(__float_as_uint(fabsf(v.x)), __float_as_uint(fabsf(v.y))), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w))));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, off));
+    sq = __uint_as_float(am) / 127.f;
+    if (sq > 0.f) {
+      const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dd = fmaf(sq, (float)quantize_i8(x[e], sq), -x[e]);
+        e8 = fmaf(dd, dd, e8);
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) e8 += __shfl_xor(e8, off);
+  }
   if (q >= B) return;
   if (lane == 0) {
     eq[q] = sqrtf(e2) * 1.0000002f;  // (any summation order of the squares stays below this)
     flag[q] = 0;
+    if (eq8) {
+      eq8[q] = sqrtf(e8) * 1.000001f;
+      qscale[q] = sq;
+    }
   }
   if (lane < cstride) count[q * cstride + lane] = 0;
   if (gmax)
@@ -274,9 +353,12 @@ __device__ unsigned long long g_filter_timing[8];
 // (D = 64, long streams: tile = 1024).
 // BOUND: no thresholds, no candidates -- the launch only records, per query, the best approximate score of each of
 // p.ngroups consecutive parts of its key range (filter_prepare_kernel turns them into the first lower bound).
-template <int D, int QW, bool BOUND = false>
+// I8: the level runs on the int8 copy (filter_common.h): the ring geometry of a bf16 bank of D / 2 elements (a key is D
+// bytes), v_mfma_i32_16x16x64_i8, integer thresholds; the queries are quantised from the normalised fp32 rows here.
+template <int D, int QW, bool BOUND = false, bool I8 = false>
 __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
-  using C = FilterCfg<D>;
+  using C = FilterCfg<I8 ? D / 2 : D>;
+  static_assert(!(I8 && BOUND), "the bound pass runs on the bf16 copy");
   static_assert(QW == 32 || QW == 64 || QW == 128, "two, four or eight query groups of 16 per wave");
   constexpr int QT = C::WAVES * QW;
   constexpr int NG = QW / 16;  // query groups per wave: each A fragment (16 keys x 32 elements) feeds NG MFMAs
@@ -332,9 +414,35 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     const int nstages = (int)(seg.st1 - seg.st0);
 
     // ---- B operands: group gq's query q_lo + 16 gq, k-step t = elements 32 t + 8 g .. + 7, converted to bf16 (RNE) ----
-    bf16x8 bq[NG][C::KS32];
+    // (int8 levels: elements 64 t + 16 g .. + 15, quantised with the query's scale exactly as filter_prep_kernel did)
+    bf16x8 bq[I8 ? 1 : NG][I8 ? 1 : C::KS32];
+    i32x4 bqi[I8 ? NG : 1][I8 ? C::KS32 : 1];
     constexpr int TB = C::KS32 < 4 ? C::KS32 : 4;
-    if (p.Qb) {  // prepared image: block (group * KS32 + t), this lane's 16 bytes; groups beyond the padded batch: zeros
+    if constexpr (I8) {
+#pragma unroll
+      for (int gq = 0; gq < NG; ++gq) {
+        const int64_t qq = q_lo + 16 * gq;
+        const int64_t qr = qq < p.B ? qq : p.B - 1;
+        const float sq = p.thr.qscale[qr];
+        const float* r0 = p.Qn + qr * D + 16 * g;
+#pragma unroll
+        for (int t = 0; t < C::KS32; ++t) {
+          float4 u[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) u[c] = *reinterpret_cast<const float4*>(r0 + 64 * t + 4 * c);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            unsigned w = 0u;
+            if (sq > 0.f)
+              w = ((unsigned)quantize_i8(u[c].x, sq) & 0xFFu) | (((unsigned)quantize_i8(u[c].y, sq) & 0xFFu) << 8) |
+                  (((unsigned)quantize_i8(u[c].z, sq) & 0xFFu) << 16) | (((unsigned)quantize_i8(u[c].w, sq) & 0xFFu) << 24);
+            bqi[gq][t][c] = (int)w;
+          }
+          asm volatile("" : "+v"(bqi[gq][t]));
+        }
+        asm volatile("" ::: "memory");
+      }
+    } else if (p.Qb) {  // prepared image: block (group * KS32 + t), this lane's 16 bytes; groups beyond the padded batch: zeros
       const int64_t qg0 = (qtile * QT + wave * QW) >> 4;
       const int64_t ngroups16 = ((p.B + 31) / 32 * 32) >> 4;
 #pragma unroll
@@ -369,9 +477,12 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     }
     // padded queries never pass: +inf threshold
     float thr[NG];
+    int thr8[NG];  // (int8 levels) the integer threshold
 #pragma unroll
-    for (int gq = 0; gq < NG; ++gq)
-      thr[gq] = (!BOUND && q_lo + 16 * gq < p.B) ? filter_threshold(p.thr, q_lo + 16 * gq) : __builtin_huge_valf();
+    for (int gq = 0; gq < NG; ++gq) {
+      thr[gq] = (!BOUND && !I8 && q_lo + 16 * gq < p.B) ? filter_threshold(p.thr, q_lo + 16 * gq) : __builtin_huge_valf();
+      thr8[gq] = (I8 && q_lo + 16 * gq < p.B) ? filter_threshold_i8(p.thr, q_lo + 16 * gq) : INT_MAX;
+    }
     // bound pass: running maxima of the current group (group g = stages [ceil(g n / G), ceil((g+1) n / G)) of the range)
     float gm[NG];
 #pragma unroll
@@ -434,10 +545,10 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     // hand them to the loop as plain register values
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
 #pragma unroll
-    for (int gq = 0; gq < NG; ++gq) asm volatile("" : "+v"(thr[gq]));
+    for (int gq = 0; gq < NG; ++gq) asm volatile("" : "+v"(thr[gq]), "+v"(thr8[gq]));
     int thr_i[NG];
 #pragma unroll
-    for (int gq = 0; gq < NG; ++gq) thr_i[gq] = thr[gq] >= 0.f ? __float_as_int(thr[gq]) : INT_MIN;
+    for (int gq = 0; gq < NG; ++gq) thr_i[gq] = I8 ? thr8[gq] : (thr[gq] >= 0.f ? __float_as_int(thr[gq]) : INT_MIN);
 
     // ---- ring prologue ------------------------------------------------------------------------------------------
     const int pro = nstages < C::SLOTS - 1 ? nstages : C::SLOTS - 1;
@@ -469,12 +580,18 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
       fring_wait(full + slot, (unsigned)(C::WAVES * (gen + 1)));
       RG_FT(t1);
       // epilogue of sub-tile u: a[h][gq][r] = approximate score of key 16 h + 4 g + r of the sub-tile for query j of group gq
-      auto pass_mask = [&](const f32x4 (&a)[2][NG], int gq, float thr) {
+      using acc_t = typename std::conditional<I8, i32x4, f32x4>::type;
+      auto pass_mask = [&](const acc_t (&a)[2][NG], int gq) {  // float scores against thr, integer sums against thr_i
         unsigned mk = 0;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) mk |= (a[h][gq][r] >= thr) ? (1u << (4 * h + r)) : 0u;
+          for (int r = 0; r < 4; ++r) {
+            bool ok;
+            if constexpr (I8) ok = a[h][gq][r] >= thr_i[gq];
+            else ok = a[h][gq][r] >= thr[gq];
+            mk |= ok ? (1u << (4 * h + r)) : 0u;
+          }
         return mk;
       };
       // the groups' entries of one sub-tile: ballots first, ONE buffer check per (up to) four groups -- a flush is ~60
@@ -502,7 +619,11 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
           }
         }
       };
-      auto epilogue = [&](int u, const f32x4 (&a)[2][NG]) {
+      auto as_bits = [](auto x) {  // a score as the signed integer the hit test compares
+        if constexpr (I8) return (int)x;
+        else return __float_as_int(x);
+      };
+      auto epilogue = [&](int u, const acc_t (&a)[2][NG]) {
         // Filter levels test "does any of the lane's 8 scores reach the threshold" on the scores' BIT PATTERNS as signed
         // integers: for a threshold >= +0 that is the float comparison (negative scores are negative integers, the MFMA
         // never produces -0 or NaN from finite operands), v_max3_i32 needs none of the canonicalising v_max x, x that
@@ -514,21 +635,21 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
         if constexpr (BOUND) {
 #pragma unroll
           for (int gq = 0; gq < NG; ++gq) {  // (a chain, not a tree: hipcc folds it into v_max3_f32 -- 4 instructions, not 7)
-            m[gq] = a[0][gq][0];
+            m[gq] = (float)a[0][gq][0];
 #pragma unroll
-            for (int r = 1; r < 4; ++r) m[gq] = fmaxf(m[gq], a[0][gq][r]);
+            for (int r = 1; r < 4; ++r) m[gq] = fmaxf(m[gq], (float)a[0][gq][r]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) m[gq] = fmaxf(m[gq], a[1][gq][r]);
+            for (int r = 0; r < 4; ++r) m[gq] = fmaxf(m[gq], (float)a[1][gq][r]);
             gm[gq] = fmaxf(gm[gq], m[gq]);
           }
         } else {
 #pragma unroll
           for (int gq = 0; gq < NG; ++gq) {
-            mi[gq] = __float_as_int(a[0][gq][0]);
+            mi[gq] = as_bits(a[0][gq][0]);
 #pragma unroll
-            for (int r = 1; r < 4; ++r) mi[gq] = max(mi[gq], __float_as_int(a[0][gq][r]));
+            for (int r = 1; r < 4; ++r) mi[gq] = max(mi[gq], as_bits(a[0][gq][r]));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mi[gq] = max(mi[gq], __float_as_int(a[1][gq][r]));
+            for (int r = 0; r < 4; ++r) mi[gq] = max(mi[gq], as_bits(a[1][gq][r]));
             hit = hit || (mi[gq] >= thr_i[gq]);
           }
         }
@@ -542,7 +663,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
 #pragma unroll
           for (int gq = 0; gq < NG; ++gq) {
             km[gq] = 0;
-            if (__any(mi[gq] >= thr_i[gq])) km[gq] = pass_mask(a, gq, thr[gq]);
+            if (__any(mi[gq] >= thr_i[gq])) km[gq] = pass_mask(a, gq);
           }
           if (stage_key0 + C::STAGE_KEYS > (int)p.N) {  // the range's last stage: keys >= N (padding, or the next level's)
             unsigned vm = 0;
@@ -561,7 +682,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
       // loads, invisible to hipcc's waitcnt bookkeeping: RG_FWAIT counts them (LDS returns in order; anything else
       // outstanding only makes the wait stricter) and names the fragment so its MFMAs stay behind the wait.
       const unsigned addr = apos + (unsigned)(slot * C::STAGE_BYTES);
-      f32x4 acc[2][NG];
+      acc_t acc[2][NG];
       f32x4 fr[4];
 #define RG_FREAD(n_)                                                                                       \
   asm volatile("ds_read_b128 %0, %1 offset:%2"                                                             \
@@ -571,17 +692,22 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
 #define RG_FSTEP(n_)                                                                                       \
   {                                                                                                        \
     if constexpr ((n_) % C::KSTEPS == 0) {                                                                 \
-      _Pragma("unroll") for (int gq = 0; gq < NG; ++gq) acc[0][gq] = acc[1][gq] = f32x4{0.f, 0.f, 0.f, 0.f}; \
+      _Pragma("unroll") for (int gq = 0; gq < NG; ++gq) acc[0][gq] = acc[1][gq] = acc_t{0, 0, 0, 0};       \
     }                                                                                                      \
     if constexpr ((n_) + 3 < C::NSTEP) RG_FWAIT(3, n_);                                                     \
     else if constexpr ((n_) + 2 < C::NSTEP) RG_FWAIT(2, n_);                                                \
     else if constexpr ((n_) + 1 < C::NSTEP) RG_FWAIT(1, n_);                                                \
     else RG_FWAIT(0, n_);                                                                                   \
-    {                                                                                                      \
+    if constexpr (I8) {                                                                                    \
+      const i32x4 a_ = __builtin_bit_cast(i32x4, fr[(n_)&3]);                                               \
+      _Pragma("unroll") for (int gq = 0; gq < NG; ++gq)                                                     \
+        acc[(n_) & 1][gq] = __builtin_bit_cast(acc_t, __builtin_amdgcn_mfma_i32_16x16x64_i8(                \
+            a_, bqi[gq][((n_) >> 1) % C::KS32], __builtin_bit_cast(i32x4, acc[(n_) & 1][gq]), 0, 0, 0));    \
+    } else {                                                                                               \
       const bf16x8 a_ = __builtin_bit_cast(bf16x8, fr[(n_)&3]);                                             \
       _Pragma("unroll") for (int gq = 0; gq < NG; ++gq)                                                     \
-        acc[(n_) & 1][gq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, bq[gq][((n_) >> 1) % C::KS32],      \
-                                                                    acc[(n_) & 1][gq], 0, 0, 0);          \
+        acc[(n_) & 1][gq] = __builtin_bit_cast(acc_t, __builtin_amdgcn_mfma_f32_16x16x32_bf16(              \
+            a_, bq[gq][((n_) >> 1) % C::KS32], __builtin_bit_cast(f32x4, acc[(n_) & 1][gq]), 0, 0, 0));     \
     }                                                                                                      \
     if constexpr ((n_) + 4 < C::NSTEP) RG_FREAD((n_) + 4);                                                  \
     if constexpr ((n_) % C::KSTEPS == C::KSTEPS - 1) epilogue((n_) / C::KSTEPS, acc);                       \
@@ -1082,6 +1208,7 @@ struct FilterSchedule {
   int slab0;                        // level 0 by dense kernel + topk_rows (needs B * n0 floats of workspace)
   int nlev;                         // filter levels
   int64_t ends[FILTER_MAX_LEVELS];  // their ends (multiples of 256 except the last = N)
+  int i8_levels;                    // the last i8_levels levels run on the int8 copy (filter_common.h)
 };
 
 constexpr int64_t FILTER_SLAB_MAX_B = 16384;
@@ -1235,6 +1362,20 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
   return sc;
 }
 
+// Which levels run on the int8 copy: the LAST level of a large batch (D = 128 / 256).  Its threshold is the highest of the
+// call, so the ~4x wider eps costs ~100 extra candidates per query (1 KiB row gathers: ~2.5 ms at the bench shape) where
+// the matrix work of three quarters of the bank halves (25.6 -> ~13 ms).  Earlier levels and smaller batches stay on
+// bf16: a level of a few thousand queries is not matrix-bound enough to pay for the extra rescoring.
+// RAGRAPH_FILTER_I8 = n forces the last n levels (0: none) -- A/B runs and the tests of the int8 path on small shapes.
+static int filter_i8_levels(const FilterSchedule& sc, int64_t B, int D) {
+  const char* env = getenv("RAGRAPH_FILTER_I8");  // (read per call: the tests switch it)
+  const int force = env ? atoi(env) : -1;
+  if (D != 128 && D != 256) return 0;
+  if (B <= 256) return 0;  // (the direct kernel has no int8 form)
+  if (force >= 0) return force < sc.nlev ? force : sc.nlev;
+  return B > FILTER_SLAB_MAX_B ? 1 : 0;
+}
+
 // workspace of level 0: the tile kernel's, or the score slab
 static size_t filter_level0_ws(const FilterSchedule& sc, int64_t B, int D, int k) {
   if (sc.bound_keys > 0) return 0;
@@ -1261,11 +1402,32 @@ extern "C" int ragraph_keys_to_bf16(const float* Kn, int64_t N, int D, uint16_t*
   else if (D == 128) hipLaunchKernelGGL(keys_to_bf16_kernel<128>, grid, dim3(256), 0, st, Kn, N, npad, Kb, tail);
   else hipLaunchKernelGGL(keys_to_bf16_kernel<64>, grid, dim3(256), 0, st, Kn, N, npad, Kb, tail);
   RG_CHECK_LAUNCH("keys_to_bf16");
+  // the int8 copy behind it (filter_common.h): the bank's largest |k_i| -> one scale, then quantise + lay out
+  signed char* Kb8 = reinterpret_cast<signed char*>(Kb + (npad + 1) * D);
+  unsigned* tail8 = reinterpret_cast<unsigned*>(Kb8 + npad * D);
+  if (hipMemsetAsync(tail8, 0, (size_t)D * sizeof(uint16_t), st) != hipSuccess) {
+    set_error("keys_to_bf16: memset failed");
+    return RAGRAPH_EDEVICE;
+  }
+  const int64_t n4 = N * D / 4;
+  int64_t ab = cdiv(n4, (int64_t)256);
+  if (ab > 4096) ab = 4096;
+  hipLaunchKernelGGL(bank_absmax_kernel, dim3((unsigned)ab), dim3(256), 0, st, Kn, n4, tail8);
+  const dim3 grid8((unsigned)cdiv(npad * (D / 16), 256));
+  if (D == 256) hipLaunchKernelGGL(keys_to_i8_kernel<256>, grid8, dim3(256), 0, st, Kn, N, npad, Kb8, tail8);
+  else if (D == 128) hipLaunchKernelGGL(keys_to_i8_kernel<128>, grid8, dim3(256), 0, st, Kn, N, npad, Kb8, tail8);
+  else hipLaunchKernelGGL(keys_to_i8_kernel<64>, grid8, dim3(256), 0, st, Kn, N, npad, Kb8, tail8);
+  RG_CHECK_LAUNCH("keys_to_bf16(int8 copy)");
   return RAGRAPH_OK;
 }
 
-// bank rows padded to whole ring stages + one row that carries the bank's largest rounding error
-extern "C" int64_t ragraph_keys_bf16_rows(int64_t N) { return N < 1 ? 0 : filter_round_up(N) + 1; }
+// rows of D uint16: the bf16 copy padded to whole ring stages + one row that carries the bank's largest rounding error,
+// then the int8 copy (half as many rows) + one row with its largest error and its scale
+extern "C" int64_t ragraph_keys_bf16_rows(int64_t N) {
+  if (N < 1) return 0;
+  const int64_t npad = filter_round_up(N);
+  return npad + 1 + npad / 2 + 1;
+}
 
 extern "C" int ragraph_topk_cosine_filtered_cap(int k) { return 2048; }
 static int rescore_slices(int64_t B, int k);
@@ -1316,6 +1478,8 @@ struct FilterWs {
   int* overflow_list;   // [B] queries the final level sends to the exact fallback
   float* part_s;        // (B <= 64) sliced rescoring: [B][8][k] partial winners
   int* part_i;
+  float* eq8;           // [B] |dq| of the int8 rounding, [B] the query's int8 scale (int8 levels)
+  float* qscale;
 };
 
 static size_t filter_ws_carve(char* w, int64_t B, int D, int k, int cap, FilterWs* out) {
@@ -1337,6 +1501,8 @@ static size_t filter_ws_carve(char* w, int64_t B, int D, int k, int cap, FilterW
   f.overflow_list = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   f.part_s = B <= 64 ? reinterpret_cast<float*>(take((size_t)B * 8 * k * sizeof(float))) : nullptr;
   f.part_i = B <= 64 ? reinterpret_cast<int*>(take((size_t)B * 8 * k * sizeof(int))) : nullptr;
+  f.eq8 = reinterpret_cast<float*>(take((size_t)B * sizeof(float)));
+  f.qscale = reinterpret_cast<float*>(take((size_t)B * sizeof(float)));
   if (out) *out = f;
   return off;
 }
@@ -1356,9 +1522,9 @@ static int rescore_slices(int64_t B, int k) {
 }
 
 // Ring-kernel launch shared by the filter levels and the bound pass (B > 256: the direct kernel takes smaller batches).
-template <int D, int QW, bool BOUND>
+template <int D, int QW, bool BOUND, bool I8 = false>
 static int launch_ring(FilterParams p, int64_t B, int prof_slot, hipStream_t st) {
-  using C = FilterCfg<D>;
+  using C = FilterCfg<I8 ? D / 2 : D>;
   p.qtiles = cdiv(B, (int64_t)C::WAVES * QW);
   const int CUS = filter_device_cus();
   p.xcd_map = p.qtiles >= 64 ? 1 : 0;
@@ -1378,12 +1544,12 @@ static int launch_ring(FilterParams p, int64_t B, int prof_slot, hipStream_t st)
     p.depth[v] = SegmentWalker::choose_depth(nq, p.nstages_total, p.wgs_per_group, p.lb_min, 0).depth;
   }
   static DeviceOnce lds_once;  // per template instance and device (common.h)
-  if (hipError_t e = raise_dynamic_lds(lds_once, &topk_filter_kernel<D, QW, BOUND>, (int)C::LDS_BYTES); e != hipSuccess) {
+  if (hipError_t e = raise_dynamic_lds(lds_once, &topk_filter_kernel<D, QW, BOUND, I8>, (int)C::LDS_BYTES); e != hipSuccess) {
     set_error("topk_cosine_filtered: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
     return RAGRAPH_EDEVICE;
   }
   if (g_prof_on) (void)hipEventRecord(g_prof_ev[2 * prof_slot], st);
-  hipLaunchKernelGGL((topk_filter_kernel<D, QW, BOUND>), dim3((unsigned)CUS), dim3(C::THREADS), C::LDS_BYTES, st, p);
+  hipLaunchKernelGGL((topk_filter_kernel<D, QW, BOUND, I8>), dim3((unsigned)CUS), dim3(C::THREADS), C::LDS_BYTES, st, p);
   if (g_prof_on) (void)hipEventRecord(g_prof_ev[2 * prof_slot + 1], st);
   RG_CHECK_LAUNCH("topk_cosine_filtered(filter)");
 #ifdef RG_TOPK_TIMING
@@ -1409,8 +1575,27 @@ static int launch_ring(FilterParams p, int64_t B, int prof_slot, hipStream_t st)
 // kernel with two -- at D = 64 and long streams four -- query groups per wave.
 template <int D>
 static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64_t key0, int64_t key1, const FilterThr& thr,
-                         int cap, int bound_groups, int prof_slot, hipStream_t st) {
+                         int cap, int bound_groups, int prof_slot, hipStream_t st, const signed char* Kb8 = nullptr) {
   using C = FilterCfg<D>;
+  if constexpr (D >= 128) {
+    if (Kb8) {  // an int8 level (filter_i8_levels): the ring kernel over the int8 copy, stages of twice as many keys
+      using C8 = FilterCfg<D / 2>;
+      FilterParams p{};
+      p.Qn = f.Qn;
+      p.Kb = reinterpret_cast<const uint16_t*>(Kb8);
+      p.thr = thr;
+      p.count = f.count;
+      p.cstride = filter_count_stride(B);
+      p.Qb = nullptr;
+      p.cand = f.cand;
+      p.B = B;
+      p.N = key1;
+      p.cap = cap;
+      p.stage_base = key0 / C8::STAGE_KEYS;  // key0 is a multiple of 256
+      p.nstages_total = cdiv(key1 - key0, C8::STAGE_KEYS);
+      return launch_ring<D, 64, false, true>(p, B, prof_slot, st);
+    }
+  }
   if (B <= 256) {
     DirectArgs a{};
     a.Qb = f.Qb;
@@ -1549,18 +1734,25 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   RG_REQUIRE(used <= ws_bytes, RAGRAPH_EWORKSPACE, "topk_cosine_filtered: the schedule of this call needs %zu bytes of workspace, "
              "%zu given", used, ws_bytes);
   const unsigned* max_kerr2 = reinterpret_cast<const unsigned*>(Kb + filter_round_up(N) * D);
+  // the int8 copy lies behind the bf16 copy and its tail row (ragraph_keys_to_bf16)
+  const signed char* Kb8 = reinterpret_cast<const signed char*>(Kb + (filter_round_up(N) + 1) * D);
+  const unsigned* tail8 = reinterpret_cast<const unsigned*>(Kb8 + filter_round_up(N) * D);
+  sc.i8_levels = filter_i8_levels(sc, B, D);
   const bool bound = sc.bound_keys > 0;
 
   // one launch: normalised queries, their bf16 rounding errors, empty lists, clear flags (+ group maxima at -inf)
   hipLaunchKernelGGL(filter_prep_kernel<D>, dim3((unsigned)cdiv(B <= FILTER_QB_MAX_B ? (B + 31) / 32 * 32 : B, 4)), dim3(256), 0, st, Q, B,
                      f.Qn, f.eq, f.count, f.flag, overflow, bound ? f.gmax : nullptr, bound ? filter_bound_parts(k, sc.bound_keys, D, B, exchange ? n_shards : 1) : k,
                      B <= FILTER_QB_MAX_B ? f.Qb : nullptr,
-                     filter_count_stride(B));
+                     filter_count_stride(B), sc.i8_levels > 0 ? f.eq8 : nullptr, f.qscale);
   RG_CHECK_LAUNCH("topk_cosine_filtered(prepare)");
 
   FilterThr thr{};
   thr.eq = f.eq;
   thr.max_kerr2 = max_kerr2;
+  thr.eq8 = f.eq8;
+  thr.qscale = f.qscale;
+  thr.tail8 = tail8;
   thr.k = k;
   const int parts = bound ? filter_bound_parts(k, sc.bound_keys, D, B, exchange ? n_shards : 1) : k;
   thr.ngroups = parts;
@@ -1604,7 +1796,7 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
     thr.gmax = (l == 0 && bound && !exchange && parts == k) ? f.gmax : nullptr;  // (k parts: the minimum, inline)
     if (!exchange) thr.theta = (l == 0 && bound && parts > k) ? f.theta : nullptr;
     thr.prev_scores = out_scores;
-    rc = run_bf16_pass<D>(f, Kb, B, key0, sc.ends[l], thr, cap, 0, l, st);
+    rc = run_bf16_pass<D>(f, Kb, B, key0, sc.ends[l], thr, cap, 0, l, st, l >= sc.nlev - sc.i8_levels ? Kb8 : nullptr);
     if (rc != RAGRAPH_OK) return rc;
     if (g_prof_on) g_prof_have = l + 1;
     rc = run_rescore<D>(f, Kn, N, B, cap, k, idx_base, l > 0, l == sc.nlev - 1, out_scores, out_idx, overflow,

@@ -448,7 +448,8 @@ def test_topk_cosine_filtered_bit_exact(dev, B, N, k):
     q = rng.standard_normal((B, 256), dtype=np.float32)
     knd = _t(kn, dev)
     kb = K.keys_to_bf16(knd)
-    assert (kb.shape[0] - 1) % 128 == 0 and kb.shape[0] > N  # padded to whole stages + one row with the bank's max rounding error
+    npad = -(-N // 256) * 256   # bf16 copy padded to whole stages + its error row, then the int8 copy (half the rows) + its row
+    assert kb.shape[0] == npad + 1 + npad // 2 + 1
     s, i, over = K.topk_cosine_filtered(_t(q, dev), knd, kb, k, idx_base=9)
     assert over == 0
     rs, ri = cref.topk_cosine(q, kn, k, idx_base=9)
@@ -709,3 +710,55 @@ def test_topk_cosine_fused_overflow_zero_queries_and_dispatch(dev, monkeypatch):
     assert torch.equal(i2, i3) and torch.equal(s2, s3)
     rs2, ri2 = cref.topk_cosine(q2, kn2, 5)
     assert np.array_equal(i2.cpu().numpy(), ri2) and np.array_equal(s2.cpu().numpy(), rs2)
+
+
+@pytest.mark.parametrize("D,B,N,k,levels", [(256, 700, 70000, 10, 3), (128, 513, 33000, 7, 3), (256, 3000, 40000, 5, 1),
+                                            (128, 17000, 70000, 10, -1), (256, 17000, 66000, 32, -1)])
+def test_topk_cosine_filtered_int8_levels_bit_exact(dev, monkeypatch, D, B, N, k, levels):
+    """Filter levels on the INT8 copy (v_mfma_i32_16x16x64_i8, integer thresholds; csrc/filter_common.h): forced on every
+    level of small shapes (RAGRAPH_FILTER_I8), and the product rule -- the last level of a batch of more than 16384 queries --
+    as it stands (levels = -1).  Always the oracle's bits: exact duplicates, a query that is a stored key, a zero query
+    (scale 0: everything passes, the exact scan answers), ragged tiles and banks."""
+    from ragraph_amd import kernels as K
+
+    if levels >= 0:
+        monkeypatch.setenv("RAGRAPH_FILTER_I8", str(levels))
+    else:
+        monkeypatch.delenv("RAGRAPH_FILTER_I8", raising=False)
+    rng = _rng(D + B + N + k)
+    kn = _bank(rng, N, D)
+    kn[N // 2:N // 2 + 40] = kn[:40]
+    q = rng.standard_normal((B, D), dtype=np.float32)
+    q[3] = 2.5 * kn[11]
+    q[B - 1] = 0.0
+    knd = _t(kn, dev)
+    s, i, over = K.topk_cosine_filtered(_t(q, dev), knd, K.keys_to_bf16(knd), k, idx_base=5)
+    assert int(over) >= 1                                   # the zero query
+    rows = np.arange(B) if B <= 4000 else np.unique(np.concatenate([[3, B - 1], rng.integers(0, B, 700)]))
+    rs, ri = cref.topk_cosine(q[rows], kn, k, idx_base=5)
+    assert np.array_equal(i.cpu().numpy()[rows], ri)
+    assert np.array_equal(s.cpu().numpy()[rows], rs)
+    if B > 4000:                                            # every row against the fp32 kernel
+        s32, i32 = K.topk_cosine(_t(q, dev), knd, k, idx_base=5)
+        assert torch.equal(i, i32) and torch.equal(s, s32)
+
+
+def test_int8_copy_scale_and_error_bound(dev):
+    """The int8 copy's tail row: the bank's scale = max |k_i| / 127 and max_k |dk|^2 of the dequantised rows, against numpy;
+    heavy-tailed rows (one large entry) widen the scale for the whole bank -- the bound follows, the result stays exact."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(41)
+    N, D = 3000, 256
+    kn = _bank(rng, N, D)
+    kn[17] = 0
+    kn[17, 5] = 1.0                                         # a one-hot key: |k_i| = 1 sets the scale
+    knd = _t(kn, dev)
+    kb = K.keys_to_bf16(knd)
+    npad = -(-N // 256) * 256
+    tail = kb[npad + 1 + npad // 2].cpu().numpy().view(np.float32)
+    sk = np.float32(np.abs(kn).max()) / np.float32(127.0)
+    assert tail[1] == sk
+    ki = np.clip(np.rint(kn / sk), -127, 127).astype(np.float32)
+    err2 = ((ki * sk - kn).astype(np.float64) ** 2).sum(1).max()
+    assert abs(tail[0] - err2) <= 1e-5 * err2 and tail[0] >= err2 * (1 - 1e-6)
