@@ -46,8 +46,9 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: ~2.5 PF dense = 1024 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz
+INT8_MFMA_PEAK_TOPS = 5033.2    # same guide, Matrix cores: I8 "the cycles of the BF16 form at 2x the K, so 2x BF16 per clock"
 HBM_PEAK_GBS = 8000.0           # spec; ~6300 achievable
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
 
 
 def parse():
@@ -203,15 +204,20 @@ def small_batch_rates(tgb, dim, k, dev):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         filtered = K.filter_helps(B, n_keys, dim, k)
+        n_i8 = 0
         if filtered:
             plan = (ctypes.c_int64 * 7)()
             L.ragraph_topk_cosine_filtered_plan(B, n_keys, dim, k, plan)
-            streamed = (n_keys + int(plan[6])) * dim * 2 + B * dim * 4
+            n_i8 = L.ragraph_topk_cosine_filtered_i8_levels(B, n_keys, dim, k)
+            ends = [0] + [int(plan[3 + l]) for l in range(int(plan[2]))]
+            per_key = [dim * (1 if l >= int(plan[2]) - n_i8 else 2) for l in range(int(plan[2]))]   # int8 levels: D bytes per key
+            streamed = int(plan[6]) * dim * 2 + sum((ends[l + 1] - ends[l]) * per_key[l] for l in range(int(plan[2]))) + B * dim * 4
         else:
             streamed = n_keys * dim * 4 + B * dim * 4
         gbs = streamed / ms / 1e6
         flops = 2.0 * B * n_keys * dim
-        rec = {"ms": round(ms, 4), "queries_per_s": round(B / ms * 1e3, 1), "path": "bf16-filtered" if filtered else "fp32",
+        rec = {"ms": round(ms, 4), "queries_per_s": round(B / ms * 1e3, 1),
+               "path": ("bf16-filtered" + (f", last {n_i8} level(s) on int8" if n_i8 else "")) if filtered else "fp32",
                "streamed_GB": round(streamed / 1e9, 4), "GBps_streamed": round(gbs, 1),
                "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
                "algorithmic_GBps": round(n_keys * dim * 4 / ms / 1e6, 1), "TFLOPs": round(flops / ms / 1e9, 1)}
@@ -390,6 +396,7 @@ def main():
     L = K.N.lib()
     L.ragraph_profile_filter_kernel(1)
     filter_ms = []
+    level_ms = []   # per step: [(slot, ms, int8?, keys)] of the call's filter launches (slot 3 = the bound pass)
 
     def step():
         with torch.no_grad():
@@ -399,6 +406,9 @@ def main():
         ms = L.ragraph_profile_last_filter_ms()  # waits for this step's filter launches (they are the step's tail)
         if ms > 0:
             filter_ms.append(ms)
+            a_ms, a_i8, a_keys = (ctypes.c_float * 4)(), (ctypes.c_int * 4)(), (ctypes.c_int64 * 4)()
+            L.ragraph_profile_last_filter_levels(a_ms, a_i8, a_keys)
+            level_ms.append([(s_, float(a_ms[s_]), int(a_i8[s_]), int(a_keys[s_])) for s_ in range(4) if a_ms[s_] > 0])
 
     for _ in range(args.warmup):
         step()
@@ -431,25 +441,51 @@ def main():
     flops = 2.0 * n_q_local * n_local * args.dim
     filtered = len(filt_timer.events) > 0
     traffic_unit = ("GB per launch, HBM side = (2*FETCH_SIZE + WRITE_SIZE) from rocprofv3 --pmc (separate passes), "
-                    "profiles/r2_pmc_traffic.json")
+                    "profiles/r3_pmc_traffic.json")
     if filtered:
-        # dominant kernel = the bf16 filter (its own events inside the library, ragraph_profile_last_filter_ms)
+        # Dominant kernel = the filter kernel (ragraph::topk_filter_kernel), timed per launch by events the library records
+        # around its launches on the launch stream.  A call launches it once per level -- the first on the bf16 copy
+        # (v_mfma_f32_16x16x32_bf16), the later ones on the int8 copy (v_mfma_i32_16x16x64_i8, twice the rate per clock) --
+        # plus the bound pass over a prefix; `roofline` is the launch that takes longest, priced against the peak of ITS
+        # matrix instruction; `levels` lists them all, `whole_call` the algorithmic 2 B N D over their sum.
         kernel_ms = sum(filter_ms) / max(len(filter_ms), 1)
         call_ms = filt_timer.mean_ms()
-        achieved = flops / (kernel_ms * 1e-3) / 1e12
+        per = {}
+        for step_levels in level_ms:
+            for slot, ms, i8, keys in step_levels:
+                per.setdefault(slot, {"ms": [], "i8": i8, "keys": keys})["ms"].append(ms)
+        levels = []
+        for slot in sorted(per):
+            e = per[slot]
+            ms = sum(e["ms"]) / len(e["ms"])
+            ops = 2.0 * n_q_local * e["keys"] * args.dim
+            peak = INT8_MFMA_PEAK_TOPS if e["i8"] else BF16_MFMA_PEAK_TFLOPS
+            levels.append({"launch": "bound pass (prefix)" if slot == 3 else f"level {slot + 1}", "dtype": "int8" if e["i8"] else "bf16",
+                           "keys": e["keys"], "ms": round(ms, 3), "achieved": round(ops / (ms * 1e-3) / 1e12, 1), "peak": peak,
+                           "frac": round(ops / (ms * 1e-3) / 1e12 / peak, 4)})
+        dom = max((lv for lv in levels if not lv["launch"].startswith("bound")), key=lambda lv: lv["ms"], default=None)
+        whole = flops / (kernel_ms * 1e-3) / 1e12
+        if dom is None:
+            dom = {"dtype": "bf16", "ms": kernel_ms, "achieved": round(whole, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
+                   "frac": round(whole / BF16_MFMA_PEAK_TFLOPS, 4), "launch": "all", "keys": n_local}
+        insn = "v_mfma_i32_16x16x64_i8 on the int8 copy" if dom["dtype"] == "int8" else "v_mfma_f32_16x16x32_bf16 on the bf16 copy"
         roofline = {
-            "kernel": "ragraph::topk_filter_kernel (bf16 MFMA filter of the exact top-k, v_mfma_f32_16x16x32_bf16)",
-            "bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": traffic_unit,
-            "launch_ms": round(kernel_ms, 3),
-            "note": "algorithmic flops 2*B*N*D of the score matrix / mean duration of the filter kernel (events "
-                    "recorded around its launches inside the library: the bound pass over a prefix of the bank, "
-                    "whose flops are overhead and not counted, and the filter levels, summed per call). The whole "
-                    f"exact retrieval call (this kernel + exact fp32 rescoring of the survivors) takes "
-                    f"{call_ms:.2f} ms; `exact_fp32` below is the same step on the fp32 MFMA kernel alone. "
-                    f"tools/microbench/mfma_bf16_shape_bench.hip: this kernel's bare inner loop sustains 1.71 PFLOP/s on random "
-                    f"operands (1.61 with the 32x32x16 shape of round 1; 2.2 on near-constant operands): the clock "
-                    f"the chip holds under real data bounds it well below the nominal peak",
+            "kernel": f"ragraph::topk_filter_kernel, {dom['launch']} of the exact top-k's filter ({insn})",
+            "bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"], "unit": "TFLOP/s",
+            "frac": dom["frac"], "traffic": traffic, "traffic_unit": traffic_unit,
+            "launch_ms": dom["ms"], "dtype": dom["dtype"],
+            "levels": levels,
+            "whole_call": {"filter_ms": round(kernel_ms, 3), "algorithmic_TFLOPs": round(whole, 1),
+                           "vs_bf16_peak": round(whole / BF16_MFMA_PEAK_TFLOPS, 4),
+                           "what": "2*B*N*D of the whole score matrix / the summed duration of the call's filter launches "
+                                   "(bound pass + bf16 level + int8 levels)"},
+            "note": "achieved = 2*B*keys*D operations of the launch that takes longest (for the int8 levels: integer "
+                    "multiply-adds counted as 2, against the int8 dense peak = twice the bf16 one) / its mean duration from "
+                    "events recorded around it inside the library on the launch stream.  The whole exact retrieval call "
+                    f"(every filter launch + exact fp32 rescoring of the survivors) takes {call_ms:.2f} ms; `exact_fp32` "
+                    "below is the same step on the fp32 MFMA kernel alone.  The bare inner loops sustain 1.68 PFLOP/s (bf16) "
+                    "and 3.29 Pop/s (int8) on random operands (tools/microbench/mfma_i8_bench.hip): the clock the chip holds "
+                    "under real data bounds both well below the nominal peaks",
             "retrieval_call_ms": round(call_ms, 3),
         }
     else:
@@ -482,7 +518,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32" if args.exact_fp32 else "f32 (exact results; candidates pre-filtered on bf16 MFMA with a proven bound)",
+        "dtype": "f32" if args.exact_fp32 else "f32 (exact results; candidates pre-filtered on bf16 / int8 MFMA with proven bounds)",
         "data": "synthetic",
         "config": {"workload": f"RAGraph_node forward, synthetic {n}-node graph (F={args.feat}, mean degree ~10), "
                                f"{args.bank}-key x {args.dim}-d bank, k={args.k}, C={args.classes} "

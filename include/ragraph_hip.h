@@ -130,6 +130,9 @@ size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_t N, int D,
  * plan[3..3+L) = their ends (increasing multiples of 256, the last = N; level l filters [end[l-1], end[l]), the first
  * starts at 0).  Returns L, or a negative error code. */
 int ragraph_topk_cosine_filtered_plan(int64_t B, int64_t N, int D, int k, int64_t plan[7]);
+/* How many of that schedule's LAST levels run on the int8 copy (v_mfma_i32_16x16x64_i8: twice the bf16 rate, a ~5x wider
+ * error bound, so ~3x the candidates -- the late levels of batches of >= 1024 queries at D = 128 / 256). */
+int ragraph_topk_cosine_filtered_i8_levels(int64_t B, int64_t N, int D, int k);
 int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const float* Kn, const float* Kp, const uint16_t* Kb,
                                      int64_t N, int D, int k, int64_t idx_base, float* out_scores, int64_t* out_idx,
                                      int* overflow, int64_t* overflow_idx, void* ws, size_t ws_bytes, void* stream);
@@ -189,6 +192,9 @@ int ragraph_theta_sharpen_f32(const float* gathered, int G, int64_t B, int m, in
  * duration in ms (negative if none).  Not part of the reference's interface. */
 int ragraph_profile_filter_kernel(int on);
 float ragraph_profile_last_filter_ms(void);
+/* The same per launch of the most recent call: slots 0..2 = the filter levels, slot 3 = the bound pass; HOST arrays of four:
+ * ms_host (negative: no such launch), i8_host (1: the level ran on the int8 copy), keys_host (keys the launch covered). */
+int ragraph_profile_last_filter_levels(float* ms_host, int* i8_host, int64_t* keys_host);
 
 /* Cross-shard / cross-split merge of sorted top-k lists (no counterpart in the reference: it is single-GPU).
  *   scores,idx [G,B,k] (list g of query b at ((g*B)+b)*k) -> out [B,k], canonical order; result independent of G.

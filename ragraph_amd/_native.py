@@ -38,9 +38,11 @@ SIGNATURES = {
     "ragraph_keys_to_bf16": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "ragraph_profile_filter_kernel": (_i32, [_i32]),
     "ragraph_profile_last_filter_ms": (ctypes.c_float, []),
+    "ragraph_profile_last_filter_levels": (_i32, [_vp, _vp, _vp]),
     "ragraph_topk_cosine_filtered_cap": (_i32, [_i32]),
     "ragraph_topk_cosine_filtered_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
     "ragraph_topk_cosine_filtered_plan": (_i32, [_i64, _i64, _i32, _i32, _vp]),
+    "ragraph_topk_cosine_filtered_i8_levels": (_i32, [_i64, _i64, _i32, _i32]),
     "ragraph_topk_cosine_filtered_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp,
                                                 _sz, _vp]),
     "ragraph_topk_cosine_filtered_sharded_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp,

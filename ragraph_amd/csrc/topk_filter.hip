@@ -1155,6 +1155,8 @@ using namespace ragraph;
 // stream.  Off by default; enabling creates the events once.
 static hipEvent_t g_prof_ev[2 * 4];  // three filter levels + the bound pass (slot 3)
 static int g_prof_created = 0, g_prof_on = 0, g_prof_have = 0, g_prof_bound = 0;
+static int g_prof_i8[4] = {0, 0, 0, 0};
+static int64_t g_prof_keys[4] = {0, 0, 0, 0};
 extern "C" int ragraph_profile_filter_kernel(int on) {
   if (on && !g_prof_created) {
     for (int i = 0; i < 2 * 4; ++i)
@@ -1187,6 +1189,24 @@ extern "C" float ragraph_profile_last_filter_ms(void) {
     total += ms;
   }
   return total;
+}
+
+// Per launch of the most recent call: slot 0..2 = the filter levels, slot 3 = the bound pass.  ms_host[s] (negative: no such
+// launch), i8_host[s] = 1 if the level ran on the int8 copy, keys_host[s] = keys it covered.  Host arrays of 4 entries.
+extern "C" int ragraph_profile_last_filter_levels(float* ms_host, int* i8_host, int64_t* keys_host) {
+  RG_REQUIRE(ms_host && i8_host && keys_host, RAGRAPH_EINVAL, "profile: null pointer");
+  for (int s_ = 0; s_ < 4; ++s_) {
+    ms_host[s_] = -1.f;
+    i8_host[s_] = g_prof_i8[s_];
+    keys_host[s_] = g_prof_keys[s_];
+    const bool have = g_prof_on && (s_ == 3 ? g_prof_bound != 0 : s_ < g_prof_have);
+    if (!have) continue;
+    float ms = 0.f;
+    if (hipEventSynchronize(g_prof_ev[2 * s_ + 1]) == hipSuccess &&
+        hipEventElapsedTime(&ms, g_prof_ev[2 * s_], g_prof_ev[2 * s_ + 1]) == hipSuccess)
+      ms_host[s_] = ms;
+  }
+  return RAGRAPH_OK;
 }
 
 // Schedule of a call: exact fp32 top-k over the first n0 keys (its k-th score is the first bound), then bf16 filter +
@@ -1292,7 +1312,19 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
                    // by its list inserts -- against the tile kernel's 3.2 ms)
     sc.nlev = 0;
     int64_t prev = n0;
-    for (int64_t frac : {32, 4}) {
+    // (RAGRAPH_FILTER_FRACS="a,b": the first ends as fractions N/a, N/b of the bank -- schedule experiments)
+    int64_t fracs[2] = {32, 4};
+    int nfr = 2;
+    if (const char* fe = getenv("RAGRAPH_FILTER_FRACS")) {
+      long long a = 0, b = 0;
+      nfr = sscanf(fe, "%lld,%lld", &a, &b);
+      if (nfr < 1 || a < 2) nfr = 0;
+      fracs[0] = a;
+      fracs[1] = b;
+      if (nfr == 2 && b < 2) nfr = 1;
+    }
+    for (int fi = 0; fi < nfr; ++fi) {
+      const int64_t frac = fracs[fi];
       int64_t e = filter_round_up(N / frac);
       if (e < 4 * prev) e = filter_round_up(4 * prev);  // a level is at least 4x what came before
       if (e * 2 >= N) break;                            // too close to the end: the last level takes the rest
@@ -1373,7 +1405,11 @@ static int filter_i8_levels(const FilterSchedule& sc, int64_t B, int D) {
   if (D != 128 && D != 256) return 0;
   if (B <= 256) return 0;  // (the direct kernel has no int8 form)
   if (force >= 0) return force < sc.nlev ? force : sc.nlev;
-  return B > FILTER_SLAB_MAX_B ? 1 : 0;
+  // measured on the 1M x 256 bank (ms per call, 0 / 1 / 2 int8 levels; profiles/r3_i8_ab.txt): 512 queries 0.317 / 0.314 /
+  // 0.314; 1024: 0.538 / 0.519 / 0.505; 2048: 0.98 / 0.80 / 0.83; 4096: 1.75 / 1.34 / 1.28; 16384: 6.09 / 4.55 / 4.19;
+  // 100 000 (the bench step): 38.3 / 28.3 / 26.9 (three: 27.7)
+  if (B < 1024) return 0;
+  return sc.nlev < 2 ? sc.nlev : 2;
 }
 
 // workspace of level 0: the tile kernel's, or the score slab
@@ -1450,6 +1486,12 @@ extern "C" size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_
     if (exact0 > level0) level0 = exact0;
   }
   return level0 + filter_ws_carve(nullptr, B, D, k, cap, nullptr);
+}
+
+extern "C" int ragraph_topk_cosine_filtered_i8_levels(int64_t B, int64_t N, int D, int k) {
+  if (B < 1 || N < 1 || k < 1 || k > 32 || k > N || !filter_dim_ok(D)) return 0;
+  const FilterSchedule sc = filter_schedule(B, N, D, k);
+  return filter_i8_levels(sc, B, D);
 }
 
 extern "C" int ragraph_topk_cosine_filtered_plan(int64_t B, int64_t N, int D, int k, int64_t plan[7]) {
@@ -1593,6 +1635,12 @@ static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64
       p.cap = cap;
       p.stage_base = key0 / C8::STAGE_KEYS;  // key0 is a multiple of 256
       p.nstages_total = cdiv(key1 - key0, C8::STAGE_KEYS);
+      // (int8 operands are 16 bytes per 64 elements: eight query groups fit the registers four bf16 groups take, and an
+      // A fragment then feeds eight MFMAs -- 3.53 vs 3.29 Pop/s in the bare loop, tools/microbench/mfma_i8_bench.hip)
+      const char* e = getenv("RAGRAPH_FILTER_I8_QW");
+      const int qw = e ? atoi(e) : 64;
+      if (qw == 128 && cdiv(B, (int64_t)1024) * p.nstages_total >= 32 * (int64_t)filter_device_cus())
+        return launch_ring<D, 128, false, true>(p, B, prof_slot, st);
       return launch_ring<D, 64, false, true>(p, B, prof_slot, st);
     }
   }
@@ -1762,7 +1810,11 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   // out_idx hold every level's running result, local indices)
   if (bound) {
     rc = run_bf16_pass<D>(f, Kb, B, 0, sc.bound_keys, thr, cap, parts, 3, st);
-    if (g_prof_on) g_prof_bound = 1;
+    if (g_prof_on) {
+      g_prof_bound = 1;
+      g_prof_i8[3] = 0;
+      g_prof_keys[3] = sc.bound_keys;
+    }
   } else if (sc.slab0) {
     float* S = reinterpret_cast<float*>(w);  // one slab of scores, reused: written and read back while it is in cache
     for (int64_t b0 = 0; b0 < B && rc == RAGRAPH_OK; b0 += FILTER_SLAB_MAX_B) {
@@ -1797,6 +1849,10 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
     if (!exchange) thr.theta = (l == 0 && bound && parts > k) ? f.theta : nullptr;
     thr.prev_scores = out_scores;
     rc = run_bf16_pass<D>(f, Kb, B, key0, sc.ends[l], thr, cap, 0, l, st, l >= sc.nlev - sc.i8_levels ? Kb8 : nullptr);
+    if (g_prof_on) {
+      g_prof_i8[l] = l >= sc.nlev - sc.i8_levels;
+      g_prof_keys[l] = sc.ends[l] - key0;
+    }
     if (rc != RAGRAPH_OK) return rc;
     if (g_prof_on) g_prof_have = l + 1;
     rc = run_rescore<D>(f, Kn, N, B, cap, k, idx_base, l > 0, l == sc.nlev - 1, out_scores, out_idx, overflow,

@@ -1,29 +1,31 @@
 #!/usr/bin/env python3
-"""Copy what tools/gpu_round_r2.sh left under gpurun_out/<tag>/ into profiles/r2_* (the files the docs and bench.py cite)
-and rebuild profiles/r2_pmc_traffic.json from the PMC summaries.   python tools/collect_profiles.py r2c"""
+"""Copy what tools/gpu_round_r3.sh left under gpurun_out/<tag>/ into profiles/r3_* (the files the docs and bench.py cite)
+and rebuild profiles/r3_pmc_traffic.json from the PMC summaries.   python tools/collect_profiles.py r3"""
 import csv, json, os, re, shutil, sys
 
 tag = sys.argv[1]
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(R, "gpurun_out", tag), os.path.join(R, "profiles")
+P = "r3"
 
 
 def cp(a, b):
     shutil.copyfile(os.path.join(src, a), os.path.join(dst, b))
 
 
-cp("kernel_stats.csv", "r2_bench_c2_kernel_stats.csv")
-cp("trace_summary.txt", "r2_bench_c2_trace_summary.txt")
-with open(os.path.join(dst, "r2_bench_c2_pmc_traffic.txt"), "w") as f:
+cp("kernel_stats.csv", f"{P}_bench_c2_kernel_stats.csv")
+cp("trace_summary.txt", f"{P}_bench_c2_trace_summary.txt")
+with open(os.path.join(dst, f"{P}_bench_c2_pmc_traffic.txt"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE (first block) and, separate run, --pmc WRITE_SIZE (second block) of\n"
-            "# `python3 bench.py --steps 2 --warmup 1 --no-extras` on MI355X; KB per dispatch, mean (tools/pmc_summary.py)\n")
+            "# `python3 bench.py --steps 2 --warmup 1 --no-extras` on MI355X; KB per dispatch, mean and max (tools/pmc_summary.py)\n")
     f.write(open(os.path.join(src, "pmc_fetch.txt")).read())
     f.write(open(os.path.join(src, "pmc_write.txt")).read())
-line = json.load(open(os.path.join(src, "bench.json")))
-json.dump(line, open(os.path.join(dst, "r2_bench_line.json"), "w"))
-for B in (1, 16, 256):
-    cp(f"smallb_B{B}_kernel_stats.csv", f"r2_smallb_B{B}_kernel_stats.csv")
-    cp(f"smallb_B{B}_pmc.txt", f"r2_smallb_B{B}_pmc_traffic.txt")
+line = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+json.dump(line, open(os.path.join(dst, f"{P}_bench_line.json"), "w"))
+SMALL = (1, 16, 256, 512, 4096)
+for B in SMALL:
+    cp(f"smallb_B{B}_kernel_stats.csv", f"{P}_smallb_B{B}_kernel_stats.csv")
+    cp(f"smallb_B{B}_pmc.txt", f"{P}_smallb_B{B}_pmc_traffic.txt")
 
 
 def pmc(path):
@@ -32,9 +34,12 @@ def pmc(path):
         if not l.startswith(" "):
             cur = l.strip()
         else:
-            m = re.match(r"\s+(\w+)\s+mean/dispatch\s+([0-9.]+)", l)
+            m = re.match(r"\s+(\w+)\s+mean/dispatch\s+([0-9.]+)\s+\(n=(\d+)\)(?:\s+max/dispatch\s+([0-9.]+))?", l)
             if m:
                 out.setdefault(cur, {})[m.group(1)] = float(m.group(2))
+                out[cur][m.group(1) + "_n"] = int(m.group(3))
+                if m.group(4):
+                    out[cur][m.group(1) + "_max"] = float(m.group(4))
     return out
 
 
@@ -46,35 +51,44 @@ def kernel_us(path, name):
 
 
 fe, wr = pmc(os.path.join(src, "pmc_fetch.txt")), pmc(os.path.join(src, "pmc_write.txt"))
-lev, bnd = "ragraph::topk_filter_kernel<256, 64, false>", "ragraph::topk_filter_kernel<256, 64, true>"
-kb = 3 * (2 * fe[lev]["FETCH_SIZE"] + wr[lev]["WRITE_SIZE"]) + 2 * fe[bnd]["FETCH_SIZE"] + wr[bnd]["WRITE_SIZE"]
 out = {
     "_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate run, --pmc WRITE_SIZE on MI355X "
-            "(tools/gpu_round_r2.sh, collected by tools/collect_profiles.py; summaries profiles/r2_bench_c2_pmc_traffic.txt, "
-            "profiles/r2_smallb_B*_pmc_traffic.txt); values are KB per dispatch (mean). HBM-side bytes = (2*FETCH_SIZE + "
+            "(tools/gpu_round_r3.sh, collected by tools/collect_profiles.py; summaries profiles/r3_bench_c2_pmc_traffic.txt, "
+            "profiles/r3_smallb_B*_pmc_traffic.txt); values are KB per dispatch. HBM-side bytes = (2*FETCH_SIZE + "
             "WRITE_SIZE)*1024: on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM "
             "section). Infinity-Cache hits are included in FETCH_SIZE.",
-    "topk_filter_kernel B=100000 N=1000000 D=256 k=10": {
-        "FETCH_SIZE_KB_per_level_dispatch": fe[lev]["FETCH_SIZE"], "WRITE_SIZE_KB_per_level_dispatch": wr[lev]["WRITE_SIZE"],
-        "FETCH_SIZE_KB_bound_pass": fe[bnd]["FETCH_SIZE"], "WRITE_SIZE_KB_bound_pass": wr[bnd]["WRITE_SIZE"],
-        "hbm_side_GB": round(kb * 1024 / 1e9, 1),
-        "note": "per retrieval call = bound pass + three filter levels (summed; the bench's `launch`). Algorithmic minimum: the "
-                "bf16 copy once (0.51 GB) + the queries (0.1 GB); the rest are re-reads of the key stream by the 8 XCD groups "
-                "(each streams the bank for its ~24 query tiles of 512), served by L2 misses into the Infinity Cache / HBM: "
-                f"at {line['roofline']['launch_ms']:.1f} ms per call this is {kb * 1024 / 1e9 / line['roofline']['launch_ms']:.2f} TB/s, "
-                "a few % of HBM bandwidth -- the kernel is MFMA-bound."},
 }
-for B, qreg in ((1, "true"), (16, "true"), (256, "false")):
-    p = pmc(os.path.join(src, f"smallb_B{B}_pmc.txt"))
-    k = f"ragraph::topk_filter_direct_kernel<256, {qreg}, false>"
-    us = kernel_us(os.path.join(src, f"smallb_B{B}_kernel_stats.csv"), f"topk_filter_direct_kernel<256, {qreg}, false>")
-    f_kb, w_kb = p[k]["FETCH_SIZE"], p[k].get("WRITE_SIZE", 0.0)
-    gb = (2 * f_kb + w_kb) * 1024 / 1e9
-    call = re.search(r"([0-9.]+) ms per call", open(os.path.join(src, f"smallb_B{B}.log")).read())
-    out[f"topk_filter_direct_kernel B={B} N=1000000 D=256 k=10"] = {
-        "FETCH_SIZE_KB": f_kb, "WRITE_SIZE_KB": w_kb, "hbm_side_GB": round(gb, 3), "kernel_us": round(us, 1),
-        "kernel_TBps": round(gb / us * 1e3, 2),
-        "note": "one pass over the bf16 copy (2 N D = 0.512 GB) for all query groups; whole call "
-                f"(prep + bound pass + this + rescoring) {float(call.group(1)):.3f} ms under rocprofv3" if call else ""}
-json.dump(out, open(os.path.join(dst, "r2_pmc_traffic.json"), "w"), indent=2)
-print(json.dumps({k: v for k, v in out.items() if k != "_how"}, indent=1)[:1800])
+names = {"int8": "ragraph::topk_filter_kernel<256, 64, false, true>", "bf16": "ragraph::topk_filter_kernel<256, 64, false, false>",
+         "bound": "ragraph::topk_filter_kernel<256, 64, true, false>"}
+rec, total_kb = {}, 0.0
+for key, nm in names.items():
+    if nm in fe and nm in wr:
+        per_call = fe[nm]["FETCH_SIZE_n"] / max(fe[names["bound"]]["FETCH_SIZE_n"], 1) if names["bound"] in fe else 1
+        rec[key] = {"FETCH_SIZE_KB_mean": fe[nm]["FETCH_SIZE"], "WRITE_SIZE_KB_mean": wr[nm]["WRITE_SIZE"],
+                    "FETCH_SIZE_KB_max": fe[nm].get("FETCH_SIZE_max"), "WRITE_SIZE_KB_max": wr[nm].get("WRITE_SIZE_max"),
+                    "dispatches_per_call": per_call}
+        total_kb += per_call * (2 * fe[nm]["FETCH_SIZE"] + wr[nm]["WRITE_SIZE"])
+dom = rec.get("int8") or rec.get("bf16")
+if dom:
+    dom_kb = 2 * (dom["FETCH_SIZE_KB_max"] or dom["FETCH_SIZE_KB_mean"]) + (dom["WRITE_SIZE_KB_max"] or dom["WRITE_SIZE_KB_mean"])
+    out["topk_filter_kernel B=100000 N=1000000 D=256 k=10"] = {
+        "per_kernel": rec,
+        "hbm_side_GB": round(dom_kb * 1024 / 1e9, 2),
+        "hbm_side_GB_whole_call": round(total_kb * 1024 / 1e9, 2),
+        "note": "hbm_side_GB = the launch that takes longest (the last level, on the int8 copy: the largest dispatch of that "
+                "kernel); _whole_call = bound pass + every level. Algorithmic minimum of the last level: 3/4 of the int8 copy "
+                "once (0.19 GB) + the queries (0.1 GB); the rest are re-reads of the key stream by the 8 XCD groups (each streams "
+                "the bank for its ~24 query tiles of 512), L2 misses served by the Infinity Cache / HBM -- a few % of HBM "
+                "bandwidth: the kernel is MFMA-bound."}
+for B in SMALL:
+    f1 = pmc(os.path.join(src, f"smallb_B{B}_pmc.txt"))
+    for nm, d in f1.items():
+        if "topk_filter" in nm and "FETCH_SIZE" in d and "true>" not in nm.split("(")[0][-12:]:
+            us = kernel_us(os.path.join(src, f"smallb_B{B}_kernel_stats.csv"), nm.replace("ragraph::", ""))
+            gb = (2 * d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0.0)) * 1024 / 1e9
+            out[f"{nm.split('<')[0].replace('ragraph::', '')} B={B} N=1000000 D=256 k=10 [{nm}]"] = {
+                "FETCH_SIZE_KB": d["FETCH_SIZE"], "WRITE_SIZE_KB": d.get("WRITE_SIZE"), "hbm_side_GB": round(gb, 3),
+                "kernel_us": None if us is None else round(us, 1),
+                "kernel_TBps": None if not us else round(gb / us * 1e3, 2)}
+json.dump(out, open(os.path.join(dst, f"{P}_pmc_traffic.json"), "w"), indent=2)
+print(json.dumps(out, indent=1)[:3000])

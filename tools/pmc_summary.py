@@ -19,4 +19,4 @@ for k, cs in acc.items():
         for d, x in v:
             per[d] += x
         vals = list(per.values())
-        print(f"   {c:32s} mean/dispatch {sum(vals)/len(vals):18.1f}  (n={len(vals)})")
+        print(f"   {c:32s} mean/dispatch {sum(vals)/len(vals):18.1f}  (n={len(vals)})  max/dispatch {max(vals):18.1f}")
