@@ -1399,7 +1399,7 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
 // the matrix work of three quarters of the bank halves (25.6 -> ~13 ms).  Earlier levels and smaller batches stay on
 // bf16: a level of a few thousand queries is not matrix-bound enough to pay for the extra rescoring.
 // RAGRAPH_FILTER_I8 = n forces the last n levels (0: none) -- A/B runs and the tests of the int8 path on small shapes.
-static int filter_i8_levels(const FilterSchedule& sc, int64_t B, int D) {
+static int filter_i8_levels(const FilterSchedule& sc, int64_t B, int D, int64_t N) {
   const char* env = getenv("RAGRAPH_FILTER_I8");  // (read per call: the tests switch it)
   const int force = env ? atoi(env) : -1;
   if (D != 128 && D != 256) return 0;
@@ -1408,7 +1408,9 @@ static int filter_i8_levels(const FilterSchedule& sc, int64_t B, int D) {
   // measured on the 1M x 256 bank (ms per call, 0 / 1 / 2 int8 levels; profiles/r3_i8_ab.txt): 512 queries 0.317 / 0.314 /
   // 0.314; 1024: 0.538 / 0.519 / 0.505; 2048: 0.98 / 0.80 / 0.83; 4096: 1.75 / 1.34 / 1.28; 16384: 6.09 / 4.55 / 4.19;
   // 100 000 (the bench step): 38.3 / 28.3 / 26.9 (three: 27.7)
-  if (B < 1024) return 0;
+  // (short banks: the launch is not matrix-bound, and an int8 level quantises its queries from the fp32 rows per segment
+  // where the bf16 levels of up to 16384 queries load a prepared image -- Cora-sized 2708 x 10 000 x 128: 0.087 -> 0.100 ms)
+  if (B < 1024 || N < 65536) return 0;
   return sc.nlev < 2 ? sc.nlev : 2;
 }
 
@@ -1491,7 +1493,7 @@ extern "C" size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_
 extern "C" int ragraph_topk_cosine_filtered_i8_levels(int64_t B, int64_t N, int D, int k) {
   if (B < 1 || N < 1 || k < 1 || k > 32 || k > N || !filter_dim_ok(D)) return 0;
   const FilterSchedule sc = filter_schedule(B, N, D, k);
-  return filter_i8_levels(sc, B, D);
+  return filter_i8_levels(sc, B, D, N);
 }
 
 extern "C" int ragraph_topk_cosine_filtered_plan(int64_t B, int64_t N, int D, int k, int64_t plan[7]) {
@@ -1785,7 +1787,7 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   // the int8 copy lies behind the bf16 copy and its tail row (ragraph_keys_to_bf16)
   const signed char* Kb8 = reinterpret_cast<const signed char*>(Kb + (filter_round_up(N) + 1) * D);
   const unsigned* tail8 = reinterpret_cast<const unsigned*>(Kb8 + filter_round_up(N) * D);
-  sc.i8_levels = filter_i8_levels(sc, B, D);
+  sc.i8_levels = filter_i8_levels(sc, B, D, plan_N);
   const bool bound = sc.bound_keys > 0;
 
   // one launch: normalised queries, their bf16 rounding errors, empty lists, clear flags (+ group maxima at -inf)
