@@ -133,6 +133,12 @@ int ragraph_topk_cosine_filtered_plan(int64_t B, int64_t N, int D, int k, int64_
 /* How many of that schedule's LAST levels run on the int8 copy (v_mfma_i32_16x16x64_i8: twice the bf16 rate, a ~5x wider
  * error bound, so ~3x the candidates -- the late levels of batches of >= 1024 queries at D = 128 / 256). */
 int ragraph_topk_cosine_filtered_i8_levels(int64_t B, int64_t N, int D, int k);
+/* Cap on the int8 levels of the CALLING THREAD's following filtered calls (thread-local; -1 = the built-in rule, 0 = none);
+ * returns the previous value.  For callers that know their bank: the int8 bound is only as tight as the bank's LARGEST
+ * entry allows (one scale for all keys), so a heavy-tailed bank passes many more candidates on int8 than on bf16 -- still
+ * exact, but slower.  ragraph_amd/kernels_index.py sets it per bank from the copy's measured error row and from calls whose
+ * candidate lists overflowed. */
+int ragraph_topk_cosine_filtered_max_i8_levels(int n);
 int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const float* Kn, const float* Kp, const uint16_t* Kb,
                                      int64_t N, int D, int k, int64_t idx_base, float* out_scores, int64_t* out_idx,
                                      int* overflow, int64_t* overflow_idx, void* ws, size_t ws_bytes, void* stream);

@@ -43,6 +43,7 @@ SIGNATURES = {
     "ragraph_topk_cosine_filtered_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
     "ragraph_topk_cosine_filtered_plan": (_i32, [_i64, _i64, _i32, _i32, _vp]),
     "ragraph_topk_cosine_filtered_i8_levels": (_i32, [_i64, _i64, _i32, _i32]),
+    "ragraph_topk_cosine_filtered_max_i8_levels": (_i32, [_i32]),
     "ragraph_topk_cosine_filtered_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp,
                                                 _sz, _vp]),
     "ragraph_topk_cosine_filtered_sharded_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp,

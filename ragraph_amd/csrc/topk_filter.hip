@@ -1399,19 +1399,31 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
 // the matrix work of three quarters of the bank halves (25.6 -> ~13 ms).  Earlier levels and smaller batches stay on
 // bf16: a level of a few thousand queries is not matrix-bound enough to pay for the extra rescoring.
 // RAGRAPH_FILTER_I8 = n forces the last n levels (0: none) -- A/B runs and the tests of the int8 path on small shapes.
+// A caller that knows its bank (ragraph_amd/kernels_index.py: the copy's measured error, or a call that overflowed) caps
+// the int8 levels of ITS thread's following calls: -1 = the rule below, 0 = none.  Thread-local: no shared state.
+static thread_local int t_max_i8_levels = -1;
+extern "C" int ragraph_topk_cosine_filtered_max_i8_levels(int n) {
+  const int old = t_max_i8_levels;
+  t_max_i8_levels = n < 0 ? -1 : n;
+  return old;
+}
+
 static int filter_i8_levels(const FilterSchedule& sc, int64_t B, int D, int64_t N) {
   const char* env = getenv("RAGRAPH_FILTER_I8");  // (read per call: the tests switch it)
   const int force = env ? atoi(env) : -1;
   if (D != 128 && D != 256) return 0;
   if (B <= 256) return 0;  // (the direct kernel has no int8 form)
   if (force >= 0) return force < sc.nlev ? force : sc.nlev;
+  if (t_max_i8_levels == 0) return 0;
   // measured on the 1M x 256 bank (ms per call, 0 / 1 / 2 int8 levels; profiles/r3_i8_ab.txt): 512 queries 0.317 / 0.314 /
   // 0.314; 1024: 0.538 / 0.519 / 0.505; 2048: 0.98 / 0.80 / 0.83; 4096: 1.75 / 1.34 / 1.28; 16384: 6.09 / 4.55 / 4.19;
   // 100 000 (the bench step): 38.3 / 28.3 / 26.9 (three: 27.7)
   // (short banks: the launch is not matrix-bound, and an int8 level quantises its queries from the fp32 rows per segment
   // where the bf16 levels of up to 16384 queries load a prepared image -- Cora-sized 2708 x 10 000 x 128: 0.087 -> 0.100 ms)
   if (B < 1024 || N < 65536) return 0;
-  return sc.nlev < 2 ? sc.nlev : 2;
+  int n = sc.nlev < 2 ? sc.nlev : 2;
+  if (t_max_i8_levels > 0 && n > t_max_i8_levels) n = t_max_i8_levels;
+  return n;
 }
 
 // workspace of level 0: the tile kernel's, or the score slab

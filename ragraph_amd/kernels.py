@@ -149,6 +149,25 @@ def keys_to_bf16(keys_normalized: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def bank_copy_errors(keys_bf16: torch.Tensor, n_keys: int):
+    """(max |dk| of the bf16 copy, max |dk| of the int8 copy, int8 scale) read from the copies' tail rows -- ONE
+    synchronisation, for the owner of a bank version (KeyIndex) to judge once whether int8 levels suit this bank."""
+    npad = -(-n_keys // 256) * 256
+    t16 = keys_bf16[npad, :2].contiguous().view(torch.float32).cpu()
+    t8 = keys_bf16[npad + 1 + npad // 2, :4].contiguous().view(torch.float32).cpu()
+    return float(t16[0]) ** 0.5, float(t8[0]) ** 0.5, float(t8[1])
+
+
+def filtered_i8_levels(B: int, n_keys: int, D: int, k: int) -> int:
+    """How many trailing levels of a filtered call of this shape run on the int8 copy (under this thread's current cap)."""
+    return N.lib().ragraph_topk_cosine_filtered_i8_levels(B, n_keys, D, k)
+
+
+def set_max_i8_levels(n: int) -> int:
+    """Cap the int8 levels of this thread's following filtered calls (-1: the library's rule); returns the old cap."""
+    return N.lib().ragraph_topk_cosine_filtered_max_i8_levels(int(n))
+
+
 def filter_helps(B: int, n_keys: int, D: int, k: int) -> bool:
     """True when the bf16-filtered exact top-k is the faster way to the same bits.  Measured on MI355X (ms, filtered vs
     fp32 kernels, D = 256, k = 10): see DESIGN.md section 4.0 (batch-size table).  Small score matrices stay on the

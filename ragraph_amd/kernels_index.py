@@ -11,6 +11,12 @@ class KeyIndex:
     shim) simply always takes topk_cosine."""
 
     MAX_FILTERED_BATCH = 262144
+    # int8 levels only for banks whose int8 copy is accurate enough: max |dk| of the dequantised rows.  Gaussian-like unit
+    # rows of 256 elements give 0.015 (eps ~ 0.022, ~3x the bf16 candidates: pays, DESIGN.md section 4.0a); the error grows
+    # with the bank's largest entry (ONE scale for all keys), and a bank with a one-hot row reaches 0.036 -- thousands of
+    # candidates per query.  Above this the levels stay on bf16; a bank that still overflows on int8 is caught by
+    # _poll_overflow.
+    I8_MAX_ERR = 0.02
 
     def __init__(self, keys_normalized: torch.Tensor, ops=None):
         if ops is None:
@@ -20,7 +26,9 @@ class KeyIndex:
         self._packed = None
         self._bf16 = None
         self._filter_off = False  # set when this bank defeats the filter (see _poll_overflow)
-        self._pending = None      # (pinned word, event, batch) of the last filtered call's overflow count
+        self._i8_off = False      # set when this bank defeats the INT8 levels only (heavy-tailed rows: one scale for all keys)
+        self._pending = None      # (pinned word, event, batch, had int8 levels) of the last filtered call's overflow count
+        self._i8_ok = None        # the int8 copy's error row read (once, lazily): accurate enough for int8 levels?
         self._host_word = self._event = None
         self.overflowed_queries = 0
 
@@ -38,7 +46,24 @@ class KeyIndex:
         self._pending = None
         self.overflowed_queries += n_over
         if B >= 64 and 4 * n_over > B:
-            self._filter_off = True
+            if pend[3] and not self._i8_off:   # the call had int8 levels: their wider bound is the first suspect
+                self._i8_off = True
+            else:
+                self._filter_off = True
+
+    def _cap_i8(self):
+        """Before a filtered call: cap this thread's int8 levels for THIS bank (ops.set_max_i8_levels; the caller resets it
+        to -1 afterwards).  The bank's int8 error row is read once per bank version (one synchronisation; never while a
+        HIP graph is being captured -- an unjudged bank then stays on bf16).  Returns (the setter or None, int8 allowed)."""
+        cap = getattr(self.ops, "set_max_i8_levels", None)
+        if cap is None:
+            return None, False
+        if self._i8_ok is None and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+            _, e8, _ = self.ops.bank_copy_errors(self._bf16, self.keys_normalized.shape[0])
+            self._i8_ok = e8 <= self.I8_MAX_ERR
+        allowed = bool(self._i8_ok) and not self._i8_off
+        cap(-1 if allowed else 0)
+        return cap, allowed
 
     def topk(self, q: torch.Tensor, k: int, idx_base: int = 0, exchange=None, plan_n: int = 0):
         """exchange / plan_n: this index holds one shard of a row-sharded bank (ShardedToyGraphBase): the filtered path
@@ -52,8 +77,13 @@ class KeyIndex:
             if fhelps is not None and fhelps(B, max(plan_n, kn.shape[0]), D, k) and B <= self.MAX_FILTERED_BATCH:
                 if self._bf16 is None:
                     self._bf16 = ops.keys_to_bf16(kn)
-                s, i, _ = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base, exchange=exchange,
-                                                   plan_n=plan_n)
+                cap, _ = self._cap_i8()   # (per shard: which kernel a level runs on does not change the exchanges)
+                try:
+                    s, i, _ = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base, exchange=exchange,
+                                                       plan_n=plan_n)
+                finally:
+                    if cap is not None:
+                        cap(-1)
                 return s, i
             fhelps = None  # (fp32 kernels: the shard's own exact top-k, no exchange needed)
         self._poll_overflow()
@@ -72,14 +102,20 @@ class KeyIndex:
                 outs = [self.topk(q[b0:b0 + self.MAX_FILTERED_BATCH], k, idx_base)
                         for b0 in range(0, B, self.MAX_FILTERED_BATCH)]
                 return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
-            s, i, over = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base, keys_packed=self._packed)
+            cap, had_i8 = self._cap_i8()
+            had_i8 = had_i8 and ops.filtered_i8_levels(B, kn.shape[0], D, k) > 0   # (did THIS call have int8 levels?)
+            try:
+                s, i, over = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base, keys_packed=self._packed)
+            finally:
+                if cap is not None:
+                    cap(-1)
             if self._pending is None and over.is_cuda and not torch.cuda.is_current_stream_capturing():
                 if self._host_word is None:
                     self._host_word = torch.zeros(1, dtype=torch.int32).pin_memory()
                     self._event = torch.cuda.Event()
                 self._host_word.copy_(over, non_blocking=True)
                 self._event.record()
-                self._pending = (self._host_word, self._event, B)
+                self._pending = (self._host_word, self._event, B, had_i8)
             elif not over.is_cuda:  # (the CPU tests' oracle shim)
                 self.overflowed_queries += int(over)
             return s, i

@@ -762,3 +762,57 @@ def test_int8_copy_scale_and_error_bound(dev):
     ki = np.clip(np.rint(kn / sk), -127, 127).astype(np.float32)
     err2 = ((ki * sk - kn).astype(np.float64) ** 2).sum(1).max()
     assert abs(tail[0] - err2) <= 1e-5 * err2 and tail[0] >= err2 * (1 - 1e-6)
+
+
+def test_key_index_keeps_heavy_tailed_banks_off_int8(dev):
+    """One scale serves the whole int8 copy, so a bank with a one-hot row quantises its ordinary rows on a grid set by that
+    row: KeyIndex reads the copy's measured error once and keeps such a bank's levels on bf16 (exactness never depends on
+    it: both answers are the oracle's); a Gaussian bank takes the int8 levels."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(77)
+    N, D, B, k = 70000, 256, 1100, 10
+    kn = _bank(rng, N, D)
+    q = rng.standard_normal((B, D), dtype=np.float32)
+    idx = K.KeyIndex(_t(kn, dev))
+    s, i = idx.topk(_t(q, dev), k)
+    assert idx._i8_ok is True
+    rs, ri = cref.topk_cosine(q[:300], kn, k)
+    assert np.array_equal(i.cpu().numpy()[:300], ri) and np.array_equal(s.cpu().numpy()[:300], rs)
+    kn2 = kn.copy()
+    kn2[123] = 0
+    kn2[123, 9] = 1.0
+    idx2 = K.KeyIndex(_t(kn2, dev))
+    s2, i2 = idx2.topk(_t(q, dev), k)
+    assert idx2._i8_ok is False
+    e16, e8, sk = K.bank_copy_errors(idx2._bf16, N)
+    assert e8 > K.KeyIndex.I8_MAX_ERR and abs(sk - 1.0 / 127.0) < 1e-9 and e16 < 0.004
+    rs2, ri2 = cref.topk_cosine(q[:300], kn2, k)
+    assert np.array_equal(i2.cpu().numpy()[:300], ri2) and np.array_equal(s2.cpu().numpy()[:300], rs2)
+    assert K.N.lib().ragraph_topk_cosine_filtered_max_i8_levels(-1) == -1     # the cap does not leak out of a call
+
+
+def test_key_index_drops_int8_before_the_filter_when_a_bank_overflows(dev):
+    """A clustered bank passes the error-row test (its entries are ordinary) but puts thousands of keys within the INT8
+    bound of a query's k-th best -- and only hundreds within the bf16 bound.  The first calls overflow on the int8 levels;
+    KeyIndex notices (the count arrives asynchronously), keeps this bank's levels on bf16 and the filter ON; every answer
+    is the oracle's."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(91)
+    N, D, B, k = 70000, 256, 1200, 10
+    centre = rng.standard_normal((1, D), dtype=np.float32)
+    # (noise 0.5: ~90 keys within the bf16 bound of a query's k-th best, ~12 000 within the int8 bound)
+    kn = cref.normalize_rows(np.concatenate([centre + 0.5 * rng.standard_normal((30000, D), dtype=np.float32),
+                                             rng.standard_normal((N - 30000, D), dtype=np.float32)]))
+    q = (centre + 0.5 * rng.standard_normal((B, D), dtype=np.float32)).astype(np.float32)
+    idx = K.KeyIndex(_t(kn, dev))
+    qd = _t(q, dev)
+    rs, ri = cref.topk_cosine(q[:200], kn, k)
+    for _ in range(4):
+        s, i = idx.topk(qd, k)
+        torch.cuda.synchronize()
+        assert np.array_equal(i.cpu().numpy()[:200], ri) and np.array_equal(s.cpu().numpy()[:200], rs)
+    assert idx._i8_ok is True                    # ordinary entries: the error row does not give the bank away
+    assert idx.overflowed_queries > B // 4       # the int8 levels did overflow ...
+    assert idx._i8_off and not idx._filter_off   # ... so int8 is what goes; the bf16 filter stays
