@@ -1278,6 +1278,10 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
   FilterSchedule sc{};
   const int cap = 2048;
   const bool bound = N >= 8192 && filter_bound_pass_enabled();
+  // int8 levels (filter_common.h): D = 128 / 256, the ring kernel's batch sizes, banks long enough to be matrix-bound (an
+  // int8 level quantises its queries from the fp32 rows per segment where the bf16 levels of up to 16384 queries load a
+  // prepared image -- Cora-sized 2708 x 10 000 x 128: 0.087 -> 0.100 ms)
+  const bool i8_ok = (D == 128 || D == 256) && B > 256 && N * n_shards >= 65536;
   // bound_keys / eff_div ~ the exact sample the bound is worth: planned for 4 k parts, corrected below if the prefix is
   // too short for that many
   const double eff_div = filter_bound_eff(k, B <= 64 ? k : 4 * k);
@@ -1335,11 +1339,12 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
     // the k keys behind the bound must lie inside the first level (it has to find at least k candidates)
     if (sc.bound_keys > sc.ends[0]) sc.bound_keys = sc.ends[0] / FILTER_PAD_KEYS * FILTER_PAD_KEYS;
     if (sc.bound_keys / (FILTER_STAGE_BYTES / (2 * D)) < k) sc.bound_keys = 0;  // every part needs a stage of its own
+    sc.i8_levels = i8_ok && B >= 1024 ? 2 : 0;  // (banks below 4 x 4096 keys come here with any batch)
     return sc;
   }
   double best = 1e30;
   int64_t best_n0 = 4096, best_nA = 0;
-  int best_L = FILTER_MAX_LEVELS;
+  int best_L = FILTER_MAX_LEVELS, best_i8 = 0;
   // RAGRAPH_FILTER_FORCE_N0 / _L: schedule experiments (n0 = the exact sample the first bound is worth, L levels)
   static const int64_t force_n0 = [] { const char* e = getenv("RAGRAPH_FILTER_FORCE_N0"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
   static const int force_L = [] { const char* e = getenv("RAGRAPH_FILTER_FORCE_L"); return e ? atoi(e) : 0; }();
@@ -1365,18 +1370,47 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
       const double r = pow((double)N / (double)n0, 1.0 / L);
       if (1.3 * k * r > cap / 2 && !(force_n0 > 0 && force_L > 0)) continue;
       // a level: launches + the rescoring kernels' latency floor, plus ~0.4 - 0.5 ns per candidate (1 KB row gather each)
-      const double cost = B <= 256 ? first + L * (25.0 + (double)B * 1.3 * k * r * 0.5e-3) + (L - 1) * 15.0  /* (a second pass start-up) */
-                                   : first + L * (60.0 + (double)B * 1.3 * k * r * 0.4e-3);
-      if (cost < best) {
-        best = cost;
-        best_n0 = n0;
-        best_nA = nA;
-        best_L = L;
+      if (B <= 256) {
+        const double cost = first + L * (25.0 + (double)B * 1.3 * k * r * 0.5e-3) + (L - 1) * 15.0;  /* (a second pass start-up) */
+        if (cost < best) {
+          best = cost;
+          best_n0 = n0;
+          best_nA = nA;
+          best_L = L;
+        }
+        continue;
+      }
+      // Ring kernel: + the matrix work of each level -- 2 B keys D at ~1.25 PFLOP/s on the bf16 copy, ~2.4 Pop/s on the
+      // int8 copy, whose ~5x wider bound passes ~3x the candidates -- for 0, 1 or 2 trailing int8
+      // levels.  (Without int8 the matrix term is the same for every (n0, L): the choice among those is round 2's.)
+      // Measured against forced schedules at 512 / 1024 / 2048 queries x 1M keys (profiles/r3_i8_ab.txt).
+      // (a candidate costs ~0.4 ns while a level's rescoring is a latency chain -- up to ~1000 queries -- and ~0.18 ns once it
+      // is bound by the row gathers: 100 000 queries x ~130 candidates x 1 KiB in 1.8 ms)
+      const double per_cand = 0.18e-3 + 0.22e-3 * (B <= 1024 ? 1.0 : 1024.0 / (double)B);
+      for (int i8 = 0; i8 <= (i8_ok ? (L < 2 ? L : 2) : 0); ++i8) {
+        double cost = first, e_prev = 0.0, e = (double)n0;
+        bool fits = true;
+        for (int l = 0; l < L; ++l) {
+          e = l + 1 == L ? (double)N : e * r;
+          const bool q8 = l >= L - i8;
+          const double cands = 1.3 * k * r * (q8 ? 3.0 : 1.0);
+          if (cands > cap / 2 && !(force_n0 > 0 && force_L > 0)) fits = false;
+          cost += 60.0 + (e - e_prev) * (double)B * 2.0 * D / (q8 ? 2.4e9 : 1.25e9) + (double)B * cands * per_cand;
+          e_prev = e;
+        }
+        if (fits && cost < best) {
+          best = cost;
+          best_n0 = n0;
+          best_nA = nA;
+          best_L = L;
+          best_i8 = i8;
+        }
       }
     }
   }
   sc.bound_keys = bound ? (best_nA ? best_nA : prefix_for(4096)) : 0;
   sc.n0 = best_n0;
+  sc.i8_levels = best_i8;
   sc.slab0 = 1;
   sc.nlev = 0;
   const double r = pow((double)N / (double)best_n0, 1.0 / best_L);
@@ -1415,13 +1449,12 @@ static int filter_i8_levels(const FilterSchedule& sc, int64_t B, int D, int64_t 
   if (B <= 256) return 0;  // (the direct kernel has no int8 form)
   if (force >= 0) return force < sc.nlev ? force : sc.nlev;
   if (t_max_i8_levels == 0) return 0;
-  // measured on the 1M x 256 bank (ms per call, 0 / 1 / 2 int8 levels; profiles/r3_i8_ab.txt): 512 queries 0.317 / 0.314 /
-  // 0.314; 1024: 0.538 / 0.519 / 0.505; 2048: 0.98 / 0.80 / 0.83; 4096: 1.75 / 1.34 / 1.28; 16384: 6.09 / 4.55 / 4.19;
-  // 100 000 (the bench step): 38.3 / 28.3 / 26.9 (three: 27.7)
-  // (short banks: the launch is not matrix-bound, and an int8 level quantises its queries from the fp32 rows per segment
-  // where the bf16 levels of up to 16384 queries load a prepared image -- Cora-sized 2708 x 10 000 x 128: 0.087 -> 0.100 ms)
-  if (B < 1024 || N < 65536) return 0;
-  int n = sc.nlev < 2 ? sc.nlev : 2;
+  // The schedule plans them (filter_schedule: sc.i8_levels -- the level STRUCTURE never depends on the per-thread cap, so
+  // the shards of a bank keep the same phases whatever each thinks of its rows).  Measured on the 1M x 256 bank (ms per
+  // call, 0 / 1 / 2 int8 levels on round 2's schedules; profiles/r3_i8_ab.txt): 1024 queries 0.538 / 0.519 / 0.505; 2048:
+  // 0.98 / 0.80 / 0.83; 4096: 1.75 / 1.34 / 1.28; 16384: 6.09 / 4.55 / 4.19; 100 000 (the bench step): 38.3 / 28.3 / 26.9
+  // (three: 27.7); with the schedule chosen for int8 (two levels, the second on int8): 512: 0.314 -> 0.276, 1024: 0.509 -> 0.426.
+  int n = sc.i8_levels < sc.nlev ? sc.i8_levels : sc.nlev;
   if (t_max_i8_levels > 0 && n > t_max_i8_levels) n = t_max_i8_levels;
   return n;
 }

@@ -800,7 +800,7 @@ def test_key_index_drops_int8_before_the_filter_when_a_bank_overflows(dev):
     from ragraph_amd import kernels as K
 
     rng = _rng(91)
-    N, D, B, k = 70000, 256, 1200, 10
+    N, D, B, k = 70000, 256, 17000, 10     # (a batch whose schedule plans int8 levels on a bank of this size)
     centre = rng.standard_normal((1, D), dtype=np.float32)
     # (noise 0.5: ~90 keys within the bf16 bound of a query's k-th best, ~12 000 within the int8 bound)
     kn = cref.normalize_rows(np.concatenate([centre + 0.5 * rng.standard_normal((30000, D), dtype=np.float32),
