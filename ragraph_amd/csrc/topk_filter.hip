@@ -359,7 +359,7 @@ template <int D, int QW, bool BOUND = false, bool I8 = false>
 __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
   using C = FilterCfg<I8 ? D / 2 : D>;
   static_assert(!(I8 && BOUND), "the bound pass runs on the bf16 copy");
-  static_assert(QW == 32 || QW == 64 || QW == 128, "two, four or eight query groups of 16 per wave");
+  static_assert(QW == 32 || QW == 64 || QW == 96 || QW == 128, "two, four, six or eight query groups of 16 per wave");
   constexpr int QT = C::WAVES * QW;
   constexpr int NG = QW / 16;  // query groups per wave: each A fragment (16 keys x 32 elements) feeds NG MFMAs
   extern __shared__ float4 fsmem4[];
@@ -597,7 +597,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
       // the groups' entries of one sub-tile: ballots first, ONE buffer check per (up to) four groups -- a flush is ~60
       // instructions and every copy of it sits in the stage loop's instruction stream
       auto push_groups = [&](const unsigned (&km)[NG], unsigned off) {
-        constexpr int GB = NG < 4 ? NG : 4;  // groups per check: at most 64 GB = 256 entries < CAND_BUF
+        constexpr int GB = NG < 4 ? NG : (NG % 4 == 0 ? 4 : 3);  // groups per check: at most 64 GB = 256 entries < CAND_BUF
 #pragma unroll
         for (int g0 = 0; g0 < NG; g0 += GB) {
           unsigned long long bm[GB];
@@ -1682,12 +1682,19 @@ static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64
       p.cap = cap;
       p.stage_base = key0 / C8::STAGE_KEYS;  // key0 is a multiple of 256
       p.nstages_total = cdiv(key1 - key0, C8::STAGE_KEYS);
-      // (int8 operands are 16 bytes per 64 elements: eight query groups fit the registers four bf16 groups take, and an
-      // A fragment then feeds eight MFMAs -- 3.53 vs 3.29 Pop/s in the bare loop, tools/microbench/mfma_i8_bench.hip)
+      // int8 operands are 16 bytes per 64 elements: SIX query groups per wave (tile = 768 queries) fit the registers four
+      // bf16 groups take (224 VGPRs, no scratch), and an A fragment then feeds six MFMAs, a stage 3072 cycles of them
+      // between two ring hand-overs: the bench's last level 14.45 -> 13.8 ms (A/B on one box, profiles/r3_i8_ab.txt).
+      // Eight groups (tile = 1024) spill (256 VGPRs + 80 B of scratch): 14.2 ms.  Long streams only, and only where the
+      // larger tile does not add padding queries (the last tile of 4096 queries would be a third full).
       const char* e = getenv("RAGRAPH_FILTER_I8_QW");
-      const int qw = e ? atoi(e) : 64;
+      const int qw_env = e ? atoi(e) : 0;
+      const int64_t pad96 = cdiv(B, (int64_t)768) * 768 - B, pad64 = cdiv(B, (int64_t)512) * 512 - B;
+      const bool long96 = cdiv(B, (int64_t)768) * p.nstages_total >= 32 * (int64_t)filter_device_cus();
+      const int qw = qw_env ? qw_env : (long96 && (pad96 - pad64) * 50 <= B ? 96 : 64);
       if (qw == 128 && cdiv(B, (int64_t)1024) * p.nstages_total >= 32 * (int64_t)filter_device_cus())
         return launch_ring<D, 128, false, true>(p, B, prof_slot, st);
+      if (qw == 96 && long96) return launch_ring<D, 96, false, true>(p, B, prof_slot, st);
       return launch_ring<D, 64, false, true>(p, B, prof_slot, st);
     }
   }
