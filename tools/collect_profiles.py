@@ -58,11 +58,19 @@ out = {
             "WRITE_SIZE)*1024: on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM "
             "section). Infinity-Cache hits are included in FETCH_SIZE.",
 }
-names = {"int8": "ragraph::topk_filter_kernel<256, 64, false, true>", "bf16": "ragraph::topk_filter_kernel<256, 64, false, false>",
-         "bound": "ragraph::topk_filter_kernel<256, 64, true, false>"}
+def find(kind):
+    """The filter kernel's PMC name for a kind of launch, whatever its queries-per-wave template argument."""
+    for nm in fe:
+        m = re.match(r"ragraph::topk_filter_kernel<256, (\d+), (true|false), (true|false)>", nm)
+        if m and (m.group(2), m.group(3)) == {"int8": ("false", "true"), "bf16": ("false", "false"), "bound": ("true", "false")}[kind]:
+            return nm
+    return None
+
+
+names = {k_: find(k_) for k_ in ("int8", "bf16", "bound")}
 rec, total_kb = {}, 0.0
 for key, nm in names.items():
-    if nm in fe and nm in wr:
+    if nm and nm in fe and nm in wr:
         per_call = fe[nm]["FETCH_SIZE_n"] / max(fe[names["bound"]]["FETCH_SIZE_n"], 1) if names["bound"] in fe else 1
         rec[key] = {"FETCH_SIZE_KB_mean": fe[nm]["FETCH_SIZE"], "WRITE_SIZE_KB_mean": wr[nm]["WRITE_SIZE"],
                     "FETCH_SIZE_KB_max": fe[nm].get("FETCH_SIZE_max"), "WRITE_SIZE_KB_max": wr[nm].get("WRITE_SIZE_max"),
