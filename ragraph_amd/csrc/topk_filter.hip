@@ -1281,7 +1281,10 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
   // int8 levels (filter_common.h): D = 128 / 256, the ring kernel's batch sizes, banks long enough to be matrix-bound (an
   // int8 level quantises its queries from the fp32 rows per segment where the bf16 levels of up to 16384 queries load a
   // prepared image -- Cora-sized 2708 x 10 000 x 128: 0.087 -> 0.100 ms)
-  const bool i8_ok = (D == 128 || D == 256) && B > 256 && N * n_shards >= 65536;
+  static const bool i8_d64 = [] { const char* e = getenv("RAGRAPH_FILTER_I8_D64"); return !e || atoi(e) != 0; }();  // A/B
+  // (D = 64, the edge flavour: one MFMA per 16-key half and query group, so the epilogue weighs more -- 65 536 x 4M x 64:
+  // 22.5 -> 15.5 ms with eight groups per wave; eps is the same 0.02 but the scores' spread is 1/8: fewer extra candidates)
+  const bool i8_ok = (D == 128 || D == 256 || (D == 64 && i8_d64)) && B > 256 && N * n_shards >= 65536;
   // bound_keys / eff_div ~ the exact sample the bound is worth: planned for 4 k parts, corrected below if the prefix is
   // too short for that many
   const double eff_div = filter_bound_eff(k, B <= 64 ? k : 4 * k);
@@ -1445,7 +1448,7 @@ extern "C" int ragraph_topk_cosine_filtered_max_i8_levels(int n) {
 static int filter_i8_levels(const FilterSchedule& sc, int64_t B, int D, int64_t N) {
   const char* env = getenv("RAGRAPH_FILTER_I8");  // (read per call: the tests switch it)
   const int force = env ? atoi(env) : -1;
-  if (D != 128 && D != 256) return 0;
+  if (D != 64 && D != 128 && D != 256) return 0;
   if (B <= 256) return 0;  // (the direct kernel has no int8 form)
   if (force >= 0) return force < sc.nlev ? force : sc.nlev;
   if (t_max_i8_levels == 0) return 0;
@@ -1666,7 +1669,7 @@ template <int D>
 static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64_t key0, int64_t key1, const FilterThr& thr,
                          int cap, int bound_groups, int prof_slot, hipStream_t st, const signed char* Kb8 = nullptr) {
   using C = FilterCfg<D>;
-  if constexpr (D >= 128) {
+  {
     if (Kb8) {  // an int8 level (filter_i8_levels): the ring kernel over the int8 copy, stages of twice as many keys
       using C8 = FilterCfg<D / 2>;
       FilterParams p{};
@@ -1689,12 +1692,17 @@ static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64
       // larger tile does not add padding queries (the last tile of 4096 queries would be a third full).
       const char* e = getenv("RAGRAPH_FILTER_I8_QW");
       const int qw_env = e ? atoi(e) : 0;
-      const int64_t pad96 = cdiv(B, (int64_t)768) * 768 - B, pad64 = cdiv(B, (int64_t)512) * 512 - B;
-      const bool long96 = cdiv(B, (int64_t)768) * p.nstages_total >= 32 * (int64_t)filter_device_cus();
-      const int qw = qw_env ? qw_env : (long96 && (pad96 - pad64) * 50 <= B ? 96 : 64);
+      const int64_t pad64 = cdiv(B, (int64_t)512) * 512 - B;
+      auto fits = [&](int64_t tile) {  // a long stream per workgroup, and at most 2 % more padding queries than tiles of 512
+        return cdiv(B, tile) * p.nstages_total >= 32 * (int64_t)filter_device_cus() && (cdiv(B, tile) * tile - B - pad64) * 50 <= B;
+      };
+      // (D = 64: eight groups are 32 registers of operands -- no spill -- and 65 536 x 4M x 64 runs 15.5 ms against 16.3 with
+      // six and 17.0 with four)
+      const int qw = qw_env ? qw_env : (D == 64 && fits(1024) ? 128 : (fits(768) ? 96 : 64));
       if (qw == 128 && cdiv(B, (int64_t)1024) * p.nstages_total >= 32 * (int64_t)filter_device_cus())
         return launch_ring<D, 128, false, true>(p, B, prof_slot, st);
-      if (qw == 96 && long96) return launch_ring<D, 96, false, true>(p, B, prof_slot, st);
+      if (qw == 96 && cdiv(B, (int64_t)768) * p.nstages_total >= 32 * (int64_t)filter_device_cus())
+        return launch_ring<D, 96, false, true>(p, B, prof_slot, st);
       return launch_ring<D, 64, false, true>(p, B, prof_slot, st);
     }
   }

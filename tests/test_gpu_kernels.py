@@ -713,7 +713,8 @@ def test_topk_cosine_fused_overflow_zero_queries_and_dispatch(dev, monkeypatch):
 
 
 @pytest.mark.parametrize("D,B,N,k,levels", [(256, 700, 70000, 10, 3), (128, 513, 33000, 7, 3), (256, 3000, 40000, 5, 1),
-                                            (128, 17000, 70000, 10, -1), (256, 17000, 66000, 32, -1)])
+                                            (64, 900, 70000, 10, 3), (64, 3000, 100000, 5, 2),
+                                            (128, 17000, 70000, 10, -1), (256, 17000, 66000, 32, -1), (64, 20000, 131072, 10, -1)])
 def test_topk_cosine_filtered_int8_levels_bit_exact(dev, monkeypatch, D, B, N, k, levels):
     """Filter levels on the INT8 copy (v_mfma_i32_16x16x64_i8, integer thresholds; csrc/filter_common.h): forced on every
     level of small shapes (RAGRAPH_FILTER_I8), and the product rule -- the last level of a batch of more than 16384 queries --
