@@ -191,7 +191,8 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
                                                           unsigned char* __restrict__ flag, int* __restrict__ overflow,
                                                           int* __restrict__ gmax, int ngroups,
                                                           uint16_t* __restrict__ Qb, int cstride,
-                                                          float* __restrict__ eq8, float* __restrict__ qscale) {
+                                                          float* __restrict__ eq8, float* __restrict__ qscale,
+                                                          signed char* __restrict__ Qb8) {
   const int lane = threadIdx.x & 63;
   const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q == 0 && lane == 0) *overflow = 0;
@@ -238,13 +239,23 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, off));
     sq = __uint_as_float(am) / 127.f;
+    unsigned w8 = 0u;
     if (sq > 0.f) {
       const float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float dd = fmaf(sq, (float)quantize_i8(x[e], sq), -x[e]);
+        const int qi = quantize_i8(x[e], sq);
+        w8 |= ((unsigned)qi & 0xFFu) << (8 * e);
+        const float dd = fmaf(sq, (float)qi, -x[e]);
         e8 = fmaf(dd, dd, e8);
       }
+    }
+    if (Qb8 && lane < NCH) {
+      // the direct kernel's int8 B operands (<= 256 queries), fragment order: this lane's elements 4 l .. 4 l + 3 are dword
+      // l % 4 of the 16-byte piece l / 4 = 4 t + g of its row (padding queries of the last group of 32: zero rows)
+      const int c = lane >> 2;
+      char* base = reinterpret_cast<char*>(Qb8) + ((q >> 4) * (D / 64) + (c >> 2)) * 1024 + ((c & 3) * 16 + (int)(q & 15)) * 16 + (lane & 3) * 4;
+      *reinterpret_cast<unsigned*>(base) = w8;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) e8 += __shfl_xor(e8, off);
@@ -1274,6 +1285,7 @@ static double filter_bound_eff(int k, int parts) {
 
 // n_shards > 1 (row-sharded bank, N = the largest shard): the shards pool their first samples through the exchange, so
 // the sample is planned for the WHOLE bank and every shard scans its share of the prefix.
+static int rescore_slices(int64_t B, int k);
 static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_shards = 1) {
   FilterSchedule sc{};
   const int cap = 2048;
@@ -1285,6 +1297,8 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
   // (D = 64, the edge flavour: one MFMA per 16-key half and query group, so the epilogue weighs more -- 65 536 x 4M x 64:
   // 22.5 -> 15.5 ms with eight groups per wave; eps is the same 0.02 but the scores' spread is 1/8: fewer extra candidates)
   const bool i8_ok = (D == 128 || D == 256 || (D == 64 && i8_d64)) && B > 256 && N * n_shards >= 65536;
+  static const bool i8_direct_env = [] { const char* e = getenv("RAGRAPH_FILTER_I8_DIRECT"); return !e || atoi(e) != 0; }();  // A/B
+  const bool i8_direct = (D == 128 || D == 256) && B <= 256 && N * n_shards >= 65536 && i8_direct_env;
   // bound_keys / eff_div ~ the exact sample the bound is worth: planned for 4 k parts, corrected below if the prefix is
   // too short for that many
   const double eff_div = filter_bound_eff(k, B <= 64 ? k : 4 * k);
@@ -1374,12 +1388,27 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
       if (1.3 * k * r > cap / 2 && !(force_n0 > 0 && force_L > 0)) continue;
       // a level: launches + the rescoring kernels' latency floor, plus ~0.4 - 0.5 ns per candidate (1 KB row gather each)
       if (B <= 256) {
-        const double cost = first + L * (25.0 + (double)B * 1.3 * k * r * 0.5e-3) + (L - 1) * 15.0;  /* (a second pass start-up) */
-        if (cost < best) {
-          best = cost;
-          best_n0 = n0;
-          best_nA = nA;
-          best_L = L;
+        // Direct kernel.  On the int8 copy its pass streams half the bytes and does half the matrix work (one query: 78 ->
+        // 40 us of kernel; 256: 124 -> ~75) while ~3x the candidates come back: the same model with 3.9 k r candidates per
+        // level and that saving decides between the two -- and moves n0 up when int8 wins.
+        // (int8 wins at every batch size from 1 to 256 on the 1M x 256 bank -- 0.106 -> 0.074, 0.124 -> 0.091, 0.139 -> 0.109,
+        // 0.192 -> 0.153 ms -- so where it is eligible the model only chooses ITS schedule; the two constants are not
+        // comparable across the dtypes)
+        for (int q8 = i8_direct ? 1 : 0; q8 <= (i8_direct ? 1 : 0); ++q8) {
+          const double cands = 1.3 * k * r * (q8 ? 3.0 : 1.0);
+          // (a handful of queries keep S sub-lists of `cap` slots each: filter_cap)
+          if (cands > cap * (q8 ? rescore_slices(B, k) : 1) / 2 && !(force_n0 > 0 && force_L > 0)) continue;
+          // (the sliced / wide rescoring of a small call is a latency chain: measured 1.2 - 3.7 ns per candidate on the int8
+          // schedules -- forced n0 at 1 / 16 / 64 queries, profiles/r3_i8_ab.txt -- where round 2 fitted 0.5 to its bf16 ones)
+          const double cost = first + L * (25.0 + (double)B * cands * (q8 ? 2.0e-3 : 0.5e-3)) + (L - 1) * (q8 ? 30.0 : 15.0)  /* (a second pass start-up; 256 queries, int8: one level 0.156, two 0.162 ms) */
+                              - (q8 ? 32.0 + 0.08 * (double)B : 0.0);
+          if (cost < best) {
+            best = cost;
+            best_n0 = n0;
+            best_nA = nA;
+            best_L = L;
+            best_i8 = q8 ? L : 0;
+          }
         }
         continue;
       }
@@ -1449,7 +1478,10 @@ static int filter_i8_levels(const FilterSchedule& sc, int64_t B, int D, int64_t 
   const char* env = getenv("RAGRAPH_FILTER_I8");  // (read per call: the tests switch it)
   const int force = env ? atoi(env) : -1;
   if (D != 64 && D != 128 && D != 256) return 0;
-  if (B <= 256) return 0;  // (the direct kernel has no int8 form)
+  if (B <= 256) {  // the direct kernel's int8 form (D = 128 / 256): every level or none, as the schedule planned
+    if (D == 64 || t_max_i8_levels == 0 || sc.i8_levels == 0) return 0;
+    return sc.nlev;
+  }
   if (force >= 0) return force < sc.nlev ? force : sc.nlev;
   if (t_max_i8_levels == 0) return 0;
   // The schedule plans them (filter_schedule: sc.i8_levels -- the level STRUCTURE never depends on the per-thread cap, so
@@ -1572,6 +1604,7 @@ struct FilterWs {
   int* part_i;
   float* eq8;           // [B] |dq| of the int8 rounding, [B] the query's int8 scale (int8 levels)
   float* qscale;
+  signed char* Qb8;     // (B <= 256) the queries as int8 B operands in fragment order, padded to whole groups of 32
 };
 
 static size_t filter_ws_carve(char* w, int64_t B, int D, int k, int cap, FilterWs* out) {
@@ -1595,6 +1628,7 @@ static size_t filter_ws_carve(char* w, int64_t B, int D, int k, int cap, FilterW
   f.part_i = B <= 64 ? reinterpret_cast<int*>(take((size_t)B * 8 * k * sizeof(int))) : nullptr;
   f.eq8 = reinterpret_cast<float*>(take((size_t)B * sizeof(float)));
   f.qscale = reinterpret_cast<float*>(take((size_t)B * sizeof(float)));
+  f.Qb8 = B <= 256 ? reinterpret_cast<signed char*>(take((size_t)((B + 31) / 32 * 32) * D)) : nullptr;
   if (out) *out = f;
   return off;
 }
@@ -1670,7 +1704,7 @@ static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64
                          int cap, int bound_groups, int prof_slot, hipStream_t st, const signed char* Kb8 = nullptr) {
   using C = FilterCfg<D>;
   {
-    if (Kb8) {  // an int8 level (filter_i8_levels): the ring kernel over the int8 copy, stages of twice as many keys
+    if (Kb8 && B > 256) {  // an int8 level (filter_i8_levels): the ring kernel over the int8 copy, stages of twice as many keys
       using C8 = FilterCfg<D / 2>;
       FilterParams p{};
       p.Qn = f.Qn;
@@ -1708,8 +1742,9 @@ static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64
   }
   if (B <= 256) {
     DirectArgs a{};
-    a.Qb = f.Qb;
-    a.Kb = Kb;
+    a.Qb = Kb8 ? reinterpret_cast<const uint16_t*>(f.Qb8) : f.Qb;
+    a.Kb = Kb8 ? reinterpret_cast<const uint16_t*>(Kb8) : Kb;
+    a.i8 = Kb8 ? 1 : 0;
     a.B = B;
     a.key0 = key0;
     a.key1 = key1;
@@ -1854,7 +1889,7 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   hipLaunchKernelGGL(filter_prep_kernel<D>, dim3((unsigned)cdiv(B <= FILTER_QB_MAX_B ? (B + 31) / 32 * 32 : B, 4)), dim3(256), 0, st, Q, B,
                      f.Qn, f.eq, f.count, f.flag, overflow, bound ? f.gmax : nullptr, bound ? filter_bound_parts(k, sc.bound_keys, D, B, exchange ? n_shards : 1) : k,
                      B <= FILTER_QB_MAX_B ? f.Qb : nullptr,
-                     filter_count_stride(B), sc.i8_levels > 0 ? f.eq8 : nullptr, f.qscale);
+                     filter_count_stride(B), sc.i8_levels > 0 ? f.eq8 : nullptr, f.qscale, B <= 256 ? f.Qb8 : nullptr);
   RG_CHECK_LAUNCH("topk_cosine_filtered(prepare)");
 
   FilterThr thr{};

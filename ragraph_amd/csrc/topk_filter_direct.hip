@@ -75,10 +75,17 @@ __device__ unsigned long long g_direct_t[2][2][8];
 #define RG_DSTAMP(i_)
 #endif
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
 // QREG: <= 32 queries, B operands in registers; else `qgroups` groups in LDS.
-template <int D, bool QREG, bool BOUND>
+// I8: the pass runs on the int8 copy (filter_common.h): the unit / sub-tile geometry of a bf16 bank of D / 2 elements (a key is
+// D bytes: the 0.512 GB stream of a 1M x 256 bank becomes 0.256 GB), v_mfma_i32_16x16x64_i8, integer thresholds; p.Qb is the
+// queries' int8 image (filter_prep_kernel), same block structure as the bf16 one at half the k-steps.
+template <int D, bool QREG, bool BOUND, bool I8 = false>
 __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams p) {
-  using C = DirectCfg<D>;
+  using C = DirectCfg<I8 ? D / 2 : D>;
+  static_assert(!(I8 && BOUND), "the bound pass runs on the bf16 copy");
+  using acc_t = typename std::conditional<I8, i32x4, f32x4>::type;
   RG_DSTAMP(0);
   extern __shared__ float4 dsmem4[];
   char* smem = reinterpret_cast<char*>(dsmem4);
@@ -94,9 +101,15 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
 
   // ---- thresholds (one per query of the tile) and, beyond 32 queries, the B operands in LDS -------------------------
   if (tid < 256) {
-    float t = __builtin_huge_valf();  // padded queries never pass
-    if (!BOUND && tid < p.B) t = filter_threshold(p.thr, tid);
-    thr_lds[tid] = t;
+    if constexpr (I8) {  // (the integer threshold, kept as bits in the float array)
+      int t = INT_MAX;
+      if (tid < p.B) t = filter_threshold_i8(p.thr, tid);
+      thr_lds[tid] = __int_as_float(t);
+    } else {
+      float t = __builtin_huge_valf();  // padded queries never pass
+      if (!BOUND && tid < p.B) t = filter_threshold(p.thr, tid);
+      thr_lds[tid] = t;
+    }
   }
   // the B operands: filter_prep_kernel left them in HBM as bf16 in fragment order, so a workgroup copies its image
   // into LDS linearly (33..256 queries) or a wave takes its 64 VGPRs straight from it (<= 32 queries)
@@ -184,16 +197,45 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
 
   // epilogue of a 32-key sub-tile against one group of 16 queries: a[h][r] = approximate score of key 16 h + 4 g + r of the
   // sub-tile for query 16 gq + j
-  auto epilogue = [&](const f32x4 (&a)[2], int gq, int64_t unit, int sub, int part) {
+  auto epilogue = [&](const acc_t (&a)[2], int gq, int64_t unit, int sub, int part) {
 #if defined(RG_DIRECT_ABL) && (RG_DIRECT_ABL & 1)   // timing build: no epilogue (results invalid); the scores stay live
-    if (a[0][0] + a[1][3] == 123456.f) wbuf[0] = make_uint2(1u, 2u);
+    if (a[0][0] + a[1][3] == 123456) wbuf[0] = make_uint2(1u, 2u);
     return;
 #endif
-    float m = a[0][0];  // (a chain, not a tree: hipcc folds it into v_max3_f32)
+    if constexpr (I8) {  // integer sums against the integer threshold
+      int m = a[0][0];
 #pragma unroll
-    for (int r = 1; r < 4; ++r) m = fmaxf(m, a[0][r]);
+      for (int r = 1; r < 4; ++r) m = max(m, a[0][r]);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) m = fmaxf(m, a[1][r]);
+      for (int r = 0; r < 4; ++r) m = max(m, a[1][r]);
+      const int th = __float_as_int(thr_lds[16 * gq + j]);
+      if (__any(m >= th)) {
+        unsigned mk = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mk |= (a[h][r] >= th) ? (1u << (4 * h + r)) : 0u;
+        const int64_t key_base = (unit * C::SUBS + sub) * 32 + 4 * g;
+        if (key_base + 32 > p.key_end) {
+          unsigned vm = 0;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) vm |= (key_base + (r & 3) + 16 * (r >> 2) < p.key_end) ? (1u << r) : 0u;
+          mk &= vm;
+        }
+        const unsigned long long bal = __ballot(mk != 0);
+        if (bal) {
+          const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+          if (mk) wbuf[pos] = make_uint2((unsigned)key_base, ((unsigned)(16 * gq + j) << 16) | mk);
+          wcnt += __popcll(bal);
+        }
+      }
+      return;
+    }
+    float m = (float)a[0][0];  // (a chain, not a tree: hipcc folds it into v_max3_f32)
+#pragma unroll
+    for (int r = 1; r < 4; ++r) m = fmaxf(m, (float)a[0][r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m = fmaxf(m, (float)a[1][r]);
     if constexpr (BOUND) {
       if (part != cur_part) {  // wave-uniform: the run crossed into the next part
         flush_max();
@@ -209,7 +251,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) mk |= (a[h][r] >= th) ? (1u << (4 * h + r)) : 0u;
+          for (int r = 0; r < 4; ++r) mk |= ((float)a[h][r] >= th) ? (1u << (4 * h + r)) : 0u;
         const int64_t key_base = (unit * C::SUBS + sub) * 32 + 4 * g;  // the lane's keys: + r + 16 h  (mask bit 4 h + r)
         if (key_base + 32 > p.key_end) {
           unsigned vm = 0;
@@ -251,17 +293,24 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
       }
 #pragma unroll
       for (int sub = 0; sub < C::SUBS; ++sub) {
-        f32x4 acc[2][2];  // [group][half]
+        acc_t acc[2][2];  // [group][half]
 #pragma unroll
-        for (int gq = 0; gq < 2; ++gq) acc[gq][0] = acc[gq][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int gq = 0; gq < 2; ++gq) acc[gq][0] = acc[gq][1] = acc_t{0, 0, 0, 0};
 #pragma unroll
         for (int t = 0; t < C::KS32; ++t)
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            const bf16x8 a_ = __builtin_bit_cast(bf16x8, A[(sub * C::KS32 + t) * 2 + h]);
 #pragma unroll
-            for (int gq = 0; gq < 2; ++gq)
-              acc[gq][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, bq[gq * C::KS32 + t], acc[gq][h], 0, 0, 0);
+            for (int gq = 0; gq < 2; ++gq) {
+              if constexpr (I8)
+                acc[gq][h] = __builtin_bit_cast(acc_t, __builtin_amdgcn_mfma_i32_16x16x64_i8(
+                    __builtin_bit_cast(i32x4, A[(sub * C::KS32 + t) * 2 + h]), __builtin_bit_cast(i32x4, bq[gq * C::KS32 + t]),
+                    __builtin_bit_cast(i32x4, acc[gq][h]), 0, 0, 0));
+              else
+                acc[gq][h] = __builtin_bit_cast(acc_t, __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, A[(sub * C::KS32 + t) * 2 + h]), bq[gq * C::KS32 + t],
+                    __builtin_bit_cast(f32x4, acc[gq][h]), 0, 0, 0));
+            }
           }
 #pragma unroll
         for (int gq = 0; gq < 2; ++gq) epilogue(acc[gq], gq, unit, sub, part_of(sub));
@@ -285,18 +334,24 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
           if (wcnt > C::CAND_BUF - 64 * C::SUBS) flush();
         }
         const unsigned cur = qaddr0 + (unsigned)gq * C::GROUP_BYTES;
-        f32x4 acc[C::SUBS][2];
+        acc_t acc[C::SUBS][2];
 #pragma unroll
-        for (int sub = 0; sub < C::SUBS; ++sub) acc[sub][0] = acc[sub][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int sub = 0; sub < C::SUBS; ++sub) acc[sub][0] = acc[sub][1] = acc_t{0, 0, 0, 0};
 #define RG_GSTEP(t_)                                                                                            \
   if constexpr ((t_) < C::KS32) {                                                                               \
     RG_BWAIT(t_);                                                                                               \
     {                                                                                                           \
-      const bf16x8 b_ = __builtin_bit_cast(bf16x8, fr[(t_) % C::LA]);                                           \
       _Pragma("unroll") for (int sub = 0; sub < C::SUBS; ++sub)                                                 \
-        _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                           \
-          acc[sub][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                                \
-              __builtin_bit_cast(bf16x8, A[(sub * C::KS32 + (t_)) * 2 + h]), b_, acc[sub][h], 0, 0, 0);         \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                         \
+          if constexpr (I8)                                                                                     \
+            acc[sub][h] = __builtin_bit_cast(acc_t, __builtin_amdgcn_mfma_i32_16x16x64_i8(                      \
+                __builtin_bit_cast(i32x4, A[(sub * C::KS32 + (t_)) * 2 + h]),                                   \
+                __builtin_bit_cast(i32x4, fr[(t_) % C::LA]), __builtin_bit_cast(i32x4, acc[sub][h]), 0, 0, 0)); \
+          else                                                                                                  \
+            acc[sub][h] = __builtin_bit_cast(acc_t, __builtin_amdgcn_mfma_f32_16x16x32_bf16(                    \
+                __builtin_bit_cast(bf16x8, A[(sub * C::KS32 + (t_)) * 2 + h]),                                  \
+                __builtin_bit_cast(bf16x8, fr[(t_) % C::LA]), __builtin_bit_cast(f32x4, acc[sub][h]), 0, 0, 0)); \
+        }                                                                                                       \
     }                                                                                                           \
     RG_BREAD(t_, cur, (t_) + C::LA);                                                                            \
   }
@@ -361,14 +416,14 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
 #undef RG_DLOAD
 }
 
-template <int D, bool QREG, bool BOUND>
+template <int D, bool QREG, bool BOUND, bool I8 = false>
 static int launch_direct(const DirectParams& p, int grid, size_t lds, hipStream_t st) {
   static DeviceOnce lds_once;  // per device (common.h)
-  if (hipError_t e = raise_dynamic_lds(lds_once, &topk_filter_direct_kernel<D, QREG, BOUND>, 160 * 1024); e != hipSuccess) {
+  if (hipError_t e = raise_dynamic_lds(lds_once, &topk_filter_direct_kernel<D, QREG, BOUND, I8>, 160 * 1024); e != hipSuccess) {
     set_error("topk_cosine_filtered(direct): cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
     return RAGRAPH_EDEVICE;
   }
-  hipLaunchKernelGGL((topk_filter_direct_kernel<D, QREG, BOUND>), dim3((unsigned)grid), dim3(512), lds, st, p);
+  hipLaunchKernelGGL((topk_filter_direct_kernel<D, QREG, BOUND, I8>), dim3((unsigned)grid), dim3(512), lds, st, p);
   RG_CHECK_LAUNCH("topk_cosine_filtered(direct filter)");
 #ifdef RG_DIRECT_TIMING
   {
@@ -385,9 +440,42 @@ static int launch_direct(const DirectParams& p, int grid, size_t lds, hipStream_
   return RAGRAPH_OK;
 }
 
+// The same launch on the int8 copy (a.i8: a.Kb = the int8 copy, a.Qb = the queries' int8 image): the geometry of D / 2.
+template <int D>
+static int launch_filter_direct_i8(const DirectArgs& a, hipStream_t st) {
+  using C = DirectCfg<D / 2>;
+  RG_REQUIRE(a.B >= 1 && a.B <= 256 && a.bound_groups == 0, RAGRAPH_EINVAL, "filter(direct, int8): bad batch / mode");
+  RG_REQUIRE(a.key0 % C::UNIT_KEYS == 0 && a.key1 > a.key0, RAGRAPH_EINVAL, "filter(direct, int8): bad key range");
+  DirectParams p{};
+  p.Qb = a.Qb;
+  p.Kb = a.Kb;
+  p.B = a.B;
+  p.unit0 = a.key0 / C::UNIT_KEYS;
+  p.nunits = cdiv(a.key1 - a.key0, (int64_t)C::UNIT_KEYS);
+  p.key_end = a.key1;
+  p.thr = a.thr;
+  p.count = a.count;
+  p.cand = a.cand;
+  p.cap = a.cap;
+  p.nsub = a.nsub < 1 ? 1 : a.nsub;
+  RG_REQUIRE((p.nsub & (p.nsub - 1)) == 0 && p.nsub <= FILTER_COUNT_STRIDE, RAGRAPH_EINVAL, "filter(direct): nsub=%d", p.nsub);
+  p.subcap = a.cap / p.nsub;
+  p.qgroups = 2 * (int)cdiv(a.B, 32);
+  const int cus = device_cus_multiple_of_8();
+  int64_t grid = cdiv(p.nunits, (int64_t)C::WAVES);
+  if (grid > cus) grid = cus;
+  const bool qreg = a.B <= 32;
+  const size_t lds = C::lds_bytes(qreg ? 0 : p.qgroups);
+  return qreg ? launch_direct<D, true, false, true>(p, (int)grid, lds, st) : launch_direct<D, false, false, true>(p, (int)grid, lds, st);
+}
+
 template <int D>
 int launch_filter_direct(const DirectArgs& a, hipStream_t st) {
   using C = DirectCfg<D>;
+  if constexpr (D >= 128) {
+    if (a.i8) return launch_filter_direct_i8<D>(a, st);
+  }
+  RG_REQUIRE(!a.i8, RAGRAPH_EUNSUPPORTED, "filter(direct): no int8 form at D = %d", D);
   RG_REQUIRE(a.B >= 1 && a.B <= 256, RAGRAPH_EINVAL, "filter(direct): B=%lld not in [1,256]", (long long)a.B);
   RG_REQUIRE(a.key0 % C::UNIT_KEYS == 0 && a.key1 > a.key0, RAGRAPH_EINVAL, "filter(direct): bad key range");
   DirectParams p{};

@@ -817,3 +817,31 @@ def test_key_index_drops_int8_before_the_filter_when_a_bank_overflows(dev):
     assert idx._i8_ok is True                    # ordinary entries: the error row does not give the bank away
     assert idx.overflowed_queries > B // 4       # the int8 levels did overflow ...
     assert idx._i8_off and not idx._filter_off   # ... so int8 is what goes; the bf16 filter stays
+
+
+@pytest.mark.parametrize("D,B,N,k", [(256, 1, 70000, 10), (256, 16, 100000, 5), (128, 33, 70000, 10), (256, 200, 150000, 10),
+                                     (128, 256, 66000, 7), (256, 64, 300000, 10)])
+def test_topk_cosine_filtered_int8_direct_kernel_bit_exact(dev, D, B, N, k):
+    """Up to 256 queries against a bank of >= 65 536 keys: the direct kernel's pass runs on the int8 copy (half the stream,
+    half the matrix work; the schedule planned for ~3x the candidates) -- the oracle's bits, with ties, a zero query and the
+    sliced rescoring of a handful of queries."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(3 * D + B + N + k)
+    kn = _bank(rng, N, D)
+    kn[N // 2:N // 2 + 40] = kn[:40]
+    q = rng.standard_normal((B, D), dtype=np.float32)
+    if B > 2:
+        q[B - 1] = 0.0
+    assert K.filtered_i8_levels(B, N, D, k) >= 1
+    knd = _t(kn, dev)
+    s, i, over = K.topk_cosine_filtered(_t(q, dev), knd, K.keys_to_bf16(knd), k, idx_base=2)
+    rs, ri = cref.topk_cosine(q, kn, k, idx_base=2)
+    assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs)
+    old = K.set_max_i8_levels(0)                               # the same call kept on bf16: the same bits
+    try:
+        assert K.filtered_i8_levels(B, N, D, k) == 0
+        s2, i2, _ = K.topk_cosine_filtered(_t(q, dev), knd, K.keys_to_bf16(knd), k, idx_base=2)
+    finally:
+        K.set_max_i8_levels(old)
+    assert torch.equal(i, i2) and torch.equal(s, s2)
