@@ -29,6 +29,7 @@ class KeyIndex:
         self._i8_off = False      # set when this bank defeats the INT8 levels only (heavy-tailed rows: one scale for all keys)
         self._pending = None      # (pinned word, event, batch, had int8 levels) of the last filtered call's overflow count
         self._i8_ok = None        # the int8 copy's error row read (once, lazily): accurate enough for int8 levels?
+        self._seen_i8, self._seen_bf16 = [0, 0], [0, 0]   # [queries, overflowed] of the polled calls with / without int8
         self._host_word = self._event = None
         self.overflowed_queries = 0
 
@@ -45,11 +46,19 @@ class KeyIndex:
         n_over, B = int(pend[0][0]), pend[2]
         self._pending = None
         self.overflowed_queries += n_over
-        if B >= 64 and 4 * n_over > B:
-            if pend[3] and not self._i8_off:   # the call had int8 levels: their wider bound is the first suspect
+        # judged over whole calls of >= 64 queries, or over the calls seen so far once they add up to 8 queries (graph
+        # classification retrieves ONE query per forward: a bank that sends every such call to the exact scan must not stay)
+        acc = self._seen_i8 if pend[3] else self._seen_bf16
+        acc[0] += B
+        acc[1] += n_over
+        if (B >= 64 and 4 * n_over > B) or (acc[0] >= 8 and 4 * acc[1] > acc[0]):
+            if pend[3] and not self._i8_off:   # the call(s) had int8 levels: their wider bound is the first suspect
                 self._i8_off = True
             else:
                 self._filter_off = True
+            acc[0] = acc[1] = 0
+        elif acc[0] >= 4096:
+            acc[0] = acc[1] = 0
 
     def _cap_i8(self):
         """Before a filtered call: cap this thread's int8 levels for THIS bank (ops.set_max_i8_levels; the caller resets it

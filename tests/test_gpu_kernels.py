@@ -845,3 +845,24 @@ def test_topk_cosine_filtered_int8_direct_kernel_bit_exact(dev, D, B, N, k):
     finally:
         K.set_max_i8_levels(old)
     assert torch.equal(i, i2) and torch.equal(s, s2)
+
+
+def test_key_index_small_batches_leave_int8_when_the_bank_overflows(dev):
+    """Calls of fewer than 64 queries against a clustered bank: the int8 pass overflows the lists of every call (40 queries
+    keep two sub-lists of 2048 each; ~12 000 keys lie within the int8 bound); after the first calls KeyIndex keeps the bank on
+    bf16 (it used to judge only single calls of >= 64 queries)."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(93)
+    N, D, k = 70000, 256, 10
+    centre = rng.standard_normal((1, D), dtype=np.float32)
+    kn = cref.normalize_rows(np.concatenate([centre + 0.5 * rng.standard_normal((30000, D), dtype=np.float32),
+                                             rng.standard_normal((N - 30000, D), dtype=np.float32)]))
+    idx = K.KeyIndex(_t(kn, dev))
+    for c in range(6):
+        q = (centre + 0.5 * rng.standard_normal((40, D), dtype=np.float32)).astype(np.float32)
+        s, i = idx.topk(_t(q, dev), k)
+        torch.cuda.synchronize()
+        rs, ri = cref.topk_cosine(q, kn, k)
+        assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs)
+    assert idx._i8_off and not idx._filter_off and idx.overflowed_queries >= 3
