@@ -141,8 +141,12 @@ __global__ void __launch_bounds__(256) bank_absmax_kernel(const float* __restric
   if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(tail8 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(tail8 + 2, m);
 }
 
-__device__ __forceinline__ int quantize_i8(float x, float scale) {  // rint(x / scale) clamped to [-127, 127]; scale > 0
-  return (int)fminf(fmaxf(__builtin_rintf(x / scale), -127.f), 127.f);
+// rint(x * inv_scale) clamped to [-127, 127], inv_scale = 1 / scale computed ONCE per row with one fp32 division: a multiply
+// per element (the ring kernel quantises 256 elements per lane and segment: divisions were 5 us of every segment).  Whatever
+// integer comes out, the bound uses the error of THAT integer (|s q - x| is measured, not assumed), and the prepare launch and
+// the kernels call this one function with the same inv_scale, so they produce the same operands.
+__device__ __forceinline__ int quantize_i8(float x, float inv_scale) {
+  return (int)fminf(fmaxf(__builtin_rintf(__fmul_rn(x, inv_scale)), -127.f), 127.f);
 }
 
 template <int D>
@@ -152,6 +156,7 @@ __global__ void __launch_bounds__(256) keys_to_i8_kernel(const float* __restrict
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t row = i / TPR;
   const float sk = __uint_as_float(tail8[2]) / 127.f;
+  const float inv_sk = sk > 0.f ? 1.f / sk : 0.f;
   if (i == 0) tail8[1] = __float_as_uint(sk);
   unsigned w[4] = {0u, 0u, 0u, 0u};
   float e2 = 0.f;
@@ -162,7 +167,7 @@ __global__ void __launch_bounds__(256) keys_to_i8_kernel(const float* __restrict
       const float x[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int qi = quantize_i8(x[e], sk);
+        const int qi = quantize_i8(x[e], inv_sk);
         w[c] |= ((unsigned)qi & 0xFFu) << (8 * e);
         const float d = fmaf(sk, (float)qi, -x[e]);
         e2 = fmaf(d, d, e2);
@@ -244,7 +249,7 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
       const float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int qi = quantize_i8(x[e], sq);
+        const int qi = quantize_i8(x[e], 1.f / sq);
         w8 |= ((unsigned)qi & 0xFFu) << (8 * e);
         const float dd = fmaf(sq, (float)qi, -x[e]);
         e8 = fmaf(dd, dd, e8);
@@ -435,6 +440,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
         const int64_t qq = q_lo + 16 * gq;
         const int64_t qr = qq < p.B ? qq : p.B - 1;
         const float sq = p.thr.qscale[qr];
+        const float inv_sq = sq > 0.f ? 1.f / sq : 0.f;
         const float* r0 = p.Qn + qr * D + 16 * g;
 #pragma unroll
         for (int t = 0; t < C::KS32; ++t) {
@@ -445,8 +451,8 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
           for (int c = 0; c < 4; ++c) {
             unsigned w = 0u;
             if (sq > 0.f)
-              w = ((unsigned)quantize_i8(u[c].x, sq) & 0xFFu) | (((unsigned)quantize_i8(u[c].y, sq) & 0xFFu) << 8) |
-                  (((unsigned)quantize_i8(u[c].z, sq) & 0xFFu) << 16) | (((unsigned)quantize_i8(u[c].w, sq) & 0xFFu) << 24);
+              w = ((unsigned)quantize_i8(u[c].x, inv_sq) & 0xFFu) | (((unsigned)quantize_i8(u[c].y, inv_sq) & 0xFFu) << 8) |
+                  (((unsigned)quantize_i8(u[c].z, inv_sq) & 0xFFu) << 16) | (((unsigned)quantize_i8(u[c].w, inv_sq) & 0xFFu) << 24);
             bqi[gq][t][c] = (int)w;
           }
           asm volatile("" : "+v"(bqi[gq][t]));
