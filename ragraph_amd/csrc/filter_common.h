@@ -110,17 +110,21 @@ __device__ __forceinline__ float filter_threshold(const FilterThr& t, int64_t q)
 
 // The int8 levels' integer threshold: a key can only belong to the exact top-k if I = sum qi ki >= the result (see the
 // layout comment above).  INT_MIN: everything passes (zero queries / banks, whose scales are 0).
-__device__ __forceinline__ int filter_threshold_i8(const FilterThr& t, int64_t q) {
-  if (t.ablate == 1) return INT_MAX;
+// (_at: for a given lower bound theta of the query's exact k-th best score)
+__device__ __forceinline__ int filter_threshold_i8_at(const FilterThr& t, int64_t q, float theta) {
   const float ek = sqrtf(__uint_as_float(t.tail8[0]));
   const float e = t.eq8[q];
   const float eps = fmaf(fmaf(e, ek, e + ek), 1.0009765625f, FILTER_EPS_SLACK);
   const float sc = t.qscale[q] * __uint_as_float(t.tail8[1]);
   if (!(sc > 0.f)) return INT_MIN;
-  const float x = __fsub_rn(filter_theta(t, q), eps) / sc;
+  const float x = __fsub_rn(theta, eps) / sc;
   if (!(x > -8.4e6f)) return INT_MIN;   // (also NaN)
   if (x > 8.4e6f) return INT_MAX;       // beyond any |I| <= 127^2 * 256: nothing can pass
   return (int)floorf(x) - 2;
+}
+__device__ __forceinline__ int filter_threshold_i8(const FilterThr& t, int64_t q) {
+  if (t.ablate == 1) return INT_MAX;
+  return filter_threshold_i8_at(t, q, filter_theta(t, q));
 }
 
 // Candidate counters of a call of fewer than 2048 queries.  A returning atomicAdd costs ~11 ns per operation on ONE address

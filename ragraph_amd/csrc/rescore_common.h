@@ -58,8 +58,10 @@ __device__ __forceinline__ void wave_select(const float (&s)[NSL], const int (&i
     }
 #pragma unroll
     for (int v = 0; v < NSL; ++v) {
-#pragma unroll 8
-      for (int o = 0; o < 64; ++o) {
+      // (only up to the slot's last pair: a list of 40 candidates leaves most of its second slot empty)
+      const unsigned long long nz = __ballot(mine[v] != 0ull);
+      const int top = nz ? 64 - __clzll((long long)nz) : 0;
+      for (int o = 0; o < top; ++o) {
         const unsigned long long src = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)khi[v], o) << 32) |
                                        (unsigned)__builtin_amdgcn_readlane((int)klo[v], o);
 #pragma unroll
@@ -221,12 +223,13 @@ __device__ __forceinline__ float coop_scores_few(const float4* __restrict__ qrow
 // Rescoring of one query by one wave with NS candidate slots per lane (n <= 64 * NS reserved slots): exact scores (one
 // lane per candidate, the k = 0..D-1 fmaf chain from +0), merge with the previous level's winners, canonical top-k.
 // COOP: rows staged through the LDS tile `sm` (coop_scores); else every lane reads its own row.
-template <int D, int NS, bool COOP = false, bool FEW = false>
+// CS: ints per list entry (2: the scored lists' {key, I} pairs, of which only the key is read here).
+template <int D, int NS, bool COOP = false, bool FEW = false, int CS = 1>
 __device__ __forceinline__ void rescore_query(const float4* __restrict__ qrow, const float* __restrict__ Kn,
                                               const int* __restrict__ cand, int n, int lane, int k, int64_t base,
                                               const float* prev_s, const int64_t* prev_i, float* out_s, int64_t* out_i,
                                               float* sm = nullptr) {
-  const int first_keys = cand[lane];  // (no dependence on n: the list has >= 64 slots; issued next to the count's load)
+  const int first_keys = cand[lane * CS];  // (no dependence on n: the list has >= 64 slots; issued next to the count's load)
   float s[NS + 1];
   int id[NS + 1];
   // the previous level's winners ride along as already-scored candidates (lane l holds entry l; k <= 32)
@@ -244,7 +247,7 @@ __device__ __forceinline__ void rescore_query(const float4* __restrict__ qrow, c
     id[u] = INT_MAX;
     int key = -1;
     if (u == 0) key = c < n ? first_keys : -1;
-    else if (c < n) key = cand[c];
+    else if (c < n) key = cand[c * CS];
     if constexpr (COOP) {
       if (64 * u < n) {  // wave-uniform
         const float acc = FEW ? coop_scores_few<D>(qrow, Kn, key, lane, sm) : coop_scores<D>(qrow, Kn, key, lane, sm);

@@ -371,10 +371,15 @@ __device__ unsigned long long g_filter_timing[8];
 // p.ngroups consecutive parts of its key range (filter_prepare_kernel turns them into the first lower bound).
 // I8: the level runs on the int8 copy (filter_common.h): the ring geometry of a bf16 bank of D / 2 elements (a key is D
 // bytes), v_mfma_i32_16x16x64_i8, integer thresholds; the queries are quantised from the normalised fp32 rows here.
-template <int D, int QW, bool BOUND = false, bool I8 = false>
+// SCORED (int8 levels of large calls): a list entry is {key, I} -- the integer sum that admitted the key (for a lane with two
+// passing keys of one query: the larger of the two for both, an upper bound) -- in an int2 list of p.cap entries; the
+// rescoring (topk_rescore_scored_kernel) then scores the most promising entries first and never fetches the rows of
+// those whose I cannot reach the exact k-th best found that way.
+template <int D, int QW, bool BOUND = false, bool I8 = false, bool SCORED = false>
 __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
   using C = FilterCfg<I8 ? D / 2 : D>;
   static_assert(!(I8 && BOUND), "the bound pass runs on the bf16 copy");
+  static_assert(I8 || !SCORED, "scored lists carry the int8 levels' integer sums");
   static_assert(QW == 32 || QW == 64 || QW == 96 || QW == 128, "two, four, six or eight query groups of 16 per wave");
   constexpr int QT = C::WAVES * QW;
   constexpr int NG = QW / 16;  // query groups per wave: each A fragment (16 keys x 32 elements) feeds NG MFMAs
@@ -542,7 +547,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
           const uint2 e = wbuf[i];
           const int64_t q = q_wave + (e.x >> 25);
           const int key0 = key_org + (int)(e.x & 0x1FFFFFFu);
-          unsigned mk = e.y;
+          unsigned mk = SCORED ? (e.y & 0xFFu) : e.y;
           int slot = atomicAdd(p.count + q * p.cstride, __popc(mk));
           // retired here on every path: a return hipcc still considers pending where the flush rejoins the stage loop
           // would put its vmcnt(0) -- which also drains the DMA ring -- in front of every sub-tile
@@ -550,7 +555,11 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
           while (mk) {
             const int r = __ffs(mk) - 1;
             mk &= mk - 1;
-            if (slot < p.cap) p.cand[q * p.cap + slot] = key0 + (r & 3) + 16 * (r >> 2);
+            if constexpr (SCORED) {
+              if (slot < p.cap) reinterpret_cast<int2*>(p.cand)[q * p.cap + slot] = make_int2(key0 + (r & 3) + 16 * (r >> 2), (int)e.y >> 8);
+            } else {
+              if (slot < p.cap) p.cand[q * p.cap + slot] = key0 + (r & 3) + 16 * (r >> 2);
+            }
             ++slot;
           }
         }
@@ -613,7 +622,8 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
       };
       // the groups' entries of one sub-tile: ballots first, ONE buffer check per (up to) four groups -- a flush is ~60
       // instructions and every copy of it sits in the stage loop's instruction stream
-      auto push_groups = [&](const unsigned (&km)[NG], unsigned off) {
+      // (SCORED: the lane's largest sum rides in the entry's upper 24 bits -- |I| <= 127^2 * 256 < 2^23)
+      auto push_groups = [&](const unsigned (&km)[NG], const int (&mi)[NG], unsigned off) {
         constexpr int GB = NG < 4 ? NG : (NG % 4 == 0 ? 4 : 3);  // groups per check: at most 64 GB = 256 entries < CAND_BUF
 #pragma unroll
         for (int g0 = 0; g0 < NG; g0 += GB) {
@@ -630,7 +640,9 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
           for (int i = 0; i < GB; ++i) {
             if (bm[i]) {
               const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm[i] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm[i], 0u));
-              if (km[g0 + i]) wbuf[pos] = make_uint2(((unsigned)(j + 16 * (g0 + i)) << 25) | off, km[g0 + i]);
+              if (km[g0 + i])
+                wbuf[pos] = make_uint2(((unsigned)(j + 16 * (g0 + i)) << 25) | off,
+                                       SCORED ? (km[g0 + i] | ((unsigned)mi[g0 + i] << 8)) : km[g0 + i]);
               wcnt += __popcll(bm[i]);
             }
           }
@@ -689,7 +701,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
 #pragma unroll
             for (int gq = 0; gq < NG; ++gq) km[gq] &= vm;
           }
-          push_groups(km, (unsigned)(key_base - key_org));
+          push_groups(km, mi, (unsigned)(key_base - key_org));
         }
       };
       // ---- SUBS sub-tiles of 32 keys x QW queries, KSTEPS fragments each (k-step major: both 16-key halves of a step);
@@ -888,6 +900,226 @@ __global__ void __launch_bounds__(128) topk_rescore_coop_kernel(const float* __r
   else if (n <= 512) RG_RESCORE(8, false);  // long lists are rare: the plain form keeps the kernel out of scratch
   else RG_RESCORE(CPL, false);
 #undef RG_RESCORE
+}
+
+// SCORED lists (the int8 levels of large calls: entries {key, I}, topk_filter_kernel<..., SCORED>): one wave per query, in
+// two rounds.  Round 1 scores the SCORED_R1 entries with the largest I exactly; the k-th best of those and the previous
+// level's winners is a lower bound theta_e of the query's final k-th best score -- k distinct keys reach it -- and a key
+// can only enter the top-k if its exact score s >= theta_e, so its I >= (theta_e - eps) / (s_q s_k) (the level's own bound,
+// filter_threshold_i8_at; a lane's shared I is an upper bound, which only keeps an entry in).  Round 2 scores the entries
+// that pass THAT threshold; the rest are never fetched.  The int8 bound admits ~3x the candidates of the bf16 one
+// because its eps is ~5x wider -- but theta_e sits ~0.3 sigma above the threshold the level ran with (that came from a
+// quarter of the keys), and two thirds of the admitted keys fall below it: ~120 -> ~35 row gathers per query on the
+// bench's last level.  Which entries round 1 takes changes the work, never the result: every entry that could belong
+// to the top-k is scored with the same fmaf chain, and the selection is the canonical one.
+constexpr int SCORED_R1 = 16;
+// The selections here are by COUNTING over the few pairs in play (a pair's rank = the number of better pairs, each
+// broadcast once with v_readlane), not wave_select's rounds over every slot: the kernel runs one wave per query and
+// ~3000 VALU instructions of selection per query were as long as its row gathers.
+__device__ __forceinline__ bool pair_gt(unsigned ah, unsigned al, unsigned bh, unsigned bl) {
+  return ah > bh || (ah == bh && al > bl);
+}
+// Returns false (nothing written) when more than 64 round-2 entries beat round 1's k-th pair: the caller then scores
+// the whole list the plain way (a level whose first bound was useless; rare).
+template <int D, int NS>
+__device__ __forceinline__ bool rescore_scored_query(const float4* __restrict__ qrow, const float* __restrict__ Kn,
+                                                     const int2* __restrict__ cb, int n, int lane, int k, int64_t base,
+                                                     const float* prev_s, const int64_t* prev_i, float* out_s, int64_t* out_i,
+                                                     float* sm, int* surv, int* stage, const FilterThr& thr, int64_t b) {
+  int key[NS], iv[NS];
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    const int c = lane + 64 * u;
+    int2 e = make_int2(-1, INT_MIN);
+    if (c < n) e = cb[c];
+    key[u] = e.x;
+    iv[u] = e.y;
+  }
+  // round 1: every lane's best entry; the SCORED_R1 lanes with the largest of those (ties: lower lane) -- n > 24, so the
+  // first 25 lanes hold an entry each and round 1 is full
+  int bi = iv[0], bkey = key[0];
+#pragma unroll
+  for (int u = 1; u < NS; ++u) {
+    const bool t = iv[u] > bi;
+    bi = t ? iv[u] : bi;
+    bkey = t ? key[u] : bkey;
+  }
+  const int nl = n < 64 ? n : 64;
+  int rank = 0;
+  for (int o = 0; o < nl; ++o) {
+    const int io = __builtin_amdgcn_readlane(bi, o);
+    rank += (io > bi || (io == bi && o < lane)) ? 1 : 0;
+  }
+  const bool lane_r1 = lane < nl && rank < SCORED_R1;
+  if (lane_r1) stage[rank] = bkey;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int r1key = lane < SCORED_R1 ? stage[lane] : -1;
+  __builtin_amdgcn_wave_barrier();
+  const float e1 = coop_scores_few<D>(qrow, Kn, r1key, lane, sm);
+  // W: round 1 (lanes 0..15) and the previous winners (lanes 16..16+k-1) as canonical 64-bit keys (0 = no pair)
+  unsigned wh = 0u, wl = 0u;
+  if (lane < SCORED_R1) {
+    wh = select_ord(e1);
+    wl = ~(unsigned)r1key;
+  } else if (prev_s && lane < SCORED_R1 + k) {
+    const int64_t pv = prev_i[lane - SCORED_R1];
+    if (pv < INT_MAX) {
+      wh = select_ord(prev_s[lane - SCORED_R1]);
+      wl = ~(unsigned)(int)pv;
+    }
+  }
+  const int nwl = prev_s ? SCORED_R1 + k : SCORED_R1;
+  const bool w_valid = (wh | wl) != 0u;
+  const int n_w = __popcll(__ballot(w_valid));
+  int rank_w = 0;
+  for (int o = 0; o < nwl; ++o) {
+    const unsigned oh = (unsigned)__builtin_amdgcn_readlane((int)wh, o), ol = (unsigned)__builtin_amdgcn_readlane((int)wl, o);
+    rank_w += pair_gt(oh, ol, wh, wl) ? 1 : 0;
+  }
+  // theta_e = the k-th best of W, a lower bound of the final k-th best (-inf: fewer than k pairs, everything is scored)
+  unsigned kh = 0u, kl = 0u;
+  if (n_w >= k) {
+    const unsigned long long at = __ballot(w_valid && rank_w == k - 1);
+    const int src = __ffsll((long long)at) - 1;
+    kh = (unsigned)__builtin_amdgcn_readlane((int)wh, src);
+    kl = (unsigned)__builtin_amdgcn_readlane((int)wl, src);
+  }
+  const float theta_e = n_w >= k ? select_unord(kh) : RG_NEG_INF;
+  const int t_e = filter_threshold_i8_at(thr, b, theta_e);
+  // round 2: the entries outside round 1 whose I reaches t_e, compacted
+  int ns = 0;
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    const bool in_r1 = lane_r1 && key[u] == bkey;
+    const bool keep = key[u] >= 0 && !in_r1 && iv[u] >= t_e;
+    const unsigned long long bm = __ballot(keep);
+    const int pos = ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
+    if (keep) surv[pos] = key[u];
+    ns += __popcll(bm);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // scored in batches of 64; those that beat W's k-th pair (a handful) are kept, one per lane of the "beaters" row
+  unsigned bh = 0u, bl = 0u;  // lane p: beater p
+  int nb = 0;
+  for (int c0 = 0; c0 < ns; c0 += 64) {
+    const int c = c0 + lane;
+    const int kk = c < ns ? surv[c] : -1;
+    const float acc = ns - c0 <= 16 ? coop_scores_few<D>(qrow, Kn, kk, lane, sm) : coop_scores<D>(qrow, Kn, kk, lane, sm);
+    const unsigned sh = select_ord(acc), sl = ~(unsigned)kk;
+    const bool beats = kk >= 0 && pair_gt(sh, sl, kh, kl);
+    const unsigned long long bm = __ballot(beats);
+    const int cnt = __popcll(bm);
+    if (nb + cnt > 64) return false;  // (wave-uniform)
+    const int pos = nb + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
+    if (beats) {
+      stage[pos] = (int)sh;
+      stage[64 + pos] = (int)sl;
+    }
+    nb += cnt;
+  }
+  if (nb > 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < nb) {
+      bh = (unsigned)stage[lane];
+      bl = (unsigned)stage[64 + lane];
+    }
+  }
+  // final ranks: a pair of W gains the beaters better than it; a beater counts the better pairs of both rows
+  int rank_b = 0;
+  for (int o = 0; o < nb; ++o) {
+    const unsigned oh = (unsigned)__builtin_amdgcn_readlane((int)bh, o), ol = (unsigned)__builtin_amdgcn_readlane((int)bl, o);
+    rank_w += pair_gt(oh, ol, wh, wl) ? 1 : 0;
+    rank_b += pair_gt(oh, ol, bh, bl) ? 1 : 0;
+  }
+  if (nb > 0)
+    for (int o = 0; o < nwl; ++o) {
+      const unsigned oh = (unsigned)__builtin_amdgcn_readlane((int)wh, o), ol = (unsigned)__builtin_amdgcn_readlane((int)wl, o);
+      rank_b += pair_gt(oh, ol, bh, bl) ? 1 : 0;
+    }
+  if (w_valid && rank_w < k) {
+    out_s[rank_w] = select_unord(wh);
+    out_i[rank_w] = (int64_t)(int)~wl + base;
+  }
+  if (lane < nb && rank_b < k) {
+    out_s[rank_b] = select_unord(bh);
+    out_i[rank_b] = (int64_t)(int)~bl + base;
+  }
+  if (lane < k && lane >= n_w + nb) {
+    out_s[lane] = RG_NEG_INF;
+    out_i[lane] = INT64_MAX;
+  }
+  return true;
+}
+
+template <int D>
+__global__ void __launch_bounds__(128) topk_rescore_scored_kernel(const float* __restrict__ Qn, const float* __restrict__ Kn,
+                                                                  int* __restrict__ count, const int2* __restrict__ cand,
+                                                                  int64_t B, int cap, int cs, int k, int64_t idx_base,
+                                                                  const float* prev_s, const int64_t* prev_i, int final_level,
+                                                                  float* out_s, int64_t* out_i, int* __restrict__ overflow,
+                                                                  int* __restrict__ overflow_list,
+                                                                  unsigned char* __restrict__ flag, int64_t scan_n, FilterThr thr) {
+  __shared__ float4 qs[2][D / 4];
+  __shared__ __attribute__((aligned(16))) float tile[2][64 * RESCORE_LD];
+  __shared__ int surv[2][256];
+  __shared__ int stage[2][128];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 2 + w;
+  if (b >= B) return;  // whole wave
+  int n = count[b * cs];
+  bool over = flag[b] != 0;
+  float4 qv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (lane < D / 4) qv4 = reinterpret_cast<const float4*>(Qn + b * D)[lane];
+  if (lane < D / 4) qs[w][lane] = qv4;
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0 && n >= 0) count[b * cs] = 0;
+  if (n > cap) {
+    over = true;
+    n = cap;
+  }
+  if (final_level && over && scan_n > 0) {
+    if (lane == 0) atomicAdd(overflow, 1);
+    exact_scan_wave<D>(qs[w], Kn, scan_n, k, idx_base, lane, out_s + b * k, out_i + b * k);
+    return;
+  }
+  if (lane == 0) {
+    if (final_level) {
+      if (over) {
+        const int pos = atomicAdd(overflow, 1);
+        overflow_list[pos] = (int)b;
+      }
+    } else if (over) {
+      flag[b] = 1;
+    }
+  }
+  const int64_t base = final_level ? idx_base : 0;
+  const float* ps = prev_s ? prev_s + b * k : nullptr;
+  const int64_t* pi = prev_i ? prev_i + b * k : nullptr;
+  const int2* cb = cand + b * cap;
+  const int* ck = reinterpret_cast<const int*>(cb);
+#define RG_PLAIN(NS_, COOP_, FEW_) \
+  rescore_query<D, NS_, COOP_, FEW_, 2>(qs[w], Kn, ck, n, lane, k, base, ps, pi, out_s + b * k, out_i + b * k, tile[w])
+#define RG_SCORED(NS_) \
+  rescore_scored_query<D, NS_>(qs[w], Kn, cb, n, lane, k, base, ps, pi, out_s + b * k, out_i + b * k, tile[w], surv[w], stage[w], \
+                               thr, b)
+  if (n <= 16) RG_PLAIN(1, true, true);
+  else if (n <= 24) RG_PLAIN(1, true, false);   // (round 1 alone would take most of such a list)
+  else if (n <= 64) {
+    if (!RG_SCORED(1)) RG_PLAIN(1, true, false);
+  } else if (n <= 128) {
+    if (!RG_SCORED(2)) RG_PLAIN(2, true, false);
+  } else if (n <= 256) {
+    if (!RG_SCORED(4)) RG_PLAIN(4, true, false);
+  } else if (n <= 512) RG_PLAIN(8, false, false);  // long lists are rare: every entry, lane-private row reads
+  else RG_PLAIN(16, false, false);
+#undef RG_PLAIN
+#undef RG_SCORED
 }
 
 // The exact fallback for a query whose candidate list overflowed (thousands of keys within eps of the k-th best:
@@ -1152,6 +1384,17 @@ static bool rescore_coop() {  // RAGRAPH_RESCORE_COOP=0: every lane reads its ow
     return !(e && atoi(e) == 0);
   }();
   return on;
+}
+
+// Scored candidate lists for the int8 levels (topk_rescore_scored_kernel): calls whose rescoring is bound by the row
+// gathers, i.e. the ones that take the one-wave-per-query kernels.  RAGRAPH_FILTER_SCORED=0/1: A/B.
+static bool filter_scored_lists(int64_t B) {
+  static const int env = [] {
+    const char* e = getenv("RAGRAPH_FILTER_SCORED");
+    return e ? atoi(e) : -1;
+  }();
+  if (B < 2048 || !rescore_coop()) return false;  // (below: the wide kernels, a latency chain that two rounds would lengthen)
+  return env != 0;
 }
 
 static bool filter_wide_waves(int64_t B) {  // RAGRAPH_FILTER_QW128=0/1: A/B; default from 1024 queries (one full tile)
@@ -1654,7 +1897,7 @@ static int rescore_slices(int64_t B, int k) {
 }
 
 // Ring-kernel launch shared by the filter levels and the bound pass (B > 256: the direct kernel takes smaller batches).
-template <int D, int QW, bool BOUND, bool I8 = false>
+template <int D, int QW, bool BOUND, bool I8 = false, bool SCORED = false>
 static int launch_ring(FilterParams p, int64_t B, int prof_slot, hipStream_t st) {
   using C = FilterCfg<I8 ? D / 2 : D>;
   p.qtiles = cdiv(B, (int64_t)C::WAVES * QW);
@@ -1676,12 +1919,12 @@ static int launch_ring(FilterParams p, int64_t B, int prof_slot, hipStream_t st)
     p.depth[v] = SegmentWalker::choose_depth(nq, p.nstages_total, p.wgs_per_group, p.lb_min, 0).depth;
   }
   static DeviceOnce lds_once;  // per template instance and device (common.h)
-  if (hipError_t e = raise_dynamic_lds(lds_once, &topk_filter_kernel<D, QW, BOUND, I8>, (int)C::LDS_BYTES); e != hipSuccess) {
+  if (hipError_t e = raise_dynamic_lds(lds_once, &topk_filter_kernel<D, QW, BOUND, I8, SCORED>, (int)C::LDS_BYTES); e != hipSuccess) {
     set_error("topk_cosine_filtered: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
     return RAGRAPH_EDEVICE;
   }
   if (g_prof_on) (void)hipEventRecord(g_prof_ev[2 * prof_slot], st);
-  hipLaunchKernelGGL((topk_filter_kernel<D, QW, BOUND, I8>), dim3((unsigned)CUS), dim3(C::THREADS), C::LDS_BYTES, st, p);
+  hipLaunchKernelGGL((topk_filter_kernel<D, QW, BOUND, I8, SCORED>), dim3((unsigned)CUS), dim3(C::THREADS), C::LDS_BYTES, st, p);
   if (g_prof_on) (void)hipEventRecord(g_prof_ev[2 * prof_slot + 1], st);
   RG_CHECK_LAUNCH("topk_cosine_filtered(filter)");
 #ifdef RG_TOPK_TIMING
@@ -1707,7 +1950,8 @@ static int launch_ring(FilterParams p, int64_t B, int prof_slot, hipStream_t st)
 // kernel with two -- at D = 64 and long streams four -- query groups per wave.
 template <int D>
 static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64_t key0, int64_t key1, const FilterThr& thr,
-                         int cap, int bound_groups, int prof_slot, hipStream_t st, const signed char* Kb8 = nullptr) {
+                         int cap, int bound_groups, int prof_slot, hipStream_t st, const signed char* Kb8 = nullptr,
+                         bool scored = false) {
   using C = FilterCfg<D>;
   {
     if (Kb8 && B > 256) {  // an int8 level (filter_i8_levels): the ring kernel over the int8 copy, stages of twice as many keys
@@ -1722,7 +1966,7 @@ static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64
       p.cand = f.cand;
       p.B = B;
       p.N = key1;
-      p.cap = cap;
+      p.cap = scored ? cap / 2 : cap;  // (scored lists: {key, I} pairs in the same buffer)
       p.stage_base = key0 / C8::STAGE_KEYS;  // key0 is a multiple of 256
       p.nstages_total = cdiv(key1 - key0, C8::STAGE_KEYS);
       // int8 operands are 16 bytes per 64 elements: SIX query groups per wave (tile = 768 queries) fit the registers four
@@ -1739,10 +1983,15 @@ static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64
       // (D = 64: eight groups are 32 registers of operands -- no spill -- and 65 536 x 4M x 64 runs 15.5 ms against 16.3 with
       // six and 17.0 with four)
       const int qw = qw_env ? qw_env : (D == 64 && fits(1024) ? 128 : (fits(768) ? 96 : 64));
-      if (qw == 128 && cdiv(B, (int64_t)1024) * p.nstages_total >= 32 * (int64_t)filter_device_cus())
-        return launch_ring<D, 128, false, true>(p, B, prof_slot, st);
-      if (qw == 96 && cdiv(B, (int64_t)768) * p.nstages_total >= 32 * (int64_t)filter_device_cus())
-        return launch_ring<D, 96, false, true>(p, B, prof_slot, st);
+      const bool long128 = qw == 128 && cdiv(B, (int64_t)1024) * p.nstages_total >= 32 * (int64_t)filter_device_cus();
+      const bool long96 = qw == 96 && cdiv(B, (int64_t)768) * p.nstages_total >= 32 * (int64_t)filter_device_cus();
+      if (scored) {
+        if (long128) return launch_ring<D, 128, false, true, true>(p, B, prof_slot, st);
+        if (long96) return launch_ring<D, 96, false, true, true>(p, B, prof_slot, st);
+        return launch_ring<D, 64, false, true, true>(p, B, prof_slot, st);
+      }
+      if (long128) return launch_ring<D, 128, false, true>(p, B, prof_slot, st);
+      if (long96) return launch_ring<D, 96, false, true>(p, B, prof_slot, st);
       return launch_ring<D, 64, false, true>(p, B, prof_slot, st);
     }
   }
@@ -1796,7 +2045,7 @@ static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64
 template <int D>
 static int run_rescore(const FilterWs& f, const float* Kn, int64_t N, int64_t B, int cap, int k, int64_t idx_base, int merge,
                        int final_level, float* out_scores, int64_t* out_idx, int* overflow, int* fallback_done, bool few,
-                       hipStream_t st) {
+                       hipStream_t st, const FilterThr* scored_thr = nullptr) {
   const float* ps = merge ? out_scores : nullptr;
   const int64_t* pi = merge ? out_idx : nullptr;
   static const int64_t wide_max_b = [] {  // RAGRAPH_RESCORE_WIDE_BELOW: A/B of the crossover
@@ -1813,7 +2062,12 @@ static int run_rescore(const FilterWs& f, const float* Kn, int64_t N, int64_t B,
   // mid-sized calls: an overflowed query is scanned by its own rescoring wave (no fallback launch); large batches keep
   // the dedicated launch, whose four-wave workgroups scan a bank faster when MANY queries overflow
   const int64_t scan_n = B <= FILTER_SLAB_MAX_B ? N : 0;
-  if (B < wide_max_b && S > 1) {
+  if (scored_thr) {  // (filter_scored_lists: a large call's int8 level)
+    *fallback_done = scan_n > 0;
+    hipLaunchKernelGGL((topk_rescore_scored_kernel<D>), dim3((unsigned)cdiv(B, 2)), dim3(128), 0, st, f.Qn, Kn, f.count,
+                       reinterpret_cast<const int2*>(f.cand), B, cap / 2, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx,
+                       overflow, f.overflow_list, f.flag, scan_n, *scored_thr);
+  } else if (B < wide_max_b && S > 1) {
     hipLaunchKernelGGL((topk_rescore_wide_kernel<D, true, true>), dim3((unsigned)B, (unsigned)S), dim3(256), 0, st, f.Qn, Kn, f.count,
                        f.cand, B, N, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list,
                        f.flag, f.part_s, f.part_i);
@@ -1951,7 +2205,9 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
     thr.gmax = (l == 0 && bound && !exchange && parts == k) ? f.gmax : nullptr;  // (k parts: the minimum, inline)
     if (!exchange) thr.theta = (l == 0 && bound && parts > k) ? f.theta : nullptr;
     thr.prev_scores = out_scores;
-    rc = run_bf16_pass<D>(f, Kb, B, key0, sc.ends[l], thr, cap, 0, l, st, l >= sc.nlev - sc.i8_levels ? Kb8 : nullptr);
+    const bool i8_level = l >= sc.nlev - sc.i8_levels;
+    const bool scored = i8_level && !exchange && filter_scored_lists(B);
+    rc = run_bf16_pass<D>(f, Kb, B, key0, sc.ends[l], thr, cap, 0, l, st, i8_level ? Kb8 : nullptr, scored);
     if (g_prof_on) {
       g_prof_i8[l] = l >= sc.nlev - sc.i8_levels;
       g_prof_keys[l] = sc.ends[l] - key0;
@@ -1959,7 +2215,7 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
     if (rc != RAGRAPH_OK) return rc;
     if (g_prof_on) g_prof_have = l + 1;
     rc = run_rescore<D>(f, Kn, N, B, cap, k, idx_base, l > 0, l == sc.nlev - 1, out_scores, out_idx, overflow,
-                        &fallback_done, exchange != nullptr && l > 0, st);
+                        &fallback_done, exchange != nullptr && l > 0, st, scored ? &thr : nullptr);
     if (rc != RAGRAPH_OK) return rc;
     key0 = sc.ends[l];
     if (exchange && l + 1 < sc.nlev) {  // this shard's k-th exact score so far sharpens theta; then the other shards'
