@@ -1388,13 +1388,18 @@ static bool rescore_coop() {  // RAGRAPH_RESCORE_COOP=0: every lane reads its ow
 
 // Scored candidate lists for the int8 levels (topk_rescore_scored_kernel): calls whose rescoring is bound by the row
 // gathers, i.e. the ones that take the one-wave-per-query kernels.  RAGRAPH_FILTER_SCORED=0/1: A/B.
-static bool filter_scored_lists(int64_t B) {
+// D = 256 only: measured with / without (ms per call, profiles/r3_scored_ab.txt) 2048 x 1M x 256: 0.874 / 0.836, 16384:
+// 4.50 / 4.21, 100 000: 24.4 / 22.8; but 50 000 x 2M x 128: 12.71 / 12.63 and 65 536 x 4M x 64: 15.73 / 15.93 -- shorter rows
+// are cheaper to fetch and their scores spread wider against the same eps (fewer extra candidates to prune), so the
+// second round only adds latency.
+static bool filter_scored_lists(int64_t B, int D) {
   static const int env = [] {
     const char* e = getenv("RAGRAPH_FILTER_SCORED");
     return e ? atoi(e) : -1;
   }();
   if (B < 2048 || !rescore_coop()) return false;  // (below: the wide kernels, a latency chain that two rounds would lengthen)
-  return env != 0;
+  if (env >= 0) return env != 0;
+  return D == 256;
 }
 
 static bool filter_wide_waves(int64_t B) {  // RAGRAPH_FILTER_QW128=0/1: A/B; default from 1024 queries (one full tile)
@@ -1538,6 +1543,13 @@ static int rescore_slices(int64_t B, int k);
 static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_shards = 1) {
   FilterSchedule sc{};
   const int cap = 2048;
+  // scored lists (one bank, >= 2048 queries): an int8 level's rescoring fetches about a third of its candidates' rows, which
+  // makes int8 pay on EVERY level (the bench step, 2 / 3 int8 levels: 24.3 / 23.85 ms; without the scores 26.9 / 27.7)
+  const bool scored = n_shards == 1 && filter_scored_lists(B, D);
+  // (the model's price of an int8 candidate under scored lists, relative to the plain lists'; fitted: 0.6 moves 8192+ queries
+  // x 1M keys from two levels to three, all int8 -- 8192: 2.37 -> 2.33 ms, 16384: 4.30 -> 4.13 -- while 0.45 also shrank the
+  // first sample of 2048 - 8192 queries, which measured 2 - 4 % slower; RAGRAPH_FILTER_SCORED_CAND: A/B)
+  static const double scored_cand = [] { const char* e = getenv("RAGRAPH_FILTER_SCORED_CAND"); return e ? atof(e) : 0.6; }();
   const bool bound = N >= 8192 && filter_bound_pass_enabled();
   // int8 levels (filter_common.h): D = 128 / 256, the ring kernel's batch sizes, banks long enough to be matrix-bound (an
   // int8 level quantises its queries from the fp32 rows per segment where the bf16 levels of up to 16384 queries load a
@@ -1605,7 +1617,7 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
     // the k keys behind the bound must lie inside the first level (it has to find at least k candidates)
     if (sc.bound_keys > sc.ends[0]) sc.bound_keys = sc.ends[0] / FILTER_PAD_KEYS * FILTER_PAD_KEYS;
     if (sc.bound_keys / (FILTER_STAGE_BYTES / (2 * D)) < k) sc.bound_keys = 0;  // every part needs a stage of its own
-    sc.i8_levels = i8_ok && B >= 1024 ? 2 : 0;  // (banks below 4 x 4096 keys come here with any batch)
+    sc.i8_levels = i8_ok && B >= 1024 ? (scored ? 3 : 2) : 0;  // (banks below 4 x 4096 keys come here with any batch)
     return sc;
   }
   double best = 1e30;
@@ -1668,7 +1680,7 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
       // (a candidate costs ~0.4 ns while a level's rescoring is a latency chain -- up to ~1000 queries -- and ~0.18 ns once it
       // is bound by the row gathers: 100 000 queries x ~130 candidates x 1 KiB in 1.8 ms)
       const double per_cand = 0.18e-3 + 0.22e-3 * (B <= 1024 ? 1.0 : 1024.0 / (double)B);
-      for (int i8 = 0; i8 <= (i8_ok ? (L < 2 ? L : 2) : 0); ++i8) {
+      for (int i8 = 0; i8 <= (i8_ok ? (L < 2 || scored ? L : 2) : 0); ++i8) {
         double cost = first, e_prev = 0.0, e = (double)n0;
         bool fits = true;
         for (int l = 0; l < L; ++l) {
@@ -1676,7 +1688,8 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
           const bool q8 = l >= L - i8;
           const double cands = 1.3 * k * r * (q8 ? 3.0 : 1.0);
           if (cands > cap / 2 && !(force_n0 > 0 && force_L > 0)) fits = false;
-          cost += 60.0 + (e - e_prev) * (double)B * 2.0 * D / (q8 ? 2.4e9 : 1.25e9) + (double)B * cands * per_cand;
+          cost += 60.0 + (e - e_prev) * (double)B * 2.0 * D / (q8 ? 2.4e9 : 1.25e9) +
+                  (double)B * cands * per_cand * (q8 && scored ? scored_cand : 1.0);
           e_prev = e;
         }
         if (fits && cost < best) {
@@ -2206,7 +2219,7 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
     if (!exchange) thr.theta = (l == 0 && bound && parts > k) ? f.theta : nullptr;
     thr.prev_scores = out_scores;
     const bool i8_level = l >= sc.nlev - sc.i8_levels;
-    const bool scored = i8_level && !exchange && filter_scored_lists(B);
+    const bool scored = i8_level && !exchange && filter_scored_lists(B, D);
     rc = run_bf16_pass<D>(f, Kb, B, key0, sc.ends[l], thr, cap, 0, l, st, i8_level ? Kb8 : nullptr, scored);
     if (g_prof_on) {
       g_prof_i8[l] = l >= sc.nlev - sc.i8_levels;

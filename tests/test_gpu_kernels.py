@@ -744,6 +744,49 @@ def test_topk_cosine_filtered_int8_levels_bit_exact(dev, monkeypatch, D, B, N, k
         assert torch.equal(i, i32) and torch.equal(s, s32)
 
 
+@pytest.mark.parametrize("D,B,N,k", [(256, 2500, 70000, 10), (128, 2100, 66000, 32), (64, 2048, 70000, 1),
+                                     (256, 4100, 131072, 5)])
+def test_topk_cosine_filtered_scored_lists_bit_exact(dev, monkeypatch, D, B, N, k):
+    """Scored candidate lists (int8 levels of >= 2048 queries; the product rule takes them at D = 256, forced here at every
+    width): entries {key, I}, rescoring in two rounds -- the 16 largest I first, then only the entries whose I can still
+    reach the k-th best found.  Whatever round 1 picks the result is the oracle's: clusters of near-duplicates of 60 / 160 /
+    400 keys put a query's list in every branch (most of round 2 beating round 1's k-th pair; more than 64 doing so: the
+    plain path; lists beyond 256 entries), exact duplicates tie on I and on the score, a zero query overflows.  With and
+    without the scores: the same bits."""
+    from ragraph_amd import kernels as K
+
+    monkeypatch.setenv("RAGRAPH_FILTER_I8", "3")
+    rng = _rng(3 * D + B + N + k)
+    kn = _bank(rng, N, D)
+    centres = rng.standard_normal((3, D), dtype=np.float32)
+    at = [N // 3, N // 2 + 1000, N - 5000]
+    for c, (lo, n) in enumerate(zip(at, (60, 160, 400))):
+        kn[lo:lo + n] = cref.normalize_rows(centres[c] + 2e-3 * rng.standard_normal((n, D), dtype=np.float32))
+    kn[N // 2:N // 2 + 40] = kn[:40]
+    q = rng.standard_normal((B, D), dtype=np.float32)
+    for c in range(3):
+        q[10 + 4 * c] = centres[c]
+        q[11 + 4 * c] = centres[c] + 1e-3 * rng.standard_normal(D, dtype=np.float32)
+        q[12 + 4 * c] = 3.0 * kn[at[c] + 7]
+    q[3] = 2.5 * kn[11]
+    q[B - 1] = 0.0
+    knd, qd = _t(kn, dev), _t(q, dev)
+    kb = K.keys_to_bf16(knd)
+    outs = {}
+    for scored in ("1", "0"):
+        monkeypatch.setenv("RAGRAPH_FILTER_SCORED", scored)
+        s, i, over = K.topk_cosine_filtered(qd, knd, kb, k, idx_base=9)
+        assert int(over) >= 1                                   # the zero query
+        outs[scored] = (s, i)
+    assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])
+    rows = np.unique(np.concatenate([np.arange(24), [B - 1], rng.integers(0, B, 400)]))
+    rs, ri = cref.topk_cosine(q[rows], kn, k, idx_base=9)
+    assert np.array_equal(outs["1"][1].cpu().numpy()[rows], ri)
+    assert np.array_equal(outs["1"][0].cpu().numpy()[rows], rs)
+    s32, i32 = K.topk_cosine(qd, knd, k, idx_base=9)            # every row against the fp32 kernel
+    assert torch.equal(outs["1"][1], i32) and torch.equal(outs["1"][0], s32)
+
+
 def test_int8_copy_scale_and_error_bound(dev):
     """The int8 copy's tail row: the bank's scale = max |k_i| / 127 and max_k |dk|^2 of the dequantised rows, against numpy;
     heavy-tailed rows (one large entry) widen the scale for the whole bank -- the bound follows, the result stays exact."""
