@@ -574,7 +574,8 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     for (int gq = 0; gq < NG; ++gq) asm volatile("" : "+v"(thr[gq]), "+v"(thr8[gq]));
     int thr_i[NG];
 #pragma unroll
-    for (int gq = 0; gq < NG; ++gq) thr_i[gq] = I8 ? thr8[gq] : (thr[gq] >= 0.f ? __float_as_int(thr[gq]) : INT_MIN);
+    for (int gq = 0; gq < NG; ++gq)  // (int8: INT_MIN / INT_MAX -- everything / nothing passes -- clamped beyond any |I| < 2^23)
+      thr_i[gq] = I8 ? max(-(1 << 24), min(1 << 24, thr8[gq])) : (thr[gq] >= 0.f ? __float_as_int(thr[gq]) : INT_MIN);
 
     // ---- ring prologue ------------------------------------------------------------------------------------------
     const int pro = nstages < C::SLOTS - 1 ? nstages : C::SLOTS - 1;
@@ -609,13 +610,22 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
       using acc_t = typename std::conditional<I8, i32x4, f32x4>::type;
       auto pass_mask = [&](const acc_t (&a)[2][NG], int gq) {  // float scores against thr, integer sums against thr_i
         unsigned mk = 0;
+        if constexpr (I8) {
+          // bit = the sign of (thr - 1) - I, in unsigned arithmetic (|I| < 2^23 and thr_i is clamped to +-2^24: no wrap):
+          // subtract, shift, shift-or -- three plain VALU instructions per score where compare + select through VCC costs
+          // the same plus a wait state each, on a path that half of the last level's sub-tiles take
+          const unsigned tm1 = (unsigned)(thr_i[gq] - 1);
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mk |= ((tm1 - (unsigned)a[h][gq][r]) >> 31) << (4 * h + r);
+          return mk;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            bool ok;
-            if constexpr (I8) ok = a[h][gq][r] >= thr_i[gq];
-            else ok = a[h][gq][r] >= thr[gq];
+            const bool ok = a[h][gq][r] >= thr[gq];
             mk |= ok ? (1u << (4 * h + r)) : 0u;
           }
         return mk;
