@@ -541,6 +541,12 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     int wcnt = 0;  // wave-uniform
     int key_org = (int)((p.stage_base + st0) * C::STAGE_KEYS);
     auto flush = [&]() {
+#ifdef RG_FLUSH_ABLATE
+      if (p.thr.ablate == 2) {  // (timing experiment: the candidate path without its flushes)
+        wcnt = 0;
+        return;
+      }
+#endif
       for (int i0 = 0; i0 < wcnt; i0 += 64) {
         const int i = i0 + lane;
         if (i < wcnt) {
@@ -611,14 +617,13 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
       auto pass_mask = [&](const acc_t (&a)[2][NG], int gq) {  // float scores against thr, integer sums against thr_i
         unsigned mk = 0;
         if constexpr (I8) {
-          // bit = the sign of (thr - 1) - I, in unsigned arithmetic (|I| < 2^23 and thr_i is clamped to +-2^24: no wrap):
-          // subtract, shift, shift-or -- three plain VALU instructions per score where compare + select through VCC costs
-          // the same plus a wait state each, on a path that half of the last level's sub-tiles take
+          // bit = the sign of (thr - 1) - I, in unsigned arithmetic (|I| < 2^23 and thr_i is clamped to +-2^24: no wrap),
+          // shifted into the mask by v_alignbit ({mask, e} >> 31 = mask << 1 | sign(e)): two plain VALU instructions per
+          // score where compare + select + or through VCC is three plus a wait state, on a path that half of the last
+          // level's sub-tiles take (and every sub-tile of the first)
           const unsigned tm1 = (unsigned)(thr_i[gq] - 1);
 #pragma unroll
-          for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mk |= ((tm1 - (unsigned)a[h][gq][r]) >> 31) << (4 * h + r);
+          for (int b = 7; b >= 0; --b) mk = __builtin_amdgcn_alignbit(mk, tm1 - (unsigned)a[b >> 2][gq][b & 3], 31);
           return mk;
         }
 #pragma unroll

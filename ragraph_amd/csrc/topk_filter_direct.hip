@@ -210,11 +210,11 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
       for (int r = 0; r < 4; ++r) m = max(m, a[1][r]);
       const int th = __float_as_int(thr_lds[16 * gq + j]);
       if (__any(m >= th)) {
+        // (the pass bits by subtract + v_alignbit, as the ring kernel's pass_mask: th clamped beyond any |I| < 2^23)
         unsigned mk = 0;
+        const unsigned tm1 = (unsigned)(max(-(1 << 24), min(1 << 24, th)) - 1);
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) mk |= (a[h][r] >= th) ? (1u << (4 * h + r)) : 0u;
+        for (int b = 7; b >= 0; --b) mk = __builtin_amdgcn_alignbit(mk, tm1 - (unsigned)a[b >> 2][b & 3], 31);
         const int64_t key_base = (unit * C::SUBS + sub) * 32 + 4 * g;
         if (key_base + 32 > p.key_end) {
           unsigned vm = 0;
