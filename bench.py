@@ -482,7 +482,7 @@ def main():
             "whole_call": {"filter_ms": round(kernel_ms, 3), "algorithmic_TFLOPs": round(whole, 1),
                            "vs_bf16_peak": round(whole / BF16_MFMA_PEAK_TFLOPS, 4),
                            "what": "2*B*N*D of the whole score matrix / the summed duration of the call's filter launches "
-                                   "(bound pass + bf16 level + int8 levels)"},
+                                   "(bound pass + the levels)"},
             "note": "achieved = 2*B*keys*D operations of the launch that takes longest (for the int8 levels: integer "
                     "multiply-adds counted as 2, against the int8 dense peak = twice the bf16 one) / its mean duration from "
                     "events recorded around it inside the library on the launch stream.  The whole exact retrieval call "

@@ -61,7 +61,7 @@ out = {
 def find(kind):
     """The filter kernel's PMC name for a kind of launch, whatever its queries-per-wave template argument."""
     for nm in fe:
-        m = re.match(r"ragraph::topk_filter_kernel<256, (\d+), (true|false), (true|false)>", nm)
+        m = re.match(r"ragraph::topk_filter_kernel<256, (\d+), (true|false), (true|false)(?:, (?:true|false))?>", nm)
         if m and (m.group(2), m.group(3)) == {"int8": ("false", "true"), "bf16": ("false", "false"), "bound": ("true", "false")}[kind]:
             return nm
     return None
@@ -91,7 +91,9 @@ if dom:
 for B in SMALL:
     f1 = pmc(os.path.join(src, f"smallb_B{B}_pmc.txt"))
     for nm, d in f1.items():
-        if "topk_filter" in nm and "FETCH_SIZE" in d and "true>" not in nm.split("(")[0][-12:]:
+        targs = [t.strip() for t in nm.split("(")[0].split("<", 1)[-1].rstrip(">").split(",")]
+        is_bound = len(targs) >= 3 and targs[2] == "true"   # ring <D, QW, BOUND, ...>, direct <D, QREG, BOUND, ...>
+        if "topk_filter" in nm and "FETCH_SIZE" in d and not is_bound:
             us = kernel_us(os.path.join(src, f"smallb_B{B}_kernel_stats.csv"), nm.replace("ragraph::", ""))
             gb = (2 * d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0.0)) * 1024 / 1e9
             out[f"{nm.split('<')[0].replace('ragraph::', '')} B={B} N=1000000 D=256 k=10 [{nm}]"] = {
