@@ -2234,7 +2234,12 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
     if (!exchange) thr.theta = (l == 0 && bound && parts > k) ? f.theta : nullptr;
     thr.prev_scores = out_scores;
     const bool i8_level = l >= sc.nlev - sc.i8_levels;
-    const bool scored = i8_level && !exchange && filter_scored_lists(B, D);
+    // (sharded banks keep the plain lists: a level's threshold already is the k-th best over ALL shards -- sharper than
+    // anything round 1 can find among this shard's keys, so nothing is pruned and only the second round's latency and the
+    // 16-row tiles' occupancy are lost: emulated rank of 2 / 4 / 8 GPUs 13.49 -> 13.26 / 7.61 -> 8.00 / 4.76 -> 5.24 ms per
+    // step, profiles/r3_emul.txt.  RAGRAPH_FILTER_SCORED_SHARDS = largest shard count that takes them: A/B.)
+    static const int scored_shards = [] { const char* e = getenv("RAGRAPH_FILTER_SCORED_SHARDS"); return e ? atoi(e) : 0; }();
+    const bool scored = i8_level && (!exchange || n_shards <= scored_shards) && filter_scored_lists(B, D);
     rc = run_bf16_pass<D>(f, Kb, B, key0, sc.ends[l], thr, cap, 0, l, st, i8_level ? Kb8 : nullptr, scored);
     if (g_prof_on) {
       g_prof_i8[l] = l >= sc.nlev - sc.i8_levels;
