@@ -1407,14 +1407,16 @@ static bool rescore_coop() {  // RAGRAPH_RESCORE_COOP=0: every lane reads its ow
 // 4.50 / 4.21, 100 000: 24.4 / 22.8; but 50 000 x 2M x 128: 12.71 / 12.63 and 65 536 x 4M x 64: 15.73 / 15.93 -- shorter rows
 // are cheaper to fetch and their scores spread wider against the same eps (fewer extra candidates to prune), so the
 // second round only adds latency.
-static bool filter_scored_lists(int64_t B, int D) {
+// k <= 16: round 1 is 16 rows and lists beyond 256 entries take the plain path -- 50 000 x 1M x 256 at k = 16: 14.5 / 13.7 ms,
+// k = 20: 15.6 / 15.8, k = 32: 18.7 / 20.3.
+static bool filter_scored_lists(int64_t B, int D, int k) {
   static const int env = [] {
     const char* e = getenv("RAGRAPH_FILTER_SCORED");
     return e ? atoi(e) : -1;
   }();
   if (B < 2048 || !rescore_coop()) return false;  // (below: the wide kernels, a latency chain that two rounds would lengthen)
   if (env >= 0) return env != 0;
-  return D == 256;
+  return D == 256 && k <= 16;
 }
 
 static bool filter_wide_waves(int64_t B) {  // RAGRAPH_FILTER_QW128=0/1: A/B; default from 1024 queries (one full tile)
@@ -1560,7 +1562,7 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
   const int cap = 2048;
   // scored lists (one bank, >= 2048 queries): an int8 level's rescoring fetches about a third of its candidates' rows, which
   // makes int8 pay on EVERY level (the bench step, 2 / 3 int8 levels: 24.3 / 23.85 ms; without the scores 26.9 / 27.7)
-  const bool scored = n_shards == 1 && filter_scored_lists(B, D);
+  const bool scored = n_shards == 1 && filter_scored_lists(B, D, k);
   // (the model's price of an int8 candidate under scored lists, relative to the plain lists'; fitted: 0.6 moves 8192+ queries
   // x 1M keys from two levels to three, all int8 -- 8192: 2.37 -> 2.33 ms, 16384: 4.30 -> 4.13 -- while 0.45 also shrank the
   // first sample of 2048 - 8192 queries, which measured 2 - 4 % slower; RAGRAPH_FILTER_SCORED_CAND: A/B)
@@ -2239,7 +2241,7 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
     // 16-row tiles' occupancy are lost: emulated rank of 2 / 4 / 8 GPUs 13.49 -> 13.26 / 7.61 -> 8.00 / 4.76 -> 5.24 ms per
     // step, profiles/r3_emul.txt.  RAGRAPH_FILTER_SCORED_SHARDS = largest shard count that takes them: A/B.)
     static const int scored_shards = [] { const char* e = getenv("RAGRAPH_FILTER_SCORED_SHARDS"); return e ? atoi(e) : 0; }();
-    const bool scored = i8_level && (!exchange || n_shards <= scored_shards) && filter_scored_lists(B, D);
+    const bool scored = i8_level && (!exchange || n_shards <= scored_shards) && filter_scored_lists(B, D, k);
     rc = run_bf16_pass<D>(f, Kb, B, key0, sc.ends[l], thr, cap, 0, l, st, i8_level ? Kb8 : nullptr, scored);
     if (g_prof_on) {
       g_prof_i8[l] = l >= sc.nlev - sc.i8_levels;
