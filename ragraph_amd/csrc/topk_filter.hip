@@ -36,6 +36,7 @@
 #include "rescore_common.h"
 #include "segment_plan.h"
 #include <cmath>
+#include <vector>
 #include <type_traits>
 
 namespace ragraph {
@@ -1082,7 +1083,7 @@ __global__ void __launch_bounds__(128) topk_rescore_scored_kernel(const float* _
                                                                   unsigned char* __restrict__ flag, int64_t scan_n, FilterThr thr) {
   __shared__ float4 qs[2][D / 4];
   __shared__ __attribute__((aligned(16))) float tile[2][64 * RESCORE_LD];
-  __shared__ int surv[2][256];
+  __shared__ int surv[2][1024];
   __shared__ int stage[2][128];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t b = (int64_t)blockIdx.x * 2 + w;
@@ -1131,8 +1132,11 @@ __global__ void __launch_bounds__(128) topk_rescore_scored_kernel(const float* _
     if (!RG_SCORED(2)) RG_PLAIN(2, true, false);
   } else if (n <= 256) {
     if (!RG_SCORED(4)) RG_PLAIN(4, true, false);
-  } else if (n <= 512) RG_PLAIN(8, false, false);  // long lists are rare: every entry, lane-private row reads
-  else RG_PLAIN(16, false, false);
+  } else if (n <= 512) {  // (the single level of a call of a few hundred queries admits ~400 per query and prunes 90 %)
+    if (!RG_SCORED(8)) RG_PLAIN(8, false, false);
+  } else if (n <= 1024) {
+    if (!RG_SCORED(16)) RG_PLAIN(16, false, false);
+  } else RG_PLAIN(32, false, false);
 #undef RG_PLAIN
 #undef RG_SCORED
 }
@@ -1414,7 +1418,12 @@ static bool filter_scored_lists(int64_t B, int D, int k) {
     const char* e = getenv("RAGRAPH_FILTER_SCORED");
     return e ? atoi(e) : -1;
   }();
-  if (B < 2048 || !rescore_coop()) return false;  // (below: the wide kernels, a latency chain that two rounds would lengthen)
+  // every call of the ring kernel (> 256 queries): a scored list needs so few rows that ONE wave per query beats the
+  // four-wave workgroups of the wide kernels even at a few hundred queries, whose single level admits ~380 candidates per
+  // query and prunes 90 % of them (257 x 1M x 256: 0.214 -> 0.189 ms, 512: 0.267 -> 0.228, 1024: 0.436 -> 0.377, 1536: 0.580 ->
+  // 0.490; RAGRAPH_FILTER_SCORED_MIN_B: A/B)
+  static const int64_t min_b = [] { const char* e = getenv("RAGRAPH_FILTER_SCORED_MIN_B"); return e ? (int64_t)atoll(e) : (int64_t)257; }();
+  if (B < min_b || B <= 256 || !rescore_coop()) return false;
   if (env >= 0) return env != 0;
   return D == 256 && k <= 16;
 }
@@ -1562,7 +1571,8 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
   const int cap = 2048;
   // scored lists (one bank, >= 2048 queries): an int8 level's rescoring fetches about a third of its candidates' rows, which
   // makes int8 pay on EVERY level (the bench step, 2 / 3 int8 levels: 24.3 / 23.85 ms; without the scores 26.9 / 27.7)
-  const bool scored = n_shards == 1 && filter_scored_lists(B, D, k);
+  const bool scored = n_shards == 1 && B >= 2048 && filter_scored_lists(B, D, k);  // (below 2048 queries the plain lists' plans
+                                                                                   // stay: a smaller first sample measured slower)
   // (the model's price of an int8 candidate under scored lists, relative to the plain lists'; fitted: 0.6 moves 8192+ queries
   // x 1M keys from two levels to three, all int8 -- 8192: 2.37 -> 2.33 ms, 16384: 4.30 -> 4.13 -- while 0.45 also shrank the
   // first sample of 2048 - 8192 queries, which measured 2 - 4 % slower; RAGRAPH_FILTER_SCORED_CAND: A/B)
@@ -1899,7 +1909,8 @@ static size_t filter_ws_carve(char* w, int64_t B, int D, int k, int cap, FilterW
   f.eq = reinterpret_cast<float*>(take((size_t)B * sizeof(float)));
   f.count = reinterpret_cast<int*>(take((size_t)B * filter_count_stride(B) * sizeof(int)));
   f.flag = reinterpret_cast<unsigned char*>(take((size_t)B));
-  f.cand = reinterpret_cast<int*>(take((size_t)B * cap * sizeof(int)));
+  // (a call that may keep scored lists -- {key, I} -- gets 8 bytes per slot; sharded calls of the same shape do not use them)
+  f.cand = reinterpret_cast<int*>(take((size_t)B * cap * (filter_scored_lists(B, D, k) ? sizeof(int2) : sizeof(int))));
   f.gmax = reinterpret_cast<int*>(take((size_t)B * filter_bound_parts(k, INT64_MAX, 256) * sizeof(int)));
   f.theta = reinterpret_cast<float*>(take((size_t)B * sizeof(float)));
   f.overflow_list = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
@@ -1996,7 +2007,7 @@ static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64
       p.cand = f.cand;
       p.B = B;
       p.N = key1;
-      p.cap = scored ? cap / 2 : cap;  // (scored lists: {key, I} pairs in the same buffer)
+      p.cap = cap;  // (scored lists: {key, I} pairs, the same number of slots -- filter_ws_carve gives them 8 bytes each)
       p.stage_base = key0 / C8::STAGE_KEYS;  // key0 is a multiple of 256
       p.nstages_total = cdiv(key1 - key0, C8::STAGE_KEYS);
       // int8 operands are 16 bytes per 64 elements: SIX query groups per wave (tile = 768 queries) fit the registers four
@@ -2095,7 +2106,7 @@ static int run_rescore(const FilterWs& f, const float* Kn, int64_t N, int64_t B,
   if (scored_thr) {  // (filter_scored_lists: a large call's int8 level)
     *fallback_done = scan_n > 0;
     hipLaunchKernelGGL((topk_rescore_scored_kernel<D>), dim3((unsigned)cdiv(B, 2)), dim3(128), 0, st, f.Qn, Kn, f.count,
-                       reinterpret_cast<const int2*>(f.cand), B, cap / 2, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx,
+                       reinterpret_cast<const int2*>(f.cand), B, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx,
                        overflow, f.overflow_list, f.flag, scan_n, *scored_thr);
   } else if (B < wide_max_b && S > 1) {
     hipLaunchKernelGGL((topk_rescore_wide_kernel<D, true, true>), dim3((unsigned)B, (unsigned)S), dim3(256), 0, st, f.Qn, Kn, f.count,
@@ -2248,6 +2259,26 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
       g_prof_keys[l] = sc.ends[l] - key0;
     }
     if (rc != RAGRAPH_OK) return rc;
+    static const bool dbg_counts = [] { const char* e = getenv("RAGRAPH_FILTER_DEBUG_COUNTS"); return e && atoi(e) != 0; }();
+    if (dbg_counts) {  // diagnostic (synchronises): the level's candidate counts per query, before the rescoring resets them
+      const int cs_ = filter_count_stride(B);
+      std::vector<int> h((size_t)B * cs_);
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpy(h.data(), f.count, h.size() * sizeof(int), hipMemcpyDeviceToHost);
+      const int nsub_ = B <= 256 ? rescore_slices(B, k) : 1;
+      long long tot = 0, mx = 0, over_half = 0, over_cap = 0;
+      for (int64_t b = 0; b < B; ++b) {
+        long long c = 0;
+        for (int u = 0; u < nsub_; ++u) c += h[(size_t)b * cs_ + u];
+        tot += c;
+        mx = c > mx ? c : mx;
+        over_half += c > cap / 2;
+        over_cap += c > cap;
+      }
+      fprintf(stderr, "[filter counts] level %d (%s%s, keys %lld..%lld): mean %.1f max %lld per query; %lld of %lld queries above %d, %lld above %d\n",
+              l, i8_level ? "int8" : "bf16", scored ? ", scored" : "", (long long)key0, (long long)sc.ends[l], (double)tot / (double)B, mx,
+              over_half, (long long)B, cap / 2, over_cap, cap);
+    }
     if (g_prof_on) g_prof_have = l + 1;
     rc = run_rescore<D>(f, Kn, N, B, cap, k, idx_base, l > 0, l == sc.nlev - 1, out_scores, out_idx, overflow,
                         &fallback_done, exchange != nullptr && l > 0, st, scored ? &thr : nullptr);
