@@ -152,6 +152,9 @@ struct DirectArgs {
   int nsub;               // sub-lists per query (a power of two <= FILTER_COUNT_STRIDE; wave w appends to w % nsub)
   int* gmax_out;          // (bound pass) [B,bound_groups]
   int bound_groups;
+  int scored;             // (i8) the lists hold {key, I} pairs in int2 slots, I = an upper bound of the integer sum that
+                          // admitted the key (the lane's largest, rounded up to a multiple of 256): topk_filter.hip,
+                          // topk_rescore_scored_kernel
   int i8;                 // the pass runs on the int8 copy: Kb = that copy, Qb = the queries' int8 image (Qb8 of the prepare
                           // launch: block (qg * D/64 + t), lane j + 16 g = elements 64 t + 16 g .. + 15 of query 16 qg + j)
 };

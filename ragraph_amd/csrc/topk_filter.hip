@@ -1004,38 +1004,45 @@ __device__ __forceinline__ bool rescore_scored_query(const float4* __restrict__ 
   }
   const float theta_e = n_w >= k ? select_unord(kh) : RG_NEG_INF;
   const int t_e = filter_threshold_i8_at(thr, b, theta_e);
-  // round 2: the entries outside round 1 whose I reaches t_e, compacted
-  int ns = 0;
-#pragma unroll
-  for (int u = 0; u < NS; ++u) {
-    const bool in_r1 = lane_r1 && key[u] == bkey;
-    const bool keep = key[u] >= 0 && !in_r1 && iv[u] >= t_e;
-    const unsigned long long bm = __ballot(keep);
-    const int pos = ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
-    if (keep) surv[pos] = key[u];
-    ns += __popcll(bm);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // scored in batches of 64; those that beat W's k-th pair (a handful) are kept, one per lane of the "beaters" row
+  // round 2, four slots (256 entries) at a time: the entries outside round 1 whose I reaches t_e are compacted into the
+  // wave's list and scored in batches of 64; those that beat W's k-th pair (a handful) are kept, one per lane of the
+  // "beaters" row
   unsigned bh = 0u, bl = 0u;  // lane p: beater p
   int nb = 0;
-  for (int c0 = 0; c0 < ns; c0 += 64) {
-    const int c = c0 + lane;
-    const int kk = c < ns ? surv[c] : -1;
-    const float acc = ns - c0 <= 16 ? coop_scores_few<D>(qrow, Kn, kk, lane, sm) : coop_scores<D>(qrow, Kn, kk, lane, sm);
-    const unsigned sh = select_ord(acc), sl = ~(unsigned)kk;
-    const bool beats = kk >= 0 && pair_gt(sh, sl, kh, kl);
-    const unsigned long long bm = __ballot(beats);
-    const int cnt = __popcll(bm);
-    if (nb + cnt > 64) return false;  // (wave-uniform)
-    const int pos = nb + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
-    if (beats) {
-      stage[pos] = (int)sh;
-      stage[64 + pos] = (int)sl;
+#pragma unroll
+  for (int u0 = 0; u0 < NS; u0 += 4) {
+    int ns = 0;
+#pragma unroll
+    for (int u = u0; u < (u0 + 4 < NS ? u0 + 4 : NS); ++u) {
+      const bool in_r1 = lane_r1 && key[u] == bkey;
+      const bool keep = key[u] >= 0 && !in_r1 && iv[u] >= t_e;
+      const unsigned long long bm = __ballot(keep);
+      const int pos = ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
+      if (keep) surv[pos] = key[u];
+      ns += __popcll(bm);
     }
-    nb += cnt;
+    if (ns == 0) continue;  // (wave-uniform)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int c0 = 0; c0 < ns; c0 += 64) {
+      const int c = c0 + lane;
+      const int kk = c < ns ? surv[c] : -1;
+      const float acc = ns - c0 <= 16 ? coop_scores_few<D>(qrow, Kn, kk, lane, sm) : coop_scores<D>(qrow, Kn, kk, lane, sm);
+      const unsigned sh = select_ord(acc), sl = ~(unsigned)kk;
+      const bool beats = kk >= 0 && pair_gt(sh, sl, kh, kl);
+      const unsigned long long bm = __ballot(beats);
+      const int cnt = __popcll(bm);
+      if (nb + cnt > 64) return false;  // (wave-uniform)
+      const int pos = nb + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
+      if (beats) {
+        stage[pos] = (int)sh;
+        stage[64 + pos] = (int)sl;
+      }
+      nb += cnt;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // (the next four slots reuse the list)
   }
   if (nb > 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1083,18 +1090,19 @@ __global__ void __launch_bounds__(128) topk_rescore_scored_kernel(const float* _
                                                                   unsigned char* __restrict__ flag, int64_t scan_n, FilterThr thr) {
   __shared__ float4 qs[2][D / 4];
   __shared__ __attribute__((aligned(16))) float tile[2][64 * RESCORE_LD];
-  __shared__ int surv[2][1024];
+  __shared__ int surv[2][256];
   __shared__ int stage[2][128];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t b = (int64_t)blockIdx.x * 2 + w;
   if (b >= B) return;  // whole wave
+  // (the count, the flag and the query row are independent loads: issued together, one latency)
   int n = count[b * cs];
   bool over = flag[b] != 0;
   float4 qv4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (lane < D / 4) qv4 = reinterpret_cast<const float4*>(Qn + b * D)[lane];
   if (lane < D / 4) qs[w][lane] = qv4;
   __builtin_amdgcn_wave_barrier();
-  if (lane == 0 && n >= 0) count[b * cs] = 0;
+  if (lane == 0 && n >= 0) count[b * cs] = 0;  // the next level starts from an empty list
   if (n > cap) {
     over = true;
     n = cap;
@@ -1119,26 +1127,30 @@ __global__ void __launch_bounds__(128) topk_rescore_scored_kernel(const float* _
   const int64_t* pi = prev_i ? prev_i + b * k : nullptr;
   const int2* cb = cand + b * cap;
   const int* ck = reinterpret_cast<const int*>(cb);
-#define RG_PLAIN(NS_, COOP_, FEW_) \
-  rescore_query<D, NS_, COOP_, FEW_, 2>(qs[w], Kn, ck, n, lane, k, base, ps, pi, out_s + b * k, out_i + b * k, tile[w])
 #define RG_SCORED(NS_) \
   rescore_scored_query<D, NS_>(qs[w], Kn, cb, n, lane, k, base, ps, pi, out_s + b * k, out_i + b * k, tile[w], surv[w], stage[w], \
                                thr, b)
-  if (n <= 16) RG_PLAIN(1, true, true);
-  else if (n <= 24) RG_PLAIN(1, true, false);   // (round 1 alone would take most of such a list)
-  else if (n <= 64) {
-    if (!RG_SCORED(1)) RG_PLAIN(1, true, false);
-  } else if (n <= 128) {
-    if (!RG_SCORED(2)) RG_PLAIN(2, true, false);
-  } else if (n <= 256) {
-    if (!RG_SCORED(4)) RG_PLAIN(4, true, false);
-  } else if (n <= 512) {  // (the single level of a call of a few hundred queries admits ~400 per query and prunes 90 %)
-    if (!RG_SCORED(8)) RG_PLAIN(8, false, false);
-  } else if (n <= 1024) {
-    if (!RG_SCORED(16)) RG_PLAIN(16, false, false);
-  } else RG_PLAIN(32, false, false);
-#undef RG_PLAIN
+  bool done = false;
+  if (n > 24) {  // (round 1 alone would take most of a shorter list)
+    if (n <= 64) done = RG_SCORED(1);
+    else if (n <= 128) done = RG_SCORED(2);
+    else if (n <= 256) done = RG_SCORED(4);
+    else if (n <= 512) done = RG_SCORED(8);  // (the single level of a few hundred queries admits ~400 each and prunes 90 %)
+    else if (n <= 1024) done = RG_SCORED(16);
+  }
 #undef RG_SCORED
+  if (done) return;
+  // every entry the plain way: short lists, lists beyond 1024 entries, more than 64 entries beating round 1's k-th pair
+#define RG_PLAIN(NS_, COOP_, FEW_) \
+  rescore_query<D, NS_, COOP_, FEW_, 2>(qs[w], Kn, ck, n, lane, k, base, ps, pi, out_s + b * k, out_i + b * k, tile[w])
+  if (n <= 16) RG_PLAIN(1, true, true);
+  else if (n <= 64) RG_PLAIN(1, true, false);
+  else if (n <= 128) RG_PLAIN(2, true, false);
+  else if (n <= 256) RG_PLAIN(4, true, false);
+  else if (n <= 512) RG_PLAIN(8, false, false);   // long plain lists are rare: lane-private row reads
+  else if (n <= 1024) RG_PLAIN(16, false, false);
+  else RG_PLAIN(32, false, false);
+#undef RG_PLAIN
 }
 
 // The exact fallback for a query whose candidate list overflowed (thousands of keys within eps of the k-th best:
@@ -1418,12 +1430,15 @@ static bool filter_scored_lists(int64_t B, int D, int k) {
     const char* e = getenv("RAGRAPH_FILTER_SCORED");
     return e ? atoi(e) : -1;
   }();
-  // every call of the ring kernel (> 256 queries): a scored list needs so few rows that ONE wave per query beats the
+  // every call of the ring kernel (> 256 queries) ...: a scored list needs so few rows that ONE wave per query beats the
   // four-wave workgroups of the wide kernels even at a few hundred queries, whose single level admits ~380 candidates per
   // query and prunes 90 % of them (257 x 1M x 256: 0.214 -> 0.189 ms, 512: 0.267 -> 0.228, 1024: 0.436 -> 0.377, 1536: 0.580 ->
   // 0.490; RAGRAPH_FILTER_SCORED_MIN_B: A/B)
-  static const int64_t min_b = [] { const char* e = getenv("RAGRAPH_FILTER_SCORED_MIN_B"); return e ? (int64_t)atoll(e) : (int64_t)257; }();
-  if (B < min_b || B <= 256 || !rescore_coop()) return false;
+  // ... and the direct kernel's calls of 65 - 256 queries (entries carry ceil(I / 256)): 128 x 1M: 0.111 -> 0.106 ms, 256:
+  // 0.148 -> 0.136.  Up to 64 queries the direct kernel keeps several sub-lists per query and several workgroups rescore
+  // each: one wave per query measured slower there (one query 0.075 -> 0.080 ms).
+  static const int64_t min_b = [] { const char* e = getenv("RAGRAPH_FILTER_SCORED_MIN_B"); return e ? (int64_t)atoll(e) : (int64_t)65; }();
+  if (B < (min_b > 65 ? min_b : 65) || !rescore_coop()) return false;
   if (env >= 0) return env != 0;
   return D == 256 && k <= 16;
 }
@@ -2041,6 +2056,7 @@ static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64
     a.Qb = Kb8 ? reinterpret_cast<const uint16_t*>(f.Qb8) : f.Qb;
     a.Kb = Kb8 ? reinterpret_cast<const uint16_t*>(Kb8) : Kb;
     a.i8 = Kb8 ? 1 : 0;
+    a.scored = Kb8 && scored ? 1 : 0;
     a.B = B;
     a.key0 = key0;
     a.key1 = key1;

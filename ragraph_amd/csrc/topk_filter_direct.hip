@@ -61,6 +61,7 @@ struct DirectParams {
   int* count;             // [B][FILTER_COUNT_STRIDE]
   int* cand;
   int cap, nsub, subcap;  // nsub sub-lists of subcap = cap / nsub slots per query
+  int scored;             // (int8) lists of {key, I} pairs (int2 slots): filter_common.h DirectArgs
   int* gmax;              // BOUND
   int ngroups;            // BOUND: parts of the range
   int qgroups;            // groups of 16 queries (2..16, even: the query image is padded to whole 32s)
@@ -167,8 +168,9 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
       const int i = i0 + lane;
       if (i < wcnt) {
         const uint2 e = wbuf[i];
-        const int64_t q = e.y >> 16;
-        unsigned mk = e.y & 0xFFFFu;
+        // (int8 entries: mask | query << 8 | ceil(I / 256) << 16 -- the lane's largest sum as an upper bound in units of 256)
+        const int64_t q = I8 ? ((e.y >> 8) & 0xFFu) : (e.y >> 16);
+        unsigned mk = I8 ? (e.y & 0xFFu) : (e.y & 0xFFFFu);
         int slot = atomicAdd(p.count + q * FILTER_COUNT_STRIDE + sub, __popc(mk));
         // retired here on every path: a returning atomic hipcc still considers pending where the flush rejoins the
         // unit loop would put its vmcnt(0) -- which also drains the prefetched unit -- in front of every group pass
@@ -176,7 +178,12 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
         while (mk) {
           const int r = __ffs(mk) - 1;
           mk &= mk - 1;
-          if (slot < p.subcap) p.cand[q * p.cap + sub * p.subcap + slot] = (int)e.x + (r & 3) + 16 * (r >> 2);
+          if (slot < p.subcap) {
+            const int64_t at = q * p.cap + sub * p.subcap + slot;
+            const int key = (int)e.x + (r & 3) + 16 * (r >> 2);
+            if (I8 && p.scored) reinterpret_cast<int2*>(p.cand)[at] = make_int2(key, (int)(((int)e.y >> 16) * 256));
+            else p.cand[at] = key;
+          }
           ++slot;
         }
       }
@@ -225,7 +232,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
         const unsigned long long bal = __ballot(mk != 0);
         if (bal) {
           const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-          if (mk) wbuf[pos] = make_uint2((unsigned)key_base, ((unsigned)(16 * gq + j) << 16) | mk);
+          if (mk) wbuf[pos] = make_uint2((unsigned)key_base, mk | ((unsigned)(16 * gq + j) << 8) | ((unsigned)((m + 255) >> 8) << 16));
           wcnt += __popcll(bal);
         }
       }
@@ -460,6 +467,7 @@ static int launch_filter_direct_i8(const DirectArgs& a, hipStream_t st) {
   p.nsub = a.nsub < 1 ? 1 : a.nsub;
   RG_REQUIRE((p.nsub & (p.nsub - 1)) == 0 && p.nsub <= FILTER_COUNT_STRIDE, RAGRAPH_EINVAL, "filter(direct): nsub=%d", p.nsub);
   p.subcap = a.cap / p.nsub;
+  p.scored = a.scored;
   p.qgroups = 2 * (int)cdiv(a.B, 32);
   const int cus = device_cus_multiple_of_8();
   int64_t grid = cdiv(p.nunits, (int64_t)C::WAVES);

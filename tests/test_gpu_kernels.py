@@ -745,10 +745,11 @@ def test_topk_cosine_filtered_int8_levels_bit_exact(dev, monkeypatch, D, B, N, k
 
 
 @pytest.mark.parametrize("D,B,N,k", [(256, 2500, 70000, 10), (128, 2100, 66000, 32), (64, 2048, 70000, 1),
-                                     (256, 4100, 131072, 5)])
+                                     (256, 4100, 131072, 5), (256, 700, 300000, 10), (256, 200, 150000, 10),
+                                     (128, 90, 70000, 5), (256, 65, 1000000, 16)])
 def test_topk_cosine_filtered_scored_lists_bit_exact(dev, monkeypatch, D, B, N, k):
-    """Scored candidate lists (int8 levels of >= 2048 queries; the product rule takes them at D = 256, forced here at every
-    width): entries {key, I}, rescoring in two rounds -- the 16 largest I first, then only the entries whose I can still
+    """Scored candidate lists (int8 levels of calls of 65 queries and more -- the ring kernel's and the direct kernel's; the
+    product rule takes them at D = 256 and k <= 16, forced here at every width): entries {key, I}, rescoring in two rounds -- the 16 largest I first, then only the entries whose I can still
     reach the k-th best found.  Whatever round 1 picks the result is the oracle's: clusters of near-duplicates of 60 / 160 /
     400 keys put a query's list in every branch (most of round 2 beating round 1's k-th pair; more than 64 doing so: the
     plain path; lists beyond 256 entries), exact duplicates tie on I and on the score, a zero query overflows.  With and
