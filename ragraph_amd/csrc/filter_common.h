@@ -84,6 +84,9 @@ struct FilterThr {
   const float* eq8;
   const float* qscale;
   const unsigned* tail8;
+  const unsigned char* flag;  // [B] non-zero: the query's final answer comes from the exact scan anyway (a list of an
+                              // earlier level overflowed, or it is a ZERO query -- every score +0, every key within any
+                              // bound: filter_prep_kernel marks it) -- nothing passes the filter for it
 };
 
 __device__ __forceinline__ float filter_eps(const FilterThr& t, int64_t q) {
@@ -104,12 +107,12 @@ __device__ __forceinline__ float filter_theta(const FilterThr& t, int64_t q) {
 }
 
 __device__ __forceinline__ float filter_threshold(const FilterThr& t, int64_t q) {
-  if (t.ablate == 1) return __builtin_huge_valf();
+  if (t.ablate == 1 || (t.flag && t.flag[q])) return __builtin_huge_valf();
   return __fsub_rn(filter_theta(t, q), filter_eps(t, q));
 }
 
 // The int8 levels' integer threshold: a key can only belong to the exact top-k if I = sum qi ki >= the result (see the
-// layout comment above).  INT_MIN: everything passes (zero queries / banks, whose scales are 0).
+// layout comment above).  INT_MIN: everything passes (a zero BANK, whose scale is 0; zero queries are flagged and pass nothing).
 // (_at: for a given lower bound theta of the query's exact k-th best score)
 __device__ __forceinline__ int filter_threshold_i8_at(const FilterThr& t, int64_t q, float theta) {
   const float ek = sqrtf(__uint_as_float(t.tail8[0]));
@@ -123,7 +126,7 @@ __device__ __forceinline__ int filter_threshold_i8_at(const FilterThr& t, int64_
   return (int)floorf(x) - 2;
 }
 __device__ __forceinline__ int filter_threshold_i8(const FilterThr& t, int64_t q) {
-  if (t.ablate == 1) return INT_MAX;
+  if (t.ablate == 1 || (t.flag && t.flag[q])) return INT_MAX;
   return filter_threshold_i8_at(t, q, filter_theta(t, q));
 }
 

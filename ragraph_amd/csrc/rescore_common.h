@@ -277,10 +277,29 @@ __device__ __forceinline__ void rescore_query(const float4* __restrict__ qrow, c
 // The exact fallback for one query by ONE wave (a candidate list overflowed: near-duplicate banks, zero queries): every
 // lane scores its own key per step with the fp32 chain, the wave keeps the sorted list (lane p = entry p).  Slow -- a
 // full scan of the bank by 64 lanes -- and rare; the four-wave, LDS-staged form is exact_scan_query (topk_filter.hip).
+// A ZERO query (the usual reason for an overflow on an ordinary bank: every score is +0, so every key passes any bound)
+// needs no scan: all chains end at +0 and the canonical order is the index order.  Wave-uniform result.
+template <int D>
+__device__ __forceinline__ bool zero_query_answer(const float4* qrow, int k, int64_t idx_base, int lane,
+                                                  float* __restrict__ out_s, int64_t* __restrict__ out_i) {
+  bool nz = false;
+  for (int d4 = lane; d4 < D / 4; d4 += 64) {
+    const float4 v = qrow[d4];
+    nz = nz || ((__float_as_uint(v.x) | __float_as_uint(v.y) | __float_as_uint(v.z) | __float_as_uint(v.w)) & 0x7FFFFFFFu) != 0u;
+  }
+  if (__any(nz)) return false;
+  if (lane < k) {
+    out_s[lane] = 0.f;
+    out_i[lane] = idx_base + lane;
+  }
+  return true;
+}
+
 template <int D>
 __device__ __forceinline__ void exact_scan_wave(const float4* qrow, const float* __restrict__ Kn, int64_t N, int k,
                                                 int64_t idx_base, int lane, float* __restrict__ out_s,
                                                 int64_t* __restrict__ out_i) {
+  if (zero_query_answer<D>(qrow, k, idx_base, lane, out_s, out_i)) return;
   float es = RG_NEG_INF;
   int ei = INT_MAX;
   float kth_s = RG_NEG_INF;

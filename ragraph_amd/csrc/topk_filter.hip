@@ -239,11 +239,11 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) e2 += __shfl_xor(e2, off);
   float e8 = 0.f, sq = 0.f;
+  unsigned am = max(max(__float_as_uint(fabsf(v.x)), __float_as_uint(fabsf(v.y))), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w))));
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, off));
   if (eq8) {  // (kernel-uniform) the query's int8 scale and rounding error (filter_common.h; the ring kernel re-quantises
               // the row with the SAME expression, so this is the error of the operands it multiplies)
-    unsigned am = max(max(__float_as_uint(fabsf(v.x)), __float_as_uint(fabsf(v.y))), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w))));
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, off));
     sq = __uint_as_float(am) / 127.f;
     unsigned w8 = 0u;
     if (sq > 0.f) {
@@ -269,7 +269,10 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
   if (q >= B) return;
   if (lane == 0) {
     eq[q] = sqrtf(e2) * 1.0000002f;  // (any summation order of the squares stays below this)
-    flag[q] = 0;
+    // a ZERO query scores +0 against every key: within any bound of its k-th best, i.e. its lists can only overflow -- it
+    // is flagged as overflowed from the start (nothing passes the filter for a flagged query: FilterThr::flag) and the
+    // final level's scan path answers it without scanning (zero_query_answer)
+    flag[q] = am == 0u ? 1 : 0;
     if (eq8) {
       eq8[q] = sqrtf(e8) * 1.000001f;
       qscale[q] = sq;
@@ -1165,6 +1168,10 @@ __device__ __forceinline__ void exact_scan_query(const float4* qs /* LDS: the qu
                                                  float (*ps)[32], int64_t (*pi)[32], float* __restrict__ out_s,
                                                  int64_t* __restrict__ out_i) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (zero_query_answer<D>(qs, w == 0 ? k : 0, idx_base, lane, out_s, out_i)) {  // (no scan; every wave takes the same branch,
+    __syncthreads();                                                             // wave 0 writes)
+    return;
+  }
   float es = RG_NEG_INF;  // lane p < k: entry p of this wave's sorted list
   int ei = INT_MAX;
   float kth_s = RG_NEG_INF;
@@ -2215,6 +2222,7 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   thr.eq8 = f.eq8;
   thr.qscale = f.qscale;
   thr.tail8 = tail8;
+  thr.flag = f.flag;
   thr.k = k;
   const int parts = bound ? filter_bound_parts(k, sc.bound_keys, D, B, exchange ? n_shards : 1) : k;
   thr.ngroups = parts;

@@ -788,6 +788,30 @@ def test_topk_cosine_filtered_scored_lists_bit_exact(dev, monkeypatch, D, B, N, 
     assert torch.equal(outs["1"][1], i32) and torch.equal(outs["1"][0], s32)
 
 
+@pytest.mark.parametrize("B", [1, 40, 300, 2500])
+def test_zero_queries_are_answered_without_candidates(dev, B):
+    """An all-zero query scores +0 against every key, so no bound can exclude anything: the prepare launch flags it, a
+    flagged query passes nothing through the filter levels, and the final level's scan path writes its answer (+0, the
+    first k indices) without scanning.  Counted in *overflow like any row the filter could not serve."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(B)
+    N, D, k = 200000, 256, 10
+    kn = _bank(rng, N, D)
+    q = rng.standard_normal((B, D), dtype=np.float32)
+    zeros = sorted({0, B // 2, B - 1})
+    q[zeros] = 0.0
+    knd = _t(kn, dev)
+    s, i, over = K.topk_cosine_filtered(_t(q, dev), knd, K.keys_to_bf16(knd), k, idx_base=3)
+    assert int(over) == len(zeros)
+    s, i = s.cpu().numpy(), i.cpu().numpy()
+    for z in zeros:
+        assert np.array_equal(i[z], np.arange(3, 3 + k)) and np.all(s[z] == 0) and not np.signbit(s[z]).any()
+    rows = np.arange(B) if B <= 300 else rng.integers(0, B, 200)
+    rs, ri = cref.topk_cosine(q[rows], kn, k, idx_base=3)
+    assert np.array_equal(i[rows], ri) and np.array_equal(s[rows], rs)
+
+
 def test_int8_copy_scale_and_error_bound(dev):
     """The int8 copy's tail row: the bank's scale = max |k_i| / 127 and max_k |dk|^2 of the dequantised rows, against numpy;
     heavy-tailed rows (one large entry) widen the scale for the whole bank -- the bound follows, the result stays exact."""
