@@ -4,6 +4,7 @@ import torch
 import torch.nn as nn
 
 from .gcnlayers import GcnLayers
+from .layers.gcn import sparse_features
 
 
 class PrePrompt(nn.Module):
@@ -15,14 +16,17 @@ class PrePrompt(nn.Module):
         """preprompt.py:57-62.  Returns (h, c).  The node flavour's c is the 3-hop subgraph readout that a Python loop
         over nnz(A^3) computes (preprompt.py:8-27) and inference() throws away; here c is the plain mean readout of h
         (the graph flavour's AvgReadout, RAGraph_graph/preprompt.py:48-54)."""
+        sparse_features(seq)  # (bag-of-words features are judged here, once per tensor version: layers/gcn.py)
         h = self.gcn(seq, adj, sparse, LP).squeeze(0)
         return h.detach(), h.mean(dim=0, keepdim=True).detach()
 
     def inference(self, features, adj):
         """preprompt.py:64-66: L GCN layers, detached."""
+        sparse_features(features)
         return self.gcn(features, adj, False, False).squeeze(0).detach()
 
     def encode(self, features, adj):  # RAGraph_node_fewshot/preprompt.py:74-75
+        sparse_features(features)
         return self.gcn.encode(features, adj)
 
     def decode(self, features, adj):  # RAGraph_node_fewshot/preprompt.py:77-78

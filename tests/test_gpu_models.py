@@ -74,6 +74,62 @@ def test_gcn_layer_g4_and_propagation_g5(dev):
         assert np.array_equal(y.cpu().numpy(), pipeline.propagate(cref.dense_to_csr(g5["adj"]), g5["x"], k))
 
 
+def test_gcn_layer_bag_of_words_features_take_the_sparse_product(dev, monkeypatch):
+    """Cora-shaped features (1.3 % non-zeros over 1433 columns): the layer multiplies X's non-zeros only (CSR SpMM against
+    W^T) -- the dense kernel's fmaf chain with the zero terms left out, i.e. the same bits as the dense path and as the
+    oracle; dense or narrow feature matrices keep the dense kernel; the CSR form is cached per tensor version."""
+    from ragraph_amd import kernels as K
+    from ragraph_amd.graph import CSRGraph
+    from ragraph_amd.layers import gcn as G
+
+    rng = np.random.default_rng(5)
+    n, F, D = 700, 1433, 128
+    X = (rng.random((n, F)) < 0.013).astype(np.float32) * rng.integers(1, 4, (n, F)).astype(np.float32)
+    X[3] = 0.0                                                   # a node without any word
+    X[5, :] = (rng.random(F) < 0.5).astype(np.float32)           # and a long row
+    adj = (rng.random((n, n)) < 0.01).astype(np.float32)
+    adj = np.maximum(adj, adj.T) + np.eye(n, dtype=np.float32)
+    adj = adj / adj.sum(1, keepdims=True)
+    layer = G.GCN(F, D).to(dev)
+    with torch.no_grad():
+        layer.bias.copy_(T(rng.standard_normal(D).astype(np.float32), dev))
+    g = CSRGraph.from_dense(T(adj, dev))
+    Xd = T(X, dev)
+    calls = []
+    real = K.linear
+    monkeypatch.setattr(K, "linear", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
+    with torch.no_grad():
+        assert layer((Xd, g)) is not None and calls == [1]       # a layer never probes its input itself ...
+        calls.clear()
+        assert G.sparse_features(Xd) is not None                 # ... the encoder's entry point does (PrePrompt)
+        H = layer((Xd.unsqueeze(0).squeeze(0), g))               # (a fresh view of the judged tensor, as GcnLayers passes)
+        assert calls == []
+        ref = pipeline.gcn_layer(X, cref.dense_to_csr(adj), layer.fc.weight.detach().cpu().numpy(),
+                                 layer.bias.detach().cpu().numpy(), 0.25)
+        assert np.array_equal(H.cpu().numpy(), ref)              # the oracle's dense chain, bit for bit
+        monkeypatch.setattr(G, "SPARSE_FEATURES_MAX_DENSITY", 0.0)
+        Xd2 = Xd.clone()
+        assert G.sparse_features(Xd2) is None
+        H2 = layer((Xd2, g))                                     # the same numbers on the dense kernel
+        assert calls == [1] and torch.equal(H, H2)
+        monkeypatch.setattr(G, "SPARSE_FEATURES_MAX_DENSITY", 0.05)
+        Xd.add_(1.0)                                             # a new version of the tensor: judged again -- dense now
+        assert G.sparse_features(Xd) is None
+        H3 = layer((Xd, g))
+        assert calls == [1, 1]
+        assert np.array_equal(H3.cpu().numpy(), pipeline.gcn_layer(X + 1.0, cref.dense_to_csr(adj),
+                                                                   layer.fc.weight.detach().cpu().numpy(),
+                                                                   layer.bias.detach().cpu().numpy(), 0.25))
+        layer.fc.weight.mul_(0.5)                                # W^T follows the parameter's version
+        Xs = T(X, dev)
+        assert G.sparse_features(Xs) is not None
+        H4 = layer((Xs, g))
+        assert calls == [1, 1]
+        assert np.array_equal(H4.cpu().numpy(), pipeline.gcn_layer(X, cref.dense_to_csr(adj),
+                                                                   layer.fc.weight.detach().cpu().numpy(),
+                                                                   layer.bias.detach().cpu().numpy(), 0.25))
+
+
 def test_node_forward_g6(dev):
     from ragraph_amd.preprompt import PrePrompt
     from ragraph_amd.RAGraph import RAGraph
