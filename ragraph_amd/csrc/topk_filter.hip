@@ -545,12 +545,6 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     int wcnt = 0;  // wave-uniform
     int key_org = (int)((p.stage_base + st0) * C::STAGE_KEYS);
     auto flush = [&]() {
-#ifdef RG_FLUSH_ABLATE
-      if (p.thr.ablate == 2) {  // (timing experiment: the candidate path without its flushes)
-        wcnt = 0;
-        return;
-      }
-#endif
       for (int i0 = 0; i0 < wcnt; i0 += 64) {
         const int i = i0 + lane;
         if (i < wcnt) {
