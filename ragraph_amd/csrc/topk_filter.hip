@@ -362,6 +362,22 @@ __global__ void __launch_bounds__(256) theta_sharpen_kernel(const float* __restr
   if (lane < n && rank == k - 1) theta[b] = fmaxf(theta[b], v);
 }
 
+#ifdef RG_RING_STAMPS  // diagnostic build only: wall-clock stamps (10 ns ticks) through the first segment of workgroup 0 and
+                       // of the last workgroup: entry, operands loaded, thresholds ready, ring primed, stages done, flushed
+__device__ unsigned long long g_ring_t[2][2][8];
+__device__ unsigned long long g_ring_span[2][2];   // [BOUND][earliest entry, latest exit] over all workgroups
+__device__ unsigned long long g_ring_max[2][8];    // [BOUND][phase]: the longest phase over all workgroups' first segments
+#define RG_RSTAMP(i_)                                                                                     \
+  if (threadIdx.x == 0 && first_seg) {                                                                    \
+    const unsigned long long now_ = wall_clock64();                                                       \
+    if (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) g_ring_t[BOUND][blockIdx.x != 0][i_] = now_;      \
+    if ((i_) == 0) atomicMin(&g_ring_span[BOUND][0], now_);                                               \
+    else atomicMax(&g_ring_max[BOUND][i_], now_ - rs_prev);                                               \
+    rs_prev = now_;                                                                                       \
+  }
+#else
+#define RG_RSTAMP(i_)
+#endif
 #ifdef RG_TOPK_TIMING  // diagnostic build only: per-wave cycle totals of the ring's phases
 __device__ unsigned long long g_filter_timing[8];
 #define RG_FT(var_) const unsigned long long var_ = __builtin_amdgcn_s_memtime()
@@ -432,6 +448,11 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
   SegmentWalker walker(nq, p.nstages_total, p.wgs_per_group, p.lb_min, 0, p.depth[nq != nq0],
                        p.xcd_map ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);
   Segment seg;
+  [[maybe_unused]] bool first_seg = true;
+#ifdef RG_RING_STAMPS
+  unsigned long long rs_prev = 0;
+#endif
+  RG_RSTAMP(0);
   while (walker.next(seg)) {
     const int64_t qtile = p.xcd_map ? x + 8 * seg.tile : seg.tile;
     const int64_t q_lo = qtile * QT + wave * QW + j;  // group gq's query: q_lo + 16 gq
@@ -501,6 +522,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
         asm volatile("" ::: "memory");
       }
     }
+    RG_RSTAMP(1);
     // padded queries never pass: +inf threshold
     float thr[NG];
     int thr8[NG];  // (int8 levels) the integer threshold
@@ -574,6 +596,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     // still considers pending at the loop's back edge) would drain them every sub-tile: retire the thresholds here and
     // hand them to the loop as plain register values
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    RG_RSTAMP(2);
 #pragma unroll
     for (int gq = 0; gq < NG; ++gq) asm volatile("" : "+v"(thr[gq]), "+v"(thr8[gq]));
     int thr_i[NG];
@@ -589,6 +612,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     __syncthreads();
     if (tid < pro) full[tid] = C::WAVES;
     __syncthreads();
+    RG_RSTAMP(3);
 
     int pending = -1;
 #ifdef RG_TOPK_TIMING
@@ -800,10 +824,16 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     if (lane == 0)
       for (int i = 0; i < 6; ++i) atomicAdd(&g_filter_timing[i], tw[i]);
 #endif
+    RG_RSTAMP(4);
     flush();
     if constexpr (BOUND) flush_max();
+    RG_RSTAMP(5);
+    first_seg = false;
     __syncthreads();  // flags are re-initialised by the next segment
   }
+#ifdef RG_RING_STAMPS
+  if (threadIdx.x == 0) atomicMax(&g_ring_span[BOUND][1], wall_clock64());
+#endif
 }
 
 // One wave per query.  prev_* (the previous level's exact top-k, local indices) may alias out_*.  A query whose list
@@ -1974,6 +2004,12 @@ static int launch_ring(FilterParams p, int64_t B, int prof_slot, hipStream_t st)
     p.depth[v] = 0;
     if (nq < 1 || (v == 1 && (!p.xcd_map || p.qtiles % 8 == 0))) continue;
     p.depth[v] = SegmentWalker::choose_depth(nq, p.nstages_total, p.wgs_per_group, p.lb_min, 0).depth;
+    // Short launches cut the remainder at once (depth 0): a workgroup WALKS the plan's lockstep steps to its segment, every
+    // step a few 64-bit divisions, and with a few tiles over 256 workgroups the last ones walk ~40 of them -- 22.8 us of
+    // a 39-us launch (2708 queries x 10 000 keys: -DRG_RING_STAMPS); the re-reads the steps save are nothing at this size.
+    static const int depth_env = [] { const char* e = getenv("RAGRAPH_FILTER_DEPTH"); return e ? atoi(e) : -1; }();  // A/B
+    if (p.qtiles * p.nstages_total / CUS < 16) p.depth[v] = 0;
+    if (depth_env >= 0) p.depth[v] = depth_env < p.depth[v] ? depth_env : p.depth[v];
   }
   static DeviceOnce lds_once;  // per template instance and device (common.h)
   if (hipError_t e = raise_dynamic_lds(lds_once, &topk_filter_kernel<D, QW, BOUND, I8, SCORED>, (int)C::LDS_BYTES); e != hipSuccess) {
@@ -1984,6 +2020,28 @@ static int launch_ring(FilterParams p, int64_t B, int prof_slot, hipStream_t st)
   hipLaunchKernelGGL((topk_filter_kernel<D, QW, BOUND, I8, SCORED>), dim3((unsigned)CUS), dim3(C::THREADS), C::LDS_BYTES, st, p);
   if (g_prof_on) (void)hipEventRecord(g_prof_ev[2 * prof_slot + 1], st);
   RG_CHECK_LAUNCH("topk_cosine_filtered(filter)");
+#ifdef RG_RING_STAMPS
+  {
+    (void)hipDeviceSynchronize();
+    unsigned long long t[2][2][8];
+    (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_ring_t), sizeof(t));
+    for (int b = 0; b < 2; ++b)
+      fprintf(stderr, "[ring stamps, %s%s launch, %s workgroup, 10 ns ticks] operands %lld thresholds %lld ring primed %lld stages %lld "
+              "flush %lld (entered %lld after workgroup 0)\n", BOUND ? "bound" : "filter", I8 ? " int8" : "", b ? "last" : "first",
+              (long long)(t[BOUND][b][1] - t[BOUND][b][0]), (long long)(t[BOUND][b][2] - t[BOUND][b][1]),
+              (long long)(t[BOUND][b][3] - t[BOUND][b][2]), (long long)(t[BOUND][b][4] - t[BOUND][b][3]),
+              (long long)(t[BOUND][b][5] - t[BOUND][b][4]), (long long)(t[BOUND][b][0] - t[BOUND][0][0]));
+    unsigned long long span[2][2], mx[2][8];
+    (void)hipMemcpyFromSymbol(span, HIP_SYMBOL(g_ring_span), sizeof(span));
+    (void)hipMemcpyFromSymbol(mx, HIP_SYMBOL(g_ring_max), sizeof(mx));
+    fprintf(stderr, "[ring stamps, all workgroups] first entry to last exit %lld; longest first-segment phases: operands %lld thresholds %lld "
+            "ring primed %lld stages %lld flush %lld\n", (long long)(span[BOUND][1] - span[BOUND][0]), (long long)mx[BOUND][1],
+            (long long)mx[BOUND][2], (long long)mx[BOUND][3], (long long)mx[BOUND][4], (long long)mx[BOUND][5]);
+    unsigned long long init_span[2][2] = {{~0ull, 0ull}, {~0ull, 0ull}}, zero[2][8] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ring_span), init_span, sizeof(init_span));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ring_max), zero, sizeof(zero));
+  }
+#endif
 #ifdef RG_TOPK_TIMING
   {
     (void)hipDeviceSynchronize();
