@@ -465,6 +465,21 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     i32x4 bqi[I8 ? NG : 1][I8 ? C::KS32 : 1];
     constexpr int TB = C::KS32 < 4 ? C::KS32 : 4;
     if constexpr (I8) {
+      if (p.Qb) {  // prepared int8 image (filter_prep_kernel, up to FILTER_QB_MAX_B queries): block (group * KS32 + t), this
+                   // lane's 16 bytes -- the very bytes the quantisation below would produce; groups beyond the batch: zeros
+        const int64_t qg0 = (qtile * QT + wave * QW) >> 4;
+        const int64_t ngroups16 = ((p.B + 31) / 32 * 32) >> 4;
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+          const bool have = qg0 + gq < ngroups16;  // (wave-uniform)
+          const i32x4* src = reinterpret_cast<const i32x4*>(p.Qb) + ((qg0 + gq) * C::KS32) * 64 + lane;
+#pragma unroll
+          for (int t = 0; t < C::KS32; ++t) {
+            i32x4 z = {0, 0, 0, 0};
+            bqi[gq][t] = have ? src[t * 64] : z;
+          }
+        }
+      } else
 #pragma unroll
       for (int gq = 0; gq < NG; ++gq) {
         const int64_t qq = q_lo + 16 * gq;
@@ -1630,7 +1645,12 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
   static const bool i8_d64 = [] { const char* e = getenv("RAGRAPH_FILTER_I8_D64"); return !e || atoi(e) != 0; }();  // A/B
   // (D = 64, the edge flavour: one MFMA per 16-key half and query group, so the epilogue weighs more -- 65 536 x 4M x 64:
   // 22.5 -> 15.5 ms with eight groups per wave; eps is the same 0.02 but the scores' spread is 1/8: fewer extra candidates)
-  const bool i8_ok = (D == 128 || D == 256 || (D == 64 && i8_d64)) && B > 256 && N * n_shards >= 65536;
+  // (with the prepared int8 operand image and the scored lists, D = 256 also pays on banks of 32 768+ keys from 2048 queries:
+  // 4096 x 40 000: 0.189 -> 0.160 ms, 2100 x 60 000: 0.180 -> 0.150, 16 384 x 50 000: 0.64 -> 0.49; not at D = 128 -- 8192 x
+  // 50 000: 0.237 -> 0.244 -- nor on shorter banks -- 8192 x 20 000 x 256: 0.221 -> 0.238)
+  const bool i8_ok = (D == 128 || D == 256 || (D == 64 && i8_d64)) && B > 256 &&
+                     (N * n_shards >= 65536 || (D == 256 && B >= 2048 && N * n_shards >= 32768));
+  const bool mid_i8 = i8_ok && N * n_shards < 65536;
   static const bool i8_direct_env = [] { const char* e = getenv("RAGRAPH_FILTER_I8_DIRECT"); return !e || atoi(e) != 0; }();  // A/B
   const bool i8_direct = (D == 128 || D == 256) && B <= 256 && N * n_shards >= 65536 && i8_direct_env;
   // bound_keys / eff_div ~ the exact sample the bound is worth: planned for 4 k parts, corrected below if the prefix is
@@ -1753,7 +1773,9 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
       // (a candidate costs ~0.4 ns while a level's rescoring is a latency chain -- up to ~1000 queries -- and ~0.18 ns once it
       // is bound by the row gathers: 100 000 queries x ~130 candidates x 1 KiB in 1.8 ms)
       const double per_cand = 0.18e-3 + 0.22e-3 * (B <= 1024 ? 1.0 : 1024.0 / (double)B);
-      for (int i8 = 0; i8 <= (i8_ok ? (L < 2 || scored ? L : 2) : 0); ++i8) {
+      // (mid_i8 -- D = 256 banks of 32 768 .. 65 535 keys: the constants below were fitted on million-key banks and overprice
+      // these shapes' candidates; what measured faster there is the bf16 plan with every level moved to int8: see below)
+      for (int i8 = 0; i8 <= (i8_ok && !mid_i8 ? (L < 2 || scored ? L : 2) : 0); ++i8) {
         double cost = first, e_prev = 0.0, e = (double)n0;
         bool fits = true;
         for (int l = 0; l < L; ++l) {
@@ -1777,7 +1799,7 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
   }
   sc.bound_keys = bound ? (best_nA ? best_nA : prefix_for(4096)) : 0;
   sc.n0 = best_n0;
-  sc.i8_levels = best_i8;
+  sc.i8_levels = mid_i8 ? best_L : best_i8;
   sc.slab0 = 1;
   sc.nlev = 0;
   const double r = pow((double)N / (double)best_n0, 1.0 / best_L);
@@ -1939,7 +1961,7 @@ struct FilterWs {
   int* part_i;
   float* eq8;           // [B] |dq| of the int8 rounding, [B] the query's int8 scale (int8 levels)
   float* qscale;
-  signed char* Qb8;     // (B <= 256) the queries as int8 B operands in fragment order, padded to whole groups of 32
+  signed char* Qb8;     // (B <= FILTER_QB_MAX_B) the queries as int8 B operands in fragment order, padded to whole groups of 32
 };
 
 static size_t filter_ws_carve(char* w, int64_t B, int D, int k, int cap, FilterWs* out) {
@@ -1964,7 +1986,7 @@ static size_t filter_ws_carve(char* w, int64_t B, int D, int k, int cap, FilterW
   f.part_i = B <= 64 ? reinterpret_cast<int*>(take((size_t)B * 8 * k * sizeof(int))) : nullptr;
   f.eq8 = reinterpret_cast<float*>(take((size_t)B * sizeof(float)));
   f.qscale = reinterpret_cast<float*>(take((size_t)B * sizeof(float)));
-  f.Qb8 = B <= 256 ? reinterpret_cast<signed char*>(take((size_t)((B + 31) / 32 * 32) * D)) : nullptr;
+  f.Qb8 = B <= FILTER_QB_MAX_B ? reinterpret_cast<signed char*>(take((size_t)((B + 31) / 32 * 32) * D)) : nullptr;
   if (out) *out = f;
   return off;
 }
@@ -2077,7 +2099,9 @@ static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64
       p.thr = thr;
       p.count = f.count;
       p.cstride = filter_count_stride(B);
-      p.Qb = nullptr;
+      static const bool i8_image = [] { const char* e = getenv("RAGRAPH_FILTER_I8_IMAGE"); return !e || atoi(e) != 0; }();  // A/B
+      // (the int8 image, or NULL beyond FILTER_QB_MAX_B queries: quantised per segment)
+      p.Qb = i8_image ? reinterpret_cast<const uint16_t*>(f.Qb8) : nullptr;
       p.cand = f.cand;
       p.B = B;
       p.N = key1;
@@ -2265,7 +2289,7 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   hipLaunchKernelGGL(filter_prep_kernel<D>, dim3((unsigned)cdiv(B <= FILTER_QB_MAX_B ? (B + 31) / 32 * 32 : B, 4)), dim3(256), 0, st, Q, B,
                      f.Qn, f.eq, f.count, f.flag, overflow, bound ? f.gmax : nullptr, bound ? filter_bound_parts(k, sc.bound_keys, D, B, exchange ? n_shards : 1) : k,
                      B <= FILTER_QB_MAX_B ? f.Qb : nullptr,
-                     filter_count_stride(B), sc.i8_levels > 0 ? f.eq8 : nullptr, f.qscale, B <= 256 ? f.Qb8 : nullptr);
+                     filter_count_stride(B), sc.i8_levels > 0 ? f.eq8 : nullptr, f.qscale, B <= FILTER_QB_MAX_B ? f.Qb8 : nullptr);
   RG_CHECK_LAUNCH("topk_cosine_filtered(prepare)");
 
   FilterThr thr{};
