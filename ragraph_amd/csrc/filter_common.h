@@ -107,8 +107,9 @@ __device__ __forceinline__ float filter_theta(const FilterThr& t, int64_t q) {
 }
 
 __device__ __forceinline__ float filter_threshold(const FilterThr& t, int64_t q) {
-  if (t.ablate == 1 || (t.flag && t.flag[q])) return __builtin_huge_valf();
-  return __fsub_rn(filter_theta(t, q), filter_eps(t, q));
+  const unsigned char fl = t.flag ? t.flag[q] : 0;  // (loaded next to the bound's operands: one latency, not two)
+  const float thr = __fsub_rn(filter_theta(t, q), filter_eps(t, q));
+  return (t.ablate == 1 || fl) ? __builtin_huge_valf() : thr;
 }
 
 // The int8 levels' integer threshold: a key can only belong to the exact top-k if I = sum qi ki >= the result (see the
@@ -126,8 +127,9 @@ __device__ __forceinline__ int filter_threshold_i8_at(const FilterThr& t, int64_
   return (int)floorf(x) - 2;
 }
 __device__ __forceinline__ int filter_threshold_i8(const FilterThr& t, int64_t q) {
-  if (t.ablate == 1 || (t.flag && t.flag[q])) return INT_MAX;
-  return filter_threshold_i8_at(t, q, filter_theta(t, q));
+  const unsigned char fl = t.flag ? t.flag[q] : 0;
+  const int thr = filter_threshold_i8_at(t, q, filter_theta(t, q));
+  return (t.ablate == 1 || fl) ? INT_MAX : thr;
 }
 
 // Candidate counters of a call of fewer than 2048 queries.  A returning atomicAdd costs ~11 ns per operation on ONE address
