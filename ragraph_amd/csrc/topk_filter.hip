@@ -1584,10 +1584,13 @@ struct FilterSchedule {
 };
 
 constexpr int64_t FILTER_SLAB_MAX_B = 16384;
-// up to this many queries the prepare launch also leaves the queries as bf16 B operands in fragment order: the direct
+// up to this many queries the prepare launch also leaves the queries as bf16 (and int8) B operands in fragment order: the direct
 // kernel's image (<= 256), and the ring kernel's operand load -- 32 independent 16-byte loads per lane instead of eight
 // dependent batches of fp32 loads + conversions (13 us per segment at D = 256), which short launches cannot amortise
-constexpr int64_t FILTER_QB_MAX_B = 16384;
+// (every filtered call: KeyIndex cuts batches at 262 144 queries.  Large batches have long segments on ONE GPU -- the images
+// save ~0.7 % of the bench step -- but the short launches of a key-sharded rank do not: the bound launch of one rank of 8
+// spent a quarter of its 0.27 ms converting operands.  The images are 3 D bytes per query: 77 MB at 100 000 queries.)
+constexpr int64_t FILTER_QB_MAX_B = 262144;
 constexpr int64_t FILTER_SLAB_MAX_SCORES = (int64_t)1 << 26;  // 256 MiB of scores
 
 // Banks of >= 8192 keys (KeyIndex sends >= 16384) take their first bound from the BOUND pass instead of an
