@@ -904,7 +904,7 @@ __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restri
 // CU -- such a level is a chain of memory latencies per query, and occupancy is what hides them; the rare longer list
 // takes the lane-private row reads.
 template <int D, int CPL, bool FEWTILE = false>
-__global__ void __launch_bounds__(128) topk_rescore_coop_kernel(const float* __restrict__ Qn, const float* __restrict__ Kn,
+__global__ void __launch_bounds__(128, FEWTILE ? 4 : 1) topk_rescore_coop_kernel(const float* __restrict__ Qn, const float* __restrict__ Kn,
                                                                 int* __restrict__ count,
                                                                 const int* __restrict__ cand, int64_t B, int cap, int cs, int k,
                                                                 int64_t idx_base, const float* prev_s,
