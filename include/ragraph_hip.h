@@ -106,7 +106,9 @@ int ragraph_topk_cosine_bank_f32(const float* Q, int64_t B, const float* Kn, con
  *   everything seen so far and a tighter bound for the next level (large batches: [0,N/32), [N/32,N/4), [N/4,N); small
  *   ones: fewer, steeper levels -- ragraph_topk_cosine_filtered_plan).  The result has the same bits as
  *   ragraph_topk_cosine_f32.  D in {64,128,256}, k <= 32.
- *   Kb   bf16 copy of Kn made by ragraph_keys_to_bf16 (ragraph_keys_bf16_rows(N) rows x D, uint16 storage).
+ *   Kb   bf16 copy of Kn made by ragraph_keys_to_bf16 (ragraph_keys_bf16_rows(N) rows x D, uint16 storage: the bf16 rows
+ *        padded to a multiple of 256 keys, a tail row, the int8 rows, their tail row, and 256 rows of slack that the last
+ *        stage of an int8 level may read).
  *   Kp   optional packed fp32 copy (ragraph_pack_keys_f32) for the fp32 level, or NULL.
  *   overflow  device int, set by the call: number of queries whose candidate list exceeded its capacity
  *        (ragraph_topk_cosine_filtered_cap(k) keys per list; a batch of <= 64 queries keeps up to 8 such lists per query,

@@ -1627,6 +1627,18 @@ static double filter_bound_eff(int k, int parts) {
   return log((double)k) + 1.0;
 }
 
+// D = 64: a stage of the int8 copy holds 512 keys (32 KB / 64 B) and a level starts at a whole stage, so the inner level ends
+// are multiples of 512 -- a level that started at an odd multiple of 256 would begin with the previous level's last 256
+// keys again, and a key listed twice breaks the selection (distinct pairs are what its ranks count).
+static void filter_align_ends(FilterSchedule& sc, int D) {
+  if (D != 64) return;
+  for (int l = 0; l + 1 < sc.nlev; ++l) {
+    const int64_t e = sc.ends[l] / 512 * 512;
+    if (e >= 512 && (l == 0 || e > sc.ends[l - 1])) sc.ends[l] = e;
+  }
+  if (sc.bound_keys > sc.ends[0]) sc.bound_keys = sc.ends[0] / FILTER_PAD_KEYS * FILTER_PAD_KEYS;
+}
+
 // n_shards > 1 (row-sharded bank, N = the largest shard): the shards pool their first samples through the exchange, so
 // the sample is planned for the WHOLE bank and every shard scans its share of the prefix.
 static int rescore_slices(int64_t B, int k);
@@ -1714,6 +1726,7 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
     if (sc.bound_keys > sc.ends[0]) sc.bound_keys = sc.ends[0] / FILTER_PAD_KEYS * FILTER_PAD_KEYS;
     if (sc.bound_keys / (FILTER_STAGE_BYTES / (2 * D)) < k) sc.bound_keys = 0;  // every part needs a stage of its own
     sc.i8_levels = i8_ok && B >= 1024 ? (scored ? 3 : 2) : 0;  // (banks below 4 x 4096 keys come here with any batch)
+    filter_align_ends(sc, D);
     return sc;
   }
   double best = 1e30;
@@ -1817,6 +1830,7 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
   if (sc.bound_keys > sc.ends[0]) sc.bound_keys = sc.ends[0] / FILTER_PAD_KEYS * FILTER_PAD_KEYS;
   if (sc.bound_keys / stage_keys < k) sc.bound_keys = 0;  // every part needs a stage of its own: else the exact slab
   if (sc.bound_keys == 0 && B * sc.n0 > FILTER_SLAB_MAX_SCORES) sc.slab0 = 0;
+  filter_align_ends(sc, D);
   return sc;
 }
 
@@ -1901,10 +1915,13 @@ extern "C" int ragraph_keys_to_bf16(const float* Kn, int64_t N, int D, uint16_t*
 
 // rows of D uint16: the bf16 copy padded to whole ring stages + one row that carries the bank's largest rounding error,
 // then the int8 copy (half as many rows) + one row with its largest error and its scale
+constexpr int64_t FILTER_COPY_SLACK_ROWS = 256;  // rows of 2 D bytes: >= 16 KB at any supported D
 extern "C" int64_t ragraph_keys_bf16_rows(int64_t N) {
   if (N < 1) return 0;
   const int64_t npad = filter_round_up(N);
-  return npad + 1 + npad / 2 + 1;
+  // + FILTER_COPY_SLACK_ROWS: at D = 64 a stage of the int8 copy is 512 keys, so the last stage of a bank padded to an odd
+  // multiple of 256 keys reads 16 KB past the copy's rows (keys >= N never pass): the buffer must own those bytes
+  return npad + 1 + npad / 2 + 1 + FILTER_COPY_SLACK_ROWS;
 }
 
 extern "C" int ragraph_topk_cosine_filtered_cap(int k) { return 2048; }
@@ -2109,7 +2126,9 @@ static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64
       p.B = B;
       p.N = key1;
       p.cap = cap;  // (scored lists: {key, I} pairs, the same number of slots -- filter_ws_carve gives them 8 bytes each)
-      p.stage_base = key0 / C8::STAGE_KEYS;  // key0 is a multiple of 256
+      RG_REQUIRE(key0 % C8::STAGE_KEYS == 0, RAGRAPH_EINVAL, "topk_cosine_filtered: an int8 level must start at a whole stage "
+                 "(key %lld, %d keys per stage)", (long long)key0, (int)C8::STAGE_KEYS);
+      p.stage_base = key0 / C8::STAGE_KEYS;
       p.nstages_total = cdiv(key1 - key0, C8::STAGE_KEYS);
       // int8 operands are 16 bytes per 64 elements: SIX query groups per wave (tile = 768 queries) fit the registers four
       // bf16 groups take (224 VGPRs, no scratch), and an A fragment then feeds six MFMAs, a stage 3072 cycles of them

@@ -3,6 +3,8 @@
 Bar: BIT-EXACT for every fmaf-chain kernel (scores, linear, SpMM, norms, gathers, sums) and for all indices; 1e-6
 for the kernels that call expf/logf (softmax family), whose libm differs between host and device.
 """
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -449,7 +451,7 @@ def test_topk_cosine_filtered_bit_exact(dev, B, N, k):
     knd = _t(kn, dev)
     kb = K.keys_to_bf16(knd)
     npad = -(-N // 256) * 256   # bf16 copy padded to whole stages + its error row, then the int8 copy (half the rows) + its row
-    assert kb.shape[0] == npad + 1 + npad // 2 + 1
+    assert kb.shape[0] == npad + 1 + npad // 2 + 1 + 256   # (+ slack the int8 levels' last stage may read)
     s, i, over = K.topk_cosine_filtered(_t(q, dev), knd, kb, k, idx_base=9)
     assert over == 0
     rs, ri = cref.topk_cosine(q, kn, k, idx_base=9)
@@ -810,6 +812,27 @@ def test_zero_queries_are_answered_without_candidates(dev, B):
     rows = np.arange(B) if B <= 300 else rng.integers(0, B, 200)
     rs, ri = cref.topk_cosine(q[rows], kn, k, idx_base=3)
     assert np.array_equal(i[rows], ri) and np.array_equal(s[rows], rs)
+
+
+def test_int8_levels_at_d64_start_at_whole_stages(dev):
+    """D = 64: a stage of the int8 copy is 512 keys, level ends used to be multiples of 256 -- a level that began at an odd
+    multiple re-read the previous level's last 256 keys, a winner among those was listed twice and the selection (ranks of
+    DISTINCT pairs) went wrong for that query (found by tools/soak_filtered.py: 12 of 5056 rows on this very shape).  The
+    inner ends are multiples of 512 now; every row equals the fp32 kernel's."""
+    from ragraph_amd import kernels as K
+
+    B, N, D, k = 5056, 593347, 64, 5
+    plan = (ctypes.c_int64 * 7)()
+    for shape in ((B, N), (20000, 131072 + 256), (100000, 4000000)):
+        nlev = K.N.lib().ragraph_topk_cosine_filtered_plan(shape[0], shape[1], D, k, plan)
+        assert all(int(plan[3 + l]) % 512 == 0 for l in range(nlev - 1))
+    g = torch.Generator(device=dev).manual_seed(0)
+    kn = K.normalize_rows(torch.randn(N, D, device=dev, generator=g))
+    q = torch.randn(B, D, device=dev, generator=g)
+    assert K.filtered_i8_levels(B, N, D, k) > 0
+    s1, i1, over = K.topk_cosine_filtered(q, kn, K.keys_to_bf16(kn), k, idx_base=5)
+    s0, i0 = K.topk_cosine(q, kn, k, idx_base=5)
+    assert int(over) == 0 and torch.equal(i0, i1) and torch.equal(s0, s1)
 
 
 def test_int8_copy_scale_and_error_bound(dev):
