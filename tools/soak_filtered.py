@@ -1,6 +1,7 @@
 """Randomised soak of the bf16-filtered exact top-k against the fp32 kernels (both on the GPU; the fp32 kernels are
 the oracle-checked ones): random shapes, banks with duplicates / clusters / tiny norms, random idx_base.
-  python tools/soak_filtered.py [seconds] [seed]"""
+  python tools/soak_filtered.py [seconds] [seed] [filtered|index]
+"index": through KeyIndex.topk -- the product dispatch (fused small-bank kernel, direct / ring filter, fp32 kernels)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,6 +9,7 @@ from ragraph_amd import kernels as K
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+mode = sys.argv[3] if len(sys.argv) > 3 else "filtered"
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(seed)
 cpu = torch.Generator().manual_seed(seed)
@@ -45,7 +47,14 @@ while time.time() - t0 < budget:
     if kind == 4 and B > 3:
         q[2] = 0.0  # zero query: every key ties
     base = (0, 5, 1_000_000)[ri(0, 2)]
-    s1, i1, over = K.topk_cosine_filtered(q, kn, K.keys_to_bf16(kn), k, idx_base=base)
+    if mode == "index":
+        idx = K.KeyIndex(kn)
+        s1, i1 = idx.topk(q, k, idx_base=base)
+        if ri(0, 1):  # a second call on the same index (cached copies, the overflow feedback of the first)
+            s1, i1 = idx.topk(q, k, idx_base=base)
+        over = 0
+    else:
+        s1, i1, over = K.topk_cosine_filtered(q, kn, K.keys_to_bf16(kn), k, idx_base=base)
     s0, i0 = K.topk_cosine(q, kn, k, idx_base=base)
     ok = torch.equal(i0, i1) and torch.equal(s0, s1)
     n += 1
