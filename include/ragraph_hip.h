@@ -167,6 +167,9 @@ int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const float* Kn,
  * are padded with -inf / INT64_MAX); ragraph_topk_merge_f32 over the shards' lists gives the global result, bit-identical
  * to one GPU.  exchange = NULL: exactly ragraph_topk_cosine_filtered_f32. */
 typedef void (*ragraph_exchange_fn)(void* ctx, int phase);
+/* ws of the sharded entry: the schedule is planned for (plan_N, n_shards), whose first sample -- hence level-0 scratch --
+ * can differ from the single bank's; at least ragraph_topk_cosine_filtered_workspace_bytes(B, plan_N, D, k). */
+size_t ragraph_topk_cosine_filtered_sharded_workspace_bytes(int64_t B, int64_t plan_N, int D, int k, int n_shards);
 int ragraph_topk_cosine_filtered_sharded_f32(const float* Q, int64_t B, const float* Kn, const float* Kp, const uint16_t* Kb,
                                              int64_t N, int D, int k, int64_t idx_base, float* out_scores, int64_t* out_idx,
                                              int* overflow, int64_t* overflow_idx, void* ws, size_t ws_bytes, void* stream,

@@ -1931,13 +1931,13 @@ static int filter_cap(int64_t B, int k) { return ragraph_topk_cosine_filtered_ca
 
 static size_t filter_ws_carve(char* w, int64_t B, int D, int k, int cap, struct FilterWs* out);
 
-extern "C" size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_t N, int D, int k) {
-  if (B < 1 || N < 1 || k < 1 || !filter_dim_ok(D)) return 0;
+static size_t filter_workspace_bytes(int64_t B, int64_t N, int D, int k, int n_shards) {
+  if (B < 1 || N < 1 || k < 1 || n_shards < 1 || !filter_dim_ok(D)) return 0;
   const int cap = filter_cap(B, k);
   // run_filtered may turn the planned bound pass into an exact level 0 (a shard shorter than twice the prefix, a shard's
   // share of a pooled sample, the schedule switches): size for whichever of the two needs more, and run_filtered checks
   // the schedule it really runs against ws_bytes before carving
-  FilterSchedule sc = filter_schedule(B, N, D, k);
+  FilterSchedule sc = filter_schedule(B, N, D, k, n_shards);
   size_t level0 = filter_level0_ws(sc, B, D, k);
   if (sc.bound_keys > 0) {
     sc.bound_keys = 0;
@@ -1945,6 +1945,15 @@ extern "C" size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_
     if (exact0 > level0) level0 = exact0;
   }
   return level0 + filter_ws_carve(nullptr, B, D, k, cap, nullptr);
+}
+
+extern "C" size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_t N, int D, int k) {
+  return filter_workspace_bytes(B, N, D, k, 1);
+}
+// The sharded entry plans for (plan_N, n_shards): its first sample can be another one than the single bank's of plan_N rows.
+extern "C" size_t ragraph_topk_cosine_filtered_sharded_workspace_bytes(int64_t B, int64_t plan_N, int D, int k, int n_shards) {
+  const size_t a = filter_workspace_bytes(B, plan_N, D, k, n_shards), b = filter_workspace_bytes(B, plan_N, D, k, 1);
+  return a > b ? a : b;  // (exchange = NULL runs the single-bank schedule)
 }
 
 extern "C" int ragraph_topk_cosine_filtered_i8_levels(int64_t B, int64_t N, int D, int k) {

@@ -232,7 +232,11 @@ def topk_cosine_filtered(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf
     scores = torch.empty((B, k), dtype=torch.float32, device=q.device)
     idx = torch.empty((B, k), dtype=torch.int64, device=q.device)
     overflow = torch.empty(1, dtype=torch.int32, device=q.device)
-    nbytes = L.ragraph_topk_cosine_filtered_workspace_bytes(B, max(plan_n, Nk), D, k)
+    if exchange is None:
+        nbytes = L.ragraph_topk_cosine_filtered_workspace_bytes(B, max(plan_n, Nk), D, k)
+    else:  # (the sharded schedule -- planned for (plan_n, n_shards) -- can need another level-0 scratch)
+        nbytes = L.ragraph_topk_cosine_filtered_sharded_workspace_bytes(B, max(plan_n, Nk), D, k,
+                                                                        int(getattr(exchange, "n_shards", 1)))
     if nbytes == 0:
         raise RagraphNativeError(f"topk_cosine_filtered: unsupported shape B={B} N={Nk} D={D} k={k}")
     ws = _workspace(nbytes, q.device)

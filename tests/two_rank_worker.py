@@ -64,6 +64,22 @@ def main():
         res["key_shard_topk_equal"] = bool(torch.equal(got_i, want_i) and torch.equal(got_s, want_s))
         res["exchange_count"] = {str(p): c for p, c in sharded.exchange_count.items()}
 
+        # the edge flavour's width: D = 64, whose int8 levels start at whole 512-key stages (an uneven shard size on purpose)
+        N64, B64 = 300_001, 6000
+        g64 = torch.Generator(device=dev).manual_seed(99)
+        K64 = K.normalize_rows(torch.randn(N64, 64, device=dev, generator=g64))
+        q64 = torch.randn(B64, 64, device=dev, generator=g64)
+        want64_s, want64_i = K.KeyIndex(K.normalize_rows(K64)).topk(q64, k)   # (the sharded bank normalises its rows again)
+        lo64, hi64 = shard_bounds(N64, world, rank)
+        sh64 = ShardedToyGraphBase(K64[lo64:hi64].contiguous(), torch.zeros(N64, 1, device=dev), torch.zeros(N64, 1, device=dev),
+                                   lo64, k, values_replicated=True)
+        got64_s, got64_i = sh64.topk(q64, k)
+        res["key_shard_topk_d64_equal"] = bool(torch.equal(got64_i, want64_i) and torch.equal(got64_s, want64_s))
+        if not res["key_shard_topk_d64_equal"]:
+            res["d64_detail"] = {"shapes": [list(got64_i.shape), list(want64_i.shape)], "dtypes": [str(got64_i.dtype), str(want64_i.dtype)],
+                                 "rows_differ": int((got64_i != want64_i).any(dim=1).sum()) if got64_i.shape == want64_i.shape else -1,
+                                 "scores_differ": int((got64_s != want64_s).any(dim=1).sum()) if got64_s.shape == want64_s.shape else -1}
+
         model.toy_graph_base = single
         model.query_shard = QueryShard()
         with torch.no_grad():
