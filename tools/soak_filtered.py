@@ -23,8 +23,9 @@ t0, n, n_over_total, kinds = time.time(), 0, 0, {}
 while time.time() - t0 < budget:
     D = (64, 128, 256)[ri(0, 2)]
     k = (1, 2, 3, 5, 10, 17, 32)[ri(0, 6)]
-    N = (ri(8192, 40000), ri(40000, 200000), ri(200000, 600000), 65536, 16384, 8192)[ri(0, 5)]
-    B = (ri(1, 40), ri(40, 300), ri(300, 3000), ri(3000, 20000), 256, 257, 512, 16384, 16385)[ri(0, 8)]
+    N = (ri(8192, 40000), ri(40000, 200000), ri(200000, 600000), 65536, 16384, 8192, 32768, 32767, 65535, ri(32768, 70000))[ri(0, 9)]
+    B = (ri(1, 40), ri(40, 300), ri(300, 3000), ri(3000, 20000), 256, 257, 512, 16384, 16385, 64, 65, 2047, 2048,
+         ri(2048, 6000))[ri(0, 13)]
     if B * N > 3e9:
         B = max(1, int(3e9 // N))
     kind = ri(0, 4)
