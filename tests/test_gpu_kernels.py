@@ -719,7 +719,7 @@ def test_topk_cosine_fused_overflow_zero_queries_and_dispatch(dev, monkeypatch):
                                             (128, 17000, 70000, 10, -1), (256, 17000, 66000, 32, -1), (64, 20000, 131072, 10, -1)])
 def test_topk_cosine_filtered_int8_levels_bit_exact(dev, monkeypatch, D, B, N, k, levels):
     """Filter levels on the INT8 copy (v_mfma_i32_16x16x64_i8, integer thresholds; csrc/filter_common.h): forced on every
-    level of small shapes (RAGRAPH_FILTER_I8), and the product rule -- the last level of a batch of more than 16384 queries --
+    level of small shapes (RAGRAPH_FILTER_I8), and the product rule -- whatever levels the schedule plans for the shape --
     as it stands (levels = -1).  Always the oracle's bits: exact duplicates, a query that is a stored key, a zero query
     (scale 0: everything passes, the exact scan answers), ragged tiles and banks."""
     from ragraph_amd import kernels as K
