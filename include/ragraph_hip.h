@@ -113,7 +113,8 @@ int ragraph_topk_cosine_bank_f32(const float* Q, int64_t B, const float* Kn, con
  *   overflow  device int, set by the call: number of queries whose candidate list exceeded its capacity
  *        (ragraph_topk_cosine_filtered_cap(k) keys per list; a batch of <= 64 queries keeps up to 8 such lists per query,
  *        one per rescoring workgroup) at some level; only possible on banks with thousands of keys within EPS
- *        of a query's k-th best (near-duplicate banks, zero queries).  The call itself recomputes those rows with an
+ *        of a query's k-th best (near-duplicate banks; all-zero queries, which are answered without a scan, may or may
+ *        not be counted).  The call itself recomputes those rows with an
  *        exact fp32 scan of the bank ON THE DEVICE (its last launch; an empty list on ordinary banks), so every row of
  *        the result is exact and nothing is read back: the call never synchronises and is HIP-graph capturable.  The
  *        count is diagnostic (a bank that sends many queries to the scan is better served by the fp32 kernels).

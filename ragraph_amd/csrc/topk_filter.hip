@@ -191,6 +191,9 @@ __global__ void __launch_bounds__(256) keys_to_i8_kernel(const float* __restrict
 // Everything a call needs before its first filter launch, in ONE launch (one wave per query): the normalised query row
 // (the norm tree, sqrt and divisions of normalize_rows_kernel, so the same bits), |dq| of its bf16 rounding, an empty
 // candidate list, a clear overflow flag, and -- before a bound pass -- the group maxima at -inf.
+constexpr int FILTER_FIX_MAX_Q = 1024;  // overflowed queries whose scan topk_overflow_fixup_kernel may cut into slices
+constexpr int FILTER_FIX_SLICES = 16;   // at most (16 x 32 partial winners: eight per lane of the merging wave)
+
 template <int D>
 __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restrict__ Q, int64_t B, float* __restrict__ Qn,
                                                           float* __restrict__ eq, int* __restrict__ count,
@@ -198,10 +201,11 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
                                                           int* __restrict__ gmax, int ngroups,
                                                           uint16_t* __restrict__ Qb, int cstride,
                                                           float* __restrict__ eq8, float* __restrict__ qscale,
-                                                          signed char* __restrict__ Qb8) {
+                                                          signed char* __restrict__ Qb8, int* __restrict__ fix_done) {
   const int lane = threadIdx.x & 63;
   const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q == 0 && lane == 0) *overflow = 0;
+  if (q < FILTER_FIX_MAX_Q && lane == 0) fix_done[q] = 0;  // tickets of topk_overflow_fixup_kernel
   if (q >= (Qb ? (B + 31) / 32 * 32 : B)) return;
   constexpr int NCH = D / 4;  // float4 chunks per row: 16 / 32 / 64 -- at most one per lane
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -272,7 +276,7 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
     // a ZERO query scores +0 against every key: within any bound of its k-th best, i.e. its lists can only overflow -- it
     // is flagged as overflowed from the start (nothing passes the filter for a flagged query: FilterThr::flag) and the
     // final level's scan path answers it without scanning (zero_query_answer)
-    flag[q] = am == 0u ? 1 : 0;
+    flag[q] = am == 0u ? 2 : 0;  // (2: a zero query -- the one-wave rescoring kernels answer it at the final level, uncounted)
     if (eq8) {
       eq8[q] = sqrtf(e8) * 1.000001f;
       qscale[q] = sq;
@@ -851,6 +855,19 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
 #endif
 }
 
+// flag[b] == 2 (filter_prep_kernel: a ZERO query).  Intermediate levels leave it alone (nothing passed for it; its running
+// result is never used); the final level writes its answer -- every score +0, the canonical order is the index order --
+// and the query is neither counted in *overflow nor listed for the scan.  Returns true when the wave is done with the query.
+__device__ __forceinline__ bool zero_query_level(unsigned char fl, int final_level, int k, int64_t idx_base, int lane,
+                                                 float* __restrict__ out_s, int64_t* __restrict__ out_i) {
+  if (fl != 2) return false;
+  if (final_level && lane < k) {
+    out_s[lane] = 0.f;
+    out_i[lane] = idx_base + lane;
+  }
+  return true;
+}
+
 // One wave per query.  prev_* (the previous level's exact top-k, local indices) may alias out_*.  A query whose list
 // overflowed (now or at an earlier level: flag) is appended to overflow_idx by the final level.  Most queries hold far
 // fewer candidates than the capacity: the slot count is a wave-uniform choice among 1, 2, 4, 8 and CPL.
@@ -869,8 +886,10 @@ __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restri
   if (lane < D / 4) qs[w][lane] = reinterpret_cast<const float4*>(Qn + b * D)[lane];  // the query row
   __builtin_amdgcn_wave_barrier();
   int n = count[b * cs];
-  bool over = flag[b] != 0;
+  const unsigned char fl = flag[b];
+  bool over = fl != 0;
   if (lane == 0 && n >= 0) count[b * cs] = 0;  // the next level starts from an empty list (ordered behind the read through n)
+  if (zero_query_level(fl, final_level, k, idx_base, lane, out_s + b * k, out_i + b * k)) return;
   if (n > cap) {  // slots reserved beyond the capacity: candidates were dropped
     over = true;
     n = cap;
@@ -919,12 +938,14 @@ __global__ void __launch_bounds__(128, FEWTILE ? 4 : 1) topk_rescore_coop_kernel
   if (b >= B) return;  // whole wave
   // (the count, the flag and the query row are independent loads: issued together, one latency)
   int n = count[b * cs];
-  bool over = flag[b] != 0;
+  const unsigned char fl = flag[b];
+  bool over = fl != 0;
   float4 qv4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (lane < D / 4) qv4 = reinterpret_cast<const float4*>(Qn + b * D)[lane];
   if (lane < D / 4) qs[w][lane] = qv4;
   __builtin_amdgcn_wave_barrier();
   if (lane == 0 && n >= 0) count[b * cs] = 0;  // the next level starts from an empty list (ordered behind the read through n)
+  if (zero_query_level(fl, final_level, k, idx_base, lane, out_s + b * k, out_i + b * k)) return;
   if (n > cap) {
     over = true;
     n = cap;
@@ -1139,12 +1160,14 @@ __global__ void __launch_bounds__(128) topk_rescore_scored_kernel(const float* _
   if (b >= B) return;  // whole wave
   // (the count, the flag and the query row are independent loads: issued together, one latency)
   int n = count[b * cs];
-  bool over = flag[b] != 0;
+  const unsigned char fl = flag[b];
+  bool over = fl != 0;
   float4 qv4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (lane < D / 4) qv4 = reinterpret_cast<const float4*>(Qn + b * D)[lane];
   if (lane < D / 4) qs[w][lane] = qv4;
   __builtin_amdgcn_wave_barrier();
   if (lane == 0 && n >= 0) count[b * cs] = 0;  // the next level starts from an empty list
+  if (zero_query_level(fl, final_level, k, idx_base, lane, out_s + b * k, out_i + b * k)) return;
   if (n > cap) {
     over = true;
     n = cap;
@@ -1434,24 +1457,79 @@ __global__ void __launch_bounds__(256) topk_rescore_wide_kernel(const float* __r
 // Large batches (the one-wave-per-query rescoring kernels): the final level has listed the overflowed queries, and this
 // launch -- a fixed grid that finds an empty list on ordinary banks and returns -- runs exact_scan_query for each.
 // (Below 2048 queries the workgroup-per-query rescoring kernels call it themselves and this launch is not made.)
+// The exact scan of the queries the final level could not serve, in ONE launch behind it (calls of 65 queries and more;
+// smaller ones scan inside their rescoring launch).  Few overflowed queries -- the usual case when there are any: a
+// tight cluster next to a handful of queries -- would leave the chip idle behind one workgroup per query (25 ms per
+// scan of 1M x 256 keys; 94 ms when the query's own rescoring wave did it), so a query's scan is cut into up to
+// FILTER_FIX_SLICES key slices (as many as keep ~256 workgroups busy), each workgroup leaves its slice's k winners in
+// part_s / part_i, and the query's last slice to finish (a ticket) merges them: 1.6 ms for one query.  Many overflowed
+// queries take one workgroup each as before.  A ZERO query is answered without a scan.
 template <int D>
 __global__ void __launch_bounds__(256) topk_overflow_fixup_kernel(const float* __restrict__ Qn, const float* __restrict__ Kn,
                                                                   int64_t N, int k, int64_t idx_base,
                                                                   const int* __restrict__ overflow,
                                                                   const int* __restrict__ overflow_list,
                                                                   int64_t* __restrict__ overflow_idx_out,
-                                                                  float* __restrict__ out_s, int64_t* __restrict__ out_i) {
+                                                                  float* __restrict__ out_s, int64_t* __restrict__ out_i,
+                                                                  int* __restrict__ done, float* __restrict__ part_s,
+                                                                  int64_t* __restrict__ part_i) {
   __shared__ float4 qs[D / 4];
   __shared__ __attribute__((aligned(16))) float tile[4][64 * RESCORE_LD];
   __shared__ float ps[4][32];
   __shared__ int64_t pi[4][32];
+  __shared__ int ticket_s;
   const int n_over = *overflow;
-  for (int o = blockIdx.x; o < n_over; o += gridDim.x) {
+  if (n_over <= 0) return;
+  int SL = 1;
+  if (n_over <= FILTER_FIX_MAX_Q)
+    while (SL < FILTER_FIX_SLICES && 2 * SL * n_over <= (int)gridDim.x) SL *= 2;
+  const int64_t chunk = ((N + SL - 1) / SL + 63) / 64 * 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int64_t item = blockIdx.x; item < (int64_t)n_over * SL; item += gridDim.x) {
+    const int o = (int)(item / SL), sl = (int)(item % SL);
     const int64_t b = overflow_list[o];
-    if (overflow_idx_out && threadIdx.x == 0) overflow_idx_out[o] = b;
+    if (overflow_idx_out && threadIdx.x == 0 && sl == 0) overflow_idx_out[o] = b;
+    __syncthreads();  // (the previous item's readers of qs)
     if (threadIdx.x < D / 4) qs[threadIdx.x] = reinterpret_cast<const float4*>(Qn + b * D)[threadIdx.x];
     __syncthreads();
-    exact_scan_query<D>(qs, Kn, N, k, idx_base, tile, ps, pi, out_s + b * k, out_i + b * k);
+    if (SL == 1) {
+      exact_scan_query<D>(qs, Kn, N, k, idx_base, tile, ps, pi, out_s + b * k, out_i + b * k);
+      continue;
+    }
+    const int64_t lo = sl * chunk, hi = lo + chunk < N ? lo + chunk : N;
+    float* my_s = part_s + ((int64_t)o * SL + sl) * 32;
+    int64_t* my_i = part_i + ((int64_t)o * SL + sl) * 32;
+    if (lo < hi) {
+      exact_scan_query<D>(qs, Kn + lo * D, hi - lo, k, lo, tile, ps, pi, my_s, my_i);   // (indices local to the bank)
+    } else if (threadIdx.x < k) {
+      my_s[threadIdx.x] = RG_NEG_INF;
+      my_i[threadIdx.x] = INT64_MAX;
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) ticket_s = atomicAdd(done + o, 1);
+    __syncthreads();
+    if (ticket_s != SL - 1) continue;  // (workgroup-uniform)
+    __threadfence();
+    if (w == 0) {  // the query's last slice: SL k <= 512 partial winners, eight slots per lane
+      float s8[8];
+      int id8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = lane + 64 * u;
+        s8[u] = RG_NEG_INF;
+        id8[u] = INT_MAX;
+        if (e < SL * k) {
+          const int64_t at = ((int64_t)o * SL + e / k) * 32 + e % k;
+          const int64_t pv = __builtin_nontemporal_load(part_i + at);
+          if (pv < INT_MAX) {
+            s8[u] = __builtin_nontemporal_load(part_s + at);
+            id8[u] = (int)pv;
+          }
+        }
+      }
+      wave_select<8>(s8, id8, k, lane, idx_base, out_s + b * k, out_i + b * k);
+    }
   }
 }
 
@@ -1986,6 +2064,9 @@ struct FilterWs {
   int* gmax;            // [B, FILTER_BOUND_PARTS_MAX] part maxima of the bound pass
   float* theta;         // [B] the first bound
   int* overflow_list;   // [B] queries the final level sends to the exact fallback
+  int* fix_done;        // [FILTER_FIX_MAX_Q] tickets, [.. x FILTER_FIX_SLICES x 32] partial winners of the sliced fallback scans
+  float* fix_s;
+  int64_t* fix_i;
   float* part_s;        // (B <= 64) sliced rescoring: [B][8][k] partial winners
   int* part_i;
   float* eq8;           // [B] |dq| of the int8 rounding, [B] the query's int8 scale (int8 levels)
@@ -2011,6 +2092,9 @@ static size_t filter_ws_carve(char* w, int64_t B, int D, int k, int cap, FilterW
   f.gmax = reinterpret_cast<int*>(take((size_t)B * filter_bound_parts(k, INT64_MAX, 256) * sizeof(int)));
   f.theta = reinterpret_cast<float*>(take((size_t)B * sizeof(float)));
   f.overflow_list = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
+  f.fix_done = reinterpret_cast<int*>(take((size_t)FILTER_FIX_MAX_Q * sizeof(int)));
+  f.fix_s = reinterpret_cast<float*>(take((size_t)FILTER_FIX_MAX_Q * FILTER_FIX_SLICES * 32 * sizeof(float)));
+  f.fix_i = reinterpret_cast<int64_t*>(take((size_t)FILTER_FIX_MAX_Q * FILTER_FIX_SLICES * 32 * sizeof(int64_t)));
   f.part_s = B <= 64 ? reinterpret_cast<float*>(take((size_t)B * 8 * k * sizeof(float))) : nullptr;
   f.part_i = B <= 64 ? reinterpret_cast<int*>(take((size_t)B * 8 * k * sizeof(int))) : nullptr;
   f.eq8 = reinterpret_cast<float*>(take((size_t)B * sizeof(float)));
@@ -2232,7 +2316,10 @@ static int run_rescore(const FilterWs& f, const float* Kn, int64_t N, int64_t B,
   const int cs = filter_count_stride(B);
   // mid-sized calls: an overflowed query is scanned by its own rescoring wave (no fallback launch); large batches keep
   // the dedicated launch, whose four-wave workgroups scan a bank faster when MANY queries overflow
-  const int64_t scan_n = B <= FILTER_SLAB_MAX_B ? N : 0;
+  // the one-wave-per-query kernels leave overflowed queries to topk_overflow_fixup_kernel (their own wave scanning a
+  // million keys took 94 ms; RAGRAPH_RESCORE_SCAN_IN_WAVE=1: the old behaviour, A/B)
+  static const bool scan_in_wave = [] { const char* e = getenv("RAGRAPH_RESCORE_SCAN_IN_WAVE"); return e && atoi(e) != 0; }();
+  const int64_t scan_n = scan_in_wave && B <= FILTER_SLAB_MAX_B ? N : 0;
   if (scored_thr) {  // (filter_scored_lists: a large call's int8 level)
     *fallback_done = scan_n > 0;
     hipLaunchKernelGGL((topk_rescore_scored_kernel<D>), dim3((unsigned)cdiv(B, 2)), dim3(128), 0, st, f.Qn, Kn, f.count,
@@ -2320,7 +2407,7 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   hipLaunchKernelGGL(filter_prep_kernel<D>, dim3((unsigned)cdiv(B <= FILTER_QB_MAX_B ? (B + 31) / 32 * 32 : B, 4)), dim3(256), 0, st, Q, B,
                      f.Qn, f.eq, f.count, f.flag, overflow, bound ? f.gmax : nullptr, bound ? filter_bound_parts(k, sc.bound_keys, D, B, exchange ? n_shards : 1) : k,
                      B <= FILTER_QB_MAX_B ? f.Qb : nullptr,
-                     filter_count_stride(B), sc.i8_levels > 0 ? f.eq8 : nullptr, f.qscale, B <= FILTER_QB_MAX_B ? f.Qb8 : nullptr);
+                     filter_count_stride(B), sc.i8_levels > 0 ? f.eq8 : nullptr, f.qscale, B <= FILTER_QB_MAX_B ? f.Qb8 : nullptr, f.fix_done);
   RG_CHECK_LAUNCH("topk_cosine_filtered(prepare)");
 
   FilterThr thr{};
@@ -2427,9 +2514,8 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   // overflowed queries (none on ordinary banks): exact fp32 scan on the device -- no host read-back (the sliced
   // rescoring of a handful of queries has done it inside its merge launch)
   if (fallback_done) return RAGRAPH_OK;
-  const int fix_grid = (int)(B < 256 ? B : 256);
-  hipLaunchKernelGGL(topk_overflow_fixup_kernel<D>, dim3((unsigned)fix_grid), dim3(256), 0, st, f.Qn, Kn, N, k, idx_base,
-                     overflow, f.overflow_list, overflow_idx, out_scores, out_idx);
+  hipLaunchKernelGGL(topk_overflow_fixup_kernel<D>, dim3(256), dim3(256), 0, st, f.Qn, Kn, N, k, idx_base,
+                     overflow, f.overflow_list, overflow_idx, out_scores, out_idx, f.fix_done, f.fix_s, f.fix_i);
   RG_CHECK_LAUNCH("topk_cosine_filtered(overflow fallback)");
   return RAGRAPH_OK;
 }

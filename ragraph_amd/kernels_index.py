@@ -17,6 +17,7 @@ class KeyIndex:
     # candidates per query.  Above this the levels stay on bf16; a bank that still overflows on int8 is caught by
     # _poll_overflow.
     I8_MAX_ERR = 0.02
+    OVERFLOW_FRACTION = 1.0 / 64   # of a call of >= 64 queries sent to the exact scan: the filter (level dtype) costs more than it saves
 
     def __init__(self, keys_normalized: torch.Tensor, ops=None):
         if ops is None:
@@ -36,8 +37,10 @@ class KeyIndex:
     def _poll_overflow(self):
         """The filtered call repairs overflowed rows on the device and reads nothing back; its count arrives here after
         the fact (pinned host word + event, polled without waiting).  A bank of near-duplicates (thousands of keys within
-        the bf16 bound of a query's k-th best) sends its queries to the exact fallback scan: still exact, but once a
-        quarter of a sizeable batch goes that way the filter only adds cost -- this bank version stays on fp32."""
+        the bound of a query's k-th best) sends its queries to the exact fallback scan: still exact, but a scan reads the
+        whole bank for ONE query (~0.2 ms of HBM time at 1M x 256 keys, 1.7 ms when it is the only one) where the fp32
+        kernels spend ~3.5 us more per query than the filter: beyond OVERFLOW_FRACTION of a batch the levels first leave
+        int8 (the bf16 bound is ~5x tighter), then the bank leaves the filter."""
         pend = self._pending
         if pend is None or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
             return  # (an event query is not a capturable call)
@@ -51,7 +54,7 @@ class KeyIndex:
         acc = self._seen_i8 if pend[3] else self._seen_bf16
         acc[0] += B
         acc[1] += n_over
-        if (B >= 64 and 4 * n_over > B) or (acc[0] >= 8 and 4 * acc[1] > acc[0]):
+        if (B >= 64 and n_over >= 2 and n_over > self.OVERFLOW_FRACTION * B) or (acc[0] >= 8 and 4 * acc[1] > acc[0]):
             if pend[3] and not self._i8_off:   # the call(s) had int8 levels: their wider bound is the first suspect
                 self._i8_off = True
             else:
