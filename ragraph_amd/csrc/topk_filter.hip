@@ -1335,6 +1335,13 @@ __global__ void __launch_bounds__(256) topk_rescore_wide_kernel(const float* __r
     over = over || flag[b] != 0;
     if (final_level && over) {  // (block-uniform) the exact scan right here: these calls need no fallback launch
       __syncthreads();          // every wave has read the counter
+      if (gridDim.x >= 65) {    // (calls of 65 queries and more: the fixup launch behind this one scans it -- in slices)
+        if (threadIdx.x == 0) {
+          count[b * cs] = 0;
+          overflow_list[atomicAdd(overflow, 1)] = (int)b;
+        }
+        return;
+      }
       if (threadIdx.x == 0) {
         atomicAdd(overflow, 1);
         count[b * cs] = 0;
@@ -2341,12 +2348,12 @@ static int run_rescore(const FilterWs& f, const float* Kn, int64_t N, int64_t B,
     }
 #endif
   } else if (B <= wide_coop_max_b) {  // one workgroup per CU: its 70 KB of tiles cost no occupancy
-    *fallback_done = 1;  // (the wide kernels answer an overflowed query themselves on the final level)
+    *fallback_done = B < 65;  // (up to 64 queries the wide kernels answer an overflowed query themselves on the final level)
     hipLaunchKernelGGL((topk_rescore_wide_kernel<D, false, true>), dim3((unsigned)B), dim3(256), 0, st, f.Qn, Kn, f.count, f.cand,
                        B, N, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag,
                        (float*)nullptr, (int*)nullptr);
   } else if (B < wide_max_b) {  // too few queries to fill the chip with one wave each
-    *fallback_done = 1;
+    *fallback_done = B < 65;
     hipLaunchKernelGGL((topk_rescore_wide_kernel<D, false, false>), dim3((unsigned)B), dim3(256), 0, st, f.Qn, Kn, f.count, f.cand,
                        B, N, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag,
                        (float*)nullptr, (int*)nullptr);
