@@ -23,7 +23,8 @@ def sparse_features(x: torch.Tensor, probe: bool = True):
     version (one count + one synchronisation; never while a HIP graph is being captured: an unjudged tensor is dense).
     probe=False only looks the tensor up: the encoder's entry points (PrePrompt) judge what they are GIVEN -- the
     dataset's features -- and the layers never probe their inputs, most of which are activations made anew (and at the
-    same address) every forward."""
+    same address) every forward.  The entry follows the tensor's version counter: features changed in place are judged
+    again, except through `.data` (which has a counter of its own) -- make a new tensor for new features."""
     if x.dim() == 3 and x.shape[0] == 1:
         x = x[0]
     if x.dim() != 2 or x.shape[1] < SPARSE_FEATURES_MIN_COLS or x.shape[1] > K.ROW_BLOCK or x.numel() == 0 or not x.is_cuda:
