@@ -20,8 +20,10 @@
 //      filter_schedule() below, readable through ragraph_topk_cosine_filtered_plan.
 // A query whose candidate list overflows its capacity (adversarial banks: thousands of keys within eps of the k-th
 // best) is recomputed by an exact fp32 scan of the bank ON THE DEVICE (exact_scan_query: inside the sliced rescoring
-// launch for <= 64 queries, topk_overflow_fixup_kernel otherwise); *overflow only counts those rows.  The call never
-// synchronises and reads nothing back.
+// launch for <= 64 queries; otherwise topk_overflow_fixup_kernel, one launch behind the last level that cuts the scans of
+// a few queries into key slices); *overflow only counts those rows.  The call never synchronises and reads nothing back.
+// Levels may run on an int8 copy of the bank instead (v_mfma_i32_16x16x64_i8, integer thresholds: filter_common.h), whose
+// candidate lists can carry the integer score that admitted each key (SCORED: topk_rescore_scored_kernel).
 //
 // Two filter kernels share one bank layout (filter_common.h: MFMA fragment order of v_mfma_f32_16x16x32_bf16):
 // topk_filter_direct_kernel (topk_filter_direct.hip) for up to 256 queries, and this file's RING kernel above that:
