@@ -1559,10 +1559,8 @@ static bool rescore_coop() {  // RAGRAPH_RESCORE_COOP=0: every lane reads its ow
 // k <= 16: round 1 is 16 rows and lists beyond 256 entries take the plain path -- 50 000 x 1M x 256 at k = 16: 14.5 / 13.7 ms,
 // k = 20: 15.6 / 15.8, k = 32: 18.7 / 20.3.
 static bool filter_scored_lists(int64_t B, int D, int k) {
-  static const int env = [] {
-    const char* e = getenv("RAGRAPH_FILTER_SCORED");
-    return e ? atoi(e) : -1;
-  }();
+  const char* env_s = getenv("RAGRAPH_FILTER_SCORED");  // (read per call: the tests switch it)
+  const int env = env_s ? atoi(env_s) : -1;
   // every call of the ring kernel (> 256 queries) ...: a scored list needs so few rows that ONE wave per query beats the
   // four-wave workgroups of the wide kernels even at a few hundred queries, whose single level admits ~380 candidates per
   // query and prunes 90 % of them (257 x 1M x 256: 0.214 -> 0.189 ms, 512: 0.267 -> 0.228, 1024: 0.436 -> 0.377, 1536: 0.580 ->
