@@ -241,3 +241,20 @@ def test_sharded_filtered_exchange_matches_single_gpu(dev, G, B, pool):
     assert torch.equal(mi, full_i) and torch.equal(ms, full_s)
     assert all(o[2] == 0 for o in out)
     assert phases and all(p0 == 0 for p0 in phases[:G])   # every shard went through the first-bound exchange
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tool,args", [("soak_filtered.py", ["8", "123"]), ("soak_filtered.py", ["8", "124", "index"]),
+                                       ("shard_soak.py", ["soak", "8", "125"]), ("soak_ops.py", ["8", "126"])])
+def test_randomised_soaks_short(dev, tool, args):
+    """A few seconds of each randomised parity soak (tools/): random shapes of the filtered top-k (the C entry and the
+    KeyIndex dispatch), of 2-8 emulated key shards, and of the dense / sparse / row kernels against the fp32 kernel / the
+    CPU oracle.  The long runs found what the fixed shapes had missed (DESIGN.md section 0, row "soak"); this keeps them
+    running.  (A child process: the soaks own their streams and threads.)"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", tool)] + args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok:" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
