@@ -65,6 +65,8 @@ def test_filtered_topk_plan_is_well_formed():
                     assert nlev == nl and 1 <= nl <= 3, (B, Nk, D, k)
                     assert k <= n0 <= Nk
                     assert ends[-1] == Nk and all(e % 256 == 0 for e in ends[:-1])
+                    if D == 64:  # a stage of the int8 copy holds 512 keys there: a level starts at a whole stage
+                        assert all(e % 512 == 0 for e in ends[:-1]), (B, Nk, k, ends)
                     assert all(a < b for a, b in zip(ends, ends[1:])) and (nl == 1 or n0 < ends[0])
                     if Nk >= 65536:  # the shapes KeyIndex sends here
                         prev = n0
@@ -84,6 +86,59 @@ def test_filtered_topk_plan_is_well_formed():
     # the bench shape keeps the three-level schedule the measurements in DESIGN.md describe
     assert L.ragraph_topk_cosine_filtered_plan(100_000, 1_000_000, 256, 10, plan) == 3
     assert list(plan) == [15625, 2, 3, 62720, 250880, 1_000_000, 18944]
+
+
+def test_sharded_workspace_covers_both_schedules():
+    """The sharded entry plans for (plan_N, n_shards); its workspace size covers that schedule AND the single bank's (a
+    NULL exchange runs the latter), for every shard count."""
+    from ragraph_amd import _native as N
+
+    L = N.lib()
+    for B in (40, 300, 3000, 20000, 100_000):
+        for Nk in (30_000, 125_000, 500_000, 1_000_000):
+            for D in (64, 256):
+                single = L.ragraph_topk_cosine_filtered_workspace_bytes(B, Nk, D, 10)
+                for G in (1, 2, 3, 8):
+                    sharded = L.ragraph_topk_cosine_filtered_sharded_workspace_bytes(B, Nk, D, 10, G)
+                    assert sharded >= single > 0, (B, Nk, D, G)
+    assert L.ragraph_topk_cosine_filtered_sharded_workspace_bytes(10, 1000, 100, 3, 2) == 0  # unsupported D
+
+
+def test_key_index_overflow_policy_on_host():
+    """KeyIndex judges a bank by what its overflowed queries cost (kernels_index.py): more than 1/64 of a call of >= 64
+    queries (and at least two) takes the levels off int8 first, then the bank off the filter; a handful of queries per
+    call are judged cumulatively (a quarter of at least eight); ordinary counts change nothing."""
+    import torch
+
+    from ragraph_amd.kernels_index import KeyIndex
+
+    class Done:
+        def query(self):
+            return True
+
+    def poll(idx, n_over, B, had_i8):
+        idx._pending = (torch.tensor([n_over], dtype=torch.int32), Done(), B, had_i8)
+        idx._poll_overflow()
+
+    idx = KeyIndex(torch.zeros(4, 8), ops=object())
+    poll(idx, 1, 100_000, True)          # one query of a large call: nothing
+    poll(idx, 1500, 100_000, True)       # 1.5 %: below 1/64
+    assert not idx._i8_off and not idx._filter_off
+    poll(idx, 1600, 100_000, True)       # above 1/64 on int8 levels: int8 goes first
+    assert idx._i8_off and not idx._filter_off
+    poll(idx, 1600, 100_000, False)      # ... and on bf16 levels the filter
+    assert idx._filter_off
+    idx = KeyIndex(torch.zeros(4, 8), ops=object())
+    poll(idx, 1, 64, True)               # a single query never decides
+    assert not idx._i8_off
+    poll(idx, 2, 64, True)
+    assert idx._i8_off and not idx._filter_off
+    idx = KeyIndex(torch.zeros(4, 8), ops=object())
+    for _ in range(7):
+        poll(idx, 1, 1, False)           # one query per forward, every one overflowing: judged over eight of them
+    assert not idx._filter_off
+    poll(idx, 1, 1, False)
+    assert idx._filter_off and idx.overflowed_queries == 8
 
 
 def test_filtered_dispatch_rule():
