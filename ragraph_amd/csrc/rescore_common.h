@@ -128,20 +128,24 @@ constexpr int RESCORE_LD = 68;  // floats per staged row: 16-B aligned, and 16 l
 // covers four rows x 256 B (16 lanes per row, coalesced) instead of one 16-B piece of 64 different rows, which is what
 // the texture path's line rate pays for; the 64 x 64-float block goes through the wave's LDS tile and every lane then
 // runs its own candidate's fmaf chain over it in natural order -- the same chain, so the same bits.
-template <int D>
+// ROWS = 32: candidates in lanes 0..31 only, a tile of 32 rows (half the LDS and half the load registers: the scored
+// rescoring of large calls, whose second round is ~25 rows, runs three waves per SIMD with it instead of two).
+template <int D, int ROWS = 64>
 __device__ __forceinline__ float coop_scores(const float4* __restrict__ qrow, const float* __restrict__ Kn, int key,
                                              int lane, float* sm) {
+  static_assert(ROWS == 64 || ROWS == 32, "whole or half tiles");
+  constexpr int NT = ROWS / 4;  // load instructions per 64-float block: four rows x 256 B each
   float acc = 0.f;
   const int rr = lane >> 4, cc = lane & 15;
   constexpr int NDC = D / 64;
-  // the next 64-float block's sixteen loads are in flight while this one is staged and consumed: a wave's chain is one
+  // the next 64-float block's loads are in flight while this one is staged and consumed: a wave's chain is one
   // memory latency per list, not one per block (the kernel runs eight waves per CU and lives on latency hiding)
-  int krow[16];
+  int krow[NT];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) krow[t] = __shfl(key, 4 * t + rr);
-  float4 v[16];
+  for (int t = 0; t < NT; ++t) krow[t] = __shfl(key, 4 * t + rr);
+  float4 v[NT];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
+  for (int t = 0; t < NT; ++t) {
     v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (krow[t] >= 0) v[t] = *reinterpret_cast<const float4*>(Kn + (int64_t)krow[t] * D + cc * 4);
   }
@@ -149,10 +153,10 @@ __device__ __forceinline__ float coop_scores(const float4* __restrict__ qrow, co
   for (int dc = 0; dc < NDC; ++dc) {
     __builtin_amdgcn_wave_barrier();  // (single wave: LDS executes its requests in order; only the compiler must not reorder)
 #pragma unroll
-    for (int t = 0; t < 16; ++t) *reinterpret_cast<float4*>(sm + (4 * t + rr) * RESCORE_LD + cc * 4) = v[t];
+    for (int t = 0; t < NT; ++t) *reinterpret_cast<float4*>(sm + (4 * t + rr) * RESCORE_LD + cc * 4) = v[t];
     if (dc + 1 < NDC) {
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
+      for (int t = 0; t < NT; ++t) {
         v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (krow[t] >= 0) v[t] = *reinterpret_cast<const float4*>(Kn + (int64_t)krow[t] * D + cc * 4 + (dc + 1) * 64);
       }
@@ -160,14 +164,16 @@ __device__ __forceinline__ float coop_scores(const float4* __restrict__ qrow, co
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (ROWS == 64 || lane < ROWS) {
 #pragma unroll
-    for (int e4 = 0; e4 < 16; ++e4) {
-      const float4 kv = *reinterpret_cast<const float4*>(sm + lane * RESCORE_LD + e4 * 4);
-      const float4 qv = qrow[dc * 16 + e4];
-      acc = fmaf(qv.x, kv.x, acc);
-      acc = fmaf(qv.y, kv.y, acc);
-      acc = fmaf(qv.z, kv.z, acc);
-      acc = fmaf(qv.w, kv.w, acc);
+      for (int e4 = 0; e4 < 16; ++e4) {
+        const float4 kv = *reinterpret_cast<const float4*>(sm + lane * RESCORE_LD + e4 * 4);
+        const float4 qv = qrow[dc * 16 + e4];
+        acc = fmaf(qv.x, kv.x, acc);
+        acc = fmaf(qv.y, kv.y, acc);
+        acc = fmaf(qv.z, kv.z, acc);
+        acc = fmaf(qv.w, kv.w, acc);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

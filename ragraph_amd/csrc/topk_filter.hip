@@ -1002,7 +1002,7 @@ __device__ __forceinline__ bool pair_gt(unsigned ah, unsigned al, unsigned bh, u
 }
 // Returns false (nothing written) when more than 64 round-2 entries beat round 1's k-th pair: the caller then scores
 // the whole list the plain way (a level whose first bound was useless; rare).
-template <int D, int NS>
+template <int D, int NS, int ROWS = 64>
 __device__ __forceinline__ bool rescore_scored_query(const float4* __restrict__ qrow, const float* __restrict__ Kn,
                                                      const int2* __restrict__ cb, int n, int lane, int k, int64_t base,
                                                      const float* prev_s, const int64_t* prev_i, float* out_s, int64_t* out_i,
@@ -1090,10 +1090,10 @@ __device__ __forceinline__ bool rescore_scored_query(const float4* __restrict__ 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int c0 = 0; c0 < ns; c0 += 64) {
+    for (int c0 = 0; c0 < ns; c0 += ROWS) {  // (ROWS = 32: the half tile of the large calls' kernel)
       const int c = c0 + lane;
-      const int kk = c < ns ? surv[c] : -1;
-      const float acc = ns - c0 <= 16 ? coop_scores_few<D>(qrow, Kn, kk, lane, sm) : coop_scores<D>(qrow, Kn, kk, lane, sm);
+      const int kk = (lane < ROWS && c < ns) ? surv[c] : -1;
+      const float acc = ns - c0 <= 16 ? coop_scores_few<D>(qrow, Kn, kk, lane, sm) : coop_scores<D, ROWS>(qrow, Kn, kk, lane, sm);
       const unsigned sh = select_ord(acc), sl = ~(unsigned)kk;
       const bool beats = kk >= 0 && pair_gt(sh, sl, kh, kl);
       const unsigned long long bm = __ballot(beats);
@@ -1145,7 +1145,10 @@ __device__ __forceinline__ bool rescore_scored_query(const float4* __restrict__ 
   return true;
 }
 
-template <int D>
+// SMALL (calls of 8192 queries and more, whose lists average ~120 entries and whose second round ~25 rows): half tiles and
+// at most four entry slots per lane -- 15 KB less LDS per workgroup and ~50 fewer registers, three waves per SIMD instead
+// of two for a kernel that lives on hiding row-gather latency; the few longer lists take lane-private row reads.
+template <int D, bool SMALL = false>
 __global__ void __launch_bounds__(128) topk_rescore_scored_kernel(const float* __restrict__ Qn, const float* __restrict__ Kn,
                                                                   int* __restrict__ count, const int2* __restrict__ cand,
                                                                   int64_t B, int cap, int cs, int k, int64_t idx_base,
@@ -1153,8 +1156,9 @@ __global__ void __launch_bounds__(128) topk_rescore_scored_kernel(const float* _
                                                                   float* out_s, int64_t* out_i, int* __restrict__ overflow,
                                                                   int* __restrict__ overflow_list,
                                                                   unsigned char* __restrict__ flag, int64_t scan_n, FilterThr thr) {
+  constexpr int ROWS = SMALL ? 32 : 64;
   __shared__ float4 qs[2][D / 4];
-  __shared__ __attribute__((aligned(16))) float tile[2][64 * RESCORE_LD];
+  __shared__ __attribute__((aligned(16))) float tile[2][ROWS * RESCORE_LD];
   __shared__ int surv[2][256];
   __shared__ int stage[2][128];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1195,15 +1199,17 @@ __global__ void __launch_bounds__(128) topk_rescore_scored_kernel(const float* _
   const int2* cb = cand + b * cap;
   const int* ck = reinterpret_cast<const int*>(cb);
 #define RG_SCORED(NS_) \
-  rescore_scored_query<D, NS_>(qs[w], Kn, cb, n, lane, k, base, ps, pi, out_s + b * k, out_i + b * k, tile[w], surv[w], stage[w], \
-                               thr, b)
+  rescore_scored_query<D, NS_, ROWS>(qs[w], Kn, cb, n, lane, k, base, ps, pi, out_s + b * k, out_i + b * k, tile[w], surv[w], \
+                                     stage[w], thr, b)
   bool done = false;
   if (n > 24) {  // (round 1 alone would take most of a shorter list)
     if (n <= 64) done = RG_SCORED(1);
     else if (n <= 128) done = RG_SCORED(2);
     else if (n <= 256) done = RG_SCORED(4);
-    else if (n <= 512) done = RG_SCORED(8);  // (the single level of a few hundred queries admits ~400 each and prunes 90 %)
-    else if (n <= 1024) done = RG_SCORED(16);
+    else if constexpr (!SMALL) {
+      if (n <= 512) done = RG_SCORED(8);  // (the single level of a few hundred queries admits ~400 each and prunes 90 %)
+      else if (n <= 1024) done = RG_SCORED(16);
+    }
   }
 #undef RG_SCORED
   if (done) return;
@@ -1211,9 +1217,9 @@ __global__ void __launch_bounds__(128) topk_rescore_scored_kernel(const float* _
 #define RG_PLAIN(NS_, COOP_, FEW_) \
   rescore_query<D, NS_, COOP_, FEW_, 2>(qs[w], Kn, ck, n, lane, k, base, ps, pi, out_s + b * k, out_i + b * k, tile[w])
   if (n <= 16) RG_PLAIN(1, true, true);
-  else if (n <= 64) RG_PLAIN(1, true, false);
-  else if (n <= 128) RG_PLAIN(2, true, false);
-  else if (n <= 256) RG_PLAIN(4, true, false);
+  else if (n <= 64) RG_PLAIN(1, !SMALL, false);   // (the half tile holds no 64-row batch: lane-private row reads)
+  else if (n <= 128) RG_PLAIN(2, !SMALL, false);
+  else if (n <= 256) RG_PLAIN(4, !SMALL, false);
   else if (n <= 512) RG_PLAIN(8, false, false);   // long plain lists are rare: lane-private row reads
   else if (n <= 1024) RG_PLAIN(16, false, false);
   else RG_PLAIN(32, false, false);
@@ -2329,9 +2335,15 @@ static int run_rescore(const FilterWs& f, const float* Kn, int64_t N, int64_t B,
   const int64_t scan_n = scan_in_wave && B <= FILTER_SLAB_MAX_B ? N : 0;
   if (scored_thr) {  // (filter_scored_lists: a large call's int8 level)
     *fallback_done = scan_n > 0;
-    hipLaunchKernelGGL((topk_rescore_scored_kernel<D>), dim3((unsigned)cdiv(B, 2)), dim3(128), 0, st, f.Qn, Kn, f.count,
-                       reinterpret_cast<const int2*>(f.cand), B, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx,
-                       overflow, f.overflow_list, f.flag, scan_n, *scored_thr);
+    static const bool small_env = [] { const char* e = getenv("RAGRAPH_RESCORE_SCORED_SMALL"); return !e || atoi(e) != 0; }();  // A/B
+    if (B >= 8192 && small_env)
+      hipLaunchKernelGGL((topk_rescore_scored_kernel<D, true>), dim3((unsigned)cdiv(B, 2)), dim3(128), 0, st, f.Qn, Kn, f.count,
+                         reinterpret_cast<const int2*>(f.cand), B, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx,
+                         overflow, f.overflow_list, f.flag, scan_n, *scored_thr);
+    else
+      hipLaunchKernelGGL((topk_rescore_scored_kernel<D, false>), dim3((unsigned)cdiv(B, 2)), dim3(128), 0, st, f.Qn, Kn, f.count,
+                         reinterpret_cast<const int2*>(f.cand), B, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx,
+                         overflow, f.overflow_list, f.flag, scan_n, *scored_thr);
   } else if (B < wide_max_b && S > 1) {
     hipLaunchKernelGGL((topk_rescore_wide_kernel<D, true, true>), dim3((unsigned)B, (unsigned)S), dim3(256), 0, st, f.Qn, Kn, f.count,
                        f.cand, B, N, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list,
