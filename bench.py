@@ -233,6 +233,63 @@ def small_batch_rates(tgb, dim, k, dev):
     return out
 
 
+def reference_bank_rates(args, dev, adj, feats, batches=(1, 500, 100_000), dedup=True, reps=None):
+    """Retrieval against a bank shaped like the reference's OWN banks instead of SURVEY section 8(d)'s Gaussian one:
+    args.bank rows made by the reference's recipe (ragraph_amd.bank_build.build_reference_recipe_bank: ToyGraphBase.py:91-119
+    over synthetic resource graphs with the query graph's feature distribution, an encoder with a non-zero bias as after
+    pre-training) -- three quarters of the rows are one vector (Augmentation.py:9-20 zeroes the augmented passes'
+    features) and the sampled rows repeat (multinomial with replacement).  Queries = the bench graph's node embeddings by
+    the same encoder.  Through the product dispatch (KeyIndex: exact duplicates collapsed, winners expanded in canonical
+    order); 64 rows of the largest batch are checked against the fp32 kernel over every row (bits)."""
+    from ragraph_amd import kernels as K
+    from ragraph_amd.bank_build import build_reference_recipe_bank
+    from ragraph_amd.preprompt import PrePrompt
+
+    state = torch.random.get_rng_state()
+    torch.manual_seed(1)
+    pre = PrePrompt(args.feat, args.dim, "prelu", 1, 0.3).to(dev)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        pre.gcn.convs[0].bias.normal_(0, 0.1)
+        tgb = build_reference_recipe_bank(pre, args.bank, args.feat, args.classes, args.dim, device=dev)
+        h = pre.inference(feats, adj)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    torch.random.set_rng_state(state)
+    kn = tgb.keys_normalized
+    index = K.KeyIndex(kn, dedup=dedup)
+    out = {"bank_rows": int(kn.shape[0]), "bank_build_s": round(build_s, 2)}
+    for B in batches:
+        B = min(B, h.shape[0])
+        q = h[:B].contiguous()
+        for _ in range(3):          # (overflow counts arrive one call late: let the dispatch settle before timing)
+            s, i = index.topk(q, args.k)
+            torch.cuda.synchronize()
+        n = reps or (3 if B > 4096 else 20)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            s, i = index.topk(q, args.k)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        inner = index.search_index
+        out[f"B{B}"] = {"ms": round(ms, 4), "queries_per_s": round(B / ms * 1e3, 1),
+                        "filter": "off (fp32 kernels)" if inner._filter_off or not K.filter_helps(B, inner.keys_normalized.shape[0], args.dim, args.k)
+                        else ("bf16 levels" if inner._i8_off or not inner._i8_ok else "int8 levels")}
+    rows = torch.linspace(0, B - 1, min(64, B), device=dev).long()
+    s32, i32 = K.topk_cosine(q[rows].contiguous(), kn, args.k)
+    if not (torch.equal(i[rows], i32) and torch.equal(s[rows], s32)):
+        raise SystemExit("bench.py: retrieval on the reference-shaped bank differs from the fp32 kernel over every row")
+    top_is_copy = float((i[:, args.k - 1] - i[:, 0] == args.k - 1).float().mean()) if args.k > 1 else 0.0
+    if index.duplicate_stats is not None:
+        out.update(unique_rows=index.duplicate_stats[1], largest_group=index.duplicate_stats[2])
+    out.update(collapsed=bool(index._collapsed), overflowed_queries=index.overflowed_queries,
+               verified_rows_vs_fp32_kernel=int(rows.numel()),
+               queries_answered_by_k_consecutive_rows=round(top_is_copy, 4))
+    return out
+
+
 def cpu_baseline(args, model, feats, adj):
     """The reference's op chain on the host cores (oracle/ref_torch.py), BASELINE.md section 3: GNN part on the whole
     graph (sparse CSR: the reference's dense adjacency would be 40 GB); retrieval exactly as the reference computes it
@@ -554,6 +611,7 @@ def main():
         result["gnn_fwd_nodes_per_s"] = round(gnn_only_rate(model, feats, adj, max(args.steps, 3)), 1)
         K.filter_helps = real_filter_helps
         result["retrieval_small_batch"] = small_batch_rates(model.toy_graph_base, args.dim, args.k, dev)
+        result["retrieval_reference_bank"] = reference_bank_rates(args, dev, adj, feats)
         if not args.exact_fp32:
             # the same step on the fp32 MFMA kernels alone (the path the bf16 filter replaces bit for bit)
             K.filter_helps = lambda *a, **kw: False

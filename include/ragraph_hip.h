@@ -216,6 +216,36 @@ int ragraph_topk_merge_f32(const float* scores, const int64_t* idx, int G, int64
                            int64_t* out_idx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * a3  banks of duplicates  -- the reference's own bank recipe makes most rows bit-identical:
+ *     RAGraph_node/ragraph_utils/ToyGraphBase.py:91-119 appends 1 + num_augment_scale passes per resource graph, :98 draws
+ *     a pass's rows WITH replacement, and Augmentation.py:9-20 multiplies the augmented passes' features by
+ *     bernoulli(sample_prob * 0.01) (zero for nearly every node), so those passes store normalize(PReLU(bias)) over and
+ *     over.  The search runs over one representative per group of identical rows; the winners are expanded afterwards.
+ *
+ * ragraph_dedup_rows_f32: groups the BIT-identical rows of Kn [N,D] (N < 2^31).
+ *   stats      [2] int64: number of groups U, size of the largest group;
+ *   uniq_row   [N] int64: entries 0..U-1 = the lowest row of every group, ascending (Kn[uniq_row[:U]] = the unique bank);
+ *   group_ptr  [N+1] int32: group u's rows are members[group_ptr[u] .. group_ptr[u+1]) (entries beyond U equal N);
+ *   members    [N] int32: every group's rows in ascending order.
+ *   A 64-bit row hash orders the rows (stable radix sort); rows are merged only after a bit-by-bit comparison, so the
+ *   grouping never depends on the hash being collision-free (a collision can split a group in two; the expansion below
+ *   is correct for any partition into groups of identical rows).  Asynchronous; the caller reads `stats` when it needs U.
+ *
+ * ragraph_topk_expand_groups_f32: the canonical top-k of the bank from the canonical top-ku (ku = min(k, U)) of the unique
+ *   rows: scores_u / idx_u [B,ku] (idx_u - idx_base_u = group number; entries outside [0,U) -- the -inf / INT64_MAX padding
+ *   of a shard's list -- are empty groups) -> out_scores / out_idx [B,k] (bank rows + idx_base), score descending then row
+ *   ascending; groups whose scores tie are merged by row; fewer than k rows in all: padded with -inf / INT64_MAX.
+ *   Identical rows have identical scores (one fmaf chain over the same bits), so the result has the bits of the search
+ *   over all N rows.  ku <= 64, k <= RAGRAPH_TOPK_MAX.
+ */
+size_t ragraph_dedup_rows_workspace_bytes(int64_t N);
+int ragraph_dedup_rows_f32(const float* Kn, int64_t N, int D, int64_t* stats, int64_t* uniq_row, int32_t* group_ptr,
+                           int32_t* members, void* ws, size_t ws_bytes, void* stream);
+int ragraph_topk_expand_groups_f32(const float* scores_u, const int64_t* idx_u, int ku, int64_t idx_base_u,
+                                   const int32_t* group_ptr, const int32_t* members, int64_t U, int64_t B, int k,
+                                   int64_t idx_base, float* out_scores, int64_t* out_idx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * a2  value/label gather  -- ToyGraphBase.py:70-71  resource_values[topk_indices], resource_labels[topk_indices]
  *     out[m,:] = V[idx[m] - idx_base, :] for m in [0,M); rows with idx outside [idx_base, idx_base+N) are written
  *     as zeros (lets each shard gather only the winners it owns; a sum over shards completes it).  Any D >= 1.

@@ -97,6 +97,46 @@ def topk_merge(scores, idx):
     return s, i
 
 
+def dedup_rows(Kn):
+    """Groups of BIT-identical rows (ragraph_dedup_rows_f32): (U, largest group, uniq_row [U] = every group's lowest row,
+    ascending; group_ptr [U+1] int32; members [N] int32, every group's rows ascending)."""
+    Kn = _f32(Kn)
+    N = Kn.shape[0]
+    rows = np.ascontiguousarray(Kn).view(np.uint32).reshape(N, -1)
+    _, first, inverse = np.unique(rows, axis=0, return_index=True, return_inverse=True)
+    inverse = inverse.reshape(-1)
+    order = np.argsort(first, kind="stable")              # groups numbered by their lowest row
+    rank = np.empty_like(order)
+    rank[order] = np.arange(order.size)
+    gid = rank[inverse]
+    U = order.size
+    counts = np.bincount(gid, minlength=U)
+    group_ptr = np.zeros(U + 1, dtype=np.int32)
+    group_ptr[1:] = np.cumsum(counts)
+    members = np.argsort(gid, kind="stable").astype(np.int32)   # stable: ascending rows inside a group
+    return U, int(counts.max()), first[order].astype(np.int64), group_ptr, members
+
+
+def topk_expand_groups(scores_u, idx_u, group_ptr, members, k, idx_base=0, idx_base_u=0):
+    """ragraph_topk_expand_groups_f32: every listed group's rows with the group's score, sorted in canonical order (score
+    descending, row ascending), the first k; padded with -inf / INT64_MAX."""
+    scores_u, idx_u = _f32(scores_u), _i64(idx_u)
+    B, ku = scores_u.shape
+    U = group_ptr.shape[0] - 1
+    out_s = np.full((B, k), -np.inf, dtype=np.float32)
+    out_i = np.full((B, k), np.iinfo(np.int64).max, dtype=np.int64)
+    for b in range(B):
+        cand = []
+        for j in range(ku):
+            u = int(idx_u[b, j]) - idx_base_u
+            if 0 <= u < U:
+                cand += [(scores_u[b, j], int(r)) for r in members[group_ptr[u]:group_ptr[u + 1]][:k]]
+        cand.sort(key=lambda t: (-t[0], t[1]))
+        for r, (sc, row) in enumerate(cand[:k]):
+            out_s[b, r], out_i[b, r] = sc, row + idx_base
+    return out_s, out_i
+
+
 def gather_rows(V, idx, idx_base=0):
     V, idx = _f32(V), _i64(idx)
     N, D = V.shape

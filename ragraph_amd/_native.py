@@ -55,6 +55,9 @@ SIGNATURES = {
     "ragraph_theta_sharpen_f32": (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "ragraph_topk_cosine_bank_f32": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _sz, _vp]),
     "ragraph_topk_merge_f32": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
+    "ragraph_dedup_rows_workspace_bytes": (_sz, [_i64]),
+    "ragraph_dedup_rows_f32": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ragraph_topk_expand_groups_f32": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _i64, _i64, _i32, _i64, _vp, _vp, _vp]),
     "ragraph_gather_rows_f32": (_i32, [_vp, _i64, _i32, _vp, _i64, _i64, _vp, _vp]),
     "ragraph_gather_reduce_f32": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp, _i64, _i32, _i64, _f32, _vp, _vp, _vp]),
     "ragraph_linear_f32": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _i32, _f32, _vp, _vp]),

@@ -156,3 +156,22 @@ def _blocks_to_csr(blocks: torch.Tensor) -> CSRGraph:
     rowptr = torch.zeros(G * S + 1, dtype=torch.int64, device=blocks.device)
     rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=G * S), 0)
     return CSRGraph(rowptr, cols.to(torch.int32), blocks[nz[:, 0], nz[:, 1], nz[:, 2]].contiguous(), G * S)
+
+
+def build_reference_recipe_bank(pretrain_model, n_rows: int, num_node_attributes: int, num_class: int, emb_size: int,
+                                query_graph_hop: int = 3, seed: int = 21, device="cuda", attr_dist: str = "normal"):
+    """A node-flavour bank of n_rows rows made by the reference's OWN recipe (ToyGraphBase.py:40-45,91-119 through
+    build_toy_graph above) over synthetic resource graphs: per graph one original pass + num_augment_scale = 3 augmented
+    passes of num_inverse_sample = 10 rows drawn with replacement.  The augmented passes see features multiplied by
+    bernoulli(sample_prob * 0.01) (Augmentation.py:17-18) -- zero for practically every node -- so their rows are all
+    normalize(PReLU(bias)): three quarters of such a bank are copies of one vector, and the sampled rows repeat as well.
+    Measurement and test input (bench.py `retrieval_reference_bank`, tests/test_gpu_fullsize.py); returns the ToyGraphBase."""
+    from .data import synthetic_tu_dataset
+    from .ragraph_utils.ToyGraphBase import ToyGraphBase
+
+    tgb = ToyGraphBase(pretrain_model, num_class, emb_size, query_graph_hop, device=device, flavour="node")
+    per_graph = (1 + tgb.num_augment_scale) * tgb.num_inverse_sample
+    ds = synthetic_tu_dataset(num_graphs=-(-n_rows // per_graph), num_node_attributes=num_node_attributes,
+                              num_node_labels=num_class, seed=seed, attr_dist=attr_dist)
+    build_toy_graph(tgb, ds)
+    return tgb

@@ -87,8 +87,9 @@ class DataLoader:
 
 # ---- synthetic generators (deterministic per seed) -----------------------------------------------------------------
 def synthetic_tu_dataset(num_graphs=64, num_node_attributes=18, num_node_labels=3, num_classes=2, min_nodes=10,
-                         max_nodes=80, mean_degree=3.7, seed=9, name="SYNTH_TU") -> GraphDataset:
-    """TU-shaped graphs (ENZYMES: 18 attrs + 3 one-hot node labels; PROTEINS: 1 + 3), sizes ~U[min,max]."""
+                         max_nodes=80, mean_degree=3.7, seed=9, name="SYNTH_TU", attr_dist="uniform") -> GraphDataset:
+    """TU-shaped graphs (ENZYMES: 18 attrs + 3 one-hot node labels; PROTEINS: 1 + 3), sizes ~U[min,max].  attr_dist:
+    "uniform" [0, 1) attributes (TU-like) or "normal" (the feature distribution of bench.py's query graph)."""
     rng = np.random.default_rng(seed)
     graphs = []
     for _ in range(num_graphs):
@@ -99,7 +100,8 @@ def synthetic_tu_dataset(num_graphs=64, num_node_attributes=18, num_node_labels=
         keep = src != dst
         und = np.unique(np.stack([np.minimum(src, dst)[keep], np.maximum(src, dst)[keep]], 1), axis=0)
         ei = np.concatenate([und, und[:, ::-1]], 0).T                                   # both directions, once each
-        attrs = rng.random((n, num_node_attributes), dtype=np.float32)
+        attrs = (rng.random((n, num_node_attributes), dtype=np.float32) if attr_dist == "uniform" else
+                 rng.standard_normal((n, num_node_attributes), dtype=np.float32))
         nl = np.eye(num_node_labels, dtype=np.float32)[rng.integers(0, num_node_labels, n)]
         graphs.append(Data(torch.from_numpy(np.concatenate([attrs, nl], 1)), torch.from_numpy(ei.copy()).long(),
                            torch.tensor([int(rng.integers(0, num_classes))])))

@@ -354,6 +354,45 @@ def topk_merge(scores: torch.Tensor, idx: torch.Tensor):
     return out_s, out_i
 
 
+def dedup_rows(keys_normalized: torch.Tensor):
+    """Groups of bit-identical bank rows (ragraph_dedup_rows_f32; the reference's bank recipe stores most rows several
+    hundred thousand times over, ToyGraphBase.py:91-119 + Augmentation.py:9-20).  Returns (U, largest group, uniq_row [U]
+    int64 = every group's lowest row, ascending; group_ptr [U+1] int32; members [N] int32 = the groups' rows, ascending).
+    Reads the two counts back: ONE synchronisation, for the owner of a bank version (KeyIndex)."""
+    L = _ready()
+    kn = _f32c(keys_normalized, "dedup_rows.keys")
+    Nk, D = kn.shape
+    dev = kn.device
+    stats = torch.empty(2, dtype=torch.int64, device=dev)
+    uniq_row = torch.empty(Nk, dtype=torch.int64, device=dev)
+    group_ptr = torch.empty(Nk + 1, dtype=torch.int32, device=dev)
+    members = torch.empty(Nk, dtype=torch.int32, device=dev)
+    nbytes = L.ragraph_dedup_rows_workspace_bytes(Nk)
+    if nbytes == 0:
+        raise RagraphNativeError(f"dedup_rows: unsupported bank of {Nk} rows")
+    ws = _workspace(nbytes, dev)
+    N.check(L.ragraph_dedup_rows_f32(kn.data_ptr(), Nk, D, stats.data_ptr(), uniq_row.data_ptr(), group_ptr.data_ptr(),
+                                     members.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "dedup_rows")
+    U, largest = (int(x) for x in stats.tolist())
+    return U, largest, uniq_row[:U], group_ptr[:U + 1], members
+
+
+def topk_expand_groups(scores_u: torch.Tensor, idx_u: torch.Tensor, group_ptr: torch.Tensor, members: torch.Tensor, k: int,
+                       idx_base: int = 0, idx_base_u: int = 0):
+    """Canonical top-k of a bank from the canonical top-ku of its unique rows (dedup_rows): [B,ku] -> [B,k], same bits
+    as the search over every row (ragraph_topk_expand_groups_f32)."""
+    L = _ready()
+    su = _f32c(scores_u, "topk_expand_groups.scores")
+    iu = _idxc(idx_u, "topk_expand_groups.idx")
+    B, ku = su.shape
+    out_s = torch.empty((B, k), dtype=torch.float32, device=su.device)
+    out_i = torch.empty((B, k), dtype=torch.int64, device=su.device)
+    N.check(L.ragraph_topk_expand_groups_f32(su.data_ptr(), iu.data_ptr(), ku, idx_base_u, group_ptr.data_ptr(),
+                                             members.data_ptr(), group_ptr.numel() - 1, B, k, idx_base, out_s.data_ptr(),
+                                             out_i.data_ptr(), _stream()), "topk_expand_groups")
+    return out_s, out_i
+
+
 def gather_rows(v: torch.Tensor, idx: torch.Tensor, idx_base: int = 0) -> torch.Tensor:
     """v[idx] -- ToyGraphBase.py:70-71.  Rows outside [idx_base, idx_base+N) come back as zeros."""
     L = _ready()

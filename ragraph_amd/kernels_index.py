@@ -18,8 +18,17 @@ class KeyIndex:
     # _poll_overflow.
     I8_MAX_ERR = 0.02
     OVERFLOW_FRACTION = 1.0 / 64   # of a call of >= 64 queries sent to the exact scan: the filter (level dtype) costs more than it saves
+    # Exact duplicates (the reference's bank recipe stores three of four rows as copies of ONE vector, ToyGraphBase.py:91-119
+    # + Augmentation.py:9-20; the sampled rows repeat as well, :98 replacement=True): banks of at least DEDUP_MIN_ROWS rows
+    # are grouped once per bank version (hash + sort + bit-wise compare on the device, one synchronisation), and when at
+    # most DEDUP_MAX_UNIQUE of the rows are unique -- or one row is stored more than DEDUP_MAX_GROUP times: every query
+    # next to it would fill its candidate list with copies -- the search runs over the unique rows (their own copies,
+    # their own dispatch) and the winners are expanded to bank rows in canonical order: the same bits.
+    DEDUP_MIN_ROWS = 2048
+    DEDUP_MAX_UNIQUE = 0.9
+    DEDUP_MAX_GROUP = 64
 
-    def __init__(self, keys_normalized: torch.Tensor, ops=None):
+    def __init__(self, keys_normalized: torch.Tensor, ops=None, dedup: bool = True):
         if ops is None:
             from . import kernels as ops  # the HIP library; raises loudly without a GPU
         self.ops = ops
@@ -32,7 +41,38 @@ class KeyIndex:
         self._i8_ok = None        # the int8 copy's error row read (once, lazily): accurate enough for int8 levels?
         self._seen_i8, self._seen_bf16 = [0, 0], [0, 0]   # [queries, overflowed] of the polled calls with / without int8
         self._host_word = self._event = None
-        self.overflowed_queries = 0
+        self._overflowed = 0
+        # None: duplicates not looked at yet; False: looked at, searched as it is; else (KeyIndex over the unique rows,
+        # group_ptr, members)
+        self._collapsed = None if dedup else False
+        self.duplicate_stats = None   # (rows, unique rows, largest group) once judged
+
+    @property
+    def overflowed_queries(self) -> int:
+        """Queries of polled filtered calls that went to the exact scan (diagnostic)."""
+        return self._overflowed + (self._collapsed[0].overflowed_queries if self._collapsed else 0)
+
+    @property
+    def search_index(self) -> "KeyIndex":
+        """The index whose rows the kernels actually stream: the one over the unique rows when the bank was collapsed."""
+        return self._collapsed[0] if self._collapsed else self
+
+    def _judge_duplicates(self):
+        """Once per bank version (never while a HIP graph is being captured: one read-back)."""
+        kn = self.keys_normalized
+        dedup = getattr(self.ops, "dedup_rows", None)
+        if dedup is None or kn.shape[0] < self.DEDUP_MIN_ROWS:
+            self._collapsed = False
+            return
+        if kn.is_cuda and torch.cuda.is_current_stream_capturing():
+            return   # (stays undecided: searched as it is for now)
+        U, largest, uniq_row, group_ptr, members = dedup(kn)
+        self.duplicate_stats = (kn.shape[0], U, largest)
+        if U > self.DEDUP_MAX_UNIQUE * kn.shape[0] and largest <= self.DEDUP_MAX_GROUP:
+            self._collapsed = False
+            return
+        unique = self.ops.gather_rows(kn, uniq_row)   # (normalised rows copied bit for bit: still normalised)
+        self._collapsed = (KeyIndex(unique, self.ops, dedup=False), group_ptr, members)
 
     def _poll_overflow(self):
         """The filtered call repairs overflowed rows on the device and reads nothing back; its count arrives here after
@@ -48,7 +88,7 @@ class KeyIndex:
             return
         n_over, B = int(pend[0][0]), pend[2]
         self._pending = None
-        self.overflowed_queries += n_over
+        self._overflowed += n_over
         # judged over whole calls of >= 64 queries, or over the calls seen so far once they add up to 8 queries (graph
         # classification retrieves ONE query per forward: a bank that sends every such call to the exact scan must not stay)
         acc = self._seen_i8 if pend[3] else self._seen_bf16
@@ -84,6 +124,12 @@ class KeyIndex:
         ranks take it alike."""
         ops, kn = self.ops, self.keys_normalized
         B, D = q.shape
+        if self._collapsed is None:
+            self._judge_duplicates()
+        if self._collapsed and exchange is None:
+            inner, group_ptr, members = self._collapsed
+            su, iu = inner.topk(q, min(k, inner.keys_normalized.shape[0]))
+            return ops.topk_expand_groups(su, iu, group_ptr, members, k, idx_base=idx_base)
         fhelps = getattr(ops, "filter_helps", None)
         if exchange is not None:
             if fhelps is not None and fhelps(B, max(plan_n, kn.shape[0]), D, k) and B <= self.MAX_FILTERED_BATCH:
@@ -129,7 +175,7 @@ class KeyIndex:
                 self._event.record()
                 self._pending = (self._host_word, self._event, B, had_i8)
             elif not over.is_cuda:  # (the CPU tests' oracle shim)
-                self.overflowed_queries += int(over)
+                self._overflowed += int(over)
             return s, i
         helps = getattr(ops, "packed_keys_help", None)
         if helps is not None and helps(B, D, k):

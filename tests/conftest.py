@@ -15,19 +15,15 @@ def pytest_configure(config):
 _two_rank = None
 
 
-def pytest_sessionstart(session):
+def pytest_collection_finish(session):
     """tests/test_gpu_two_rank.py: its two worker processes must be started before THIS process initialises the GPU
-    (torch.cuda.device_count() does not; any test's first kernel does).  Only when GPU tests are selected and a device
-    exists; the workers run beside the other tests and the test collects their reports."""
+    (collection imports the test modules but runs no kernel).  Only when that test is among the collected (not
+    deselected) items and a device node exists -- /dev/kfd: probing through torch could initialise HIP in this
+    process on builds without amdsmi.  The workers run beside the other tests and the test collects their reports."""
     global _two_rank
-    expr = session.config.getoption("markexpr", "") or ""
-    if "not gpu" in expr or os.environ.get("RAGRAPH_SKIP_TWO_RANK") == "1":
+    if _two_rank is not None or os.environ.get("RAGRAPH_SKIP_TWO_RANK") == "1":
         return
-    try:
-        import torch
-        if torch.cuda.device_count() < 1:
-            return
-    except Exception:
+    if not any("test_gpu_two_rank" in item.nodeid for item in session.items) or not os.path.exists("/dev/kfd"):
         return
     import socket
     import subprocess
@@ -39,17 +35,24 @@ def pytest_sessionstart(session):
     out = tempfile.mkdtemp(prefix="ragraph_two_rank_")
     worker = os.path.join(ROOT, "tests", "two_rank_worker.py")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), out], env=env,
-                              stdout=open(os.path.join(out, f"rank{r}.log"), "w"), stderr=subprocess.STDOUT)
-             for r in range(2)]
-    _two_rank = (procs, out)
+    logs = [open(os.path.join(out, f"rank{r}.log"), "w") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), out], env=env, stdout=logs[r],
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    _two_rank = (procs, out, logs)
 
 
 def pytest_sessionfinish(session, exitstatus):
     if _two_rank is not None:
+        import shutil
+
         for p in _two_rank[0]:
             if p.poll() is None:
                 p.kill()
+            p.wait()
+        for f in _two_rank[2]:
+            f.close()
+        if exitstatus == 0:   # (a failed session keeps the workers' logs and reports for the post-mortem)
+            shutil.rmtree(_two_rank[1], ignore_errors=True)
 
 
 @pytest.fixture(scope="session")

@@ -141,6 +141,70 @@ def test_key_index_overflow_policy_on_host():
     assert idx._filter_off and idx.overflowed_queries == 8
 
 
+def test_key_index_collapses_exact_duplicates_on_host():
+    """KeyIndex over a bank of duplicates (host logic with oracle-backed kernels on CPU tensors): the search runs over
+    the unique rows and the expansion restores the canonical top-k of every row -- for a reference-shaped bank (three
+    quarters one vector, ToyGraphBase.py:91-119 + Augmentation.py:9-20), tied groups, a zero query, k above the number of
+    unique rows; banks below the thresholds are searched as they are."""
+    import numpy as np
+    import torch
+
+    from oracle import cref
+    from ragraph_amd.kernels_index import KeyIndex
+
+    class Ops:
+        searched = []
+
+        @staticmethod
+        def topk_cosine(q, kn, k, idx_base=0):
+            Ops.searched.append(kn.shape[0])
+            s, i = cref.topk_cosine(q.numpy(), kn.numpy(), k, idx_base)
+            return torch.from_numpy(s), torch.from_numpy(i)
+
+        @staticmethod
+        def gather_rows(v, idx, idx_base=0):
+            return torch.from_numpy(cref.gather_rows(v.numpy(), idx.numpy(), idx_base))
+
+        @staticmethod
+        def dedup_rows(kn):
+            U, largest, uniq, ptr, mem = cref.dedup_rows(kn.numpy())
+            return U, largest, torch.from_numpy(uniq), torch.from_numpy(ptr), torch.from_numpy(mem)
+
+        @staticmethod
+        def topk_expand_groups(su, iu, ptr, mem, k, idx_base=0, idx_base_u=0):
+            s, i = cref.topk_expand_groups(su.numpy(), iu.numpy(), ptr.numpy(), mem.numpy(), k, idx_base, idx_base_u)
+            return torch.from_numpy(s), torch.from_numpy(i)
+
+    rng = np.random.default_rng(3)
+    N, D = 4000, 32
+    real = cref.normalize_rows(rng.standard_normal((N // 4, D), dtype=np.float32))
+    real[rng.random(N // 4) < 0.3] = real[7]
+    kn = np.tile(cref.normalize_rows(rng.standard_normal((1, D), dtype=np.float32)), (N, 1))
+    kn[np.flatnonzero(np.arange(N) % 40 < 10)] = real
+    q = rng.standard_normal((9, D), dtype=np.float32)
+    q[0] = 0.0
+    q[1] = kn[39]
+    q[2] = real[7]
+    idx = KeyIndex(torch.from_numpy(kn), ops=Ops)
+    for k in (1, 10, 64):
+        s, i = idx.topk(torch.from_numpy(q), k, idx_base=5)
+        rs, ri = cref.topk_cosine(q, kn, k, idx_base=5)
+        assert np.array_equal(i.numpy(), ri) and np.array_equal(s.numpy(), rs)
+    n, U, largest = idx.duplicate_stats
+    assert n == N and U < N // 4 and largest == 3 * N // 4 and idx.search_index.keys_normalized.shape[0] == U
+    assert set(Ops.searched) == {U}                       # every search ran over the unique rows only
+    few = KeyIndex(torch.from_numpy(np.tile(kn[:3], (1000, 1))), ops=Ops)   # 3 unique rows, k = 10
+    s, i = few.topk(torch.from_numpy(q), 10)
+    rs, ri = cref.topk_cosine(q, np.tile(kn[:3], (1000, 1)), 10)
+    assert np.array_equal(i.numpy(), ri) and np.array_equal(s.numpy(), rs)
+    plain = KeyIndex(torch.from_numpy(cref.normalize_rows(rng.standard_normal((3000, D), dtype=np.float32))), ops=Ops)
+    plain.topk(torch.from_numpy(q), 5)
+    assert plain._collapsed is False and plain.duplicate_stats == (3000, 3000, 1)
+    small = KeyIndex(torch.from_numpy(kn[:1000].copy()), ops=Ops)            # below DEDUP_MIN_ROWS: not even looked at
+    small.topk(torch.from_numpy(q), 5)
+    assert small._collapsed is False and small.duplicate_stats is None
+
+
 def test_filtered_dispatch_rule():
     """kernels.filter_helps (pure host arithmetic): which shapes take the bf16-filtered exact top-k.  Banks of >= 65536
     keys at any batch size; >= 32768 keys from 128 queries; >= 8192 keys from 512 queries (D >= 128) or 2048 / 8192

@@ -136,6 +136,54 @@ def test_filtered_topk_matches_fp32_kernel_at_full_size(dev):
 
 
 @pytest.mark.gpu
+def test_reference_recipe_bank_1m_rows(dev):
+    """A 1M x 256 bank built by the reference's own recipe (bank_build.build_toy_graph over 25 000 synthetic resource
+    graphs; RAGraph_node/ragraph_utils/ToyGraphBase.py:91-119, Augmentation.py:9-20): three quarters of its rows are one
+    vector and the sampled rows repeat.  The product dispatch collapses the exact duplicates, searches the unique rows on
+    the filtered path WITHOUT overflowing, and returns the bits of the fp32 kernel over all 1M rows (every query) and of
+    the oracle (a sample)."""
+    from ragraph_amd import kernels as K
+    from ragraph_amd.bank_build import build_reference_recipe_bank
+    from ragraph_amd.data import synthetic_big_graph
+    from ragraph_amd.graph import CSRGraph
+    from ragraph_amd.preprompt import PrePrompt
+
+    F, C, D, k, N = 128, 3, 256, 10, 1_000_000
+    torch.manual_seed(0)
+    pre = PrePrompt(F, D, "prelu", 1, 0.3).to(dev)
+    with torch.no_grad():
+        pre.gcn.convs[0].bias.normal_(0, 0.1)           # (a pre-trained encoder's bias is not zero)
+        tgb = build_reference_recipe_bank(pre, N, F, C, D, device=dev)
+        n_q = 20_000
+        adj = CSRGraph.from_edge_index_sym_normalized(synthetic_big_graph(n_q, 10, seed=8, device=dev), n_q)
+        h = pre.inference(torch.randn(n_q, F, device=dev, generator=torch.Generator(device=dev).manual_seed(4321)), adj)
+    kn = tgb.keys_normalized
+    assert kn.shape == (N, D)
+    s, i = tgb.topk(h, k)
+    index = tgb._index
+    n, U, largest = index.duplicate_stats
+    assert n == N and U <= N // 2 and largest >= N // 2     # >= 50 % duplicate rows; one vector stored > 500 000 times
+    inner = index.search_index
+    assert inner is not index and inner.keys_normalized.shape[0] == U and U >= 65536
+    s0, i0 = K.topk_cosine(h, kn, k)                        # the fp32 kernel over every one of the 1M rows
+    assert torch.equal(i, i0) and torch.equal(s, s0)
+    rows = torch.arange(0, n_q, 1250)
+    rs, ri = cref.topk_cosine(h[rows].cpu().numpy(), kn.cpu().numpy(), k)
+    assert np.array_equal(i[rows].cpu().numpy(), ri) and np.array_equal(s[rows].cpu().numpy(), rs)
+    # the search over the unique rows took the filtered path and nothing overflowed
+    assert K.filter_helps(n_q, U, D, k) and inner._bf16 is not None and not inner._filter_off
+    _, _, over = K.topk_cosine_filtered(h, inner.keys_normalized, inner._bf16, k)
+    assert int(over) == 0
+    # single queries and a few hundred (the reference's real batch sizes) through the same index: same rows
+    for lo, B in ((7, 1), (100, 16), (1000, 500)):
+        sb, ib = tgb.topk(h[lo:lo + B].contiguous(), k)
+        assert torch.equal(ib, i[lo:lo + B]) and torch.equal(sb, s[lo:lo + B])
+    torch.cuda.synchronize()
+    tgb.topk(h[:64].contiguous(), k)
+    assert index.overflowed_queries == 0
+
+
+@pytest.mark.gpu
 def test_filtered_topk_beyond_2gib_of_bf16_keys(dev):
     """4.5M x 256 keys: the bf16 copy (2.3 GB) and the fp32 / packed copies (4.6 GB each) cross the 2^31- and 2^32-byte
     marks, where a 32-bit or sign-extended offset in a kernel's address arithmetic would read the wrong rows (seen once:

@@ -495,16 +495,20 @@ def test_topk_cosine_filtered_overflow_falls_back(dev):
     assert np.array_equal(i.cpu().numpy(), ri)
     assert np.array_equal(s.cpu().numpy(), rs)
     # the bank-side dispatch notices that this bank defeats the filter and keeps it on the fp32 kernels afterwards
-    big = _t(np.concatenate([kn] * 4), dev)             # 80000 keys: large enough for the filtered path
+    # (80000 DISTINCT near-duplicates: large enough for the filtered path; exact copies would be collapsed by KeyIndex,
+    # tests/test_gpu_dedup.py)
+    kn4 = cref.normalize_rows(base + 1e-3 * rng.standard_normal((80000, 256), dtype=np.float32))
+    big = _t(kn4, dev)
     index = K.KeyIndex(big)
     qd = _t(q, dev)
     s1, i1 = index.topk(qd, 10)
+    assert index._collapsed is False
     assert index._bf16 is not None and not index._filter_off   # filtered call; its overflow count is not read back ...
     torch.cuda.synchronize()
     s2, i2 = index.topk(qd, 10)                                 # ... it arrives later and is noticed at the next call
     assert index._filter_off and index.overflowed_queries >= 301
     assert torch.equal(i1, i2) and torch.equal(s1, s2)
-    rs4, ri4 = cref.topk_cosine(q, np.concatenate([kn] * 4), 10)
+    rs4, ri4 = cref.topk_cosine(q, kn4, 10)
     assert np.array_equal(i1.cpu().numpy(), ri4) and np.array_equal(s1.cpu().numpy(), rs4)
 
 
@@ -736,7 +740,7 @@ def test_topk_cosine_filtered_int8_levels_bit_exact(dev, monkeypatch, D, B, N, k
     q[B - 1] = 0.0
     knd = _t(kn, dev)
     s, i, over = K.topk_cosine_filtered(_t(q, dev), knd, K.keys_to_bf16(knd), k, idx_base=5)
-    assert int(over) >= 0                                   # (a zero query is answered without a scan; the wide kernels count it)
+    assert int(over) <= 1                                   # (only the zero query may go to a scan: the FILTERED path produced every other row)
     rows = np.arange(B) if B <= 4000 else np.unique(np.concatenate([[3, B - 1], rng.integers(0, B, 700)]))
     rs, ri = cref.topk_cosine(q[rows], kn, k, idx_base=5)
     assert np.array_equal(i.cpu().numpy()[rows], ri)
@@ -779,7 +783,7 @@ def test_topk_cosine_filtered_scored_lists_bit_exact(dev, monkeypatch, D, B, N, 
     for scored in ("1", "0"):
         monkeypatch.setenv("RAGRAPH_FILTER_SCORED", scored)
         s, i, over = K.topk_cosine_filtered(qd, knd, kb, k, idx_base=9)
-        assert int(over) >= 0                                   # (a zero query is answered without a scan; the wide kernels count it)
+        assert int(over) <= 1                                   # (only the zero query may go to a scan: the FILTERED path produced every other row)
         outs[scored] = (s, i)
     assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])
     rows = np.unique(np.concatenate([np.arange(24), [B - 1], rng.integers(0, B, 400)]))

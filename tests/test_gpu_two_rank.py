@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 def test_two_ranks_on_the_hip_library_match_single_process(dev, two_rank_job):
     assert two_rank_job is not None, "conftest did not start the two-rank job (no ROCm device at session start?)"
-    procs, out = two_rank_job
+    procs, out = two_rank_job[0], two_rank_job[1]
     for p in procs:
         p.wait(timeout=900)
     reports = []
