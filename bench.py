@@ -190,7 +190,6 @@ def small_batch_rates(tgb, dim, k, dev):
     out = {}
     kn = tgb.keys_normalized
     index = tgb._index if tgb._index is not None else K.KeyIndex(kn)
-    n_keys = kn.shape[0]
     L = K.N.lib()
     for B in (1, 16, 256, 512, 4096):
         q = torch.randn(B, dim, device=dev, generator=torch.Generator(device=dev).manual_seed(4321 + B))
@@ -205,12 +204,17 @@ def small_batch_rates(tgb, dim, k, dev):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        filtered = K.filter_helps(B, n_keys, dim, k)
+        inner = index.search_index               # (the rows the kernels stream: the unique ones of a collapsed bank)
+        n_keys = inner.keys_normalized.shape[0]
+        filtered = K.filter_helps(B, n_keys, dim, k) and not inner._filter_off
         n_i8 = 0
         if filtered:
             plan = (ctypes.c_int64 * 7)()
             L.ragraph_topk_cosine_filtered_plan(B, n_keys, dim, k, plan)
-            n_i8 = L.ragraph_topk_cosine_filtered_i8_levels(B, n_keys, dim, k)
+            cap, allowed = inner._cap_i8()       # the int8 levels THIS bank's calls run with (KeyIndex caps them per bank)
+            n_i8 = L.ragraph_topk_cosine_filtered_i8_levels(B, n_keys, dim, k) if allowed else 0
+            if cap is not None:
+                cap(-1)
             ends = [0] + [int(plan[3 + l]) for l in range(int(plan[2]))]
             per_key = [dim * (1 if l >= int(plan[2]) - n_i8 else 2) for l in range(int(plan[2]))]   # int8 levels: D bytes per key
             streamed = int(plan[6]) * dim * 2 + sum((ends[l + 1] - ends[l]) * per_key[l] for l in range(int(plan[2]))) + B * dim * 4
@@ -290,16 +294,59 @@ def reference_bank_rates(args, dev, adj, feats, batches=(1, 500, 100_000), dedup
     return out
 
 
+def host_cpu_info():
+    """What the CPU baseline ran on: cores this process may use (affinity mask, capped by a cgroup CPU quota when one is
+    set -- os.cpu_count() reports the machine's, not the container's), CPU model, torch's BLAS."""
+    import re
+
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    cores = max(1, min(affinity, int(quota + 0.5)) if quota else affinity)
+    model = sockets = None
+    try:
+        info = open("/proc/cpuinfo").read()
+        m = re.search(r"model name\s*:\s*(.+)", info)
+        model = m.group(1).strip() if m else None
+        sockets = len(set(re.findall(r"physical id\s*:\s*(\d+)", info))) or None
+    except OSError:
+        pass
+    cfg = torch.__config__.show()
+    blas = re.search(r"BLAS_INFO=(\w+)", cfg)
+    par = torch.__config__.parallel_info()
+    mkl = re.search(r"Math Kernel Library Version ([^\n]+?) for", par)
+    return {"cores_used": cores, "affinity_cores": affinity, "cgroup_cpu_quota": quota, "os_cpu_count": os.cpu_count(),
+            "cpu_model": model, "sockets": sockets,
+            "torch_blas": (blas.group(1) if blas else "?") + (f" ({mkl.group(1).strip()})" if mkl else "")}
+
+
 def cpu_baseline(args, model, feats, adj):
     """The reference's op chain on the host cores (oracle/ref_torch.py), BASELINE.md section 3: GNN part on the whole
     graph (sparse CSR: the reference's dense adjacency would be 40 GB); retrieval exactly as the reference computes it
     (bank re-normalised on every call, the B x N slab materialised, torch.topk, gathers) on ONE slab of 1024 queries --
-    1 warm-up + 3 timed repetitions, median -- extrapolated to the full forward; and the 'fair' row with the bank
-    normalised once (1 warm-up + 3 repetitions).  (Round 2 ran 3 + 5 repetitions: 95 % of the command's wall time, with a
-    spread of a few per cent between repetitions.)"""
+    1 warm-up + 3 timed repetitions, median -- extrapolated to the full forward; the 'fair' row with the bank normalised
+    once; and the per-phase split of one slab (normalise / GEMM / top-k / gather) with the GEMM's GFLOP/s, so that the
+    number can be judged against the cores it ran on.  Threads = the cores this process may USE (host_cpu_info: affinity
+    mask and cgroup quota; os.cpu_count() is the machine's)."""
     from oracle import ref_torch
 
-    cores = os.cpu_count() or 1
+    host = host_cpu_info()
+    cores = host["cores_used"]
     torch.set_num_threads(cores)
     n = feats.shape[0]
     slab = min(args.cpu_slab, n)
@@ -334,15 +381,37 @@ def cpu_baseline(args, model, feats, adj):
             _, idx = torch.topk(S, args.k, largest=True, sorted=True)
             return vals[idx].sum(dim=1), labs[idx].mean(dim=1)
         t_fair, ts_fair = timed(fair, 1, 3)
+        # one slab, phase by phase (the same ops as ref_torch.retrieve, timed apart; one warm repetition each)
+        phases = {}
+        tp = time.perf_counter()
+        kn2 = torch.nn.functional.normalize(keys, p=2, dim=-1)
+        qn = torch.nn.functional.normalize(q, p=2, dim=-1)
+        phases["normalize_bank_and_queries_s"] = time.perf_counter() - tp
+        tp = time.perf_counter()
+        S = torch.matmul(qn, kn2.t())
+        phases["score_gemm_s"] = time.perf_counter() - tp
+        tp = time.perf_counter()
+        _, idx = torch.topk(S, args.k, largest=True, sorted=True)
+        phases["topk_s"] = time.perf_counter() - tp
+        tp = time.perf_counter()
+        vals[idx].sum(dim=1), labs[idx].mean(dim=1)
+        phases["gather_reduce_s"] = time.perf_counter() - tp
+        gemm_gflops = 2.0 * slab * keys.shape[0] * keys.shape[1] / phases["score_gemm_s"] / 1e9
+        del S, kn2
     est_full = t_gnn + t_ref * (n / slab)
     est_fair = t_gnn + t_fair * (n / slab)
     return {"value": round(n / est_full, 2), "unit": "queries/s", "cores": cores, "kind": "port",
+            "cpu_model": host["cpu_model"], "affinity_cores": host["affinity_cores"], "cgroup_cpu_quota": host["cgroup_cpu_quota"],
+            "os_cpu_count": host["os_cpu_count"], "sockets": host["sockets"], "torch_blas": host["torch_blas"],
+            "torch_threads": torch.get_num_threads(),
             "sample": f"GNN encode+{model.query_graph_hop}-hop on all {n} nodes ({t_gnn:.2f}s, torch sparse CSR) + retrieval of "
                       f"one slab of {slab} of the {n} queries vs the full {keys.shape[0]}x{keys.shape[1]} bank, 1 warm-up + 3 "
                       f"repetitions, median {t_ref:.2f}s (bank re-normalised per call as the reference does), extrapolated "
                       f"to {n} queries",
             "retrieval_only_queries_per_s": round(slab / t_ref, 2),
             "retrieval_rep_seconds": [round(t, 3) for t in ts_ref],
+            "phases_one_slab": {**{k_: round(v, 4) for k_, v in phases.items()}, "score_gemm_GFLOPs": round(gemm_gflops, 1),
+                                "gnn_all_nodes_s": round(t_gnn, 3)},
             "fair": {"value": round(n / est_fair, 2), "retrieval_only_queries_per_s": round(slab / t_fair, 2),
                      "rep_seconds": [round(t, 3) for t in ts_fair],
                      "note": "bank normalised once (ref_torch.retrieve(renormalize_bank=False) arithmetic), 1 warm-up + 3 "
@@ -410,8 +479,10 @@ def timed_steps(step, steps, world, dev, on_step=None):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
+        from ragraph_amd.sharded import all_reduce   # (stages device tensors through the host under --backend gloo)
+
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed, out
 
