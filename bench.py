@@ -208,7 +208,16 @@ def small_batch_rates(tgb, dim, k, dev):
         n_keys = inner.keys_normalized.shape[0]
         filtered = K.filter_helps(B, n_keys, dim, k) and not inner._filter_off
         n_i8 = 0
-        if filtered:
+        one_launch = filtered and K.small_helps(B, n_keys, dim, k)
+        if one_launch:   # csrc/topk_small.hip: a bf16 prefix (bound pass) + one pass over the int8 (or bf16) copy, one launch
+            cap, allowed = inner._cap_i8()
+            i8 = ctypes.c_int(0)
+            prefix = L.ragraph_topk_cosine_small_prefix_keys(B, n_keys, dim, ctypes.byref(i8))
+            if cap is not None:
+                cap(-1)
+            n_i8 = i8.value
+            streamed = prefix * dim * 2 + n_keys * dim * (1 if n_i8 else 2) + B * dim * 4
+        elif filtered:
             plan = (ctypes.c_int64 * 7)()
             L.ragraph_topk_cosine_filtered_plan(B, n_keys, dim, k, plan)
             cap, allowed = inner._cap_i8()       # the int8 levels THIS bank's calls run with (KeyIndex caps them per bank)
@@ -223,7 +232,8 @@ def small_batch_rates(tgb, dim, k, dev):
         gbs = streamed / ms / 1e6
         flops = 2.0 * B * n_keys * dim
         rec = {"ms": round(ms, 4), "queries_per_s": round(B / ms * 1e3, 1),
-               "path": ("bf16-filtered" + (f", last {n_i8} level(s) on int8" if n_i8 else "")) if filtered else "fp32",
+               "path": ("one launch (bound pass + " + ("int8" if n_i8 else "bf16") + " filter pass + exact rescoring + selection)") if one_launch
+               else (("bf16-filtered" + (f", last {n_i8} level(s) on int8" if n_i8 else "")) if filtered else "fp32"),
                "streamed_GB": round(streamed / 1e9, 4), "GBps_streamed": round(gbs, 1),
                "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
                "algorithmic_GBps": round(n_keys * dim * 4 / ms / 1e6, 1),

@@ -188,6 +188,29 @@ int ragraph_topk_cosine_filtered_sharded_f32(const float* Q, int64_t B, const fl
  * call leaves them zero (keep one buffer per stream).  ws: ragraph_topk_cosine_fused_workspace_bytes (the splits' lists).
  * Every tile streams the whole bf16 copy (2 N D bytes) from L2: meant for banks whose copy is a few MB
  * (ragraph_amd/kernels_index.py decides). */
+/* a1 + a2 in ONE launch for up to 32 queries against a LARGE bank  -- SimilarityFunctions.py:6-16 + ToyGraphBase.py:66-67 at
+ * the reference's smallest batches (RAGraph_graph/RAGraph.py:48-60 retrieves ONE query per forward).  Same result, bit for
+ * bit, as ragraph_topk_cosine_f32 / _filtered_f32.  Every workgroup of the launch prepares the queries, takes its share of a
+ * bf16 bound pass over a prefix of the bank (part maxima published by atomicMax), waits a BOUNDED time for the other
+ * workgroups' shares (no grid barrier: the k-th largest of whatever maxima are published is a valid bound), streams its
+ * share of the int8 copy (bf16 when ragraph_topk_cosine_filtered_max_i8_levels(0) is in force for the thread, or D = 64),
+ * scores its own candidates exactly (fp32 chains) and appends the exact pairs to per-query lists; the last workgroup to
+ * finish (a ticket) selects every query's canonical top-k, answers zero queries and -- for a query whose list of exact pairs
+ * passes its capacity (near-duplicate banks) -- runs the exact scan.  ragraph_amd/csrc/topk_small.hip.
+ *   Q [B,D] raw queries, 1 <= B <= 32; Kn [N,D] unit rows, N >= 65536; Kb = ragraph_keys_to_bf16(Kn); D in {64,128,256}; k <= 32
+ *   (ragraph_topk_cosine_small_ok).  overflow: device int, set to the number of queries answered by the exact scan.
+ *   state: ragraph_topk_cosine_small_state_bytes() bytes, ZERO before the first call; every call leaves them zero (one
+ *   buffer per stream: calls on a stream are ordered).  ws: ragraph_topk_cosine_small_workspace_bytes (the pair lists).
+ *   RAGRAPH_SMALL_WAIT_TICKS: the wait's limit in 10-ns ticks (default 3000; 0: never wait -- test hook). */
+int ragraph_topk_cosine_small_ok(int64_t B, int64_t N, int D, int k);
+size_t ragraph_topk_cosine_small_state_bytes(void);
+/* keys of the bf16 prefix the call's bound pass reads; *i8 (may be NULL) = 1 when its filter pass streams the int8 copy */
+int64_t ragraph_topk_cosine_small_prefix_keys(int64_t B, int64_t N, int D, int* i8);
+size_t ragraph_topk_cosine_small_workspace_bytes(int64_t B, int D, int k);
+int ragraph_topk_cosine_small_f32(const float* Q, int64_t B, const float* Kn, const uint16_t* Kb, int64_t N, int D, int k,
+                                  int64_t idx_base, float* out_scores, int64_t* out_idx, int* overflow, int* state, void* ws,
+                                  size_t ws_bytes, void* stream);
+
 int ragraph_topk_cosine_fused_ok(int64_t B, int64_t N, int D, int k);
 size_t ragraph_topk_cosine_fused_workspace_bytes(int64_t B, int64_t N, int D, int k);
 int ragraph_topk_cosine_fused_f32(const float* Q, int64_t B, const float* Kn, const uint16_t* Kb, int64_t N, int D, int k,

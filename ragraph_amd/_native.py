@@ -49,6 +49,11 @@ SIGNATURES = {
                                                 _sz, _vp]),
     "ragraph_topk_cosine_filtered_sharded_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp,
                                                         _vp, _sz, _vp, _i64, _vp, _vp, _vp, _i32]),
+    "ragraph_topk_cosine_small_ok": (_i32, [_i64, _i64, _i32, _i32]),
+    "ragraph_topk_cosine_small_state_bytes": (_sz, []),
+    "ragraph_topk_cosine_small_prefix_keys": (_i64, [_i64, _i64, _i32, _vp]),
+    "ragraph_topk_cosine_small_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "ragraph_topk_cosine_small_f32": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ragraph_topk_cosine_fused_ok": (_i32, [_i64, _i64, _i32, _i32]),
     "ragraph_topk_cosine_fused_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
     "ragraph_topk_cosine_fused_f32": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -60,6 +60,17 @@ __host__ __device__ constexpr int64_t filter_i8_block_offset(int64_t subtile, in
   return (subtile * (D / 32) + 2 * t + h) * 1024;
 }
 
+// rint(x * inv_scale) clamped to [-127, 127], inv_scale = 1 / scale computed ONCE per row with one fp32 division: a multiply
+// per element (the ring kernel quantises 256 elements per lane and segment: divisions were 5 us of every segment).  Whatever
+// integer comes out, the bound uses the error of THAT integer (|s q - x| is measured, not assumed), and the prepare launch and
+// the kernels call this one function with the same inv_scale, so they produce the same operands.
+__device__ __forceinline__ int quantize_i8(float x, float inv_scale) {
+  return (int)fminf(fmaxf(__builtin_rintf(__fmul_rn(x, inv_scale)), -127.f), 127.f);
+}
+
+// This thread's cap on int8 levels (ragraph_topk_cosine_filtered_max_i8_levels; -1 = the library's rule, 0 = none).
+int filter_thread_i8_cap();
+
 // float <-> int with the same order (for atomicMax on scores of either sign)
 __device__ __forceinline__ int f2ord(float f) {
   const int b = __float_as_int(f);

@@ -144,14 +144,6 @@ __global__ void __launch_bounds__(256) bank_absmax_kernel(const float* __restric
   if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(tail8 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(tail8 + 2, m);
 }
 
-// rint(x * inv_scale) clamped to [-127, 127], inv_scale = 1 / scale computed ONCE per row with one fp32 division: a multiply
-// per element (the ring kernel quantises 256 elements per lane and segment: divisions were 5 us of every segment).  Whatever
-// integer comes out, the bound uses the error of THAT integer (|s q - x| is measured, not assumed), and the prepare launch and
-// the kernels call this one function with the same inv_scale, so they produce the same operands.
-__device__ __forceinline__ int quantize_i8(float x, float inv_scale) {
-  return (int)fminf(fmaxf(__builtin_rintf(__fmul_rn(x, inv_scale)), -127.f), 127.f);
-}
-
 template <int D>
 __global__ void __launch_bounds__(256) keys_to_i8_kernel(const float* __restrict__ Kn, int64_t N, int64_t Npad,
                                                          signed char* __restrict__ Kb8, unsigned* __restrict__ tail8) {
@@ -1938,6 +1930,7 @@ extern "C" int ragraph_topk_cosine_filtered_max_i8_levels(int n) {
   t_max_i8_levels = n < 0 ? -1 : n;
   return old;
 }
+int ragraph::filter_thread_i8_cap() { return t_max_i8_levels; }  // (topk_small.hip: the single-launch call honours the same cap)
 
 static int filter_i8_levels(const FilterSchedule& sc, int64_t B, int D, int64_t N) {
   const char* env = getenv("RAGRAPH_FILTER_I8");  // (read per call: the tests switch it)

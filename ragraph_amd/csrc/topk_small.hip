@@ -1,0 +1,979 @@
+// The exact cosine top-k of UP TO 32 QUERIES against a large bank in ONE LAUNCH (SimilarityFunctions.py:6-16 +
+// ToyGraphBase.py:66-67 at the reference's smallest batch sizes: RAGraph_graph/RAGraph.py:48-60 retrieves ONE query per
+// forward).
+//
+// The multi-launch filtered call (topk_filter.hip) spends, for one query against 1M x 256 keys, 42 us streaming the int8
+// copy and as long again on everything around it: prepare 5 us, bound pass 9 us, rescoring 18 us, and ~4.5 us of idle
+// chip at each of the four launch boundaries.  Here every workgroup does all of it, and nothing waits for a launch:
+//
+//   0. prepare (every workgroup, redundantly -- 32 rows): normalised queries (normalize_rows' tree: the same bits), their
+//      bf16 / int8 rounding errors and int8 scales, into LDS; each wave builds its MFMA B operands from there.
+//   1. bound: the workgroup's share of a bf16 pass over a PREFIX of the bank; per query the best approximate score of each
+//      of G = min(4k, 64) parts of the prefix goes to global memory by atomicMax (order-preserving unsigned; 0 = nothing
+//      published).  Each part's best key has an exact score >= its approximate one - eps, the parts' best keys are distinct,
+//      so the k-th largest of the PUBLISHED maxima, minus eps, is a lower bound theta of the query's final k-th best score
+//      -- with all parts published or only some of them (-inf when fewer than k are).
+//   2. a BOUNDED wait: the workgroup announces its bound units (a counter) and waits until every workgroup has, or a time
+//      limit passes (workgroups of another process may hold the CUs of ours: RAGRAPH_SMALL_WAIT_TICKS).  No grid
+//      barrier: whatever is published at that moment is a valid bound; a workgroup that had to move on early refreshes its
+//      thresholds from the published maxima while it streams.
+//   3. filter: the workgroup's share of ONE pass over the int8 copy (D bytes per key; bf16 when the bank's int8 copy is not
+//      accurate enough), the register-fed stream of topk_filter_direct.hip; keys whose integer sum reaches the query's
+//      threshold T = floor((theta - eps_bf16 - eps_int8) / (s_q s_k)) - 2 are kept in a wave-private LDS buffer.
+//   4. exact rescoring AT THE SOURCE: each wave scores its own candidates with the k = 0..D-1 fmaf chain from +0 (rows
+//      fetched cooperatively, 16 at a time), the workgroup reserves list space with ONE atomic per query and stores the
+//      exact (score, key) pairs.  There are no candidate lists of approximate hits, hence no sub-lists and no list
+//      overflow from the approximate filter; a query whose exact-pair list passes SMALL_LIST_CAP (a bank of near-
+//      duplicates) stops passing keys and is answered by an exact scan (5 below).
+//   5. the LAST workgroup to finish (a ticket) selects every query's canonical top-k from its pair list (a lane-maxima bound
+//      prunes the list to <= 128 pairs, ranks by counting), answers zero queries (scores +0, rows in order) and
+//      overflowed ones (exact scan by four waves), and leaves the state buffer zeroed for the next call.
+//
+// The result has the bits of ragraph_topk_cosine_f32: every output score is the fp32 chain, the selection the canonical
+// one; the approximate phases only decide which keys are scored.
+#include "rescore_common.h"
+#include <type_traits>
+
+namespace ragraph {
+
+constexpr int SMALL_MAX_B = 32;
+constexpr int SMALL_LIST_CAP = 4096;     // exact (score, key) pairs per query in the workspace
+constexpr int SMALL_PARTS_MAX = 64;      // parts of the bound prefix (one per lane of the selecting wave)
+constexpr int SMALL_WG_LIST = 1024;      // exact pairs a workgroup collects in LDS before its one reservation per query
+constexpr int SMALL_PAIRBUF = 512;       // (key, query) pairs a wave expands at a time
+// state buffer (ints; ZERO before the first call, left zero by every call): [0] workgroups past their bound units,
+// [1] workgroups done, cnt[q] at 32 + 32 q (a 128-byte line each), part maxima [32][64] from 32 + 32 * 32
+constexpr int SMALL_STATE_CNT0 = 32;
+constexpr int SMALL_STATE_GMAX0 = SMALL_STATE_CNT0 + 32 * SMALL_MAX_B;
+constexpr int SMALL_STATE_INTS = SMALL_STATE_GMAX0 + SMALL_MAX_B * SMALL_PARTS_MAX;
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct SmallParams {
+  const float* Q;          // [B,D] raw queries
+  const float* Kn;         // [N,D] normalised keys (fp32: the exact chains)
+  const uint16_t* Kb;      // bf16 copy, fragment order (filter_common.h)
+  const signed char* Kb8;  // int8 copy behind it
+  const unsigned* max_kerr2;  // bf16 copy's tail: max |dk|^2
+  const unsigned* tail8;      // int8 copy's tail: max |dk|^2, s_k
+  int64_t N, idx_base;
+  int B, k;
+  int64_t bound_units;     // bound pass: units [0, bound_units) of the bf16 copy ...
+  int parts;               // ... in `parts` parts
+  int64_t nunits;          // filter pass: units of the copy it streams
+  unsigned wait_ticks;     // 10 ns ticks a workgroup waits for the others' bound units at most
+  int* state;
+  float* list_s;           // [B][SMALL_LIST_CAP] exact scores ...
+  int* list_k;             // ... and keys
+  float* out_s;
+  int64_t* out_i;
+  int* overflow;           // out: queries answered by the exact scan
+};
+
+template <int D_>
+struct SmallGeo {  // unit geometry of a fragment-order copy whose keys take 2 D_ bytes (the int8 copy of D: D_ = D / 2)
+  static constexpr int KS = D_ / 32;                 // MFMA k-steps per sub-tile
+  static constexpr int KSTEPS = D_ / 16;             // 1-KiB blocks per 32-key sub-tile
+  static constexpr int SUBS = 16 / KSTEPS;           // sub-tiles per 16-KiB unit
+  static constexpr int UNIT_KEYS = 32 * SUBS;
+};
+
+__device__ __forceinline__ unsigned small_f2u(float f) { return (unsigned)f2ord(f) ^ 0x80000000u; }  // order-preserving, > 0
+__device__ __forceinline__ float small_u2f(unsigned u) { return ord2f((int)(u ^ 0x80000000u)); }
+
+template <int D, bool I8>
+struct SmallLds {
+  static constexpr int QLD = D + 4;  // floats per query row in LDS (16-B pad: a column of 16 rows spreads over the banks)
+  static constexpr int CAND_BUF = 512;
+  static constexpr size_t qn = 0;
+  static constexpr size_t wbuf = qn + (size_t)SMALL_MAX_B * QLD * 4;
+  static constexpr size_t pairbuf = wbuf + (size_t)8 * CAND_BUF * 8;
+  static constexpr size_t tile = pairbuf + (size_t)8 * SMALL_PAIRBUF * 8;
+  static constexpr size_t wg_s = tile + (size_t)8 * 16 * RESCORE_LD * 4;
+  static constexpr size_t wg_k = wg_s + (size_t)SMALL_WG_LIST * 4;
+  static constexpr size_t wg_q = wg_k + (size_t)SMALL_WG_LIST * 4;
+  static constexpr size_t small = wg_q + (size_t)SMALL_WG_LIST * 4;   // per-query scalars
+  static constexpr size_t bytes_stream = small + 32 * 4 * 12;
+  // the last workgroup's exact scan: four 64-row tiles + partial lists, over everything but the query rows
+  static constexpr size_t scan_tile = wbuf;
+  static constexpr size_t scan_ps = scan_tile + (size_t)4 * 64 * RESCORE_LD * 4;
+  static constexpr size_t scan_pi = scan_ps + 4 * 32 * 4;
+  static constexpr size_t bytes_scan = scan_pi + 4 * 32 * 8;
+  static constexpr size_t bytes = bytes_stream > bytes_scan ? bytes_stream : bytes_scan;
+};
+
+// canonical 64-bit key of a pair (rescore_common.h: wave_select's order)
+__device__ __forceinline__ unsigned long long small_key64(float s, int key) {
+  return ((unsigned long long)select_ord(s) << 32) | (unsigned)~(unsigned)key;
+}
+
+#ifdef RG_SMALL_TIMING  // diagnostic build: wall-clock stamps (10 ns ticks) of workgroup 0 and of the last workgroup to finish
+__device__ unsigned long long g_small_t[2][16];
+#define RG_SSTAMP(i_) \
+  if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); if (blockIdx.x == 0) g_small_t[0][i_] = now_; st_[i_] = now_; }
+#else
+#define RG_SSTAMP(i_)
+#endif
+
+template <int D, bool I8>
+__global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
+#ifdef RG_SMALL_TIMING
+  unsigned long long st_[16] = {};
+#endif
+  RG_SSTAMP(0);
+  using GB = SmallGeo<D>;                 // the bf16 copy (bound pass; the filter pass when !I8)
+  using GF = SmallGeo<I8 ? D / 2 : D>;    // the copy the filter pass streams
+  using L = SmallLds<D, I8>;
+  using acc_t = typename std::conditional<I8, i32x4, f32x4>::type;
+  constexpr int QLD = L::QLD;
+  extern __shared__ float4 small_smem4[];
+  char* smem = reinterpret_cast<char*>(small_smem4);
+  float* qn = reinterpret_cast<float*>(smem + L::qn);
+  uint2* wbuf_all = reinterpret_cast<uint2*>(smem + L::wbuf);
+  int2* pair_all = reinterpret_cast<int2*>(smem + L::pairbuf);
+  float* tile_all = reinterpret_cast<float*>(smem + L::tile);
+  float* wg_s = reinterpret_cast<float*>(smem + L::wg_s);
+  int* wg_k = reinterpret_cast<int*>(smem + L::wg_k);
+  int* wg_q = reinterpret_cast<int*>(smem + L::wg_q);
+  float* sc_eqb = reinterpret_cast<float*>(smem + L::small);  // [32] |dq| of the bf16 rounding
+  float* sc_eq8 = sc_eqb + 32;                                // [32] |dq| of the int8 rounding
+  float* sc_qs = sc_eq8 + 32;                                 // [32] int8 scale of the query
+  int* sc_flag = reinterpret_cast<int*>(sc_qs + 32);          // [32] 2: zero query
+  float* thr_lds = reinterpret_cast<float*>(sc_flag + 32);    // [32] pass thresholds (int8: integer bits)
+  float* theta_lds = thr_lds + 32;                            // [32] theta itself: an exact score below it cannot be in the top-k
+  int* qcnt = reinterpret_cast<int*>(theta_lds + 32);         // [32] this workgroup's exact pairs per query
+  int* qbase = qcnt + 32;                                     // [32] their place in the query's list
+  int* misc = qbase + 32;                                     // [0] wg_n, [1] all bound units in, [2] last workgroup, [3] overflowed queries
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int B = p.B, k = p.k;
+  const int G = (int)gridDim.x;
+  const int ngq = B > 16 ? 2 : 1;  // query groups of 16 (block-uniform)
+  int* cnt_g = p.state + SMALL_STATE_CNT0;
+  unsigned* gmax_g = reinterpret_cast<unsigned*>(p.state + SMALL_STATE_GMAX0);
+
+  const unsigned lane16 = (unsigned)lane * 16u;
+  f32x4 A0[16], A1[16];
+#define RG_SLOAD(buf_, base_, u_)                                                                                  \
+  {                                                                                                                \
+    const char* ub_ = reinterpret_cast<const char*>(base_) + (uint64_t)(u_) * (16 * 1024) + lane16;                \
+    _Pragma("unroll") for (int b_ = 0; b_ < 16; ++b_)                                                              \
+      buf_[b_] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ub_ + b_ * 1024));                      \
+  }
+  // this wave's first unit of the bound pass: its loads need no query -- in flight during the prepare phase
+  const int64_t u_first = (int64_t)blockIdx.x * 8 + wave;
+  if (u_first < p.bound_units) RG_SLOAD(A0, p.Kb, u_first);
+
+  // ---- 0. prepare: one wave per query row (filter_prep_kernel's arithmetic) ----------------------------------------
+  if (tid < 32) qcnt[tid] = 0;
+  if (tid < 4) misc[tid] = 0;
+  for (int q = wave; q < 16 * ngq; q += 8) {
+    constexpr int NCH = D / 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < NCH && q < B) v = reinterpret_cast<const float4*>(p.Q + (int64_t)q * D)[lane];
+    float pp = 0.f;
+    pp = fmaf(v.x, v.x, pp);
+    pp = fmaf(v.y, v.y, pp);
+    pp = fmaf(v.z, v.z, pp);
+    pp = fmaf(v.w, v.w, pp);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) pp = __fadd_rn(pp, __shfl_xor(pp, off));
+    const float d = fmaxf(sqrtf(pp), 1e-12f);
+    v.x = v.x / d; v.y = v.y / d; v.z = v.z / d; v.w = v.w / d;
+    if (lane < NCH) *reinterpret_cast<float4*>(qn + q * QLD + 4 * lane) = v;
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    float e2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float dd = x[e] - (float)(__bf16)x[e];
+      e2 = fmaf(dd, dd, e2);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) e2 += __shfl_xor(e2, off);
+    unsigned am = max(max(__float_as_uint(fabsf(v.x)), __float_as_uint(fabsf(v.y))), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w))));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, off));
+    const float sq = __uint_as_float(am) / 127.f;
+    float e8 = 0.f;
+    if (I8 && sq > 0.f) {
+      const float inv = 1.f / sq;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int qi = quantize_i8(x[e], inv);
+        const float dd = fmaf(sq, (float)qi, -x[e]);
+        e8 = fmaf(dd, dd, e8);
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) e8 += __shfl_xor(e8, off);
+    if (lane == 0) {
+      sc_eqb[q] = sqrtf(e2) * 1.0000002f;
+      sc_eq8[q] = sqrtf(e8) * 1.000001f;
+      sc_qs[q] = sq;
+      sc_flag[q] = (q < B && am == 0u) ? 2 : 0;
+    }
+  }
+  __syncthreads();
+  RG_SSTAMP(1);
+
+  // the bound pass's B operands (bf16): lane j + 16 g of k-step t of group gq = elements 32 t + 8 g .. + 7 of query 16 gq + j
+  bf16x8 bqb[2 * GB::KS];
+#pragma unroll
+  for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+    for (int t = 0; t < GB::KS; ++t) {
+      const float* src = qn + (16 * gq + j) * QLD + 32 * t + 8 * g;
+      const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+      bf16x8 o;
+      o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
+      o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
+      bqb[gq * GB::KS + t] = gq < ngq ? o : bf16x8{};
+    }
+
+  // ---- 1. bound: units 8 b + w (+ 8 G i) of the prefix belong to wave w of workgroup b -- neighbouring units, mostly one
+  // part: the workgroup combines its waves' maxima in LDS and publishes ONE atomicMax per query and part (agent-scope
+  // atomics execute at the memory side of the fabric: ~50 of them on one word, as when every wave published its own,
+  // took 10 us of a 16-query call) ----------------------------------------------------------------------------------
+  {
+    float* wmax = tile_all;                                       // [8][32] the wave's running maxima of its current part
+    int* wpart = reinterpret_cast<int*>(tile_all + 8 * 32);       // [8] that part (-1: none)
+    int cur_part = -1;  // wave-uniform
+    if (lane < 32) wmax[wave * 32 + lane] = RG_NEG_INF;
+    for (int64_t u = u_first; u < p.bound_units; u += (int64_t)G * 8) {
+      if (u != u_first) RG_SLOAD(A0, p.Kb, u);                    // (the first unit's loads were issued before the prepare phase)
+      const int part = (int)(u * p.parts / p.bound_units);         // (parts <= units: a unit lies in one part)
+      if (part != cur_part) {
+        if (cur_part >= 0 && lane < B) {                           // (rare: a wave with units in several parts publishes the old one itself)
+          const float v = wmax[wave * 32 + lane];
+          if (v > RG_NEG_INF) atomicMax(gmax_g + lane * SMALL_PARTS_MAX + cur_part, small_f2u(v));
+          wmax[wave * 32 + lane] = RG_NEG_INF;
+        }
+        cur_part = part;
+      }
+#pragma unroll
+      for (int sub = 0; sub < GB::SUBS; ++sub) {
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq) {
+          if (gq >= ngq) break;
+          f32x4 acc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+#pragma unroll
+          for (int t = 0; t < GB::KS; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+              acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A0[(sub * GB::KS + t) * 2 + h]),
+                                                               bqb[gq * GB::KS + t], acc[h], 0, 0, 0);
+          float m = acc[0][0];
+#pragma unroll
+          for (int r = 1; r < 4; ++r) m = fmaxf(m, acc[0][r]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[1][r]);
+          m = fmaxf(m, __shfl_xor(m, 16));
+          m = fmaxf(m, __shfl_xor(m, 32));
+          if (g == 0) wmax[wave * 32 + 16 * gq + j] = fmaxf(wmax[wave * 32 + 16 * gq + j], m);
+        }
+      }
+    }
+    if (lane == 0) wpart[wave] = cur_part;
+    __syncthreads();
+    if (tid < B) {  // runs of waves in one part leave as one atomic
+      float m = RG_NEG_INF;
+      int part = -1;
+      for (int w = 0; w < 8; ++w) {
+        const int pw = wpart[w];
+        if (pw < 0) continue;
+        if (pw != part) {
+          if (part >= 0 && m > RG_NEG_INF) atomicMax(gmax_g + tid * SMALL_PARTS_MAX + part, small_f2u(m));
+          part = pw;
+          m = RG_NEG_INF;
+        }
+        m = fmaxf(m, wmax[w * 32 + tid]);
+      }
+      if (part >= 0 && m > RG_NEG_INF) atomicMax(gmax_g + tid * SMALL_PARTS_MAX + part, small_f2u(m));
+    }
+  }
+  // (the part maxima are agent-scope atomics: performed once they are acknowledged -- no cache write-back is needed to
+  // publish them, only this wait before the workgroup announces itself)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  RG_SSTAMP(2);
+  // the filter pass's B operands
+  i32x4 bq8[I8 ? 2 * GF::KS : 1];
+  if constexpr (I8) {
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+      for (int t = 0; t < GF::KS; ++t) {  // elements 64 t + 16 g .. + 15 of query 16 gq + j
+        const int q = 16 * gq + j;
+        const float* src = qn + q * QLD + 64 * t + 16 * g;
+        const float sq = sc_qs[q];
+        const float inv = sq > 0.f ? 1.f / sq : 0.f;
+        i32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 a = *reinterpret_cast<const float4*>(src + 4 * c);
+          o[c] = (int)(((unsigned)quantize_i8(a.x, inv) & 0xFFu) | (((unsigned)quantize_i8(a.y, inv) & 0xFFu) << 8) |
+                       (((unsigned)quantize_i8(a.z, inv) & 0xFFu) << 16) | (((unsigned)quantize_i8(a.w, inv) & 0xFFu) << 24));
+        }
+        bq8[gq * GF::KS + t] = (gq < ngq && sq > 0.f) ? o : i32x4{0, 0, 0, 0};
+      }
+  }
+
+  // this wave's units of the filter pass: gw, gw + W, ...; the first one's loads fly during the wait
+  const int64_t W = (int64_t)G * 8;
+  const int64_t gw = (int64_t)blockIdx.x * 8 + wave;
+  const int64_t n_mine = gw < p.nunits ? (p.nunits - gw + W - 1) / W : 0;
+  const char* fbase = I8 ? reinterpret_cast<const char*>(p.Kb8) : reinterpret_cast<const char*>(p.Kb);
+  if (n_mine > 0) RG_SLOAD(A0, fbase, gw);
+
+  // ---- 2. announce the bound units, wait (bounded), thresholds ------------------------------------------------------
+  __syncthreads();
+  RG_SSTAMP(3);
+  // Cross-workgroup traffic of this kernel is agent-scope ATOMICS only (read-modify-writes, and relaxed atomic loads /
+  // stores, which go past the XCD's L2): a __threadfence() would write the whole L2 back (buffer_wbl2: 10 - 30 us with 256
+  // workgroups at it -- measured: it was most of a 175-us first version); ordering comes from s_waitcnt vmcnt(0) before
+  // the barrier that precedes a workgroup's announcement.
+  if (tid == 0) {
+    __hip_atomic_fetch_add(p.state, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = wall_clock64();
+    int in = __hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (in < G && (unsigned)(wall_clock64() - t0) < p.wait_ticks) {
+      __builtin_amdgcn_s_sleep(1);
+      in = __hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    misc[1] = in >= G;
+  }
+  __syncthreads();
+  RG_SSTAMP(4);
+  const float ek_b = sqrtf(__uint_as_float(*p.max_kerr2));
+  const float ek_8 = I8 ? sqrtf(__uint_as_float(p.tail8[0])) : 0.f;
+  const float sk_8 = I8 ? __uint_as_float(p.tail8[1]) : 0.f;
+  // threshold of query q from the part maxima published so far (one wave; every lane returns with thr_lds[q] written)
+  auto load_part = [&](int q) -> unsigned {  // this lane's part maximum of query q as published so far (0: nothing yet)
+    return (q < B && lane < p.parts) ? __hip_atomic_load(gmax_g + q * SMALL_PARTS_MAX + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  };
+  auto make_threshold = [&](int q, unsigned u) {
+    const float e = sc_eqb[q];
+    const float eps_b = fmaf(fmaf(e, ek_b, e + ek_b), 1.0009765625f, FILTER_EPS_SLACK);
+    float v = RG_NEG_INF;
+    if (u != 0u) v = __fsub_rn(small_u2f(u), eps_b);
+    int rank = 0;
+    for (int o = 0; o < p.parts; ++o) {
+      const float x = __shfl(v, o);
+      rank += (x > v || (x == v && o < lane)) ? 1 : 0;
+    }
+    const unsigned long long kth = __ballot(lane < p.parts && rank == k - 1);
+    const float theta = kth ? __shfl(v, __ffsll((long long)kth) - 1) : RG_NEG_INF;
+    if (lane == 0) {
+      theta_lds[q] = fmaxf(theta_lds[q], theta);
+      float out;
+      if (sc_flag[q]) {
+        out = I8 ? __int_as_float(INT_MAX) : __builtin_huge_valf();   // a zero query passes nothing (answered at the end)
+      } else if constexpr (I8) {
+        const float e8 = sc_eq8[q];
+        const float eps = fmaf(fmaf(e8, ek_8, e8 + ek_8), 1.0009765625f, FILTER_EPS_SLACK);
+        const float sc = sc_qs[q] * sk_8;
+        int t;
+        if (!(sc > 0.f)) t = INT_MIN;
+        else {
+          const float xq = __fsub_rn(theta, eps) / sc;
+          t = !(xq > -8.4e6f) ? INT_MIN : (xq > 8.4e6f ? INT_MAX : (int)floorf(xq) - 2);
+        }
+        // (never below a threshold already in force: a list that passed its cap has raised it to INT_MAX)
+        const int old = __float_as_int(thr_lds[q]);
+        out = __int_as_float(t > old ? t : old);
+      } else {
+        const float t = __fsub_rn(theta, eps_b);
+        out = fmaxf(t, thr_lds[q]);
+      }
+      thr_lds[q] = out;
+    }
+  };
+  if (tid < 32) {
+    thr_lds[tid] = I8 ? __int_as_float(tid < B ? INT_MIN : INT_MAX) : (tid < B ? RG_NEG_INF : __builtin_huge_valf());
+    theta_lds[tid] = RG_NEG_INF;
+  }
+  __syncthreads();
+  {  // a wave's queries: wave, wave + 8, ... -- all their part maxima are requested before the first is used
+    unsigned up[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) up[c] = load_part(wave + 8 * c);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (wave + 8 * c < B) make_threshold(wave + 8 * c, up[c]);
+  }
+  __syncthreads();
+  RG_SSTAMP(5);
+  bool refresh = wave == 0 && misc[1] == 0;   // (wave-uniform) some workgroup's bound units were still missing
+
+  // ---- 3. filter pass ---------------------------------------------------------------------------------------------
+  uint2* wbuf = wbuf_all + wave * L::CAND_BUF;
+  int wcnt = 0;  // wave-uniform
+  // exact score of (query q, key) by this lane alone (the slow paths: a flood of candidates in mid-stream)
+  auto lane_score = [&](int q, int key) {
+    const float4* kr = reinterpret_cast<const float4*>(p.Kn + (int64_t)key * D);
+    const float4* qr = reinterpret_cast<const float4*>(qn + q * QLD);
+    float acc = 0.f;
+#pragma unroll 8
+    for (int d4 = 0; d4 < D / 4; ++d4) {
+      const float4 kv = kr[d4], qv = qr[d4];
+      acc = fmaf(qv.x, kv.x, acc);
+      acc = fmaf(qv.y, kv.y, acc);
+      acc = fmaf(qv.z, kv.z, acc);
+      acc = fmaf(qv.w, kv.w, acc);
+    }
+    return acc;
+  };
+  auto append_global = [&](int q, int key, float s) {  // one atomic per pair: only where a workgroup's LDS list is full
+    const int pos = atomicAdd(cnt_g + 32 * q, 1);
+    if (pos < SMALL_LIST_CAP) {
+      __hip_atomic_store(p.list_s + (int64_t)q * SMALL_LIST_CAP + pos, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.list_k + (int64_t)q * SMALL_LIST_CAP + pos, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      thr_lds[q] = I8 ? __int_as_float(INT_MAX) : __builtin_huge_valf();   // the exact scan answers this query: pass nothing more
+    }
+  };
+  // mid-stream flush (the buffer filled up: a flood): every lane scores its entries' keys itself
+  auto flush_slow = [&]() {
+    for (int i0 = 0; i0 < wcnt; i0 += 64) {
+      const int i = i0 + lane;
+      if (i < wcnt) {
+        const uint2 e = wbuf[i];
+        const int q = (int)((e.y >> 8) & 0xFFu);
+        unsigned mk = e.y & 0xFFu;
+        while (mk) {
+          const int r = __ffs(mk) - 1;
+          mk &= mk - 1;
+          const int key = (int)e.x + (r & 3) + 16 * (r >> 2);
+          const float s = lane_score(q, key);
+          if (s >= theta_lds[q]) append_global(q, key, s);
+        }
+      }
+    }
+    wcnt = 0;
+  };
+  auto epilogue = [&](const acc_t (&a)[2], int gq, int64_t unit, int sub) {
+    const int64_t key_base = (unit * GF::SUBS + sub) * 32 + 4 * g;  // the lane's keys: + r + 16 h  (mask bit 4 h + r)
+    unsigned mk = 0;
+    bool any;
+    if constexpr (I8) {
+      int m = a[0][0];
+#pragma unroll
+      for (int r = 1; r < 4; ++r) m = max(m, a[0][r]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m = max(m, a[1][r]);
+      const int th = __float_as_int(thr_lds[16 * gq + j]);
+      any = __any(m >= th);
+      if (any) {
+        const unsigned tm1 = (unsigned)(max(-(1 << 24), min(1 << 24, th)) - 1);
+#pragma unroll
+        for (int b = 7; b >= 0; --b) mk = __builtin_amdgcn_alignbit(mk, tm1 - (unsigned)a[b >> 2][b & 3], 31);
+        if (th == INT_MAX) mk = 0;  // (the clamp would let |I| >= 2^24 through: impossible, but the sentinel must pass nothing)
+      }
+    } else {
+      float m = a[0][0];
+#pragma unroll
+      for (int r = 1; r < 4; ++r) m = fmaxf(m, a[0][r]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m = fmaxf(m, a[1][r]);
+      const float th = thr_lds[16 * gq + j];
+      any = __any(m >= th);
+      if (any) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mk |= (a[h][r] >= th) ? (1u << (4 * h + r)) : 0u;
+      }
+    }
+    if (!any) return;
+    if (key_base + 32 > p.N) {
+      unsigned vm = 0;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) vm |= (key_base + (r & 3) + 16 * (r >> 2) < p.N) ? (1u << r) : 0u;
+      mk &= vm;
+    }
+    const unsigned long long bal = __ballot(mk != 0);
+    if (bal) {
+      const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+      if (mk) wbuf[pos] = make_uint2((unsigned)key_base, mk | ((unsigned)(16 * gq + j) << 8));
+      wcnt += __popcll(bal);
+    }
+  };
+  auto process = [&](f32x4 (&A)[16], int64_t unit) {
+    if (wcnt > L::CAND_BUF - 128 * GF::SUBS) flush_slow();  // two groups x SUBS sub-tiles x <= 64 entries
+#pragma unroll
+    for (int sub = 0; sub < GF::SUBS; ++sub) {
+      acc_t acc[2][2];  // [group][half]
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq) acc[gq][0] = acc[gq][1] = acc_t{0, 0, 0, 0};
+#pragma unroll
+      for (int t = 0; t < GF::KS; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int gq = 0; gq < 2; ++gq) {
+            if (gq >= ngq) continue;
+            if constexpr (I8)
+              acc[gq][h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, A[(sub * GF::KS + t) * 2 + h]),
+                                                                 bq8[gq * GF::KS + t], acc[gq][h], 0, 0, 0);
+            else
+              acc[gq][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[(sub * GF::KS + t) * 2 + h]),
+                                                                   bqb[gq * GF::KS + t], acc[gq][h], 0, 0, 0);
+          }
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq)
+        if (gq < ngq) epilogue(acc[gq], gq, unit, sub);
+    }
+  };
+  if (n_mine > 0) {
+    int64_t i = 0;
+    for (; i + 2 <= n_mine; i += 2) {  // pairs: A0 then A1, the other buffer's loads always in flight
+      RG_SLOAD(A1, fbase, gw + (i + 1) * W);
+      process(A0, gw + i * W);
+      if (i + 2 < n_mine) RG_SLOAD(A0, fbase, gw + (i + 2) * W);
+      process(A1, gw + (i + 1) * W);
+      if (refresh && (i & 30) == 30) {   // (wave 0 of a workgroup that moved on early) the others' maxima may have arrived
+        const bool all_in = __hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= G;
+        for (int q = 0; q < B; ++q) make_threshold(q, load_part(q));
+        refresh = !all_in;
+      }
+    }
+    if (i < n_mine) process(A0, gw + i * W);  // odd count: the last unit, nothing behind it
+  }
+#undef RG_SLOAD
+
+  RG_SSTAMP(6);
+  // ---- 4. exact scores of this wave's candidates: (key, query) pairs, 16 rows per memory round trip ------------------
+  {
+    int2* pairs = pair_all + wave * SMALL_PAIRBUF;
+    float* tile = tile_all + wave * 16 * RESCORE_LD;
+    for (int i0 = 0; i0 < wcnt; i0 += 64) {
+      const int i = i0 + lane;
+      uint2 e = make_uint2(0u, 0u);
+      if (i < wcnt) e = wbuf[i];
+      unsigned mk = e.y & 0xFFu;
+      const int q = (int)((e.y >> 8) & 0xFFu);
+      int incl = __popc(mk);
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+      }
+      const int total = __shfl(incl, 63);  // <= 512 = SMALL_PAIRBUF
+      int at = incl - __popc(mk);
+      while (mk) {
+        const int r = __ffs(mk) - 1;
+        mk &= mk - 1;
+        pairs[at++] = make_int2((int)e.x + (r & 3) + 16 * (r >> 2), q);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int r0 = 0; r0 < total; r0 += 16) {
+        int key = -1, pq = 0;
+        if (lane < 16 && r0 + lane < total) {
+          const int2 pr = pairs[r0 + lane];
+          key = pr.x;
+          pq = pr.y;
+        }
+        const float s = coop_scores_few<D>(reinterpret_cast<const float4*>(qn + pq * QLD), p.Kn, key, lane, tile);
+        // theta is a proven lower bound of the query's final k-th best EXACT score: a key that scores below it is out
+        // (the approximate pass let it through on its error bound; ~3 of 4 candidates end here)
+        if (key >= 0 && s < theta_lds[pq]) key = -1;
+        const unsigned long long have = __ballot(key >= 0);
+        int base = 0;
+        if (lane == 0) base = atomicAdd(misc, __popcll(have));
+        base = __shfl(base, 0);
+        if (key >= 0) {
+          const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(have >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)have, 0u));
+          if (slot < SMALL_WG_LIST) {
+            wg_s[slot] = s;
+            wg_k[slot] = key;
+            wg_q[slot] = pq;
+          } else {
+            append_global(pq, key, s);
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // (the pair buffer is rewritten by the next chunk)
+    }
+  }
+  __syncthreads();
+  RG_SSTAMP(7);
+  {  // one reservation per query for the workgroup's pairs
+    const int n = misc[0] < SMALL_WG_LIST ? misc[0] : SMALL_WG_LIST;
+    int r[SMALL_WG_LIST / 512];
+#pragma unroll
+    for (int c = 0; c < SMALL_WG_LIST / 512; ++c) {
+      const int i = tid + 512 * c;
+      r[c] = i < n ? atomicAdd(qcnt + wg_q[i], 1) : 0;
+    }
+    __syncthreads();
+    if (tid < B && qcnt[tid] > 0) qbase[tid] = atomicAdd(cnt_g + 32 * tid, qcnt[tid]);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < SMALL_WG_LIST / 512; ++c) {
+      const int i = tid + 512 * c;
+      if (i < n) {
+        const int q = wg_q[i];
+        const int pos = qbase[q] + r[c];
+        if (pos < SMALL_LIST_CAP) {  // (agent-scope stores: written through, visible to the last workgroup without a fence)
+          __hip_atomic_store(p.list_s + (int64_t)q * SMALL_LIST_CAP + pos, wg_s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(p.list_k + (int64_t)q * SMALL_LIST_CAP + pos, wg_k[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  }
+
+  // ---- 5. the last workgroup selects ----------------------------------------------------------------------------------
+  RG_SSTAMP(8);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's list stores and reservations are acknowledged
+  __syncthreads();
+  RG_SSTAMP(9);
+  if (tid == 0) misc[2] = __hip_atomic_fetch_add(p.state + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1;
+  __syncthreads();
+  if (!misc[2]) return;
+  RG_SSTAMP(10);
+  float* ps = reinterpret_cast<float*>(smem + L::scan_ps);      // [4][32] (also: a wave's staging row for wave_select)
+  int64_t* pi = reinterpret_cast<int64_t*>(smem + L::scan_pi);  // [4][32]
+  // per-wave staging for the selection (the stream's buffers are free now): 512 canonical keys + winners
+  unsigned long long* surv = reinterpret_cast<unsigned long long*>(pair_all + wave * SMALL_PAIRBUF);
+  for (int q = wave; q < B; q += 8) {
+    float* os = p.out_s + (int64_t)q * k;
+    int64_t* oi = p.out_i + (int64_t)q * k;
+    if (sc_flag[q]) {  // zero query: every score +0, canonical order = row order
+      if (lane < k) {
+        os[lane] = 0.f;
+        oi[lane] = p.idx_base + lane;
+      }
+      continue;
+    }
+    const int n = __hip_atomic_load(cnt_g + 32 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef RG_SMALL_TIMING
+    if (q == 0 && lane == 0) g_small_t[0][13] = (unsigned long long)n;
+    if (q == 0 && lane == 0) g_small_t[0][14] = (unsigned long long)misc[0];
+#endif
+    if (n > SMALL_LIST_CAP) {
+      if (lane == 0) atomicOr(qcnt + q, 1 << 30);  // (marks the query for the scan below; qcnt is free now)
+      continue;
+    }
+    const float* ls = p.list_s + (int64_t)q * SMALL_LIST_CAP;
+    const int* lk = p.list_k + (int64_t)q * SMALL_LIST_CAP;
+    auto load_pair = [&](int i, float& s, int& id) {  // (other workgroups' stores: past this CU's caches)
+      s = RG_NEG_INF;
+      id = INT_MAX;
+      if (i < n) {
+        s = __hip_atomic_load(ls + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        id = __hip_atomic_load(lk + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    };
+    if (n <= 128) {
+      float s2[2];
+      int id2[2];
+      load_pair(lane, s2[0], id2[0]);
+      load_pair(lane + 64, s2[1], id2[1]);
+      wave_select<2>(s2, id2, k, lane, p.idx_base, os, oi);
+      continue;
+    }
+    // the k-th largest of the 64 lanes' best pairs bounds the k-th best of all from below: survivors are few
+    unsigned long long best = 0ull;
+    const bool one_pass = n <= 1024;  // (wave-uniform) the list stays in registers: sixteen pairs per lane
+    unsigned long long held[16];
+    if (one_pass) {
+      float s16[16];
+      int id16[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) load_pair(lane + 64 * u, s16[u], id16[u]);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        held[u] = id16[u] == INT_MAX ? 0ull : small_key64(s16[u], id16[u]);
+        best = held[u] > best ? held[u] : best;
+      }
+    }
+    for (int i0 = 0; i0 < n && !one_pass; i0 += 64 * 8) {  // (eight independent loads per lane in flight)
+      float s8[8];
+      int id8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) load_pair(i0 + lane + 64 * u, s8[u], id8[u]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const unsigned long long key = id8[u] == INT_MAX ? 0ull : small_key64(s8[u], id8[u]);
+        best = key > best ? key : best;
+      }
+    }
+    int rank = 0;
+    for (int o = 0; o < 64; ++o) {
+      const unsigned long long x = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(best >> 32), o) << 32) |
+                                   (unsigned)__builtin_amdgcn_readlane((int)(unsigned)best, o);
+      rank += (x > best || (x == best && o < lane)) ? 1 : 0;
+    }
+    const unsigned long long kb = __ballot(rank == k - 1);
+    const int src = __ffsll((long long)kb) - 1;
+    const unsigned long long bound = ((unsigned long long)(unsigned)__shfl((int)(best >> 32), src) << 32) | (unsigned)__shfl((int)(unsigned)best, src);
+    int ns = 0;  // wave-uniform
+    if (one_pass) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const bool keep = held[u] != 0ull && held[u] >= bound;
+        const unsigned long long bal = __ballot(keep);
+        const int pos = ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+        if (keep && pos < 128) surv[pos] = held[u];
+        ns += __popcll(bal);
+      }
+    }
+    for (int i0 = 0; i0 < n && !one_pass; i0 += 64 * 8) {
+      float s8[8];
+      int id8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) load_pair(i0 + lane + 64 * u, s8[u], id8[u]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const unsigned long long key = id8[u] == INT_MAX ? 0ull : small_key64(s8[u], id8[u]);
+        const bool keep = key != 0ull && key >= bound;
+        const unsigned long long bal = __ballot(keep);
+        const int pos = ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+        if (keep && pos < 128) surv[pos] = key;
+        ns += __popcll(bal);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (ns <= 128) {
+      float s2[2];
+      int id2[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        s2[u] = RG_NEG_INF;
+        id2[u] = INT_MAX;
+        if (lane + 64 * u < ns) {
+          const unsigned long long key = surv[lane + 64 * u];
+          s2[u] = select_unord((unsigned)(key >> 32));
+          id2[u] = (int)~(unsigned)key;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      wave_select<2>(s2, id2, k, lane, p.idx_base, os, oi);
+    } else {
+      // (thousands of pairs tie with the bound: a bank of duplicates the collapsing did not see) chunks of 64 against the
+      // running winners, staged through LDS
+      float* ws_ = reinterpret_cast<float*>(surv);                 // [32] running scores
+      int64_t* wi_ = reinterpret_cast<int64_t*>(surv + 32);        // [32] running local ids
+      if (lane < 32) {
+        ws_[lane] = RG_NEG_INF;
+        wi_[lane] = INT64_MAX;
+      }
+      for (int i0 = 0; i0 < n; i0 += 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float s2[2];
+        int id2[2];
+        load_pair(i0 + lane, s2[0], id2[0]);
+        s2[1] = RG_NEG_INF;
+        id2[1] = INT_MAX;
+        if (lane < k) {
+          s2[1] = ws_[lane];
+          id2[1] = wi_[lane] >= INT_MAX ? INT_MAX : (int)wi_[lane];
+        }
+        __builtin_amdgcn_wave_barrier();
+        wave_select<2>(s2, id2, k, lane, 0, ws_, wi_);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (lane < k) {
+        os[lane] = ws_[lane];
+        oi[lane] = wi_[lane] >= INT_MAX ? INT64_MAX : wi_[lane] + p.idx_base;
+      }
+    }
+  }
+  __syncthreads();
+  RG_SSTAMP(11);
+  // overflowed queries: the exact scan (four waves stage rows through 64-row tiles; the others wait at the barriers)
+  int n_over = 0;
+  for (int q = 0; q < B; ++q) {
+    if (!(qcnt[q] >> 30)) continue;  // (block-uniform)
+    ++n_over;
+    const float4* qs = reinterpret_cast<const float4*>(qn + q * QLD);
+    float (*tile4)[64 * RESCORE_LD] = reinterpret_cast<float (*)[64 * RESCORE_LD]>(smem + L::scan_tile);
+    float (*ps4)[32] = reinterpret_cast<float (*)[32]>(ps);
+    int64_t (*pi4)[32] = reinterpret_cast<int64_t (*)[32]>(pi);
+    const int w = wave;
+    float es = RG_NEG_INF;
+    int ei = INT_MAX;
+    if (w < 4) {
+      float kth_s = RG_NEG_INF;
+      int kth_i = INT_MAX;
+      for (int64_t base = (int64_t)w * 64; base < p.N; base += 256) {
+        const int key = base + lane < p.N ? (int)(base + lane) : -1;
+        const float sc = coop_scores<D>(qs, p.Kn, key, lane, tile4[w]);
+        unsigned long long pend = __ballot(key >= 0 && cand_better(sc, key, kth_s, kth_i));
+        while (pend) {
+          const int src = __ffsll((long long)pend) - 1;
+          pend &= pend - 1;
+          const float s = __shfl(sc, src);
+          const int id = __shfl(key, src);
+          const unsigned long long ahead = __ballot(lane < k && cand_better(es, ei, s, id));
+          const int pos = __popcll(ahead);
+          const float us = __shfl_up(es, 1);
+          const int ui = __shfl_up(ei, 1);
+          if (pos < k) {
+            if (lane == pos) {
+              es = s;
+              ei = id;
+            } else if (lane > pos && lane < k) {
+              es = us;
+              ei = ui;
+            }
+          }
+          kth_s = __shfl(es, k - 1);
+          kth_i = __shfl(ei, k - 1);
+          pend &= __ballot(key >= 0 && cand_better(sc, key, kth_s, kth_i));
+        }
+      }
+      if (lane < 32) {
+        ps4[w][lane] = lane < k ? es : RG_NEG_INF;
+        pi4[w][lane] = (lane < k && ei != INT_MAX) ? (int64_t)ei : INT64_MAX;
+      }
+    }
+    __syncthreads();
+    if (w == 0) {  // 4 k <= 128 partial winners: two per lane
+      float s2[2];
+      int id2[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = lane + 64 * u;
+        const bool have = e < 4 * k;
+        s2[u] = have ? ps4[e / k][e % k] : RG_NEG_INF;
+        const int64_t pv = have ? pi4[e / k][e % k] : INT64_MAX;
+        id2[u] = pv >= INT_MAX ? INT_MAX : (int)pv;
+      }
+      wave_select<2>(s2, id2, k, lane, p.idx_base, p.out_s + (int64_t)q * k, p.out_i + (int64_t)q * k);
+    }
+    __syncthreads();
+  }
+  // leave the state zeroed for the next call (every other workgroup has finished: the ticket said so)
+  for (int i = tid; i < SMALL_STATE_INTS; i += 512) p.state[i] = 0;
+  if (tid == 0) *p.overflow = n_over;
+  RG_SSTAMP(12);
+#ifdef RG_SMALL_TIMING
+  if (tid == 0)
+    for (int i = 0; i < 16; ++i) g_small_t[1][i] = st_[i];
+#endif
+}
+
+static int small_prefix_keys(int B, bool i8) {
+  // keys of the bound pass's prefix (with G = 4 k parts the bound is worth the exact k-th best of ~0.85 of it): one query's
+  // call streams 16 K keys of the bf16 copy before its pass over the int8 copy; more queries buy a sharper bound with a
+  // longer prefix (their candidates cost B times as much).  The int8 bound is ~5x wider: twice the prefix.
+  const int base = B <= 2 ? 8192 : (B <= 8 ? 16384 : 32768);
+  return i8 ? 2 * base : base;
+}
+
+template <int D, bool I8>
+static int launch_small(const SmallParams& p, int grid, hipStream_t st) {
+  using L = SmallLds<D, I8>;
+  static DeviceOnce lds_once;
+  if (hipError_t e = raise_dynamic_lds(lds_once, &topk_small_kernel<D, I8>, 160 * 1024); e != hipSuccess) {
+    set_error("topk_cosine_small: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+    return RAGRAPH_EDEVICE;
+  }
+  hipLaunchKernelGGL((topk_small_kernel<D, I8>), dim3((unsigned)grid), dim3(512), L::bytes, st, p);
+  RG_CHECK_LAUNCH("topk_cosine_small");
+#ifdef RG_SMALL_TIMING
+  {
+    (void)hipDeviceSynchronize();
+    unsigned long long t[2][16];
+    (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_small_t), sizeof(t));
+    static const char* names[13] = {"", "prepare", "bound", "operands", "wait", "thresholds", "stream", "rescoring", "store", "fence", "ticket", "select", "scan+reset"};
+    for (int b = 0; b < 2; ++b) {
+      fprintf(stderr, "[small timing, %s workgroup of %d, 10 ns ticks]", b ? "last" : "first", grid);
+      for (int i = 1; i < 13; ++i)
+        if (t[b][i] && t[b][i - 1]) fprintf(stderr, " %s %lld", names[i], (long long)(t[b][i] - t[b][i - 1]));
+      fprintf(stderr, " | entered %lld after workgroup 0, total %lld\n", (long long)(t[b][0] - t[0][0]), (long long)(t[b][b ? 12 : 9] - t[b][0]));
+    }
+    fprintf(stderr, "[small timing] exact pairs of query 0: %lld; pairs of the last workgroup: %lld\n", (long long)t[0][13], (long long)t[0][14]);
+  }
+#endif
+  return RAGRAPH_OK;
+}
+
+}  // namespace ragraph
+
+using namespace ragraph;
+
+extern "C" int ragraph_topk_cosine_small_ok(int64_t B, int64_t N, int D, int k) {
+  return B >= 1 && B <= SMALL_MAX_B && (D == 64 || D == 128 || D == 256) && k >= 1 && k <= 32 && N >= 65536 && N < ((int64_t)1 << 31);
+}
+extern "C" size_t ragraph_topk_cosine_small_state_bytes(void) { return (size_t)SMALL_STATE_INTS * sizeof(int); }
+extern "C" size_t ragraph_topk_cosine_small_workspace_bytes(int64_t B, int D, int k) {
+  if (B < 1 || B > SMALL_MAX_B) return 0;
+  return (size_t)B * SMALL_LIST_CAP * (sizeof(float) + sizeof(int));
+}
+
+static bool small_uses_i8(int D) {
+  static const bool i8_env = [] { const char* e = getenv("RAGRAPH_FILTER_I8_DIRECT"); return !e || atoi(e) != 0; }();  // A/B
+  return (D == 128 || D == 256) && i8_env && filter_thread_i8_cap() != 0;
+}
+// keys of the bf16 prefix a call's bound pass reads; *i8 = 1 when its filter pass streams the int8 copy (under this thread's cap)
+extern "C" int64_t ragraph_topk_cosine_small_prefix_keys(int64_t B, int64_t N, int D, int* i8) {
+  if (!ragraph_topk_cosine_small_ok(B, N, D, 1)) return 0;
+  const bool q8 = small_uses_i8(D);
+  if (i8) *i8 = q8 ? 1 : 0;
+  int64_t prefix = small_prefix_keys((int)B, q8);
+  if (prefix > N / 4) prefix = N / 4;
+  const int unit_b = D == 256 ? 32 : (D == 128 ? 64 : 128);
+  return prefix / unit_b * unit_b;
+}
+
+extern "C" int ragraph_topk_cosine_small_f32(const float* Q, int64_t B, const float* Kn, const uint16_t* Kb, int64_t N, int D, int k,
+                                             int64_t idx_base, float* out_scores, int64_t* out_idx, int* overflow, int* state,
+                                             void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(Q && Kn && Kb && out_scores && out_idx && overflow && state && ws, RAGRAPH_EINVAL, "topk_cosine_small: null pointer");
+  RG_REQUIRE(ragraph_topk_cosine_small_ok(B, N, D, k), RAGRAPH_EUNSUPPORTED,
+             "topk_cosine_small: B=%lld N=%lld D=%d k=%d outside 1..32 queries, N >= 65536, D in {64,128,256}, k <= 32", (long long)B,
+             (long long)N, D, k);
+  RG_REQUIRE(aligned16(Q) && aligned16(Kn) && aligned16(Kb), RAGRAPH_EINVAL, "topk_cosine_small: Q / Kn / Kb must be 16-byte aligned");
+  RG_REQUIRE(ws_bytes >= ragraph_topk_cosine_small_workspace_bytes(B, D, k), RAGRAPH_EWORKSPACE, "topk_cosine_small: workspace too small");
+  const char* wt = getenv("RAGRAPH_SMALL_WAIT_TICKS");  // (read per call: the tests force the move-on-early path with 0)
+  const unsigned wait_ticks = wt ? (unsigned)atoll(wt) : 3000u;
+  const bool i8 = small_uses_i8(D);
+  const int64_t npad = (N + FILTER_PAD_KEYS - 1) / FILTER_PAD_KEYS * FILTER_PAD_KEYS;
+  SmallParams p{};
+  p.Q = Q;
+  p.Kn = Kn;
+  p.Kb = Kb;
+  p.max_kerr2 = reinterpret_cast<const unsigned*>(Kb + npad * D);
+  p.Kb8 = reinterpret_cast<const signed char*>(Kb + (npad + 1) * D);
+  p.tail8 = reinterpret_cast<const unsigned*>(p.Kb8 + npad * D);
+  p.N = N;
+  p.idx_base = idx_base;
+  p.B = (int)B;
+  p.k = k;
+  const int unit_b = D == 256 ? 32 : (D == 128 ? 64 : 128);            // keys per 16-KiB unit of the bf16 copy
+  const int unit_f = i8 ? 2 * unit_b : unit_b;                          // ... of the copy the filter pass streams
+  int64_t prefix = small_prefix_keys((int)B, i8);
+  if (prefix > N / 4) prefix = N / 4;
+  p.bound_units = prefix / unit_b;
+  int parts = 4 * k < SMALL_PARTS_MAX ? 4 * k : SMALL_PARTS_MAX;
+  if (parts > p.bound_units) parts = (int)p.bound_units;   // (a unit lies in one part)
+  RG_REQUIRE(parts >= k, RAGRAPH_EUNSUPPORTED, "topk_cosine_small: the bank is too short for a bound pass of k = %d parts", k);
+  p.parts = parts;
+  p.nunits = cdiv(N, (int64_t)unit_f);   // (the copies are padded to whole units: 256 keys)
+  p.wait_ticks = wait_ticks;
+  p.state = state;
+  p.list_s = reinterpret_cast<float*>(ws);
+  p.list_k = reinterpret_cast<int*>(p.list_s + (size_t)B * SMALL_LIST_CAP);
+  p.out_s = out_scores;
+  p.out_i = out_idx;
+  p.overflow = overflow;
+  const int cus = device_cus_multiple_of_8();
+  int64_t grid = cdiv(p.nunits, (int64_t)8);
+  if (grid > cus) grid = cus;
+  hipStream_t st = as_stream(stream);
+  if (D == 256) return i8 ? launch_small<256, true>(p, (int)grid, st) : launch_small<256, false>(p, (int)grid, st);
+  if (D == 128) return i8 ? launch_small<128, true>(p, (int)grid, st) : launch_small<128, false>(p, (int)grid, st);
+  return launch_small<64, false>(p, (int)grid, st);
+}

@@ -326,6 +326,58 @@ def topk_cosine_fused(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf16:
     return scores, idx
 
 
+SMALL_MAX_B = 32
+
+
+def small_helps(B: int, n_keys: int, D: int, k: int) -> bool:
+    """True when the single-launch kernel for a handful of queries against a large bank (csrc/topk_small.hip) is the way
+    to the exact top-k: up to 32 queries, banks the filtered path takes at any batch size (>= 65536 keys).  Measured on
+    MI355X, 1M x 256 bank, k = 10 (ms per call, this kernel vs the four-launch filtered call): DESIGN.md section 4.0c."""
+    if os.environ.get("RAGRAPH_EXACT_FP32") == "1" or os.environ.get("RAGRAPH_TOPK_SMALL", "1") == "0":
+        return False
+    return 1 <= B <= SMALL_MAX_B and D in (64, 128, 256) and k <= 32 and 65536 <= n_keys < 2 ** 31
+
+
+_small_state: dict = {}
+
+
+def _small_state_buf(device) -> torch.Tensor:
+    """The single-launch kernel's state words: zero before the first call, left zero by every call; one buffer per
+    (device, stream) -- calls on a stream are ordered."""
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    key = (dev, _raw_stream(dev) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream)
+    t = _small_state.get(key)
+    if t is None:
+        t = torch.zeros(N.lib().ragraph_topk_cosine_small_state_bytes() // 4, dtype=torch.int32, device=device)
+        _small_state[key] = t
+    return t
+
+
+def topk_cosine_small(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf16: torch.Tensor, k: int, idx_base: int = 0):
+    """Exact top-k (same bits as topk_cosine) of up to 32 queries in ONE launch (ragraph_topk_cosine_small_f32).  Returns
+    (scores, idx, overflow): overflow = 1-element int32 device tensor, the queries answered by the exact scan."""
+    L = _ready()
+    q = _f32c(q, "topk_cosine_small.q")
+    kn = _f32c(keys_normalized, "topk_cosine_small.keys")
+    B, D = q.shape
+    Nk = kn.shape[0]
+    if keys_bf16.dtype != torch.int16 or not keys_bf16.is_contiguous() or keys_bf16.shape[1] != D or \
+            keys_bf16.shape[0] != L.ragraph_keys_bf16_rows(Nk):
+        raise RagraphNativeError("topk_cosine_small: keys_bf16 must come from keys_to_bf16(keys_normalized)")
+    scores = torch.empty((B, k), dtype=torch.float32, device=q.device)
+    idx = torch.empty((B, k), dtype=torch.int64, device=q.device)
+    overflow = torch.empty(1, dtype=torch.int32, device=q.device)
+    nbytes = L.ragraph_topk_cosine_small_workspace_bytes(B, D, k)
+    if nbytes == 0:
+        raise RagraphNativeError(f"topk_cosine_small: unsupported shape B={B} N={Nk} D={D} k={k}")
+    ws = _workspace(nbytes, q.device)
+    N.check(L.ragraph_topk_cosine_small_f32(q.data_ptr(), B, kn.data_ptr(), keys_bf16.data_ptr(), Nk, D, k, idx_base,
+                                            scores.data_ptr(), idx.data_ptr(), overflow.data_ptr(),
+                                            _small_state_buf(q.device).data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+            "topk_cosine_small")
+    return scores, idx, overflow
+
+
 def theta_sharpen(gathered: torch.Tensor, theta: torch.Tensor, k: int) -> torch.Tensor:
     """In place: theta[b] = max(theta[b], k-th largest of gathered[:, b, :]) -- the per-level exchange of a filtered
     retrieval over a row-sharded bank (gathered = all_gather of every shard's best m exact scores, [G, B, m])."""

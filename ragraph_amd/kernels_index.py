@@ -103,6 +103,19 @@ class KeyIndex:
         elif acc[0] >= 4096:
             acc[0] = acc[1] = 0
 
+    def _note_overflow(self, over, B: int, had_i8: bool):
+        """After a filtered call: its overflow count travels to a pinned host word behind an event (no wait) and is
+        judged by _poll_overflow at a later call."""
+        if not over.is_cuda:  # (the CPU tests' oracle shim)
+            self._overflowed += int(over)
+        elif self._pending is None and not torch.cuda.is_current_stream_capturing():
+            if self._host_word is None:
+                self._host_word = torch.zeros(1, dtype=torch.int32).pin_memory()
+                self._event = torch.cuda.Event()
+            self._host_word.copy_(over, non_blocking=True)
+            self._event.record()
+            self._pending = (self._host_word, self._event, B, had_i8)
+
     def _cap_i8(self):
         """Before a filtered call: cap this thread's int8 levels for THIS bank (ops.set_max_i8_levels; the caller resets it
         to -1 afterwards).  The bank's int8 error row is read once per bank version (one synchronisation; never while a
@@ -150,6 +163,19 @@ class KeyIndex:
             if self._bf16 is None:
                 self._bf16 = ops.keys_to_bf16(kn)
             return ops.topk_cosine_fused(q, kn, self._bf16, k, idx_base=idx_base)
+        small = getattr(ops, "small_helps", None)
+        if small is not None and not self._filter_off and small(B, kn.shape[0], D, k):
+            # a handful of queries against a large bank: every phase of the filtered call in ONE launch (csrc/topk_small.hip)
+            if self._bf16 is None:
+                self._bf16 = ops.keys_to_bf16(kn)
+            cap, had_i8 = self._cap_i8()
+            try:
+                s, i, over = ops.topk_cosine_small(q, kn, self._bf16, k, idx_base=idx_base)
+            finally:
+                if cap is not None:
+                    cap(-1)
+            self._note_overflow(over, B, had_i8 and D in (128, 256))
+            return s, i
         if fhelps is not None and not self._filter_off and fhelps(B, kn.shape[0], D, k):
             if self._bf16 is None:
                 self._bf16 = ops.keys_to_bf16(kn)
@@ -167,15 +193,7 @@ class KeyIndex:
             finally:
                 if cap is not None:
                     cap(-1)
-            if self._pending is None and over.is_cuda and not torch.cuda.is_current_stream_capturing():
-                if self._host_word is None:
-                    self._host_word = torch.zeros(1, dtype=torch.int32).pin_memory()
-                    self._event = torch.cuda.Event()
-                self._host_word.copy_(over, non_blocking=True)
-                self._event.record()
-                self._pending = (self._host_word, self._event, B, had_i8)
-            elif not over.is_cuda:  # (the CPU tests' oracle shim)
-                self._overflowed += int(over)
+            self._note_overflow(over, B, had_i8)
             return s, i
         helps = getattr(ops, "packed_keys_help", None)
         if helps is not None and helps(B, D, k):

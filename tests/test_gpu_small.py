@@ -1,0 +1,116 @@
+"""ragraph_topk_cosine_small_f32 (csrc/topk_small.hip): the exact top-k of up to 32 queries against a large bank in ONE
+launch -- prepare, bound pass, bounded wait, filter pass on the int8 / bf16 copy, exact rescoring at the source, selection
+by the last workgroup -- against the oracle, bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _bank(rng, N, D):
+    return cref.normalize_rows(rng.standard_normal((N, D), dtype=np.float32))
+
+
+@pytest.mark.parametrize("D,B,N,k", [(256, 1, 65536, 10), (256, 1, 1_000_000, 10), (256, 16, 300_000, 5), (256, 32, 70_001, 32),
+                                     (256, 17, 100_000, 1), (128, 1, 70_000, 10), (128, 9, 131_072, 7), (128, 32, 250_000, 16),
+                                     (64, 1, 70_000, 10), (64, 20, 400_000, 10), (256, 2, 65_793, 3)])
+def test_topk_cosine_small_bit_exact(dev, D, B, N, k):
+    """Every width, 1..32 queries (one or two MFMA query groups), ragged banks, k from 1 to 32, exact duplicates (ties on
+    the score: the canonical order decides), a stored key as query, a zero query; on the int8 copy where the width has
+    one and with the thread's int8 cap at 0 (bf16 pass): the oracle's bits both ways; and again through the same state
+    buffer (every call leaves it zeroed)."""
+    from ragraph_amd import kernels as K
+
+    rng = np.random.default_rng(7 * D + B + N + k)
+    kn = _bank(rng, N, D)
+    kn[N // 2:N // 2 + 40] = kn[:40]
+    q = rng.standard_normal((B, D), dtype=np.float32)
+    q[0] = 2.5 * kn[11]
+    if B > 2:
+        q[B - 1] = 0.0
+    knd, qd = _t(kn, dev), _t(q, dev)
+    kb = K.keys_to_bf16(knd)
+    assert K.small_helps(B, N, D, k)
+    rs, ri = cref.topk_cosine(q, kn, k, idx_base=5)
+    for cap in (-1, 0, -1):
+        old = K.set_max_i8_levels(cap)
+        try:
+            s, i, over = K.topk_cosine_small(qd, knd, kb, k, idx_base=5)
+        finally:
+            K.set_max_i8_levels(old)
+        assert int(over) == 0
+        assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs), f"int8 cap {cap}"
+    state = K._small_state_buf(qd.device)
+    assert int(state.abs().sum()) == 0
+
+
+def test_topk_cosine_small_moves_on_without_the_other_workgroups(dev, monkeypatch):
+    """RAGRAPH_SMALL_WAIT_TICKS=0: no workgroup waits for the others' bound units -- thresholds come from whatever part maxima
+    are published (possibly none: everything passes until the refresh) -- the result is the oracle's all the same."""
+    from ragraph_amd import kernels as K
+
+    monkeypatch.setenv("RAGRAPH_SMALL_WAIT_TICKS", "0")
+    rng = np.random.default_rng(23)
+    N, D, k = 300_000, 256, 10
+    kn = _bank(rng, N, D)
+    knd = _t(kn, dev)
+    kb = K.keys_to_bf16(knd)
+    for B in (1, 5, 32):
+        q = rng.standard_normal((B, D), dtype=np.float32)
+        s, i, over = K.topk_cosine_small(_t(q, dev), knd, kb, k)
+        rs, ri = cref.topk_cosine(q, kn, k)
+        assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs)
+    assert int(K._small_state_buf(knd.device).abs().sum()) == 0
+
+
+def test_topk_cosine_small_near_duplicate_bank_takes_the_exact_scan(dev):
+    """Tens of thousands of keys within the bound of a query's k-th best: the list of exact pairs passes its capacity, the
+    query stops passing keys and the last workgroup answers it by the exact scan (counted in `overflow`); queries away
+    from the cluster are served from their lists in the same launch.  Then the product dispatch on such a bank."""
+    from ragraph_amd import kernels as K
+
+    rng = np.random.default_rng(5)
+    N, D, k = 80_000, 256, 10
+    base = rng.standard_normal((1, D), dtype=np.float32)
+    kn = cref.normalize_rows(np.concatenate([base + 1e-3 * rng.standard_normal((30_000, D), dtype=np.float32),
+                                             rng.standard_normal((N - 30_000, D), dtype=np.float32)]))
+    q = np.concatenate([base + 1e-3 * rng.standard_normal((3, D), dtype=np.float32),
+                        rng.standard_normal((4, D), dtype=np.float32)]).astype(np.float32)
+    knd, qd = _t(kn, dev), _t(q, dev)
+    kb = K.keys_to_bf16(knd)
+    s, i, over = K.topk_cosine_small(qd, knd, kb, k)
+    rs, ri = cref.topk_cosine(q, kn, k)
+    assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs)
+    assert int(over) >= 3   # (the bound pass's prefix IS the cluster here: the other queries' bounds are weak too)
+    index = K.KeyIndex(knd)
+    for _ in range(6):
+        s2, i2 = index.topk(qd, k)
+        torch.cuda.synchronize()
+        assert torch.equal(i2, i) and torch.equal(s2, s)
+    assert index.overflowed_queries >= 3
+
+
+def test_key_index_sends_a_handful_of_queries_to_the_single_launch(dev, monkeypatch):
+    from ragraph_amd import kernels as K
+
+    rng = np.random.default_rng(9)
+    kn = _bank(rng, 200_000, 256)
+    knd = _t(kn, dev)
+    index = K.KeyIndex(knd)
+    calls = []
+    real = K.topk_cosine_small
+    monkeypatch.setattr(K, "topk_cosine_small", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
+    for B in (1, 32, 33):
+        q = rng.standard_normal((B, 256), dtype=np.float32)
+        s, i = index.topk(_t(q, dev), 10, idx_base=7)
+        rs, ri = cref.topk_cosine(q, kn, 10, idx_base=7)
+        assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs)
+    assert calls == [1, 1]                        # 33 queries: the multi-launch filtered call
+    assert not K.small_helps(1, 60_000, 256, 10) and not K.small_helps(1, 200_000, 96, 10)
