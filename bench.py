@@ -558,6 +558,9 @@ def main():
     elapsed, out = timed_steps(step, args.steps, world, dev, grab_filter_ms)
     topk_timer.enabled = filt_timer.enabled = False
     L.ragraph_profile_filter_kernel(0)
+    # candidates per query of the last timed call's levels (sampled by the call itself: every 64th query; the 16 ints it
+    # leaves at the end of its workspace, include/ragraph_hip.h)
+    cand_levels = K.filter_stats_levels(K.last_filter_stats.cpu().tolist()) if K.last_filter_stats is not None else []
     assert torch.isfinite(out).all()
     verified = None
     if args.emulate_rank_of <= 1 and not args.exact_fp32 and not args.no_extras:
@@ -605,6 +608,8 @@ def main():
             levels.append({"launch": "bound pass (prefix)" if slot == 3 else f"level {slot + 1}", "dtype": "int8" if e["i8"] else "bf16",
                            "keys": e["keys"], "ms": round(ms, 3), "achieved": round(ops / (ms * 1e-3) / 1e12, 1), "peak": peak,
                            "frac": round(ops / (ms * 1e-3) / 1e12 / peak, 4)})
+            if slot < 3 and slot < len(cand_levels) and cand_levels[slot][2] is not None:
+                levels[-1]["candidates_per_query"] = round(cand_levels[slot][2], 1)
         dom = max((lv for lv in levels if not lv["launch"].startswith("bound")), key=lambda lv: lv["ms"], default=None)
         whole = flops / (kernel_ms * 1e-3) / 1e12
         if dom is None:

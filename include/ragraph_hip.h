@@ -125,6 +125,14 @@ int64_t ragraph_keys_bf16_rows(int64_t N);
 int ragraph_keys_to_bf16(const float* Kn, int64_t N, int D, uint16_t* Kb, void* stream);
 int ragraph_topk_cosine_filtered_cap(int k);
 size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_t N, int D, int k);
+/* Candidate statistics of the most recent filtered call on a workspace: 16 ints at byte offset
+ * ragraph_topk_cosine_filtered_stats_offset(ws_bytes) of the workspace AS PASSED to the call (its last bytes), written by the
+ * call's own launches: [0] 0x52414753, [1] levels, [2+l] sum of the candidate counts of every 64th query at level l (l < 3),
+ * [5+l] how many queries that sum covers, [8+l] 1 if level l ran on the int8 copy, [11+l] keys of level l, [14] queries of
+ * the call.  sum / queries = candidates per query: what a level's rescoring costs.  The owner of a bank reads them back
+ * asynchronously (ragraph_amd/kernels_index.py: a bank whose int8 levels pass hundreds of candidates per query without
+ * overflowing is slower on int8 than on bf16 -- the overflow count alone would never show it). */
+size_t ragraph_topk_cosine_filtered_stats_offset(size_t ws_bytes);
 /* The schedule the call above will follow for this shape (host-side arithmetic only, no device work):
  * plan[1] = how the first lower bound of a query's k-th best score is made: 2 = bound pass (banks of >= 8192 keys: a
  * bf16 pass over keys [0, plan[6]) records the best approximate score of each of k parts; the smallest, minus eps, is
@@ -201,7 +209,7 @@ int ragraph_topk_cosine_filtered_sharded_f32(const float* Q, int64_t B, const fl
  *   (ragraph_topk_cosine_small_ok).  overflow: device int, set to the number of queries answered by the exact scan.
  *   state: ragraph_topk_cosine_small_state_bytes() bytes, ZERO before the first call; every call leaves them zero (one
  *   buffer per stream: calls on a stream are ordered).  ws: ragraph_topk_cosine_small_workspace_bytes (the pair lists).
- *   RAGRAPH_SMALL_WAIT_TICKS: the wait's limit in 10-ns ticks (default 3000; 0: never wait -- test hook). */
+ *   RAGRAPH_SMALL_WAIT_TICKS: the wait's limit in 10-ns ticks (default 200000 = 2 ms; 0: never wait -- test hook). */
 int ragraph_topk_cosine_small_ok(int64_t B, int64_t N, int D, int k);
 size_t ragraph_topk_cosine_small_state_bytes(void);
 /* keys of the bf16 prefix the call's bound pass reads; *i8 (may be NULL) = 1 when its filter pass streams the int8 copy */

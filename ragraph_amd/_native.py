@@ -41,6 +41,7 @@ SIGNATURES = {
     "ragraph_profile_last_filter_levels": (_i32, [_vp, _vp, _vp]),
     "ragraph_topk_cosine_filtered_cap": (_i32, [_i32]),
     "ragraph_topk_cosine_filtered_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
+    "ragraph_topk_cosine_filtered_stats_offset": (_sz, [_sz]),
     "ragraph_topk_cosine_filtered_sharded_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32]),
     "ragraph_topk_cosine_filtered_plan": (_i32, [_i64, _i64, _i32, _i32, _vp]),
     "ragraph_topk_cosine_filtered_i8_levels": (_i32, [_i64, _i64, _i32, _i32]),

@@ -185,6 +185,24 @@ __global__ void __launch_bounds__(256) keys_to_i8_kernel(const float* __restrict
 // Everything a call needs before its first filter launch, in ONE launch (one wave per query): the normalised query row
 // (the norm tree, sqrt and divisions of normalize_rows_kernel, so the same bits), |dq| of its bf16 rounding, an empty
 // candidate list, a clear overflow flag, and -- before a bound pass -- the group maxima at -inf.
+// Candidate statistics of a call (FILTER_STATS_INTS ints at the very end of the caller's workspace; zeroed and labelled by
+// the prepare launch): every 64th query adds its candidate count of the level to cstat[0] and 1 to cstat[3] -- a sampled
+// mean the owner of the bank reads back asynchronously (ragraph_amd/kernels_index.py: a bank whose int8 levels pass hundreds
+// of candidates per query WITHOUT overflowing is slower on int8 than on bf16, and nothing else would notice).
+// Layout: [0] magic, [1] levels, [2 + l] sampled candidates of level l, [5 + l] sampled queries, [8 + l] level l ran on
+// int8, [11 + l] keys of level l, [14] queries of the call.
+constexpr int FILTER_STATS_INTS = 16;
+constexpr int FILTER_STATS_MAGIC = 0x52414753;
+__device__ __forceinline__ void note_candidates(int* cstat, int64_t b, int n) {
+  if (cstat && (b & 63) == 0) {
+    atomicAdd(cstat, n);
+    atomicAdd(cstat + 3, 1);
+  }
+}
+struct FilterStatsInit {
+  int nlev, i8[3], keys[3];
+};
+
 constexpr int FILTER_FIX_MAX_Q = 1024;  // overflowed queries whose scan topk_overflow_fixup_kernel may cut into slices
 constexpr int FILTER_FIX_SLICES = 16;   // at most (16 x 32 partial winners: eight per lane of the merging wave)
 
@@ -195,10 +213,20 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
                                                           int* __restrict__ gmax, int ngroups,
                                                           uint16_t* __restrict__ Qb, int cstride,
                                                           float* __restrict__ eq8, float* __restrict__ qscale,
-                                                          signed char* __restrict__ Qb8, int* __restrict__ fix_done) {
+                                                          signed char* __restrict__ Qb8, int* __restrict__ fix_done,
+                                                          int* __restrict__ stats, FilterStatsInit si) {
   const int lane = threadIdx.x & 63;
   const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q == 0 && lane == 0) *overflow = 0;
+  if (q == 0 && lane < FILTER_STATS_INTS && stats) {
+    int v = 0;
+    if (lane == 0) v = FILTER_STATS_MAGIC;
+    else if (lane == 1) v = si.nlev;
+    else if (lane >= 8 && lane < 11) v = si.i8[lane - 8];
+    else if (lane >= 11 && lane < 14) v = si.keys[lane - 11];
+    else if (lane == 14) v = B > INT_MAX ? INT_MAX : (int)B;
+    stats[lane] = v;
+  }
   if (q < FILTER_FIX_MAX_Q && lane == 0) fix_done[q] = 0;  // tickets of topk_overflow_fixup_kernel
   if (q >= (Qb ? (B + 31) / 32 * 32 : B)) return;
   constexpr int NCH = D / 4;  // float4 chunks per row: 16 / 32 / 64 -- at most one per lane
@@ -872,7 +900,7 @@ __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restri
                                                            const float* prev_s, const int64_t* prev_i, int final_level,
                                                            float* out_s, int64_t* out_i, int* __restrict__ overflow,
                                                            int* __restrict__ overflow_list,
-                                                           unsigned char* __restrict__ flag) {
+                                                           unsigned char* __restrict__ flag, int* __restrict__ cstat) {
   __shared__ float4 qs[4][D / 4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t b = (int64_t)blockIdx.x * 4 + w;
@@ -883,6 +911,7 @@ __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restri
   const unsigned char fl = flag[b];
   bool over = fl != 0;
   if (lane == 0 && n >= 0) count[b * cs] = 0;  // the next level starts from an empty list (ordered behind the read through n)
+  if (lane == 0) note_candidates(cstat, b, n);
   if (zero_query_level(fl, final_level, k, idx_base, lane, out_s + b * k, out_i + b * k)) return;
   if (n > cap) {  // slots reserved beyond the capacity: candidates were dropped
     over = true;
@@ -924,7 +953,8 @@ __global__ void __launch_bounds__(128, FEWTILE ? 4 : 1) topk_rescore_coop_kernel
                                                                 const int64_t* prev_i, int final_level, float* out_s,
                                                                 int64_t* out_i, int* __restrict__ overflow,
                                                                 int* __restrict__ overflow_list,
-                                                                unsigned char* __restrict__ flag, int64_t scan_n) {
+                                                                unsigned char* __restrict__ flag, int64_t scan_n,
+                                                                int* __restrict__ cstat) {
   __shared__ float4 qs[2][D / 4];
   __shared__ __attribute__((aligned(16))) float tile[2][(FEWTILE ? 16 : 64) * RESCORE_LD];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -939,6 +969,7 @@ __global__ void __launch_bounds__(128, FEWTILE ? 4 : 1) topk_rescore_coop_kernel
   if (lane < D / 4) qs[w][lane] = qv4;
   __builtin_amdgcn_wave_barrier();
   if (lane == 0 && n >= 0) count[b * cs] = 0;  // the next level starts from an empty list (ordered behind the read through n)
+  if (lane == 0) note_candidates(cstat, b, n);
   if (zero_query_level(fl, final_level, k, idx_base, lane, out_s + b * k, out_i + b * k)) return;
   if (n > cap) {
     over = true;
@@ -1147,7 +1178,8 @@ __global__ void __launch_bounds__(128) topk_rescore_scored_kernel(const float* _
                                                                   const float* prev_s, const int64_t* prev_i, int final_level,
                                                                   float* out_s, int64_t* out_i, int* __restrict__ overflow,
                                                                   int* __restrict__ overflow_list,
-                                                                  unsigned char* __restrict__ flag, int64_t scan_n, FilterThr thr) {
+                                                                  unsigned char* __restrict__ flag, int64_t scan_n, FilterThr thr,
+                                                                  int* __restrict__ cstat) {
   constexpr int ROWS = SMALL ? 32 : 64;
   __shared__ float4 qs[2][D / 4];
   __shared__ __attribute__((aligned(16))) float tile[2][ROWS * RESCORE_LD];
@@ -1165,6 +1197,7 @@ __global__ void __launch_bounds__(128) topk_rescore_scored_kernel(const float* _
   if (lane < D / 4) qs[w][lane] = qv4;
   __builtin_amdgcn_wave_barrier();
   if (lane == 0 && n >= 0) count[b * cs] = 0;  // the next level starts from an empty list
+  if (lane == 0) note_candidates(cstat, b, n);
   if (zero_query_level(fl, final_level, k, idx_base, lane, out_s + b * k, out_i + b * k)) return;
   if (n > cap) {
     over = true;
@@ -1309,7 +1342,8 @@ __global__ void __launch_bounds__(256) topk_rescore_wide_kernel(const float* __r
                                                                 int64_t* out_i, int* __restrict__ overflow,
                                                                 int* __restrict__ overflow_list,
                                                                 unsigned char* __restrict__ flag,
-                                                                float* __restrict__ part_s, int* __restrict__ part_i) {
+                                                                float* __restrict__ part_s, int* __restrict__ part_i,
+                                                                int* __restrict__ cstat) {
   __shared__ float4 qs[D / 4];
   __shared__ float ps[4][32];
   __shared__ int64_t pi[4][32];
@@ -1326,6 +1360,10 @@ __global__ void __launch_bounds__(256) topk_rescore_wide_kernel(const float* __r
   // the merge launch looks after overflow and empties the counters
   const int subcap = SLICED ? cap / (int)gridDim.y : cap;
   int n = count[b * cs + (SLICED ? (int)blockIdx.y : 0)];
+  if (threadIdx.x == 0 && cstat && (b & 63) == 0) {  // (sliced: every sub-list's workgroup adds its part, the first one counts the query)
+    atomicAdd(cstat, n);
+    if (!SLICED || blockIdx.y == 0) atomicAdd(cstat + 3, 1);
+  }
   bool over = false;
   if (n > subcap) {
     over = true;
@@ -2015,6 +2053,11 @@ static int filter_cap(int64_t B, int k) { return ragraph_topk_cosine_filtered_ca
 
 static size_t filter_ws_carve(char* w, int64_t B, int D, int k, int cap, struct FilterWs* out);
 
+constexpr size_t FILTER_STATS_BYTES = 256;  // (the statistics block plus the slack that aligns it)
+extern "C" size_t ragraph_topk_cosine_filtered_stats_offset(size_t ws_bytes) {
+  return ws_bytes < FILTER_STATS_INTS * sizeof(int) ? 0 : (ws_bytes - FILTER_STATS_INTS * sizeof(int)) & ~(size_t)15;
+}
+
 static size_t filter_workspace_bytes(int64_t B, int64_t N, int D, int k, int n_shards) {
   if (B < 1 || N < 1 || k < 1 || n_shards < 1 || !filter_dim_ok(D)) return 0;
   const int cap = filter_cap(B, k);
@@ -2028,7 +2071,7 @@ static size_t filter_workspace_bytes(int64_t B, int64_t N, int D, int k, int n_s
     const size_t exact0 = filter_level0_ws(sc, B, D, k);
     if (exact0 > level0) level0 = exact0;
   }
-  return level0 + filter_ws_carve(nullptr, B, D, k, cap, nullptr);
+  return level0 + filter_ws_carve(nullptr, B, D, k, cap, nullptr) + FILTER_STATS_BYTES;
 }
 
 extern "C" size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_t N, int D, int k) {
@@ -2306,7 +2349,7 @@ static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64
 template <int D>
 static int run_rescore(const FilterWs& f, const float* Kn, int64_t N, int64_t B, int cap, int k, int64_t idx_base, int merge,
                        int final_level, float* out_scores, int64_t* out_idx, int* overflow, int* fallback_done, bool few,
-                       hipStream_t st, const FilterThr* scored_thr = nullptr) {
+                       hipStream_t st, const FilterThr* scored_thr = nullptr, int* cstat = nullptr) {
   const float* ps = merge ? out_scores : nullptr;
   const int64_t* pi = merge ? out_idx : nullptr;
   static const int64_t wide_max_b = [] {  // RAGRAPH_RESCORE_WIDE_BELOW: A/B of the crossover
@@ -2332,15 +2375,15 @@ static int run_rescore(const FilterWs& f, const float* Kn, int64_t N, int64_t B,
     if (B >= 8192 && small_env)
       hipLaunchKernelGGL((topk_rescore_scored_kernel<D, true>), dim3((unsigned)cdiv(B, 2)), dim3(128), 0, st, f.Qn, Kn, f.count,
                          reinterpret_cast<const int2*>(f.cand), B, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx,
-                         overflow, f.overflow_list, f.flag, scan_n, *scored_thr);
+                         overflow, f.overflow_list, f.flag, scan_n, *scored_thr, cstat);
     else
       hipLaunchKernelGGL((topk_rescore_scored_kernel<D, false>), dim3((unsigned)cdiv(B, 2)), dim3(128), 0, st, f.Qn, Kn, f.count,
                          reinterpret_cast<const int2*>(f.cand), B, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx,
-                         overflow, f.overflow_list, f.flag, scan_n, *scored_thr);
+                         overflow, f.overflow_list, f.flag, scan_n, *scored_thr, cstat);
   } else if (B < wide_max_b && S > 1) {
     hipLaunchKernelGGL((topk_rescore_wide_kernel<D, true, true>), dim3((unsigned)B, (unsigned)S), dim3(256), 0, st, f.Qn, Kn, f.count,
                        f.cand, B, N, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list,
-                       f.flag, f.part_s, f.part_i);
+                       f.flag, f.part_s, f.part_i, cstat);
     *fallback_done = 1;
 #ifdef RG_WIDE_TIMING
     {
@@ -2356,25 +2399,25 @@ static int run_rescore(const FilterWs& f, const float* Kn, int64_t N, int64_t B,
     *fallback_done = B < 65;  // (up to 64 queries the wide kernels answer an overflowed query themselves on the final level)
     hipLaunchKernelGGL((topk_rescore_wide_kernel<D, false, true>), dim3((unsigned)B), dim3(256), 0, st, f.Qn, Kn, f.count, f.cand,
                        B, N, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag,
-                       (float*)nullptr, (int*)nullptr);
+                       (float*)nullptr, (int*)nullptr, cstat);
   } else if (B < wide_max_b) {  // too few queries to fill the chip with one wave each
     *fallback_done = B < 65;
     hipLaunchKernelGGL((topk_rescore_wide_kernel<D, false, false>), dim3((unsigned)B), dim3(256), 0, st, f.Qn, Kn, f.count, f.cand,
                        B, N, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag,
-                       (float*)nullptr, (int*)nullptr);
+                       (float*)nullptr, (int*)nullptr, cstat);
   } else if (rescore_coop() && few) {
     *fallback_done = scan_n > 0;
     hipLaunchKernelGGL((topk_rescore_coop_kernel<D, 32, true>), dim3((unsigned)cdiv(B, 2)), dim3(128), 0, st, f.Qn, Kn, f.count,
                        f.cand, B, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag,
-                       scan_n);
+                       scan_n, cstat);
   } else if (rescore_coop()) {
     *fallback_done = scan_n > 0;
     hipLaunchKernelGGL((topk_rescore_coop_kernel<D, 32>), dim3((unsigned)cdiv(B, 2)), dim3(128), 0, st, f.Qn, Kn, f.count,
                        f.cand, B, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag,
-                       scan_n);
+                       scan_n, cstat);
   } else
     hipLaunchKernelGGL((topk_rescore_kernel<D, 32>), dim3((unsigned)cdiv(B, 4)), dim3(256), 0, st, f.Qn, Kn, f.count, f.cand,
-                       B, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag);
+                       B, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag, cstat);
   RG_CHECK_LAUNCH("topk_cosine_filtered(rescore)");
   return RAGRAPH_OK;
 }
@@ -2405,9 +2448,11 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   char* w = static_cast<char*>(ws);
   const size_t sample_ws = filter_level0_ws(sc, B, D, k);
   FilterWs f;
-  const size_t used = sample_ws + filter_ws_carve(w + sample_ws, B, D, k, cap, &f);
+  const size_t used = sample_ws + filter_ws_carve(w + sample_ws, B, D, k, cap, &f) + FILTER_STATS_BYTES;
   RG_REQUIRE(used <= ws_bytes, RAGRAPH_EWORKSPACE, "topk_cosine_filtered: the schedule of this call needs %zu bytes of workspace, "
              "%zu given", used, ws_bytes);
+  // the call's candidate statistics: the last FILTER_STATS_INTS ints of the workspace AS PASSED (ragraph_topk_cosine_filtered_stats_offset)
+  int* stats = reinterpret_cast<int*>(w + ragraph_topk_cosine_filtered_stats_offset(ws_bytes));
   const unsigned* max_kerr2 = reinterpret_cast<const unsigned*>(Kb + filter_round_up(N) * D);
   // the int8 copy lies behind the bf16 copy and its tail row (ragraph_keys_to_bf16)
   const signed char* Kb8 = reinterpret_cast<const signed char*>(Kb + (filter_round_up(N) + 1) * D);
@@ -2415,11 +2460,19 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   sc.i8_levels = filter_i8_levels(sc, B, D, plan_N);
   const bool bound = sc.bound_keys > 0;
 
+  FilterStatsInit stats_init{};
+  stats_init.nlev = sc.nlev;
+  for (int l = 0; l < sc.nlev && l < 3; ++l) {
+    stats_init.i8[l] = l >= sc.nlev - sc.i8_levels;
+    const int64_t lk = sc.ends[l] - (l ? sc.ends[l - 1] : 0);
+    stats_init.keys[l] = lk > INT_MAX ? INT_MAX : (int)lk;
+  }
   // one launch: normalised queries, their bf16 rounding errors, empty lists, clear flags (+ group maxima at -inf)
   hipLaunchKernelGGL(filter_prep_kernel<D>, dim3((unsigned)cdiv(B <= FILTER_QB_MAX_B ? (B + 31) / 32 * 32 : B, 4)), dim3(256), 0, st, Q, B,
                      f.Qn, f.eq, f.count, f.flag, overflow, bound ? f.gmax : nullptr, bound ? filter_bound_parts(k, sc.bound_keys, D, B, exchange ? n_shards : 1) : k,
                      B <= FILTER_QB_MAX_B ? f.Qb : nullptr,
-                     filter_count_stride(B), sc.i8_levels > 0 ? f.eq8 : nullptr, f.qscale, B <= FILTER_QB_MAX_B ? f.Qb8 : nullptr, f.fix_done);
+                     filter_count_stride(B), sc.i8_levels > 0 ? f.eq8 : nullptr, f.qscale, B <= FILTER_QB_MAX_B ? f.Qb8 : nullptr, f.fix_done,
+                     stats, stats_init);
   RG_CHECK_LAUNCH("topk_cosine_filtered(prepare)");
 
   FilterThr thr{};
@@ -2511,7 +2564,7 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
     }
     if (g_prof_on) g_prof_have = l + 1;
     rc = run_rescore<D>(f, Kn, N, B, cap, k, idx_base, l > 0, l == sc.nlev - 1, out_scores, out_idx, overflow,
-                        &fallback_done, exchange != nullptr && l > 0, st, scored ? &thr : nullptr);
+                        &fallback_done, exchange != nullptr && l > 0, st, scored ? &thr : nullptr, l < 3 ? stats + 2 + l : nullptr);
     if (rc != RAGRAPH_OK) return rc;
     key0 = sc.ends[l];
     if (exchange && l + 1 < sc.nlev) {  // this shard's k-th exact score so far sharpens theta; then the other shards'

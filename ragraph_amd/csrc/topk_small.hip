@@ -107,6 +107,54 @@ __device__ __forceinline__ unsigned long long small_key64(float s, int key) {
   return ((unsigned long long)select_ord(s) << 32) | (unsigned)~(unsigned)key;
 }
 
+// Canonical top-k of a list held as NPL canonical keys per lane (0 = empty): the k-th largest of the 64 lanes' best keys
+// bounds the k-th best of all from below, the keys at or above it (a few dozen) are compacted into `surv` and ranked by
+// counting (wave_select<2>).  false: more than 128 keys survive (ties) -- the caller takes the chunked path.
+template <int NPL>
+__device__ __forceinline__ bool small_select_held(const unsigned long long (&held)[NPL], int k, int lane, int64_t idx_base,
+                                                  unsigned long long* surv, float* os, int64_t* oi) {
+  unsigned long long best = 0ull;
+#pragma unroll
+  for (int u = 0; u < NPL; ++u) best = held[u] > best ? held[u] : best;
+  int rank = 0;
+  for (int o = 0; o < 64; ++o) {
+    const unsigned long long x = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(best >> 32), o) << 32) |
+                                 (unsigned)__builtin_amdgcn_readlane((int)(unsigned)best, o);
+    rank += (x > best || (x == best && o < lane)) ? 1 : 0;
+  }
+  const unsigned long long kb = __ballot(rank == k - 1);
+  const int src = __ffsll((long long)kb) - 1;
+  const unsigned long long bound = ((unsigned long long)(unsigned)__shfl((int)(best >> 32), src) << 32) | (unsigned)__shfl((int)(unsigned)best, src);
+  int ns = 0;  // wave-uniform
+#pragma unroll
+  for (int u = 0; u < NPL; ++u) {
+    const bool keep = held[u] != 0ull && held[u] >= bound;
+    const unsigned long long bal = __ballot(keep);
+    const int pos = ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+    if (keep && pos < 128) surv[pos] = held[u];
+    ns += __popcll(bal);
+  }
+  if (ns > 128) return false;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float s2[2];
+  int id2[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    s2[u] = RG_NEG_INF;
+    id2[u] = INT_MAX;
+    if (lane + 64 * u < ns) {
+      const unsigned long long key = surv[lane + 64 * u];
+      s2[u] = select_unord((unsigned)(key >> 32));
+      id2[u] = (int)~(unsigned)key;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  wave_select<2>(s2, id2, k, lane, idx_base, os, oi);
+  return true;
+}
+
 #ifdef RG_SMALL_TIMING  // diagnostic build: wall-clock stamps (10 ns ticks) of workgroup 0 and of the last workgroup to finish
 __device__ unsigned long long g_small_t[2][16];
 #define RG_SSTAMP(i_) \
@@ -163,6 +211,8 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
     _Pragma("unroll") for (int b_ = 0; b_ < 16; ++b_)                                                              \
       buf_[b_] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ub_ + b_ * 1024));                      \
   }
+  // (the copies' error rows: requested now, used by the thresholds)
+  const unsigned tail_b = *p.max_kerr2, tail_8e = I8 ? p.tail8[0] : 0u, tail_8s = I8 ? p.tail8[1] : 0u;
   // this wave's first unit of the bound pass: its loads need no query -- in flight during the prepare phase
   const int64_t u_first = (int64_t)blockIdx.x * 8 + wave;
   if (u_first < p.bound_units) RG_SLOAD(A0, p.Kb, u_first);
@@ -170,10 +220,18 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   // ---- 0. prepare: one wave per query row (filter_prep_kernel's arithmetic) ----------------------------------------
   if (tid < 32) qcnt[tid] = 0;
   if (tid < 4) misc[tid] = 0;
-  for (int q = wave; q < 16 * ngq; q += 8) {
-    constexpr int NCH = D / 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < NCH && q < B) v = reinterpret_cast<const float4*>(p.Q + (int64_t)q * D)[lane];
+  constexpr int NCH = D / 4;
+  float4 vrow[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {  // (a wave's rows: wave, wave + 8, ... -- all requested before the first is used)
+    vrow[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < NCH && wave + 8 * c < B) vrow[c] = reinterpret_cast<const float4*>(p.Q + (int64_t)(wave + 8 * c) * D)[lane];
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int q = wave + 8 * c;
+    if (q >= 16 * ngq) break;
+    float4 v = vrow[c];
     float pp = 0.f;
     pp = fmaf(v.x, v.x, pp);
     pp = fmaf(v.y, v.y, pp);
@@ -334,21 +392,24 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   // stores, which go past the XCD's L2): a __threadfence() would write the whole L2 back (buffer_wbl2: 10 - 30 us with 256
   // workgroups at it -- measured: it was most of a 175-us first version); ordering comes from s_waitcnt vmcnt(0) before
   // the barrier that precedes a workgroup's announcement.
+  // (only the workgroups that HAVE bound units announce themselves -- the first G_b = ceil(units / 8) of the grid, which the
+  // dispatcher starts first: a workgroup that starts late and has none delays nobody)
+  const int G_b = (int)(((p.bound_units + 7) / 8) < G ? (p.bound_units + 7) / 8 : G);
   if (tid == 0) {
-    __hip_atomic_fetch_add(p.state, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)blockIdx.x < G_b) __hip_atomic_fetch_add(p.state, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long t0 = wall_clock64();
     int in = __hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (in < G && (unsigned)(wall_clock64() - t0) < p.wait_ticks) {
+    while (in < G_b && (unsigned)(wall_clock64() - t0) < p.wait_ticks) {
       __builtin_amdgcn_s_sleep(1);
       in = __hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    misc[1] = in >= G;
+    misc[1] = in >= G_b;
   }
   __syncthreads();
   RG_SSTAMP(4);
-  const float ek_b = sqrtf(__uint_as_float(*p.max_kerr2));
-  const float ek_8 = I8 ? sqrtf(__uint_as_float(p.tail8[0])) : 0.f;
-  const float sk_8 = I8 ? __uint_as_float(p.tail8[1]) : 0.f;
+  const float ek_b = sqrtf(__uint_as_float(tail_b));
+  const float ek_8 = I8 ? sqrtf(__uint_as_float(tail_8e)) : 0.f;
+  const float sk_8 = I8 ? __uint_as_float(tail_8s) : 0.f;
   // threshold of query q from the part maxima published so far (one wave; every lane returns with thr_lds[q] written)
   auto load_part = [&](int q) -> unsigned {  // this lane's part maximum of query q as published so far (0: nothing yet)
     return (q < B && lane < p.parts) ? __hip_atomic_load(gmax_g + q * SMALL_PARTS_MAX + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
@@ -359,8 +420,8 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
     float v = RG_NEG_INF;
     if (u != 0u) v = __fsub_rn(small_u2f(u), eps_b);
     int rank = 0;
-    for (int o = 0; o < p.parts; ++o) {
-      const float x = __shfl(v, o);
+    for (int o = 0; o < p.parts; ++o) {  // (o is wave-uniform: v_readlane, not a ds_bpermute round trip per part)
+      const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), o));
       rank += (x > v || (x == v && o < lane)) ? 1 : 0;
     }
     const unsigned long long kth = __ballot(lane < p.parts && rank == k - 1);
@@ -534,7 +595,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
       if (i + 2 < n_mine) RG_SLOAD(A0, fbase, gw + (i + 2) * W);
       process(A1, gw + (i + 1) * W);
       if (refresh && (i & 30) == 30) {   // (wave 0 of a workgroup that moved on early) the others' maxima may have arrived
-        const bool all_in = __hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= G;
+        const bool all_in = __hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= G_b;
         for (int q = 0; q < B; ++q) make_threshold(q, load_part(q));
         refresh = !all_in;
       }
@@ -639,7 +700,35 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   int64_t* pi = reinterpret_cast<int64_t*>(smem + L::scan_pi);  // [4][32]
   // per-wave staging for the selection (the stream's buffers are free now): 512 canonical keys + winners
   unsigned long long* surv = reinterpret_cast<unsigned long long*>(pair_all + wave * SMALL_PAIRBUF);
-  for (int q = wave; q < B; q += 8) {
+  // a wave's queries: wave, wave + 8, ...; their counts and first 256 pairs are requested before the first is used
+  int nq[4];
+  float pf_s[4][4];
+  int pf_k[4][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int q = wave + 8 * c;
+    nq[c] = q < B ? __hip_atomic_load(cnt_g + 32 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      pf_s[c][u] = RG_NEG_INF;
+      pf_k[c][u] = INT_MAX;
+      if (q < B) {  // (slots beyond the count hold stale pairs: masked below)
+        pf_s[c][u] = __hip_atomic_load(p.list_s + (int64_t)q * SMALL_LIST_CAP + lane + 64 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pf_k[c][u] = __hip_atomic_load(p.list_k + (int64_t)q * SMALL_LIST_CAP + lane + 64 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+#ifdef RG_SMALL_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  RG_SSTAMP(13);
+#endif
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int q = wave + 8 * c;
+    if (q >= B) break;
+#ifdef RG_SMALL_TIMING
+    if (c == 1) { RG_SSTAMP(14); }
+#endif
     float* os = p.out_s + (int64_t)q * k;
     int64_t* oi = p.out_i + (int64_t)q * k;
     if (sc_flag[q]) {  // zero query: every score +0, canonical order = row order
@@ -649,11 +738,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
       }
       continue;
     }
-    const int n = __hip_atomic_load(cnt_g + 32 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef RG_SMALL_TIMING
-    if (q == 0 && lane == 0) g_small_t[0][13] = (unsigned long long)n;
-    if (q == 0 && lane == 0) g_small_t[0][14] = (unsigned long long)misc[0];
-#endif
+    const int n = nq[c];
     if (n > SMALL_LIST_CAP) {
       if (lane == 0) atomicOr(qcnt + q, 1 << 30);  // (marks the query for the scan below; qcnt is free now)
       continue;
@@ -671,121 +756,57 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
     if (n <= 128) {
       float s2[2];
       int id2[2];
-      load_pair(lane, s2[0], id2[0]);
-      load_pair(lane + 64, s2[1], id2[1]);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bool have = lane + 64 * u < n;
+        s2[u] = have ? pf_s[c][u] : RG_NEG_INF;
+        id2[u] = have ? pf_k[c][u] : INT_MAX;
+      }
       wave_select<2>(s2, id2, k, lane, p.idx_base, os, oi);
       continue;
     }
-    // the k-th largest of the 64 lanes' best pairs bounds the k-th best of all from below: survivors are few
-    unsigned long long best = 0ull;
-    const bool one_pass = n <= 1024;  // (wave-uniform) the list stays in registers: sixteen pairs per lane
-    unsigned long long held[16];
-    if (one_pass) {
+    if (n <= 256) {
+      // (k rounds of a wave-wide maximum -- wave_select<4> -- measured slower than the bound + ranking by counting at
+      // k = 10: 18 vs 11.6 us for the two queries of a wave)
+      unsigned long long held[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) held[u] = lane + 64 * u < n ? small_key64(pf_s[c][u], pf_k[c][u]) : 0ull;
+      if (small_select_held<4>(held, k, lane, p.idx_base, surv, os, oi)) continue;
+    } else if (n <= 1024) {  // the list in registers: sixteen pairs per lane, all loads in flight at once
+      unsigned long long held[16];
       float s16[16];
       int id16[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) load_pair(lane + 64 * u, s16[u], id16[u]);
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        held[u] = id16[u] == INT_MAX ? 0ull : small_key64(s16[u], id16[u]);
-        best = held[u] > best ? held[u] : best;
-      }
+      for (int u = 0; u < 16; ++u) held[u] = id16[u] == INT_MAX ? 0ull : small_key64(s16[u], id16[u]);
+      if (small_select_held<16>(held, k, lane, p.idx_base, surv, os, oi)) continue;
     }
-    for (int i0 = 0; i0 < n && !one_pass; i0 += 64 * 8) {  // (eight independent loads per lane in flight)
-      float s8[8];
-      int id8[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) load_pair(i0 + lane + 64 * u, s8[u], id8[u]);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const unsigned long long key = id8[u] == INT_MAX ? 0ull : small_key64(s8[u], id8[u]);
-        best = key > best ? key : best;
-      }
-    }
-    int rank = 0;
-    for (int o = 0; o < 64; ++o) {
-      const unsigned long long x = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(best >> 32), o) << 32) |
-                                   (unsigned)__builtin_amdgcn_readlane((int)(unsigned)best, o);
-      rank += (x > best || (x == best && o < lane)) ? 1 : 0;
-    }
-    const unsigned long long kb = __ballot(rank == k - 1);
-    const int src = __ffsll((long long)kb) - 1;
-    const unsigned long long bound = ((unsigned long long)(unsigned)__shfl((int)(best >> 32), src) << 32) | (unsigned)__shfl((int)(unsigned)best, src);
-    int ns = 0;  // wave-uniform
-    if (one_pass) {
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const bool keep = held[u] != 0ull && held[u] >= bound;
-        const unsigned long long bal = __ballot(keep);
-        const int pos = ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-        if (keep && pos < 128) surv[pos] = held[u];
-        ns += __popcll(bal);
-      }
-    }
-    for (int i0 = 0; i0 < n && !one_pass; i0 += 64 * 8) {
-      float s8[8];
-      int id8[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) load_pair(i0 + lane + 64 * u, s8[u], id8[u]);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const unsigned long long key = id8[u] == INT_MAX ? 0ull : small_key64(s8[u], id8[u]);
-        const bool keep = key != 0ull && key >= bound;
-        const unsigned long long bal = __ballot(keep);
-        const int pos = ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-        if (keep && pos < 128) surv[pos] = key;
-        ns += __popcll(bal);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (ns <= 128) {
-      float s2[2];
-      int id2[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        s2[u] = RG_NEG_INF;
-        id2[u] = INT_MAX;
-        if (lane + 64 * u < ns) {
-          const unsigned long long key = surv[lane + 64 * u];
-          s2[u] = select_unord((unsigned)(key >> 32));
-          id2[u] = (int)~(unsigned)key;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      wave_select<2>(s2, id2, k, lane, p.idx_base, os, oi);
-    } else {
-      // (thousands of pairs tie with the bound: a bank of duplicates the collapsing did not see) chunks of 64 against the
-      // running winners, staged through LDS
+    // longer lists (and ties by the hundred: a bank of duplicates the collapsing did not see): chunks of 1024 pairs -- sixteen
+    // per lane, all loads in flight -- against the running winners, which ride in a seventeenth slot between chunks (LDS)
+    {
       float* ws_ = reinterpret_cast<float*>(surv);                 // [32] running scores
       int64_t* wi_ = reinterpret_cast<int64_t*>(surv + 32);        // [32] running local ids
-      if (lane < 32) {
-        ws_[lane] = RG_NEG_INF;
-        wi_[lane] = INT64_MAX;
-      }
-      for (int i0 = 0; i0 < n; i0 += 64) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        float s2[2];
-        int id2[2];
-        load_pair(i0 + lane, s2[0], id2[0]);
-        s2[1] = RG_NEG_INF;
-        id2[1] = INT_MAX;
-        if (lane < k) {
-          s2[1] = ws_[lane];
-          id2[1] = wi_[lane] >= INT_MAX ? INT_MAX : (int)wi_[lane];
+      for (int i0 = 0; i0 < n; i0 += 1024) {
+        float s17[17];
+        int id17[17];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) load_pair(i0 + lane + 64 * u, s17[u], id17[u]);
+        s17[16] = RG_NEG_INF;
+        id17[16] = INT_MAX;
+        if (i0 > 0 && lane < k) {
+          s17[16] = ws_[lane];
+          id17[16] = wi_[lane] >= INT_MAX ? INT_MAX : (int)wi_[lane];
         }
         __builtin_amdgcn_wave_barrier();
-        wave_select<2>(s2, id2, k, lane, 0, ws_, wi_);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (lane < k) {
-        os[lane] = ws_[lane];
-        oi[lane] = wi_[lane] >= INT_MAX ? INT64_MAX : wi_[lane] + p.idx_base;
+        if (i0 + 1024 >= n) {
+          wave_select<17>(s17, id17, k, lane, p.idx_base, os, oi);
+        } else {
+          wave_select<17>(s17, id17, k, lane, 0, ws_, wi_);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
       }
     }
   }
@@ -868,7 +889,7 @@ static int small_prefix_keys(int B, bool i8) {
   // keys of the bound pass's prefix (with G = 4 k parts the bound is worth the exact k-th best of ~0.85 of it): one query's
   // call streams 16 K keys of the bf16 copy before its pass over the int8 copy; more queries buy a sharper bound with a
   // longer prefix (their candidates cost B times as much).  The int8 bound is ~5x wider: twice the prefix.
-  const int base = B <= 2 ? 8192 : (B <= 8 ? 16384 : 32768);
+  const int base = B <= 1 ? 8192 : (B <= 8 ? 16384 : 32768);
   return i8 ? 2 * base : base;
 }
 
@@ -894,7 +915,8 @@ static int launch_small(const SmallParams& p, int grid, hipStream_t st) {
         if (t[b][i] && t[b][i - 1]) fprintf(stderr, " %s %lld", names[i], (long long)(t[b][i] - t[b][i - 1]));
       fprintf(stderr, " | entered %lld after workgroup 0, total %lld\n", (long long)(t[b][0] - t[0][0]), (long long)(t[b][b ? 12 : 9] - t[b][0]));
     }
-    fprintf(stderr, "[small timing] exact pairs of query 0: %lld; pairs of the last workgroup: %lld\n", (long long)t[0][13], (long long)t[0][14]);
+    fprintf(stderr, "[small timing] last workgroup, wave 0: selection loads %lld, first query %lld ticks\n", (long long)(t[1][13] - t[1][10]),
+            t[1][14] ? (long long)(t[1][14] - t[1][13]) : (long long)(t[1][11] - t[1][13]));
   }
 #endif
   return RAGRAPH_OK;
@@ -938,7 +960,10 @@ extern "C" int ragraph_topk_cosine_small_f32(const float* Q, int64_t B, const fl
   RG_REQUIRE(aligned16(Q) && aligned16(Kn) && aligned16(Kb), RAGRAPH_EINVAL, "topk_cosine_small: Q / Kn / Kb must be 16-byte aligned");
   RG_REQUIRE(ws_bytes >= ragraph_topk_cosine_small_workspace_bytes(B, D, k), RAGRAPH_EWORKSPACE, "topk_cosine_small: workspace too small");
   const char* wt = getenv("RAGRAPH_SMALL_WAIT_TICKS");  // (read per call: the tests force the move-on-early path with 0)
-  const unsigned wait_ticks = wt ? (unsigned)atoll(wt) : 3000u;
+  // (2 ms: a cold start -- code pages, TLB -- can delay single workgroups by tens of microseconds, and a workgroup that
+  // moves on without the others' maxima passes every key of its share; the limit only has to keep a call from hanging
+  // when another process holds the CUs our later workgroups need)
+  const unsigned wait_ticks = wt ? (unsigned)atoll(wt) : 200000u;
   const bool i8 = small_uses_i8(D);
   const int64_t npad = (N + FILTER_PAD_KEYS - 1) / FILTER_PAD_KEYS * FILTER_PAD_KEYS;
   SmallParams p{};

@@ -168,6 +168,19 @@ def set_max_i8_levels(n: int) -> int:
     return N.lib().ragraph_topk_cosine_filtered_max_i8_levels(int(n))
 
 
+def expected_i8_candidates(B: int, n_keys: int, D: int, k: int) -> float:
+    """Candidates per query the schedule's cost model expects from the int8 levels of a filtered call of this shape (under
+    this thread's int8 cap): ~3.9 k (level end / previous end) per level."""
+    L = N.lib()
+    plan = (ctypes.c_int64 * 7)()
+    if L.ragraph_topk_cosine_filtered_plan(B, n_keys, D, k, plan) <= 0:
+        return 0.0
+    nlev = int(plan[2])
+    n_i8 = L.ragraph_topk_cosine_filtered_i8_levels(B, n_keys, D, k)
+    ends = [max(int(plan[0]), 1)] + [int(plan[3 + l]) for l in range(nlev)]
+    return sum(3.9 * k * ends[l + 1] / ends[l] for l in range(nlev) if l >= nlev - n_i8)
+
+
 def filter_helps(B: int, n_keys: int, D: int, k: int) -> bool:
     """True when the bf16-filtered exact top-k is the faster way to the same bits.  Measured on MI355X (ms, filtered vs
     fp32 kernels, D = 256, k = 10): see DESIGN.md section 4.0 (batch-size table).  Small score matrices stay on the
@@ -198,6 +211,20 @@ FILTER_MIN_B = int(os.environ.get("RAGRAPH_FILTER_MIN_B", "1"))  # banks of >= 6
 
 
 _EXCHANGE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int)
+
+# Candidate statistics of the most recent topk_cosine_filtered call of this process: a view of the 16 ints the call's
+# launches leave at the end of its workspace (include/ragraph_hip.h: ragraph_topk_cosine_filtered_stats_offset).
+last_filter_stats = None
+FILTER_STATS_MAGIC = 0x52414753
+
+
+def filter_stats_levels(stats) -> list:
+    """[(dtype, keys, candidates per query or None)] per level from a HOST copy of last_filter_stats."""
+    st = [int(x) for x in stats]
+    if len(st) < 16 or st[0] != FILTER_STATS_MAGIC:
+        return []
+    return [("int8" if st[8 + l] else "bf16", st[11 + l], (st[2 + l] / st[5 + l]) if st[5 + l] else None)
+            for l in range(min(st[1], 3))]
 
 
 def topk_cosine_filtered(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf16: torch.Tensor, k: int,
@@ -240,6 +267,9 @@ def topk_cosine_filtered(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf
     if nbytes == 0:
         raise RagraphNativeError(f"topk_cosine_filtered: unsupported shape B={B} N={Nk} D={D} k={k}")
     ws = _workspace(nbytes, q.device)
+    global last_filter_stats
+    off = L.ragraph_topk_cosine_filtered_stats_offset(ws.numel())
+    last_filter_stats = ws[off:off + 64].view(torch.int32)   # (valid until the next filtered call on this stream)
     if exchange is None:
         N.check(L.ragraph_topk_cosine_filtered_f32(q.data_ptr(), B, kn.data_ptr(), kp, keys_bf16.data_ptr(), Nk, D, k,
                                                    idx_base, scores.data_ptr(), idx.data_ptr(), overflow.data_ptr(), None,
@@ -326,12 +356,13 @@ def topk_cosine_fused(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf16:
     return scores, idx
 
 
-SMALL_MAX_B = 32
+SMALL_MAX_B = 16   # (the kernel takes up to 32; measured against the four-launch call on the 1M x 256 bank, ms: 1 query 0.067 vs
+                   # 0.093, 8: 0.073 vs 0.097, 16: 0.087 vs 0.094, 24: 0.104 vs 0.100, 32: 0.113 vs 0.096 -- profiles/r4_small_ab.txt)
 
 
 def small_helps(B: int, n_keys: int, D: int, k: int) -> bool:
     """True when the single-launch kernel for a handful of queries against a large bank (csrc/topk_small.hip) is the way
-    to the exact top-k: up to 32 queries, banks the filtered path takes at any batch size (>= 65536 keys).  Measured on
+    to the exact top-k: up to 16 queries, banks the filtered path takes at any batch size (>= 65536 keys).  Measured on
     MI355X, 1M x 256 bank, k = 10 (ms per call, this kernel vs the four-launch filtered call): DESIGN.md section 4.0c."""
     if os.environ.get("RAGRAPH_EXACT_FP32") == "1" or os.environ.get("RAGRAPH_TOPK_SMALL", "1") == "0":
         return False

@@ -24,6 +24,14 @@ class KeyIndex:
     # most DEDUP_MAX_UNIQUE of the rows are unique -- or one row is stored more than DEDUP_MAX_GROUP times: every query
     # next to it would fill its candidate list with copies -- the search runs over the unique rows (their own copies,
     # their own dispatch) and the winners are expanded to bank rows in canonical order: the same bits.
+    # Candidates per query the int8 levels of a call may pass (sampled by the call itself, read back asynchronously): an int8
+    # level saves ~0.2 ps of matrix time per (query, key) against bf16 and passes ~3x the candidates at ~0.25 ns each, so
+    # 2/3 of its candidates must stay below ~0.8e-3 x its keys; with a floor for short levels.  A bank beyond that is
+    # slower on int8 than on bf16 although nothing overflows (near-duplicate clusters of a few hundred rows): bf16 from
+    # then on.
+    I8_MAX_CANDIDATES_BASE = 300.0
+    I8_MAX_CANDIDATES_PER_KEY = 1.2e-3
+    I8_MAX_CANDIDATES_VS_PLAN = 2.5   # ... and never below this multiple of what the schedule's cost model planned for
     DEDUP_MIN_ROWS = 2048
     DEDUP_MAX_UNIQUE = 0.9
     DEDUP_MAX_GROUP = 64
@@ -42,6 +50,7 @@ class KeyIndex:
         self._seen_i8, self._seen_bf16 = [0, 0], [0, 0]   # [queries, overflowed] of the polled calls with / without int8
         self._host_word = self._event = None
         self._overflowed = 0
+        self.last_i8_candidates = None   # candidates per query over the int8 levels of the last polled call (sampled)
         # None: duplicates not looked at yet; False: looked at, searched as it is; else (KeyIndex over the unique rows,
         # group_ptr, members)
         self._collapsed = None if dedup else False
@@ -89,6 +98,15 @@ class KeyIndex:
         n_over, B = int(pend[0][0]), pend[2]
         self._pending = None
         self._overflowed += n_over
+        if pend[3] and pend[0].numel() > 16:   # the call's sampled candidate counts (int8 levels only are judged)
+            from .kernels import filter_stats_levels
+            i8 = [(keys, c) for dt, keys, c in filter_stats_levels(pend[0][1:17].tolist()) if dt == "int8" and c is not None]
+            if i8:
+                self.last_i8_candidates = sum(c for _, c in i8)
+                limit = max(self.I8_MAX_CANDIDATES_BASE + self.I8_MAX_CANDIDATES_PER_KEY * sum(kk for kk, _ in i8),
+                            self.I8_MAX_CANDIDATES_VS_PLAN * (pend[4] if len(pend) > 4 else 0.0))
+                if self.last_i8_candidates > limit:
+                    self._i8_off = True
         # judged over whole calls of >= 64 queries, or over the calls seen so far once they add up to 8 queries (graph
         # classification retrieves ONE query per forward: a bank that sends every such call to the exact scan must not stay)
         acc = self._seen_i8 if pend[3] else self._seen_bf16
@@ -103,18 +121,21 @@ class KeyIndex:
         elif acc[0] >= 4096:
             acc[0] = acc[1] = 0
 
-    def _note_overflow(self, over, B: int, had_i8: bool):
+    def _note_overflow(self, over, B: int, had_i8: bool, stats=None, planned: float = 0.0):
         """After a filtered call: its overflow count travels to a pinned host word behind an event (no wait) and is
         judged by _poll_overflow at a later call."""
         if not over.is_cuda:  # (the CPU tests' oracle shim)
             self._overflowed += int(over)
         elif self._pending is None and not torch.cuda.is_current_stream_capturing():
             if self._host_word is None:
-                self._host_word = torch.zeros(1, dtype=torch.int32).pin_memory()
+                self._host_word = torch.zeros(17, dtype=torch.int32).pin_memory()   # [0] overflow, [1:17] the call's statistics
                 self._event = torch.cuda.Event()
-            self._host_word.copy_(over, non_blocking=True)
+            self._host_word[:1].copy_(over, non_blocking=True)
+            self._host_word[1:].zero_()
+            if stats is not None:
+                self._host_word[1:].copy_(stats, non_blocking=True)
             self._event.record()
-            self._pending = (self._host_word, self._event, B, had_i8)
+            self._pending = (self._host_word, self._event, B, had_i8, planned)
 
     def _cap_i8(self):
         """Before a filtered call: cap this thread's int8 levels for THIS bank (ops.set_max_i8_levels; the caller resets it
@@ -188,12 +209,15 @@ class KeyIndex:
                 return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
             cap, had_i8 = self._cap_i8()
             had_i8 = had_i8 and ops.filtered_i8_levels(B, kn.shape[0], D, k) > 0   # (did THIS call have int8 levels?)
+            planned = 0.0
+            if had_i8 and self._pending is None and hasattr(ops, "expected_i8_candidates"):
+                planned = ops.expected_i8_candidates(B, kn.shape[0], D, k)
             try:
                 s, i, over = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base, keys_packed=self._packed)
             finally:
                 if cap is not None:
                     cap(-1)
-            self._note_overflow(over, B, had_i8)
+            self._note_overflow(over, B, had_i8, getattr(ops, "last_filter_stats", None), planned)
             return s, i
         helps = getattr(ops, "packed_keys_help", None)
         if helps is not None and helps(B, D, k):

@@ -962,3 +962,42 @@ def test_key_index_small_batches_leave_int8_when_the_bank_overflows(dev):
         rs, ri = cref.topk_cosine(q, kn, k)
         assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs)
     assert idx._i8_off and not idx._filter_off and idx.overflowed_queries >= 3
+
+
+def test_candidate_statistics_and_cost_aware_int8_demotion(dev):
+    """A filtered call leaves its sampled candidate counts per level at the end of its workspace.  A bank with a cluster of
+    a few thousand keys around the queries passes ~1000 candidates per query on its int8 level WITHOUT overflowing (the bf16
+    bound passes a handful): nothing fails, the call is merely slower than on bf16 -- KeyIndex reads the counts
+    asynchronously and keeps such a bank off int8 within three calls.  An ordinary bank stays on int8.  Every answer is
+    the oracle's."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(97)
+    N, D, B, k = 70000, 256, 17000, 10     # (a batch whose schedule plans int8 levels on a bank of this size)
+    centre = rng.standard_normal((1, D), dtype=np.float32)
+    kn = cref.normalize_rows(np.concatenate([rng.standard_normal((N - 3000, D), dtype=np.float32),
+                                             centre + 0.5 * rng.standard_normal((3000, D), dtype=np.float32)]))
+    q = (centre + 0.5 * rng.standard_normal((B, D), dtype=np.float32)).astype(np.float32)
+    knd, qd = _t(kn, dev), _t(q, dev)
+    s, i, over = K.topk_cosine_filtered(qd, knd, K.keys_to_bf16(knd), k)
+    levels = K.filter_stats_levels(K.last_filter_stats.cpu().tolist())
+    assert int(over) == 0 and len(levels) >= 1 and all(c is not None for _, _, c in levels)
+    assert sum(keys for _, keys, _ in levels) == N and levels[-1][0] == "int8"
+    assert max(c for dt, _, c in levels if dt == "int8") > 400     # the cluster's level
+    rs, ri = cref.topk_cosine(q[:200], kn, k)
+    assert np.array_equal(i.cpu().numpy()[:200], ri) and np.array_equal(s.cpu().numpy()[:200], rs)
+    idx = K.KeyIndex(knd)
+    for _ in range(3):
+        s2, i2 = idx.topk(qd, k)
+        torch.cuda.synchronize()
+        assert torch.equal(i2, i) and torch.equal(s2, s)
+    idx.topk(qd, k)
+    assert idx._i8_off and not idx._filter_off and idx.overflowed_queries == 0
+    assert idx.last_i8_candidates > K.KeyIndex.I8_MAX_CANDIDATES_VS_PLAN * K.expected_i8_candidates(B, N, D, k)
+    plain = K.KeyIndex(_t(_bank(rng, N, D), dev))
+    qp = _t(rng.standard_normal((B, D), dtype=np.float32), dev)
+    for _ in range(3):
+        plain.topk(qp, k)
+        torch.cuda.synchronize()
+    plain.topk(qp, k)
+    assert not plain._i8_off and plain.last_i8_candidates is not None and plain.last_i8_candidates < 600

@@ -37,7 +37,7 @@ def test_topk_cosine_small_bit_exact(dev, D, B, N, k):
         q[B - 1] = 0.0
     knd, qd = _t(kn, dev), _t(q, dev)
     kb = K.keys_to_bf16(knd)
-    assert K.small_helps(B, N, D, k)
+    assert K.small_helps(min(B, K.SMALL_MAX_B), N, D, k)
     rs, ri = cref.topk_cosine(q, kn, k, idx_base=5)
     for cap in (-1, 0, -1):
         old = K.set_max_i8_levels(cap)
@@ -107,10 +107,10 @@ def test_key_index_sends_a_handful_of_queries_to_the_single_launch(dev, monkeypa
     calls = []
     real = K.topk_cosine_small
     monkeypatch.setattr(K, "topk_cosine_small", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
-    for B in (1, 32, 33):
+    for B in (1, K.SMALL_MAX_B, K.SMALL_MAX_B + 1):
         q = rng.standard_normal((B, 256), dtype=np.float32)
         s, i = index.topk(_t(q, dev), 10, idx_base=7)
         rs, ri = cref.topk_cosine(q, kn, 10, idx_base=7)
         assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs)
-    assert calls == [1, 1]                        # 33 queries: the multi-launch filtered call
+    assert calls == [1, 1]                        # one query more: the multi-launch filtered call
     assert not K.small_helps(1, 60_000, 256, 10) and not K.small_helps(1, 200_000, 96, 10)
