@@ -536,7 +536,8 @@ def main():
     filt_timer = EventTimer(K, "topk_cosine_filtered")    # bound pass + bf16 filter + rescoring
     model, feats, adj, n_local = build_workload(args, dev, rank, world, args.shard, force_dist)
     L = K.N.lib()
-    L.ragraph_profile_filter_kernel(1)
+    prof = L.ragraph_filter_profile_create()   # caller-owned; attached to this thread for the timed region
+    L.ragraph_filter_profile_attach(prof)
     filter_ms = []
     level_ms = []   # per step: [(slot, ms, int8?, keys)] of the call's filter launches (slot 3 = the bound pass)
 
@@ -545,11 +546,11 @@ def main():
             return model(feats, adj)
 
     def grab_filter_ms():
-        ms = L.ragraph_profile_last_filter_ms()  # waits for this step's filter launches (they are the step's tail)
+        ms = L.ragraph_filter_profile_last_ms(prof)  # waits for this step's filter launches (they are the step's tail)
         if ms > 0:
             filter_ms.append(ms)
             a_ms, a_i8, a_keys = (ctypes.c_float * 4)(), (ctypes.c_int * 4)(), (ctypes.c_int64 * 4)()
-            L.ragraph_profile_last_filter_levels(a_ms, a_i8, a_keys)
+            L.ragraph_filter_profile_levels(prof, a_ms, a_i8, a_keys)
             level_ms.append([(s_, float(a_ms[s_]), int(a_i8[s_]), int(a_keys[s_])) for s_ in range(4) if a_ms[s_] > 0])
 
     for _ in range(args.warmup):
@@ -557,7 +558,8 @@ def main():
     topk_timer.enabled = filt_timer.enabled = True
     elapsed, out = timed_steps(step, args.steps, world, dev, grab_filter_ms)
     topk_timer.enabled = filt_timer.enabled = False
-    L.ragraph_profile_filter_kernel(0)
+    L.ragraph_filter_profile_attach(None)
+    L.ragraph_filter_profile_destroy(prof)
     # candidates per query of the last timed call's levels (sampled by the call itself: every 64th query; the 16 ints it
     # leaves at the end of its workspace, include/ragraph_hip.h)
     cand_levels = K.filter_stats_levels(K.last_filter_stats.cpu().tolist()) if K.last_filter_stats is not None else []

@@ -9,9 +9,8 @@
  *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host; row-major, contiguous, fp32;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous on it;
  *   - no allocation, no synchronisation and no global state inside a call (graph-capturable, thread-safe per
- *     stream); scratch comes from the caller via (ws, ws_bytes) sized by the matching *_workspace_bytes().  The one
- *     exception is the measurement hook ragraph_profile_filter_kernel(): while it is ON the filtered top-k records
- *     events into process-global slots (one measuring thread at a time, not capturable); it is OFF by default;
+ *     stream); scratch comes from the caller via (ws, ws_bytes) sized by the matching *_workspace_bytes().  Per-thread
+ *     settings (the int8 cap, an attached ragraph_filter_profile) are thread-local, their objects caller-owned;
  *   - return 0 on success, a negative RAGRAPH_E* code otherwise; ragraph_last_error() gives the thread's last
  *     message.  There is NO CPU fallback: without a gfx950 device every compute entry returns RAGRAPH_EDEVICE.
  *
@@ -230,14 +229,21 @@ int ragraph_topk_cosine_fused_f32(const float* Q, int64_t B, const float* Kn, co
  * (The k-th largest of a subset of all scores bounds the k-th largest of all from below.) */
 int ragraph_theta_sharpen_f32(const float* gathered, int G, int64_t B, int m, int k, float* theta, void* stream);
 
-/* Measurement hook (bench.py): when enabled, ragraph_topk_cosine_filtered_f32 brackets its bf16 filter kernel with
- * events on the caller's stream; ragraph_profile_last_filter_ms() waits for the latest one and returns its
- * duration in ms (negative if none).  Not part of the reference's interface. */
-int ragraph_profile_filter_kernel(int on);
-float ragraph_profile_last_filter_ms(void);
-/* The same per launch of the most recent call: slots 0..2 = the filter levels, slot 3 = the bound pass; HOST arrays of four:
- * ms_host (negative: no such launch), i8_host (1: the level ran on the int8 copy), keys_host (keys the launch covered). */
-int ragraph_profile_last_filter_levels(float* ms_host, int* i8_host, int64_t* keys_host);
+/* Measurement (bench.py's roofline; not part of the reference's interface): a CALLER-OWNED profile object.  While one is
+ * attached to the calling thread (thread-local, like the int8 cap: no process-global state), every filtered call of that
+ * thread records HIP events around its filter launches on the caller's stream into it -- such a call is not
+ * graph-capturable.  create / destroy allocate and free the object and its events outside any compute call.
+ *   ragraph_filter_profile_attach(p)   attach p (NULL: detach) to this thread; returns what was attached before
+ *   ragraph_filter_profile_last_ms(p)  waits for the most recent recorded call's filter launches; their summed ms (< 0: none)
+ *   ragraph_filter_profile_levels(p)   the same per launch: slots 0..2 = the filter levels, slot 3 = the bound pass; HOST
+ *                                      arrays of four: ms_host (negative: no such launch), i8_host (1: the level ran on the
+ *                                      int8 copy), keys_host (keys the launch covered). */
+typedef struct ragraph_filter_profile ragraph_filter_profile;
+ragraph_filter_profile* ragraph_filter_profile_create(void);
+void ragraph_filter_profile_destroy(ragraph_filter_profile* p);
+ragraph_filter_profile* ragraph_filter_profile_attach(ragraph_filter_profile* p);
+float ragraph_filter_profile_last_ms(ragraph_filter_profile* p);
+int ragraph_filter_profile_levels(ragraph_filter_profile* p, float* ms_host, int* i8_host, int64_t* keys_host);
 
 /* Cross-shard / cross-split merge of sorted top-k lists (no counterpart in the reference: it is single-GPU).
  *   scores,idx [G,B,k] (list g of query b at ((g*B)+b)*k) -> out [B,k], canonical order; result independent of G.

@@ -36,9 +36,11 @@ SIGNATURES = {
     "ragraph_pack_keys_f32": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "ragraph_keys_bf16_rows": (_i64, [_i64]),
     "ragraph_keys_to_bf16": (_i32, [_vp, _i64, _i32, _vp, _vp]),
-    "ragraph_profile_filter_kernel": (_i32, [_i32]),
-    "ragraph_profile_last_filter_ms": (ctypes.c_float, []),
-    "ragraph_profile_last_filter_levels": (_i32, [_vp, _vp, _vp]),
+    "ragraph_filter_profile_create": (_vp, []),
+    "ragraph_filter_profile_destroy": (None, [_vp]),
+    "ragraph_filter_profile_attach": (_vp, [_vp]),
+    "ragraph_filter_profile_last_ms": (ctypes.c_float, [_vp]),
+    "ragraph_filter_profile_levels": (_i32, [_vp, _vp, _vp, _vp]),
     "ragraph_topk_cosine_filtered_cap": (_i32, [_i32]),
     "ragraph_topk_cosine_filtered_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
     "ragraph_topk_cosine_filtered_stats_offset": (_sz, [_sz]),

@@ -36,6 +36,7 @@
 // Work plan: segment_plan.h with zero warm-up cost (there are no lists): every workgroup gets the same number of stages.
 #include "filter_common.h"
 #include "rescore_common.h"
+#include <new>
 #include "segment_plan.h"
 #include <cmath>
 #include <vector>
@@ -1625,39 +1626,55 @@ static int filter_device_cus() { return device_cus_multiple_of_8(); }  // per de
 using namespace ragraph;
 
 // Optional timing of the filter kernel alone (bench.py's roofline): events recorded around its launches on the caller's
-// stream.  Off by default; enabling creates the events once.
-static hipEvent_t g_prof_ev[2 * 4];  // three filter levels + the bound pass (slot 3)
-static int g_prof_created = 0, g_prof_on = 0, g_prof_have = 0, g_prof_bound = 0;
-static int g_prof_i8[4] = {0, 0, 0, 0};
-static int64_t g_prof_keys[4] = {0, 0, 0, 0};
-extern "C" int ragraph_profile_filter_kernel(int on) {
-  if (on && !g_prof_created) {
-    for (int i = 0; i < 2 * 4; ++i)
-      if (hipEventCreate(&g_prof_ev[i]) != hipSuccess) {
-        set_error("profile: cannot create events");
-        return RAGRAPH_EDEVICE;
-      }
-    g_prof_created = 1;
+// stream, into a CALLER-OWNED object attached to the calling thread (no process-global state: the attachment is
+// thread-local, like the int8 cap).
+struct ragraph_filter_profile {
+  hipEvent_t ev[2 * 4];  // three filter levels + the bound pass (slot 3)
+  int have, bound;
+  int i8[4];
+  int64_t keys[4];
+};
+static thread_local ragraph_filter_profile* t_prof = nullptr;
+extern "C" ragraph_filter_profile* ragraph_filter_profile_create(void) {
+  ragraph_filter_profile* p = new (std::nothrow) ragraph_filter_profile();
+  if (!p) {
+    set_error("profile: out of memory");
+    return nullptr;
   }
-  g_prof_on = on ? 1 : 0;
-  g_prof_have = g_prof_bound = 0;
-  return RAGRAPH_OK;
+  for (int i = 0; i < 2 * 4; ++i)
+    if (hipEventCreate(&p->ev[i]) != hipSuccess) {
+      for (int j = 0; j < i; ++j) (void)hipEventDestroy(p->ev[j]);
+      delete p;
+      set_error("profile: cannot create events");
+      return nullptr;
+    }
+  return p;
 }
-// Milliseconds the filter kernel ran in the most recent call (its launches summed; synchronises with them), or a
-// negative number if none was timed.
-extern "C" float ragraph_profile_last_filter_ms(void) {
-  if (!g_prof_on || !g_prof_have) return -1.f;
+extern "C" void ragraph_filter_profile_destroy(ragraph_filter_profile* p) {
+  if (!p) return;
+  if (t_prof == p) t_prof = nullptr;
+  for (int i = 0; i < 2 * 4; ++i) (void)hipEventDestroy(p->ev[i]);
+  delete p;
+}
+extern "C" ragraph_filter_profile* ragraph_filter_profile_attach(ragraph_filter_profile* p) {
+  ragraph_filter_profile* old = t_prof;
+  t_prof = p;
+  if (p) p->have = p->bound = 0;
+  return old;
+}
+// Milliseconds the filter kernel ran in the most recent call recorded into `p` (its launches summed; synchronises with
+// them), or a negative number if none was timed.
+extern "C" float ragraph_filter_profile_last_ms(ragraph_filter_profile* p) {
+  if (!p || !p->have) return -1.f;
   float total = 0.f;
-  if (g_prof_bound) {
+  if (p->bound) {
     float ms = 0.f;
-    if (hipEventSynchronize(g_prof_ev[7]) != hipSuccess || hipEventElapsedTime(&ms, g_prof_ev[6], g_prof_ev[7]) != hipSuccess)
-      return -1.f;
+    if (hipEventSynchronize(p->ev[7]) != hipSuccess || hipEventElapsedTime(&ms, p->ev[6], p->ev[7]) != hipSuccess) return -1.f;
     total += ms;
   }
-  for (int l = 0; l < g_prof_have; ++l) {
+  for (int l = 0; l < p->have; ++l) {
     float ms = 0.f;
-    if (hipEventSynchronize(g_prof_ev[2 * l + 1]) != hipSuccess ||
-        hipEventElapsedTime(&ms, g_prof_ev[2 * l], g_prof_ev[2 * l + 1]) != hipSuccess)
+    if (hipEventSynchronize(p->ev[2 * l + 1]) != hipSuccess || hipEventElapsedTime(&ms, p->ev[2 * l], p->ev[2 * l + 1]) != hipSuccess)
       return -1.f;
     total += ms;
   }
@@ -1666,17 +1683,16 @@ extern "C" float ragraph_profile_last_filter_ms(void) {
 
 // Per launch of the most recent call: slot 0..2 = the filter levels, slot 3 = the bound pass.  ms_host[s] (negative: no such
 // launch), i8_host[s] = 1 if the level ran on the int8 copy, keys_host[s] = keys it covered.  Host arrays of 4 entries.
-extern "C" int ragraph_profile_last_filter_levels(float* ms_host, int* i8_host, int64_t* keys_host) {
-  RG_REQUIRE(ms_host && i8_host && keys_host, RAGRAPH_EINVAL, "profile: null pointer");
+extern "C" int ragraph_filter_profile_levels(ragraph_filter_profile* p, float* ms_host, int* i8_host, int64_t* keys_host) {
+  RG_REQUIRE(p && ms_host && i8_host && keys_host, RAGRAPH_EINVAL, "profile: null pointer");
   for (int s_ = 0; s_ < 4; ++s_) {
     ms_host[s_] = -1.f;
-    i8_host[s_] = g_prof_i8[s_];
-    keys_host[s_] = g_prof_keys[s_];
-    const bool have = g_prof_on && (s_ == 3 ? g_prof_bound != 0 : s_ < g_prof_have);
+    i8_host[s_] = p->i8[s_];
+    keys_host[s_] = p->keys[s_];
+    const bool have = s_ == 3 ? p->bound != 0 : s_ < p->have;
     if (!have) continue;
     float ms = 0.f;
-    if (hipEventSynchronize(g_prof_ev[2 * s_ + 1]) == hipSuccess &&
-        hipEventElapsedTime(&ms, g_prof_ev[2 * s_], g_prof_ev[2 * s_ + 1]) == hipSuccess)
+    if (hipEventSynchronize(p->ev[2 * s_ + 1]) == hipSuccess && hipEventElapsedTime(&ms, p->ev[2 * s_], p->ev[2 * s_ + 1]) == hipSuccess)
       ms_host[s_] = ms;
   }
   return RAGRAPH_OK;
@@ -2200,9 +2216,9 @@ static int launch_ring(FilterParams p, int64_t B, int prof_slot, hipStream_t st)
     set_error("topk_cosine_filtered: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
     return RAGRAPH_EDEVICE;
   }
-  if (g_prof_on) (void)hipEventRecord(g_prof_ev[2 * prof_slot], st);
+  if (t_prof) (void)hipEventRecord(t_prof->ev[2 * prof_slot], st);
   hipLaunchKernelGGL((topk_filter_kernel<D, QW, BOUND, I8, SCORED>), dim3((unsigned)CUS), dim3(C::THREADS), C::LDS_BYTES, st, p);
-  if (g_prof_on) (void)hipEventRecord(g_prof_ev[2 * prof_slot + 1], st);
+  if (t_prof) (void)hipEventRecord(t_prof->ev[2 * prof_slot + 1], st);
   RG_CHECK_LAUNCH("topk_cosine_filtered(filter)");
 #ifdef RG_RING_STAMPS
   {
@@ -2314,9 +2330,9 @@ static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64
     a.nsub = rescore_slices(B, thr.k);
     a.gmax_out = f.gmax;
     a.bound_groups = bound_groups;
-    if (g_prof_on) (void)hipEventRecord(g_prof_ev[2 * prof_slot], st);
+    if (t_prof) (void)hipEventRecord(t_prof->ev[2 * prof_slot], st);
     const int rc = launch_filter_direct<D>(a, st);
-    if (g_prof_on) (void)hipEventRecord(g_prof_ev[2 * prof_slot + 1], st);
+    if (t_prof) (void)hipEventRecord(t_prof->ev[2 * prof_slot + 1], st);
     return rc;
   }
   FilterParams p{};
@@ -2443,7 +2459,7 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
     const char* e = getenv("RAGRAPH_FILTER_ABLATE");
     return e ? atoi(e) : 0;
   }();
-  if (g_prof_on) g_prof_have = g_prof_bound = 0;
+  if (t_prof) t_prof->have = t_prof->bound = 0;
 
   char* w = static_cast<char*>(ws);
   const size_t sample_ws = filter_level0_ws(sc, B, D, k);
@@ -2491,10 +2507,10 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   // out_idx hold every level's running result, local indices)
   if (bound) {
     rc = run_bf16_pass<D>(f, Kb, B, 0, sc.bound_keys, thr, cap, parts, 3, st);
-    if (g_prof_on) {
-      g_prof_bound = 1;
-      g_prof_i8[3] = 0;
-      g_prof_keys[3] = sc.bound_keys;
+    if (t_prof) {
+      t_prof->bound = 1;
+      t_prof->i8[3] = 0;
+      t_prof->keys[3] = sc.bound_keys;
     }
   } else if (sc.slab0) {
     float* S = reinterpret_cast<float*>(w);  // one slab of scores, reused: written and read back while it is in cache
@@ -2537,9 +2553,9 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
     static const int scored_shards = [] { const char* e = getenv("RAGRAPH_FILTER_SCORED_SHARDS"); return e ? atoi(e) : 0; }();
     const bool scored = i8_level && (!exchange || n_shards <= scored_shards) && filter_scored_lists(B, D, k);
     rc = run_bf16_pass<D>(f, Kb, B, key0, sc.ends[l], thr, cap, 0, l, st, i8_level ? Kb8 : nullptr, scored);
-    if (g_prof_on) {
-      g_prof_i8[l] = l >= sc.nlev - sc.i8_levels;
-      g_prof_keys[l] = sc.ends[l] - key0;
+    if (t_prof) {
+      t_prof->i8[l] = l >= sc.nlev - sc.i8_levels;
+      t_prof->keys[l] = sc.ends[l] - key0;
     }
     if (rc != RAGRAPH_OK) return rc;
     static const bool dbg_counts = [] { const char* e = getenv("RAGRAPH_FILTER_DEBUG_COUNTS"); return e && atoi(e) != 0; }();
@@ -2562,7 +2578,7 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
               l, i8_level ? "int8" : "bf16", scored ? ", scored" : "", (long long)key0, (long long)sc.ends[l], (double)tot / (double)B, mx,
               over_half, (long long)B, cap / 2, over_cap, cap);
     }
-    if (g_prof_on) g_prof_have = l + 1;
+    if (t_prof) t_prof->have = l + 1;
     rc = run_rescore<D>(f, Kn, N, B, cap, k, idx_base, l > 0, l == sc.nlev - 1, out_scores, out_idx, overflow,
                         &fallback_done, exchange != nullptr && l > 0, st, scored ? &thr : nullptr, l < 3 ? stats + 2 + l : nullptr);
     if (rc != RAGRAPH_OK) return rc;

@@ -98,6 +98,7 @@ class KeyIndex:
         n_over, B = int(pend[0][0]), pend[2]
         self._pending = None
         self._overflowed += n_over
+        i8_was_off = self._i8_off               # (the call ran under this setting: the overflow rule below judges IT)
         if pend[3] and pend[0].numel() > 16:   # the call's sampled candidate counts (int8 levels only are judged)
             from .kernels import filter_stats_levels
             i8 = [(keys, c) for dt, keys, c in filter_stats_levels(pend[0][1:17].tolist()) if dt == "int8" and c is not None]
@@ -113,7 +114,7 @@ class KeyIndex:
         acc[0] += B
         acc[1] += n_over
         if (B >= 64 and n_over >= 2 and n_over > self.OVERFLOW_FRACTION * B) or (acc[0] >= 8 and 4 * acc[1] > acc[0]):
-            if pend[3] and not self._i8_off:   # the call(s) had int8 levels: their wider bound is the first suspect
+            if pend[3] and not i8_was_off:     # the call(s) had int8 levels: their wider bound is the first suspect
                 self._i8_off = True
             else:
                 self._filter_off = True

@@ -24,7 +24,7 @@ L = _native.lib()
 for _ in range(2):
     index.topk(q, k)
 torch.cuda.synchronize()
-L.ragraph_profile_filter_kernel(1)
+prof = L.ragraph_filter_profile_create(); L.ragraph_filter_profile_attach(prof)
 acc = None
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 tot = 0.0
@@ -37,9 +37,9 @@ for _ in range(reps):
     a_ms = (ctypes.c_float * 4)()
     a_i8 = (ctypes.c_int * 4)()
     a_keys = (ctypes.c_int64 * 4)()
-    n = L.ragraph_profile_last_filter_levels(a_ms, a_i8, a_keys)
+    n = L.ragraph_filter_profile_levels(prof, a_ms, a_i8, a_keys)
     row = [a_ms[i] for i in range(4)]
     acc = row if acc is None else [x + y for x, y in zip(acc, row)]
-L.ragraph_profile_filter_kernel(0)
+L.ragraph_filter_profile_attach(None)
 print(f"B={B} N={N} D={D} k={k}: call {tot / reps:.3f} ms; levels (ms, int8, keys): "
       + ", ".join(f"({acc[i] / reps:.3f}, {a_i8[i]}, {a_keys[i]})" for i in range(4)))

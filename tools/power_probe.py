@@ -16,9 +16,9 @@ for name in ("random", "constant"):
         kn = K.normalize_rows(torch.ones(N, D, device=dev))
         q = torch.ones(B, D, device=dev)
     kb = K.keys_to_bf16(kn)
-    L = K.N.lib(); L.ragraph_profile_filter_kernel(1)
+    L = K.N.lib(); prof = L.ragraph_filter_profile_create(); L.ragraph_filter_profile_attach(prof)
     for _ in range(3):
         K.topk_cosine_filtered(q, kn, kb, k)
-        ms = L.ragraph_profile_last_filter_ms()
+        ms = L.ragraph_filter_profile_last_ms(prof)
     print(name, "filter kernel ms:", round(ms, 2), flush=True)
     del kn, q, kb
