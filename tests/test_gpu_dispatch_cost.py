@@ -1,0 +1,78 @@
+"""The dispatch rules (KeyIndex, kernels.*_helps, the schedule's cost model) against the clock: for a spread of shapes the
+product path is timed next to its forced alternatives -- int8 levels capped to bf16, scored lists off, the single-launch
+kernels off, the fp32 kernels -- and must be within 10 % (+ 4 us) of the fastest, so that the environment switches of
+DESIGN.md section 6 cannot silently rot.  Same bits on every path (checked)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _time(fn, reps, rounds=3):
+    best = float("inf")
+    for _ in range(rounds):          # best of a few medians-by-mean: another tenant's burst must not fail the test
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / reps)
+    return best, out
+
+
+SHAPES = [  # B, N, D, k, alternatives
+    (1, 1_000_000, 256, 10, ("small_off", "fp32")),
+    (16, 1_000_000, 256, 10, ("small_off", "i8_off")),
+    (256, 1_000_000, 256, 10, ("i8_off", "scored_off")),
+    (4096, 1_000_000, 256, 10, ("i8_off", "scored_off")),
+    (20_000, 500_000, 128, 10, ("i8_off",)),
+    (2708, 10_000, 64, 5, ("fused_off",)),
+    (8192, 5_000, 128, 5, ("fused_off",)),
+    (4096, 4_000_000, 64, 10, ("i8_off",)),
+]
+
+
+@pytest.mark.parametrize("B,N,D,k,alts", SHAPES)
+def test_product_dispatch_is_within_ten_percent_of_the_best_alternative(dev, monkeypatch, B, N, D, k, alts):
+    from ragraph_amd import kernels as K
+
+    g = torch.Generator(device=dev).manual_seed(B + N + D)
+    kn = K.normalize_rows(torch.randn(N, D, device=dev, generator=g))
+    q = torch.randn(B, D, device=dev, generator=g)
+    index = K.KeyIndex(kn)
+    reps = 20 if B <= 4096 else 5
+
+    def run():
+        return index.topk(q, k)
+
+    t_prod, ref = _time(run, reps)
+    times = {"product": t_prod}
+    for alt in alts:
+        with monkeypatch.context() as m:
+            old_cap = None
+            if alt == "small_off":
+                m.setenv("RAGRAPH_TOPK_SMALL", "0")
+            elif alt == "fused_off":
+                m.setenv("RAGRAPH_TOPK_FUSED", "0")
+            elif alt == "scored_off":
+                m.setenv("RAGRAPH_FILTER_SCORED", "0")
+            elif alt == "fp32":
+                m.setenv("RAGRAPH_EXACT_FP32", "1")
+            elif alt == "i8_off":           # (KeyIndex caps the int8 levels per bank: the bank is taken off int8 for this leg)
+                old_cap = index._i8_off
+                index._i8_off = True
+            try:
+                times[alt], out = _time(run, reps)
+            finally:
+                if old_cap is not None:
+                    index._i8_off = old_cap
+            assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), f"{alt}: other bits than the product path"
+    best = min(times.values())
+    assert times["product"] <= 1.10 * best + 0.004, f"B={B} N={N} D={D}: ms per call {times}"
+    print(f"\n[dispatch cost] B={B} N={N} D={D} k={k}: " + ", ".join(f"{a} {t:.4f}" for a, t in times.items()))
