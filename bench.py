@@ -48,7 +48,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: ~2.5 PF dense = 1024 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz
 INT8_MFMA_PEAK_TOPS = 5033.2    # same guide, Matrix cores: I8 "the cycles of the BF16 form at 2x the K, so 2x BF16 per clock"
 HBM_PEAK_GBS = 8000.0           # spec; ~6300 achievable
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r4_pmc_traffic.json")
 
 
 def parse():
@@ -558,6 +558,20 @@ def main():
     topk_timer.enabled = filt_timer.enabled = True
     elapsed, out = timed_steps(step, args.steps, world, dev, grab_filter_ms)
     topk_timer.enabled = filt_timer.enabled = False
+    collectives = ranks_seen = None
+    if world > 1 or force_dist:
+        # what the process group really is, and what its collectives cost: one more step OUTSIDE the timed region with every
+        # collective of ragraph_amd.sharded bracketed by events on the stream it is ordered on
+        from ragraph_amd import sharded as SH
+
+        ones = torch.ones(1, device=dev, dtype=torch.int64)
+        SH.all_reduce(ones, dist.ReduceOp.SUM)
+        ranks_seen = {"world_size": dist.get_world_size(), "all_reduce_of_ones": int(ones.item()), "backend": dist.get_backend()}
+        SH.collective_times.reset()
+        SH.collective_times.enabled = True
+        step()
+        collectives = SH.collective_times.report()
+        SH.collective_times.enabled = False
     L.ragraph_filter_profile_attach(None)
     L.ragraph_filter_profile_destroy(prof)
     # candidates per query of the last timed call's levels (sampled by the call itself: every 64th query; the 16 ints it
@@ -588,7 +602,7 @@ def main():
     flops = 2.0 * n_q_local * n_local * args.dim
     filtered = len(filt_timer.events) > 0
     traffic_unit = ("GB per launch, HBM side = (2*FETCH_SIZE + WRITE_SIZE) from rocprofv3 --pmc (separate passes), "
-                    "profiles/r3_pmc_traffic.json")
+                    "profiles/r4_pmc_traffic.json")
     if filtered:
         # Dominant kernel = the filter kernel (ragraph::topk_filter_kernel), timed per launch by events the library records
         # around its launches on the launch stream.  A call launches it once per level -- the first on the bf16 copy
@@ -676,6 +690,9 @@ def main():
                    "parallelism": "single GPU" if G == 1 else par},
         "roofline": roofline,
     }
+    if ranks_seen is not None:
+        result["ranks_seen"] = ranks_seen
+        result["collectives_per_step"] = collectives
     if args.emulate_rank_of > 1:
         result["emulated"] = (f"rank 0 of a {args.emulate_rank_of}-GPU job ({args.shard}-sharded), collectives replaced by "
                               f"their local part: value is NOT a job throughput")

@@ -2096,7 +2096,9 @@ extern "C" size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_
 // The sharded entry plans for (plan_N, n_shards): its first sample can be another one than the single bank's of plan_N rows.
 extern "C" size_t ragraph_topk_cosine_filtered_sharded_workspace_bytes(int64_t B, int64_t plan_N, int D, int k, int n_shards) {
   const size_t a = filter_workspace_bytes(B, plan_N, D, k, n_shards), b = filter_workspace_bytes(B, plan_N, D, k, 1);
-  return a > b ? a : b;  // (exchange = NULL runs the single-bank schedule)
+  const size_t c = ragraph_topk_cosine_workspace_bytes(B, plan_N, D, k);   // (a short shard's exact top-k)
+  const size_t ab = a > b ? a : b;  // (exchange = NULL runs the single-bank schedule)
+  return ab > c ? ab : c;
 }
 
 extern "C" int ragraph_topk_cosine_filtered_i8_levels(int64_t B, int64_t N, int D, int k) {
@@ -2446,6 +2448,44 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   hipStream_t st = as_stream(stream);
   const int cap = filter_cap(B, k);
   FilterSchedule sc = filter_schedule(B, plan_N, D, k, exchange ? n_shards : 1);  // (sharded banks: the same schedule on every shard)
+  // A shard SHORTER than the largest one (shards of a bank whose exact duplicates were collapsed per shard hold different
+  // numbers of unique rows): the same phases -- the exchanges must line up across the ranks -- over proportionally fewer
+  // keys; a shard too short for that structure takes part as an EXACT participant: its fp32 top-k once, offered at every
+  // exchange (exact scores of k distinct keys are valid lower bounds at every phase).
+  bool exact_participant = false;
+  if (exchange && plan_N - N > 1024) {
+    int64_t prev = 0;
+    for (int l = 0; l + 1 < sc.nlev; ++l) {
+      int64_t e = (int64_t)((double)sc.ends[l] * (double)N / (double)plan_N) / 512 * 512;   // (512: whole int8 stages at any width)
+      if (e < prev + 512 || e + 512 > N) exact_participant = true;
+      sc.ends[l] = e;
+      prev = e;
+    }
+    sc.bound_keys = (int64_t)((double)sc.bound_keys * (double)N / (double)plan_N) / FILTER_PAD_KEYS * FILTER_PAD_KEYS;
+    if (sc.nlev > 1 && sc.bound_keys > sc.ends[0]) sc.bound_keys = sc.ends[0];
+    if (sc.bound_keys / (FILTER_STAGE_BYTES / (2 * D)) < (int64_t)filter_bound_parts(k, sc.bound_keys, D, B, n_shards)) sc.bound_keys = 0;
+    sc.n0 = sc.n0 < N ? sc.n0 : N;
+    if (N < 16384 || N * 8 < plan_N) exact_participant = true;
+  }
+  if (exact_participant) {
+    RG_REQUIRE(ws_bytes >= ragraph_topk_cosine_workspace_bytes(B, N, D, k), RAGRAPH_EWORKSPACE,
+               "topk_cosine_filtered: workspace too small for a short shard's exact top-k");
+    int rc0 = ragraph_topk_cosine_bank_f32(Q, B, Kn, D == 256 ? Kp : nullptr, N, D, k, idx_base, out_scores, out_idx, ws, ws_bytes, stream);
+    if (rc0 != RAGRAPH_OK) return rc0;
+    if (hipMemsetAsync(overflow, 0, sizeof(int), st) != hipSuccess) {
+      set_error("topk_cosine_filtered: memset failed");
+      return RAGRAPH_EDEVICE;
+    }
+    FilterThr t0{};
+    t0.prev_scores = out_scores;
+    t0.k = k;
+    for (int ph = 0; ph < sc.nlev; ++ph) {   // phase 0 + one exchange behind every level but the last
+      hipLaunchKernelGGL(filter_theta_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, t0, B, ph == 0 ? 1 : 0, theta);
+      RG_CHECK_LAUNCH("topk_cosine_filtered(theta)");
+      exchange(ctx, ph);
+    }
+    return RAGRAPH_OK;
+  }
   sc.ends[sc.nlev - 1] = N;
   if (sc.bound_keys > N / 2) sc.bound_keys = 0, sc.n0 = sc.n0 < N ? sc.n0 : N;
   if (exchange && n_shards > 1 && sc.bound_keys > 0 && B <= FILTER_SLAB_MAX_B && plan_N >= 4 * 4096) {  // (the cost-model branch)
@@ -2610,7 +2650,7 @@ static int filtered_entry(const float* Q, int64_t B, const float* Kn, const floa
   RG_REQUIRE(filter_dim_ok(D), RAGRAPH_EUNSUPPORTED, "topk_cosine_filtered: D=%d not in {64,128,256}", D);
   RG_REQUIRE(B >= 1 && N >= 1 && k >= 1 && k <= 32 && k <= N, RAGRAPH_EINVAL, "topk_cosine_filtered: bad B/N/k");
   RG_REQUIRE(N < (int64_t)INT_MAX - 1024, RAGRAPH_EUNSUPPORTED, "topk_cosine_filtered: shard rows must fit int32");
-  RG_REQUIRE(plan_N >= N && plan_N - N <= 1024, RAGRAPH_EINVAL, "topk_cosine_filtered: plan_N must be the largest shard's size");
+  RG_REQUIRE(plan_N >= N && (exchange || plan_N - N <= 1024), RAGRAPH_EINVAL, "topk_cosine_filtered: plan_N must be the largest shard's size");
   RG_REQUIRE(!exchange || theta, RAGRAPH_EINVAL, "topk_cosine_filtered: an exchange needs the theta buffer");
   RG_REQUIRE(aligned16(Q) && aligned16(Kn) && aligned16(Kb) && aligned16(ws), RAGRAPH_EINVAL,
              "topk_cosine_filtered: pointers must be 16-B aligned");

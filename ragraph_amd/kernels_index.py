@@ -29,9 +29,10 @@ class KeyIndex:
     # 2/3 of its candidates must stay below ~0.8e-3 x its keys; with a floor for short levels.  A bank beyond that is
     # slower on int8 than on bf16 although nothing overflows (near-duplicate clusters of a few hundred rows): bf16 from
     # then on.
+    # (measured, 17 000 queries x 70 000 keys: an ordinary bank passes 117 + 102 on its two int8 levels -- 54 + 41 on bf16 --, a
+    # bank with a 3000-key cluster around the queries 665 -- 64 on bf16 --, nothing overflowing: tools/stats_probe.py)
     I8_MAX_CANDIDATES_BASE = 300.0
     I8_MAX_CANDIDATES_PER_KEY = 1.2e-3
-    I8_MAX_CANDIDATES_VS_PLAN = 2.5   # ... and never below this multiple of what the schedule's cost model planned for
     DEDUP_MIN_ROWS = 2048
     DEDUP_MAX_UNIQUE = 0.9
     DEDUP_MAX_GROUP = 64
@@ -65,6 +66,15 @@ class KeyIndex:
     def search_index(self) -> "KeyIndex":
         """The index whose rows the kernels actually stream: the one over the unique rows when the bank was collapsed."""
         return self._collapsed[0] if self._collapsed else self
+
+    def search_rows(self, min_unique: int = 0) -> int:
+        """Rows the kernels search for this bank: judges its duplicates now (ShardedToyGraphBase calls this on every rank
+        before the ranks agree on plan_n).  A collapsed bank of fewer than min_unique unique rows is searched as it is."""
+        if self._collapsed is None:
+            self._judge_duplicates()
+        if self._collapsed and self._collapsed[0].keys_normalized.shape[0] < min_unique:
+            self._collapsed = False
+        return int(self.search_index.keys_normalized.shape[0])
 
     def _judge_duplicates(self):
         """Once per bank version (never while a HIP graph is being captured: one read-back)."""
@@ -104,9 +114,7 @@ class KeyIndex:
             i8 = [(keys, c) for dt, keys, c in filter_stats_levels(pend[0][1:17].tolist()) if dt == "int8" and c is not None]
             if i8:
                 self.last_i8_candidates = sum(c for _, c in i8)
-                limit = max(self.I8_MAX_CANDIDATES_BASE + self.I8_MAX_CANDIDATES_PER_KEY * sum(kk for kk, _ in i8),
-                            self.I8_MAX_CANDIDATES_VS_PLAN * (pend[4] if len(pend) > 4 else 0.0))
-                if self.last_i8_candidates > limit:
+                if self.last_i8_candidates > self.I8_MAX_CANDIDATES_BASE + self.I8_MAX_CANDIDATES_PER_KEY * sum(kk for kk, _ in i8):
                     self._i8_off = True
         # judged over whole calls of >= 64 queries, or over the calls seen so far once they add up to 8 queries (graph
         # classification retrieves ONE query per forward: a bank that sends every such call to the exact scan must not stay)
@@ -122,7 +130,7 @@ class KeyIndex:
         elif acc[0] >= 4096:
             acc[0] = acc[1] = 0
 
-    def _note_overflow(self, over, B: int, had_i8: bool, stats=None, planned: float = 0.0):
+    def _note_overflow(self, over, B: int, had_i8: bool, stats=None):
         """After a filtered call: its overflow count travels to a pinned host word behind an event (no wait) and is
         judged by _poll_overflow at a later call."""
         if not over.is_cuda:  # (the CPU tests' oracle shim)
@@ -136,7 +144,7 @@ class KeyIndex:
             if stats is not None:
                 self._host_word[1:].copy_(stats, non_blocking=True)
             self._event.record()
-            self._pending = (self._host_word, self._event, B, had_i8, planned)
+            self._pending = (self._host_word, self._event, B, had_i8)
 
     def _cap_i8(self):
         """Before a filtered call: cap this thread's int8 levels for THIS bank (ops.set_max_i8_levels; the caller resets it
@@ -161,10 +169,20 @@ class KeyIndex:
         B, D = q.shape
         if self._collapsed is None:
             self._judge_duplicates()
-        if self._collapsed and exchange is None:
+        if self._collapsed:
             inner, group_ptr, members = self._collapsed
-            su, iu = inner.topk(q, min(k, inner.keys_normalized.shape[0]))
-            return ops.topk_expand_groups(su, iu, group_ptr, members, k, idx_base=idx_base)
+            U = inner.keys_normalized.shape[0]
+            if exchange is None:
+                su, iu = inner.topk(q, min(k, U))
+                return ops.topk_expand_groups(su, iu, group_ptr, members, k, idx_base=idx_base)
+            if U >= k:
+                # one shard of a row-sharded bank: the unique rows take part in the exchanges (plan_n = the largest number of
+                # searched rows over the shards -- ShardedToyGraphBase asks search_rows() of every rank); the shard's list
+                # (padded with -inf / INT64_MAX where nothing can reach the global top-k any more) is expanded to bank rows
+                su, iu = inner.topk(q, k, 0, exchange, plan_n)
+                return ops.topk_expand_groups(su, iu, group_ptr, members, k, idx_base=idx_base)
+            raise RuntimeError("KeyIndex: a collapsed shard of fewer unique rows than k cannot take part in the exchanges; "
+                               "ShardedToyGraphBase keeps such a shard uncollapsed (search_rows(min_unique=k))")
         fhelps = getattr(ops, "filter_helps", None)
         if exchange is not None:
             if fhelps is not None and fhelps(B, max(plan_n, kn.shape[0]), D, k) and B <= self.MAX_FILTERED_BATCH:
@@ -210,15 +228,12 @@ class KeyIndex:
                 return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
             cap, had_i8 = self._cap_i8()
             had_i8 = had_i8 and ops.filtered_i8_levels(B, kn.shape[0], D, k) > 0   # (did THIS call have int8 levels?)
-            planned = 0.0
-            if had_i8 and self._pending is None and hasattr(ops, "expected_i8_candidates"):
-                planned = ops.expected_i8_candidates(B, kn.shape[0], D, k)
             try:
                 s, i, over = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base, keys_packed=self._packed)
             finally:
                 if cap is not None:
                     cap(-1)
-            self._note_overflow(over, B, had_i8, getattr(ops, "last_filter_stats", None), planned)
+            self._note_overflow(over, B, had_i8, getattr(ops, "last_filter_stats", None))
             return s, i
         helps = getattr(ops, "packed_keys_help", None)
         if helps is not None and helps(B, D, k):

@@ -28,31 +28,68 @@ def _staged(group, *tensors) -> bool:
     return dist.get_backend(group) == "gloo" and any(t.is_cuda for t in tensors)
 
 
+class CollectiveTimes:
+    """Optional per-collective timing (bench.py, N > 1): while enabled, every collective of this module is bracketed by
+    events on the current stream (the stream the collective is ordered on); ms() sums them per kind after a synchronise."""
+
+    def __init__(self):
+        self.enabled = False
+        self.events = {}   # kind -> [(start, end, bytes)]
+
+    def start(self, kind: str, tensor: torch.Tensor):
+        if not (self.enabled and tensor.is_cuda):
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.events.setdefault(kind, []).append((e0, e1, tensor.numel() * tensor.element_size()))
+        return e1
+
+    def report(self) -> dict:
+        torch.cuda.synchronize()
+        return {kind: {"calls": len(ev), "ms": round(sum(a.elapsed_time(b) for a, b, _ in ev), 4),
+                       "MB": round(sum(n for _, _, n in ev) / 1e6, 3)} for kind, ev in self.events.items()}
+
+    def reset(self):
+        self.events = {}
+
+
+collective_times = CollectiveTimes()
+
+
 def all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None) -> None:
+    end = collective_times.start("all_gather", out)
     if _staged(group, out, inp):
         host = torch.empty(out.shape, dtype=out.dtype)
         dist.all_gather_into_tensor(host, inp.cpu().contiguous(), group=group)
         out.copy_(host)
     else:
         dist.all_gather_into_tensor(out, inp, group=group)
+    if end is not None:
+        end.record()
 
 
 def all_to_all_single(out: torch.Tensor, inp: torch.Tensor, recv, send, group=None) -> None:
+    end = collective_times.start("all_to_all", out)
     if _staged(group, out, inp):
         host = torch.empty(out.shape, dtype=out.dtype)
         dist.all_to_all_single(host, inp.cpu().contiguous(), recv, send, group=group)
         out.copy_(host)
     else:
         dist.all_to_all_single(out, inp, recv, send, group=group)
+    if end is not None:
+        end.record()
 
 
 def all_reduce(t: torch.Tensor, op, group=None) -> None:
+    end = collective_times.start("all_reduce", t)
     if _staged(group, t):
         host = t.cpu()
         dist.all_reduce(host, op=op, group=group)
         t.copy_(host)
     else:
         dist.all_reduce(t, op=op, group=group)
+    if end is not None:
+        end.record()
 
 
 def shard_bounds(N: int, world: int, rank: int):
@@ -134,9 +171,11 @@ class ShardedToyGraphBase:
 
         exchange_fn.n_shards = self.emulate_world if self.emulate_world > 1 else self.world
         self._exchange_fn = exchange_fn
-        n_local = int(keys.shape[0])
+        # rows this shard SEARCHES: its unique rows when KeyIndex collapses exact duplicates (the reference's bank recipe stores
+        # most rows many times over; every shard judges its own rows) -- plan_n is the largest of those over the ranks
+        n_local = self._index.search_rows(min_unique=64) if hasattr(self._index, "search_rows") else int(keys.shape[0])
         if plan_n:
-            self.plan_n = int(plan_n)
+            self.plan_n = max(int(plan_n), n_local) if n_local != int(keys.shape[0]) else int(plan_n)
         elif self.collective:
             t = torch.tensor([n_local], dtype=torch.int64, device=keys.device)
             all_reduce(t, dist.ReduceOp.MAX, group)

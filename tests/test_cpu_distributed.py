@@ -40,6 +40,16 @@ class OracleOps:
         return torch.from_numpy(cref.gather_rows(v.numpy(), idx.numpy(), idx_base))
 
     @staticmethod
+    def dedup_rows(kn):
+        U, largest, uniq, ptr, mem = cref.dedup_rows(kn.numpy())
+        return U, largest, torch.from_numpy(uniq), torch.from_numpy(ptr), torch.from_numpy(mem)
+
+    @staticmethod
+    def topk_expand_groups(su, iu, ptr, mem, k, idx_base=0, idx_base_u=0):
+        s, i = cref.topk_expand_groups(su.numpy(), iu.numpy(), ptr.numpy(), mem.numpy(), k, idx_base, idx_base_u)
+        return torch.from_numpy(s), torch.from_numpy(i)
+
+    @staticmethod
     def theta_sharpen(gathered, theta, k):
         G, B, m = gathered.shape
         union = gathered.permute(1, 0, 2).reshape(B, G * m)
@@ -234,3 +244,63 @@ def test_sharded_theta_exchange_world2(tmp_path, skew):
         lo, hi = int(got["tlo"]), int(got["thi"])
         assert np.array_equal(got["ti"], ri[lo:hi]) and np.array_equal(got["sv"], rsv[lo:hi])
         assert np.array_equal(got["ml"], rml[lo:hi]) and np.array_equal(got["full_ml"], rml)
+
+
+def _dup_worker(rank, world, port, N, D, B, k, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ragraph_amd.sharded import ShardedToyGraphBase, shard_bounds
+
+        keys, q = _dup_bank(N, D, B)
+        lo, hi = shard_bounds(N, world, rank)
+        rng = np.random.default_rng(11)
+        vals = torch.from_numpy(rng.standard_normal((N, D), dtype=np.float32))
+        labs = torch.from_numpy(np.eye(3, dtype=np.float32)[rng.integers(0, 3, N)])
+        tgb = ShardedToyGraphBase(torch.from_numpy(keys[lo:hi]), vals, labs, lo, k, ops=FilteredOracleOps, values_replicated=True)
+        s, i = tgb.topk(torch.from_numpy(q))
+        sv, ml, ti = tgb.retrieve_reduced_rows(torch.from_numpy(q))
+        stats = tgb._index.duplicate_stats
+        np.savez(os.path.join(out_dir, f"d{rank}.npz"), s=s.numpy(), i=i.numpy(), ti=ti.numpy(), plan_n=tgb.plan_n,
+                 searched=tgb._index.search_rows(), rows=hi - lo, stats=np.array(stats if stats else (0, 0, 0)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _dup_bank(N, D, B):
+    """A bank in the reference's proportions (three quarters one vector, repeats among the rest), the first shard with far
+    more distinct rows than the second."""
+    rng = np.random.default_rng(21)
+    real = cref.normalize_rows(rng.standard_normal((N, D), dtype=np.float32))
+    const = cref.normalize_rows(rng.standard_normal((1, D), dtype=np.float32))[0]
+    keys = real.copy()
+    keys[np.arange(N) % 4 != 0] = const               # 75 % copies of one vector
+    keys[N // 2:][np.arange(N - N // 2) % 8 != 0] = const   # the second half: 87.5 %
+    rep = rng.random(N) < 0.2
+    keys[rep] = keys[rng.integers(0, N, N)[rep]]
+    q = rng.standard_normal((B, D), dtype=np.float32)
+    q[0] = const + 0.05 * rng.standard_normal(D).astype(np.float32)
+    q[1] = 0.0
+    return keys, q
+
+
+def test_sharded_duplicate_bank_world2(tmp_path):
+    """Key sharding over a bank of duplicates: every shard collapses ITS exact duplicates (different numbers of unique rows
+    per shard), the ranks agree on plan_n = the largest searched row count, the per-shard lists of unique rows are expanded
+    to bank rows before the merge -- the single-GPU result over all N rows, bit for bit."""
+    N, D, B, k, world = 9000, 32, 19, 10, 2
+    mp.spawn(_dup_worker, args=(world, _free_port(), N, D, B, k, str(tmp_path)), nprocs=world, join=True)
+    keys, q = _dup_bank(N, D, B)
+    rs, ri = cref.topk_cosine(q, cref.normalize_rows(keys), k)
+    got = [dict(np.load(tmp_path / f"d{r}.npz")) for r in range(world)]
+    for r, g in enumerate(got):
+        assert np.array_equal(g["i"], ri) and np.array_equal(g["s"], rs)
+        assert g["searched"] < g["rows"] // 2 and g["stats"][1] == g["searched"]      # collapsed
+        assert g["plan_n"] == max(int(x["searched"]) for x in got)
+    assert got[0]["searched"] > 1.5 * got[1]["searched"]                               # unequal shards
+    lo1 = N // 2
+    from ragraph_amd.sharded import shard_bounds
+    for r, g in enumerate(got):
+        a, b = shard_bounds(B, world, r)
+        assert np.array_equal(g["ti"], ri[a:b])
+    assert lo1 > 0

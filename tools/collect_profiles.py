@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Copy what tools/gpu_round_r3.sh left under gpurun_out/<tag>/ into profiles/r3_* (the files the docs and bench.py cite)
+"""Copy what tools/gpu_round_<round>.sh left under gpurun_out/<tag>/ into profiles/r3_* (the files the docs and bench.py cite)
 and rebuild profiles/r3_pmc_traffic.json from the PMC summaries.   python tools/collect_profiles.py r3"""
 import csv, json, os, re, shutil, sys
 
 tag = sys.argv[1]
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(R, "gpurun_out", tag), os.path.join(R, "profiles")
-P = "r3"
+P = tag[:2] if tag[:1] == "r" and tag[1:2].isdigit() else "r3"   # r3 / r4: the round prefix of the profiles
 
 
 def cp(a, b):
@@ -53,8 +53,8 @@ def kernel_us(path, name):
 fe, wr = pmc(os.path.join(src, "pmc_fetch.txt")), pmc(os.path.join(src, "pmc_write.txt"))
 out = {
     "_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate run, --pmc WRITE_SIZE on MI355X "
-            "(tools/gpu_round_r3.sh, collected by tools/collect_profiles.py; summaries profiles/r3_bench_c2_pmc_traffic.txt, "
-            "profiles/r3_smallb_B*_pmc_traffic.txt); values are KB per dispatch. HBM-side bytes = (2*FETCH_SIZE + "
+            "(tools/gpu_round_<round>.sh, collected by tools/collect_profiles.py; summaries profiles/<round>_bench_c2_pmc_traffic.txt, "
+            "profiles/<round>_smallb_B*_pmc_traffic.txt); values are KB per dispatch. HBM-side bytes = (2*FETCH_SIZE + "
             "WRITE_SIZE)*1024: on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM "
             "section). Infinity-Cache hits are included in FETCH_SIZE.",
 }
