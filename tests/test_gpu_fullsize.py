@@ -292,6 +292,77 @@ def test_sharded_filtered_exchange_matches_single_gpu(dev, G, B, pool):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B", [3000, 300])
+def test_sharded_unequal_shards_of_a_duplicate_bank(dev, B):
+    """Three row shards of a bank of duplicates, each collapsed by its own KeyIndex to a different number of unique rows: one
+    searched as it is (200 000 distinct rows = plan_n), one at a quarter of that (the same phases over proportionally
+    fewer keys), one tiny (an exact participant: its fp32 top-k offered at every exchange).  Threads as ranks, exchanges
+    through a barrier as in the test above; the expanded per-shard lists merge to the fp32 kernel's result over all
+    600 000 rows, bit for bit."""
+    import threading
+
+    from ragraph_amd import kernels as K
+
+    g = torch.Generator(device=dev).manual_seed(33)
+    D, k, G, n = 256, 10, 3, 200_000
+    const = K.normalize_rows(torch.randn(1, D, device=dev, generator=g))
+    shards = []
+    for r, distinct in enumerate((1.0, 0.25, 0.05)):
+        rows = K.normalize_rows(torch.randn(n, D, device=dev, generator=g))
+        if distinct < 1.0:
+            keep = torch.rand(n, device=dev, generator=g) < distinct
+            rows[~keep] = const
+            rep = torch.rand(n, device=dev, generator=g) < 0.1
+            rows[rep] = rows[torch.randint(0, n, (n,), device=dev, generator=g)[rep]]
+        shards.append(rows.contiguous())
+    kn = torch.cat(shards)
+    q = torch.randn(B, D, device=dev, generator=g)
+    q[0] = const[0] + 0.05 * q[0]          # next to the row stored ~340 000 times in shards 1 and 2
+    q[1] = shards[2][7]
+    q[2] = 0.0
+    full_s, full_i = K.topk_cosine(q, kn, k)
+    idx = [K.KeyIndex(sh) for sh in shards]
+    searched = [ix.search_rows(min_unique=64) for ix in idx]
+    assert searched[0] == n and 40_000 < searched[1] < 70_000 and searched[2] < 16_000
+    plan_n = max(searched)
+    barrier = threading.Barrier(G)
+    slots = [None] * G
+    out, errs = [None] * G, []
+    m = min(k, 2 * (-(-k // G)))
+
+    def exchange_for(r):
+        def exchange(phase, theta, scores):
+            torch.cuda.current_stream().synchronize()
+            slots[r] = scores[:, :m].clone()
+            torch.cuda.current_stream().synchronize()
+            barrier.wait()
+            K.theta_sharpen(torch.stack(slots).contiguous(), theta, k)
+            torch.cuda.current_stream().synchronize()
+            barrier.wait()
+        exchange.n_shards = G
+        return exchange
+
+    def run(r):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                s, i = idx[r].topk(q, k, idx_base=r * n, exchange=exchange_for(r), plan_n=plan_n)
+                torch.cuda.current_stream().synchronize()
+                out[r] = (s, i)
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    ms, mi = K.topk_merge(torch.stack([o[0] for o in out]), torch.stack([o[1] for o in out]))
+    assert torch.equal(mi, full_i) and torch.equal(ms, full_s)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tool,args", [("soak_filtered.py", ["8", "123"]), ("soak_filtered.py", ["8", "124", "index"]),
                                        ("shard_soak.py", ["soak", "8", "125"]), ("soak_ops.py", ["8", "126"])])
 def test_randomised_soaks_short(dev, tool, args):
