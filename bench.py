@@ -164,6 +164,7 @@ def build_workload(args, dev, rank, world, shard, force_dist=False):
 def gnn_only_rate(model, feats, adj, steps):
     from ragraph_amd.ragraph_utils import Propagation
 
+    @torch.no_grad()
     def run():
         h = model.pretrain_model.inference(feats, adj)
         return Propagation.aggregate_k_hop_features(adj, h, model.query_graph_hop)

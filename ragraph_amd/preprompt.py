@@ -12,6 +12,7 @@ class PrePrompt(nn.Module):
         super().__init__()
         self.gcn = GcnLayers(n_in, n_h, num_layers_num, p)
 
+    @torch.no_grad()   # (the reference detaches the result: nothing upstream of it can train through this call)
     def embed(self, seq, adj, sparse, msk, LP):
         """preprompt.py:57-62.  Returns (h, c).  The node flavour's c is the 3-hop subgraph readout that a Python loop
         over nnz(A^3) computes (preprompt.py:8-27) and inference() throws away; here c is the plain mean readout of h
@@ -20,6 +21,7 @@ class PrePrompt(nn.Module):
         h = self.gcn(seq, adj, sparse, LP).squeeze(0)
         return h.detach(), h.mean(dim=0, keepdim=True).detach()
 
+    @torch.no_grad()   # (detached by the reference: always the inference kernels, whatever the caller's grad mode)
     def inference(self, features, adj):
         """preprompt.py:64-66: L GCN layers, detached."""
         sparse_features(features)

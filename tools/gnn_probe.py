@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Kernel times of the c2 GNN forward's pieces (100k-node graph, F = 128 -> 256): SpMM at widths 128 / 256, the dense layer
+with and without the fused bias + PReLU, the two associations of the encoder, a propagation hop."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ragraph_amd import kernels as K
+from ragraph_amd.data import synthetic_big_graph
+from ragraph_amd.graph import CSRGraph
+
+dev = torch.device("cuda", 0)
+n, F, D = 100_000, 128, 256
+g = CSRGraph.from_edge_index_sym_normalized(synthetic_big_graph(n, 10, seed=8, device=dev), n)
+X = torch.randn(n, F, device=dev)
+H = torch.randn(n, D, device=dev)
+W = torch.randn(D, F, device=dev) * 0.05
+b = torch.randn(D, device=dev) * 0.1
+vn = K.csr_row_normalize(g.rowptr, g.val)
+
+
+def t(fn, reps=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+print(f"spmm D=128 (no epilogue):          {t(lambda: K.spmm_csr(g.rowptr, g.col, g.val, X)):7.1f} us")
+print(f"spmm D=256 (bias + PReLU):         {t(lambda: K.spmm_csr(g.rowptr, g.col, g.val, H, bias=b, act=K.ACT_PRELU, alpha=0.25)):7.1f} us")
+print(f"spmm D=256 (ReLU, a hop):          {t(lambda: K.spmm_csr(g.rowptr, g.col, vn, H, act=K.ACT_RELU)):7.1f} us")
+print(f"linear 128 -> 256:                 {t(lambda: K.linear(X, W)):7.1f} us")
+print(f"linear 128 -> 256 + bias + PReLU:  {t(lambda: K.linear(X, W, b, act=K.ACT_PRELU, alpha=0.25)):7.1f} us")
+print(f"encoder, reference order:          {t(lambda: K.spmm_csr(g.rowptr, g.col, g.val, K.linear(X, W), bias=b, act=K.ACT_PRELU, alpha=0.25)):7.1f} us")
+print(f"encoder, aggregate first:          {t(lambda: K.linear(K.spmm_csr(g.rowptr, g.col, g.val, X), W, b, act=K.ACT_PRELU, alpha=0.25)):7.1f} us")
