@@ -333,6 +333,15 @@ int ragraph_spmm_csr_ws_f32(const int64_t* rowptr, const int32_t* col, const flo
                             const float* bias, int act, float alpha, float beta, const float* Y_in, float* Y, int64_t nnz,
                             void* ws, size_t ws_bytes, void* stream);
 
+/* a7, several hops  -- Propagation.py:19-25 with the features PANEL-major between the hops: [D / 32][n][32] floats (a row's
+ * 32-column blocks, one 128-byte line each).  The column-panel hop gives every XCD one panel (D = 256): the rows it gathers
+ * from are n x 128 bytes instead of n x 1 KiB, a third of which fit its L2 on a graph without locality (c2: L2 hit rate 15 ->
+ * 34 %, a hop 132 -> ~116 us).  x_panels / y_panels: 0 = row-major [n, D], 1 = panel-major.  Same chains as ragraph_spmm_csr_f32
+ * (per element, CSR order, blocks of 4096 edges), hence the same bits in every layout; no bias / residual.
+ * D in {64, 128} or a multiple of 256. */
+int ragraph_spmm_csr_panels_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n, const float* X,
+                                int x_panels, int D, int act, float alpha, float* Y, int y_panels, void* stream);
+
 /* a7  adj / adj.sum(dim=1, keepdim=True)  -- Propagation.py:15-16.  val_out[e] = val[e] / rowsum(row(e)), rowsum =
  *     sequential fp32 adds in CSR order.  In-place allowed.  (A zero row sum gives inf/nan exactly as the reference.) */
 int ragraph_csr_row_normalize_f32(const int64_t* rowptr, const float* val, int64_t n, float* val_out, void* stream);

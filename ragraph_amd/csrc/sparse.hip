@@ -65,9 +65,11 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) {
   return make_float4(__fadd_rn(a.x, b.x), __fadd_rn(a.y, b.y), __fadd_rn(a.z, b.z), __fadd_rn(a.w, b.w));
 }
 
+// panel_n > 0: Y is PANEL-major -- [D / 32][panel_n][32] floats (a row's eight-float4 pieces of one 128-byte line go to the
+// panel of their column block): the layout the column-panel hops below read.
 __device__ __forceinline__ void spmm_epilogue_store(float4 acc, const float* __restrict__ bias, int act, float alpha,
                                                     float beta, const float* __restrict__ Yin, float* __restrict__ Y,
-                                                    int64_t row, int D4, int c4) {
+                                                    int64_t row, int D4, int c4, int64_t panel_n = 0) {
   if (bias) acc = add4(acc, reinterpret_cast<const float4*>(bias)[c4]);
   acc.x = apply_act(acc.x, act, alpha); acc.y = apply_act(acc.y, act, alpha);
   acc.z = apply_act(acc.z, act, alpha); acc.w = apply_act(acc.w, act, alpha);
@@ -75,7 +77,8 @@ __device__ __forceinline__ void spmm_epilogue_store(float4 acc, const float* __r
     const float4 y = reinterpret_cast<const float4*>(Yin)[row * D4 + c4];
     acc.x = fmaf(beta, y.x, acc.x); acc.y = fmaf(beta, y.y, acc.y); acc.z = fmaf(beta, y.z, acc.z); acc.w = fmaf(beta, y.w, acc.w);
   }
-  reinterpret_cast<float4*>(Y)[row * D4 + c4] = acc;
+  if (panel_n > 0) reinterpret_cast<float4*>(Y)[((int64_t)(c4 >> 3) * panel_n + row) * 8 + (c4 & 7)] = acc;
+  else reinterpret_cast<float4*>(Y)[row * D4 + c4] = acc;
 }
 
 // skip_long != 0: rows longer than ROW_BLOCK are left to the long-row kernels.
@@ -86,7 +89,7 @@ __global__ void __launch_bounds__(256) spmm_csr_kernel(const int64_t* __restrict
                                                        const float* __restrict__ X, int D,
                                                        const float* __restrict__ bias, int act, float alpha, float beta,
                                                        const float* __restrict__ Yin, float* __restrict__ Y,
-                                                       int skip_long, unsigned RUN) {
+                                                       int skip_long, unsigned RUN, int64_t panel_n = 0) {
   constexpr int RPB = 256 / LPR;  // rows per block
   const int lr = threadIdx.x % LPR;
   const int gbase = (threadIdx.x & 63) - lr;  // first lane of this row's group inside the wave
@@ -129,8 +132,85 @@ __global__ void __launch_bounds__(256) spmm_csr_kernel(const int64_t* __restrict
       }
     }
     if (!live || !colok) continue;
-    spmm_epilogue_store(acc, bias, act, alpha, beta, Yin, Y, row, D4, c4);
+    spmm_epilogue_store(acc, bias, act, alpha, beta, Yin, Y, row, D4, c4, panel_n);
   }
+}
+
+// ---- column-panel hops (round 4; measured as a microbenchmark in round 3: profiles/r3_spmm_panel.txt) -----------------
+// On a graph without locality every XCD gathers from all of X (102 MB at c2) and its 4-MiB L2 hits 15 % of the row
+// gathers.  Between the hops of a k-hop propagation the features can stay PANEL-major, [D / 32][n][32]: a panel row is one
+// 128-byte line, workgroup b runs on XCD b % 8 and the workgroups of XCD x work through panels x, x + 8, ... (D = 256:
+// exactly one panel per XCD), so the rows an XCD gathers from are n x 128 bytes (12.8 MB at c2: a third of them fit its L2;
+// hit rate 34 %, traffic -11 %, time -12 %).  LP = 8 lanes hold one output row of the panel as float4, a wave 8 rows; edges
+// in chunks of 8.  A row's chain is the row kernel's -- same edges, same order, per element, blocks of ROW_BLOCK edges each
+// from +0 and added in order -- so every layout gives the same bits.
+__global__ void __launch_bounds__(256) spmm_panel_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                         const float* __restrict__ val, int64_t n, const float* __restrict__ Xp,
+                                                         float* __restrict__ Y, int64_t y_panel_stride, int64_t y_row_stride,
+                                                         int P, int act, float alpha) {
+  constexpr int LP = 8, ROWS_W = 8, ROWS_B = 32, CH = 8;
+  const int lane = threadIdx.x & 63;
+  const int lr = lane % LP;
+  const int gbase = lane - lr;
+  const unsigned xcd = blockIdx.x % 8, i = blockIdx.x / 8;   // i-th workgroup of this XCD
+  const int64_t row_blocks = (n + ROWS_B - 1) / ROWS_B;
+  int panel;
+  int64_t rb;
+  if (P >= 8) {  // XCD x: panels x, x + 8, ... in turn, all row blocks of one before the next
+    panel = (int)xcd + 8 * (int)(i / row_blocks);
+    rb = i % row_blocks;
+  } else {       // 8 / P XCDs share a panel, each a contiguous part of the row blocks
+    const int share = 8 / P;
+    panel = (int)(xcd % P);
+    const int64_t per = (row_blocks + share - 1) / share;
+    rb = (int64_t)(xcd / P) * per + i;
+    if (i >= per) return;
+  }
+  if (panel >= P || rb >= row_blocks) return;
+  int64_t row = rb * ROWS_B + (threadIdx.x >> 6) * ROWS_W + lane / LP;
+  const bool live = row < n;
+  if (!live) row = n - 1;
+  const int64_t e0 = rowptr[row];
+  const int64_t deg = live ? rowptr[row + 1] - e0 : 0;
+  int64_t maxdeg = deg;  // the longest row of the wave sets the trip counts (shuffles need every lane)
+#pragma unroll
+  for (int off = 32; off >= LP; off >>= 1) {
+    const int64_t o = ((int64_t)__shfl_xor((int)(maxdeg >> 32), off) << 32) | (unsigned)__shfl_xor((int)maxdeg, off);
+    maxdeg = o > maxdeg ? o : maxdeg;
+  }
+  const float4* X4 = reinterpret_cast<const float4*>(Xp + (int64_t)panel * n * 32) + lr;
+  float4 total = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t b0 = 0; b0 < maxdeg || b0 == 0; b0 += ROW_BLOCK) {
+    const int cnt_w = maxdeg - b0 < ROW_BLOCK ? (int)(maxdeg - b0) : ROW_BLOCK;          // wave-uniform
+    const int cnt = deg - b0 < ROW_BLOCK ? (int)(deg - b0 > 0 ? deg - b0 : 0) : ROW_BLOCK;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = 0; base < cnt_w; base += CH) {
+      const int e = base + lr;
+      const bool ok = e < cnt;
+      const int my_c = ok ? col[e0 + b0 + e] : 0;
+      const float my_v = ok ? val[e0 + b0 + e] : 0.f;
+      float4 x[CH];
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int c = __shfl(my_c, gbase + k);
+        x[k] = (base + k < cnt) ? X4[(int64_t)c * 8] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const float v = __shfl(my_v, gbase + k);
+        if (base + k < cnt) {
+          acc.x = fmaf(v, x[k].x, acc.x); acc.y = fmaf(v, x[k].y, acc.y);
+          acc.z = fmaf(v, x[k].z, acc.z); acc.w = fmaf(v, x[k].w, acc.w);
+        }
+      }
+    }
+    if (b0 == 0) total = acc;
+    else if (b0 < deg) total = add4(total, acc);
+  }
+  if (!live) return;
+  total.x = apply_act(total.x, act, alpha); total.y = apply_act(total.y, act, alpha);
+  total.z = apply_act(total.z, act, alpha); total.w = apply_act(total.w, act, alpha);
+  reinterpret_cast<float4*>(Y + (int64_t)panel * y_panel_stride + row * y_row_stride)[lr] = total;
 }
 
 // ---- long rows, with a workspace ------------------------------------------------------------------------------------
@@ -447,6 +527,42 @@ extern "C" int ragraph_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, c
                                     const float* X, int D, const float* bias, int act, float alpha, float beta,
                                     const float* Y_in, float* Y, void* stream) {
   return ragraph_spmm_csr_ws_f32(rowptr, col, val, n, X, D, bias, act, alpha, beta, Y_in, Y, 0, nullptr, 0, stream);
+}
+
+extern "C" int ragraph_spmm_csr_panels_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n, const float* X,
+                                           int x_panels, int D, int act, float alpha, float* Y, int y_panels, void* stream) {
+  RG_REQUIRE(rowptr && X && Y, RAGRAPH_EINVAL, "spmm_csr_panels: null pointer");
+  RG_REQUIRE(n >= 1 && (D == 64 || D == 128 || D == 256 || (D % 256 == 0 && D <= 2048)), RAGRAPH_EUNSUPPORTED,
+             "spmm_csr_panels: D=%d (panels of 32 columns: 2, 4 or a multiple of 8 of them)", D);
+  RG_REQUIRE(aligned16(X) && aligned16(Y) && X != Y, RAGRAPH_EINVAL, "spmm_csr_panels: X, Y must be 16-B aligned and distinct");
+  RG_REQUIRE(act >= RAGRAPH_ACT_NONE && act <= RAGRAPH_ACT_ELU, RAGRAPH_EINVAL, "spmm_csr_panels: bad act %d", act);
+  hipStream_t st = as_stream(stream);
+  const int P = D / 32;
+  if (!x_panels) {  // row-major in: the row kernel, storing row-major or panel-major
+    static const unsigned xcd_run = [] {
+      const char* e = getenv("RAGRAPH_SPMM_XCD_RUN");
+      const int v = e ? atoi(e) : 32;
+      return (unsigned)(v < 1 ? 1 : v);
+    }();
+    const int D4 = D >> 2;
+    const int64_t pn = y_panels ? n : 0;
+#define RG_SPMM_P(LPR_)                                                                                                     \
+  hipLaunchKernelGGL(spmm_csr_kernel<LPR_>, dim3((unsigned)cdiv(n, 256 / (LPR_))), dim3(256), 0, st, rowptr, col, val, n, X, D, \
+                     (const float*)nullptr, act, alpha, 0.f, (const float*)nullptr, Y, 0, xcd_run, pn)
+    if (D4 <= 16) RG_SPMM_P(16);
+    else if (D4 <= 32) RG_SPMM_P(32);
+    else RG_SPMM_P(64);
+#undef RG_SPMM_P
+    RG_CHECK_LAUNCH("spmm_csr_panels");
+    return RAGRAPH_OK;
+  }
+  const int64_t row_blocks = cdiv(n, 32);
+  const int64_t per_xcd = P >= 8 ? row_blocks * (P / 8) : cdiv(row_blocks, (int64_t)(8 / P));
+  RG_REQUIRE(per_xcd * 8 < ((int64_t)1 << 31), RAGRAPH_EUNSUPPORTED, "spmm_csr_panels: too many rows");
+  hipLaunchKernelGGL(spmm_panel_kernel, dim3((unsigned)(per_xcd * 8)), dim3(256), 0, st, rowptr, col, val, n, X, Y,
+                     y_panels ? n * 32 : (int64_t)32, y_panels ? (int64_t)32 : (int64_t)D, P, act, alpha);
+  RG_CHECK_LAUNCH("spmm_csr_panels");
+  return RAGRAPH_OK;
 }
 
 extern "C" int ragraph_csr_row_normalize_f32(const int64_t* rowptr, const float* val, int64_t n, float* val_out,

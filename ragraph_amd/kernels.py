@@ -556,6 +556,29 @@ def spmm_csr(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, x: torc
     return y
 
 
+def spmm_csr_panels(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, x: torch.Tensor, x_panels: bool, y_panels: bool,
+                    act: int = ACT_NONE, alpha: float = 0.0) -> torch.Tensor:
+    """act(A @ x) with x and / or the result PANEL-major ([D/32][n][32] floats, stored as an [n, D]-sized tensor) --
+    the hops of a k-hop propagation between which the features never need to be row-major (ragraph_spmm_csr_panels_f32:
+    an XCD gathers from one panel; same bits as spmm_csr in every layout)."""
+    L = _ready()
+    rowptr = _idxc(rowptr, "spmm_csr_panels.rowptr")
+    col = _idxc(col, "spmm_csr_panels.col", torch.int32)
+    val = _f32c(val, "spmm_csr_panels.val")
+    x = _f32c(x, "spmm_csr_panels.x")
+    n, D = rowptr.numel() - 1, x.shape[1]
+    y = torch.empty((n, D), dtype=torch.float32, device=x.device)
+    N.check(L.ragraph_spmm_csr_panels_f32(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), n, x.data_ptr(), int(x_panels), D, act,
+                                          float(alpha), y.data_ptr(), int(y_panels), _stream()), "spmm_csr_panels")
+    return y
+
+
+def panels_help(n: int, D: int, k: int) -> bool:
+    """A k-hop propagation whose intermediate features are worth keeping panel-major: at least two hops over a table much
+    larger than the eight L2s (c2: 100 000 x 256 -- 102 MB; a table that fits the L2s gains nothing), D = 256 (one panel per XCD)."""
+    return k >= 2 and D == 256 and n * D * 4 >= (64 << 20) and os.environ.get("RAGRAPH_SPMM_PANELS", "1") != "0"
+
+
 def csr_row_normalize(rowptr: torch.Tensor, val: torch.Tensor) -> torch.Tensor:
     """val / rowsum -- Propagation.py:15-16."""
     L = _ready()

@@ -1003,3 +1003,41 @@ def test_candidate_statistics_and_cost_aware_int8_demotion(dev):
         torch.cuda.synchronize()
     plain.topk(qp, k)
     assert not plain._i8_off and plain.last_i8_candidates is not None and 100 < plain.last_i8_candidates < 350
+
+
+@pytest.mark.parametrize("n,D,deg", [(3000, 256, 9), (5001, 128, 5), (777, 64, 12), (40000, 256, 11), (2500, 512, 4)])
+def test_spmm_csr_panels_bit_exact(dev, n, D, deg):
+    """The column-panel hops (features [D/32][n][32] between the hops of a propagation): row -> panel, panel -> panel and panel ->
+    row give the bits of the row kernel and of the oracle in every combination -- with a hub row of more than 4096 edges (summed
+    in blocks of 4096, as everywhere), empty rows, and the ReLU epilogue."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(n + D)
+    src = rng.integers(0, n, n * deg)
+    dst = rng.integers(0, n, n * deg)
+    hub = min(n - 1, 17)
+    extra = min(n, 6000)
+    src = np.concatenate([src, np.full(extra, hub)])               # row `hub` has > 4096 entries when n allows
+    dst = np.concatenate([dst, rng.permutation(n)[:extra]])
+    keep = src != 5                                                  # row 5 stays empty
+    order = np.lexsort((dst[keep], src[keep]))
+    r, c = src[keep][order], dst[keep][order]
+    rowptr = np.zeros(n + 1, np.int64)
+    np.add.at(rowptr, r + 1, 1)
+    rowptr = np.cumsum(rowptr)
+    val = rng.standard_normal(r.size).astype(np.float32) * 0.3
+    X = rng.standard_normal((n, D), dtype=np.float32)
+    rp, cc, vv, Xd = _t(rowptr, dev), _t(c.astype(np.int32), dev), _t(val, dev), _t(X, dev)
+    ref = K.spmm_csr(rp, cc, vv, Xd, act=K.ACT_RELU)
+    oref = cref.spmm_csr(rowptr, c.astype(np.int32), val, X, act=cref.ACT_RELU)
+    assert np.array_equal(ref.cpu().numpy(), oref)
+    yp = K.spmm_csr_panels(rp, cc, vv, Xd, x_panels=False, y_panels=True, act=K.ACT_RELU)           # row -> panel
+    back = yp.view(D // 32, n, 32).permute(1, 0, 2).reshape(n, D)
+    assert torch.equal(back, ref)
+    xp = Xd.view(n, D // 32, 32).permute(1, 0, 2).contiguous().view(n, D)                            # X as panels
+    assert torch.equal(K.spmm_csr_panels(rp, cc, vv, xp, x_panels=True, y_panels=False, act=K.ACT_RELU), ref)   # panel -> row
+    y2 = K.spmm_csr_panels(rp, cc, vv, xp, x_panels=True, y_panels=True, act=K.ACT_RELU)             # panel -> panel
+    assert torch.equal(y2.view(D // 32, n, 32).permute(1, 0, 2).reshape(n, D), ref)
+    # two hops through panels = two hops of the row kernel
+    two = K.spmm_csr_panels(rp, cc, vv, yp, x_panels=True, y_panels=False, act=K.ACT_RELU)
+    assert torch.equal(two, K.spmm_csr(rp, cc, vv, ref, act=K.ACT_RELU))
