@@ -38,11 +38,11 @@ namespace ragraph {
 
 constexpr int SMALL_MAX_B = 32;
 constexpr int SMALL_LIST_CAP = 4096;     // exact (score, key) pairs per query in the workspace
-constexpr int SMALL_PARTS_MAX = 64;      // parts of the bound prefix (one per lane of the selecting wave)
+constexpr int SMALL_PARTS_MAX = 256;     // parts of the bound prefix: ONE PER WORKGROUP that has bound units (four per lane of the selecting wave)
 constexpr int SMALL_WG_LIST = 1024;      // exact pairs a workgroup collects in LDS before its one reservation per query
 constexpr int SMALL_PAIRBUF = 512;       // (key, query) pairs a wave expands at a time
-// state buffer (ints; ZERO before the first call, left zero by every call): [0] workgroups past their bound units,
-// [1] workgroups done, cnt[q] at 32 + 32 q (a 128-byte line each), part maxima [32][64] from 32 + 32 * 32
+// state buffer (ints; ZERO before the first call, left zero by every call): [1] workgroups done, cnt[q] at 32 + 32 q (a
+// 128-byte line each), part maxima [32][256] from 32 + 32 * 32
 constexpr int SMALL_STATE_CNT0 = 32;
 constexpr int SMALL_STATE_GMAX0 = SMALL_STATE_CNT0 + 32 * SMALL_MAX_B;
 constexpr int SMALL_STATE_INTS = SMALL_STATE_GMAX0 + SMALL_MAX_B * SMALL_PARTS_MAX;
@@ -59,7 +59,7 @@ struct SmallParams {
   int64_t N, idx_base;
   int B, k;
   int64_t bound_units;     // bound pass: units [0, bound_units) of the bf16 copy ...
-  int parts;               // ... in `parts` parts
+  int parts;               // ... dealt over the first `parts` workgroups (= the parts of the bound)
   int64_t nunits;          // filter pass: units of the copy it streams
   unsigned wait_ticks;     // 10 ns ticks a workgroup waits for the others' bound units at most
   int* state;
@@ -213,8 +213,12 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   }
   // (the copies' error rows: requested now, used by the thresholds)
   const unsigned tail_b = *p.max_kerr2, tail_8e = I8 ? p.tail8[0] : 0u, tail_8s = I8 ? p.tail8[1] : 0u;
-  // this wave's first unit of the bound pass: its loads need no query -- in flight during the prepare phase
-  const int64_t u_first = (int64_t)blockIdx.x * 8 + wave;
+  // The bound pass's units are dealt over the first G_b workgroups -- at least 64 of them when there are that many units
+  // (parts = workgroups: the bound wants >= 4 k of them), one unit per wave before a workgroup takes a second round: unit u
+  // belongs to workgroup u % G_b, wave (u / G_b) % 8.  This wave's first unit: its loads need no query -- in flight during
+  // the prepare phase.
+  const int G_b = p.parts;
+  const int64_t u_first = (int)blockIdx.x < G_b ? (int64_t)blockIdx.x + (int64_t)G_b * wave : p.bound_units;
   if (u_first < p.bound_units) RG_SLOAD(A0, p.Kb, u_first);
 
   // ---- 0. prepare: one wave per query row (filter_prep_kernel's arithmetic) ----------------------------------------
@@ -291,26 +295,17 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
       bqb[gq * GB::KS + t] = gq < ngq ? o : bf16x8{};
     }
 
-  // ---- 1. bound: units 8 b + w (+ 8 G i) of the prefix belong to wave w of workgroup b -- neighbouring units, mostly one
-  // part: the workgroup combines its waves' maxima in LDS and publishes ONE atomicMax per query and part (agent-scope
-  // atomics execute at the memory side of the fabric: ~50 of them on one word, as when every wave published its own,
-  // took 10 us of a 16-query call) ----------------------------------------------------------------------------------
+  // ---- 1. bound: units 8 b + w (+ 8 G i) of the prefix belong to wave w of workgroup b, and workgroup b's units ARE part b:
+  // its waves' maxima are combined in LDS and leave as ONE relaxed agent-scope store per query (written through, visible
+  // to every XCD; non-zero = published).  No atomic, no counter, no wait on the publishing side: a reader that finds all
+  // parts non-zero has the final maxima in the same round trip.  (The first version published by atomicMax, announced
+  // itself on a counter after waiting for its atomics, and read the maxima after the counter filled: five agent-scope
+  // round trips of 2 - 3 us each between a workgroup's bound unit and its thresholds; now two.) ------------------------
   {
-    float* wmax = tile_all;                                       // [8][32] the wave's running maxima of its current part
-    int* wpart = reinterpret_cast<int*>(tile_all + 8 * 32);       // [8] that part (-1: none)
-    int cur_part = -1;  // wave-uniform
+    float* wmax = tile_all;                                       // [8][32] the wave's maxima over its units
     if (lane < 32) wmax[wave * 32 + lane] = RG_NEG_INF;
-    for (int64_t u = u_first; u < p.bound_units; u += (int64_t)G * 8) {
+    for (int64_t u = u_first; u < p.bound_units; u += (int64_t)G_b * 8) {
       if (u != u_first) RG_SLOAD(A0, p.Kb, u);                    // (the first unit's loads were issued before the prepare phase)
-      const int part = (int)(u * p.parts / p.bound_units);         // (parts <= units: a unit lies in one part)
-      if (part != cur_part) {
-        if (cur_part >= 0 && lane < B) {                           // (rare: a wave with units in several parts publishes the old one itself)
-          const float v = wmax[wave * 32 + lane];
-          if (v > RG_NEG_INF) atomicMax(gmax_g + lane * SMALL_PARTS_MAX + cur_part, small_f2u(v));
-          wmax[wave * 32 + lane] = RG_NEG_INF;
-        }
-        cur_part = part;
-      }
 #pragma unroll
       for (int sub = 0; sub < GB::SUBS; ++sub) {
 #pragma unroll
@@ -334,27 +329,14 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
         }
       }
     }
-    if (lane == 0) wpart[wave] = cur_part;
     __syncthreads();
-    if (tid < B) {  // runs of waves in one part leave as one atomic
-      float m = RG_NEG_INF;
-      int part = -1;
-      for (int w = 0; w < 8; ++w) {
-        const int pw = wpart[w];
-        if (pw < 0) continue;
-        if (pw != part) {
-          if (part >= 0 && m > RG_NEG_INF) atomicMax(gmax_g + tid * SMALL_PARTS_MAX + part, small_f2u(m));
-          part = pw;
-          m = RG_NEG_INF;
-        }
-        m = fmaxf(m, wmax[w * 32 + tid]);
-      }
-      if (part >= 0 && m > RG_NEG_INF) atomicMax(gmax_g + tid * SMALL_PARTS_MAX + part, small_f2u(m));
+    if (tid < B && (int)blockIdx.x < G_b) {
+      float m = wmax[tid];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) m = fmaxf(m, wmax[w * 32 + tid]);
+      __hip_atomic_store(gmax_g + tid * SMALL_PARTS_MAX + blockIdx.x, small_f2u(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  // (the part maxima are agent-scope atomics: performed once they are acknowledged -- no cache write-back is needed to
-  // publish them, only this wait before the workgroup announces itself)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   RG_SSTAMP(2);
   // the filter pass's B operands
   i32x4 bq8[I8 ? 2 * GF::KS : 1];
@@ -385,46 +367,47 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   const char* fbase = I8 ? reinterpret_cast<const char*>(p.Kb8) : reinterpret_cast<const char*>(p.Kb);
   if (n_mine > 0) RG_SLOAD(A0, fbase, gw);
 
-  // ---- 2. announce the bound units, wait (bounded), thresholds ------------------------------------------------------
-  __syncthreads();
+  // ---- 2. thresholds from the published part maxima, after a BOUNDED wait for the missing ones -----------------------------
+  // Cross-workgroup traffic of this kernel is agent-scope ATOMICS only (relaxed atomic stores / loads, which go past the
+  // XCD's L2, and read-modify-writes for list space and the ticket): a __threadfence() would write the whole L2 back
+  // (buffer_wbl2: 10 - 30 us with 256 workgroups at it -- measured: it was most of a 175-us first version).
   RG_SSTAMP(3);
-  // Cross-workgroup traffic of this kernel is agent-scope ATOMICS only (read-modify-writes, and relaxed atomic loads /
-  // stores, which go past the XCD's L2): a __threadfence() would write the whole L2 back (buffer_wbl2: 10 - 30 us with 256
-  // workgroups at it -- measured: it was most of a 175-us first version); ordering comes from s_waitcnt vmcnt(0) before
-  // the barrier that precedes a workgroup's announcement.
-  // (only the workgroups that HAVE bound units announce themselves -- the first G_b = ceil(units / 8) of the grid, which the
-  // dispatcher starts first: a workgroup that starts late and has none delays nobody)
-  const int G_b = (int)(((p.bound_units + 7) / 8) < G ? (p.bound_units + 7) / 8 : G);
-  if (tid == 0) {
-    if ((int)blockIdx.x < G_b) __hip_atomic_fetch_add(p.state, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long t0 = wall_clock64();
-    int in = __hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (in < G_b && (unsigned)(wall_clock64() - t0) < p.wait_ticks) {
-      __builtin_amdgcn_s_sleep(1);
-      in = __hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    misc[1] = in >= G_b;
-  }
-  __syncthreads();
   RG_SSTAMP(4);
   const float ek_b = sqrtf(__uint_as_float(tail_b));
   const float ek_8 = I8 ? sqrtf(__uint_as_float(tail_8e)) : 0.f;
   const float sk_8 = I8 ? __uint_as_float(tail_8s) : 0.f;
   // threshold of query q from the part maxima published so far (one wave; every lane returns with thr_lds[q] written)
-  auto load_part = [&](int q) -> unsigned {  // this lane's part maximum of query q as published so far (0: nothing yet)
-    return (q < B && lane < p.parts) ? __hip_atomic_load(gmax_g + q * SMALL_PARTS_MAX + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  // this lane's parts of query q as published so far: parts lane, lane + 64, ... (0: nothing yet); the largest of them is the
+  // maximum of a coarser part (64 of them: one per lane); *missing = some part of this lane is still unpublished
+  auto load_part = [&](int q, bool* missing) -> unsigned {
+    unsigned u = 0u;
+    bool miss = false;
+    if (q < B) {
+      unsigned w4[4];
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4)
+        w4[c4] = lane + 64 * c4 < G_b ? __hip_atomic_load(gmax_g + q * SMALL_PARTS_MAX + lane + 64 * c4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        miss = miss || w4[c4] == 0u;
+        if (lane + 64 * c4 < G_b) u = w4[c4] > u ? w4[c4] : u;
+      }
+    }
+    *missing = miss;
+    return u;
   };
+  const int nparts = G_b < 64 ? G_b : 64;
   auto make_threshold = [&](int q, unsigned u) {
     const float e = sc_eqb[q];
     const float eps_b = fmaf(fmaf(e, ek_b, e + ek_b), 1.0009765625f, FILTER_EPS_SLACK);
     float v = RG_NEG_INF;
     if (u != 0u) v = __fsub_rn(small_u2f(u), eps_b);
     int rank = 0;
-    for (int o = 0; o < p.parts; ++o) {  // (o is wave-uniform: v_readlane, not a ds_bpermute round trip per part)
+    for (int o = 0; o < nparts; ++o) {  // (o is wave-uniform: v_readlane, not a ds_bpermute round trip per part)
       const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), o));
       rank += (x > v || (x == v && o < lane)) ? 1 : 0;
     }
-    const unsigned long long kth = __ballot(lane < p.parts && rank == k - 1);
+    const unsigned long long kth = __ballot(lane < nparts && rank == k - 1);
     const float theta = kth ? __shfl(v, __ffsll((long long)kth) - 1) : RG_NEG_INF;
     if (lane == 0) {
       theta_lds[q] = fmaxf(theta_lds[q], theta);
@@ -456,17 +439,26 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
     theta_lds[tid] = RG_NEG_INF;
   }
   __syncthreads();
-  {  // a wave's queries: wave, wave + 8, ... -- all their part maxima are requested before the first is used
+  {  // a wave's queries: wave, wave + 8, ... -- all their part maxima are requested in one batch, again until none is missing
+     // or the time limit has passed (workgroups of another process may hold the CUs some of ours still need)
     unsigned up[4];
+    const unsigned long long t0 = wall_clock64();
+    bool missing = true;
+    while (missing) {
+      bool mc[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) up[c] = load_part(wave + 8 * c);
+      for (int c = 0; c < 4; ++c) up[c] = load_part(wave + 8 * c, &mc[c]);
+      missing = __any(mc[0] || mc[1] || mc[2] || mc[3]);
+      if (missing && (unsigned)(wall_clock64() - t0) >= p.wait_ticks) break;
+    }
+    if (missing && lane == 0) atomicOr(misc + 1, 1);   // somebody moved on early: wave 0 refreshes while it streams
 #pragma unroll
     for (int c = 0; c < 4; ++c)
       if (wave + 8 * c < B) make_threshold(wave + 8 * c, up[c]);
   }
   __syncthreads();
   RG_SSTAMP(5);
-  bool refresh = wave == 0 && misc[1] == 0;   // (wave-uniform) some workgroup's bound units were still missing
+  bool refresh = wave == 0 && misc[1] != 0;   // (wave-uniform) some workgroup's bound units were still missing
 
   // ---- 3. filter pass ---------------------------------------------------------------------------------------------
   uint2* wbuf = wbuf_all + wave * L::CAND_BUF;
@@ -595,9 +587,14 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
       if (i + 2 < n_mine) RG_SLOAD(A0, fbase, gw + (i + 2) * W);
       process(A1, gw + (i + 1) * W);
       if (refresh && (i & 30) == 30) {   // (wave 0 of a workgroup that moved on early) the others' maxima may have arrived
-        const bool all_in = __hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= G_b;
-        for (int q = 0; q < B; ++q) make_threshold(q, load_part(q));
-        refresh = !all_in;
+        bool any_missing = false;
+        for (int q = 0; q < B; ++q) {
+          bool mq;
+          const unsigned uq = load_part(q, &mq);
+          any_missing = any_missing || __any(mq);
+          make_threshold(q, uq);
+        }
+        refresh = any_missing;
       }
     }
     if (i < n_mine) process(A0, gw + i * W);  // odd count: the last unit, nothing behind it
@@ -982,10 +979,9 @@ extern "C" int ragraph_topk_cosine_small_f32(const float* Q, int64_t B, const fl
   int64_t prefix = small_prefix_keys((int)B, i8);
   if (prefix > N / 4) prefix = N / 4;
   p.bound_units = prefix / unit_b;
-  int parts = 4 * k < SMALL_PARTS_MAX ? 4 * k : SMALL_PARTS_MAX;
-  if (parts > p.bound_units) parts = (int)p.bound_units;   // (a unit lies in one part)
-  RG_REQUIRE(parts >= k, RAGRAPH_EUNSUPPORTED, "topk_cosine_small: the bank is too short for a bound pass of k = %d parts", k);
-  p.parts = parts;
+  // (parts = the workgroups the units are dealt over, min(units, 64 .. grid): at least k of them)
+  RG_REQUIRE(p.bound_units >= 2 * k, RAGRAPH_EUNSUPPORTED, "topk_cosine_small: the bank is too short for a bound pass of k = %d parts", k);
+  p.parts = 0;   // (set below, once the grid is known)
   p.nunits = cdiv(N, (int64_t)unit_f);   // (the copies are padded to whole units: 256 keys)
   p.wait_ticks = wait_ticks;
   p.state = state;
@@ -997,6 +993,11 @@ extern "C" int ragraph_topk_cosine_small_f32(const float* Q, int64_t B, const fl
   const int cus = device_cus_multiple_of_8();
   int64_t grid = cdiv(p.nunits, (int64_t)8);
   if (grid > cus) grid = cus;
+  {
+    int64_t gb = p.bound_units < 64 ? p.bound_units : (cdiv(p.bound_units, (int64_t)8) < 64 ? (int64_t)64 : cdiv(p.bound_units, (int64_t)8));
+    p.parts = (int)(gb < grid ? gb : grid);
+  }
+  RG_REQUIRE(p.parts >= k, RAGRAPH_EUNSUPPORTED, "topk_cosine_small: %d workgroups cannot make a bound of k = %d parts", p.parts, k);
   hipStream_t st = as_stream(stream);
   if (D == 256) return i8 ? launch_small<256, true>(p, (int)grid, st) : launch_small<256, false>(p, (int)grid, st);
   if (D == 128) return i8 ? launch_small<128, true>(p, (int)grid, st) : launch_small<128, false>(p, (int)grid, st);
