@@ -128,7 +128,7 @@ size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_t N, int D,
  * ragraph_topk_cosine_filtered_stats_offset(ws_bytes) of the workspace AS PASSED to the call (its last bytes), written by the
  * call's own launches: [0] 0x52414753, [1] levels, [2+l] sum of the candidate counts of every 64th query at level l (l < 3),
  * [5+l] how many queries that sum covers, [8+l] 1 if level l ran on the int8 copy, [11+l] keys of level l, [14] queries of
- * the call.  sum / queries = candidates per query: what a level's rescoring costs.  The owner of a bank reads them back
+ * the call, [15] all-zero queries among them (answered without a scan; the overflow count may or may not include them).  sum / queries = candidates per query: what a level's rescoring costs.  The owner of a bank reads them back
  * asynchronously (ragraph_amd/kernels_index.py: a bank whose int8 levels pass hundreds of candidates per query without
  * overflowing is slower on int8 than on bf16 -- the overflow count alone would never show it). */
 size_t ragraph_topk_cosine_filtered_stats_offset(size_t ws_bytes);

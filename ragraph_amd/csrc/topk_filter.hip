@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(256) keys_to_i8_kernel(const float* __restrict
 // mean the owner of the bank reads back asynchronously (ragraph_amd/kernels_index.py: a bank whose int8 levels pass hundreds
 // of candidates per query WITHOUT overflowing is slower on int8 than on bf16, and nothing else would notice).
 // Layout: [0] magic, [1] levels, [2 + l] sampled candidates of level l, [5 + l] sampled queries, [8 + l] level l ran on
-// int8, [11 + l] keys of level l, [14] queries of the call.
+// int8, [11 + l] keys of level l, [14] queries of the call, [15] zero queries among them.
 constexpr int FILTER_STATS_INTS = 16;
 constexpr int FILTER_STATS_MAGIC = 0x52414753;
 __device__ __forceinline__ void note_candidates(int* cstat, int64_t b, int n) {
@@ -300,6 +300,8 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
     // is flagged as overflowed from the start (nothing passes the filter for a flagged query: FilterThr::flag) and the
     // final level's scan path answers it without scanning (zero_query_answer)
     flag[q] = am == 0u ? 2 : 0;  // (2: a zero query -- the one-wave rescoring kernels answer it at the final level, uncounted)
+    if (am == 0u && stats) atomicAdd(stats + 15, 1);  // (zero queries of the call: some kernels count them as overflowed, the owner of
+                                                      // the bank subtracts them before it judges the bank)
     if (eq8) {
       eq8[q] = sqrtf(e8) * 1.000001f;
       qscale[q] = sq;

@@ -345,6 +345,10 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
     for (int gq = 0; gq < 2; ++gq)
 #pragma unroll
       for (int t = 0; t < GF::KS; ++t) {  // elements 64 t + 16 g .. + 15 of query 16 gq + j
+        if (gq >= ngq) {  // (block-uniform: up to 16 queries have no second group to build)
+          bq8[gq * GF::KS + t] = i32x4{0, 0, 0, 0};
+          continue;
+        }
         const int q = 16 * gq + j;
         const float* src = qn + q * QLD + 64 * t + 16 * g;
         const float sq = sc_qs[q];

@@ -106,6 +106,8 @@ class KeyIndex:
         if not pend[1].query():
             return
         n_over, B = int(pend[0][0]), pend[2]
+        if pend[0].numel() > 16 and int(pend[0][1]) == 0x52414753:
+            n_over = max(0, n_over - int(pend[0][16]))   # (all-zero queries: answered without a scan, not the bank's fault)
         self._pending = None
         self._overflowed += n_over
         i8_was_off = self._i8_off               # (the call ran under this setting: the overflow rule below judges IT)
@@ -199,7 +201,7 @@ class KeyIndex:
             fhelps = None  # (fp32 kernels: the shard's own exact top-k, no exchange needed)
         self._poll_overflow()
         fused = getattr(ops, "fused_helps", None)
-        if fused is not None and fused(B, kn.shape[0], D, k):  # small bank: every phase in one launch
+        if fused is not None and not self._filter_off and fused(B, kn.shape[0], D, k):  # small bank: every phase in one launch
             if self._bf16 is None:
                 self._bf16 = ops.keys_to_bf16(kn)
             return ops.topk_cosine_fused(q, kn, self._bf16, k, idx_base=idx_base)

@@ -67,6 +67,13 @@ class GCN(nn.Module):
         torch.nn.init.xavier_uniform_(self.fc.weight.data)  # layers/gcn.py:18-24
         self._alpha_cache = (None, 0.25)
         self._wt_cache = (None, None)
+        # (the caches follow the parameters' version counters; a checkpoint load starts them over -- writes through `.data`
+        # bypass the counters: assign parameters with copy_() / load_state_dict)
+        self._register_load_state_dict_pre_hook(lambda *a, **kw: self._drop_caches())
+
+    def _drop_caches(self):
+        self._alpha_cache = (None, 0.25)
+        self._wt_cache = (None, None)
 
     def _alpha(self) -> float:
         """PReLU slope as a host scalar (a kernel argument), re-read only when the parameter changes."""
