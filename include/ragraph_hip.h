@@ -333,6 +333,15 @@ int ragraph_spmm_csr_ws_f32(const int64_t* rowptr, const int32_t* col, const flo
                             const float* bias, int act, float alpha, float beta, const float* Y_in, float* Y, int64_t nnz,
                             void* ws, size_t ws_bytes, void* stream);
 
+/* Integer bookkeeping primitives of ingestion (edge list -> CSR) and of the duplicate grouping: a stable LSD radix sort of
+ * 64-bit keys by their low `bits` bits (8 bits per pass) with optional 4- or 8-byte values, and int32 prefix sums (totals
+ * below 2^31).  Own kernels (csrc/sortscan.hip); exported for the tests.  Inputs are left as they are. */
+size_t ragraph_radix_sort_workspace_bytes(int64_t n, int val_bytes);
+int ragraph_radix_sort_u64(const uint64_t* keys_in, uint64_t* keys_out, const void* vals_in, void* vals_out, int val_bytes,
+                           int64_t n, int bits, void* ws, size_t ws_bytes, void* stream);
+size_t ragraph_scan_workspace_bytes(int64_t n);
+int ragraph_scan_sum_i32(const int* in, int* out, int64_t n, int inclusive, void* ws, size_t ws_bytes, void* stream);
+
 /* a7, several hops  -- Propagation.py:19-25 with the features PANEL-major between the hops: [D / 32][n][32] floats (a row's
  * 32-column blocks, one 128-byte line each).  The column-panel hop gives every XCD one panel (D = 256): the rows it gathers
  * from are n x 128 bytes instead of n x 1 KiB, a third of which fit its L2 on a graph without locality (c2: L2 hit rate 15 ->

@@ -8,7 +8,7 @@
 // "every key within eps of the k-th best" keeps whole groups of such rows (hundreds of thousands of candidates); scoring
 // one representative per group and expanding the winners is the same result for a fraction of the work.
 //
-//   ragraph_dedup_rows_f32         groups the BIT-identical rows of Kn (64-bit row hash -> stable radix sort of (hash, row)
+//   ragraph_dedup_rows_f32         groups the BIT-identical rows of Kn (64-bit row hash -> stable radix sort of (hash, row) (csrc/sortscan.hip)
 //                                  -> neighbours compared bit by bit, so a hash collision only splits a group, never
 //                                  merges two), numbers the groups by their lowest row (ascending) and lists every
 //                                  group's rows in ascending order
@@ -20,8 +20,7 @@
 //                                  k-th listed group, and when it ties with listed groups those have lower
 //                                  representatives -- at least as many rows below every row of the unlisted group as
 //                                  the tie can still place.
-#include "common.h"
-#include <hipcub/hipcub.hpp>
+#include "sortscan.h"
 
 namespace ragraph {
 
@@ -138,12 +137,8 @@ static size_t dedup_carve(char* w, int64_t N, DedupWs* out) {
   int32_t** const arrays[] = {&f.iota, &f.perm, &f.flag, &f.gid1, &f.gstart, &f.grep, &f.isrep, &f.repscan};
   for (int32_t** a : arrays) *a = reinterpret_cast<int32_t*>(take((size_t)N * 4));
   f.cnt = reinterpret_cast<int32_t*>(take((size_t)(N + 1) * 4));
-  size_t t1 = 0, t2 = 0, t3 = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t1, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int32_t*)nullptr,
-                                           (int32_t*)nullptr, (int)N, 0, 64, (hipStream_t)0);
-  (void)hipcub::DeviceScan::InclusiveSum(nullptr, t2, (const int32_t*)nullptr, (int32_t*)nullptr, (int)N, (hipStream_t)0);
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t3, (const int32_t*)nullptr, (int32_t*)nullptr, (int)N + 1, (hipStream_t)0);
-  f.temp_bytes = t1 > t2 ? (t1 > t3 ? t1 : t3) : (t2 > t3 ? t2 : t3);
+  const size_t t1 = radix_sort_temp_bytes(N, 4), t2 = scan_temp_bytes(N + 1);
+  f.temp_bytes = t1 > t2 ? t1 : t2;
   f.temp = take(f.temp_bytes + 256);
   if (out) *out = f;
   return off;
@@ -244,21 +239,21 @@ extern "C" int ragraph_dedup_rows_f32(const float* Kn, int64_t N, int D, int64_t
   const uint32_t* X = reinterpret_cast<const uint32_t*>(Kn);
   const unsigned gw = (unsigned)cdiv(N, 4), gt = (unsigned)cdiv(N, 256);
   hipLaunchKernelGGL(row_hash_kernel, dim3(gw), dim3(256), 0, st, X, N, D, f.hash_a, f.iota);
-  size_t tb = f.temp_bytes;
-  // (radix sort is stable: rows of one hash stay in ascending order, so a group's first row is its lowest)
-  RG_HIPCUB(hipcub::DeviceRadixSort::SortPairs(f.temp, tb, f.hash_a, f.hash_b, f.iota, f.perm, (int)N, 0, 64, st), "dedup_rows(sort)");
+  // (the radix sort is stable: rows of one hash stay in ascending order, so a group's first row is its lowest)
+  int rc = radix_sort_u64(f.hash_a, f.hash_b, f.iota, f.perm, 4, N, 64, f.temp, f.temp_bytes, st);
+  if (rc != RAGRAPH_OK) return rc;
   hipLaunchKernelGGL(dedup_flags_kernel, dim3(gw), dim3(256), 0, st, X, N, D, f.hash_b, f.perm, f.flag);
-  tb = f.temp_bytes;
-  RG_HIPCUB(hipcub::DeviceScan::InclusiveSum(f.temp, tb, f.flag, f.gid1, (int)N, st), "dedup_rows(scan groups)");
+  rc = scan_sum_i32(f.flag, f.gid1, N, true, f.temp, f.temp_bytes, st);
+  if (rc != RAGRAPH_OK) return rc;
   RG_HIPCUB(hipMemsetAsync(f.isrep, 0, (size_t)N * 4, st), "dedup_rows(memset)");
   RG_HIPCUB(hipMemsetAsync(f.cnt, 0, (size_t)(N + 1) * 4, st), "dedup_rows(memset)");
   RG_HIPCUB(hipMemsetAsync(stats, 0, 16, st), "dedup_rows(memset)");
   hipLaunchKernelGGL(dedup_heads_kernel, dim3(gt), dim3(256), 0, st, f.flag, f.gid1, f.perm, N, f.gstart, f.grep, f.isrep);
-  tb = f.temp_bytes;
-  RG_HIPCUB(hipcub::DeviceScan::ExclusiveSum(f.temp, tb, f.isrep, f.repscan, (int)N, st), "dedup_rows(scan representatives)");
+  rc = scan_sum_i32(f.isrep, f.repscan, N, false, f.temp, f.temp_bytes, st);
+  if (rc != RAGRAPH_OK) return rc;
   hipLaunchKernelGGL(dedup_counts_kernel, dim3(gt), dim3(256), 0, st, f.gid1, f.gstart, f.grep, f.repscan, N, f.cnt, uniq_row, stats);
-  tb = f.temp_bytes;
-  RG_HIPCUB(hipcub::DeviceScan::ExclusiveSum(f.temp, tb, f.cnt, group_ptr, (int)N + 1, st), "dedup_rows(scan counts)");
+  rc = scan_sum_i32(f.cnt, group_ptr, N + 1, false, f.temp, f.temp_bytes, st);
+  if (rc != RAGRAPH_OK) return rc;
   hipLaunchKernelGGL(dedup_members_kernel, dim3(gt), dim3(256), 0, st, f.gid1, f.gstart, f.grep, f.repscan, f.perm, group_ptr, N,
                      members);
   RG_CHECK_LAUNCH("dedup_rows");

@@ -10,11 +10,10 @@
 //
 // The reference builds both on the host (a numpy row_stack loop that densifies the block-diagonal adjacency -- quadratic
 // in the batch's node count and the reason a 100k-node graph cannot be ingested at all -- and Python loops over every
-// edge).  Here: 64-bit keys, device radix sort (rocPRIM through hipCUB: integer bookkeeping), run-length heads, a prefix
+// edge).  Here: 64-bit keys, the library's own stable radix sort and prefix sums (csrc/sortscan.hip), run-length heads, a prefix
 // sum, and kernels that count multiplicities, accumulate integer degrees (exact whatever the atomic order) and emit the
 // normalised values in double precision cast to fp32 last -- as scipy (float64) followed by torch.FloatTensor does.
-#include "common.h"
-#include <hipcub/hipcub.hpp>
+#include "sortscan.h"
 
 namespace ragraph {
 
@@ -159,12 +158,8 @@ static size_t ingest_carve(char* w, int64_t M, int64_t n, IngestWs* out) {
   f.slot = reinterpret_cast<int*>(take((size_t)M * 4));
   f.cnt = reinterpret_cast<unsigned*>(take((size_t)M * 4));
   f.deg = reinterpret_cast<unsigned*>(take((size_t)n * 4));
-  size_t t1 = 0, t2 = 0, t3 = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t1, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int64_t*)nullptr,
-                                           (int64_t*)nullptr, (int)M, 0, 64, (hipStream_t)0);
-  (void)hipcub::DeviceRadixSort::SortKeys(nullptr, t2, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)M, 0, 64, (hipStream_t)0);
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t3, (const int*)nullptr, (int*)nullptr, (int)M, (hipStream_t)0);
-  f.temp_bytes = t1 > t2 ? (t1 > t3 ? t1 : t3) : (t2 > t3 ? t2 : t3);
+  const size_t t1 = radix_sort_temp_bytes(M, 8), t3 = scan_temp_bytes(M);
+  f.temp_bytes = t1 > t3 ? t1 : t3;
   f.temp = take(f.temp_bytes + 256);
   if (out) *out = f;
   return off;
@@ -203,12 +198,11 @@ extern "C" int ragraph_csr_sym_normalized_f32(const int64_t* row, const int64_t*
   const unsigned g = (unsigned)cdiv(M, 256);
   RG_HIPCUB(hipMemsetAsync(f.deg, 0, (size_t)n * 4, st), "csr_sym_normalized(memset)");
   hipLaunchKernelGGL(sym_keys_kernel, dim3(g), dim3(256), 0, st, row, col, E, n, f.keys_a);
-  size_t tb = f.temp_bytes;
-  RG_HIPCUB(hipcub::DeviceRadixSort::SortKeys(f.temp, tb, f.keys_a, f.keys_b, (int)M, 0, key_bits((uint64_t)n * (uint64_t)n), st),
-            "csr_sym_normalized(sort)");
+  int rc = radix_sort_u64(f.keys_a, f.keys_b, nullptr, nullptr, 0, M, key_bits((uint64_t)n * (uint64_t)n), f.temp, f.temp_bytes, st);
+  if (rc != RAGRAPH_OK) return rc;
   hipLaunchKernelGGL(run_flags_kernel<false>, dim3(g), dim3(256), 0, st, f.keys_b, M, f.flag);
-  tb = f.temp_bytes;
-  RG_HIPCUB(hipcub::DeviceScan::ExclusiveSum(f.temp, tb, f.flag, f.slot, (int)M, st), "csr_sym_normalized(scan)");
+  rc = scan_sum_i32(f.flag, f.slot, M, false, f.temp, f.temp_bytes, st);
+  if (rc != RAGRAPH_OK) return rc;
   hipLaunchKernelGGL(run_positions_kernel, dim3(g), dim3(256), 0, st, f.flag, f.slot, M, f.pos, nnz);
   hipLaunchKernelGGL(sym_entries_kernel, dim3(g), dim3(256), 0, st, f.keys_b, f.pos, nnz, n, rowptr, out_col, f.cnt, f.deg);
   hipLaunchKernelGGL(sym_values_kernel, dim3(g), dim3(256), 0, st, f.keys_b, f.pos, nnz, n, f.cnt, f.deg, out_val);
@@ -230,23 +224,22 @@ extern "C" int ragraph_binorm_edges_f32(const int64_t* users, const int64_t* ite
   const unsigned gE = (unsigned)cdiv(E, 256), gM = (unsigned)cdiv(M, 256);
   RG_HIPCUB(hipMemsetAsync(f.deg, 0, (size_t)n * 4, st), "binorm_edges(memset)");
   hipLaunchKernelGGL(pair_keys_kernel, dim3(gE), dim3(256), 0, st, users, items, E, num_items, f.keys_a, f.vals_a);
-  size_t tb = f.temp_bytes;
-  // (radix sort is stable: among equal (user, item) pairs the original order survives, so a run's last element is the
+  // (the radix sort is stable: among equal (user, item) pairs the original order survives, so a run's last element is the
   // pair's last occurrence)
-  RG_HIPCUB(hipcub::DeviceRadixSort::SortPairs(f.temp, tb, f.keys_a, f.keys_b, f.vals_a, f.vals_b, (int)E, 0,
-                                               key_bits((uint64_t)num_users * (uint64_t)num_items), st), "binorm_edges(sort pairs)");
+  int rc = radix_sort_u64(f.keys_a, f.keys_b, f.vals_a, f.vals_b, 8, E, key_bits((uint64_t)num_users * (uint64_t)num_items), f.temp,
+                          f.temp_bytes, st);
+  if (rc != RAGRAPH_OK) return rc;
   hipLaunchKernelGGL(run_flags_kernel<true>, dim3(gE), dim3(256), 0, st, f.keys_b, E, f.flag);
-  tb = f.temp_bytes;
-  RG_HIPCUB(hipcub::DeviceScan::ExclusiveSum(f.temp, tb, f.flag, f.slot, (int)E, st), "binorm_edges(scan)");
+  rc = scan_sum_i32(f.flag, f.slot, E, false, f.temp, f.temp_bytes, st);
+  if (rc != RAGRAPH_OK) return rc;
   hipLaunchKernelGGL(run_positions_kernel, dim3(gE), dim3(256), 0, st, f.flag, f.slot, E, f.pos, f.count);
   // directed edges keyed by (dst, src); keys_a / vals_a are free again
   RG_HIPCUB(hipMemsetAsync(f.keys_a, 0xFF, (size_t)M * 8, st), "binorm_edges(memset keys)");  // unused tail sorts last
   hipLaunchKernelGGL(pair_edges_kernel, dim3(gE), dim3(256), 0, st, f.keys_b, f.vals_b, f.pos, f.count, step, num_users, num_items,
                      f.keys_a, f.vals_a, f.deg);
   // (vals_a beyond 2 * npairs is garbage paired with 0xFF.. keys: sorted behind every real edge)
-  tb = f.temp_bytes;
-  RG_HIPCUB(hipcub::DeviceRadixSort::SortPairs(f.temp, tb, f.keys_a, f.keys_b, f.vals_a, f.vals_b, (int)M, 0, 64, st),
-            "binorm_edges(sort edges)");
+  rc = radix_sort_u64(f.keys_a, f.keys_b, f.vals_a, f.vals_b, 8, M, 64, f.temp, f.temp_bytes, st);
+  if (rc != RAGRAPH_OK) return rc;
   hipLaunchKernelGGL(pair_emit_kernel, dim3(gM), dim3(256), 0, st, f.keys_b, f.vals_b, f.count, n, f.deg, edges, norm, times,
                      nedges);
   RG_CHECK_LAUNCH("binorm_edges");

@@ -70,3 +70,45 @@ def test_ingestion_kernels_match_host_restatement_at_scale(dev):
     e, nm, t = K.binorm_edges(torch.from_numpy(u).to(dev), torch.from_numpy(i).to(dev), torch.from_numpy(step).to(dev), U, I)
     assert np.array_equal(e.cpu().numpy(), e_ref) and np.array_equal(t.cpu().numpy(), t_ref)
     assert np.array_equal(nm.cpu().numpy(), n_ref)
+
+
+@pytest.mark.parametrize("n,bits,val_bytes", [(1, 64, 4), (255, 8, 0), (2049, 17, 8), (100_000, 40, 4), (1_000_003, 64, 8), (4097, 64, 0)])
+def test_radix_sort_and_scan_match_numpy(dev, n, bits, val_bytes):
+    """The library's own stable radix sort (64-bit keys, low `bits` bits, optional 4- / 8-byte values) and prefix sums
+    (csrc/sortscan.hip: what ingestion and the duplicate grouping of a bank are built on) against numpy's stable argsort and
+    cumsum; inputs untouched; keys drawn from few values so that stability is what is tested."""
+    import ctypes
+
+    import numpy as np
+    import torch
+
+    from ragraph_amd import kernels as K
+
+    L = K._ready()
+    rng = np.random.default_rng(n + bits)
+    keys = rng.integers(0, 2 ** 63, n, dtype=np.uint64) >> np.uint64(rng.integers(0, 50))
+    keys[rng.random(n) < 0.5] = keys[0]                       # many ties
+    mask = np.uint64((1 << bits) - 1) if bits < 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    order = np.argsort(keys & mask, kind="stable")
+    kd = torch.from_numpy(keys.view(np.int64)).to(dev)
+    ko = torch.empty_like(kd)
+    vals = np.arange(n, dtype=np.int64 if val_bytes == 8 else np.int32)
+    vd = torch.from_numpy(vals).to(dev) if val_bytes else None
+    vo = torch.empty_like(vd) if val_bytes else None
+    ws = torch.empty(L.ragraph_radix_sort_workspace_bytes(n, val_bytes), dtype=torch.uint8, device=dev)
+    K.N.check(L.ragraph_radix_sort_u64(kd.data_ptr(), ko.data_ptr(), vd.data_ptr() if val_bytes else None,
+                                       vo.data_ptr() if val_bytes else None, val_bytes, n, bits, ws.data_ptr(), ws.numel(), None), "radix_sort")
+    torch.cuda.synchronize()
+    assert np.array_equal(ko.cpu().numpy().view(np.uint64), keys[order])
+    assert np.array_equal(kd.cpu().numpy().view(np.uint64), keys)          # input untouched
+    if val_bytes:
+        assert np.array_equal(vo.cpu().numpy(), vals[order])
+    x = rng.integers(0, 7, n).astype(np.int32)
+    xd = torch.from_numpy(x).to(dev)
+    out = torch.empty_like(xd)
+    ws2 = torch.empty(L.ragraph_scan_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    for inclusive in (0, 1):
+        K.N.check(L.ragraph_scan_sum_i32(xd.data_ptr(), out.data_ptr(), n, inclusive, ws2.data_ptr(), ws2.numel(), None), "scan")
+        ref = np.cumsum(x, dtype=np.int64)
+        ref = ref if inclusive else ref - x
+        assert np.array_equal(out.cpu().numpy(), ref.astype(np.int32))
