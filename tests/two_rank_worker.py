@@ -7,7 +7,8 @@ ragraph_amd.sharded stages the collectives' device tensors through the host).  E
   * runs the KEY-sharded forward (RAGraph._forward_key_shard: its shard of the bank through
     ragraph_topk_cosine_filtered_sharded_f32 with the exchange callback issuing collectives between the call's
     launches, all_to_all of the lists, merge, query-sharded tail, all_gather of the outputs), the key-sharded
-    ShardedToyGraphBase.topk (all_gather + merge) and the QUERY-sharded forward,
+    ShardedToyGraphBase.topk (all_gather + merge), the QUERY-sharded forward, and 120 calls of the single-launch kernel for a
+    handful of queries while the other process does the same on the same GPU,
   * and reports whether each equals the single-process result bit for bit, plus the exchange phases it went through.
 Started by tests/conftest.py BEFORE the pytest process touches the GPU.   usage: two_rank_worker.py RANK WORLD PORT OUT
 """
@@ -79,6 +80,24 @@ def main():
             res["d64_detail"] = {"shapes": [list(got64_i.shape), list(want64_i.shape)], "dtypes": [str(got64_i.dtype), str(want64_i.dtype)],
                                  "rows_differ": int((got64_i != want64_i).any(dim=1).sum()) if got64_i.shape == want64_i.shape else -1,
                                  "scores_differ": int((got64_s != want64_s).any(dim=1).sum()) if got64_s.shape == want64_s.shape else -1}
+
+        # a handful of queries: the single-launch kernel (csrc/topk_small.hip) -- one workgroup per CU that WAITS (bounded) for
+        # the other workgroups' bound units -- with both processes launching it on the one GPU at the same time
+        dist.barrier()
+        small_ok, small_calls = True, 0
+        index = K.KeyIndex(Kb)
+        for rep in range(40):
+            for B in (1, 3, 16):
+                qq = h[(rep * 17 + B) % (n - 16):][:B].contiguous()
+                assert K.small_helps(B, N, D, k)
+                ss, ii = index.topk(qq, k)
+                s32, i32 = K.topk_cosine(qq, Kb, k)
+                small_ok = small_ok and bool(torch.equal(ii, i32) and torch.equal(ss, s32))
+                small_calls += 1
+        torch.cuda.synchronize()
+        res["small_launch_equal"] = small_ok
+        res["small_launch_calls"] = small_calls
+        res["small_launch_overflowed"] = int(index.overflowed_queries)
 
         model.toy_graph_base = single
         model.query_shard = QueryShard()
