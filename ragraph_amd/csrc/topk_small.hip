@@ -222,7 +222,11 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   if (u_first < p.bound_units) RG_SLOAD(A0, p.Kb, u_first);
 
   // ---- 0. prepare: one wave per query row (filter_prep_kernel's arithmetic) ----------------------------------------
-  if (tid < 32) qcnt[tid] = 0;
+  if (tid < 32) {
+    qcnt[tid] = 0;
+    thr_lds[tid] = I8 ? __int_as_float(tid < p.B ? INT_MIN : INT_MAX) : (tid < p.B ? RG_NEG_INF : __builtin_huge_valf());
+    theta_lds[tid] = RG_NEG_INF;
+  }
   if (tid < 4) misc[tid] = 0;
   constexpr int NCH = D / 4;
   float4 vrow[4];
@@ -370,6 +374,29 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   const int64_t n_mine = gw < p.nunits ? (p.nunits - gw + W - 1) / W : 0;
   const char* fbase = I8 ? reinterpret_cast<const char*>(p.Kb8) : reinterpret_cast<const char*>(p.Kb);
   if (n_mine > 0) RG_SLOAD(A0, fbase, gw);
+  // Up to 16 queries (one MFMA query group): the first TWO units of the stream are multiplied right here, while the other
+  // workgroups' part maxima are still on their way -- their accumulators wait in registers for the thresholds, their
+  // epilogues run behind phase 2.  Two rounds of the stream (2 x 32 MB chip-wide, ~7 us of HBM time) move under the
+  // wait instead of behind it.
+  const bool pre = ngq == 1 && n_mine >= 2;   // (wave-uniform)
+  acc_t accP[2][GF::SUBS][2];
+  auto unit_mfma_g0 = [&](f32x4 (&A)[16], acc_t (&out)[GF::SUBS][2]) {
+#pragma unroll
+    for (int sub = 0; sub < GF::SUBS; ++sub) {
+      out[sub][0] = out[sub][1] = acc_t{0, 0, 0, 0};
+#pragma unroll
+      for (int t = 0; t < GF::KS; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if constexpr (I8)
+            out[sub][h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, A[(sub * GF::KS + t) * 2 + h]), bq8[t],
+                                                                out[sub][h], 0, 0, 0);
+          else
+            out[sub][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[(sub * GF::KS + t) * 2 + h]), bqb[t],
+                                                                  out[sub][h], 0, 0, 0);
+        }
+    }
+  };
 
   // ---- 2. thresholds from the published part maxima, after a BOUNDED wait for the missing ones -----------------------------
   // Cross-workgroup traffic of this kernel is agent-scope ATOMICS only (relaxed atomic stores / loads, which go past the
@@ -383,14 +410,17 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   // threshold of query q from the part maxima published so far (one wave; every lane returns with thr_lds[q] written)
   // this lane's parts of query q as published so far: parts lane, lane + 64, ... (0: nothing yet); the largest of them is the
   // maximum of a coarser part (64 of them: one per lane); *missing = some part of this lane is still unpublished
-  auto load_part = [&](int q, bool* missing) -> unsigned {
+  auto issue_parts = [&](int q, unsigned (&w4)[4]) {   // the loads only: consumed by parts_of
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4)
+      w4[c4] = (q < B && lane + 64 * c4 < G_b)
+                   ? __hip_atomic_load(gmax_g + q * SMALL_PARTS_MAX + lane + 64 * c4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                   : 1u;
+  };
+  auto parts_of = [&](int q, const unsigned (&w4)[4], bool* missing) -> unsigned {
     unsigned u = 0u;
     bool miss = false;
     if (q < B) {
-      unsigned w4[4];
-#pragma unroll
-      for (int c4 = 0; c4 < 4; ++c4)
-        w4[c4] = lane + 64 * c4 < G_b ? __hip_atomic_load(gmax_g + q * SMALL_PARTS_MAX + lane + 64 * c4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
 #pragma unroll
       for (int c4 = 0; c4 < 4; ++c4) {
         miss = miss || w4[c4] == 0u;
@@ -399,6 +429,11 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
     }
     *missing = miss;
     return u;
+  };
+  auto load_part = [&](int q, bool* missing) -> unsigned {
+    unsigned w4[4];
+    issue_parts(q, w4);
+    return parts_of(q, w4, missing);
   };
   const int nparts = G_b < 64 ? G_b : 64;
   auto make_threshold = [&](int q, unsigned u) {
@@ -438,22 +473,33 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
       thr_lds[q] = out;
     }
   };
-  if (tid < 32) {
-    thr_lds[tid] = I8 ? __int_as_float(tid < B ? INT_MIN : INT_MAX) : (tid < B ? RG_NEG_INF : __builtin_huge_valf());
-    theta_lds[tid] = RG_NEG_INF;
-  }
-  __syncthreads();
   {  // a wave's queries: wave, wave + 8, ... -- all their part maxima are requested in one batch, again until none is missing
      // or the time limit has passed (workgroups of another process may hold the CUs some of ours still need)
     unsigned up[4];
     const unsigned long long t0 = wall_clock64();
-    bool missing = true;
-    while (missing) {
+    bool missing;
+    {
+      // the first request of the part maxima is ISSUED here and consumed behind the two stream units that are multiplied
+      // ahead of their thresholds: an agent-scope load is 3 - 7 us under the stream's load, which is what this phase cost
+      unsigned raw[4][4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) issue_parts(wave + 8 * c, raw[c]);
+      if (pre) {
+        RG_SLOAD(A1, fbase, gw + W);
+        unit_mfma_g0(A0, accP[0]);
+        if (n_mine > 2) RG_SLOAD(A0, fbase, gw + 2 * W);
+        unit_mfma_g0(A1, accP[1]);
+      }
+      bool mc[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) up[c] = parts_of(wave + 8 * c, raw[c], &mc[c]);
+      missing = __any(mc[0] || mc[1] || mc[2] || mc[3]);
+    }
+    while (missing && (unsigned)(wall_clock64() - t0) < p.wait_ticks) {
       bool mc[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) up[c] = load_part(wave + 8 * c, &mc[c]);
       missing = __any(mc[0] || mc[1] || mc[2] || mc[3]);
-      if (missing && (unsigned)(wall_clock64() - t0) >= p.wait_ticks) break;
     }
     if (missing && lane == 0) atomicOr(misc + 1, 1);   // somebody moved on early: wave 0 refreshes while it streams
 #pragma unroll
@@ -585,6 +631,13 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   };
   if (n_mine > 0) {
     int64_t i = 0;
+    if (pre) {  // the two units multiplied before the thresholds existed
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int sub = 0; sub < GF::SUBS; ++sub) epilogue(accP[u][sub], 0, gw + u * W, sub);
+      i = 2;
+    }
     for (; i + 2 <= n_mine; i += 2) {  // pairs: A0 then A1, the other buffer's loads always in flight
       RG_SLOAD(A1, fbase, gw + (i + 1) * W);
       process(A0, gw + i * W);
