@@ -347,9 +347,10 @@ int ragraph_scan_sum_i32(const int* in, int* out, int64_t n, int inclusive, void
  * from are n x 128 bytes instead of n x 1 KiB, a third of which fit its L2 on a graph without locality (c2: L2 hit rate 15 ->
  * 34 %, a hop 132 -> ~116 us).  x_panels / y_panels: 0 = row-major [n, D], 1 = panel-major.  Same chains as ragraph_spmm_csr_f32
  * (per element, CSR order, blocks of 4096 edges), hence the same bits in every layout; no bias / residual.
- * D in {64, 128} or a multiple of 256. */
+ * n = output rows (rowptr may be a slice of a larger graph's: a rank's rows), x_rows = rows of X (the panel stride of a
+ * panel-major X).  D in {64, 128} or a multiple of 256. */
 int ragraph_spmm_csr_panels_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n, const float* X,
-                                int x_panels, int D, int act, float alpha, float* Y, int y_panels, void* stream);
+                                int64_t x_rows, int x_panels, int D, int act, float alpha, float* Y, int y_panels, void* stream);
 
 /* a7  adj / adj.sum(dim=1, keepdim=True)  -- Propagation.py:15-16.  val_out[e] = val[e] / rowsum(row(e)), rowsum =
  *     sequential fp32 adds in CSR order.  In-place allowed.  (A zero row sum gives inf/nan exactly as the reference.) */

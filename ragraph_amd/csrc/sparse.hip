@@ -146,8 +146,8 @@ __global__ void __launch_bounds__(256) spmm_csr_kernel(const int64_t* __restrict
 // from +0 and added in order -- so every layout gives the same bits.
 __global__ void __launch_bounds__(256) spmm_panel_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                          const float* __restrict__ val, int64_t n, const float* __restrict__ Xp,
-                                                         float* __restrict__ Y, int64_t y_panel_stride, int64_t y_row_stride,
-                                                         int P, int act, float alpha) {
+                                                         int64_t x_rows, float* __restrict__ Y, int64_t y_panel_stride,
+                                                         int64_t y_row_stride, int P, int act, float alpha) {
   constexpr int LP = 8, ROWS_W = 8, ROWS_B = 32, CH = 8;
   const int lane = threadIdx.x & 63;
   const int lr = lane % LP;
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) spmm_panel_kernel(const int64_t* __restri
     const int64_t o = ((int64_t)__shfl_xor((int)(maxdeg >> 32), off) << 32) | (unsigned)__shfl_xor((int)maxdeg, off);
     maxdeg = o > maxdeg ? o : maxdeg;
   }
-  const float4* X4 = reinterpret_cast<const float4*>(Xp + (int64_t)panel * n * 32) + lr;
+  const float4* X4 = reinterpret_cast<const float4*>(Xp + (int64_t)panel * x_rows * 32) + lr;   // (x_rows: rows of the table gathered from)
   float4 total = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int64_t b0 = 0; b0 < maxdeg || b0 == 0; b0 += ROW_BLOCK) {
     const int cnt_w = maxdeg - b0 < ROW_BLOCK ? (int)(maxdeg - b0) : ROW_BLOCK;          // wave-uniform
@@ -530,8 +530,10 @@ extern "C" int ragraph_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, c
 }
 
 extern "C" int ragraph_spmm_csr_panels_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n, const float* X,
-                                           int x_panels, int D, int act, float alpha, float* Y, int y_panels, void* stream) {
+                                           int64_t x_rows, int x_panels, int D, int act, float alpha, float* Y, int y_panels,
+                                           void* stream) {
   RG_REQUIRE(rowptr && X && Y, RAGRAPH_EINVAL, "spmm_csr_panels: null pointer");
+  RG_REQUIRE(x_rows >= 1, RAGRAPH_EINVAL, "spmm_csr_panels: x_rows=%lld", (long long)x_rows);
   RG_REQUIRE(n >= 1 && (D == 64 || D == 128 || D == 256 || (D % 256 == 0 && D <= 2048)), RAGRAPH_EUNSUPPORTED,
              "spmm_csr_panels: D=%d (panels of 32 columns: 2, 4 or a multiple of 8 of them)", D);
   RG_REQUIRE(aligned16(X) && aligned16(Y) && X != Y, RAGRAPH_EINVAL, "spmm_csr_panels: X, Y must be 16-B aligned and distinct");
@@ -559,7 +561,7 @@ extern "C" int ragraph_spmm_csr_panels_f32(const int64_t* rowptr, const int32_t*
   const int64_t row_blocks = cdiv(n, 32);
   const int64_t per_xcd = P >= 8 ? row_blocks * (P / 8) : cdiv(row_blocks, (int64_t)(8 / P));
   RG_REQUIRE(per_xcd * 8 < ((int64_t)1 << 31), RAGRAPH_EUNSUPPORTED, "spmm_csr_panels: too many rows");
-  hipLaunchKernelGGL(spmm_panel_kernel, dim3((unsigned)(per_xcd * 8)), dim3(256), 0, st, rowptr, col, val, n, X, Y,
+  hipLaunchKernelGGL(spmm_panel_kernel, dim3((unsigned)(per_xcd * 8)), dim3(256), 0, st, rowptr, col, val, n, X, x_rows, Y,
                      y_panels ? n * 32 : (int64_t)32, y_panels ? (int64_t)32 : (int64_t)D, P, act, alpha);
   RG_CHECK_LAUNCH("spmm_csr_panels");
   return RAGRAPH_OK;

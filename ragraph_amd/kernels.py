@@ -568,8 +568,8 @@ def spmm_csr_panels(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, 
     x = _f32c(x, "spmm_csr_panels.x")
     n, D = rowptr.numel() - 1, x.shape[1]
     y = torch.empty((n, D), dtype=torch.float32, device=x.device)
-    N.check(L.ragraph_spmm_csr_panels_f32(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), n, x.data_ptr(), int(x_panels), D, act,
-                                          float(alpha), y.data_ptr(), int(y_panels), _stream()), "spmm_csr_panels")
+    N.check(L.ragraph_spmm_csr_panels_f32(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), n, x.data_ptr(), x.shape[0], int(x_panels),
+                                          D, act, float(alpha), y.data_ptr(), int(y_panels), _stream()), "spmm_csr_panels")
     return y
 
 

@@ -16,12 +16,15 @@ class Propagation:
         if k <= 0:
             return x if rows is None else x[rows[0]:rows[1]].contiguous()
         valn = g.row_normalized_values()
-        if (rows is None and not g.has_long_rows and not (torch.is_grad_enabled() and x.requires_grad) and x.is_cuda
+        if (not g.has_long_rows and not (torch.is_grad_enabled() and x.requires_grad) and x.is_cuda
                 and K.panels_help(x.shape[0], x.shape[1], int(k))):
             # large graphs: the features stay panel-major between the hops (an XCD gathers one 128-byte line per neighbour
-            # from its own panel instead of 1-KiB rows from the whole table); same bits
+            # from its own panel instead of 1-KiB rows from the whole table); same bits.  rows: the last hop over that
+            # slice of the row pointers only.
             for hop in range(int(k)):
-                x = K.spmm_csr_panels(g.rowptr, g.col, valn, x, x_panels=hop > 0, y_panels=hop < int(k) - 1, act=K.ACT_RELU)
+                last = hop == int(k) - 1
+                rp = g.rowptr[rows[0]:rows[1] + 1] if (last and rows is not None) else g.rowptr
+                x = K.spmm_csr_panels(rp, g.col, valn, x, x_panels=hop > 0, y_panels=not last, act=K.ACT_RELU)
             return x
         for hop in range(int(k)):
             if rows is not None and hop == int(k) - 1 and not g.has_long_rows:

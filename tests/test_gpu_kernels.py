@@ -1041,3 +1041,22 @@ def test_spmm_csr_panels_bit_exact(dev, n, D, deg):
     # two hops through panels = two hops of the row kernel
     two = K.spmm_csr_panels(rp, cc, vv, yp, x_panels=True, y_panels=False, act=K.ACT_RELU)
     assert torch.equal(two, K.spmm_csr(rp, cc, vv, ref, act=K.ACT_RELU))
+    # a rank's rows only (key-sharded retrieval: the last hop over a slice of the row pointers, gathering from the whole table)
+    lo, hi = n // 3, n // 3 + max(1, n // 5)
+    part = K.spmm_csr_panels(rp[lo:hi + 1], cc, vv, yp, x_panels=True, y_panels=False, act=K.ACT_RELU)
+    assert part.shape[0] == hi - lo and torch.equal(part, two[lo:hi])
+
+
+def test_propagation_rows_slice_through_panels(dev):
+    """aggregate_k_hop_features(rows=(lo, hi)) at c2's size (the panel hops): the rows of the whole result, bit for bit."""
+    from ragraph_amd import data
+    from ragraph_amd.ragraph_utils import Propagation
+
+    n, D = 100_000, 256
+    from ragraph_amd.graph import CSRGraph
+    g = CSRGraph.from_edge_index_sym_normalized(data.synthetic_big_graph(n, 10, seed=5, device=dev), n)
+    x = torch.randn(n, D, device=dev)
+    whole = Propagation.aggregate_k_hop_features(g, x, 3)
+    for lo, hi in ((0, 12_500), (37_500, 50_000), (99_000, 100_000)):
+        part = Propagation.aggregate_k_hop_features(g, x, 3, rows=(lo, hi))
+        assert part.shape == (hi - lo, D) and torch.equal(part, whole[lo:hi])

@@ -4,7 +4,7 @@
 # stats).  An estimate for DESIGN.md section 5, never a bench line.     gpurun --timeout 1500 -- bash tools/gpu_emul.sh 8
 #   -> gpurun_out/r3_emul.txt   (copy to profiles/)
 R=$(pwd); O=$R/gpurun_out/emul; mkdir -p $O
-OUT=$R/gpurun_out/r3_emul.txt; : > $OUT
+OUT=$R/gpurun_out/${EMUL_TAG:-r4}_emul.txt; : > $OUT
 for G in 2 4 8; do
   for shard in keys queries; do
     python bench.py --emulate-rank-of $G --shard $shard --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | grep metric | python -c "
