@@ -146,8 +146,9 @@ __global__ void __launch_bounds__(256) spmm_csr_kernel(const int64_t* __restrict
 // from +0 and added in order -- so every layout gives the same bits.
 __global__ void __launch_bounds__(256) spmm_panel_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                          const float* __restrict__ val, int64_t n, const float* __restrict__ Xp,
-                                                         int64_t x_rows, float* __restrict__ Y, int64_t y_panel_stride,
-                                                         int64_t y_row_stride, int P, int act, float alpha) {
+                                                         int64_t x_panel_stride, int x_row4, float* __restrict__ Y,
+                                                         int64_t y_panel_stride, int64_t y_row_stride, int P, int act,
+                                                         float alpha) {
   constexpr int LP = 8, ROWS_W = 8, ROWS_B = 32, CH = 8;
   const int lane = threadIdx.x & 63;
   const int lr = lane % LP;
@@ -178,7 +179,9 @@ __global__ void __launch_bounds__(256) spmm_panel_kernel(const int64_t* __restri
     const int64_t o = ((int64_t)__shfl_xor((int)(maxdeg >> 32), off) << 32) | (unsigned)__shfl_xor((int)maxdeg, off);
     maxdeg = o > maxdeg ? o : maxdeg;
   }
-  const float4* X4 = reinterpret_cast<const float4*>(Xp + (int64_t)panel * x_rows * 32) + lr;   // (x_rows: rows of the table gathered from)
+  // X panel-major: panel stride = 32 x (rows of the table), a row 8 float4; X row-major: the XCD's 128-byte slice of every
+  // 4 D-byte row -- panel stride 32 floats, a row D / 4 float4 (the same lines per XCD either way)
+  const float4* X4 = reinterpret_cast<const float4*>(Xp + (int64_t)panel * x_panel_stride) + lr;
   float4 total = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int64_t b0 = 0; b0 < maxdeg || b0 == 0; b0 += ROW_BLOCK) {
     const int cnt_w = maxdeg - b0 < ROW_BLOCK ? (int)(maxdeg - b0) : ROW_BLOCK;          // wave-uniform
@@ -193,7 +196,7 @@ __global__ void __launch_bounds__(256) spmm_panel_kernel(const int64_t* __restri
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
         const int c = __shfl(my_c, gbase + k);
-        x[k] = (base + k < cnt) ? X4[(int64_t)c * 8] : make_float4(0.f, 0.f, 0.f, 0.f);
+        x[k] = (base + k < cnt) ? X4[(int64_t)c * x_row4] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
@@ -540,7 +543,9 @@ extern "C" int ragraph_spmm_csr_panels_f32(const int64_t* rowptr, const int32_t*
   RG_REQUIRE(act >= RAGRAPH_ACT_NONE && act <= RAGRAPH_ACT_ELU, RAGRAPH_EINVAL, "spmm_csr_panels: bad act %d", act);
   hipStream_t st = as_stream(stream);
   const int P = D / 32;
-  if (!x_panels) {  // row-major in: the row kernel, storing row-major or panel-major
+  // row-major in: the XCD-sliced kernel reading its 128-byte slice of every row (RAGRAPH_SPMM_ROW_SLICES=0: the row kernel)
+  static const bool row_slices = [] { const char* e = getenv("RAGRAPH_SPMM_ROW_SLICES"); return !e || atoi(e) != 0; }();
+  if (!x_panels && !row_slices) {  // the row kernel, storing row-major or panel-major
     static const unsigned xcd_run = [] {
       const char* e = getenv("RAGRAPH_SPMM_XCD_RUN");
       const int v = e ? atoi(e) : 32;
@@ -561,8 +566,9 @@ extern "C" int ragraph_spmm_csr_panels_f32(const int64_t* rowptr, const int32_t*
   const int64_t row_blocks = cdiv(n, 32);
   const int64_t per_xcd = P >= 8 ? row_blocks * (P / 8) : cdiv(row_blocks, (int64_t)(8 / P));
   RG_REQUIRE(per_xcd * 8 < ((int64_t)1 << 31), RAGRAPH_EUNSUPPORTED, "spmm_csr_panels: too many rows");
-  hipLaunchKernelGGL(spmm_panel_kernel, dim3((unsigned)(per_xcd * 8)), dim3(256), 0, st, rowptr, col, val, n, X, x_rows, Y,
-                     y_panels ? n * 32 : (int64_t)32, y_panels ? (int64_t)32 : (int64_t)D, P, act, alpha);
+  hipLaunchKernelGGL(spmm_panel_kernel, dim3((unsigned)(per_xcd * 8)), dim3(256), 0, st, rowptr, col, val, n, X,
+                     x_panels ? x_rows * 32 : (int64_t)32, x_panels ? 8 : D / 4, Y, y_panels ? n * 32 : (int64_t)32,
+                     y_panels ? (int64_t)32 : (int64_t)D, P, act, alpha);
   RG_CHECK_LAUNCH("spmm_csr_panels");
   return RAGRAPH_OK;
 }

@@ -579,6 +579,14 @@ def panels_help(n: int, D: int, k: int) -> bool:
     return k >= 2 and D == 256 and n * D * 4 >= (64 << 20) and os.environ.get("RAGRAPH_SPMM_PANELS", "1") != "0"
 
 
+def slices_help(n: int, D: int) -> bool:
+    """A plain aggregation act(A @ x) of a NARROW row-major table much larger than the L2s (c2's encoder input: 100 000 x 128,
+    51 MB) on the XCD-sliced kernel -- every XCD gathers its 128-byte slice of each neighbour row: 73.6 -> 66.8 us
+    (tools/gnn_probe.py).  Not at D = 256: row-major slices 1 KiB apart fall on an eighth of an L2's channels (136 us, the
+    row kernel's time; the panel-major layout between the hops is what helps there)."""
+    return D == 128 and n * D * 4 >= (32 << 20) and os.environ.get("RAGRAPH_SPMM_ROW_SLICES", "1") != "0"
+
+
 def csr_row_normalize(rowptr: torch.Tensor, val: torch.Tensor) -> torch.Tensor:
     """val / rowsum -- Propagation.py:15-16."""
     L = _ready()

@@ -107,7 +107,10 @@ class GCN(nn.Module):
             # narrow features (c2: 128 -> 256): A_hat (X W^T) = (A_hat X) W^T, and the gathers of the aggregation -- what a
             # hop costs -- move half the bytes on the narrow side; bias + PReLU ride in the dense
             # kernel's epilogue.  Another association of the same sum: the oracle applies the same rule (oracle/pipeline.py).
-            agg = K.spmm_csr(g.rowptr, g.col, g.val, x, long_rows=g.has_long_rows)
+            if not g.has_long_rows and x.is_cuda and K.slices_help(x.shape[0], x.shape[1]):
+                agg = K.spmm_csr_panels(g.rowptr, g.col, g.val, x, x_panels=False, y_panels=False)   # (same bits)
+            else:
+                agg = K.spmm_csr(g.rowptr, g.col, g.val, x, long_rows=g.has_long_rows)
             return K.linear(agg, self.fc.weight, self.bias, act=K.ACT_PRELU, alpha=self._alpha())
         if xs is not None:  # bag-of-words features: X W^T over X's non-zeros only -- the same bits (see above)
             seq_fts = K.spmm_csr(xs[0], xs[1], xs[2], self._weight_t())

@@ -1034,6 +1034,7 @@ def test_spmm_csr_panels_bit_exact(dev, n, D, deg):
     yp = K.spmm_csr_panels(rp, cc, vv, Xd, x_panels=False, y_panels=True, act=K.ACT_RELU)           # row -> panel
     back = yp.view(D // 32, n, 32).permute(1, 0, 2).reshape(n, D)
     assert torch.equal(back, ref)
+    assert torch.equal(K.spmm_csr_panels(rp, cc, vv, Xd, x_panels=False, y_panels=False, act=K.ACT_RELU), ref)   # row -> row, XCD slices
     xp = Xd.view(n, D // 32, 32).permute(1, 0, 2).contiguous().view(n, D)                            # X as panels
     assert torch.equal(K.spmm_csr_panels(rp, cc, vv, xp, x_panels=True, y_panels=False, act=K.ACT_RELU), ref)   # panel -> row
     y2 = K.spmm_csr_panels(rp, cc, vv, xp, x_panels=True, y_panels=True, act=K.ACT_RELU)             # panel -> panel

@@ -37,3 +37,11 @@ print(f"linear 128 -> 256:                 {t(lambda: K.linear(X, W)):7.1f} us")
 print(f"linear 128 -> 256 + bias + PReLU:  {t(lambda: K.linear(X, W, b, act=K.ACT_PRELU, alpha=0.25)):7.1f} us")
 print(f"encoder, reference order:          {t(lambda: K.spmm_csr(g.rowptr, g.col, g.val, K.linear(X, W), bias=b, act=K.ACT_PRELU, alpha=0.25)):7.1f} us")
 print(f"encoder, aggregate first:          {t(lambda: K.linear(K.spmm_csr(g.rowptr, g.col, g.val, X), W, b, act=K.ACT_PRELU, alpha=0.25)):7.1f} us")
+# the XCD-sliced kernel in every layout combination (a hop at D = 256; the narrow aggregation at D = 128)
+Hp = H.view(n, D // 32, 32).permute(1, 0, 2).contiguous().view(n, D)
+for xp, yp in ((0, 0), (0, 1), (1, 1), (1, 0)):
+    src = Hp if xp else H
+    print(f"sliced hop D=256, x_panels={xp} y_panels={yp}: {t(lambda: K.spmm_csr_panels(g.rowptr, g.col, vn, src, bool(xp), bool(yp), act=K.ACT_RELU)):7.1f} us")
+print(f"sliced spmm D=128 row -> row:      {t(lambda: K.spmm_csr_panels(g.rowptr, g.col, g.val, X, False, False)):7.1f} us")
+from ragraph_amd.ragraph_utils import Propagation
+print(f"3 hops (product path):             {t(lambda: Propagation.aggregate_k_hop_features(g, H, 3)):7.1f} us")
