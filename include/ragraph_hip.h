@@ -484,6 +484,17 @@ int ragraph_mul_f32(const float* a, const float* b, int64_t n, float* out, void*
  *     in the same mode, gout [G,C] -> gemb [G,D]. */
 int ragraph_proto_cosine_grad_f32(const float* emb, int64_t G, int D, const float* proto, int C, int mode, const float* out,
                                   const float* gout, float* gemb, void* stream);
+/*   proto_cosine_grad_proto:  the same gradient with respect to the PROTOTYPES -- a training step of the node flavour rebuilds
+ *     them from the embeddings of that step and keeps them in the autograd graph (RAGraph_node/downprompt.py:24-25,59-78):
+ *     gproto [C,D].  Sums in a fixed order (blocks of 256 embeddings, then the blocks): run-to-run identical.  C * D <= 8192.
+ *     workspace: ragraph_proto_cosine_grad_proto_workspace_bytes(G, C, D). */
+size_t ragraph_proto_cosine_grad_proto_workspace_bytes(int64_t G, int C, int D);
+int ragraph_proto_cosine_grad_proto_f32(const float* emb, int64_t G, int D, const float* proto, int C, int mode, const float* out,
+                                        const float* gout, float* gproto, void* workspace, size_t workspace_bytes, void* stream);
+/*   axpby_dev:  out = a * w[ia] + b * w[ib] with the weights read from DEVICE memory (an index < 0: weight 0) -- the
+ *     trainable [1, 2] mixing weight of weighted_feature (RAGraph_node/downprompt.py:100-114) without a host read-back;
+ *     uncontracted like ragraph_axpby_f32. */
+int ragraph_axpby_dev_f32(const float* a, const float* b, const float* w, int ia, int ib, int64_t n, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Toy-bank construction (the step before the hot path), batched over resource graphs.

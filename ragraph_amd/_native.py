@@ -104,6 +104,9 @@ SIGNATURES = {
     "ragraph_mul_cols_act_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp]),
     "ragraph_mul_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "ragraph_proto_cosine_grad_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ragraph_proto_cosine_grad_proto_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "ragraph_proto_cosine_grad_proto_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ragraph_axpby_dev_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i64, _vp, _vp]),
     "ragraph_ingest_workspace_bytes": (_sz, [_i64, _i64]),
     "ragraph_csr_sym_normalized_f32": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ragraph_binorm_edges_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

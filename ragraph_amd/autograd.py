@@ -243,7 +243,8 @@ def mul_cols(x, w, act=K.ACT_NONE, alpha=0.0):
 
 class _ProtoCosine(torch.autograd.Function):
     """f(cosine(emb_g, proto_c)), f = identity / softmax / log_softmax (downprompt.py:41-56 graph flavour,
-    RAGraph_node/downprompt.py:41-46).  The prototypes are constants of a forward; the gradient goes to the embeddings."""
+    RAGraph_node/downprompt.py:41-46).  The gradient goes to the embeddings and -- when a training step keeps the prototypes
+    in the graph (RAGraph_node/downprompt.py:24-25: averageemb of the step's own embeddings) -- to the prototypes."""
 
     @staticmethod
     def forward(ctx, emb, proto, mode):
@@ -255,10 +256,70 @@ class _ProtoCosine(torch.autograd.Function):
     @staticmethod
     def backward(ctx, go):
         emb, proto, out = ctx.saved_tensors
-        return K.proto_cosine_grad(emb, proto, ctx.mode, out, go.contiguous()), None, None
+        go = go.contiguous()
+        gemb = K.proto_cosine_grad(emb, proto, ctx.mode, out, go) if ctx.needs_input_grad[0] else None
+        gproto = K.proto_cosine_grad_proto(emb, proto, ctx.mode, out, go) if ctx.needs_input_grad[1] else None
+        return gemb, gproto, None
 
 
 def proto_cosine(emb, proto, mode=0):
-    if torch.is_grad_enabled() and emb.requires_grad:
-        return _ProtoCosine.apply(emb, proto.detach(), mode)
+    if torch.is_grad_enabled() and (emb.requires_grad or proto.requires_grad):
+        return _ProtoCosine.apply(emb, proto, mode)
     return K.proto_cosine(emb, proto, mode)
+
+
+class _SegmentSum(torch.autograd.Function):
+    """Per-segment sum of rows (K.segment_reduce, rows added in index order); backward: every row takes its segment's
+    gradient row (a gather)."""
+
+    @staticmethod
+    def forward(ctx, x, seg_ptr):
+        ctx.save_for_backward(seg_ptr)
+        ctx.n = x.shape[0]
+        return K.segment_reduce(x, seg_ptr)
+
+    @staticmethod
+    def backward(ctx, g):
+        (seg_ptr,) = ctx.saved_tensors
+        counts = seg_ptr[1:] - seg_ptr[:-1]
+        seg_of_row = torch.repeat_interleave(torch.arange(counts.numel(), device=g.device), counts, output_size=ctx.n)
+        return K.gather_rows(g.contiguous(), seg_of_row), None
+
+
+def segment_sum(x, seg_ptr):
+    """Rows [seg_ptr[s], seg_ptr[s + 1]) of x summed per segment; seg_ptr must cover all rows of x."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _SegmentSum.apply(x, seg_ptr)
+    return K.segment_reduce(x, seg_ptr)
+
+
+class _Mix2(torch.autograd.Function):
+    """a * w[0] + b * w[1] for a trainable [1, 2] weight read on the device (weighted_feature, RAGraph_node/downprompt.py:
+    100-114).  ga = go * w[0], gb = go * w[1], gw = (sum go * a, sum go * b) -- sums in a fixed order (segment_reduce)."""
+
+    @staticmethod
+    def forward(ctx, a, b, w):
+        ctx.save_for_backward(a, b, w)
+        return K.axpby_dev(a, b, w, 0, 1)
+
+    @staticmethod
+    def backward(ctx, go):
+        a, b, w = ctx.saved_tensors
+        go = go.contiguous()
+        ga = K.axpby_dev(go, go, w, 0, -1) if ctx.needs_input_grad[0] else None
+        gb = K.axpby_dev(go, go, w, 1, -1) if ctx.needs_input_grad[1] else None
+        gw = None
+        if ctx.needs_input_grad[2]:
+            def total(t):  # all elements of t added in a fixed order: columns of the row sums, then those
+                D = t.shape[-1]
+                rows = t.reshape(-1, D)
+                col = K.segment_reduce(rows, torch.tensor([0, rows.shape[0]], dtype=torch.int64, device=t.device))
+                return K.segment_reduce(col.reshape(D, 1).contiguous(), torch.tensor([0, D], dtype=torch.int64, device=t.device))
+            gw = torch.cat([total(K.mul(go, a)), total(K.mul(go, b))], 1).reshape(w.shape)
+        return ga, gb, gw
+
+
+def mix2(a, b, w):
+    if torch.is_grad_enabled() and (a.requires_grad or b.requires_grad or w.requires_grad):
+        return _Mix2.apply(a, b, w)
+    return K.axpby_dev(a, b, w, 0, 1)

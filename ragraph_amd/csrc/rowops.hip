@@ -148,6 +148,17 @@ __global__ void __launch_bounds__(256) axpby_kernel(const float* __restrict__ a,
     out[i] = __fadd_rn(__fmul_rn(a[i], wa), __fmul_rn(b[i], wb));
 }
 
+// the same with the weights read from device memory (a trainable [1, 2] mixing weight, RAGraph_node/downprompt.py:100-114: no
+// host read-back): out = a * w[ia] + b * w[ib]; an index < 0 stands for a zero weight
+__global__ void __launch_bounds__(256) axpby_dev_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        const float* __restrict__ w, int ia, int ib, int64_t n,
+                                                        float* __restrict__ out) {
+  const float wa = ia >= 0 ? w[ia] : 0.f, wb = ib >= 0 ? w[ib] : 0.f;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    out[i] = __fadd_rn(__fmul_rn(a[i], wa), __fmul_rn(b[i], wb));
+}
+
 // ---- a13: emb_gate  x * sigmoid(z)  (RAGraph_edge/modules/RAGraph.py:168; z = x @ W + b from the linear kernel) --------
 __global__ void __launch_bounds__(256) sigmoid_gate_kernel(const float* __restrict__ x, const float* __restrict__ z,
                                                            int64_t n, float* __restrict__ out) {
@@ -348,6 +359,83 @@ __global__ void __launch_bounds__(256) proto_cosine_grad_kernel(const float* __r
   for (int e = lane; e < D; e += 64) gemb[g * D + e] -= sx * x[e];
 }
 
+// Backward of proto_cosine with respect to the PROTOTYPES (a training step of the node flavour rebuilds them from the very
+// embeddings they are compared with and keeps them in the graph: RAGraph_node/downprompt.py:24-46):
+//   gproto_c[e] = sum_g gcos_gc (x_g[e] / (|x_g| |p_c|) - cos_gc p_c[e] / |p_c|^2),  gcos as in proto_cosine_grad_kernel.
+// Two launches, every sum in a fixed order: a workgroup takes 256 consecutive embeddings, its four waves 64 each, one after the
+// other, into lane-private LDS accumulators [wave][C][D]; the waves' sums are added in wave order into partial[block][C][D],
+// and the second launch adds the blocks in order.
+__global__ void __launch_bounds__(256) proto_cosine_grad_proto_kernel(const float* __restrict__ emb, int64_t G, int D,
+                                                                      const float* __restrict__ proto, int C, int mode,
+                                                                      const float* __restrict__ out,
+                                                                      const float* __restrict__ gout,
+                                                                      float* __restrict__ partial) {
+  extern __shared__ float pacc[];  // [4][C][D]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* acc = pacc + (size_t)w * C * D;
+  for (int i = lane; i < C * D; i += 64) acc[i] = 0.f;
+  float np_mine = 1.f;  // lane c: |p_c|
+  for (int c = 0; c < C; ++c) {
+    const float* pc = proto + (int64_t)c * D;
+    float yy = 0.f;
+    for (int e = lane; e < D; e += 64) yy = fmaf(pc[e], pc[e], yy);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) yy = __fadd_rn(yy, __shfl_xor(yy, off));
+    if (lane == c) np_mine = fmaxf(sqrtf(yy), 1e-8f);
+  }
+  const int64_t g0 = (int64_t)blockIdx.x * 256 + w * 64;
+  for (int64_t g = g0; g < g0 + 64 && g < G; ++g) {
+    const float* x = emb + g * D;
+    float xx = 0.f;
+    for (int e = lane; e < D; e += 64) xx = fmaf(x[e], x[e], xx);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) xx = __fadd_rn(xx, __shfl_xor(xx, off));
+    const float nx = fmaxf(sqrtf(xx), 1e-8f);
+    const float o = (lane < C) ? out[g * C + lane] : 0.f;
+    const float go = (lane < C) ? gout[g * C + lane] : 0.f;
+    float gc = go;
+    if (mode == 1) {
+      float dot = go * o;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) dot += __shfl_xor(dot, off);
+      gc = o * (go - dot);
+    } else if (mode == 2) {
+      float sum = go;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+      gc = go - expf(o) * sum;
+    }
+    for (int c = 0; c < C; ++c) {
+      const float* pc = proto + (int64_t)c * D;
+      float xy = 0.f;
+      for (int e = lane; e < D; e += 64) xy = fmaf(x[e], pc[e], xy);
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) xy = __fadd_rn(xy, __shfl_xor(xy, off));
+      const float np = __shfl(np_mine, c);
+      const float cs = xy / (nx * np);
+      const float gcc = __shfl(gc, c);
+      const float a = gcc / (nx * np), b = gcc * cs / (np * np);
+      for (int e = lane; e < D; e += 64) acc[c * D + e] += a * x[e] - b * pc[e];
+    }
+  }
+  __syncthreads();
+  float* dst = partial + (int64_t)blockIdx.x * C * D;
+  for (int i = threadIdx.x; i < C * D; i += 256) {
+    float v = pacc[i];
+    for (int ww = 1; ww < 4; ++ww) v = __fadd_rn(v, pacc[(size_t)ww * C * D + i]);
+    dst[i] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256) proto_cosine_grad_proto_sum_kernel(const float* __restrict__ partial, int64_t blocks,
+                                                                          int CD, float* __restrict__ gproto) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= CD) return;
+  float v = 0.f;
+  for (int64_t b = 0; b < blocks; ++b) v = __fadd_rn(v, partial[b * CD + i]);
+  gproto[i] = v;
+}
+
 }  // namespace ragraph
 
 using namespace ragraph;
@@ -466,6 +554,52 @@ extern "C" int ragraph_proto_cosine_grad_f32(const float* emb, int64_t G, int D,
   hipLaunchKernelGGL(proto_cosine_grad_kernel, dim3((unsigned)cdiv(G, 4)), dim3(256), 0, as_stream(stream), emb, G, D,
                      proto, C, mode, out, gout, gemb);
   RG_CHECK_LAUNCH("proto_cosine_grad");
+  return RAGRAPH_OK;
+}
+
+extern "C" size_t ragraph_proto_cosine_grad_proto_workspace_bytes(int64_t G, int C, int D) {
+  return (size_t)(G > 0 ? cdiv(G, 256) : 1) * (size_t)C * (size_t)D * sizeof(float);
+}
+
+extern "C" int ragraph_proto_cosine_grad_proto_f32(const float* emb, int64_t G, int D, const float* proto, int C, int mode,
+                                                   const float* out, const float* gout, float* gproto, void* workspace,
+                                                   size_t workspace_bytes, void* stream) {
+  RG_REQUIRE(emb && proto && out && gout && gproto && workspace, RAGRAPH_EINVAL, "proto_cosine_grad_proto: null pointer");
+  RG_REQUIRE(C >= 1 && C <= 64, RAGRAPH_EUNSUPPORTED, "proto_cosine_grad_proto: C=%d not in [1,64]", C);
+  RG_REQUIRE(D >= 1 && mode >= 0 && mode <= 2, RAGRAPH_EINVAL, "proto_cosine_grad_proto: bad D/mode");
+  RG_REQUIRE((int64_t)C * D <= 8192, RAGRAPH_EUNSUPPORTED, "proto_cosine_grad_proto: C * D = %lld > 8192 (LDS accumulators)",
+             (long long)C * D);
+  RG_REQUIRE(workspace_bytes >= ragraph_proto_cosine_grad_proto_workspace_bytes(G, C, D), RAGRAPH_EINVAL,
+             "proto_cosine_grad_proto: workspace of %zu bytes is too small", workspace_bytes);
+  hipStream_t st = as_stream(stream);
+  const int64_t blocks = G > 0 ? cdiv(G, 256) : 0;
+  float* partial = reinterpret_cast<float*>(workspace);
+  const size_t lds = (size_t)4 * C * D * sizeof(float);
+  if (blocks > 0) {
+    static DeviceOnce lds_once;
+    if (hipError_t e = raise_dynamic_lds(lds_once, &proto_cosine_grad_proto_kernel, 160 * 1024); e != hipSuccess) {
+      set_error("proto_cosine_grad_proto: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+      return RAGRAPH_EDEVICE;
+    }
+    hipLaunchKernelGGL(proto_cosine_grad_proto_kernel, dim3((unsigned)blocks), dim3(256), lds, st, emb, G, D, proto, C, mode,
+                       out, gout, partial);
+    RG_CHECK_LAUNCH("proto_cosine_grad_proto");
+  }
+  hipLaunchKernelGGL(proto_cosine_grad_proto_sum_kernel, dim3((unsigned)cdiv((int64_t)C * D, 256)), dim3(256), 0, st, partial,
+                     blocks, C * D, gproto);
+  RG_CHECK_LAUNCH("proto_cosine_grad_proto(sum)");
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_axpby_dev_f32(const float* a, const float* b, const float* w, int ia, int ib, int64_t n, float* out,
+                                     void* stream) {
+  RG_REQUIRE(a && b && w && out, RAGRAPH_EINVAL, "axpby_dev: null pointer");
+  RG_REQUIRE(ia < 64 && ib < 64, RAGRAPH_EINVAL, "axpby_dev: weight index out of range");
+  if (n <= 0) return RAGRAPH_OK;
+  int64_t blocks = cdiv(n, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(axpby_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a, b, w, ia, ib, n, out);
+  RG_CHECK_LAUNCH("axpby_dev");
   return RAGRAPH_OK;
 }
 

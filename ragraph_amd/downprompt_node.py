@@ -62,10 +62,10 @@ class weighted_feature(nn.Module):
             self.weight[0][1] = 0.0
 
     def forward(self, graph_embedding1, graph_embedding2):
-        w0, w1 = float(self.weight[0][0]), float(self.weight[0][1])
-        mixed = K.axpby(graph_embedding1, w0, graph_embedding2, w1)
+        # (the weights stay on the device: no host read-back, and the gradient reaches them)
+        mixed = AG.mix2(graph_embedding1, graph_embedding2, self.weight)
         ones = torch.ones(mixed.shape[-1], device=mixed.device)
-        return K.mul_cols(mixed, ones, K.ACT_ELU, 1.0)
+        return AG.mul_cols(mixed, ones, K.ACT_ELU, 1.0)
 
 
 def averageemb(labels, rawret):
@@ -87,8 +87,9 @@ def averageemb(labels, rawret):
     order = torch.nonzero(keep).reshape(-1)[torch.sort(lab_k, stable=True).indices]
     seg = torch.zeros(NB_CLASSES + 1, dtype=torch.int64, device=rawret.device)
     seg[1:] = torch.cumsum(counts, 0)
-    sums = K.segment_reduce(K.gather_rows(rawret, order), seg)                    # rows added in index order
-    return K.mul_cols(sums, torch.full((rawret.shape[1],), 1.0 / half, device=rawret.device))
+    # (differentiable: a training step keeps the prototypes in the graph of its own embeddings, downprompt.py:24-25)
+    sums = AG.segment_sum(AG.gather_rows(rawret, order), seg)                     # rows added in index order
+    return AG.mul_cols(sums, torch.full((rawret.shape[1],), 1.0 / half, device=rawret.device))
 
 
 class downprompt(nn.Module):
@@ -108,7 +109,8 @@ class downprompt(nn.Module):
     def forward(self, seq, train=0):
         rawret = self.downprompt(seq)
         if train == 1:
-            # (the reference keeps the prototypes in the autograd graph of this step; here they are constants of the
-            # forward: the gradient reaches the prompt weight through the samples' side of the cosine)
-            self.ave = averageemb(labels=self.labels, rawret=rawret.detach())
-        return AG.proto_cosine(rawret, self.ave, mode=1)         # cosine to ave[0..2], softmax over dim 1
+            # as in the reference the prototypes of a training step stay in its autograd graph: the gradient reaches the
+            # prompt weight through both sides of the cosine (downprompt.py:24-25)
+            self.ave = averageemb(labels=self.labels, rawret=rawret)
+        ave = self.ave if train == 1 else self.ave.detach()      # (an evaluation never walks a past step's graph)
+        return AG.proto_cosine(rawret, ave, mode=1)              # cosine to ave[0..2], softmax over dim 1

@@ -713,6 +713,35 @@ def proto_cosine_grad(emb: torch.Tensor, proto: torch.Tensor, mode: int, out: to
     return gemb
 
 
+def proto_cosine_grad_proto(emb: torch.Tensor, proto: torch.Tensor, mode: int, out: torch.Tensor, gout: torch.Tensor):
+    """Gradient of proto_cosine with respect to the PROTOTYPES [C, D] (a training step that keeps them in the graph:
+    RAGraph_node/downprompt.py:24-25); sums in a fixed order."""
+    L = _ready()
+    emb, proto = _f32c(emb, "proto_cosine_grad_proto.emb"), _f32c(proto, "proto_cosine_grad_proto.proto")
+    out, gout = _f32c(out, "proto_cosine_grad_proto.out"), _f32c(gout, "proto_cosine_grad_proto.gout")
+    G, D = emb.shape
+    C = proto.shape[0]
+    nbytes = int(L.ragraph_proto_cosine_grad_proto_workspace_bytes(G, C, D))
+    ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=emb.device)
+    gproto = torch.empty_like(proto)
+    N.check(L.ragraph_proto_cosine_grad_proto_f32(emb.data_ptr(), G, D, proto.data_ptr(), C, mode, out.data_ptr(), gout.data_ptr(),
+                                                  gproto.data_ptr(), ws.data_ptr(), nbytes, _stream()), "proto_cosine_grad_proto")
+    return gproto
+
+
+def axpby_dev(a: torch.Tensor, b: torch.Tensor, w: torch.Tensor, ia: int, ib: int) -> torch.Tensor:
+    """a * w[ia] + b * w[ib], the weights read on the device (an index < 0: weight 0) -- RAGraph_node/downprompt.py:113."""
+    L = _ready()
+    a, b = _f32c(a, "axpby_dev.a"), _f32c(b, "axpby_dev.b")
+    w = _f32c(w, "axpby_dev.w").reshape(-1)
+    if a.shape != b.shape or max(ia, ib) >= w.numel():
+        raise RagraphNativeError(f"axpby_dev: shapes {tuple(a.shape)} / {tuple(b.shape)}, weights {w.numel()}")
+    out = torch.empty_like(a)
+    N.check(L.ragraph_axpby_dev_f32(a.data_ptr(), b.data_ptr(), w.data_ptr(), int(ia), int(ib), a.numel(), out.data_ptr(),
+                                    _stream()), "axpby_dev")
+    return out
+
+
 def topk_rows(scores: torch.Tensor, k: int):
     """torch.topk(scores, k) over a materialised [B,N] matrix, canonical tie order -- few-shot retrieve
     (RAGraph_node_fewshot/.../ToyGraphBase.py:64), edge evaluation (RAGraph_edge/utils/metrics.py:116)."""

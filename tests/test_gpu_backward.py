@@ -266,3 +266,87 @@ def test_downprompt_weight_gradients_match_torch(dev, flavour):
     assert abs(float(loss) - float(loss_ref)) < 1e-5
     assert torch.allclose(mod.weight.grad, w_ref.grad, atol=1e-5), (mod.weight.grad - w_ref.grad).abs().max()
     assert torch.allclose(hq.grad, h_ref.grad, atol=1e-5)
+
+
+def test_node_downprompt_training_step_keeps_prototypes_in_the_graph(dev):
+    """RAGraph_node/downprompt.py:24-46 with train = 1: the prototypes are averageemb of the step's OWN prompted embeddings and
+    stay in the autograd graph, so the prompt weight's gradient has two paths (samples and prototypes).  Against torch autograd
+    of the reference's formula with a zero-filled buffer (class sums / floor(n / 2))."""
+    import torch.nn.functional as F
+    from ragraph_amd import downprompt_node as dpn
+
+    torch.manual_seed(11)
+    n, D = 90, 256
+    h = torch.randn(n, D, device=dev)
+    labels = torch.randint(0, 3, (n,), device=dev)
+    tgt = labels.clone()
+    prompts = [torch.randn(1, D, device=dev) for _ in range(3)]
+    mod = dpn.downprompt(*prompts, D, 3, h.clone(), labels).to(dev)
+    out = mod(h, train=1)
+    assert mod.ave.grad_fn is not None
+    loss = F.nll_loss(torch.log(out), tgt)
+    loss.backward()
+    w_ref = mod.downprompt.weight.detach().clone().requires_grad_(True)
+    raw = F.elu(w_ref * h)
+    half = n // 2
+    ave = torch.stack([raw[labels == c].sum(0) / half for c in range(3)])
+    cos = F.cosine_similarity(raw[:, None, :], ave[None, :, :], dim=-1, eps=1e-8)
+    loss_ref = F.nll_loss(torch.log(F.softmax(cos, 1)), tgt)
+    loss_ref.backward()
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    g, gr = mod.downprompt.weight.grad, w_ref.grad
+    assert torch.allclose(g, gr, atol=2e-6 + 1e-4 * float(gr.abs().max())), (g - gr).abs().max()
+    # the prototype path matters: with detached prototypes the gradient is a different vector
+    w2 = mod.downprompt.weight.detach().clone().requires_grad_(True)
+    raw2 = F.elu(w2 * h)
+    cos2 = F.cosine_similarity(raw2[:, None, :], ave.detach()[None, :, :], dim=-1, eps=1e-8)
+    F.nll_loss(torch.log(F.softmax(cos2, 1)), tgt).backward()
+    assert (w2.grad - gr).abs().max() > 10 * (g - gr).abs().max()
+    # evaluation afterwards: no graph of the past step behind the output
+    ev = mod(h, train=0)
+    ev.sum().backward()        # (would raise "backward through the graph a second time" if it reached the past step's prototypes)
+
+
+@pytest.mark.parametrize("G,C,D,mode", [(1000, 3, 256, 1), (257, 5, 64, 2), (64, 1, 30, 0), (5000, 16, 128, 1)])
+def test_proto_cosine_gradient_for_the_prototypes(dev, G, C, D, mode):
+    """ragraph_proto_cosine_grad_proto_f32 against torch autograd; identical from run to run (fixed summation order)."""
+    import torch.nn.functional as F
+    from ragraph_amd import kernels as K
+
+    torch.manual_seed(G + C)
+    emb = torch.randn(G, D, device=dev)
+    proto = torch.randn(C, D, device=dev)
+    go = torch.randn(G, C, device=dev)
+    out = K.proto_cosine(emb, proto, mode)
+    got = K.proto_cosine_grad_proto(emb, proto, mode, out, go)
+    assert torch.equal(got, K.proto_cosine_grad_proto(emb, proto, mode, out, go))
+    pr = proto.double().clone().requires_grad_(True)
+    cos = F.cosine_similarity(emb.double()[:, None, :], pr[None, :, :], dim=-1, eps=1e-8)
+    f = cos if mode == 0 else (F.softmax(cos, 1) if mode == 1 else F.log_softmax(cos, 1))
+    (f * go.double()).sum().backward()
+    ref = pr.grad.float()
+    assert torch.allclose(got, ref, atol=1e-5 + 2e-4 * float(ref.abs().max())), (got - ref).abs().max()
+
+
+def test_weighted_feature_gradients(dev):
+    """weighted_feature (RAGraph_node/downprompt.py:100-114): ELU(w0 a + w1 b) with the [1, 2] weight on the device -- the output
+    and the gradients of a, b AND the weight against torch."""
+    import torch.nn.functional as F
+    from ragraph_amd import downprompt_node as dpn
+
+    torch.manual_seed(5)
+    a = torch.randn(37, 64, device=dev, requires_grad=True)
+    b = torch.randn(37, 64, device=dev, requires_grad=True)
+    mod = dpn.weighted_feature(2).to(dev)
+    with torch.no_grad():
+        mod.weight.copy_(torch.tensor([[0.7, -0.4]], device=dev))
+    out = mod(a, b)
+    go = torch.randn_like(out)
+    (out * go).sum().backward()
+    ar, br = a.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    wr = mod.weight.detach().clone().requires_grad_(True)
+    ref = F.elu(wr[0][0] * ar + wr[0][1] * br)
+    (ref * go).sum().backward()
+    assert torch.allclose(out, ref, atol=1e-6)
+    assert torch.allclose(a.grad, ar.grad, atol=1e-6) and torch.allclose(b.grad, br.grad, atol=1e-6)
+    assert torch.allclose(mod.weight.grad, wr.grad, atol=1e-4), (mod.weight.grad, wr.grad)
