@@ -218,6 +218,7 @@ def small_batch_rates(tgb, dim, k, dev):
                 cap(-1)
             n_i8 = i8.value
             streamed = prefix * dim * 2 + n_keys * dim * (1 if n_i8 else 2) + B * dim * 4
+            t_mfma = 2.0 * B * n_keys * dim / ((INT8_MFMA_PEAK_TOPS if n_i8 else BF16_MFMA_PEAK_TFLOPS) * 1e12)
         elif filtered:
             plan = (ctypes.c_int64 * 7)()
             L.ragraph_topk_cosine_filtered_plan(B, n_keys, dim, k, plan)
@@ -228,8 +229,12 @@ def small_batch_rates(tgb, dim, k, dev):
             ends = [0] + [int(plan[3 + l]) for l in range(int(plan[2]))]
             per_key = [dim * (1 if l >= int(plan[2]) - n_i8 else 2) for l in range(int(plan[2]))]   # int8 levels: D bytes per key
             streamed = int(plan[6]) * dim * 2 + sum((ends[l + 1] - ends[l]) * per_key[l] for l in range(int(plan[2]))) + B * dim * 4
+            # the score matrix at the dense peak of the dtype each level runs on (int8 levels: 2x the bf16 peak)
+            t_mfma = sum(2.0 * B * (ends[l + 1] - ends[l]) * dim /
+                         ((INT8_MFMA_PEAK_TOPS if l >= int(plan[2]) - n_i8 else BF16_MFMA_PEAK_TFLOPS) * 1e12) for l in range(int(plan[2])))
         else:
             streamed = n_keys * dim * 4 + B * dim * 4
+            t_mfma = 2.0 * B * n_keys * dim / (FP32_MFMA_PEAK_TFLOPS * 1e12)
         gbs = streamed / ms / 1e6
         flops = 2.0 * B * n_keys * dim
         rec = {"ms": round(ms, 4), "queries_per_s": round(B / ms * 1e3, 1),
@@ -240,9 +245,12 @@ def small_batch_rates(tgb, dim, k, dev):
                "algorithmic_GBps": round(n_keys * dim * 4 / ms / 1e6, 1),
                "algorithmic_frac_hbm_peak": round(n_keys * dim * 4 / ms / 1e6 / HBM_PEAK_GBS, 4),
                "TFLOPs": round(flops / ms / 1e9, 1)}
-        # which roofline binds this batch: one pass over the streamed copy, or the score matrix on the bf16 cores
-        t_hbm, t_mfma = streamed / (HBM_PEAK_GBS * 1e9), flops / (BF16_MFMA_PEAK_TFLOPS * 1e12)
+        # which roofline binds this batch: one pass over the streamed copy, or the score matrix on the matrix cores at the
+        # peak of the dtype every level actually runs on
+        t_hbm = streamed / (HBM_PEAK_GBS * 1e9)
         rec["bound"] = "hbm" if t_hbm >= t_mfma else "mfma"
+        nlev = int(plan[2]) if (filtered and not one_launch) else 1
+        rec["mfma_dtype"] = (("int8" if n_i8 >= nlev else "bf16 + int8") if n_i8 else "bf16") if (one_launch or filtered) else "f32"
         rec["frac_of_bound"] = round(max(t_hbm, t_mfma) / (ms * 1e-3), 4)
         out[f"B{B}"] = rec
     return out
