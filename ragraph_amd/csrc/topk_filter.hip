@@ -80,6 +80,7 @@ struct FilterParams {
   int64_t stage_base;     // first stage of the key range this launch filters
   int64_t qtiles, nstages_total;  // nstages_total = stages in the range
   int xcd_map, wgs_per_group, lb_min, depth[2];
+  int partner_lead;       // > 0: a wave's priority follows its SIMD partner's progress (see the stage loop); 0: off
   // bound pass (BOUND kernels): per query, the maxima of `ngroups` consecutive stage ranges of the launch's key range
   int* gmax;              // [B, ngroups] as order-preserving ints (f2ord), pre-filled with f2ord(-inf)
   int ngroups;
@@ -88,8 +89,14 @@ struct FilterParams {
 __device__ __forceinline__ void fring_wait(unsigned* ctr, unsigned target) {
   while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
 }
+#ifndef RG_RING_RELAXED
+#define RG_RING_RELAXED 1
+#endif
+// What a signal publishes is ordered by hand: `freec` (this wave is done READING the slot) follows the wave's own ds_reads in
+// the LDS queue, which executes a wave's operations in order; `full` (this wave's share of the stage has LANDED) follows an
+// explicit s_waitcnt vmcnt(0).  A release fence here would wait for every outstanding store of a candidate flush as well.
 __device__ __forceinline__ void fring_signal(unsigned* ctr, int lane) {
-  if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, RG_RING_RELAXED ? __ATOMIC_RELAXED : __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // fp32 -> bf16 (round to nearest even) of the bank in MFMA fragment order, rows [N, Npad) zero so the stream never needs
@@ -610,7 +617,14 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     const bool wave_live = q_wave < p.B;  // (wave-uniform)
     int wcnt = 0;  // wave-uniform
     int key_org = (int)((p.stage_base + st0) * C::STAGE_KEYS);
+#ifdef RG_TOPK_TIMING
+    unsigned long long tfl = 0, nfl = 0;
+#endif
     auto flush = [&]() {
+#ifdef RG_TOPK_TIMING
+      const unsigned long long tf0 = __builtin_amdgcn_s_memtime();
+      nfl += wcnt > 0 ? 1 : 0;
+#endif
       for (int i0 = 0; i0 < wcnt; i0 += 64) {
         const int i = i0 + lane;
         if (i < wcnt) {
@@ -635,6 +649,9 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
         }
       }
       wcnt = 0;
+#ifdef RG_TOPK_TIMING
+      tfl += __builtin_amdgcn_s_memtime() - tf0;
+#endif
     };
     // hipcc does not know about the asm DMA loads, and any vmcnt(0) it emits inside the stage loop (for a global load it
     // still considers pending at the loop's back edge) would drain them every sub-tile: retire the thresholds here and
@@ -657,6 +674,25 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     if (tid < pro) full[tid] = C::WAVES;
     __syncthreads();
     RG_RSTAMP(3);
+    // Partners on a SIMD (waves w and w + 4) run the same program -- a sub-tile's MFMAs, then its epilogue's VALU work -- and
+    // the SIMD arbitrates between them by priority, then AGE: at equal priority the older wave takes every issue slot it can
+    // use, runs a stage ahead of its partner, and then sleeps at the ring (a slot is reused when EVERY wave has left it) while
+    // the partner runs alone, its epilogues beside nobody's MFMAs: the matrix pipe was busy 65 % of the last level's cycles
+    // (SQ_VALU_MFMA_BUSY_CYCLES; wait for a free slot: 16 % of a wave's time, -DRG_TOPK_TIMING).  So the priority follows the
+    // partner's progress -- sub-tiles done, one word per wave behind the ring flags, written per sub-tile and read once per
+    // stage: a wave more than `lead` sub-tiles ahead yields (priority 0), one that is behind takes over (2), else 1.  Last
+    // level of the bench 13.4 -> 12.8 ms, wait for a free slot 1467 -> 516 ticks per stage (profiles/r4_ring_priority.txt;
+    // a start offset between the halves, static priority for the second half, priorities alternating per stage, priority
+    // per phase -- MFMAs high / epilogue low and the reverse -- and shares of the DMA deferred instead of waited for: all
+    // within noise or slower).
+    int* prog = reinterpret_cast<int*>(freec + C::SLOTS);  // [WAVES]
+    const int lead = p.partner_lead;
+    if (lead) {
+      if (lane == 0) prog[wave] = 0;
+      __builtin_amdgcn_s_setprio(1);
+    }
+    int partner_prog = 0;
+    const unsigned prog_partner_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(prog + (wave ^ (C::WAVES / 2)));
 
     int pending = -1;
 #ifdef RG_TOPK_TIMING
@@ -820,7 +856,11 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
             a_, bq[gq][((n_) >> 1) % C::KS32], __builtin_bit_cast(f32x4, acc[(n_) & 1][gq]), 0, 0, 0));     \
     }                                                                                                      \
     if constexpr ((n_) + 4 < C::NSTEP) RG_FREAD((n_) + 4);                                                  \
-    if constexpr ((n_) % C::KSTEPS == C::KSTEPS - 1) epilogue((n_) / C::KSTEPS, acc);                       \
+    if constexpr ((n_) % C::KSTEPS == C::KSTEPS - 1) {                                                     \
+      epilogue((n_) / C::KSTEPS, acc);                                                                     \
+      if (lead && lane == 0)                                                                               \
+        __hip_atomic_store(prog + wave, s * C::SUBS + (n_) / C::KSTEPS + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+    }                                                                                                      \
   }
 #define RG_FSTEP8(n_) RG_FSTEP(n_) RG_FSTEP((n_) + 1) RG_FSTEP((n_) + 2) RG_FSTEP((n_) + 3) \
     RG_FSTEP((n_) + 4) RG_FSTEP((n_) + 5) RG_FSTEP((n_) + 6) RG_FSTEP((n_) + 7)
@@ -831,7 +871,18 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
         RG_FREAD(1);
         RG_FREAD(2);
         RG_FREAD(3);
-        RG_FSTEP8(0) RG_FSTEP8(8) RG_FSTEP8(16) RG_FSTEP8(24)
+        RG_FSTEP8(0) RG_FSTEP8(8) RG_FSTEP8(16)
+        // (the partner's progress: one more read in the in-order LDS queue -- the counted waits only get stricter -- landed
+        // by the stage's last wait)
+        if (lead) asm volatile("ds_read_b32 %0, %1" : "=v"(partner_prog) : "v"(prog_partner_addr));
+        RG_FSTEP8(24)
+        if (lead) {
+          asm volatile("" : "+v"(partner_prog));
+          const int d = (s + 1) * C::SUBS - __builtin_amdgcn_readfirstlane(partner_prog);
+          if (d >= lead + 1) __builtin_amdgcn_s_setprio(0);
+          else if (d <= 1 - lead) __builtin_amdgcn_s_setprio(2);
+          else __builtin_amdgcn_s_setprio(1);
+        }
       }
 #undef RG_FSTEP8
 #undef RG_FSTEP
@@ -850,7 +901,8 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
 #endif
       if (s + C::SLOTS - 1 < nstages) {
         const int ws = (s + C::SLOTS - 1) & (C::SLOTS - 1);  // the slot stage s-1 lived in
-        fring_wait(freec + ws, (unsigned)(C::WAVES * ((s + C::SLOTS - 1) / C::SLOTS)));
+        const unsigned need = (unsigned)(C::WAVES * ((s + C::SLOTS - 1) / C::SLOTS));
+        fring_wait(freec + ws, need);
 #ifdef RG_TOPK_TIMING
         t4 = __builtin_amdgcn_s_memtime();
 #endif
@@ -865,10 +917,14 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
 #endif
     }
 #ifdef RG_TOPK_TIMING
-    if (lane == 0)
+    if (lane == 0) {
       for (int i = 0; i < 6; ++i) atomicAdd(&g_filter_timing[i], tw[i]);
+      atomicAdd(&g_filter_timing[6], tfl);   // (flushes inside the stage loop: part of `compute`)
+      atomicAdd(&g_filter_timing[7], nfl);
+    }
 #endif
     RG_RSTAMP(4);
+    if (lead) __builtin_amdgcn_s_setprio(0);
     flush();
     if constexpr (BOUND) flush_max();
     RG_RSTAMP(5);
@@ -2195,6 +2251,10 @@ static int launch_ring(FilterParams p, int64_t B, int prof_slot, hipStream_t st)
   const int CUS = filter_device_cus();
   p.xcd_map = p.qtiles >= 64 ? 1 : 0;
   p.wgs_per_group = CUS / (p.xcd_map ? 8 : 1);
+  {
+    const char* e = getenv("RAGRAPH_FILTER_PARTNER_LEAD");  // (read per call: A/B; 0 = equal priorities, the hardware's age order)
+    p.partner_lead = e ? atoi(e) : 1;
+  }
   // shortest piece of a key stream a workgroup takes: 8 stages when there is work for everybody, fewer on short launches
   // (a bound pass of 18 stages x 6 query tiles gave 14 workgroups 8 stages each and 242 nothing: 19 us of stage loop where
   // 108 workgroups need 2.5; tools/check_segment_plan.cpp covers lb_min = 1)
@@ -2254,8 +2314,9 @@ static int launch_ring(FilterParams p, int64_t B, int prof_slot, hipStream_t st)
     const double n = (double)t[5];
     if (n > 0)
       fprintf(stderr, "[filter timing] slot %d D=%d wave-stages=%.0f ticks/stage: wait_full %.1f compute %.1f signal+vmcnt "
-              "%.1f wait_free %.1f dma_issue %.1f total %.1f\n", prof_slot, D, n, t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n,
-              (t[0] + t[1] + t[2] + t[3] + t[4]) / n);
+              "%.1f wait_free %.1f dma_issue %.1f total %.1f; flushes in the loop: %.0f, %.1f ticks each = %.1f per stage\n",
+              prof_slot, D, n, t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n, (t[0] + t[1] + t[2] + t[3] + t[4]) / n, (double)t[7],
+              t[7] ? (double)t[6] / (double)t[7] : 0.0, t[6] / n);
     unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_filter_timing), zero, sizeof(zero));
   }
