@@ -431,9 +431,13 @@ __device__ unsigned long long g_filter_timing[8];
 // passing keys of one query: the larger of the two for both, an upper bound) -- in an int2 list of p.cap entries; the
 // rescoring (topk_rescore_scored_kernel) then scores the most promising entries first and never fetches the rows of
 // those whose I cannot reach the exact k-th best found that way.
-template <int D, int QW, bool BOUND = false, bool I8 = false, bool SCORED = false>
+// PIPE (int8 levels at D = 256): the epilogue of sub-tile u runs INSIDE the MFMA stream of sub-tile u + 1 -- two sets of
+// accumulators, the maxima of one query group after each of the next sub-tile's first steps, the candidate path behind them --
+// so a wave's vector work sits beside its OWN matrix work instead of waiting for the SIMD partner to be in the other phase.
+template <int D, int QW, bool BOUND = false, bool I8 = false, bool SCORED = false, bool PIPE = false>
 __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
   using C = FilterCfg<I8 ? D / 2 : D>;
+  static_assert(!PIPE || (I8 && !BOUND && C::KSTEPS >= QW / 16 + 2), "PIPE: int8 filter levels, one step per query group + 2");
   static_assert(!(I8 && BOUND), "the bound pass runs on the bf16 copy");
   static_assert(I8 || !SCORED, "scored lists carry the int8 levels' integer sums");
   static_assert(QW == 32 || QW == 64 || QW == 96 || QW == 128, "two, four, six or eight query groups of 16 per wave");
@@ -686,7 +690,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     // per phase -- MFMAs high / epilogue low and the reverse -- and shares of the DMA deferred instead of waited for: all
     // within noise or slower).
     int* prog = reinterpret_cast<int*>(freec + C::SLOTS);  // [WAVES]
-    const int lead = p.partner_lead;
+    const int lead = BOUND ? 0 : p.partner_lead;   // (the bound pass's epilogue is eight maxima: nothing to arbitrate for)
     if (lead) {
       if (lane == 0) prog[wave] = 0;
       __builtin_amdgcn_s_setprio(1);
@@ -695,12 +699,25 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     const unsigned prog_partner_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(prog + (wave ^ (C::WAVES / 2)));
 
     int pending = -1;
+    // PIPE: accumulators of the sub-tile in flight and of the one whose epilogue is running (sets alternate per sub-tile and
+    // live across stages); the "previous sub-tile" of a segment's first one is a set no threshold admits
+    using accp_t = typename std::conditional<I8, i32x4, f32x4>::type;
+    accp_t accp[2][2][NG];   // (unused without PIPE)
+    int pmi[NG];
+    bool phit = false;
+    if constexpr (PIPE) {
+#pragma unroll
+      for (int gq = 0; gq < NG; ++gq) {
+        accp[1][0][gq] = accp[1][1][gq] = accp_t{INT_MIN, INT_MIN, INT_MIN, INT_MIN};
+        pmi[gq] = INT_MIN;
+      }
+    }
 #ifdef RG_TOPK_TIMING
     unsigned long long tw[6] = {0, 0, 0, 0, 0, 0};
 #endif
     for (int s = 0; s < nstages; ++s) {
       const int slot = s & (C::SLOTS - 1), gen = s / C::SLOTS;
-      if ((s & 0x7FFF) == 0 && s > 0) {  // keep the entries' key offsets inside 25 bits
+      if (!PIPE && (s & 0x7FFF) == 0 && s > 0) {  // keep the entries' key offsets inside 25 bits
         flush();
         key_org += 0x8000 * C::STAGE_KEYS;
       }
@@ -821,6 +838,36 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
           push_groups(km, mi, (unsigned)(key_base - key_org));
         }
       };
+      // PIPE: the same epilogue in pieces -- one group's maxima per step, then the candidate path -- over the OTHER set
+      auto epi_fast = [&](const acc_t (&a)[2][NG], int gq) {
+        int m = as_bits(a[0][gq][0]);
+#pragma unroll
+        for (int r = 1; r < 4; ++r) m = max(m, as_bits(a[0][gq][r]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = max(m, as_bits(a[1][gq][r]));
+        pmi[gq] = m;
+        phit = phit || (m >= thr_i[gq]);
+      };
+      auto epi_slow = [&](const acc_t (&a)[2][NG], int stage_key0, int u) {
+        if (__any(phit)) {
+          const int key_base = stage_key0 + 32 * u + 4 * g;
+          unsigned km[NG];
+#pragma unroll
+          for (int gq = 0; gq < NG; ++gq) {
+            km[gq] = 0;
+            if (__any(pmi[gq] >= thr_i[gq])) km[gq] = pass_mask(a, gq);
+          }
+          if (stage_key0 + C::STAGE_KEYS > (int)p.N) {
+            unsigned vm = 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) vm |= (key_base + (r & 3) + 16 * (r >> 2) < (int)p.N) ? (1u << r) : 0u;
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) km[gq] &= vm;
+          }
+          push_groups(km, pmi, (unsigned)(key_base - key_org));
+        }
+        phit = false;
+      };
       // ---- SUBS sub-tiles of 32 keys x QW queries, KSTEPS fragments each (k-step major: both 16-key halves of a step);
       // one A fragment feeds all NG query groups.
       // A step is only 64 cycles of MFMA, less than an LDS round trip, so the fragment reads run FOUR steps ahead of
@@ -828,8 +875,9 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
       // loads, invisible to hipcc's waitcnt bookkeeping: RG_FWAIT counts them (LDS returns in order; anything else
       // outstanding only makes the wait stricter) and names the fragment so its MFMAs stay behind the wait.
       const unsigned addr = apos + (unsigned)(slot * C::STAGE_BYTES);
-      acc_t acc[2][NG];
+      acc_t acc[2][NG];   // (PIPE: accp instead)
       f32x4 fr[4];
+      const int stage_key0_now = (int)((p.stage_base + st0 + s) * C::STAGE_KEYS);
 #define RG_FREAD(n_)                                                                                       \
   asm volatile("ds_read_b128 %0, %1 offset:%2"                                                             \
                : "=v"(fr[(n_)&3])                                                                           \
@@ -837,14 +885,24 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
 #define RG_FWAIT(c_, n_) asm volatile("s_waitcnt lgkmcnt(" #c_ ")" : "+v"(fr[(n_)&3]))
 #define RG_FSTEP(n_)                                                                                       \
   {                                                                                                        \
-    if constexpr ((n_) % C::KSTEPS == 0) {                                                                 \
-      _Pragma("unroll") for (int gq = 0; gq < NG; ++gq) acc[0][gq] = acc[1][gq] = acc_t{0, 0, 0, 0};       \
+    constexpr int u_ = (n_) / C::KSTEPS, r_ = (n_) % C::KSTEPS, set_ = u_ & 1;                             \
+    if constexpr (r_ == 0) {                                                                               \
+      if constexpr (PIPE) {                                                                                \
+        _Pragma("unroll") for (int gq = 0; gq < NG; ++gq) accp[set_][0][gq] = accp[set_][1][gq] = acc_t{0, 0, 0, 0}; \
+      } else {                                                                                             \
+        _Pragma("unroll") for (int gq = 0; gq < NG; ++gq) acc[0][gq] = acc[1][gq] = acc_t{0, 0, 0, 0};     \
+      }                                                                                                    \
     }                                                                                                      \
     if constexpr ((n_) + 3 < C::NSTEP) RG_FWAIT(3, n_);                                                     \
     else if constexpr ((n_) + 2 < C::NSTEP) RG_FWAIT(2, n_);                                                \
     else if constexpr ((n_) + 1 < C::NSTEP) RG_FWAIT(1, n_);                                                \
     else RG_FWAIT(0, n_);                                                                                   \
-    if constexpr (I8) {                                                                                    \
+    if constexpr (I8 && PIPE) {                                                                            \
+      const i32x4 a_ = __builtin_bit_cast(i32x4, fr[(n_)&3]);                                               \
+      _Pragma("unroll") for (int gq = 0; gq < NG; ++gq)                                                     \
+        accp[set_][(n_) & 1][gq] = __builtin_bit_cast(acc_t, __builtin_amdgcn_mfma_i32_16x16x64_i8(         \
+            a_, bqi[gq][((n_) >> 1) % C::KS32], __builtin_bit_cast(i32x4, accp[set_][(n_) & 1][gq]), 0, 0, 0)); \
+    } else if constexpr (I8) {                                                                             \
       const i32x4 a_ = __builtin_bit_cast(i32x4, fr[(n_)&3]);                                               \
       _Pragma("unroll") for (int gq = 0; gq < NG; ++gq)                                                     \
         acc[(n_) & 1][gq] = __builtin_bit_cast(acc_t, __builtin_amdgcn_mfma_i32_16x16x64_i8(                \
@@ -856,10 +914,26 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
             a_, bq[gq][((n_) >> 1) % C::KS32], __builtin_bit_cast(f32x4, acc[(n_) & 1][gq]), 0, 0, 0));     \
     }                                                                                                      \
     if constexpr ((n_) + 4 < C::NSTEP) RG_FREAD((n_) + 4);                                                  \
-    if constexpr ((n_) % C::KSTEPS == C::KSTEPS - 1) {                                                     \
-      epilogue((n_) / C::KSTEPS, acc);                                                                     \
+    if constexpr (PIPE) {                                                                                  \
+      /* the previous sub-tile (the other set): group r - 1 behind step r, the candidate path behind step NG + 1 */ \
+      if constexpr (r_ >= 1 && r_ <= NG) epi_fast(accp[set_ ^ 1], r_ - 1);                                 \
+      if constexpr (r_ == NG + 1) {                                                                        \
+        epi_slow(accp[set_ ^ 1], u_ == 0 ? stage_key0_now - C::STAGE_KEYS : stage_key0_now, u_ == 0 ? C::SUBS - 1 : u_ - 1); \
+        if constexpr (u_ == 0) {                                                                           \
+          if ((s & 0x7FFF) == 0 && s > 0) { /* keep the entries' key offsets inside 25 bits */             \
+            flush();                                                                                       \
+            key_org += 0x8000 * C::STAGE_KEYS;                                                             \
+          }                                                                                                \
+        }                                                                                                  \
+      }                                                                                                    \
+      if constexpr (r_ == C::KSTEPS - 1) {                                                                 \
+        if (lead && lane == 0)                                                                             \
+          __hip_atomic_store(prog + wave, s * C::SUBS + u_ + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+      }                                                                                                    \
+    } else if constexpr (r_ == C::KSTEPS - 1) {                                                            \
+      epilogue(u_, acc);                                                                                   \
       if (lead && lane == 0)                                                                               \
-        __hip_atomic_store(prog + wave, s * C::SUBS + (n_) / C::KSTEPS + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        __hip_atomic_store(prog + wave, s * C::SUBS + u_ + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
     }                                                                                                      \
   }
 #define RG_FSTEP8(n_) RG_FSTEP(n_) RG_FSTEP((n_) + 1) RG_FSTEP((n_) + 2) RG_FSTEP((n_) + 3) \
@@ -876,6 +950,13 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
         // by the stage's last wait)
         if (lead) asm volatile("ds_read_b32 %0, %1" : "=v"(partner_prog) : "v"(prog_partner_addr));
         RG_FSTEP8(24)
+        if constexpr (PIPE) {  // the segment's last sub-tile: no next sub-tile for its epilogue to ride in
+          if (s == nstages - 1) {
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) epi_fast(accp[(C::SUBS - 1) & 1], gq);
+            epi_slow(accp[(C::SUBS - 1) & 1], stage_key0_now, C::SUBS - 1);
+          }
+        }
         if (lead) {
           asm volatile("" : "+v"(partner_prog));
           const int d = (s + 1) * C::SUBS - __builtin_amdgcn_readfirstlane(partner_prog);
@@ -2244,7 +2325,7 @@ static int rescore_slices(int64_t B, int k) {
 }
 
 // Ring-kernel launch shared by the filter levels and the bound pass (B > 256: the direct kernel takes smaller batches).
-template <int D, int QW, bool BOUND, bool I8 = false, bool SCORED = false>
+template <int D, int QW, bool BOUND, bool I8 = false, bool SCORED = false, bool PIPE = false>
 static int launch_ring(FilterParams p, int64_t B, int prof_slot, hipStream_t st) {
   using C = FilterCfg<I8 ? D / 2 : D>;
   p.qtiles = cdiv(B, (int64_t)C::WAVES * QW);
@@ -2276,12 +2357,12 @@ static int launch_ring(FilterParams p, int64_t B, int prof_slot, hipStream_t st)
     if (depth_env >= 0) p.depth[v] = depth_env < p.depth[v] ? depth_env : p.depth[v];
   }
   static DeviceOnce lds_once;  // per template instance and device (common.h)
-  if (hipError_t e = raise_dynamic_lds(lds_once, &topk_filter_kernel<D, QW, BOUND, I8, SCORED>, (int)C::LDS_BYTES); e != hipSuccess) {
+  if (hipError_t e = raise_dynamic_lds(lds_once, &topk_filter_kernel<D, QW, BOUND, I8, SCORED, PIPE>, (int)C::LDS_BYTES); e != hipSuccess) {
     set_error("topk_cosine_filtered: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
     return RAGRAPH_EDEVICE;
   }
   if (t_prof) (void)hipEventRecord(t_prof->ev[2 * prof_slot], st);
-  hipLaunchKernelGGL((topk_filter_kernel<D, QW, BOUND, I8, SCORED>), dim3((unsigned)CUS), dim3(C::THREADS), C::LDS_BYTES, st, p);
+  hipLaunchKernelGGL((topk_filter_kernel<D, QW, BOUND, I8, SCORED, PIPE>), dim3((unsigned)CUS), dim3(C::THREADS), C::LDS_BYTES, st, p);
   if (t_prof) (void)hipEventRecord(t_prof->ev[2 * prof_slot + 1], st);
   RG_CHECK_LAUNCH("topk_cosine_filtered(filter)");
 #ifdef RG_RING_STAMPS
@@ -2369,6 +2450,16 @@ static int run_bf16_pass(const FilterWs& f, const uint16_t* Kb, int64_t B, int64
       const int qw = qw_env ? qw_env : (D == 64 && fits(1024) ? 128 : (fits(768) ? 96 : 64));
       const bool long128 = qw == 128 && cdiv(B, (int64_t)1024) * p.nstages_total >= 32 * (int64_t)filter_device_cus();
       const bool long96 = qw == 96 && cdiv(B, (int64_t)768) * p.nstages_total >= 32 * (int64_t)filter_device_cus();
+      if constexpr (D == 256) {
+        // four groups per wave: the epilogue of a sub-tile inside the next one's MFMAs (PIPE: 222 VGPRs) -- 512 x 1M 0.213 ->
+        // 0.2005 ms, 1024 0.324 -> 0.308, 4096 1.053 -> 1.026, 16 384 3.53 -> 3.49; on the long streams that take six groups
+        // it only draws level (13.03 vs 13.03 - 13.13 ms: six groups in one set of accumulators stay).  RAGRAPH_FILTER_PIPE=0/2: A/B
+        const char* pe = getenv("RAGRAPH_FILTER_PIPE");  // (read per call)
+        const int pv = pe ? atoi(pe) : 1;
+        if ((pv == 1 && !long128 && !long96) || pv == 2)
+          return scored ? launch_ring<D, 64, false, true, true, true>(p, B, prof_slot, st)
+                        : launch_ring<D, 64, false, true, false, true>(p, B, prof_slot, st);
+      }
       if (scored) {
         if (long128) return launch_ring<D, 128, false, true, true>(p, B, prof_slot, st);
         if (long96) return launch_ring<D, 96, false, true, true>(p, B, prof_slot, st);
