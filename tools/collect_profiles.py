@@ -61,7 +61,7 @@ out = {
 def find(kind):
     """The filter kernel's PMC name for a kind of launch, whatever its queries-per-wave template argument."""
     for nm in fe:
-        m = re.match(r"ragraph::topk_filter_kernel<256, (\d+), (true|false), (true|false)(?:, (?:true|false))?>", nm)
+        m = re.match(r"ragraph::topk_filter_kernel<256, (\d+), (true|false), (true|false)(?:, (?:true|false))*>", nm)
         if m and (m.group(2), m.group(3)) == {"int8": ("false", "true"), "bf16": ("false", "false"), "bound": ("true", "false")}[kind]:
             return nm
     return None
