@@ -33,6 +33,11 @@ class KeyIndex:
     # bank with a 3000-key cluster around the queries 665 -- 64 on bf16 --, nothing overflowing: tools/stats_probe.py)
     I8_MAX_CANDIDATES_BASE = 300.0
     I8_MAX_CANDIDATES_PER_KEY = 1.2e-3
+    # A demotion (int8 -> bf16, filter -> fp32 kernels) is a verdict on the QUERIES seen so far as much as on the bank: after
+    # this many more queries the bank is tried one level up again, on a call of at most REPROBE_MAX_BATCH queries (a probe that
+    # overflows costs an exact scan per overflowed query); a probe that fails demotes again and quadruples the interval.
+    REPROBE_QUERIES = 1 << 20
+    REPROBE_MAX_BATCH = 4096
     DEDUP_MIN_ROWS = 2048
     DEDUP_MAX_UNIQUE = 0.9
     DEDUP_MAX_GROUP = 64
@@ -49,6 +54,10 @@ class KeyIndex:
         self._pending = None      # (pinned word, event, batch, had int8 levels) of the last filtered call's overflow count
         self._i8_ok = None        # the int8 copy's error row read (once, lazily): accurate enough for int8 levels?
         self._seen_i8, self._seen_bf16 = [0, 0], [0, 0]   # [queries, overflowed] of the polled calls with / without int8
+        self._queries = 0                                  # queries answered so far (the clock of the re-probes)
+        self._demoted = {"i8": None, "filter": None}       # query count at the demotion, or None
+        self._reprobe_after = {"i8": self.REPROBE_QUERIES, "filter": self.REPROBE_QUERIES}
+        self._probed_at = {"i8": None, "filter": None}     # query count at the last re-probe
         self._host_word = self._event = None
         self._overflowed = 0
         self.last_i8_candidates = None   # candidates per query over the int8 levels of the last polled call (sampled)
@@ -117,7 +126,7 @@ class KeyIndex:
             if i8:
                 self.last_i8_candidates = sum(c for _, c in i8)
                 if self.last_i8_candidates > self.I8_MAX_CANDIDATES_BASE + self.I8_MAX_CANDIDATES_PER_KEY * sum(kk for kk, _ in i8):
-                    self._i8_off = True
+                    self._demote("i8")
         # judged over whole calls of >= 64 queries, or over the calls seen so far once they add up to 8 queries (graph
         # classification retrieves ONE query per forward: a bank that sends every such call to the exact scan must not stay)
         acc = self._seen_i8 if pend[3] else self._seen_bf16
@@ -125,12 +134,45 @@ class KeyIndex:
         acc[1] += n_over
         if (B >= 64 and n_over >= 2 and n_over > self.OVERFLOW_FRACTION * B) or (acc[0] >= 8 and 4 * acc[1] > acc[0]):
             if pend[3] and not i8_was_off:     # the call(s) had int8 levels: their wider bound is the first suspect
-                self._i8_off = True
+                self._demote("i8")
             else:
-                self._filter_off = True
+                self._demote("filter")
             acc[0] = acc[1] = 0
         elif acc[0] >= 4096:
             acc[0] = acc[1] = 0
+
+    def _demote(self, what: str):
+        """int8 -> bf16 levels ("i8") or filter -> fp32 kernels ("filter"), until the re-probe.  A demotion within one interval
+        of the previous re-probe of the same kind is a failed probe: the next one waits four times as long."""
+        if what == "i8":
+            self._i8_off = True
+        else:
+            self._filter_off = True
+        if self._demoted[what] is None:
+            probed_at = self._probed_at[what]
+            if probed_at is not None and self._queries - probed_at < self._reprobe_after[what]:
+                self._reprobe_after[what] = min(self._reprobe_after[what] * 4, 1 << 40)   # the probe failed
+            else:
+                self._reprobe_after[what] = self.REPROBE_QUERIES
+            self._demoted[what] = self._queries
+
+    def _maybe_reprobe(self, B: int):
+        """Before a dispatch: lift a demotion whose interval has passed (filter first: it is the larger loss), on a call small
+        enough that a failed probe is cheap."""
+        if B > self.REPROBE_MAX_BATCH:
+            return
+        for what in ("filter", "i8"):
+            at = self._demoted[what]
+            if at is not None and self._queries - at >= self._reprobe_after[what]:
+                if what == "i8":
+                    self._i8_off = False
+                    self._seen_i8 = [0, 0]
+                else:
+                    self._filter_off = False
+                    self._seen_bf16 = [0, 0]
+                self._demoted[what] = None
+                self._probed_at[what] = self._queries
+                return
 
     def _note_overflow(self, over, B: int, had_i8: bool, stats=None):
         """After a filtered call: its overflow count travels to a pinned host word behind an event (no wait) and is
@@ -200,6 +242,8 @@ class KeyIndex:
                 return s, i
             fhelps = None  # (fp32 kernels: the shard's own exact top-k, no exchange needed)
         self._poll_overflow()
+        self._maybe_reprobe(B)
+        self._queries += B
         fused = getattr(ops, "fused_helps", None)
         if fused is not None and not self._filter_off and fused(B, kn.shape[0], D, k):  # small bank: every phase in one launch
             if self._bf16 is None:

@@ -388,3 +388,58 @@ def test_segment_plan_covers_every_stage_once(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:]
     assert "segment plans checked" in out.stdout
+
+
+def test_key_index_reprobes_a_demoted_bank_with_backoff():
+    """A demotion is lifted after REPROBE_QUERIES more queries, on a small call only; a probe that fails demotes again and the
+    next probe waits four times as long; a probe that holds stays (kernels_index.py)."""
+    import torch
+
+    from ragraph_amd.kernels_index import KeyIndex
+
+    class Done:
+        def query(self):
+            return True
+
+    def poll(idx, n_over, B, had_i8):
+        idx._pending = (torch.tensor([n_over], dtype=torch.int32), Done(), B, had_i8)
+        idx._poll_overflow()
+
+    idx = KeyIndex(torch.zeros(4, 8), ops=object())
+    R = KeyIndex.REPROBE_QUERIES
+    poll(idx, 1600, 100_000, True)
+    assert idx._i8_off and idx._demoted["i8"] == 0
+    idx._queries = R - 1
+    idx._maybe_reprobe(512)
+    assert idx._i8_off                       # not yet
+    idx._queries = R
+    idx._maybe_reprobe(100_000)
+    assert idx._i8_off                       # not on a large call
+    idx._maybe_reprobe(512)
+    assert not idx._i8_off and idx._demoted["i8"] is None
+    poll(idx, 200, 512, True)                # the probe overflowed: demoted again, the interval quadrupled
+    assert idx._i8_off and idx._reprobe_after["i8"] == 4 * R and idx._demoted["i8"] == R
+    idx._queries = 2 * R
+    idx._maybe_reprobe(512)
+    assert idx._i8_off
+    idx._queries = 5 * R
+    idx._maybe_reprobe(512)
+    assert not idx._i8_off
+    poll(idx, 0, 512, True)                  # this probe holds
+    poll(idx, 0, 4096, True)
+    assert not idx._i8_off and idx._reprobe_after["i8"] == 4 * R
+    idx._queries = 50 * R                    # a demotion long after a probe that held is a new story: the base interval
+    poll(idx, 1600, 100_000, True)
+    assert idx._i8_off and idx._reprobe_after["i8"] == R
+    idx._queries = 51 * R
+    idx._maybe_reprobe(512)
+    assert not idx._i8_off
+    # the filter itself: lifted before int8 when both are down
+    poll(idx, 1600, 100_000, True)
+    poll(idx, 1600, 100_000, False)
+    assert idx._i8_off and idx._filter_off
+    idx._queries = 100 * R
+    idx._maybe_reprobe(64)
+    assert not idx._filter_off and idx._i8_off
+    idx._maybe_reprobe(64)
+    assert not idx._i8_off
