@@ -943,7 +943,13 @@ static int small_prefix_keys(int B, bool i8) {
   // keys of the bound pass's prefix (with G = 4 k parts the bound is worth the exact k-th best of ~0.85 of it): one query's
   // call streams 16 K keys of the bf16 copy before its pass over the int8 copy; more queries buy a sharper bound with a
   // longer prefix (their candidates cost B times as much).  The int8 bound is ~5x wider: twice the prefix.
-  const int base = B <= 1 ? 8192 : (B <= 8 ? 16384 : 32768);
+  // (9 .. 16 queries: 24 576 x 2 keys = 1536 units = one per wave of 192 workgroups -- 16 queries 0.081 -> 0.076 ms against
+  // 32 768, 9: 0.073 -> 0.070; 20 480 / 28 672: 0.077 - 0.078)
+  int base = B <= 1 ? 8192 : (B <= 8 ? 16384 : (B <= 16 ? 24576 : 32768));
+  if (const char* e = getenv("RAGRAPH_SMALL_PREFIX_BASE")) {  // (experiments; read per call)
+    const int v = atoi(e);
+    if (v >= 4096) base = v;
+  }
   return i8 ? 2 * base : base;
 }
 
