@@ -2090,6 +2090,19 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
     }
   }
   sc.bound_keys = bound ? (best_nA ? best_nA : prefix_for(4096)) : 0;
+  if (bound && B > 128 && B <= 256 && n_shards == 1) {
+    // the direct kernel deals the prefix's 16-KiB units over all waves of the chip in contiguous runs: 2.4 units per wave take
+    // as long as 3 -- a prefix of whole rounds (8 waves x CUs units) costs what it reads: 256 queries x 1M 0.1406 -> 0.1381 ms,
+    // 192: 0.1198 -> 0.1180 (up to 128 queries, whose pass is cheaper per key, the shorter prefix loses more than it saves:
+    // 64 queries 0.110 -> 0.116).  RAGRAPH_FILTER_BOUND_ROUNDS=0: A/B
+    static const int align_env = [] { const char* e = getenv("RAGRAPH_FILTER_BOUND_ROUNDS"); return e ? atoi(e) : 1; }();
+    if (align_env) {
+      const int64_t round_keys = (int64_t)8 * filter_device_cus() * (16384 / (2 * D));
+      int64_t r = (sc.bound_keys + round_keys / 2) / round_keys;
+      if (r < 1) r = 1;
+      if (r * round_keys * 4 <= N && r * round_keys >= (int64_t)k * 4 * (FILTER_STAGE_BYTES / (2 * D))) sc.bound_keys = r * round_keys;
+    }
+  }
   sc.n0 = best_n0;
   sc.i8_levels = mid_i8 ? best_L : best_i8;
   sc.slab0 = 1;
