@@ -1,6 +1,6 @@
 """The dispatch rules (KeyIndex, kernels.*_helps, the schedule's cost model) against the clock: for a spread of shapes the
 product path is timed next to its forced alternatives -- int8 levels capped to bf16, scored lists off, the single-launch
-kernels off, the fp32 kernels -- and must be within 10 % (+ 4 us) of the fastest, so that the environment switches of
+kernels off, the fp32 kernels, the ring kernel without its wave priorities / pipelined epilogue -- and must be within 10 % (+ 4 us) of the fastest, so that the environment switches of
 DESIGN.md section 6 cannot silently rot.  Same bits on every path (checked)."""
 import os
 
@@ -30,8 +30,9 @@ SHAPES = [  # B, N, D, k, alternatives
     (1, 1_000_000, 256, 10, ("small_off", "fp32")),
     (16, 1_000_000, 256, 10, ("small_off", "i8_off")),
     (256, 1_000_000, 256, 10, ("i8_off", "scored_off")),
-    (4096, 1_000_000, 256, 10, ("i8_off", "scored_off")),
-    (20_000, 500_000, 128, 10, ("i8_off",)),
+    (4096, 1_000_000, 256, 10, ("i8_off", "scored_off", "pipe_off", "lead_off")),
+    (512, 1_000_000, 256, 10, ("pipe_off", "lead_off")),
+    (20_000, 500_000, 128, 10, ("i8_off", "lead_off")),
     (2708, 10_000, 64, 5, ("fused_off",)),
     (8192, 5_000, 128, 5, ("fused_off",)),
     (4096, 4_000_000, 64, 10, ("i8_off",)),
@@ -64,6 +65,10 @@ def test_product_dispatch_is_within_ten_percent_of_the_best_alternative(dev, mon
                 m.setenv("RAGRAPH_FILTER_SCORED", "0")
             elif alt == "fp32":
                 m.setenv("RAGRAPH_EXACT_FP32", "1")
+            elif alt == "pipe_off":         # the four-group int8 ring kernel without the epilogue in the next sub-tile's MFMAs
+                m.setenv("RAGRAPH_FILTER_PIPE", "0")
+            elif alt == "lead_off":         # equal wave priorities in the ring kernel (the hardware's age order)
+                m.setenv("RAGRAPH_FILTER_PARTNER_LEAD", "0")
             elif alt == "i8_off":           # (KeyIndex caps the int8 levels per bank: the bank is taken off int8 for this leg)
                 old_cap = index._i8_off
                 index._i8_off = True
