@@ -68,13 +68,18 @@ int ragraph_normalize_rows_f32(const float* X, int64_t n, int D, float* out, voi
  *   Q   [B,D] raw (un-normalised) queries; normalised inside (a1) into the workspace.
  *   Kn  [N,D] key bank ALREADY row-normalised by ragraph_normalize_rows_f32 (done once per bank version; the
  *       reference re-normalises its stored keys on every call, SimilarityFunctions.py:11).
- *   k   1 <= k <= min(N, RAGRAPH_TOPK_MAX) (larger k: ragraph_topk_select_rows_f32 over score slabs).  D in {64,128,256}.  B,N >= 1.  B <= 128 takes the wave-streaming
+ *   k   1 <= k <= min(N, RAGRAPH_TOPK_MAX) (larger k: ragraph_topk_select_rows_f32 over score slabs).  B,N >= 1.
+ *       Any D >= 1, as the reference (SimilarityFunctions.py:6-16 takes every emb_size): the fused kernels are written
+ *       for D in {64,128,256}; every other width takes materialised score slabs (~1 GiB of the workspace: dense kernel +
+ *       row top-k, banks beyond 2^22 rows in key chunks merged in canonical order) -- the same fmaf chains, the same
+ *       bits.  (A bank narrower than 256 columns is better zero-padded ONCE to the next fused width by its owner, as
+ *       ragraph_amd.KeyIndex does: zero columns change no bit of a norm or a score.)  B <= 128 takes the wave-streaming
  *       kernel (groups of 16 queries on 16x16x4 MFMA; HBM-bound up to 16 queries), larger B the MFMA-bound tile
  *       kernel (256 queries per workgroup on 32x32x2); same numerics, so B never changes a bit of the result.
  *       32 < k <= 64 materialises ~1 GiB slabs of scores in the workspace (dense kernel + row top-k), same bits.
  *   idx_base  added to every returned index (this shard's first global row).
  *   out_scores [B,k] fp32 descending; out_idx [B,k] int64 (torch indexing dtype).
- *   Unsupported (returns RAGRAPH_EUNSUPPORTED): other D, k > RAGRAPH_TOPK_MAX, shards of >= 2^31 rows.  NaN scores are never selected
+ *   Unsupported (returns RAGRAPH_EUNSUPPORTED): k > RAGRAPH_TOPK_MAX, shards of >= 2^31 rows.  NaN scores are never selected
  *   (torch.topk would rank NaN first) -- inputs are finite by contract.
  */
 #define RAGRAPH_TOPK_MAX 64

@@ -1044,10 +1044,26 @@ static int64_t slab_rows_for(int64_t B, int64_t N) {
   return rows < B ? rows : B;
 }
 
+// Any other row width (the reference accepts every emb_size: SimilarityFunctions.py:6-16) takes the slab path: row norms,
+// the dense kernel and the row top-k are written for any D -- the same fmaf chains, hence the same bits as the oracle.
+static bool fused_width(int D) { return D == 64 || D == 128 || D == 256; }
+
+// The dense kernel takes up to 65535 blocks of 64 columns per launch: longer banks are scored in key chunks whose
+// per-chunk lists are merged in canonical order.
+constexpr int64_t SLAB_KEY_CHUNK = (int64_t)1 << 22;
+
+static int64_t slab_chunks(int64_t N) { return cdiv(N, SLAB_KEY_CHUNK); }
+
+static size_t slab_workspace_bytes(int64_t B, int64_t N, int D, int k) {
+  const int64_t rows = slab_rows_for(B, N), G = slab_chunks(N), nc = cdiv(N, G);
+  size_t bytes = align_up((size_t)B * D * sizeof(float), 256) + align_up((size_t)rows * nc * sizeof(float), 256);
+  if (G > 1) bytes += align_up((size_t)G * rows * k * sizeof(float), 256) + align_up((size_t)G * rows * k * sizeof(int64_t), 256);
+  return bytes;
+}
+
 extern "C" size_t ragraph_topk_cosine_workspace_bytes(int64_t B, int64_t N, int D, int k) {
-  if (B < 1 || N < 1 || k < 1 || (D != 64 && D != 128 && D != 256)) return 0;
-  if (k > 32 || use_slab(B, N, D))
-    return align_up((size_t)B * D * sizeof(float), 256) + (size_t)slab_rows_for(B, N) * N * sizeof(float);
+  if (B < 1 || N < 1 || k < 1 || D < 1) return 0;
+  if (!fused_width(D) || k > 32 || use_slab(B, N, D)) return slab_workspace_bytes(B, N, D, k);
   TopkPlan pl = plan_topk(B, N, D, k);
   return pl.qn_bytes + pl.part_s_bytes + pl.part_i_bytes;
 }
@@ -1111,7 +1127,7 @@ extern "C" int ragraph_topk_cosine_bank_f32(const float* Q, int64_t B, const flo
   RG_REQUIRE(B >= 1 && N >= 1, RAGRAPH_EINVAL, "topk_cosine: B=%lld N=%lld must be >= 1", (long long)B, (long long)N);
   RG_REQUIRE(k >= 1 && k <= N, RAGRAPH_EINVAL, "topk_cosine: k=%d out of range for N=%lld (torch.topk raises too)", k,
              (long long)N);
-  RG_REQUIRE(D == 64 || D == 128 || D == 256, RAGRAPH_EUNSUPPORTED, "topk_cosine: D=%d not in {64,128,256}", D);
+  RG_REQUIRE(D >= 1, RAGRAPH_EINVAL, "topk_cosine: D=%d must be >= 1", D);
   RG_REQUIRE(k <= RAGRAPH_TOPK_MAX, RAGRAPH_EUNSUPPORTED, "topk_cosine: k=%d > %d not supported by the fused kernel", k,
              RAGRAPH_TOPK_MAX);
   RG_REQUIRE(N < (int64_t)INT_MAX - 1024, RAGRAPH_EUNSUPPORTED, "topk_cosine: shard rows must fit int32");
@@ -1119,17 +1135,41 @@ extern "C" int ragraph_topk_cosine_bank_f32(const float* Q, int64_t B, const flo
   // A handful of queries against a bank of a few thousand keys (graph classification: 16 graphs x the training set's
   // 1113): every key is still a candidate for every list, and the streaming kernel's cooperative inserts -- one
   // (query, key) at a time -- were 45 us of a 150 us forward.  The slab path (dense kernel + topk_rows) has no lists.
-  if (k > 32 || use_slab(B, N, D)) {  // materialised slabs, see slab_rows_for()
+  // Row widths other than 64 / 128 / 256 always take it (any D >= 1).
+  if (!fused_width(D) || k > 32 || use_slab(B, N, D)) {  // materialised slabs, see slab_rows_for()
     const size_t qn_bytes = align_up((size_t)B * D * sizeof(float), 256);
-    const int64_t rows = slab_rows_for(B, N);
-    RG_REQUIRE(ws_bytes >= qn_bytes + (size_t)rows * N * sizeof(float), RAGRAPH_EWORKSPACE, "topk_cosine: workspace too small");
+    const int64_t rows = slab_rows_for(B, N), G = slab_chunks(N), nc = cdiv(N, G);
+    const size_t s_bytes = align_up((size_t)rows * nc * sizeof(float), 256);
+    const size_t ps_bytes = G > 1 ? align_up((size_t)G * rows * k * sizeof(float), 256) : 0;
+    RG_REQUIRE(ws_bytes >= slab_workspace_bytes(B, N, D, k), RAGRAPH_EWORKSPACE, "topk_cosine: workspace too small");
+    RG_REQUIRE(G * k <= 4096, RAGRAPH_EUNSUPPORTED, "topk_cosine: %lld key chunks x k=%d exceed the merge", (long long)G, k);
+    hipStream_t st = as_stream(stream);
     float* Qn = reinterpret_cast<float*>(ws);
     float* S = reinterpret_cast<float*>(static_cast<char*>(ws) + qn_bytes);
+    float* part_s = reinterpret_cast<float*>(static_cast<char*>(ws) + qn_bytes + s_bytes);
+    int64_t* part_i = reinterpret_cast<int64_t*>(static_cast<char*>(ws) + qn_bytes + s_bytes + ps_bytes);
     int rc = ragraph_normalize_rows_f32(Q, B, D, Qn, stream);
     for (int64_t b0 = 0; rc == RAGRAPH_OK && b0 < B; b0 += rows) {
       const int64_t nb = (B - b0 < rows) ? B - b0 : rows;
-      rc = ragraph_linear_f32(Qn + b0 * D, nb, D, Kn, N, nullptr, RAGRAPH_ACT_NONE, 0.f, S, stream);
-      if (rc == RAGRAPH_OK) rc = ragraph_topk_rows_f32(S, nb, N, N, k, out_scores + b0 * k, out_idx + b0 * k, stream);
+      if (G == 1) {
+        rc = ragraph_linear_f32(Qn + b0 * D, nb, D, Kn, N, nullptr, RAGRAPH_ACT_NONE, 0.f, S, stream);
+        if (rc == RAGRAPH_OK) rc = ragraph_topk_rows_f32(S, nb, N, N, k, out_scores + b0 * k, out_idx + b0 * k, stream);
+        continue;
+      }
+      for (int64_t g = 0; rc == RAGRAPH_OK && g < G; ++g) {  // key chunks: lists [G][nb][k], indices made bank-relative
+        const int64_t n0 = g * nc, nn = (N - n0 < nc) ? N - n0 : nc;  // (balanced chunks: each far longer than k)
+        rc = ragraph_linear_f32(Qn + b0 * D, nb, D, Kn + n0 * D, nn, nullptr, RAGRAPH_ACT_NONE, 0.f, S, stream);
+        if (rc != RAGRAPH_OK) break;
+        rc = ragraph_topk_rows_f32(S, nb, nn, nn, k, part_s + g * nb * k, part_i + g * nb * k, stream);
+        if (rc == RAGRAPH_OK && n0 != 0) {
+          hipLaunchKernelGGL(add_idx_base_kernel, dim3((unsigned)cdiv(nb * k, 256)), dim3(256), 0, st, part_i + g * nb * k,
+                             nb * k, n0);
+          RG_CHECK_LAUNCH("topk_cosine(chunk base)");
+        }
+      }
+      if (rc == RAGRAPH_OK)
+        rc = launch_select<int64_t>(part_s, part_i, (int)G, nb, k, nb * k, (int64_t)k, (int64_t)0, out_scores + b0 * k,
+                                    out_idx + b0 * k, st);
     }
     if (rc == RAGRAPH_OK && idx_base != 0) {
       hipLaunchKernelGGL(add_idx_base_kernel, dim3((unsigned)cdiv(B * k, 256)), dim3(256), 0, as_stream(stream), out_idx,

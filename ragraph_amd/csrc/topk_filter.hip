@@ -2247,6 +2247,7 @@ extern "C" size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_
 }
 // The sharded entry plans for (plan_N, n_shards): its first sample can be another one than the single bank's of plan_N rows.
 extern "C" size_t ragraph_topk_cosine_filtered_sharded_workspace_bytes(int64_t B, int64_t plan_N, int D, int k, int n_shards) {
+  if (!filter_dim_ok(D)) return 0;  // (ragraph_topk_cosine_f32 alone takes other widths)
   const size_t a = filter_workspace_bytes(B, plan_N, D, k, n_shards), b = filter_workspace_bytes(B, plan_N, D, k, 1);
   const size_t c = ragraph_topk_cosine_workspace_bytes(B, plan_N, D, k);   // (a short shard's exact top-k)
   const size_t ab = a > b ? a : b;  // (exchange = NULL runs the single-bank schedule)

@@ -107,12 +107,37 @@ def packed_keys_help(B: int, D: int, k: int) -> bool:
     return B > 128 and D == 256 and k <= 14
 
 
+FUSED_WIDTHS = (64, 128, 256)   # row widths the fused / filtered top-k kernels are written for
+
+
+def padded_dim(D: int):
+    """The fused kernels' width that rows of D floats are zero-padded to (None beyond 256: such banks take the score-slab
+    path of ragraph_topk_cosine_f32, any D).  Zero columns change no bit of a result: a row norm's lane tree adds +0 terms,
+    a score's fmaf chain ends in fmaf(0, 0, acc) = acc (acc is never -0: the chain starts from +0)."""
+    for w in FUSED_WIDTHS:
+        if D <= w:
+            return w
+    return None
+
+
+def pad_cols(x: torch.Tensor, width: int) -> torch.Tensor:
+    """[n, D] -> [n, width] with zero columns behind (a copy; no arithmetic)."""
+    x = _f32c(x, "pad_cols.x")
+    if x.shape[1] == width:
+        return x
+    out = x.new_zeros((x.shape[0], width))
+    out[:, :x.shape[1]] = x
+    return out
+
+
 def topk_cosine(q: torch.Tensor, keys_normalized: torch.Tensor, k: int, idx_base: int = 0,
                 keys_packed: torch.Tensor | None = None):
     """Fused normalize(q) @ keys_normalized.T -> top-k.  Returns (scores [B,k] f32, idx [B,k] i64), canonical order.
 
     SimilarityFunctions.py:6-16 + ToyGraphBase.py:66-67.  `keys_normalized` must come from normalize_rows();
-    `keys_packed` (optional) from pack_keys(keys_normalized) -- same bits out, faster key stream for B > 128."""
+    `keys_packed` (optional) from pack_keys(keys_normalized) -- same bits out, faster key stream for B > 128.
+    Any D >= 1: widths other than 64 / 128 / 256 take materialised score slabs (dense kernel + row top-k, same bits);
+    KeyIndex pads banks narrower than 256 once and keeps them on the fused kernels."""
     L = _ready()
     q = _f32c(q, "topk_cosine.q")
     kn = _f32c(keys_normalized, "topk_cosine.keys")

@@ -46,6 +46,14 @@ class KeyIndex:
         if ops is None:
             from . import kernels as ops  # the HIP library; raises loudly without a GPU
         self.ops = ops
+        # Row widths the fused kernels are not written for (the reference takes any emb_size, SimilarityFunctions.py:6-16):
+        # up to 256 the bank is zero-padded ONCE to the next fused width and every query per call -- zero columns change no
+        # bit of a norm or a score (kernels.padded_dim) --; wider banks take the score-slab path of topk_cosine (any D).
+        self.dim = int(keys_normalized.shape[1])
+        pad = getattr(ops, "padded_dim", None)
+        self._width = pad(self.dim) if pad is not None else self.dim   # None: no fused kernel for this width
+        if self._width is not None and self._width != self.dim:
+            keys_normalized = ops.pad_cols(keys_normalized, self._width)
         self.keys_normalized = keys_normalized
         self._packed = None
         self._bf16 = None
@@ -210,6 +218,12 @@ class KeyIndex:
         decision that changes which collectives run is taken from plan_n -- the largest shard's size -- so that all
         ranks take it alike."""
         ops, kn = self.ops, self.keys_normalized
+        if q.shape[1] != self.dim:
+            raise ValueError(f"KeyIndex.topk: queries of {q.shape[1]} columns against a bank of {self.dim}")
+        if self._width is None:   # wider than every fused kernel: exact score slabs, this shard's own top-k (no exchange needed)
+            return ops.topk_cosine(q, kn, k, idx_base=idx_base)
+        if self._width != self.dim:
+            q = ops.pad_cols(q, self._width)
         B, D = q.shape
         if self._collapsed is None:
             self._judge_duplicates()

@@ -38,7 +38,11 @@ def test_pure_host_entry_points_work_without_gpu():
     L = N.lib()
     ws = L.ragraph_topk_cosine_workspace_bytes(4096, 1_000_000, 256, 10)
     assert ws >= 4096 * 256 * 4
-    assert L.ragraph_topk_cosine_workspace_bytes(10, 10, 100, 3) == 0  # unsupported D -> 0
+    # any row width (the reference takes every emb_size): widths without a fused kernel take score slabs
+    assert L.ragraph_topk_cosine_workspace_bytes(10, 10, 100, 3) >= 10 * 100 * 4 + 10 * 10 * 4
+    assert L.ragraph_topk_cosine_workspace_bytes(10, 10, 0, 3) == 0    # D < 1 -> 0
+    # banks longer than one dense launch's columns: key chunks + per-chunk lists
+    assert L.ragraph_topk_cosine_workspace_bytes(64, 9_000_000, 300, 10) >= 64 * 3_000_000 * 4 + 3 * 64 * 10 * 12
     # argument validation happens before any device work, so it is observable here
     rc = L.ragraph_topk_cosine_f32(None, 1, None, 1, 256, 1, 0, None, None, None, 0, None)
     assert rc == N.EINVAL and b"null" in L.ragraph_last_error()

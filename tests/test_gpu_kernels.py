@@ -323,10 +323,8 @@ def test_fuse_decode_same_bits_as_separate_entries(dev, n, D, H, C):
 def test_errors_are_loud(dev):
     from ragraph_amd import kernels as K
 
-    q = torch.randn(4, 100, device=dev)
-    kn = torch.randn(50, 100, device=dev)
     with pytest.raises(K.RagraphNativeError):
-        K.topk_cosine(q, kn, 5)  # D not in {64,128,256}
+        K.topk_cosine(torch.randn(4, 100, device=dev), torch.randn(50, 64, device=dev), 5)  # widths differ
     with pytest.raises(K.RagraphNativeError):
         K.topk_cosine(torch.randn(4, 64, device=dev), torch.randn(3, 64, device=dev), 5)  # k > N
     with pytest.raises(K.RagraphNativeError):
