@@ -24,8 +24,12 @@ the exact fp32 kernel (same indices and score bits required) and 4 of them again
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` for the dominant kernel (the bf16 MFMA
 filter of the exact top-k) and, at N = 1, next to the timed region: `retrieval_small_batch` (the reference's real batch
 sizes, B = 1 / 16 / 256 / 512 / 4096, HBM-bound up to a few hundred queries), `exact_fp32` (the same step on the fp32
-MFMA kernels alone), `gnn_fwd_nodes_per_s`, and `cpu_baseline` (the torch-CPU port of the reference's op chain,
-oracle/ref_torch.py: 1 warm-up + 3 repetitions of a 1024-query slab, median, plus the 'fair' pre-normalised-bank row).
+MFMA kernels alone), `gnn_fwd` (the metric's second half: GNN-forward nodes/s with SURVEY 8(d)'s byte model, the counter
+bytes of the same kernels, the CPU port's rate and a graph with structure), `configs` (c1, c3, few-shot, the c5-shaped
+single-GPU leg -- each with its rate and roofline fraction), `finetune_step` (forward + loss + backward + Adam of the node
+and edge flavours beside the torch-CPU restatement), `memory` (bytes of every bank image), and `cpu_baseline` (the
+torch-CPU port of the reference's op chain, oracle/ref_torch.py: 1 warm-up + 3 repetitions of a 1024-query slab, median,
+plus the 'fair' pre-normalised-bank row).  The blocks live in tools/bench_blocks.py.
 """
 from __future__ import annotations
 
@@ -48,7 +52,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: ~2.5 PF dense = 1024 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz
 INT8_MFMA_PEAK_TOPS = 5033.2    # same guide, Matrix cores: I8 "the cycles of the BF16 form at 2x the K, so 2x BF16 per clock"
 HBM_PEAK_GBS = 8000.0           # spec; ~6300 achievable
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r4_pmc_traffic.json")
+TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", f"r{r}_pmc_traffic.json") for r in (5, 4)) if os.path.exists(p)),
+                    os.path.join(ROOT, "profiles", "r5_pmc_traffic.json"))
 
 
 def parse():
@@ -65,10 +70,15 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (profiling runs)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` and `finetune_step` blocks (c1, c3, few-shot, c5)")
     ap.add_argument("--cpu-slab", type=int, default=1024, help="queries per CPU-baseline repetition (one slab)")
-    ap.add_argument("--shard", choices=("keys", "queries"), default="keys",
-                    help="N > 1: row-shard the key bank (north_star's layout; default) or split the query batch over "
-                         "the GPUs with the bank replicated")
+    ap.add_argument("--shard", choices=("keys", "queries", "hybrid"), default="keys",
+                    help="N > 1: row-shard the key bank (north_star's layout; default), split the query batch over the GPUs "
+                         "with the bank replicated, or both (--key-shards S key shards x N / S query groups)")
+    ap.add_argument("--key-shards", type=int, default=2, help="--shard hybrid: key shards per query group (2 x 4 at N = 8)")
+    ap.add_argument("--dist-timeout", type=float, default=120.0,
+                    help="N > 1: seconds a collective (and the watchdog over every rank's heartbeat) waits before the job "
+                         "exits non-zero with every rank's last phase")
     ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="G",
                     help="single process: time what rank 0 of a G-GPU job would compute (collectives replaced by their "
                          "local part); an estimate of the per-rank step for DESIGN.md, never the bench line of a real "
@@ -108,6 +118,88 @@ class EventTimer:
         self.events = []
 
 
+def _timeout(args):
+    import datetime
+
+    return datetime.timedelta(seconds=float(args.dist_timeout))
+
+
+class Heartbeat:
+    """N > 1: every rank keeps `<dir>/rank<r>.txt` = "<unix time> <phase>" up to date (bench phases, every collective and
+    every exchange of ragraph_amd.sharded); a watchdog thread per rank exits the process non-zero -- after printing EVERY
+    rank's last line to stderr -- when its own phase has not changed for `timeout` seconds: a hung exchange names the phase
+    each rank is waiting in instead of sitting until the driver's limit.  (os._exit from the thread: nothing is re-executed,
+    the launcher sees the non-zero code and ends the other ranks.)"""
+
+    def __init__(self, rank, world, timeout):
+        import tempfile
+        import threading
+
+        self.rank, self.world, self.timeout = rank, world, float(timeout)
+        self.dir = os.environ.get("RAGRAPH_HEARTBEAT_DIR") or os.path.join(
+            tempfile.gettempdir(), f"ragraph_bench_{os.environ.get('MASTER_PORT', '0')}")
+        os.makedirs(self.dir, exist_ok=True)
+        self.path = os.path.join(self.dir, f"rank{rank}.txt")
+        self.last = time.time()
+        self.phase = "start"
+        self.done = False
+        self("start")
+        self.thread = threading.Thread(target=self._watch, daemon=True)
+        self.thread.start()
+
+    def __call__(self, phase: str):
+        self.last, self.phase = time.time(), phase
+        try:
+            with open(self.path, "w") as f:
+                f.write(f"{self.last:.3f} {phase}\n")
+        except OSError:
+            pass
+
+    def report(self):
+        out = {}
+        for r in range(self.world):
+            try:
+                t, ph = open(os.path.join(self.dir, f"rank{r}.txt")).read().strip().split(" ", 1)
+                out[f"rank{r}"] = f"{ph} ({time.time() - float(t):.0f} s ago)"
+            except (OSError, ValueError):
+                out[f"rank{r}"] = "no heartbeat file"
+        return out
+
+    def _watch(self):
+        while not self.done:
+            time.sleep(min(5.0, self.timeout / 4))
+            if not self.done and time.time() - self.last > self.timeout:
+                print(json.dumps({"bench_watchdog": f"rank {self.rank}: no progress for {self.timeout:.0f} s in phase "
+                                                    f"'{self.phase}'", "ranks": self.report()}), file=sys.stderr, flush=True)
+                os._exit(124)
+
+    def stop(self):
+        self.done = True
+
+
+def preflight(rank, world, dev, backend, beat):
+    """Before anything large is built: does the process group see every rank?  all_reduce of ones, all_gather of every rank's
+    device index; rank 0 prints the record to STDERR (stdout stays the one JSON line) and every rank raises when a rank is
+    missing."""
+    from ragraph_amd import sharded as SH
+
+    beat("preflight all_reduce")
+    ones = torch.ones(1, device=dev, dtype=torch.int64)
+    SH.all_reduce(ones, dist.ReduceOp.SUM)
+    beat("preflight all_gather")
+    mine = torch.tensor([rank, dev.index if dev.index is not None else 0], device=dev, dtype=torch.int64)
+    seen = torch.empty((world, 2), device=dev, dtype=torch.int64)
+    SH.all_gather_into(seen, mine.reshape(1, 2))
+    rec = {"world_size": dist.get_world_size(), "all_reduce_of_ones": int(ones.item()), "backend": dist.get_backend(),
+           "rank_devices": {str(int(r)): int(d) for r, d in seen.tolist()}, "device_count": torch.cuda.device_count(),
+           "device_name": torch.cuda.get_device_name(dev)}
+    if rank == 0:
+        print(json.dumps({"ranks_seen": rec}), file=sys.stderr, flush=True)
+    if rec["all_reduce_of_ones"] != world or sorted(int(r) for r in rec["rank_devices"]) != list(range(world)):
+        raise SystemExit(f"bench.py: the process group does not see every rank: {rec}")
+    return rec
+
+
 def build_workload(args, dev, rank, world, shard, force_dist=False):
     from ragraph_amd import kernels as K
     from ragraph_amd.data import synthetic_bank, synthetic_big_graph
@@ -129,7 +221,32 @@ def build_workload(args, dev, rank, world, shard, force_dist=False):
     emu = args.emulate_rank_of
     G = emu if emu > 1 else world
     if G > 1 or force_dist:
-        if shard == "queries":
+        if shard == "hybrid":
+            from ragraph_amd.sharded import HybridLayout
+
+            S = args.key_shards
+            if emu > 1:   # rank 0 of emu = Q x S ranks: the exchanges of S shards, a Q-th of the queries
+                class _Slice:
+                    world, rank, collective = emu // S, 0, False
+
+                    def bounds(self, B):
+                        return shard_bounds(B, emu // S, 0)
+
+                    def gather_rows(self, local, B):
+                        return local
+                model.query_shard = _Slice()
+                lo, hi = shard_bounds(args.bank, S, 0)
+                model.toy_graph_base = ShardedToyGraphBase(Kb[lo:hi].contiguous(), Vb, Lb, lo, args.k, values_replicated=True,
+                                                           emulate_world=S)
+            else:
+                layout = HybridLayout(S, timeout=_timeout(args))
+                lo, hi = layout.key_rows(args.bank)
+                model.toy_graph_base = ShardedToyGraphBase(Kb[lo:hi].contiguous(), Vb, Lb, lo, args.k, group=layout.key_group,
+                                                           force_collectives=force_dist, values_replicated=True)
+                model.query_shard = layout.query_shard()
+                model.layout_name = layout.name
+            n_local = hi - lo
+        elif shard == "queries":
             if emu > 1:
                 class _Slice:  # rank 0 of `emu`, no process group
                     world, rank, collective = emu, 0, False
@@ -387,10 +504,9 @@ def cpu_baseline(args, model, feats, adj):
         return statistics.median(ts), ts
 
     with torch.no_grad():
-        t0 = time.perf_counter()
         h = ref_torch.gcn_layer(X, adj_cpu, p["W"], p["bias"], p["alpha"])
-        ref_torch.propagate(adj_cpu, h, model.query_graph_hop)
-        t_gnn = time.perf_counter() - t0
+        t_gnn, ts_gnn = timed(lambda: ref_torch.propagate(adj_cpu, ref_torch.gcn_layer(X, adj_cpu, p["W"], p["bias"], p["alpha"]),
+                                                          model.query_graph_hop), 1, 3)
         q = h[:slab].contiguous()
         t_ref, ts_ref = timed(lambda: ref_torch.retrieve(q, keys, vals, labs, args.k, slab=slab), 1, 3)
         kn = torch.nn.functional.normalize(keys, p=2, dim=-1)
@@ -423,14 +539,15 @@ def cpu_baseline(args, model, feats, adj):
             "cpu_model": host["cpu_model"], "affinity_cores": host["affinity_cores"], "cgroup_cpu_quota": host["cgroup_cpu_quota"],
             "os_cpu_count": host["os_cpu_count"], "sockets": host["sockets"], "torch_blas": host["torch_blas"],
             "torch_threads": torch.get_num_threads(),
-            "sample": f"GNN encode+{model.query_graph_hop}-hop on all {n} nodes ({t_gnn:.2f}s, torch sparse CSR) + retrieval of "
+            "sample": f"GNN encode+{model.query_graph_hop}-hop on all {n} nodes ({t_gnn:.2f}s, torch sparse CSR, median of 3) + retrieval of "
                       f"one slab of {slab} of the {n} queries vs the full {keys.shape[0]}x{keys.shape[1]} bank, 1 warm-up + 3 "
                       f"repetitions, median {t_ref:.2f}s (bank re-normalised per call as the reference does), extrapolated "
                       f"to {n} queries",
             "retrieval_only_queries_per_s": round(slab / t_ref, 2),
             "retrieval_rep_seconds": [round(t, 3) for t in ts_ref],
             "phases_one_slab": {**{k_: round(v, 4) for k_, v in phases.items()}, "score_gemm_GFLOPs": round(gemm_gflops, 1),
-                                "gnn_all_nodes_s": round(t_gnn, 3)},
+                                "gnn_all_nodes_s": round(t_gnn, 3), "gnn_rep_seconds": [round(t, 3) for t in ts_gnn],
+                                "gnn_nodes_per_s": round(n / t_gnn, 1)},
             "fair": {"value": round(n / est_fair, 2), "retrieval_only_queries_per_s": round(slab / t_fair, 2),
                      "rep_seconds": [round(t, 3) for t in ts_fair],
                      "note": "bank normalised once (ref_torch.retrieve(renormalize_bank=False) arithmetic), 1 warm-up + 3 "
@@ -457,11 +574,12 @@ def verify_retrieval(model, feats, adj, args, world, with_oracle):
         sharded = hasattr(tgb, "idx_base") and getattr(tgb, "collective", False)
         if sharded:
             s32, i32 = K.topk_cosine(hs, tgb.keys_normalized, k, idx_base=tgb.idx_base)
-            gs = torch.empty((world * 64, k), dtype=s32.dtype, device=s32.device)
-            gi = torch.empty((world * 64, k), dtype=i32.dtype, device=i32.device)
+            gw = tgb.world   # (the ranks that hold the shards: the whole job, or this rank's key group in the hybrid layout)
+            gs = torch.empty((gw * 64, k), dtype=s32.dtype, device=s32.device)
+            gi = torch.empty((gw * 64, k), dtype=i32.dtype, device=i32.device)
             all_gather_into(gs, s32.contiguous(), tgb.group)
             all_gather_into(gi, i32.contiguous(), tgb.group)
-            s32, i32 = K.topk_merge(gs.view(world, 64, k), gi.view(world, 64, k))
+            s32, i32 = K.topk_merge(gs.view(gw, 64, k), gi.view(gw, 64, k))
         else:
             s32, i32 = K.topk_cosine(hs, tgb.keys_normalized, k)
     ok_i, ok_s = torch.equal(i_all[rows], i32), torch.equal(s_all[rows], s32)
@@ -532,11 +650,22 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if args.backend == "gloo":
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=_timeout(args))
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=_timeout(args))
 
     from ragraph_amd import kernels as K
+
+    beat = lambda phase: None   # noqa: E731
+    hb = ranks_seen = None
+    if world > 1 or force_dist:
+        from ragraph_amd import sharded as SH
+
+        hb = Heartbeat(rank, world, args.dist_timeout)
+        beat = hb
+        SH.heartbeat = hb
+        ranks_seen = preflight(rank, world, dev, args.backend, beat)   # BEFORE the bank is built
+    beat("build workload")
 
     real_filter_helps = K.filter_helps
     if args.exact_fp32:
@@ -562,20 +691,20 @@ def main():
             L.ragraph_filter_profile_levels(prof, a_ms, a_i8, a_keys)
             level_ms.append([(s_, float(a_ms[s_]), int(a_i8[s_]), int(a_keys[s_])) for s_ in range(4) if a_ms[s_] > 0])
 
-    for _ in range(args.warmup):
+    for w_ in range(args.warmup):
+        beat(f"warm-up step {w_}")
         step()
     topk_timer.enabled = filt_timer.enabled = True
+    beat("timed steps")
     elapsed, out = timed_steps(step, args.steps, world, dev, grab_filter_ms)
     topk_timer.enabled = filt_timer.enabled = False
-    collectives = ranks_seen = None
+    collectives = None
     if world > 1 or force_dist:
-        # what the process group really is, and what its collectives cost: one more step OUTSIDE the timed region with every
-        # collective of ragraph_amd.sharded bracketed by events on the stream it is ordered on
+        # what its collectives cost: one more step OUTSIDE the timed region with every collective of ragraph_amd.sharded
+        # bracketed by events on the stream it is ordered on (what the process group is: `ranks_seen`, the pre-flight above)
         from ragraph_amd import sharded as SH
 
-        ones = torch.ones(1, device=dev, dtype=torch.int64)
-        SH.all_reduce(ones, dist.ReduceOp.SUM)
-        ranks_seen = {"world_size": dist.get_world_size(), "all_reduce_of_ones": int(ones.item()), "backend": dist.get_backend()}
+        beat("collective timing step")
         SH.collective_times.reset()
         SH.collective_times.enabled = True
         step()
@@ -595,7 +724,8 @@ def main():
 
     n = args.nodes
     G = max(world, args.emulate_rank_of, 1)
-    shard_div = G if args.shard == "queries" else 1
+    S_key = max(1, min(args.key_shards, G)) if args.shard == "hybrid" else (G if args.shard == "keys" else 1)
+    shard_div = G if args.shard == "queries" else (G // S_key if args.shard == "hybrid" else 1)
     n_q_local = -(-n // shard_div)  # queries this rank scores against its n_local keys
     traffic = None  # HBM-side GB per launch from the committed PMC run of this exact shape (cannot be sampled in-process)
     try:
@@ -611,7 +741,7 @@ def main():
     flops = 2.0 * n_q_local * n_local * args.dim
     filtered = len(filt_timer.events) > 0
     traffic_unit = ("GB per launch, HBM side = (2*FETCH_SIZE + WRITE_SIZE) from rocprofv3 --pmc (separate passes), "
-                    "profiles/r4_pmc_traffic.json")
+                    "profiles/" + os.path.basename(TRAFFIC_JSON))
     if filtered:
         # Dominant kernel = the filter kernel (ragraph::topk_filter_kernel), timed per launch by events the library records
         # around its launches on the launch stream.  A call launches it once per level -- the first on the bf16 copy
@@ -676,9 +806,15 @@ def main():
                f"(all_gather of each rank's best 2*ceil(k/G) lower bounds + k-th of the union), one all_to_all of the "
                f"per-shard lists to the rank that owns the rows, query-sharded tail, one all_gather of the [n, C] outputs "
                f"({args.backend})")
+    elif args.shard == "hybrid":
+        par = (f"{G // S_key} query groups x {S_key} key shards (rank = q * {S_key} + s): a rank scores its group's slice of the "
+               f"queries against its key shard, bound exchanges and the all_to_all of the lists stay inside the key group, two "
+               f"all_gathers of [., C] outputs (key group, query axis) ({args.backend})")
     else:
         par = (f"query batch split x{G}, bank replicated on every GPU (1 GB of 288 GB): no data-path collective, one RCCL "
                f"all_gather of the [n, C] outputs per step")
+    layout = {"keys": f"key-sharded x{G}", "queries": f"query-sharded x{G}",
+              "hybrid": f"hybrid {G // S_key}x{S_key} (query groups x key shards)"}[args.shard] if G > 1 else "single GPU"
     result = {
         "metric": "retrieved-queries/sec (RAGraph_node forward: GCN encode + cosine/top-k retrieval + 3-hop propagate + decode)",
         "value": round(n / (elapsed / args.steps), 1),
@@ -695,7 +831,7 @@ def main():
         "config": {"workload": f"RAGraph_node forward, synthetic {n}-node graph (F={args.feat}, mean degree ~10), "
                                f"{args.bank}-key x {args.dim}-d bank, k={args.k}, C={args.classes} "
                                f"(BASELINE.json configs[1])",
-                   "bank_rows_per_gpu": n_local,
+                   "bank_rows_per_gpu": n_local, "queries_per_gpu": n_q_local, "layout": layout,
                    "parallelism": "single GPU" if G == 1 else par},
         "roofline": roofline,
     }
@@ -706,26 +842,50 @@ def main():
         result["emulated"] = (f"rank 0 of a {args.emulate_rank_of}-GPU job ({args.shard}-sharded), collectives replaced by "
                               f"their local part: value is NOT a job throughput")
     extras = not args.no_extras and args.emulate_rank_of <= 1
-    if world > 1 and extras and args.shard == "keys":
-        # the other layout, right after: bank replicated, query batch split (every rank must take part)
+    if world > 1 and extras:
+        # the other layouts, right after (every rank must take part): bank replicated + query batch split, and -- from 4
+        # ranks -- query groups x key shards
         del model
         torch.cuda.empty_cache()
-        m2, f2, a2, _ = build_workload(args, dev, rank, world, "queries", force_dist)
+        others = [sh for sh in ("keys", "queries", "hybrid") if sh != args.shard and
+                  (sh != "hybrid" or (world >= 4 and world % args.key_shards == 0 and 1 < args.key_shards < world))]
+        for sh in others:
+            beat(f"layout {sh}: build")
+            m2, f2, a2, nl2 = build_workload(args, dev, rank, world, sh, force_dist)
 
-        def step2():
-            with torch.no_grad():
-                return m2(f2, a2)
-        for _ in range(max(args.warmup, 1)):
-            step2()
-        e2, _ = timed_steps(step2, args.steps, world, dev)
-        result["query_sharded"] = {"value": round(n / (e2 / args.steps), 1), "unit": "queries/s",
-                                   "ms_per_step": round(e2 / args.steps * 1e3, 3),
-                                   "parallelism": f"query batch split x{world}, bank replicated; same steps / warm-up"}
+            def step2():
+                with torch.no_grad():
+                    return m2(f2, a2)
+            for w_ in range(max(args.warmup, 1)):
+                beat(f"layout {sh}: warm-up step {w_}")
+                step2()
+            beat(f"layout {sh}: timed steps")
+            e2, _ = timed_steps(step2, args.steps, world, dev)
+            name = {"keys": "key_sharded", "queries": "query_sharded", "hybrid": "hybrid"}[sh]
+            result[name] = {"value": round(n / (e2 / args.steps), 1), "unit": "queries/s",
+                            "ms_per_step": round(e2 / args.steps * 1e3, 3), "bank_rows_per_gpu": nl2,
+                            "layout": getattr(m2, "layout_name", f"{name.replace('_', '-')} x{world}"),
+                            "note": "same steps / warm-up as the headline layout"}
+            del m2, f2, a2
+            torch.cuda.empty_cache()
     if world == 1 and extras:
-        result["gnn_fwd_nodes_per_s"] = round(gnn_only_rate(model, feats, adj, max(args.steps, 30)), 1)   # (0.6 ms each)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_blocks as BB
+
         K.filter_helps = real_filter_helps
+        cpu = None
+        if rank == 0 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args, model, feats, adj)
+        cores = cpu["cores"] if cpu else host_cpu_info()["cores_used"]
+        # both halves of BASELINE.json's metric: `value` above = retrieved queries/s of the whole forward; the GNN forward:
+        gnn = BB.gnn_fwd_block(model, feats, adj, reps=max(args.steps, 30),
+                               cpu_gnn_s=cpu["phases_one_slab"]["gnn_all_nodes_s"] if cpu else None, cpu_cores=cores)
+        gnn["structured_graph"] = BB.structured_graph_row(args.feat, args.dim, model.query_graph_hop, dev)
+        result["gnn_fwd"] = gnn
+        result["gnn_fwd_nodes_per_s"] = gnn["nodes_per_s"]
         result["retrieval_small_batch"] = small_batch_rates(model.toy_graph_base, args.dim, args.k, dev)
         result["retrieval_reference_bank"] = reference_bank_rates(args, dev, adj, feats)
+        result["memory"] = BB.memory_block(model.toy_graph_base)
         if not args.exact_fp32:
             # the same step on the fp32 MFMA kernels alone (the path the bf16 filter replaces bit for bit)
             K.filter_helps = lambda *a, **kw: False
@@ -743,10 +903,22 @@ def main():
                                                  "bound": "mfma", "achieved": round(a32, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                                  "unit": "TFLOP/s", "frac": round(a32 / FP32_MFMA_PEAK_TFLOPS, 4),
                                                  "launch_ms": round(t32, 3)}}
+        if not args.no_configs:
+            # the other configs of BASELINE.json (c1, c3, few-shot, c5-shaped single-GPU leg) and the fine-tuning steps, each
+            # with its rate and the roofline that bounds it (tools/bench_blocks.py)
+            ft = {"node_528": BB.finetune_node(dev, cores, "528", cpu=cpu is not None),
+                  "node_c2": BB.finetune_node(dev, cores, "c2", c2=(model, feats, adj), cpu=cpu is not None)}
+            result["configs"], m5 = BB.configs_block(dev)
+            ft["edge_c5"] = BB.finetune_edge(dev, cores, m5, cpu=cpu is not None)
+            del m5
+            result["finetune_step"] = ft
+        if cpu is not None:
+            result["cpu_baseline"] = cpu
     if verified is not None:
         result["verified"] = verified
-    if rank == 0 and world == 1 and extras and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args, model, feats, adj)
+    if hb is not None:
+        beat("done")
+        hb.stop()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist.is_initialized():

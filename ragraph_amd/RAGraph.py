@@ -58,6 +58,9 @@ class RAGraph(nn.Module):
         tgb = self.toy_graph_base
         queries = self._queries(pretrain_embedddings, g)
         if self.query_shard is not None and not self.training and self.flavour == "node":
+            if (getattr(tgb, "values_replicated", False) and hasattr(tgb, "retrieve_reduced_rows")
+                    and (tgb.collective or tgb.emulate_world > 1)):
+                return self._forward_hybrid(queries, pretrain_embedddings, g)
             return self._forward_query_shard(queries, pretrain_embedddings, g)
         if (not self.training and self.flavour == "node" and getattr(tgb, "values_replicated", False)
                 and hasattr(tgb, "retrieve_reduced_rows") and (tgb.collective or tgb.emulate_world > 1)):
@@ -154,6 +157,36 @@ class RAGraph(nn.Module):
         else:
             query_embeddings = Propagation.aggregate_k_hop_features(g, emb, self.query_graph_hop, rows=(lo, hi))
         return tgb.gather_output_rows(self._fuse_decode(query_embeddings, rag_embedding, rag_label), n)
+
+
+    def _forward_hybrid(self, queries, emb, g):
+        """Multi-GPU inference on Q query groups x S key shards (ragraph_amd.sharded.HybridLayout): `query_shard` splits the
+        batch over the query groups, `toy_graph_base` is the row-sharded bank of this rank's key group.  A rank filters its
+        group's slice of the queries against its key shard (exchanges with the S - 1 partners of its group only), finishes
+        its share of those rows -- merge, gathers, last hop, decoder -- and two all_gathers of [., C] outputs (key group,
+        query axis) put the whole result on every rank.  Row for row the arithmetic of forward()."""
+        from .sharded import HybridLayout as H
+
+        qs, tgb = self.query_shard, self.toy_graph_base
+        n = queries.shape[0]
+        qlo, qhi, lo, hi = H.rows(qs, tgb, n)
+        rows = (qlo + lo, qlo + hi)
+        side = None
+        if self.finetune and queries.is_cuda and n >= self.OVERLAP_MIN_NODES:  # (see forward(): propagation on a side stream)
+            main = torch.cuda.current_stream()
+            side = self._side_stream(queries.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                query_embeddings = Propagation.aggregate_k_hop_features(g, emb, self.query_graph_hop, rows=rows)
+        rag_embedding, rag_label, _ = H.retrieve_reduced_rows(qs, tgb, queries)
+        if not self.finetune:
+            return H.gather_output_rows(qs, tgb, rag_label, n)
+        if side is not None:
+            main.wait_stream(side)
+            query_embeddings.record_stream(main)
+        else:
+            query_embeddings = Propagation.aggregate_k_hop_features(g, emb, self.query_graph_hop, rows=rows)
+        return H.gather_output_rows(qs, tgb, self._fuse_decode(query_embeddings, rag_embedding, rag_label), n)
 
 
 class RAGraphGraph(RAGraph):

@@ -55,8 +55,19 @@ class CollectiveTimes:
 
 collective_times = CollectiveTimes()
 
+# Optional progress hook (bench.py, N > 1): a callable taking one short string, called BEFORE every collective of this module
+# and at every exchange of a filtered retrieval -- a rank that hangs in a collective (a peer that diverged, a dead link) has
+# then named the phase it is waiting in (bench.py writes it to a per-rank heartbeat file that its watchdog prints).
+heartbeat = None
+
+
+def _beat(what: str) -> None:
+    if heartbeat is not None:
+        heartbeat(what)
+
 
 def all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None) -> None:
+    _beat(f"all_gather {tuple(out.shape)}")
     end = collective_times.start("all_gather", out)
     if _staged(group, out, inp):
         host = torch.empty(out.shape, dtype=out.dtype)
@@ -69,6 +80,7 @@ def all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None) -> None:
 
 
 def all_to_all_single(out: torch.Tensor, inp: torch.Tensor, recv, send, group=None) -> None:
+    _beat(f"all_to_all {tuple(out.shape)}")
     end = collective_times.start("all_to_all", out)
     if _staged(group, out, inp):
         host = torch.empty(out.shape, dtype=out.dtype)
@@ -81,6 +93,7 @@ def all_to_all_single(out: torch.Tensor, inp: torch.Tensor, recv, send, group=No
 
 
 def all_reduce(t: torch.Tensor, op, group=None) -> None:
+    _beat(f"all_reduce {tuple(t.shape)}")
     end = collective_times.start("all_reduce", t)
     if _staged(group, t):
         host = t.cpu()
@@ -134,6 +147,62 @@ class QueryShard:
             a, b = shard_bounds(B, self.world, r)
             parts.append(out[r * per: r * per + (b - a)])
         return torch.cat(parts, 0)
+
+
+class HybridLayout:
+    """G = Q x S ranks: rank r = q * S + s holds KEY shard s of S and answers QUERY group q of Q -- the layout between the
+    two pure ones (S = G: key-sharded, every rank scores all queries against 1 / G of the keys and takes part in G-wide
+    exchanges at every phase; S = 1: query-sharded, bank replicated, no exchange).  With S = 2 at G = 8 a rank scores a
+    quarter of the queries against half of the keys and has ONE exchange partner: [B / Q, m] bound exchanges and one
+    all_to_all of its group's lists with that partner, then the tail on B / G rows; two all_gathers of [., C] outputs (key
+    group, then query axis) complete the step.  Every result row is the single-GPU row bit for bit: a score depends neither
+    on the query batch nor on the shard (include/ragraph_hip.h, numerics contract).
+
+    Two families of process groups are created here -- by EVERY rank, in the same order (torch.distributed.new_group is a
+    collective over the default group): `key_group` = the S ranks of my query group (ShardedToyGraphBase's group),
+    `query_group` = the Q ranks that hold my key shard (QueryShard's group for the final gather)."""
+
+    def __init__(self, key_shards: int, timeout=None):
+        if not dist.is_initialized():
+            raise RuntimeError("HybridLayout: torch.distributed is not initialised")
+        world, rank = dist.get_world_size(), dist.get_rank()
+        if key_shards < 1 or world % key_shards:
+            raise ValueError(f"HybridLayout: {key_shards} key shards do not divide {world} ranks")
+        self.S, self.Q = int(key_shards), world // int(key_shards)
+        self.q, self.s = divmod(rank, self.S)
+        kw = {} if timeout is None else {"timeout": timeout}
+        key_groups = [dist.new_group([qq * self.S + ss for ss in range(self.S)], **kw) for qq in range(self.Q)]
+        query_groups = [dist.new_group([qq * self.S + ss for qq in range(self.Q)], **kw) for ss in range(self.S)]
+        self.key_group, self.query_group = key_groups[self.q], query_groups[self.s]
+        self.name = f"hybrid {self.Q}x{self.S} (query groups x key shards)"
+
+    def key_rows(self, N: int):
+        """Bank rows of my key shard."""
+        return shard_bounds(N, self.S, self.s)
+
+    def query_shard(self) -> "QueryShard":
+        return QueryShard(self.query_group, force_collectives=True)
+
+    @staticmethod
+    def rows(qs: "QueryShard", tgb: "ShardedToyGraphBase", B: int):
+        """(qlo, qhi, lo, hi): my query group answers rows [qlo, qhi) of the batch, and within the group I finish rows
+        [qlo + lo, qlo + hi)."""
+        qlo, qhi = qs.bounds(B)
+        lo, hi = tgb.tail_bounds(qhi - qlo)
+        return qlo, qhi, lo, hi
+
+    @staticmethod
+    def retrieve_reduced_rows(qs: "QueryShard", tgb: "ShardedToyGraphBase", search_keys, k=None):
+        """(sum_k V[idx], mean_k L[idx], idx) of MY rows of the batch: my group's slice of the queries against the group's
+        key shards (exchanges and the all_to_all stay inside the key group)."""
+        qlo, qhi = qs.bounds(search_keys.shape[0])
+        return tgb.retrieve_reduced_rows(search_keys[qlo:qhi].contiguous(), k)
+
+    @staticmethod
+    def gather_output_rows(qs: "QueryShard", tgb: "ShardedToyGraphBase", local: torch.Tensor, B: int) -> torch.Tensor:
+        """[hi - lo, C] per rank -> [B, C] on every rank: the key group's rows first, then the query groups' slices."""
+        qlo, qhi = qs.bounds(B)
+        return qs.gather_rows(tgb.gather_output_rows(local, qhi - qlo), B)
 
 
 class ShardedToyGraphBase:
@@ -196,6 +265,7 @@ class ShardedToyGraphBase:
         if G <= 1 and not self.collective:
             return
         self.exchange_count[phase] = self.exchange_count.get(phase, 0) + 1
+        _beat(f"exchange phase {phase} (#{self.exchange_count[phase]})")
         k = scores.shape[1]
         m = min(k, 2 * (-(-k // G)))
         while G * m > 64 and m > -(-k // G):

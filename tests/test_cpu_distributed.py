@@ -304,3 +304,72 @@ def test_sharded_duplicate_bank_world2(tmp_path):
         a, b = shard_bounds(B, world, r)
         assert np.array_equal(g["ti"], ri[a:b])
     assert lo1 > 0
+
+
+def _hybrid_worker(rank, world, port, S, N, D, B, k, skew, out_dir):
+    import datetime
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        from ragraph_amd import sharded as SH
+        from ragraph_amd.sharded import HybridLayout, ShardedToyGraphBase
+
+        beats = []
+        SH.heartbeat = beats.append
+        layout = HybridLayout(S)
+        assert (layout.q, layout.s) == divmod(rank, S) and layout.Q * layout.S == world
+        rng = np.random.default_rng(5)
+        keys = cref.normalize_rows(rng.standard_normal((N, D), dtype=np.float32))
+        q = rng.standard_normal((B, D), dtype=np.float32)
+        if skew:  # every winner of the first queries lives in the LAST key shard
+            keys[N - 3 * k:] = cref.normalize_rows(q[0:1] + 0.05 * rng.standard_normal((3 * k, D), dtype=np.float32))
+        vals = torch.from_numpy(rng.standard_normal((N, D), dtype=np.float32))
+        labs = torch.from_numpy(np.eye(3, dtype=np.float32)[rng.integers(0, 3, N)])
+        lo, hi = layout.key_rows(N)
+        tgb = ShardedToyGraphBase(torch.from_numpy(keys[lo:hi]), vals, labs, lo, k, group=layout.key_group,
+                                  ops=FilteredOracleOps, values_replicated=True)
+        qs = layout.query_shard()
+        assert tgb.world == S and tgb.rank == layout.s and qs.world == layout.Q and qs.rank == layout.q
+        qlo, qhi, rlo, rhi = HybridLayout.rows(qs, tgb, B)
+        sv, ml, ti = HybridLayout.retrieve_reduced_rows(qs, tgb, torch.from_numpy(q))
+        full_ml = HybridLayout.gather_output_rows(qs, tgb, ml, B)
+        full_sv = HybridLayout.gather_output_rows(qs, tgb, sv, B)
+        SH.heartbeat = None
+        np.savez(os.path.join(out_dir, f"h{rank}.npz"), sv=sv.numpy(), ml=ml.numpy(), ti=ti.numpy(), full_ml=full_ml.numpy(),
+                 full_sv=full_sv.numpy(), rows=np.array([qlo + rlo, qlo + rhi]), exchanges=np.array(sorted(tgb.exchange_count.items())),
+                 beats=np.array(len(beats)), filtered_calls=np.array(FilteredOracleOps.calls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,S,B,skew", [(4, 2, 23, False), (4, 2, 64, True), (4, 4, 23, False), (4, 1, 23, False)])
+def test_hybrid_layout_world4_matches_single(tmp_path, world, S, B, skew):
+    """Q query groups x S key shards (ragraph_amd.sharded.HybridLayout; 2 x 4 at G = 8 in bench.py) under world-size-4
+    gloo: every rank's rows are the single-GPU rows bit for bit, the ranks' rows tile the batch exactly once, both
+    all_gathers put the whole [B, C] / [B, D] result on every rank in query order, and the exchanges stay inside a key
+    group (same count on its ranks).  S = world and S = 1 are the two pure layouts through the same code."""
+    N, D, k = 1501, 64, 10
+    mp.spawn(_hybrid_worker, args=(world, _free_port(), S, N, D, B, k, skew, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(5)
+    keys = cref.normalize_rows(rng.standard_normal((N, D), dtype=np.float32))
+    q = rng.standard_normal((B, D), dtype=np.float32)
+    if skew:
+        keys[N - 3 * k:] = cref.normalize_rows(q[0:1] + 0.05 * rng.standard_normal((3 * k, D), dtype=np.float32))
+    rs, ri = cref.topk_cosine(q, cref.normalize_rows(keys), k)
+    vals = rng.standard_normal((N, D), dtype=np.float32)
+    labs = np.eye(3, dtype=np.float32)[rng.integers(0, 3, N)]
+    rsv, rml = cref.gather_reduce(vals, labs, ri)
+    got = [dict(np.load(tmp_path / f"h{r}.npz")) for r in range(world)]
+    covered = np.zeros(B, dtype=np.int64)
+    for r, g in enumerate(got):
+        lo, hi = (int(x) for x in g["rows"])
+        covered[lo:hi] += 1
+        assert np.array_equal(g["ti"], ri[lo:hi]) and np.array_equal(g["sv"], rsv[lo:hi]) and np.array_equal(g["ml"], rml[lo:hi])
+        assert np.array_equal(g["full_ml"], rml) and np.array_equal(g["full_sv"], rsv)
+        assert int(g["filtered_calls"]) == 1
+        partner = got[(r // S) * S + (r % S + 1) % S]
+        assert np.array_equal(g["exchanges"], partner["exchanges"])
+        if S > 1:
+            assert int(g["beats"]) >= 3   # the exchanges and collectives reported to the heartbeat hook
+    assert (covered == 1).all()
