@@ -662,6 +662,7 @@ def main():
         from ragraph_amd import sharded as SH
 
         hb = Heartbeat(rank, world, args.dist_timeout)
+        _ACTIVE["hb"] = hb
         beat = hb
         SH.heartbeat = hb
         ranks_seen = preflight(rank, world, dev, args.backend, beat)   # BEFORE the bank is built
@@ -691,6 +692,9 @@ def main():
             L.ragraph_filter_profile_levels(prof, a_ms, a_i8, a_keys)
             level_ms.append([(s_, float(a_ms[s_]), int(a_i8[s_]), int(a_keys[s_])) for s_ in range(4) if a_ms[s_] > 0])
 
+    if os.environ.get("RAGRAPH_BENCH_HANG_RANK") == str(rank):   # (test hook: this rank stops taking part -- the watchdogs must end the job)
+        beat("hung on purpose (RAGRAPH_BENCH_HANG_RANK)")
+        time.sleep(10 ** 6)
     for w_ in range(args.warmup):
         beat(f"warm-up step {w_}")
         step()
@@ -925,5 +929,22 @@ def main():
         dist.destroy_process_group()
 
 
+_ACTIVE = {}   # the running job's Heartbeat, for the report below
+
+
+def _main_reporting():
+    """main(), and when it raises in a multi-rank job (a collective that timed out, a rank that died): every rank's last
+    heartbeat on stderr before the exception ends this rank with a non-zero code."""
+    try:
+        main()
+    except BaseException as e:   # noqa: B902  (SystemExit included: a failed check also names the phases)
+        hb = _ACTIVE.get("hb")
+        if hb is not None and not (isinstance(e, SystemExit) and e.code in (0, None)):
+            hb.stop()
+            print(json.dumps({"bench_failed": f"rank {hb.rank}: {type(e).__name__} in phase '{hb.phase}'", "ranks": hb.report()}),
+                  file=sys.stderr, flush=True)
+        raise
+
+
 if __name__ == "__main__":
-    main()
+    _main_reporting()

@@ -74,7 +74,7 @@ def gnn_bytes(n, F, D, nnz, hops):
     enc_agg, dense, hop = csr + 8 * n * F, 4 * n * F + 4 * F * D + 4 * n * D, csr + 8 * n * D
     enc_agg_nr, hop_nr = csr + 4 * nnz * F + 4 * n * F, csr + 4 * nnz * D + 4 * n * D
     return {"encode_ideal": enc_agg + dense, "hop_ideal": hop, "forward_ideal": enc_agg + dense + hops * hop,
-            "forward_no_reuse": enc_agg_nr + dense + hops * hop_nr, "encode_flops": 2.0 * n * F * D + 2.0 * nnz * F,
+            "forward_no_reuse": enc_agg_nr + dense + hops * hop_nr, "hop_no_reuse": hop_nr, "encode_flops": 2.0 * n * F * D + 2.0 * nnz * F,
             "hop_flops": 2.0 * nnz * D}
 
 
