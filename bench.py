@@ -99,6 +99,7 @@ class EventTimer:
         self.module, self.name, self.orig = module, name, getattr(module, name)
         self.events = []
         self.enabled = False
+        self.last = None   # the wrapped call's last result (the filtered call: its statistics words ride as a fourth item)
         setattr(module, name, self)
 
     def __call__(self, *a, **kw):
@@ -109,6 +110,7 @@ class EventTimer:
         out = self.orig(*a, **kw)
         e1.record()
         self.events.append((e0, e1))
+        self.last = out
         return out
 
     def mean_ms(self):
@@ -718,7 +720,8 @@ def main():
     L.ragraph_filter_profile_destroy(prof)
     # candidates per query of the last timed call's levels (sampled by the call itself: every 64th query; the 16 ints it
     # leaves at the end of its workspace, include/ragraph_hip.h)
-    cand_levels = K.filter_stats_levels(K.last_filter_stats.cpu().tolist()) if K.last_filter_stats is not None else []
+    last = filt_timer.last if isinstance(filt_timer.last, tuple) and len(filt_timer.last) == 4 else None
+    cand_levels = K.filter_stats_levels(last[3].cpu().tolist()) if last is not None else []
     assert torch.isfinite(out).all()
     verified = None
     if args.emulate_rank_of <= 1 and not args.exact_fp32 and not args.no_extras:

@@ -95,7 +95,10 @@ __device__ __forceinline__ void fring_wait(unsigned* ctr, unsigned target) {
 // What a signal publishes is ordered by hand: `freec` (this wave is done READING the slot) follows the wave's own ds_reads in
 // the LDS queue, which executes a wave's operations in order; `full` (this wave's share of the stage has LANDED) follows an
 // explicit s_waitcnt vmcnt(0).  A release fence here would wait for every outstanding store of a candidate flush as well.
+// The COMPILER must keep that order too: the asm ds_read / s_waitcnt statements in front of a signal carry no memory
+// clobber, so an empty asm with one pins the relaxed atomic behind them (no instruction, no wait).
 __device__ __forceinline__ void fring_signal(unsigned* ctr, int lane) {
+  asm volatile("" ::: "memory");
   if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, RG_RING_RELAXED ? __ATOMIC_RELAXED : __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
@@ -1511,23 +1514,15 @@ __global__ void __launch_bounds__(256) topk_rescore_wide_kernel(const float* __r
   }
   if constexpr (!SLICED) {
     over = over || flag[b] != 0;
-    if (final_level && over) {  // (block-uniform) the exact scan right here: these calls need no fallback launch
-      __syncthreads();          // every wave has read the counter
-      if (gridDim.x >= 65) {    // (calls of 65 queries and more: the fixup launch behind this one scans it -- in slices)
-        if (threadIdx.x == 0) {
-          count[b * cs] = 0;
-          overflow_list[atomicAdd(overflow, 1)] = (int)b;
-        }
-        return;
-      }
+    if (final_level && over) {  // (block-uniform) listed for the fixup launch behind this one, which scans it in key slices
+      __syncthreads();          // every wave has read the counter  (round 4 scanned up to 64 queries right here: ONE
+                                // workgroup reading the whole bank, 5 - 7 ms per query where the sliced launch takes 0.5 - 1.7)
+      // a ZERO query (flagged by the prepare launch) is answered here -- scores +0, rows in order -- and is neither listed
+      // nor counted in *overflow: no kernel of the call counts zero queries (the one-wave kernels' zero_query_level alike)
+      const bool zero = zero_query_answer<D>(qs, w == 0 ? k : 0, idx_base, lane, out_s + b * k, out_i + b * k);
       if (threadIdx.x == 0) {
-        atomicAdd(overflow, 1);
         count[b * cs] = 0;
-      }
-      if constexpr (COOP) {
-        exact_scan_query<D>(qs, Kn, N, k, idx_base, tile, ps, pi, out_s + b * k, out_i + b * k);
-      } else {
-        if (w == 0) exact_scan_wave<D>(qs, Kn, N, k, idx_base, lane, out_s + b * k, out_i + b * k);
+        if (!zero) overflow_list[atomicAdd(overflow, 1)] = (int)b;
       }
       return;
     }
@@ -1602,9 +1597,9 @@ __global__ void __launch_bounds__(256) topk_rescore_wide_kernel(const float* __r
     __syncthreads();  // every thread has read the counters
     if (threadIdx.x < S) cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) cnt[FILTER_TICKET_SLOT] = 0;
-    if (final_level && over_q) {  // (block-uniform)
-      if (threadIdx.x == 0) atomicAdd(overflow, 1);
-      exact_scan_query<D>(qs, Kn, N, k, idx_base, tile, ps, pi, out_s + b * k, out_i + b * k);
+    if (final_level && over_q) {  // (block-uniform) the fixup launch behind this one scans the bank for it, in key slices
+      const bool zero = zero_query_answer<D>(qs, w == 0 ? k : 0, idx_base, lane, out_s + b * k, out_i + b * k);   // (see above)
+      if (threadIdx.x == 0 && !zero) overflow_list[atomicAdd(overflow, 1)] = (int)b;
       return;
     }
     if (w != 0) return;
@@ -2570,7 +2565,7 @@ static int run_rescore(const FilterWs& f, const float* Kn, int64_t N, int64_t B,
     hipLaunchKernelGGL((topk_rescore_wide_kernel<D, true, true>), dim3((unsigned)B, (unsigned)S), dim3(256), 0, st, f.Qn, Kn, f.count,
                        f.cand, B, N, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list,
                        f.flag, f.part_s, f.part_i, cstat);
-    *fallback_done = 1;
+    *fallback_done = 0;   // (every call lists its overflowed queries for the sliced fixup launch)
 #ifdef RG_WIDE_TIMING
     {
       (void)hipDeviceSynchronize();
@@ -2582,12 +2577,12 @@ static int run_rescore(const FilterWs& f, const float* Kn, int64_t N, int64_t B,
     }
 #endif
   } else if (B <= wide_coop_max_b) {  // one workgroup per CU: its 70 KB of tiles cost no occupancy
-    *fallback_done = B < 65;  // (up to 64 queries the wide kernels answer an overflowed query themselves on the final level)
+    *fallback_done = 0;
     hipLaunchKernelGGL((topk_rescore_wide_kernel<D, false, true>), dim3((unsigned)B), dim3(256), 0, st, f.Qn, Kn, f.count, f.cand,
                        B, N, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag,
                        (float*)nullptr, (int*)nullptr, cstat);
   } else if (B < wide_max_b) {  // too few queries to fill the chip with one wave each
-    *fallback_done = B < 65;
+    *fallback_done = 0;
     hipLaunchKernelGGL((topk_rescore_wide_kernel<D, false, false>), dim3((unsigned)B), dim3(256), 0, st, f.Qn, Kn, f.count, f.cand,
                        B, N, cap, cs, k, idx_base, ps, pi, final_level, out_scores, out_idx, overflow, f.overflow_list, f.flag,
                        (float*)nullptr, (int*)nullptr, cstat);

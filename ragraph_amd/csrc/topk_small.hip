@@ -37,7 +37,12 @@
 namespace ragraph {
 
 constexpr int SMALL_MAX_B = 32;
-constexpr int SMALL_LIST_CAP = 4096;     // exact (score, key) pairs per query in the workspace
+// exact (score, key) pairs per query in the workspace.  A workgroup contributes at most its own k best per query from its
+// LDS list (pruned before the reservation) plus what a flood appended directly while its bound was still rising -- 256
+// workgroups x 32 + slack; beyond the cap (every workgroup moving on without a bound AND passing its whole share, for
+// several queries) the query is answered by the exact scan, as before.
+constexpr int SMALL_LIST_CAP = 16384;
+constexpr int SMALL_PRUNE_MIN = 64;      // pairs in a workgroup's LDS list from which it looks for queries to prune
 constexpr int SMALL_PARTS_MAX = 256;     // parts of the bound prefix: ONE PER WORKGROUP that has bound units (four per lane of the selecting wave)
 constexpr int SMALL_WG_LIST = 1024;      // exact pairs a workgroup collects in LDS before its one reservation per query
 constexpr int SMALL_PAIRBUF = 512;       // (key, query) pairs a wave expands at a time
@@ -191,7 +196,8 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   float* theta_lds = thr_lds + 32;                            // [32] theta itself: an exact score below it cannot be in the top-k
   int* qcnt = reinterpret_cast<int*>(theta_lds + 32);         // [32] this workgroup's exact pairs per query
   int* qbase = qcnt + 32;                                     // [32] their place in the query's list
-  int* misc = qbase + 32;                                     // [0] wg_n, [1] all bound units in, [2] last workgroup, [3] overflowed queries
+  int* misc = qbase + 32;                                     // [0] wg_n, [1] all bound units in, [2] last workgroup, [3] overflowed queries,
+                                                              // [4] rounds of a flood, [5] the workgroup's pairs, [8..24) compaction counts
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -227,7 +233,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
     thr_lds[tid] = I8 ? __int_as_float(tid < p.B ? INT_MIN : INT_MAX) : (tid < p.B ? RG_NEG_INF : __builtin_huge_valf());
     theta_lds[tid] = RG_NEG_INF;
   }
-  if (tid < 4) misc[tid] = 0;
+  if (tid < 32) misc[tid] = 0;
   constexpr int NCH = D / 4;
   float4 vrow[4];
 #pragma unroll
@@ -436,6 +442,35 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
     return parts_of(q, w4, missing);
   };
   const int nparts = G_b < 64 ? G_b : 64;
+  // theta = a PROVEN lower bound of query q's final k-th best exact score (k distinct keys score at least that): the pass
+  // threshold of the filter follows from it.  One lane.  Every value ever written is a valid bound and the words only
+  // rise, so concurrent writers (a wave's refresh, a flooded wave's ratchet) at worst leave the lower of two valid bounds.
+  auto raise_theta = [&](int q, float theta) {
+    theta_lds[q] = fmaxf(theta_lds[q], theta);
+    float out;
+    if (sc_flag[q]) {
+      out = I8 ? __int_as_float(INT_MAX) : __builtin_huge_valf();   // a zero query passes nothing (answered at the end)
+    } else if constexpr (I8) {
+      const float e8 = sc_eq8[q];
+      const float eps = fmaf(fmaf(e8, ek_8, e8 + ek_8), 1.0009765625f, FILTER_EPS_SLACK);
+      const float sc = sc_qs[q] * sk_8;
+      int t;
+      if (!(sc > 0.f)) t = INT_MIN;
+      else {
+        const float xq = __fsub_rn(theta, eps) / sc;
+        t = !(xq > -8.4e6f) ? INT_MIN : (xq > 8.4e6f ? INT_MAX : (int)floorf(xq) - 2);
+      }
+      // (never below a threshold already in force: a list that passed its cap has raised it to INT_MAX)
+      const int old = __float_as_int(thr_lds[q]);
+      out = __int_as_float(t > old ? t : old);
+    } else {
+      const float e = sc_eqb[q];
+      const float eps_b = fmaf(fmaf(e, ek_b, e + ek_b), 1.0009765625f, FILTER_EPS_SLACK);
+      const float t = __fsub_rn(theta, eps_b);
+      out = fmaxf(t, thr_lds[q]);
+    }
+    thr_lds[q] = out;
+  };
   auto make_threshold = [&](int q, unsigned u) {
     const float e = sc_eqb[q];
     const float eps_b = fmaf(fmaf(e, ek_b, e + ek_b), 1.0009765625f, FILTER_EPS_SLACK);
@@ -448,30 +483,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
     }
     const unsigned long long kth = __ballot(lane < nparts && rank == k - 1);
     const float theta = kth ? __shfl(v, __ffsll((long long)kth) - 1) : RG_NEG_INF;
-    if (lane == 0) {
-      theta_lds[q] = fmaxf(theta_lds[q], theta);
-      float out;
-      if (sc_flag[q]) {
-        out = I8 ? __int_as_float(INT_MAX) : __builtin_huge_valf();   // a zero query passes nothing (answered at the end)
-      } else if constexpr (I8) {
-        const float e8 = sc_eq8[q];
-        const float eps = fmaf(fmaf(e8, ek_8, e8 + ek_8), 1.0009765625f, FILTER_EPS_SLACK);
-        const float sc = sc_qs[q] * sk_8;
-        int t;
-        if (!(sc > 0.f)) t = INT_MIN;
-        else {
-          const float xq = __fsub_rn(theta, eps) / sc;
-          t = !(xq > -8.4e6f) ? INT_MIN : (xq > 8.4e6f ? INT_MAX : (int)floorf(xq) - 2);
-        }
-        // (never below a threshold already in force: a list that passed its cap has raised it to INT_MAX)
-        const int old = __float_as_int(thr_lds[q]);
-        out = __int_as_float(t > old ? t : old);
-      } else {
-        const float t = __fsub_rn(theta, eps_b);
-        out = fmaxf(t, thr_lds[q]);
-      }
-      thr_lds[q] = out;
-    }
+    if (lane == 0) raise_theta(q, theta);
   };
   {  // a wave's queries: wave, wave + 8, ... -- all their part maxima are requested in one batch, again until none is missing
      // or the time limit has passed (workgroups of another process may hold the CUs some of ours still need)
@@ -538,20 +550,43 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
     }
   };
   // mid-stream flush (the buffer filled up: a flood): every lane scores its entries' keys itself
+  // A flood (a bound that is still -inf because this workgroup moved on early, or thousands of near-duplicates of a query)
+  // must not fill the query's list: after every chunk of 64 entries the wave RATCHETS the bound -- among the lanes whose
+  // entry belongs to query q0, the k-th largest of the lanes' best exact scores is the score of k distinct keys, hence a
+  // valid theta -- and the raised pass threshold ends the flood at its source (each ratchet lifts theta to about the 85th
+  // percentile of what still passes: a few chunks per decade).
   auto flush_slow = [&]() {
     for (int i0 = 0; i0 < wcnt; i0 += 64) {
       const int i = i0 + lane;
+      float best = RG_NEG_INF;
+      int q = -1;
       if (i < wcnt) {
         const uint2 e = wbuf[i];
-        const int q = (int)((e.y >> 8) & 0xFFu);
+        q = (int)((e.y >> 8) & 0xFFu);
         unsigned mk = e.y & 0xFFu;
         while (mk) {
           const int r = __ffs(mk) - 1;
           mk &= mk - 1;
           const int key = (int)e.x + (r & 3) + 16 * (r >> 2);
           const float s = lane_score(q, key);
+          best = fmaxf(best, s);
           if (s >= theta_lds[q]) append_global(q, key, s);
         }
+      }
+      unsigned long long todo = __ballot(q >= 0);
+      while (todo) {  // (wave-uniform: one round per query present in the chunk)
+        const int q0 = __shfl(q, __ffsll((long long)todo) - 1);
+        const unsigned long long part = __ballot(q == q0);
+        todo &= ~part;
+        if (__popcll(part) < k) continue;
+        int rank = 0;
+        for (int o = 0; o < 64; ++o) {
+          if (!((part >> o) & 1ull)) continue;
+          const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best), o));
+          rank += (x > best || (x == best && o < lane)) ? 1 : 0;
+        }
+        const unsigned long long kth = __ballot(q == q0 && rank == k - 1);
+        if (kth && lane == __ffsll((long long)kth) - 1) raise_theta(q0, best);
       }
     }
     wcnt = 0;
@@ -643,7 +678,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
       process(A0, gw + i * W);
       if (i + 2 < n_mine) RG_SLOAD(A0, fbase, gw + (i + 2) * W);
       process(A1, gw + (i + 1) * W);
-      if (refresh && (i & 30) == 30) {   // (wave 0 of a workgroup that moved on early) the others' maxima may have arrived
+      if (refresh && (i & 6) == 6) {   // (wave 0 of a workgroup that moved on early) the others' maxima may have arrived
         bool any_missing = false;
         for (int q = 0; q < B; ++q) {
           bool mq;
@@ -660,69 +695,169 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
 
   RG_SSTAMP(6);
   // ---- 4. exact scores of this wave's candidates: (key, query) pairs, 16 rows per memory round trip ------------------
-  {
+  // entries [e_lo, e_hi) of this wave's buffer (at most 64 of them: the pair buffer holds 512 pairs)
+  auto score_entries = [&](int e_lo, int e_hi) {
     int2* pairs = pair_all + wave * SMALL_PAIRBUF;
     float* tile = tile_all + wave * 16 * RESCORE_LD;
-    for (int i0 = 0; i0 < wcnt; i0 += 64) {
-      const int i = i0 + lane;
-      uint2 e = make_uint2(0u, 0u);
-      if (i < wcnt) e = wbuf[i];
-      unsigned mk = e.y & 0xFFu;
-      const int q = (int)((e.y >> 8) & 0xFFu);
-      int incl = __popc(mk);
+    const int i = e_lo + lane;
+    uint2 e = make_uint2(0u, 0u);
+    if (i < e_hi) e = wbuf[i];
+    unsigned mk = e.y & 0xFFu;
+    const int q = (int)((e.y >> 8) & 0xFFu);
+    int incl = __popc(mk);
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int up = __shfl_up(incl, off);
-        if (lane >= off) incl += up;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int up = __shfl_up(incl, off);
+      if (lane >= off) incl += up;
+    }
+    const int total = __shfl(incl, 63);  // <= 512 = SMALL_PAIRBUF
+    int at = incl - __popc(mk);
+    while (mk) {
+      const int r = __ffs(mk) - 1;
+      mk &= mk - 1;
+      pairs[at++] = make_int2((int)e.x + (r & 3) + 16 * (r >> 2), q);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int r0 = 0; r0 < total; r0 += 16) {
+      int key = -1, pq = 0;
+      if (lane < 16 && r0 + lane < total) {
+        const int2 pr = pairs[r0 + lane];
+        key = pr.x;
+        pq = pr.y;
       }
-      const int total = __shfl(incl, 63);  // <= 512 = SMALL_PAIRBUF
-      int at = incl - __popc(mk);
-      while (mk) {
-        const int r = __ffs(mk) - 1;
-        mk &= mk - 1;
-        pairs[at++] = make_int2((int)e.x + (r & 3) + 16 * (r >> 2), q);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      for (int r0 = 0; r0 < total; r0 += 16) {
-        int key = -1, pq = 0;
-        if (lane < 16 && r0 + lane < total) {
-          const int2 pr = pairs[r0 + lane];
-          key = pr.x;
-          pq = pr.y;
+      const float s = coop_scores_few<D>(reinterpret_cast<const float4*>(qn + pq * QLD), p.Kn, key, lane, tile);
+      // theta is a proven lower bound of the query's final k-th best EXACT score: a key that scores below it is out
+      // (the approximate pass let it through on its error bound; ~3 of 4 candidates end here)
+      if (key >= 0 && s < theta_lds[pq]) key = -1;
+      const unsigned long long have = __ballot(key >= 0);
+      int base = 0;
+      if (lane == 0) base = atomicAdd(misc, __popcll(have));
+      base = __shfl(base, 0);
+      if (key >= 0) {
+        const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(have >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)have, 0u));
+        if (slot < SMALL_WG_LIST) {
+          wg_s[slot] = s;
+          wg_k[slot] = key;
+          wg_q[slot] = pq;
+        } else {
+          append_global(pq, key, s);
         }
-        const float s = coop_scores_few<D>(reinterpret_cast<const float4*>(qn + pq * QLD), p.Kn, key, lane, tile);
-        // theta is a proven lower bound of the query's final k-th best EXACT score: a key that scores below it is out
-        // (the approximate pass let it through on its error bound; ~3 of 4 candidates end here)
-        if (key >= 0 && s < theta_lds[pq]) key = -1;
-        const unsigned long long have = __ballot(key >= 0);
-        int base = 0;
-        if (lane == 0) base = atomicAdd(misc, __popcll(have));
-        base = __shfl(base, 0);
-        if (key >= 0) {
-          const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(have >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)have, 0u));
-          if (slot < SMALL_WG_LIST) {
-            wg_s[slot] = s;
-            wg_k[slot] = key;
-            wg_q[slot] = pq;
-          } else {
-            append_global(pq, key, s);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // (the pair buffer is rewritten by the next chunk)
+  };
+  // Only a workgroup's k best pairs of a query can be among the query's winners.  prune_list marks every pair of the LDS
+  // list below the workgroup's own k-th best of its query (wg_q = -1) and -- that k-th best being the exact score of k
+  // distinct keys -- raises the query's theta to it.  All eight waves call it (wave w: queries w, w + 8, ...), between
+  // barriers; n = pairs in the list.
+  auto prune_list = [&](int n) {
+    for (int q = wave; q < B; q += 8) {
+      unsigned long long held[SMALL_WG_LIST / 64];
+      int cq = 0;
+#pragma unroll
+      for (int u = 0; u < SMALL_WG_LIST / 64; ++u) {
+        const int i = lane + 64 * u;
+        held[u] = (i < n && wg_q[i] == q) ? small_key64(wg_s[i], wg_k[i]) : 0ull;
+        cq += __popcll(__ballot(held[u] != 0ull));
+      }
+      if (cq < k) continue;   // (wave-uniform)
+      unsigned long long bound = ~0ull;   // the previous round's maximum: keys are distinct, each round finds the next one
+      for (int r_ = 0; r_ < k; ++r_) {
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int u = 0; u < SMALL_WG_LIST / 64; ++u) best = (held[u] < bound && held[u] > best) ? held[u] : best;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          const unsigned long long o = ((unsigned long long)(unsigned)__shfl_xor((int)(best >> 32), off) << 32) |
+                                       (unsigned)__shfl_xor((int)(unsigned)best, off);
+          best = o > best ? o : best;
+        }
+        bound = best;
+      }
+#pragma unroll
+      for (int u = 0; u < SMALL_WG_LIST / 64; ++u)
+        if (held[u] != 0ull && held[u] < bound) wg_q[lane + 64 * u] = -1;   // below this workgroup's own k-th best
+      if (lane == 0) raise_theta(q, select_unord((unsigned)(bound >> 32)));
+    }
+  };
+  {
+    // pairs this wave will score, and the workgroup's total: when they all fit the LDS list (every ordinary call: a few
+    // pairs per workgroup) each wave scores its entries in one go.  Otherwise -- a FLOOD: a workgroup that moved on
+    // without a bound passes its whole share, a query next to thousands of near-duplicates -- the waves go in rounds of
+    // 8 entries (<= 64 pairs a wave, 512 a round) with the list pruned to the workgroup's k best per query and theta
+    // raised between the rounds, so that nothing spills into the queries' global lists and the flood thins out at once.
+    int np = 0;
+    for (int i = lane; i < wcnt; i += 64) np += __popc(wbuf[i].y & 0xFFu);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) np += __shfl_xor(np, off);
+    if (lane == 0) {
+      atomicAdd(misc + 5, np);
+      atomicMax(misc + 4, (wcnt + 7) / 8);
+    }
+    __syncthreads();
+    if (misc[5] <= SMALL_WG_LIST) {   // (block-uniform)
+      for (int i0 = 0; i0 < wcnt; i0 += 64) score_entries(i0, i0 + 64 < wcnt ? i0 + 64 : wcnt);
+    } else {
+      const int nrounds = misc[4];
+      for (int rd = 0; rd < nrounds; ++rd) {
+        if (8 * rd < wcnt) score_entries(8 * rd, 8 * rd + 8 < wcnt ? 8 * rd + 8 : wcnt);
+        if (rd + 1 == nrounds) break;
+        __syncthreads();
+        const int n = misc[0] < SMALL_WG_LIST ? misc[0] : SMALL_WG_LIST;
+        prune_list(n);
+        __syncthreads();
+        // compaction: every thread holds its two entries, then all are written back densely
+        float cs_[2];
+        int ck_[2], cq_[2];
+        bool keep[2];
+        int* wcount = misc + 8;   // [16] kept entries per (slot c, wave)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int i = tid + 512 * c;
+          keep[c] = i < n && wg_q[i] >= 0;
+          cs_[c] = keep[c] ? wg_s[i] : 0.f;
+          ck_[c] = keep[c] ? wg_k[i] : 0;
+          cq_[c] = keep[c] ? wg_q[i] : 0;
+          const unsigned long long bal = __ballot(keep[c]);
+          if (lane == 0) wcount[8 * c + wave] = __popcll(bal);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          int base = 0;
+          for (int t = 0; t < 8 * c + wave; ++t) base += wcount[t];
+          const unsigned long long bal = __ballot(keep[c]);
+          const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+          if (keep[c]) {
+            wg_s[pos] = cs_[c];
+            wg_k[pos] = ck_[c];
+            wg_q[pos] = cq_[c];
           }
         }
+        if (tid == 0) {
+          int tot = 0;
+          for (int t = 0; t < 16; ++t) tot += wcount[t];
+          misc[0] = tot;
+        }
+        __syncthreads();
       }
-      __builtin_amdgcn_wave_barrier();  // (the pair buffer is rewritten by the next chunk)
     }
   }
   __syncthreads();
   RG_SSTAMP(7);
   {  // one reservation per query for the workgroup's pairs
     const int n = misc[0] < SMALL_WG_LIST ? misc[0] : SMALL_WG_LIST;
+    if (n >= SMALL_PRUNE_MIN) {  // (block-uniform) many pairs: only this workgroup's k best of a query can be among the winners
+      prune_list(n);
+      __syncthreads();
+    }
     int r[SMALL_WG_LIST / 512];
 #pragma unroll
     for (int c = 0; c < SMALL_WG_LIST / 512; ++c) {
       const int i = tid + 512 * c;
-      r[c] = i < n ? atomicAdd(qcnt + wg_q[i], 1) : 0;
+      r[c] = (i < n && wg_q[i] >= 0) ? atomicAdd(qcnt + wg_q[i], 1) : 0;
     }
     __syncthreads();
     if (tid < B && qcnt[tid] > 0) qbase[tid] = atomicAdd(cnt_g + 32 * tid, qcnt[tid]);
@@ -730,7 +865,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
 #pragma unroll
     for (int c = 0; c < SMALL_WG_LIST / 512; ++c) {
       const int i = tid + 512 * c;
-      if (i < n) {
+      if (i < n && wg_q[i] >= 0) {
         const int q = wg_q[i];
         const int pos = qbase[q] + r[c];
         if (pos < SMALL_LIST_CAP) {  // (agent-scope stores: written through, visible to the last workgroup without a fence)

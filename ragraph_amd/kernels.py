@@ -237,14 +237,16 @@ FILTER_MIN_B = int(os.environ.get("RAGRAPH_FILTER_MIN_B", "1"))  # banks of >= 6
 
 _EXCHANGE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int)
 
-# Candidate statistics of the most recent topk_cosine_filtered call of this process: a view of the 16 ints the call's
-# launches leave at the end of its workspace (include/ragraph_hip.h: ragraph_topk_cosine_filtered_stats_offset).
-last_filter_stats = None
+# Candidate statistics of a filtered call: the 16 ints its launches leave at the end of its workspace (include/ragraph_hip.h:
+# ragraph_topk_cosine_filtered_stats_offset).  topk_cosine_filtered(..., return_stats=True) hands the caller a view of
+# THAT call's words (valid until the next filtered call on the same stream reuses the workspace); there is no module-level
+# "last call" state -- another thread, stream or index would overwrite it.
+FILTER_STATS = True   # (KeyIndex: this ops object supports return_stats)
 FILTER_STATS_MAGIC = 0x52414753
 
 
 def filter_stats_levels(stats) -> list:
-    """[(dtype, keys, candidates per query or None)] per level from a HOST copy of last_filter_stats."""
+    """[(dtype, keys, candidates per query or None)] per level from a HOST copy of a call's statistics words."""
     st = [int(x) for x in stats]
     if len(st) < 16 or st[0] != FILTER_STATS_MAGIC:
         return []
@@ -253,11 +255,14 @@ def filter_stats_levels(stats) -> list:
 
 
 def topk_cosine_filtered(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf16: torch.Tensor, k: int,
-                         idx_base: int = 0, keys_packed: torch.Tensor | None = None, exchange=None, plan_n: int = 0):
+                         idx_base: int = 0, keys_packed: torch.Tensor | None = None, exchange=None, plan_n: int = 0,
+                         return_stats: bool = False):
     """Exact top-k (same bits as topk_cosine) through the bf16 MFMA filter.  Returns (scores, idx, overflow): `overflow`
-    is a 1-element int32 DEVICE tensor counting the queries whose candidate list overflowed (none on ordinary banks);
+    is a 1-element int32 DEVICE tensor counting the queries whose candidate list overflowed (none on ordinary banks;
+    all-zero queries are answered without a scan and never counted);
     the call itself recomputed those rows with an exact fp32 scan on the device, so the result is complete and nothing
     is read back: the call is asynchronous and HIP-graph capturable.  (`int(overflow)` synchronises.)
+    return_stats=True: a fourth result, a [16] int32 device view of THIS call's candidate statistics (filter_stats_levels).
 
     Row-sharded banks: `exchange(phase, theta, scores)` is called between the phases of the call
     (ragraph_topk_cosine_filtered_sharded_f32) with theta [B] = this shard's lower bound of every query's final k-th
@@ -292,15 +297,14 @@ def topk_cosine_filtered(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf
     if nbytes == 0:
         raise RagraphNativeError(f"topk_cosine_filtered: unsupported shape B={B} N={Nk} D={D} k={k}")
     ws = _workspace(nbytes, q.device)
-    global last_filter_stats
     off = L.ragraph_topk_cosine_filtered_stats_offset(ws.numel())
-    last_filter_stats = ws[off:off + 64].view(torch.int32)   # (valid until the next filtered call on this stream)
+    stats = ws[off:off + 64].view(torch.int32)   # (valid until the next filtered call on this stream)
     if exchange is None:
         N.check(L.ragraph_topk_cosine_filtered_f32(q.data_ptr(), B, kn.data_ptr(), kp, keys_bf16.data_ptr(), Nk, D, k,
                                                    idx_base, scores.data_ptr(), idx.data_ptr(), overflow.data_ptr(), None,
                                                    ws.data_ptr(), ws.numel(), _stream()),
                 "topk_cosine_filtered")
-        return scores, idx, overflow
+        return (scores, idx, overflow, stats) if return_stats else (scores, idx, overflow)
     theta = torch.empty(B, dtype=torch.float32, device=q.device)
     errors = []
 
@@ -318,7 +322,7 @@ def topk_cosine_filtered(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf
     if errors:
         raise errors[0]
     N.check(rc, "topk_cosine_filtered(sharded)")
-    return scores, idx, overflow
+    return (scores, idx, overflow, stats) if return_stats else (scores, idx, overflow)
 
 
 def fused_helps(B: int, n_keys: int, D: int, k: int) -> bool:
@@ -394,19 +398,32 @@ def small_helps(B: int, n_keys: int, D: int, k: int) -> bool:
     return 1 <= B <= SMALL_MAX_B and D in (64, 128, 256) and k <= 32 and 65536 <= n_keys < 2 ** 31
 
 
-_small_state: dict = {}
+_small_state: dict = {}   # insertion-ordered: least recently used first
+_SMALL_STATE_MAX = 8
 
 
-def _small_state_buf(device) -> torch.Tensor:
+def _small_state_buf(device, create: bool = True):
     """The single-launch kernel's state words: zero before the first call, left zero by every call; one buffer per
-    (device, stream) -- calls on a stream are ordered."""
+    (device, stream) -- calls on a stream are ordered.  Never ALLOCATED while a HIP graph is being captured (the buffer
+    would come from the capture's private pool and be reused by later eager calls on a recycled stream handle): returns
+    None then, and the caller takes another path (small_helps_now).  The cache is bounded like the workspace cache."""
     dev = device.index if device.index is not None else torch.cuda.current_device()
     key = (dev, _raw_stream(dev) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream)
-    t = _small_state.get(key)
+    t = _small_state.pop(key, None)
     if t is None:
+        if not create or torch.cuda.is_current_stream_capturing():
+            return None
         t = torch.zeros(N.lib().ragraph_topk_cosine_small_state_bytes() // 4, dtype=torch.int32, device=device)
-        _small_state[key] = t
+    _small_state[key] = t
+    while len(_small_state) > _SMALL_STATE_MAX:
+        _small_state.pop(next(iter(_small_state)))
     return t
+
+
+def small_state_ready(device) -> bool:
+    """May the single-launch kernel run on the current stream right now?  (Always outside a capture; inside one only when
+    the stream's state buffer already exists -- e.g. from the warm-up runs every capture is preceded by.)"""
+    return _small_state_buf(device) is not None
 
 
 def topk_cosine_small(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf16: torch.Tensor, k: int, idx_base: int = 0):
@@ -427,10 +444,16 @@ def topk_cosine_small(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf16:
     if nbytes == 0:
         raise RagraphNativeError(f"topk_cosine_small: unsupported shape B={B} N={Nk} D={D} k={k}")
     ws = _workspace(nbytes, q.device)
-    N.check(L.ragraph_topk_cosine_small_f32(q.data_ptr(), B, kn.data_ptr(), keys_bf16.data_ptr(), Nk, D, k, idx_base,
-                                            scores.data_ptr(), idx.data_ptr(), overflow.data_ptr(),
-                                            _small_state_buf(q.device).data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
-            "topk_cosine_small")
+    state = _small_state_buf(q.device)
+    if state is None:
+        raise RagraphNativeError("topk_cosine_small: no state buffer for this stream yet and a HIP graph is being captured "
+                                 "(run the call once on this stream before capturing, or take topk_cosine_filtered)")
+    rc = L.ragraph_topk_cosine_small_f32(q.data_ptr(), B, kn.data_ptr(), keys_bf16.data_ptr(), Nk, D, k, idx_base,
+                                         scores.data_ptr(), idx.data_ptr(), overflow.data_ptr(), state.data_ptr(), ws.data_ptr(),
+                                         ws.numel(), _stream())
+    if rc != 0:   # (a launch that did not happen leaves the words as they were; after any error: zero them again)
+        state.zero_()
+    N.check(rc, "topk_cosine_small")
     return scores, idx, overflow
 
 

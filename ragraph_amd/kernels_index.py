@@ -69,6 +69,7 @@ class KeyIndex:
         self._host_word = self._event = None
         self._overflowed = 0
         self.last_i8_candidates = None   # candidates per query over the int8 levels of the last polled call (sampled)
+        self.last_stats = None           # device view of the last filtered call's statistics words (this index, this stream)
         # None: duplicates not looked at yet; False: looked at, searched as it is; else (KeyIndex over the unique rows,
         # group_ptr, members)
         self._collapsed = None if dedup else False
@@ -122,9 +123,7 @@ class KeyIndex:
             return  # (an event query is not a capturable call)
         if not pend[1].query():
             return
-        n_over, B = int(pend[0][0]), pend[2]
-        if pend[0].numel() > 16 and int(pend[0][1]) == 0x52414753:
-            n_over = max(0, n_over - int(pend[0][16]))   # (all-zero queries: answered without a scan, not the bank's fault)
+        n_over, B = int(pend[0][0]), pend[2]   # (no kernel counts all-zero queries: they are answered without a scan)
         self._pending = None
         self._overflowed += n_over
         i8_was_off = self._i8_off               # (the call ran under this setting: the overflow rule below judges IT)
@@ -248,8 +247,12 @@ class KeyIndex:
                     self._bf16 = ops.keys_to_bf16(kn)
                 cap, _ = self._cap_i8()   # (per shard: which kernel a level runs on does not change the exchanges)
                 try:
-                    s, i, _ = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base, exchange=exchange,
-                                                       plan_n=plan_n)
+                    if getattr(ops, "FILTER_STATS", False):
+                        s, i, _, self.last_stats = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base,
+                                                                            exchange=exchange, plan_n=plan_n, return_stats=True)
+                    else:
+                        s, i, _ = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base, exchange=exchange,
+                                                           plan_n=plan_n)
                 finally:
                     if cap is not None:
                         cap(-1)
@@ -264,7 +267,8 @@ class KeyIndex:
                 self._bf16 = ops.keys_to_bf16(kn)
             return ops.topk_cosine_fused(q, kn, self._bf16, k, idx_base=idx_base)
         small = getattr(ops, "small_helps", None)
-        if small is not None and not self._filter_off and small(B, kn.shape[0], D, k):
+        if (small is not None and not self._filter_off and small(B, kn.shape[0], D, k)
+                and getattr(ops, "small_state_ready", lambda _d: True)(q.device)):
             # a handful of queries against a large bank: every phase of the filtered call in ONE launch (csrc/topk_small.hip)
             if self._bf16 is None:
                 self._bf16 = ops.keys_to_bf16(kn)
@@ -288,12 +292,18 @@ class KeyIndex:
                 return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
             cap, had_i8 = self._cap_i8()
             had_i8 = had_i8 and ops.filtered_i8_levels(B, kn.shape[0], D, k) > 0   # (did THIS call have int8 levels?)
+            stats = None
             try:
-                s, i, over = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base, keys_packed=self._packed)
+                if getattr(ops, "FILTER_STATS", False):   # this call's own statistics words, handed on explicitly
+                    s, i, over, stats = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base,
+                                                                 keys_packed=self._packed, return_stats=True)
+                else:
+                    s, i, over = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base, keys_packed=self._packed)
             finally:
                 if cap is not None:
                     cap(-1)
-            self._note_overflow(over, B, had_i8, getattr(ops, "last_filter_stats", None))
+            self._note_overflow(over, B, had_i8, stats)
+            self.last_stats = stats   # (diagnostic: bench.py / tools read the levels' candidate counts of the last call)
             return s, i
         helps = getattr(ops, "packed_keys_help", None)
         if helps is not None and helps(B, D, k):

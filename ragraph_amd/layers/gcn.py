@@ -1,8 +1,9 @@
 """Mirror of RAGraph_*/layers/gcn.py: one GCN layer PReLU(A_hat (X W^T) + b), same parameter names (fc, act, bias)."""
+import os
+import weakref
+
 import torch
 import torch.nn as nn
-
-import weakref
 
 from .. import kernels as K
 from ..graph import as_csr
@@ -51,7 +52,12 @@ def sparse_features(x: torch.Tensor, probe: bool = True):
 
 def aggregate_first(f_in: int, f_out: int) -> bool:
     """Inference of a layer whose input is at most half as wide as its output (and a width the SpMM takes): aggregate the
-    narrow features, then multiply.  (Training keeps the reference's order: autograd.linear -> autograd.spmm_csr.)"""
+    narrow features, then multiply.  (Training keeps the reference's order: autograd.linear -> autograd.spmm_csr.)
+    Another association of the same sum: the embeddings differ from the reference order's by fp32 rounding (<= 1e-5), which
+    can flip a near-tie of the top-k; RAGRAPH_GCN_REFERENCE_ORDER=1 (read per call) keeps A_hat (X W^T) everywhere --
+    inference then has the training path's bits."""
+    if os.environ.get("RAGRAPH_GCN_REFERENCE_ORDER") == "1":
+        return False
     return f_in % 4 == 0 and f_in >= 16 and 2 * f_in <= f_out
 
 
@@ -106,7 +112,7 @@ class GCN(nn.Module):
         if xs is None and aggregate_first(x.shape[1], self.fc.weight.shape[0]):
             # narrow features (c2: 128 -> 256): A_hat (X W^T) = (A_hat X) W^T, and the gathers of the aggregation -- what a
             # hop costs -- move half the bytes on the narrow side; bias + PReLU ride in the dense
-            # kernel's epilogue.  Another association of the same sum: the oracle applies the same rule (oracle/pipeline.py).
+            # kernel's epilogue.  Another association of the same sum (oracle/pipeline.py gcn_layer(order="aggregate_first")).
             if not g.has_long_rows and x.is_cuda and K.slices_help(x.shape[0], x.shape[1]):
                 agg = K.spmm_csr_panels(g.rowptr, g.col, g.val, x, x_panels=False, y_panels=False)   # (same bits)
             else:

@@ -979,8 +979,9 @@ def test_candidate_statistics_and_cost_aware_int8_demotion(dev):
                                              rng.standard_normal((N - 3000, D), dtype=np.float32)]))
     q = (centre + 0.5 * rng.standard_normal((B, D), dtype=np.float32)).astype(np.float32)
     knd, qd = _t(kn, dev), _t(q, dev)
-    s, i, over = K.topk_cosine_filtered(qd, knd, K.keys_to_bf16(knd), k)
-    levels = K.filter_stats_levels(K.last_filter_stats.cpu().tolist())
+    s, i, over, stats = K.topk_cosine_filtered(qd, knd, K.keys_to_bf16(knd), k, return_stats=True)
+    levels = K.filter_stats_levels(stats.cpu().tolist())
+    assert not hasattr(K, "last_filter_stats")   # (no process-global view of "the last call")
     assert int(over) == 0 and len(levels) >= 1 and all(c is not None for _, _, c in levels)
     assert sum(keys for _, keys, _ in levels) == N and levels[-1][0] == "int8"
     assert max(c for dt, _, c in levels if dt == "int8") > 400     # the cluster's level

@@ -17,6 +17,6 @@ for csize in (0, 3000, 4500):
     knd, qd = torch.from_numpy(kn).to(dev), torch.from_numpy(q).to(dev)
     for cap in (-1, 0):
         K.set_max_i8_levels(cap)
-        s, i, over = K.topk_cosine_filtered(qd, knd, K.keys_to_bf16(knd), k)
-        print(f"cluster {csize} cap {cap}: over {int(over)} levels {K.filter_stats_levels(K.last_filter_stats.cpu().tolist())} planned i8 {K.expected_i8_candidates(B, N, D, k):.0f}", flush=True)
+        s, i, over, st = K.topk_cosine_filtered(qd, knd, K.keys_to_bf16(knd), k, return_stats=True)
+        print(f"cluster {csize} cap {cap}: over {int(over)} levels {K.filter_stats_levels(st.cpu().tolist())} planned i8 {K.expected_i8_candidates(B, N, D, k):.0f}", flush=True)
     K.set_max_i8_levels(-1)
