@@ -129,11 +129,15 @@ int64_t ragraph_keys_bf16_rows(int64_t N);
 int ragraph_keys_to_bf16(const float* Kn, int64_t N, int D, uint16_t* Kb, void* stream);
 int ragraph_topk_cosine_filtered_cap(int k);
 size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_t N, int D, int k);
-/* Candidate statistics of the most recent filtered call on a workspace: 16 ints at byte offset
+/* Candidate statistics of the most recent filtered call on a workspace: 32 ints at byte offset
  * ragraph_topk_cosine_filtered_stats_offset(ws_bytes) of the workspace AS PASSED to the call (its last bytes), written by the
  * call's own launches: [0] 0x52414753, [1] levels, [2+l] sum of the candidate counts of every 64th query at level l (l < 3),
  * [5+l] how many queries that sum covers, [8+l] 1 if level l ran on the int8 copy, [11+l] keys of level l, [14] queries of
- * the call, [15] all-zero queries among them (answered without a scan; the overflow count may or may not include them).  sum / queries = candidates per query: what a level's rescoring costs.  The owner of a bank reads them back
+ * the call, [15] all-zero queries among them (answered without a scan, never counted in *overflow), [16] 1 if the call
+ * filtered with a speculative first bound (ragraph_topk_cosine_filtered_set_prior), [17] queries that bound was too high
+ * for (answered by the exact scan, counted in *overflow), [18] / [19] the smallest / largest final exact k-th best score of
+ * the call's queries as order-preserving ints (bits(x) for x >= 0, bits(x) ^ 0x7FFFFFFF below: csrc/filter_common.h f2ord; INT_MAX /
+ * INT_MIN: none recorded), [20..32) reserved.  sum / queries = candidates per query: what a level's rescoring costs.  The owner of a bank reads them back
  * asynchronously (ragraph_amd/kernels_index.py: a bank whose int8 levels pass hundreds of candidates per query without
  * overflowing is slower on int8 than on bf16 -- the overflow count alone would never show it). */
 size_t ragraph_topk_cosine_filtered_stats_offset(size_t ws_bytes);
@@ -154,6 +158,18 @@ int ragraph_topk_cosine_filtered_i8_levels(int64_t B, int64_t N, int D, int k);
  * exact, but slower.  ragraph_amd/kernels_index.py sets it per bank from the copy's measured error row and from calls whose
  * candidate lists overflowed. */
 int ragraph_topk_cosine_filtered_max_i8_levels(int n);
+/* A SPECULATIVE first bound for the CALLING THREAD's following filtered calls (thread-local; NaN = none, the default);
+ * returns the previous value.  A call on a single bank whose schedule starts with a bound pass (plan[1] == 2) then skips
+ * that pass: every query starts from theta = theta_prior, each level filters with max(theta_prior, the exact k-th best so
+ * far), and a verify launch behind the last level PROVES every answer -- a query is exact iff its k-th best candidate scores
+ * at least theta_prior (every key scoring at least that passed its level) -- and sends the others to the exact scan of the
+ * call's last launch (counted in *overflow and in statistics word [17]).  The result therefore has the bits of
+ * ragraph_topk_cosine_f32 for ANY prior; a prior above a query's true k-th best costs that query an exact scan (~0.1 - 2
+ * ms), one far below it costs candidates.  The owner of a bank derives it from the k-th best scores its earlier calls
+ * reported (statistics words [18], [19]) and withdraws it when a call reports misses (ragraph_amd/kernels_index.py).
+ * The sharded entry ignores it.  The reference has no counterpart (torch.topk over the full score matrix,
+ * ToyGraphBase.py:66-67): this only removes work. */
+float ragraph_topk_cosine_filtered_set_prior(float theta_prior);
 int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const float* Kn, const float* Kp, const uint16_t* Kb,
                                      int64_t N, int D, int k, int64_t idx_base, float* out_scores, int64_t* out_idx,
                                      int* overflow, int64_t* overflow_idx, void* ws, size_t ws_bytes, void* stream);

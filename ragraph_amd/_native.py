@@ -40,6 +40,7 @@ SIGNATURES = {
     "ragraph_filter_profile_destroy": (None, [_vp]),
     "ragraph_filter_profile_attach": (_vp, [_vp]),
     "ragraph_filter_profile_last_ms": (ctypes.c_float, [_vp]),
+    "ragraph_topk_cosine_filtered_set_prior": (ctypes.c_float, [_f32]),
     "ragraph_filter_profile_levels": (_i32, [_vp, _vp, _vp, _vp]),
     "ragraph_topk_cosine_filtered_cap": (_i32, [_i32]),
     "ragraph_topk_cosine_filtered_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),

@@ -201,8 +201,11 @@ __global__ void __launch_bounds__(256) keys_to_i8_kernel(const float* __restrict
 // mean the owner of the bank reads back asynchronously (ragraph_amd/kernels_index.py: a bank whose int8 levels pass hundreds
 // of candidates per query WITHOUT overflowing is slower on int8 than on bf16, and nothing else would notice).
 // Layout: [0] magic, [1] levels, [2 + l] sampled candidates of level l, [5 + l] sampled queries, [8 + l] level l ran on
-// int8, [11 + l] keys of level l, [14] queries of the call, [15] zero queries among them.
-constexpr int FILTER_STATS_INTS = 16;
+// int8, [11 + l] keys of level l, [14] queries of the call, [15] zero queries among them, [16] 1: the call filtered with a
+// SPECULATIVE first bound (ragraph_topk_cosine_filtered_set_prior), [17] queries whose speculation failed (answered by the
+// exact scan), [18] / [19] the smallest / largest final exact k-th best score of the call's queries as order-preserving
+// ints (f2ord; what the owner of the bank builds the next call's prior from), [20..32) reserved.
+constexpr int FILTER_STATS_INTS = 32;
 constexpr int FILTER_STATS_MAGIC = 0x52414753;
 __device__ __forceinline__ void note_candidates(int* cstat, int64_t b, int n) {
   if (cstat && (b & 63) == 0) {
@@ -225,7 +228,8 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
                                                           uint16_t* __restrict__ Qb, int cstride,
                                                           float* __restrict__ eq8, float* __restrict__ qscale,
                                                           signed char* __restrict__ Qb8, int* __restrict__ fix_done,
-                                                          int* __restrict__ stats, FilterStatsInit si) {
+                                                          int* __restrict__ stats, FilterStatsInit si,
+                                                          float* __restrict__ theta_init, float prior) {
   const int lane = threadIdx.x & 63;
   const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q == 0 && lane == 0) *overflow = 0;
@@ -236,8 +240,12 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
     else if (lane >= 8 && lane < 11) v = si.i8[lane - 8];
     else if (lane >= 11 && lane < 14) v = si.keys[lane - 11];
     else if (lane == 14) v = B > INT_MAX ? INT_MAX : (int)B;
+    else if (lane == 16) v = theta_init ? 1 : 0;
+    else if (lane == 18) v = INT_MAX;   // (minimum of the k-th best scores: nothing recorded yet)
+    else if (lane == 19) v = INT_MIN;
     stats[lane] = v;
   }
+  if (theta_init && q < B && lane == 0) theta_init[q] = prior;   // a speculative first bound: the same for every query
   if (q < FILTER_FIX_MAX_Q && lane == 0) fix_done[q] = 0;  // tickets of topk_overflow_fixup_kernel
   if (q >= (Qb ? (B + 31) / 32 * 32 : B)) return;
   constexpr int NCH = D / 4;  // float4 chunks per row: 16 / 32 / 64 -- at most one per lane
@@ -1065,6 +1073,7 @@ __global__ void __launch_bounds__(256) topk_rescore_kernel(const float* __restri
       if (over) {
         const int pos = atomicAdd(overflow, 1);
         overflow_list[pos] = (int)b;
+        flag[b] = 1;   // (listed: a speculative call's verify launch must not list it again)
       }
     } else if (over) {
       flag[b] = 1;
@@ -1128,6 +1137,7 @@ __global__ void __launch_bounds__(128, FEWTILE ? 4 : 1) topk_rescore_coop_kernel
       if (over) {
         const int pos = atomicAdd(overflow, 1);
         overflow_list[pos] = (int)b;
+        flag[b] = 1;   // (listed: a speculative call's verify launch must not list it again)
       }
     } else if (over) {
       flag[b] = 1;
@@ -1356,6 +1366,7 @@ __global__ void __launch_bounds__(128) topk_rescore_scored_kernel(const float* _
       if (over) {
         const int pos = atomicAdd(overflow, 1);
         overflow_list[pos] = (int)b;
+        flag[b] = 1;   // (listed: a speculative call's verify launch must not list it again)
       }
     } else if (over) {
       flag[b] = 1;
@@ -1522,7 +1533,10 @@ __global__ void __launch_bounds__(256) topk_rescore_wide_kernel(const float* __r
       const bool zero = zero_query_answer<D>(qs, w == 0 ? k : 0, idx_base, lane, out_s + b * k, out_i + b * k);
       if (threadIdx.x == 0) {
         count[b * cs] = 0;
-        if (!zero) overflow_list[atomicAdd(overflow, 1)] = (int)b;
+        if (!zero) {
+          overflow_list[atomicAdd(overflow, 1)] = (int)b;
+          flag[b] = 1;   // (listed: a speculative call's verify launch must not list it again)
+        }
       }
       return;
     }
@@ -1599,7 +1613,10 @@ __global__ void __launch_bounds__(256) topk_rescore_wide_kernel(const float* __r
     if (threadIdx.x == 0) cnt[FILTER_TICKET_SLOT] = 0;
     if (final_level && over_q) {  // (block-uniform) the fixup launch behind this one scans the bank for it, in key slices
       const bool zero = zero_query_answer<D>(qs, w == 0 ? k : 0, idx_base, lane, out_s + b * k, out_i + b * k);   // (see above)
-      if (threadIdx.x == 0 && !zero) overflow_list[atomicAdd(overflow, 1)] = (int)b;
+      if (threadIdx.x == 0 && !zero) {
+        overflow_list[atomicAdd(overflow, 1)] = (int)b;
+        flag[b] = 1;
+      }
       return;
     }
     if (w != 0) return;
@@ -1634,6 +1651,43 @@ __global__ void __launch_bounds__(256) topk_rescore_wide_kernel(const float* __r
   }
 }
 
+// A call that filtered with a SPECULATIVE first bound (ragraph_topk_cosine_filtered_set_prior: theta = the prior for every
+// query, no bound pass) is exact for a query iff its final k-th best candidate scores at least the prior: a level filtered
+// with theta_l = max(prior, the running exact k-th best) <= the final k-th best, so every key that scores at least the
+// final k-th best passed its level.  A query whose k-th best is below the prior (or that found fewer than k candidates) is
+// listed for the exact scan of the fixup launch behind this one, like a query whose list overflowed.  The same pass
+// records the smallest / largest final k-th best of the call (stats[18] / [19]): the next call's prior comes from them.
+// (Zero queries -- flag 2 -- are answered without a scan and not judged; queries already listed by the final level
+// -- flag 1 / an overflowed list -- carry -inf or stale rows: listed twice would be scanned twice, so they are skipped by
+// their flag.)
+__global__ void __launch_bounds__(256) filter_verify_prior_kernel(const float* __restrict__ out_s, int64_t B, int k, float prior,
+                                                                  int speculative, const unsigned char* __restrict__ flag,
+                                                                  int* __restrict__ overflow, int* __restrict__ overflow_list,
+                                                                  int* __restrict__ stats) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int lo = INT_MAX, hi = INT_MIN, failed = 0;
+  if (q < B && flag[q] != 2) {
+    const float kth = out_s[q * k + k - 1];
+    if (speculative && flag[q] == 0 && !(kth >= prior)) {
+      overflow_list[atomicAdd(overflow, 1)] = (int)q;
+      failed = 1;
+    } else if (kth > RG_NEG_INF) {
+      lo = hi = f2ord(kth);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    lo = min(lo, __shfl_xor(lo, off));
+    hi = max(hi, __shfl_xor(hi, off));
+    failed += __shfl_xor(failed, off);
+  }
+  if ((threadIdx.x & 63) == 0 && stats) {
+    if (lo != INT_MAX) atomicMin(stats + 18, lo);
+    if (hi != INT_MIN) atomicMax(stats + 19, hi);
+    if (failed) atomicAdd(stats + 17, failed);
+  }
+}
+
 // Large batches (the one-wave-per-query rescoring kernels): the final level has listed the overflowed queries, and this
 // launch -- a fixed grid that finds an empty list on ordinary banks and returns -- runs exact_scan_query for each.
 // (Below 2048 queries the workgroup-per-query rescoring kernels call it themselves and this launch is not made.)
@@ -1652,13 +1706,37 @@ __global__ void __launch_bounds__(256) topk_overflow_fixup_kernel(const float* _
                                                                   int64_t* __restrict__ overflow_idx_out,
                                                                   float* __restrict__ out_s, int64_t* __restrict__ out_i,
                                                                   int* __restrict__ done, float* __restrict__ part_s,
-                                                                  int64_t* __restrict__ part_i) {
+                                                                  int64_t* __restrict__ part_i, int64_t B,
+                                                                  const unsigned char* __restrict__ flag,
+                                                                  int* __restrict__ stats) {
   __shared__ float4 qs[D / 4];
   __shared__ __attribute__((aligned(16))) float tile[4][64 * RESCORE_LD];
   __shared__ float ps[4][32];
   __shared__ int64_t pi[4][32];
   __shared__ int ticket_s;
   const int n_over = *overflow;
+  if (stats && stats[16] == 0) {
+    // the smallest / largest final k-th best score of the call's queries (stats[18] / [19]; a speculative call's verify
+    // launch has recorded them already): one value per thread, wave-reduced, two atomics per wave that saw any.  (Rows the
+    // scans below are about to rewrite still hold their candidates' k-th best, a lower value: the record is a hint.)
+    int lo = INT_MAX, hi = INT_MIN;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < B; q += (int64_t)gridDim.x * 256) {
+      const float kth = flag[q] == 2 ? RG_NEG_INF : out_s[q * k + k - 1];
+      if (kth > RG_NEG_INF) {
+        lo = min(lo, f2ord(kth));
+        hi = max(hi, f2ord(kth));
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      lo = min(lo, __shfl_xor(lo, off));
+      hi = max(hi, __shfl_xor(hi, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (lo != INT_MAX) atomicMin(stats + 18, lo);
+      if (hi != INT_MIN) atomicMax(stats + 19, hi);
+    }
+  }
   if (n_over <= 0) return;
   int SL = 1;
   if (n_over <= FILTER_FIX_MAX_Q)
@@ -2126,6 +2204,16 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
 // A caller that knows its bank (ragraph_amd/kernels_index.py: the copy's measured error, or a call that overflowed) caps
 // the int8 levels of ITS thread's following calls: -1 = the rule below, 0 = none.  Thread-local: no shared state.
 static thread_local int t_max_i8_levels = -1;
+// A SPECULATIVE first bound for the calling thread's following filtered calls (NaN = none, the default): the owner of a bank
+// that has answered many queries knows where their k-th best scores lie (the statistics words of every call), and a call
+// that starts from theta = prior for every query needs no bound pass -- filter_verify_prior_kernel proves each query's
+// answer afterwards and sends the (rare) misses to the exact scan, so the result is exact whatever the prior is.
+static thread_local float t_prior = __builtin_nanf("");
+extern "C" float ragraph_topk_cosine_filtered_set_prior(float theta_prior) {
+  const float old = t_prior;
+  t_prior = theta_prior;
+  return old;
+}
 extern "C" int ragraph_topk_cosine_filtered_max_i8_levels(int n) {
   const int old = t_max_i8_levels;
   t_max_i8_levels = n < 0 ? -1 : n;
@@ -2677,7 +2765,12 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   const signed char* Kb8 = reinterpret_cast<const signed char*>(Kb + (filter_round_up(N) + 1) * D);
   const unsigned* tail8 = reinterpret_cast<const unsigned*>(Kb8 + filter_round_up(N) * D);
   sc.i8_levels = filter_i8_levels(sc, B, D, plan_N);
-  const bool bound = sc.bound_keys > 0;
+  // a speculative first bound (this thread's prior; single banks whose schedule has a bound pass to save): no bound pass,
+  // theta = prior for every query, every level filters with max(prior, the running k-th best), and the verify launch
+  // behind the last level sends the queries the prior was too high for to the exact scan
+  const float prior = t_prior;
+  const bool spec = !exchange && sc.bound_keys > 0 && prior == prior && prior > -2.f && prior < 2.f && N == plan_N;
+  const bool bound = sc.bound_keys > 0 && !spec;
 
   FilterStatsInit stats_init{};
   stats_init.nlev = sc.nlev;
@@ -2691,7 +2784,7 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
                      f.Qn, f.eq, f.count, f.flag, overflow, bound ? f.gmax : nullptr, bound ? filter_bound_parts(k, sc.bound_keys, D, B, exchange ? n_shards : 1) : k,
                      B <= FILTER_QB_MAX_B ? f.Qb : nullptr,
                      filter_count_stride(B), sc.i8_levels > 0 ? f.eq8 : nullptr, f.qscale, B <= FILTER_QB_MAX_B ? f.Qb8 : nullptr, f.fix_done,
-                     stats, stats_init);
+                     stats, stats_init, spec ? f.theta : nullptr, prior);
   RG_CHECK_LAUNCH("topk_cosine_filtered(prepare)");
 
   FilterThr thr{};
@@ -2708,7 +2801,9 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   int rc = RAGRAPH_OK, fallback_done = 0;
   // the first bound: group maxima of a bf16 pass over a prefix, or an exact level 0 over the first n0 keys (out_scores /
   // out_idx hold every level's running result, local indices)
-  if (bound) {
+  if (spec) {
+    // (nothing to compute: the prepare launch has written theta)
+  } else if (bound) {
     rc = run_bf16_pass<D>(f, Kb, B, 0, sc.bound_keys, thr, cap, parts, 3, st);
     if (t_prof) {
       t_prof->bound = 1;
@@ -2746,7 +2841,7 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   int64_t key0 = 0;
   for (int l = 0; l < sc.nlev; ++l) {  // the first level re-reads [0, n0): its keys pass the bound and need no merge
     thr.gmax = (l == 0 && bound && !exchange && parts == k) ? f.gmax : nullptr;  // (k parts: the minimum, inline)
-    if (!exchange) thr.theta = (l == 0 && bound && parts > k) ? f.theta : nullptr;
+    if (!exchange) thr.theta = (spec || (l == 0 && bound && parts > k)) ? f.theta : nullptr;
     thr.prev_scores = out_scores;
     const bool i8_level = l >= sc.nlev - sc.i8_levels;
     // (sharded banks keep the plain lists: a level's threshold already is the k-th best over ALL shards -- sharper than
@@ -2786,6 +2881,13 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
                         &fallback_done, exchange != nullptr && l > 0, st, scored ? &thr : nullptr, l < 3 ? stats + 2 + l : nullptr);
     if (rc != RAGRAPH_OK) return rc;
     key0 = sc.ends[l];
+    if (spec && l + 1 < sc.nlev) {  // the next level filters with max(prior, the exact k-th best so far)
+      FilterThr t2 = thr;
+      t2.gmax = nullptr;
+      t2.theta = nullptr;
+      hipLaunchKernelGGL(filter_theta_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, t2, B, 0, f.theta);
+      RG_CHECK_LAUNCH("topk_cosine_filtered(theta)");
+    }
     if (exchange && l + 1 < sc.nlev) {  // this shard's k-th exact score so far sharpens theta; then the other shards'
       FilterThr t2 = thr;
       t2.gmax = nullptr;
@@ -2797,9 +2899,16 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   }
   // overflowed queries (none on ordinary banks): exact fp32 scan on the device -- no host read-back (the sliced
   // rescoring of a handful of queries has done it inside its merge launch)
+  if (spec) {
+    hipLaunchKernelGGL(filter_verify_prior_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, out_scores, B, k, prior, 1, f.flag,
+                       overflow, f.overflow_list, stats);
+    RG_CHECK_LAUNCH("topk_cosine_filtered(verify)");
+    fallback_done = 0;
+  }
   if (fallback_done) return RAGRAPH_OK;
   hipLaunchKernelGGL(topk_overflow_fixup_kernel<D>, dim3(256), dim3(256), 0, st, f.Qn, Kn, N, k, idx_base,
-                     overflow, f.overflow_list, overflow_idx, out_scores, out_idx, f.fix_done, f.fix_s, f.fix_i);
+                     overflow, f.overflow_list, overflow_idx, out_scores, out_idx, f.fix_done, f.fix_s, f.fix_i, B, f.flag,
+                     exchange ? nullptr : stats);
   RG_CHECK_LAUNCH("topk_cosine_filtered(overflow fallback)");
   return RAGRAPH_OK;
 }

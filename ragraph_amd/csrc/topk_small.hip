@@ -41,7 +41,10 @@ constexpr int SMALL_MAX_B = 32;
 // LDS list (pruned before the reservation) plus what a flood appended directly while its bound was still rising -- 256
 // workgroups x 32 + slack; beyond the cap (every workgroup moving on without a bound AND passing its whole share, for
 // several queries) the query is answered by the exact scan, as before.
-constexpr int SMALL_LIST_CAP = 16384;
+#ifndef RG_SMALL_LIST_CAP
+#define RG_SMALL_LIST_CAP 16384
+#endif
+constexpr int SMALL_LIST_CAP = RG_SMALL_LIST_CAP;
 constexpr int SMALL_PRUNE_MIN = 64;      // pairs in a workgroup's LDS list from which it looks for queries to prune
 constexpr int SMALL_PARTS_MAX = 256;     // parts of the bound prefix: ONE PER WORKGROUP that has bound units (four per lane of the selecting wave)
 constexpr int SMALL_WG_LIST = 1024;      // exact pairs a workgroup collects in LDS before its one reservation per query
@@ -197,7 +200,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   int* qcnt = reinterpret_cast<int*>(theta_lds + 32);         // [32] this workgroup's exact pairs per query
   int* qbase = qcnt + 32;                                     // [32] their place in the query's list
   int* misc = qbase + 32;                                     // [0] wg_n, [1] all bound units in, [2] last workgroup, [3] overflowed queries,
-                                                              // [4] rounds of a flood, [5] the workgroup's pairs, [8..24) compaction counts
+                                                              // [4] rounds of a flood (0: none), [8..24) compaction counts
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -783,29 +786,27 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
     }
   };
   {
-    // pairs this wave will score, and the workgroup's total: when they all fit the LDS list (every ordinary call: a few
-    // pairs per workgroup) each wave scores its entries in one go.  Otherwise -- a FLOOD: a workgroup that moved on
-    // without a bound passes its whole share, a query next to thousands of near-duplicates -- the waves go in rounds of
-    // 8 entries (<= 64 pairs a wave, 512 a round) with the list pruned to the workgroup's k best per query and theta
-    // raised between the rounds, so that nothing spills into the queries' global lists and the flood thins out at once.
+    // A wave whose pairs fit its eighth of the LDS list (every ordinary call: a few pairs per workgroup) scores them at
+    // once, without waiting for anybody.  A wave with more -- a FLOOD: a workgroup that moved on without a bound passes its
+    // whole share, a query next to thousands of near-duplicates -- announces its rounds of 8 entries (<= 64 pairs a wave,
+    // 512 a round); behind the barrier every wave joins the rounds: the list is pruned to the workgroup's k best per query
+    // and compacted, theta raised, then the flooding waves score their next 8 entries -- so nothing spills into the
+    // queries' global lists and the flood thins out at once.
     int np = 0;
     for (int i = lane; i < wcnt; i += 64) np += __popc(wbuf[i].y & 0xFFu);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) np += __shfl_xor(np, off);
-    if (lane == 0) {
-      atomicAdd(misc + 5, np);
-      atomicMax(misc + 4, (wcnt + 7) / 8);
+    const bool flooding = np > SMALL_WG_LIST / 8;   // (wave-uniform)
+    if (flooding) {
+      if (lane == 0) atomicMax(misc + 4, (wcnt + 7) / 8);
+    } else {
+      for (int i0 = 0; i0 < wcnt; i0 += 64) score_entries(i0, i0 + 64 < wcnt ? i0 + 64 : wcnt);
     }
     __syncthreads();
-    if (misc[5] <= SMALL_WG_LIST) {   // (block-uniform)
-      for (int i0 = 0; i0 < wcnt; i0 += 64) score_entries(i0, i0 + 64 < wcnt ? i0 + 64 : wcnt);
-    } else {
-      const int nrounds = misc[4];
-      for (int rd = 0; rd < nrounds; ++rd) {
-        if (8 * rd < wcnt) score_entries(8 * rd, 8 * rd + 8 < wcnt ? 8 * rd + 8 : wcnt);
-        if (rd + 1 == nrounds) break;
-        __syncthreads();
-        const int n = misc[0] < SMALL_WG_LIST ? misc[0] : SMALL_WG_LIST;
+    const int nrounds = misc[4];   // (block-uniform; 0: nobody floods)
+    for (int rd = 0; rd < nrounds; ++rd) {
+      const int n = misc[0] < SMALL_WG_LIST ? misc[0] : SMALL_WG_LIST;
+      if (n >= SMALL_PRUNE_MIN) {   // (block-uniform)
         prune_list(n);
         __syncthreads();
         // compaction: every thread holds its two entries, then all are written back densely
@@ -843,6 +844,8 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
         }
         __syncthreads();
       }
+      if (flooding && 8 * rd < wcnt) score_entries(8 * rd, 8 * rd + 8 < wcnt ? 8 * rd + 8 : wcnt);
+      __syncthreads();
     }
   }
   __syncthreads();

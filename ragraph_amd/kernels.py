@@ -188,6 +188,23 @@ def filtered_i8_levels(B: int, n_keys: int, D: int, k: int) -> int:
     return N.lib().ragraph_topk_cosine_filtered_i8_levels(B, n_keys, D, k)
 
 
+def set_filter_prior(theta_prior) -> float:
+    """A speculative first bound for this thread's following filtered calls (None / NaN: none); returns the old one.
+    ragraph_topk_cosine_filtered_set_prior: exact for any value -- queries it is too high for take the exact scan."""
+    return N.lib().ragraph_topk_cosine_filtered_set_prior(float("nan") if theta_prior is None else float(theta_prior))
+
+
+def ord2f(v: int) -> float:
+    """The float behind an order-preserving int of the statistics words (csrc/filter_common.h f2ord: non-negative floats
+    keep their bits, negative ones have the 31 low bits flipped)."""
+    import struct
+
+    v = int(v)
+    if v < 0:
+        v ^= 0x7FFFFFFF
+    return struct.unpack("<f", struct.pack("<i", v))[0]
+
+
 def set_max_i8_levels(n: int) -> int:
     """Cap the int8 levels of this thread's following filtered calls (-1: the library's rule); returns the old cap."""
     return N.lib().ragraph_topk_cosine_filtered_max_i8_levels(int(n))
@@ -262,7 +279,7 @@ def topk_cosine_filtered(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf
     all-zero queries are answered without a scan and never counted);
     the call itself recomputed those rows with an exact fp32 scan on the device, so the result is complete and nothing
     is read back: the call is asynchronous and HIP-graph capturable.  (`int(overflow)` synchronises.)
-    return_stats=True: a fourth result, a [16] int32 device view of THIS call's candidate statistics (filter_stats_levels).
+    return_stats=True: a fourth result, a [32] int32 device view of THIS call's candidate statistics (filter_stats_levels).
 
     Row-sharded banks: `exchange(phase, theta, scores)` is called between the phases of the call
     (ragraph_topk_cosine_filtered_sharded_f32) with theta [B] = this shard's lower bound of every query's final k-th
@@ -298,7 +315,7 @@ def topk_cosine_filtered(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf
         raise RagraphNativeError(f"topk_cosine_filtered: unsupported shape B={B} N={Nk} D={D} k={k}")
     ws = _workspace(nbytes, q.device)
     off = L.ragraph_topk_cosine_filtered_stats_offset(ws.numel())
-    stats = ws[off:off + 64].view(torch.int32)   # (valid until the next filtered call on this stream)
+    stats = ws[off:off + 128].view(torch.int32)   # (32 words; valid until the next filtered call on this stream)
     if exchange is None:
         N.check(L.ragraph_topk_cosine_filtered_f32(q.data_ptr(), B, kn.data_ptr(), kp, keys_bf16.data_ptr(), Nk, D, k,
                                                    idx_base, scores.data_ptr(), idx.data_ptr(), overflow.data_ptr(), None,

@@ -38,6 +38,21 @@ class KeyIndex:
     # overflows costs an exact scan per overflowed query); a probe that fails demotes again and quadruples the interval.
     REPROBE_QUERIES = 1 << 20
     REPROBE_MAX_BATCH = 4096
+    # Speculative first bound (ops.set_filter_prior, csrc/topk_filter.hip): every filtered call reports the smallest and the
+    # largest final k-th best score of its queries; once SPEC_WARM_CALLS calls over SPEC_WARM_QUERIES queries have, the next
+    # calls of at least SPEC_MIN_BATCH queries start from prior = lowest seen - max(SPEC_MARGIN x (highest - lowest seen),
+    # SPEC_MIN_MARGIN) instead of running a bound pass (a fifth to a quarter of a mid-sized call).  The call proves every
+    # answer and scans exactly for the queries the prior was too high for: one such query costs more than the pass saves, so
+    # a call that reports misses -- or candidates beyond SPEC_MAX_CANDIDATES x the bound pass's calls' -- withdraws the
+    # prior until the re-probe interval has passed (a failed re-probe quadruples it).  Banks whose queries' k-th best
+    # scores spread widely (a prior far below most of them: a flood of candidates) end there after one call.
+    SPEC_MIN_BATCH = 17
+    SPEC_WARM_CALLS = 2
+    SPEC_WARM_QUERIES = 64
+    SPEC_MARGIN = 0.5
+    SPEC_MIN_MARGIN = 0.01
+    SPEC_MAX_CANDIDATES = 1.5
+    SPEC_HISTORY = 16
     DEDUP_MIN_ROWS = 2048
     DEDUP_MAX_UNIQUE = 0.9
     DEDUP_MAX_GROUP = 64
@@ -69,7 +84,13 @@ class KeyIndex:
         self._host_word = self._event = None
         self._overflowed = 0
         self.last_i8_candidates = None   # candidates per query over the int8 levels of the last polled call (sampled)
+        # speculative first bound, per k: {"hist": [(lowest, highest k-th best of a polled call)], "queries": seen, "off_at":
+        # query count at which it was withdrawn (None: in use), "after": re-probe interval, "cand": candidates per query of
+        # the last polled call WITH a bound pass, "failed": misses so far}
+        self._spec = {}
+        self.spec_enabled = True
         self.last_stats = None           # device view of the last filtered call's statistics words (this index, this stream)
+        self.last_prior = None           # the speculative first bound the last filtered call ran with (None: a bound pass)
         # None: duplicates not looked at yet; False: looked at, searched as it is; else (KeyIndex over the unique rows,
         # group_ptr, members)
         self._collapsed = None if dedup else False
@@ -125,6 +146,9 @@ class KeyIndex:
             return
         n_over, B = int(pend[0][0]), pend[2]   # (no kernel counts all-zero queries: they are answered without a scan)
         self._pending = None
+        words = pend[0][1:].tolist()
+        if len(pend) > 4 and pend[4] and len(words) >= 20 and words[0] == 0x52414753:
+            n_over = self._judge_prior(pend[4], B, words, n_over)   # (what is left is the lists' fault)
         self._overflowed += n_over
         i8_was_off = self._i8_off               # (the call ran under this setting: the overflow rule below judges IT)
         if pend[3] and pend[0].numel() > 16:   # the call's sampled candidate counts (int8 levels only are judged)
@@ -147,6 +171,41 @@ class KeyIndex:
             acc[0] = acc[1] = 0
         elif acc[0] >= 4096:
             acc[0] = acc[1] = 0
+
+    def _judge_prior(self, k: int, B: int, words, n_over: int) -> int:
+        """A polled call's statistics words: feed the k-th-best history; judge a speculative call (misses, candidates,
+        overflowed lists).  Returns the overflow count the LISTS are to be judged by: a speculative call's misses are not
+        their fault, and neither are lists that overflowed under a prior (far below most queries' k-th best it floods them:
+        the prior goes, the bank is judged by its calls with a bound pass)."""
+        st = self._spec_state(k)
+        spec, failed, lo, hi = words[16], words[17], words[18], words[19]
+        lists_over = max(n_over - failed, 0)
+        cand = None
+        if any(words[5 + l] for l in range(3)):
+            cand = sum(words[2 + l] / words[5 + l] for l in range(min(words[1], 3)) if words[5 + l])
+        if lists_over:
+            st["hist"], st["queries"] = [], 0      # (a bank whose lists overflow is no ground for a prior)
+        elif lo != 0x7FFFFFFF and hi != -0x80000000 and B - failed > 0:
+            from .kernels import ord2f
+            st["hist"].append((ord2f(lo), ord2f(hi)))
+            del st["hist"][:-self.SPEC_HISTORY]
+            st["queries"] += B
+        if not spec:
+            if cand is not None and not lists_over:
+                st["cand"] = cand
+            return lists_over
+        st["used"] += 1
+        st["failed"] += failed
+        loose = cand is not None and st["cand"] is not None and cand > self.SPEC_MAX_CANDIDATES * max(st["cand"], 32.0)
+        if failed or loose or lists_over:
+            probed_at = st.get("probed_at")
+            if probed_at is not None and self._queries - probed_at < st["after"]:
+                st["after"] = min(st["after"] * 4, 1 << 40)   # the re-probe failed
+            st["off_at"] = self._queries
+            if failed:   # the history missed these queries' scores: start it over (their k-th best arrives with the next calls)
+                st["hist"] = []
+                st["queries"] = 0
+        return 0   # (a speculative call says nothing about the lists)
 
     def _demote(self, what: str):
         """int8 -> bf16 levels ("i8") or filter -> fp32 kernels ("filter"), until the re-probe.  A demotion within one interval
@@ -181,21 +240,44 @@ class KeyIndex:
                 self._probed_at[what] = self._queries
                 return
 
-    def _note_overflow(self, over, B: int, had_i8: bool, stats=None):
+    def _spec_state(self, k: int) -> dict:
+        st = self._spec.get(k)
+        if st is None:
+            st = self._spec[k] = {"hist": [], "queries": 0, "off_at": None, "after": self.REPROBE_QUERIES, "cand": None,
+                                  "failed": 0, "used": 0}
+        return st
+
+    def _prior_for(self, B: int, k: int):
+        """The speculative first bound for a call of B queries, or None (not warm yet, withdrawn, switched off, capturing)."""
+        if not self.spec_enabled or B < self.SPEC_MIN_BATCH or getattr(self.ops, "set_filter_prior", None) is None:
+            return None
+        st = self._spec_state(k)
+        if st["off_at"] is not None:
+            if self._queries - st["off_at"] < st["after"] or B > self.REPROBE_MAX_BATCH:
+                return None
+            st["off_at"] = None          # re-probe: a miss now quadruples the interval (see _poll_overflow)
+            st["probed_at"] = self._queries
+        if len(st["hist"]) < self.SPEC_WARM_CALLS or st["queries"] < self.SPEC_WARM_QUERIES:
+            return None
+        lo = min(h[0] for h in st["hist"])
+        hi = max(h[1] for h in st["hist"])
+        return lo - max(self.SPEC_MARGIN * (hi - lo), self.SPEC_MIN_MARGIN)
+
+    def _note_overflow(self, over, B: int, had_i8: bool, stats=None, k: int = 0):
         """After a filtered call: its overflow count travels to a pinned host word behind an event (no wait) and is
         judged by _poll_overflow at a later call."""
         if not over.is_cuda:  # (the CPU tests' oracle shim)
             self._overflowed += int(over)
         elif self._pending is None and not torch.cuda.is_current_stream_capturing():
             if self._host_word is None:
-                self._host_word = torch.zeros(17, dtype=torch.int32).pin_memory()   # [0] overflow, [1:17] the call's statistics
+                self._host_word = torch.zeros(33, dtype=torch.int32).pin_memory()   # [0] overflow, [1:33] the call's statistics
                 self._event = torch.cuda.Event()
             self._host_word[:1].copy_(over, non_blocking=True)
             self._host_word[1:].zero_()
             if stats is not None:
-                self._host_word[1:].copy_(stats, non_blocking=True)
+                self._host_word[1:1 + stats.numel()].copy_(stats, non_blocking=True)
             self._event.record()
-            self._pending = (self._host_word, self._event, B, had_i8)
+            self._pending = (self._host_word, self._event, B, had_i8, k)
 
     def _cap_i8(self):
         """Before a filtered call: cap this thread's int8 levels for THIS bank (ops.set_max_i8_levels; the caller resets it
@@ -293,6 +375,9 @@ class KeyIndex:
             cap, had_i8 = self._cap_i8()
             had_i8 = had_i8 and ops.filtered_i8_levels(B, kn.shape[0], D, k) > 0   # (did THIS call have int8 levels?)
             stats = None
+            prior = self._prior_for(B, k)
+            if prior is not None:
+                ops.set_filter_prior(prior)
             try:
                 if getattr(ops, "FILTER_STATS", False):   # this call's own statistics words, handed on explicitly
                     s, i, over, stats = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base,
@@ -302,7 +387,10 @@ class KeyIndex:
             finally:
                 if cap is not None:
                     cap(-1)
-            self._note_overflow(over, B, had_i8, stats)
+                if prior is not None:
+                    ops.set_filter_prior(None)
+            self.last_prior = prior
+            self._note_overflow(over, B, had_i8, stats, k)
             self.last_stats = stats   # (diagnostic: bench.py / tools read the levels' candidate counts of the last call)
             return s, i
         helps = getattr(ops, "packed_keys_help", None)
