@@ -2016,7 +2016,10 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
                      (N * n_shards >= 65536 || (D == 256 && B >= 2048 && N * n_shards >= 32768));
   const bool mid_i8 = i8_ok && N * n_shards < 65536;
   static const bool i8_direct_env = [] { const char* e = getenv("RAGRAPH_FILTER_I8_DIRECT"); return !e || atoi(e) != 0; }();  // A/B
-  const bool i8_direct = (D == 128 || D == 256) && B <= 256 && N * n_shards >= 65536 && i8_direct_env;
+  // (D = 64, round 5: the edge flavour's calls of up to 256 queries -- half the stream, the scores' spread 1/8 against the
+  // same eps; RAGRAPH_FILTER_I8_DIRECT_D64=0: A/B)
+  static const bool i8_direct_d64 = [] { const char* e = getenv("RAGRAPH_FILTER_I8_DIRECT_D64"); return !e || atoi(e) != 0; }();
+  const bool i8_direct = (D == 128 || D == 256 || (D == 64 && i8_direct_d64)) && B <= 256 && N * n_shards >= 65536 && i8_direct_env;
   // bound_keys / eff_div ~ the exact sample the bound is worth: planned for 4 k parts, corrected below if the prefix is
   // too short for that many
   const double eff_div = filter_bound_eff(k, B <= 64 ? k : 4 * k);
@@ -2225,8 +2228,8 @@ static int filter_i8_levels(const FilterSchedule& sc, int64_t B, int D, int64_t 
   const char* env = getenv("RAGRAPH_FILTER_I8");  // (read per call: the tests switch it)
   const int force = env ? atoi(env) : -1;
   if (D != 64 && D != 128 && D != 256) return 0;
-  if (B <= 256) {  // the direct kernel's int8 form (D = 128 / 256): every level or none, as the schedule planned
-    if (D == 64 || t_max_i8_levels == 0 || sc.i8_levels == 0) return 0;
+  if (B <= 256) {  // the direct kernel's int8 form: every level or none, as the schedule planned
+    if (t_max_i8_levels == 0 || sc.i8_levels == 0) return 0;
     return sc.nlev;
   }
   if (force >= 0) return force < sc.nlev ? force : sc.nlev;

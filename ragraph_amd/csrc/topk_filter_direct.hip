@@ -39,8 +39,9 @@ struct DirectCfg {
   static constexpr int UNIT_BLOCKS = 16;             // blocks per unit = 16 KiB in flight per wave and buffer
   static constexpr int SUBS = UNIT_BLOCKS / KSTEPS;  // sub-tiles per unit: 1 / 2 / 4
   static constexpr int UNIT_KEYS = 32 * SUBS;        // 32 / 64 / 128
-  static constexpr int CAND_BUF = SUBS == 1 ? 256 : 512;  // entries (8 B) of a wave's candidate buffer; one group pass
-                                                         // over a unit pushes at most 64 SUBS of them
+  // entries (8 B) of a wave's candidate buffer; one group pass over a unit pushes at most 64 SUBS of them, two groups are
+  // processed per flush check (D = 32: the int8 copy of a D = 64 bank, 8 sub-tiles per unit)
+  static constexpr int CAND_BUF = SUBS == 1 ? 256 : (SUBS <= 4 ? 512 : 128 * SUBS + 64);
   static constexpr int GROUP_BYTES = KS32 * 1024;    // one group of 16 queries as bf16 B operands
 #ifndef RG_DIRECT_LA
 #define RG_DIRECT_LA 4
@@ -480,10 +481,7 @@ static int launch_filter_direct_i8(const DirectArgs& a, hipStream_t st) {
 template <int D>
 int launch_filter_direct(const DirectArgs& a, hipStream_t st) {
   using C = DirectCfg<D>;
-  if constexpr (D >= 128) {
-    if (a.i8) return launch_filter_direct_i8<D>(a, st);
-  }
-  RG_REQUIRE(!a.i8, RAGRAPH_EUNSUPPORTED, "filter(direct): no int8 form at D = %d", D);
+  if (a.i8) return launch_filter_direct_i8<D>(a, st);   // (D = 64: the geometry of a 32-element bf16 row, one MFMA per half)
   RG_REQUIRE(a.B >= 1 && a.B <= 256, RAGRAPH_EINVAL, "filter(direct): B=%lld not in [1,256]", (long long)a.B);
   RG_REQUIRE(a.key0 % C::UNIT_KEYS == 0 && a.key1 > a.key0, RAGRAPH_EINVAL, "filter(direct): bad key range");
   DirectParams p{};

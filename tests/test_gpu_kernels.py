@@ -914,7 +914,10 @@ def test_key_index_drops_int8_before_the_filter_when_a_bank_overflows(dev):
 
 
 @pytest.mark.parametrize("D,B,N,k", [(256, 1, 70000, 10), (256, 16, 100000, 5), (128, 33, 70000, 10), (256, 200, 150000, 10),
-                                     (128, 256, 66000, 7), (256, 64, 300000, 10)])
+                                     (128, 256, 66000, 7), (256, 64, 300000, 10),
+                                     # D = 64 (round 5; the edge flavour's width): one MFMA per 16-key half, 8 sub-tiles per unit
+                                     (64, 1, 70000, 10), (64, 20, 131072, 10), (64, 40, 200000, 10), (64, 256, 300000, 5),
+                                     (64, 130, 70001, 10)])
 def test_topk_cosine_filtered_int8_direct_kernel_bit_exact(dev, D, B, N, k):
     """Up to 256 queries against a bank of >= 65 536 keys: the direct kernel's pass runs on the int8 copy (half the stream,
     half the matrix work; the schedule planned for ~3x the candidates) -- the oracle's bits, with ties, a zero query and the
