@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Copy what tools/gpu_round_<round>.sh left under gpurun_out/<tag>/ into profiles/r3_* (the files the docs and bench.py cite)
-and rebuild profiles/r3_pmc_traffic.json from the PMC summaries.   python tools/collect_profiles.py r3"""
+"""Copy what tools/gpu_round_<round>.sh left under gpurun_out/<tag>/ into profiles/<round>_* (the files the docs and bench.py
+cite) and rebuild profiles/<round>_pmc_traffic.json from the PMC summaries.   python tools/collect_profiles.py r5"""
 import csv, json, os, re, shutil, sys
 
 tag = sys.argv[1]
@@ -100,5 +100,44 @@ for B in SMALL:
                 "FETCH_SIZE_KB": d["FETCH_SIZE"], "WRITE_SIZE_KB": d.get("WRITE_SIZE"), "hbm_side_GB": round(gb, 3),
                 "kernel_us": None if us is None else round(us, 1),
                 "kernel_TBps": None if not us else round(gb / us * 1e3, 2)}
+# ---- round 5: the GNN forward's counter bytes (bench.py gnn_fwd.bytes_counter), the other configs, the A/B logs -------------
+def maybe_cp(a, b):
+    if os.path.exists(os.path.join(src, a)):
+        cp(a, b)
+        return True
+    return False
+
+
+GNN_FORWARDS = 13   # tools/prof_gnn.py under --pmc: 3 warm-ups + 10 repetitions
+for mode in ("plain", "structured"):
+    path = os.path.join(src, f"gnn_{mode}_pmc.txt")
+    if not os.path.exists(path):
+        continue
+    g = pmc(path)
+    per, total = {}, 0.0
+    for nm, d in g.items():
+        if "FETCH_SIZE" not in d or "csr_row_normalize" in nm or "csr_sym" in nm or "sort" in nm or "scan" in nm or "ingest" in nm:
+            continue
+        calls = d["FETCH_SIZE_n"] / GNN_FORWARDS
+        if calls < 0.9:        # (once-per-graph kernels: ingestion, row normalisation)
+            continue
+        kb = 2 * d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0.0)
+        per[nm.replace("ragraph::", "")] = {"launches_per_forward": round(calls, 2), "FETCH_SIZE_KB": d["FETCH_SIZE"],
+                                            "WRITE_SIZE_KB": d.get("WRITE_SIZE"), "hbm_side_MB_per_launch": round(kb * 1024 / 1e6, 1)}
+        total += calls * kb * 1024
+    log = open(os.path.join(src, f"gnn_{mode}.log")).read()
+    m = re.search(r"(gnn_forward n=\d+ F=\d+ D=\d+ hops=\d+) nnz=(\d+).*?: ([0-9.]+) ms per forward", log)
+    if m:
+        key = m.group(1) + (" structured+reordered" if mode == "structured" else "")
+        out[key] = {"hbm_side_bytes": int(total), "per_kernel": per, "ms_per_forward_under_rocprof": float(m.group(3)), "nnz": int(m.group(2)),
+                    "how": "tools/prof_gnn.py under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); per launch 2 FETCH + WRITE, "
+                           "summed over the launches of one forward (1 GCN layer + 3 hops)"}
+    maybe_cp(f"gnn_{mode}_kernel_stats.csv", f"{P}_gnn_{mode}_kernel_stats.csv")
+    maybe_cp(f"gnn_{mode}_pmc.txt", f"{P}_gnn_{mode}_pmc_traffic.txt")
+maybe_cp("configs.txt", f"{P}_configs.txt")
+maybe_cp("d64_ab.txt", f"{P}_d64_ab.txt")
+maybe_cp("pmc_B512_sq.txt", f"{P}_B512_sq_counters.txt")
+for B in (256, 512, 4096):
+    maybe_cp(f"smallb_noprior_B{B}_kernel_stats.csv", f"{P}_smallb_B{B}_kernel_stats_with_bound_pass.csv")
 json.dump(out, open(os.path.join(dst, f"{P}_pmc_traffic.json"), "w"), indent=2)
 print(json.dumps(out, indent=1)[:3000])
