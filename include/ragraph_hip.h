@@ -330,6 +330,15 @@ int ragraph_gather_reduce_f32(const float* V, int D, const float* L, int C, int6
 int ragraph_linear_f32(const float* X, int64_t M, int K, const float* W, int64_t N, const float* bias, int act,
                        float alpha, float* Y, void* stream);
 
+/* f4 (fine-tuning backward)  C = A^T B for tall row-major operands  -- the weight gradient of a dense layer, gW = gY^T X
+ *     (torch autograd of nn.Linear in RAGraph_node/finetune-rag.py:81-84, TaskDecoder.py:15-16; the edge flavour's gating
+ *     weight, modules/RAGraph.py:168).  A [n,M], B [n,N], C [M,N]; any n, M, N >= 1.  The rows are cut into ranges whose
+ *     partial products (fmaf chains over the range's rows in order, from +0) are added in range order: deterministic,
+ *     and within fp32 rounding of torch's (tests: 1e-4 relative).  ws: ragraph_linear_tn_workspace_bytes(n, M, N). */
+size_t ragraph_linear_tn_workspace_bytes(int64_t n, int M, int N);
+int ragraph_linear_tn_f32(const float* A, const float* B, int64_t n, int M, int N, float* C, void* ws, size_t ws_bytes,
+                          void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * a4/a7/a11  CSR SpMM with fused epilogue
  *     Y[r,:] = act( sum_{e in row r} val[e] * X[col[e],:]  + bias ) + beta * Y_in[r,:]

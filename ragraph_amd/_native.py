@@ -70,6 +70,8 @@ SIGNATURES = {
     "ragraph_gather_rows_f32": (_i32, [_vp, _i64, _i32, _vp, _i64, _i64, _vp, _vp]),
     "ragraph_gather_reduce_f32": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp, _i64, _i32, _i64, _f32, _vp, _vp, _vp]),
     "ragraph_linear_f32": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _i32, _f32, _vp, _vp]),
+    "ragraph_linear_tn_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "ragraph_linear_tn_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
     "ragraph_spmm_csr_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _i32, _f32, _f32, _vp, _vp, _vp]),
     "ragraph_radix_sort_workspace_bytes": (_sz, [_i64, _i32]),
     "ragraph_radix_sort_u64": (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _sz, _vp]),

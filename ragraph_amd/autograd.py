@@ -38,10 +38,9 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = K.linear(gy, w.t().contiguous())                      # gy @ W
         if ctx.needs_input_grad[1]:
-            gw = K.linear(gy.t().contiguous(), x.t().contiguous())     # gy^T @ x
+            gw = K.linear_tn(gy, x)                                    # gy^T @ x, no transposed copies
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            seg = torch.tensor([0, gy.shape[0]], dtype=torch.int64, device=gy.device)
-            gb = K.segment_reduce(gy, seg).reshape(-1)
+            gb = K.column_sums(gy)
         return gx, gw, gb, None, None
 
 
@@ -134,8 +133,7 @@ class _SpmmCsr(torch.autograd.Function):
             else:
                 gz = K.act_grad(y, gy, ctx.act, ctx.alpha)
             if want_alpha:
-                seg = torch.tensor([0, terms.shape[0]], dtype=torch.int64, device=gy.device)
-                galpha = K.segment_reduce(terms, seg).sum().reshape(1)   # (the last 256 -> 1 is bookkeeping)
+                galpha = K.column_sums(terms).sum().reshape(1)   # (the last 256 -> 1 is bookkeeping)
         else:
             gz = gy
         gx = gb = None
@@ -143,8 +141,7 @@ class _SpmmCsr(torch.autograd.Function):
             gt = ctx.g.transposed()
             gx = K.spmm_csr(gt.rowptr, gt.col, gt.val, gz, long_rows=gt.has_long_rows)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            seg = torch.tensor([0, gz.shape[0]], dtype=torch.int64, device=gz.device)
-            gb = K.segment_reduce(gz, seg).reshape(-1)
+            gb = K.column_sums(gz)
         return None, gx, gb, None, galpha, None
 
 
@@ -229,8 +226,7 @@ class _MulCols(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             D = x.shape[-1]
             prod = K.mul(gz.reshape(-1, D), x.reshape(-1, D))
-            seg = torch.tensor([0, prod.shape[0]], dtype=torch.int64, device=prod.device)
-            gw = K.segment_reduce(prod, seg).reshape(w.shape)
+            gw = K.column_sums(prod).reshape(w.shape)
         return gx, gw, None, None
 
 
@@ -313,7 +309,7 @@ class _Mix2(torch.autograd.Function):
             def total(t):  # all elements of t added in a fixed order: columns of the row sums, then those
                 D = t.shape[-1]
                 rows = t.reshape(-1, D)
-                col = K.segment_reduce(rows, torch.tensor([0, rows.shape[0]], dtype=torch.int64, device=t.device))
+                col = K.column_sums(rows)
                 return K.segment_reduce(col.reshape(D, 1).contiguous(), torch.tensor([0, D], dtype=torch.int64, device=t.device))
             gw = torch.cat([total(K.mul(go, a)), total(K.mul(go, b))], 1).reshape(w.shape)
         return ga, gb, gw

@@ -426,9 +426,112 @@ static int launch_linear_stream(const float* X, int64_t M, const float* W, int64
   return RAGRAPH_OK;
 }
 
+// ---- C = A^T B for TALL operands: A [n, M], B [n, N] row-major, C [M, N] -- the weight gradient of a dense layer,
+// gW = gY^T X (autograd._Linear.backward; finetune-rag.py:81-84 trains the decoder on every node of the batch: n = 100 000,
+// M = N = 256 at c2).  Through ragraph_linear_f32 that product needed both operands TRANSPOSED (two 100-MB copies) and ran as
+// 16 blocks with a 100 000-long chain each: 1.8 ms a product.  Here the contraction index is the ROW: a v_mfma_f32_32x32x2
+// step consumes two rows, its A operand is 32 consecutive floats of each of them (lane (j, h) = A[r + h][i0 + j]: one
+// coalesced dword per lane straight from the row-major operand, no transpose, no LDS), a wave holds a 64 x 64 tile of C, a
+// workgroup 128 x 128, and the rows are cut into `splits` ranges over gridDim.y whose partial tiles are summed in range
+// order by a second launch (deterministic: every C[i][j] is a fixed tree -- fmaf chains over the rows of a range from +0,
+// the ranges added in order).
+__global__ void __launch_bounds__(256) linear_tn_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_t n,
+                                                        int M, int N, int64_t chunk, int tiles_n, float* __restrict__ part) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int i0 = tm * 128 + (wave >> 1) * 64, j0 = tn * 128 + (wave & 1) * 64;
+  const int64_t r0 = (int64_t)blockIdx.y * chunk, r1 = r0 + chunk < n ? r0 + chunk : n;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const bool am[2] = {i0 + j < M, i0 + 32 + j < M};
+  const bool bm[2] = {j0 + j < N, j0 + 32 + j < N};
+  const float* ap = A + i0 + j;
+  const float* bp = B + j0 + j;
+  constexpr int U = 4;   // row pairs in flight
+  for (int64_t r = r0; r < r1; r += 2 * U) {
+    float av[U][2], bv[U][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = r + 2 * u + h;
+      const bool ok = row < r1;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        av[u][c] = (ok && am[c]) ? ap[row * M + 32 * c] : 0.f;
+        bv[u][c] = (ok && bm[c]) ? bp[row * N + 32 * c] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+  }
+  float* out = part + (int64_t)blockIdx.y * M * N;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int col = j0 + 32 * b + j;
+      if (col >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < M) out[(int64_t)row * N + col] = acc[a][b][r];
+      }
+    }
+}
+
+__global__ void __launch_bounds__(256) linear_tn_reduce_kernel(const float* __restrict__ part, int splits, int64_t mn,
+                                                               float* __restrict__ C) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= mn) return;
+  float s = part[e];
+  for (int p = 1; p < splits; ++p) s = __fadd_rn(s, part[(int64_t)p * mn + e]);
+  C[e] = s;
+}
+
+static int linear_tn_splits(int64_t n, int M, int N) {
+  const int64_t tiles = cdiv(M, 128) * cdiv(N, 128);
+  int64_t s = cdiv(1024, tiles);
+  const int64_t max_s = cdiv(n, 256);   // (at least 256 rows a range)
+  if (s > max_s) s = max_s;
+  return (int)(s < 1 ? 1 : s);
+}
+
 }  // namespace ragraph
 
 using namespace ragraph;
+
+extern "C" size_t ragraph_linear_tn_workspace_bytes(int64_t n, int M, int N) {
+  if (n < 1 || M < 1 || N < 1) return 0;
+  return (size_t)linear_tn_splits(n, M, N) * (size_t)M * (size_t)N * sizeof(float);
+}
+
+extern "C" int ragraph_linear_tn_f32(const float* A, const float* B, int64_t n, int M, int N, float* C, void* ws, size_t ws_bytes,
+                                     void* stream) {
+  RG_REQUIRE(A && B && C && ws, RAGRAPH_EINVAL, "linear_tn: null pointer");
+  RG_REQUIRE(n >= 1 && M >= 1 && N >= 1, RAGRAPH_EINVAL, "linear_tn: n, M, N must be >= 1");
+  const int splits = linear_tn_splits(n, M, N);
+  RG_REQUIRE(ws_bytes >= ragraph_linear_tn_workspace_bytes(n, M, N), RAGRAPH_EWORKSPACE, "linear_tn: workspace too small");
+  int64_t chunk = cdiv(n, (int64_t)splits);
+  chunk = (chunk + 7) / 8 * 8;   // (whole groups of four row pairs)
+  const int tiles_n = (int)cdiv(N, 128);
+  dim3 grid((unsigned)(cdiv(M, 128) * tiles_n), (unsigned)cdiv(n, chunk));
+  hipLaunchKernelGGL(linear_tn_kernel, grid, dim3(256), 0, as_stream(stream), A, B, n, M, N, chunk, tiles_n, static_cast<float*>(ws));
+  RG_CHECK_LAUNCH("linear_tn");
+  const int64_t mn = (int64_t)M * N;
+  hipLaunchKernelGGL(linear_tn_reduce_kernel, dim3((unsigned)cdiv(mn, 256)), dim3(256), 0, as_stream(stream), static_cast<const float*>(ws),
+                     (int)grid.y, mn, C);
+  RG_CHECK_LAUNCH("linear_tn(reduce)");
+  return RAGRAPH_OK;
+}
 
 extern "C" int ragraph_linear_f32(const float* X, int64_t M, int K, const float* W, int64_t N, const float* bias,
                                   int act, float alpha, float* Y, void* stream) {

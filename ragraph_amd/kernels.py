@@ -590,6 +590,38 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = No
     return y.reshape(tuple(lead) + (w.shape[0],))
 
 
+def linear_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a^T @ b for tall row-major operands: a [n, M], b [n, N] -> [M, N] (ragraph_linear_tn_f32: the weight gradient of a
+    dense layer without transposed copies, the rows cut into ranges summed in order -- deterministic)."""
+    L = _ready()
+    a, b = _f32c(a, "linear_tn.a"), _f32c(b, "linear_tn.b")
+    if a.dim() != 2 or b.dim() != 2 or a.shape[0] != b.shape[0]:
+        raise RagraphNativeError(f"linear_tn: bad shapes {tuple(a.shape)} / {tuple(b.shape)}")
+    n, M, Nn = a.shape[0], a.shape[1], b.shape[1]
+    out = torch.empty((M, Nn), dtype=torch.float32, device=a.device)
+    if n == 0:
+        return out.zero_()
+    ws = _workspace(L.ragraph_linear_tn_workspace_bytes(n, M, Nn), a.device)
+    N.check(L.ragraph_linear_tn_f32(a.data_ptr(), b.data_ptr(), n, M, Nn, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+            "linear_tn")
+    return out
+
+
+def column_sums(x: torch.Tensor) -> torch.Tensor:
+    """Sum over the rows of x [n, D] -> [D] (a bias gradient): ranges of COLSUM_ROWS rows summed sequentially by one lane
+    group each (ragraph_segment_reduce_f32), then the range sums in order -- deterministic, and chip-wide where one segment
+    of 100 000 rows was one workgroup's 7.5-ms chain."""
+    x = _f32c(x, "column_sums.x")
+    n = x.shape[0]
+    if n <= COLSUM_ROWS:
+        return segment_reduce(x, torch.tensor([0, n], dtype=torch.int64, device=x.device)).reshape(-1)
+    ptr = torch.arange(0, n + COLSUM_ROWS, COLSUM_ROWS, dtype=torch.int64, device=x.device).clamp_(max=n)
+    part = segment_reduce(x, ptr)
+    return segment_reduce(part, torch.tensor([0, part.shape[0]], dtype=torch.int64, device=x.device)).reshape(-1)
+
+
+COLSUM_ROWS = 256
+
 ROW_BLOCK = 4096  # rows / segments longer than this are summed in blocks (csrc/sparse.hip, oracle ORACLE_ROW_BLOCK)
 
 

@@ -350,3 +350,44 @@ def test_weighted_feature_gradients(dev):
     assert torch.allclose(out, ref, atol=1e-6)
     assert torch.allclose(a.grad, ar.grad, atol=1e-6) and torch.allclose(b.grad, br.grad, atol=1e-6)
     assert torch.allclose(mod.weight.grad, wr.grad, atol=1e-4), (mod.weight.grad, wr.grad)
+
+
+@pytest.mark.parametrize("n,M,N", [(1, 1, 1), (7, 3, 5), (300, 3, 256), (1000, 256, 256), (4097, 130, 70), (100_000, 256, 256),
+                                   (50_001, 3, 256)])
+def test_linear_tn_matches_torch(dev, n, M, N):
+    """gW = gY^T X without transposed copies (ragraph_linear_tn_f32): against torch in fp64 (1e-5 of the largest entry x sqrt
+    of the rows summed), deterministic from call to call, and -- one row range -- the bits of ragraph_linear_f32 on transposed copies."""
+    from ragraph_amd import kernels as K
+
+    g = torch.Generator(device=dev).manual_seed(n + M + N)
+    a = torch.randn(n, M, device=dev, generator=g)
+    b = torch.randn(n, N, device=dev, generator=g)
+    got = K.linear_tn(a, b)
+    ref = (a.double().t() @ b.double())
+    assert got.shape == (M, N)
+    assert float((got.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())) * max(1.0, n ** 0.5 / 8)
+    assert torch.equal(got, K.linear_tn(a, b))
+    if n <= 256:   # a single range: the product through the dense kernel's chains over k = rows (transposed operands), bit for bit
+        assert torch.equal(got, K.linear(a.t().contiguous(), b.t().contiguous()))
+
+
+def test_column_sums_and_decoder_training_step_at_100k_rows(dev):
+    """The bias gradient of 100 000 rows (one workgroup's 7.5-ms chain in round 4) as ranges summed chip-wide, and the decoder's
+    training step on that many rows against torch autograd."""
+    from ragraph_amd import autograd as A
+    from ragraph_amd import kernels as K
+
+    g = torch.Generator(device=dev).manual_seed(4)
+    x = torch.randn(100_000, 256, device=dev, generator=g)
+    cs = K.column_sums(x)
+    assert float((cs.double() - x.double().sum(0)).abs().max()) < 1e-2 and torch.equal(cs, K.column_sums(x))
+    assert torch.equal(K.column_sums(x[:200]), K.segment_reduce(x[:200].contiguous(), torch.tensor([0, 200], device=dev)).reshape(-1))
+    w = (0.05 * torch.randn(64, 256, device=dev, generator=g)).requires_grad_(True)
+    bia = torch.zeros(64, device=dev, requires_grad=True)
+    y = A.linear(x, w, bia, K.ACT_LEAKY, 0.01)
+    tgt = torch.randn(100_000, 64, device=dev, generator=g)
+    ((y - tgt) ** 2).mean().backward()
+    w2, b2 = w.detach().clone().requires_grad_(True), bia.detach().clone().requires_grad_(True)
+    y2 = torch.nn.functional.leaky_relu(torch.nn.functional.linear(x, w2, b2), 0.01)
+    ((y2 - tgt) ** 2).mean().backward()
+    assert close(w.grad, w2.grad) and close(bia.grad, b2.grad)
