@@ -145,6 +145,7 @@ class Heartbeat:
         self.last = time.time()
         self.phase = "start"
         self.done = False
+        self.headline = None   # the finished headline record, once there is one (see _watch)
         self("start")
         self.thread = threading.Thread(target=self._watch, daemon=True)
         self.thread.start()
@@ -173,6 +174,13 @@ class Heartbeat:
             if not self.done and time.time() - self.last > self.timeout:
                 print(json.dumps({"bench_watchdog": f"rank {self.rank}: no progress for {self.timeout:.0f} s in phase "
                                                     f"'{self.phase}'", "ranks": self.report()}), file=sys.stderr, flush=True)
+                if self.phase.startswith("layout ") and self.headline is not None:
+                    # the HEADLINE layout has been timed and verified; only an extra layout behind it stopped: every rank
+                    # leaves with 0 and rank 0 prints the line it has (the stopped layout named in it)
+                    if self.rank == 0:
+                        line = dict(self.headline, other_layouts_error=f"stopped in phase '{self.phase}' ({self.timeout:.0f} s)")
+                        print(json.dumps(line), flush=True)
+                    os._exit(0)
                 os._exit(124)
 
     def stop(self):
@@ -704,6 +712,8 @@ def main():
     for w_ in range(args.warmup):
         beat(f"warm-up step {w_}")
         step()
+        torch.cuda.synchronize()   # (untimed: the dispatch settles -- overflow counts and the speculative first bound's
+                                   # statistics arrive behind an event and are read at the NEXT call)
     topk_timer.enabled = filt_timer.enabled = True
     beat("timed steps")
     elapsed, out = timed_steps(step, args.steps, world, dev, grab_filter_ms)
@@ -860,6 +870,8 @@ def main():
         torch.cuda.empty_cache()
         others = [sh for sh in ("keys", "queries", "hybrid") if sh != args.shard and
                   (sh != "hybrid" or (world >= 4 and world % args.key_shards == 0 and 1 < args.key_shards < world))]
+        if hb is not None:
+            hb.headline = dict(result, verified=verified) if verified is not None else dict(result)
         for sh in others:
             beat(f"layout {sh}: build")
             m2, f2, a2, nl2 = build_workload(args, dev, rank, world, sh, force_dist)

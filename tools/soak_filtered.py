@@ -1,7 +1,10 @@
 """Randomised soak of the bf16-filtered exact top-k against the fp32 kernels (both on the GPU; the fp32 kernels are
 the oracle-checked ones): random shapes, banks with duplicates / clusters / tiny norms, random idx_base.
-  python tools/soak_filtered.py [seconds] [seed] [filtered|index]
-"index": through KeyIndex.topk -- the product dispatch (fused small-bank kernel, direct / ring filter, fp32 kernels)."""
+  python tools/soak_filtered.py [seconds] [seed] [filtered|index|prior|spec]
+"index": through KeyIndex.topk -- the product dispatch (fused small-bank kernel, direct / ring filter, fp32 kernels).
+"prior": topk_cosine_filtered under a FORCED speculative first bound drawn around the batch's true k-th best scores (below all
+of them, among them, above all of them).  "spec": KeyIndex over several calls with fresh queries, synchronised in between, so
+that the index derives, uses and withdraws its own prior."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -54,6 +57,37 @@ while time.time() - t0 < budget:
         if ri(0, 1):  # a second call on the same index (cached copies, the overflow feedback of the first)
             s1, i1 = idx.topk(q, k, idx_base=base)
         over = 0
+    elif mode == "spec":
+        idx = K.KeyIndex(kn)
+        over = 0
+        for c in range(ri(3, 6)):   # earlier calls with other queries of the same kind feed the statistics
+            qq = torch.randn(B, D, device=dev, generator=g)
+            if kind == 1:
+                qq = kn[torch.randint(0, N, (B,), device=dev, generator=g)] + 0.2 * qq
+            if ri(0, 3) == 0:
+                qq = qq * torch.linspace(0.2, 1.0, D, device=dev)   # a batch from another distribution now and then
+            sq, iq = idx.topk(qq, k, idx_base=base)
+            torch.cuda.synchronize()
+            s0q, i0q = K.topk_cosine(qq, kn, k, idx_base=base)
+            if not (torch.equal(iq, i0q) and torch.equal(sq, s0q)):
+                print(f"MISMATCH (spec, call {c}) B={B} N={N} D={D} k={k} kind={kind} prior={idx.search_index.last_prior}", flush=True)
+                sys.exit(1)
+        s1, i1 = idx.topk(q, k, idx_base=base)
+        kinds["spec_used"] = kinds.get("spec_used", 0) + (1 if idx.search_index.last_prior is not None else 0)
+    elif mode == "prior":
+        if not K.filter_helps(B, N, D, k):
+            continue
+        s0, i0 = K.topk_cosine(q, kn, k, idx_base=base)
+        kth = s0[:, k - 1]
+        lo, hi = float(kth.min()), float(kth.max())
+        prior = (lo - 0.02, lo - 0.2, 0.5 * (lo + hi), hi + 0.02, lo + 1e-4)[ri(0, 4)]
+        if B > 300 and prior > lo:   # (every miss is an exact scan: keep the forced-miss cases small)
+            prior = lo - 0.01
+        K.set_filter_prior(prior)
+        try:
+            s1, i1, over = K.topk_cosine_filtered(q, kn, K.keys_to_bf16(kn), k, idx_base=base)
+        finally:
+            K.set_filter_prior(None)
     else:
         s1, i1, over = K.topk_cosine_filtered(q, kn, K.keys_to_bf16(kn), k, idx_base=base)
     s0, i0 = K.topk_cosine(q, kn, k, idx_base=base)
