@@ -1,0 +1,96 @@
+"""The host-side policy of the speculative first bound (ragraph_amd/kernels_index.py: KeyIndex._prior_for / _judge_prior) on
+synthetic statistics words -- no GPU: when the prior appears, what it is, and what withdraws it."""
+import struct
+
+import torch
+
+from ragraph_amd.kernels_index import KeyIndex
+
+MAGIC = 0x52414753
+
+
+def f2ord(x):
+    b = struct.unpack("<i", struct.pack("<f", x))[0]
+    return b if b >= 0 else b ^ 0x7FFFFFFF
+
+
+class Ops:
+    """Just enough of ragraph_amd.kernels for the policy code."""
+    FILTER_STATS = True
+
+    def __init__(self):
+        self.prior = None
+
+    def set_filter_prior(self, p):
+        self.prior = p
+
+
+def words(spec, failed, lo, hi, cand=100.0, B=512):
+    w = [0] * 32
+    w[0], w[1] = MAGIC, 1
+    w[2], w[5] = int(cand * 8), 8          # sampled candidates / sampled queries of level 0
+    w[14], w[16], w[17], w[18], w[19] = B, spec, failed, f2ord(lo), f2ord(hi)
+    return w
+
+
+def index():
+    idx = KeyIndex(torch.zeros(4, 64), ops=Ops(), dedup=False)
+    idx._queries = 0
+    return idx
+
+
+def test_prior_appears_after_two_calls_and_sits_below_everything_seen():
+    idx = index()
+    assert idx._prior_for(512, 10) is None                                  # nothing seen yet
+    assert idx._judge_prior(10, 512, words(0, 0, 0.250, 0.280), 0) == 0
+    assert idx._prior_for(512, 10) is None                                  # one call is not enough
+    idx._judge_prior(10, 512, words(0, 0, 0.255, 0.290), 0)
+    p = idx._prior_for(512, 10)
+    assert abs(p - (0.250 - 0.5 * (0.290 - 0.250))) < 1e-6                   # lowest seen - half the spread
+    assert idx._prior_for(16, 10) is None                                   # the single-launch kernel's batch sizes: never
+    assert idx._prior_for(512, 5) is None                                   # another k has its own history
+    idx2 = index()
+    for _ in range(3):
+        idx2._judge_prior(10, 512, words(0, 0, 0.3000, 0.3001), 0)
+    assert abs(idx2._prior_for(512, 10) - (0.3000 - KeyIndex.SPEC_MIN_MARGIN)) < 1e-6   # a narrow spread: the minimum margin
+    idx2.spec_enabled = False
+    assert idx2._prior_for(512, 10) is None
+
+
+def test_a_miss_withdraws_the_prior_and_is_not_blamed_on_the_lists():
+    idx = index()
+    for _ in range(2):
+        idx._judge_prior(10, 512, words(0, 0, 0.25, 0.28), 0)
+    assert idx._prior_for(512, 10) is not None
+    left = idx._judge_prior(10, 512, words(1, 7, 0.26, 0.28), 7)             # a speculative call with 7 misses, 7 "overflowed"
+    assert left == 0                                                        # nothing for the int8 / filter demotion rules
+    st = idx._spec[10]
+    assert st["failed"] == 7 and st["off_at"] is not None and st["hist"] == []
+    assert idx._prior_for(512, 10) is None
+    # the re-probe interval passes (and the history refills): speculation is tried again on a small call
+    for _ in range(2):
+        idx._judge_prior(10, 512, words(0, 0, 0.20, 0.28), 0)
+    idx._queries += KeyIndex.REPROBE_QUERIES
+    assert idx._prior_for(100_000, 10) is None                               # not on a call this large
+    assert idx._prior_for(512, 10) is not None
+    # a miss right behind the re-probe quadruples the interval
+    idx._judge_prior(10, 512, words(1, 1, 0.21, 0.28), 1)
+    assert st["after"] == 4 * KeyIndex.REPROBE_QUERIES
+
+
+def test_loose_priors_and_overflowing_lists_withdraw_it_too():
+    idx = index()
+    for _ in range(2):
+        idx._judge_prior(10, 512, words(0, 0, 0.25, 0.28, cand=100.0), 0)
+    assert idx._judge_prior(10, 512, words(1, 0, 0.25, 0.28, cand=140.0), 0) == 0
+    assert idx._spec[10]["off_at"] is None                                   # 1.4 x the bound pass's candidates: kept
+    idx._judge_prior(10, 512, words(1, 0, 0.25, 0.28, cand=400.0), 0)
+    assert idx._spec[10]["off_at"] is not None                               # 4 x: the prior is too loose to pay
+    idx = index()
+    for _ in range(2):
+        idx._judge_prior(10, 512, words(0, 0, 0.25, 0.28), 0)
+    assert idx._judge_prior(10, 512, words(1, 0, 0.25, 0.28), 30) == 0       # lists overflowed UNDER the prior: its fault
+    assert idx._spec[10]["off_at"] is not None
+    idx = index()
+    assert idx._judge_prior(10, 512, words(0, 0, 0.25, 0.28), 30) == 30      # ... with a bound pass: the lists' own
+    assert idx._spec[10]["hist"] == []                                       # and such a call is no ground for a prior
