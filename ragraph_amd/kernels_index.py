@@ -147,11 +147,15 @@ class KeyIndex:
         n_over, B = int(pend[0][0]), pend[2]   # (no kernel counts all-zero queries: they are answered without a scan)
         self._pending = None
         words = pend[0][1:].tolist()
+        speculative = False
         if len(pend) > 4 and pend[4] and len(words) >= 20 and words[0] == 0x52414753:
+            speculative = bool(words[16])
             n_over = self._judge_prior(pend[4], B, words, n_over)   # (what is left is the lists' fault)
         self._overflowed += n_over
         i8_was_off = self._i8_off               # (the call ran under this setting: the overflow rule below judges IT)
-        if pend[3] and pend[0].numel() > 16:   # the call's sampled candidate counts (int8 levels only are judged)
+        # the call's sampled candidate counts (int8 levels only are judged -- and only of a call with a bound pass: what a
+        # prior far below the queries' k-th best lets through says nothing about the int8 copy, _judge_prior withdraws the prior)
+        if pend[3] and pend[0].numel() > 16 and not speculative:
             from .kernels import filter_stats_levels
             i8 = [(keys, c) for dt, keys, c in filter_stats_levels(pend[0][1:17].tolist()) if dt == "int8" and c is not None]
             if i8:
