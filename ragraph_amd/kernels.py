@@ -613,7 +613,7 @@ def column_sums(x: torch.Tensor) -> torch.Tensor:
     of 100 000 rows was one workgroup's 7.5-ms chain."""
     x = _f32c(x, "column_sums.x")
     n = x.shape[0]
-    if n <= COLSUM_ROWS:
+    if n <= COLSUM_SINGLE_MAX:   # (a batch of a few hundred nodes: one launch beats ranges + their pointer bookkeeping)
         return segment_reduce(x, torch.tensor([0, n], dtype=torch.int64, device=x.device)).reshape(-1)
     ptr = torch.arange(0, n + COLSUM_ROWS, COLSUM_ROWS, dtype=torch.int64, device=x.device).clamp_(max=n)
     part = segment_reduce(x, ptr)
@@ -621,6 +621,8 @@ def column_sums(x: torch.Tensor) -> torch.Tensor:
 
 
 COLSUM_ROWS = 256
+COLSUM_SINGLE_MAX = 2048
+LINEAR_TN_MIN_ROWS = 2048   # below: gY^T X through the dense kernel on transposed copies (tiny copies, no range sums)
 
 ROW_BLOCK = 4096  # rows / segments longer than this are summed in blocks (csrc/sparse.hip, oracle ORACLE_ROW_BLOCK)
 

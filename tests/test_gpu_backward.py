@@ -382,6 +382,7 @@ def test_column_sums_and_decoder_training_step_at_100k_rows(dev):
     cs = K.column_sums(x)
     assert float((cs.double() - x.double().sum(0)).abs().max()) < 1e-2 and torch.equal(cs, K.column_sums(x))
     assert torch.equal(K.column_sums(x[:200]), K.segment_reduce(x[:200].contiguous(), torch.tensor([0, 200], device=dev)).reshape(-1))
+    assert float((K.column_sums(x[:5000]).double() - x[:5000].double().sum(0)).abs().max()) < 1e-3     # ranges of 256 rows
     w = (0.05 * torch.randn(64, 256, device=dev, generator=g)).requires_grad_(True)
     bia = torch.zeros(64, device=dev, requires_grad=True)
     y = A.linear(x, w, bia, K.ACT_LEAKY, 0.01)
