@@ -345,6 +345,9 @@ def small_batch_rates(tgb, dim, k, dev):
             if cap is not None:
                 cap(-1)
             n_i8 = i8.value
+            spec = inner.last_prior is not None   # (a speculative first bound: no bound prefix is streamed)
+            if spec:
+                prefix = 0
             streamed = prefix * dim * 2 + n_keys * dim * (1 if n_i8 else 2) + B * dim * 4
             t_mfma = 2.0 * B * n_keys * dim / ((INT8_MFMA_PEAK_TOPS if n_i8 else BF16_MFMA_PEAK_TFLOPS) * 1e12)
         elif filtered:
@@ -367,7 +370,8 @@ def small_batch_rates(tgb, dim, k, dev):
         gbs = streamed / ms / 1e6
         flops = 2.0 * B * n_keys * dim
         rec = {"ms": round(ms, 4), "queries_per_s": round(B / ms * 1e3, 1),
-               "path": ("one launch (bound pass + " + ("int8" if n_i8 else "bf16") + " filter pass + exact rescoring + selection)") if one_launch
+               "path": (("one launch (" + ("speculative first bound: no bound pass; " if spec else "bound pass + ") + ("int8" if n_i8 else "bf16") +
+                         " filter pass + exact rescoring + selection)" + (" + the (empty) sliced-scan launch for misses" if spec else ""))) if one_launch
                else (("bf16-filtered" + (f", last {n_i8} level(s) on int8" if n_i8 else "") +
                       (", speculative first bound (no bound pass; answers proven behind the last level)" if spec else ""))
                      if filtered else "fp32"),

@@ -137,7 +137,8 @@ size_t ragraph_topk_cosine_filtered_workspace_bytes(int64_t B, int64_t N, int D,
  * filtered with a speculative first bound (ragraph_topk_cosine_filtered_set_prior), [17] queries that bound was too high
  * for (answered by the exact scan, counted in *overflow), [18] / [19] the smallest / largest final exact k-th best score of
  * the call's queries as order-preserving ints (bits(x) for x >= 0, bits(x) ^ 0x7FFFFFFF below: csrc/filter_common.h f2ord; INT_MAX /
- * INT_MIN: none recorded), [20..32) reserved.  sum / queries = candidates per query: what a level's rescoring costs.  The owner of a bank reads them back
+ * INT_MIN: none recorded), [20] the call's final *overflow (one copy of these words tells the owner of the bank
+ * everything), [21..32) reserved.  sum / queries = candidates per query: what a level's rescoring costs.  The owner of a bank reads them back
  * asynchronously (ragraph_amd/kernels_index.py: a bank whose int8 levels pass hundreds of candidates per query without
  * overflowing is slower on int8 than on bf16 -- the overflow count alone would never show it). */
 size_t ragraph_topk_cosine_filtered_stats_offset(size_t ws_bytes);

@@ -70,6 +70,14 @@ __device__ __forceinline__ int quantize_i8(float x, float inv_scale) {
 
 // This thread's cap on int8 levels (ragraph_topk_cosine_filtered_max_i8_levels; -1 = the library's rule, 0 = none).
 int filter_thread_i8_cap();
+// This thread's speculative first bound (ragraph_topk_cosine_filtered_set_prior; NaN = none).
+float filter_thread_prior();
+// topk_overflow_fixup_kernel (topk_filter.hip) for another caller's list of queries: exact fp32 scans of the bank, cut into
+// key slices, for the *count queries listed (a launch that returns at once when the list is empty).  done: >= 1024 zeroed
+// ints; part_s / part_i: 1024 x 16 x 32 floats / int64s.
+int launch_overflow_fixup(int D, const float* Qn, const float* Kn, int64_t N, int k, int64_t idx_base, const int* count,
+                          const int* list, float* out_s, int64_t* out_i, int* done, float* part_s, int64_t* part_i, int64_t B,
+                          void* stream);
 
 // float <-> int with the same order (for atomicMax on scores of either sign)
 __device__ __forceinline__ int f2ord(float f) {

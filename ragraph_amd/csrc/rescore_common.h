@@ -33,7 +33,8 @@ __device__ __forceinline__ void select_dpp_max(unsigned& hi, unsigned& lo) {
 
 template <int NSL>
 __device__ __forceinline__ void wave_select(const float (&s)[NSL], const int (&id)[NSL], int k, int lane, int64_t base,
-                                            float* out_s, int64_t* out_i) {
+                                            float* out_s, int64_t* out_i, float* kth_out = nullptr) {
+  // kth_out (optional, e.g. an LDS word): receives the k-th winner's score, -inf when fewer than k pairs exist
   unsigned khi[NSL], klo[NSL];
 #pragma unroll
   for (int u = 0; u < NSL; ++u) {
@@ -79,6 +80,12 @@ __device__ __forceinline__ void wave_select(const float (&s)[NSL], const int (&i
       out_s[lane] = RG_NEG_INF;
       out_i[lane] = INT64_MAX;
     }
+    if (kth_out) {
+#pragma unroll
+      for (int u = 0; u < NSL; ++u)
+        if (mine[u] != 0ull && rank[u] == k - 1) *kth_out = select_unord(khi[u]);
+      if (lane == 0 && n_real < k) *kth_out = RG_NEG_INF;
+    }
     return;
   }
   unsigned my_hi = 0u, my_lo = 0u;  // lane r: the r-th winner
@@ -119,6 +126,7 @@ __device__ __forceinline__ void wave_select(const float (&s)[NSL], const int (&i
     const bool empty = (my_hi | my_lo) == 0u;
     out_s[lane] = empty ? RG_NEG_INF : select_unord(my_hi);
     out_i[lane] = empty ? INT64_MAX : (int64_t)(int)~my_lo + base;
+    if (kth_out && lane == k - 1) *kth_out = empty ? RG_NEG_INF : select_unord(my_hi);
   }
 }
 

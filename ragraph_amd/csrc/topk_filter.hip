@@ -204,7 +204,8 @@ __global__ void __launch_bounds__(256) keys_to_i8_kernel(const float* __restrict
 // int8, [11 + l] keys of level l, [14] queries of the call, [15] zero queries among them, [16] 1: the call filtered with a
 // SPECULATIVE first bound (ragraph_topk_cosine_filtered_set_prior), [17] queries whose speculation failed (answered by the
 // exact scan), [18] / [19] the smallest / largest final exact k-th best score of the call's queries as order-preserving
-// ints (f2ord; what the owner of the bank builds the next call's prior from), [20..32) reserved.
+// ints (f2ord; what the owner of the bank builds the next call's prior from), [20] the call's final *overflow (so that ONE
+// copy of these words tells the owner everything), [21..32) reserved.
 constexpr int FILTER_STATS_INTS = 32;
 constexpr int FILTER_STATS_MAGIC = 0x52414753;
 __device__ __forceinline__ void note_candidates(int* cstat, int64_t b, int n) {
@@ -1728,6 +1729,7 @@ __global__ void __launch_bounds__(256) topk_overflow_fixup_kernel(const float* _
   __shared__ int64_t pi[4][32];
   __shared__ int ticket_s;
   const int n_over = *overflow;
+  if (stats && blockIdx.x == 0 && threadIdx.x == 0) stats[20] = n_over;   // (final: every launch that counts runs before this one)
   if (stats && stats[16] == 0) {
     // the smallest / largest final k-th best score of the call's queries (stats[18] / [19]; a speculative call's verify
     // launch has recorded them already): one value per thread, wave-reduced, two atomics per wave that saw any.  (Rows the
@@ -2236,6 +2238,21 @@ extern "C" int ragraph_topk_cosine_filtered_max_i8_levels(int n) {
   return old;
 }
 int ragraph::filter_thread_i8_cap() { return t_max_i8_levels; }  // (topk_small.hip: the single-launch call honours the same cap)
+float ragraph::filter_thread_prior() { return t_prior; }
+int ragraph::launch_overflow_fixup(int D, const float* Qn, const float* Kn, int64_t N, int k, int64_t idx_base, const int* count,
+                                   const int* list, float* out_s, int64_t* out_i, int* done, float* part_s, int64_t* part_i,
+                                   int64_t B, void* stream) {
+  hipStream_t st = as_stream(stream);
+#define RG_FIX(D_)                                                                                                          \
+  hipLaunchKernelGGL(topk_overflow_fixup_kernel<D_>, dim3(256), dim3(256), 0, st, Qn, Kn, N, k, idx_base, count, list,       \
+                     (int64_t*)nullptr, out_s, out_i, done, part_s, part_i, B, (const unsigned char*)nullptr, (int*)nullptr)
+  if (D == 256) RG_FIX(256);
+  else if (D == 128) RG_FIX(128);
+  else RG_FIX(64);
+#undef RG_FIX
+  RG_CHECK_LAUNCH("overflow fixup");
+  return RAGRAPH_OK;
+}
 
 static int filter_i8_levels(const FilterSchedule& sc, int64_t B, int D, int64_t N) {
   const char* env = getenv("RAGRAPH_FILTER_I8");  // (read per call: the tests switch it)

@@ -75,7 +75,18 @@ struct SmallParams {
   int* list_k;             // ... and keys
   float* out_s;
   int64_t* out_i;
-  int* overflow;           // out: queries answered by the exact scan
+  int* overflow;           // out: queries answered by an exact scan (a list beyond its cap; under a prior: a miss)
+  // a SPECULATIVE first bound (this thread's prior, ragraph_topk_cosine_filtered_set_prior): no bound units, no wait, theta =
+  // prior for every query; the last workgroup lists the queries whose k-th best pair scores below it for the sliced exact
+  // scan of the fixup launch behind this one (qn_out: their normalised rows for it)
+  int use_prior;
+  float prior;
+  float* qn_out;           // [B,D] normalised queries (written under a prior only)
+  int* miss_count;         // [1]
+  int* miss_list;          // [B]
+  int* fix_done;           // [>= B] tickets of the fixup launch: left zero
+  int* stats;              // [32] the call's statistics words (include/ragraph_hip.h: [0] magic, [14] queries, [16] speculative,
+                           // [17] misses, [18] / [19] smallest / largest final k-th best score)
 };
 
 template <int D_>
@@ -120,7 +131,7 @@ __device__ __forceinline__ unsigned long long small_key64(float s, int key) {
 // counting (wave_select<2>).  false: more than 128 keys survive (ties) -- the caller takes the chunked path.
 template <int NPL>
 __device__ __forceinline__ bool small_select_held(const unsigned long long (&held)[NPL], int k, int lane, int64_t idx_base,
-                                                  unsigned long long* surv, float* os, int64_t* oi) {
+                                                  unsigned long long* surv, float* os, int64_t* oi, float* kth_out) {
   unsigned long long best = 0ull;
 #pragma unroll
   for (int u = 0; u < NPL; ++u) best = held[u] > best ? held[u] : best;
@@ -159,7 +170,7 @@ __device__ __forceinline__ bool small_select_held(const unsigned long long (&hel
     }
   }
   __builtin_amdgcn_wave_barrier();
-  wave_select<2>(s2, id2, k, lane, idx_base, os, oi);
+  wave_select<2>(s2, id2, k, lane, idx_base, os, oi, kth_out);
   return true;
 }
 
@@ -202,6 +213,8 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   int* misc = qbase + 32;                                     // [0] wg_n, [1] all bound units in, [2] last workgroup, [3] overflowed queries,
                                                               // [4] rounds of a flood (0: none), [8..24) compaction counts
 
+  float* kth_lds = reinterpret_cast<float*>(misc + 32);       // [32] the queries' final k-th best scores (the last workgroup)
+
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -236,7 +249,10 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
     thr_lds[tid] = I8 ? __int_as_float(tid < p.B ? INT_MIN : INT_MAX) : (tid < p.B ? RG_NEG_INF : __builtin_huge_valf());
     theta_lds[tid] = RG_NEG_INF;
   }
-  if (tid < 32) misc[tid] = 0;
+  if (tid < 32) {
+    misc[tid] = 0;
+    kth_lds[tid] = RG_NEG_INF;
+  }
   constexpr int NCH = D / 4;
   float4 vrow[4];
 #pragma unroll
@@ -259,6 +275,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
     const float d = fmaxf(sqrtf(pp), 1e-12f);
     v.x = v.x / d; v.y = v.y / d; v.z = v.z / d; v.w = v.w / d;
     if (lane < NCH) *reinterpret_cast<float4*>(qn + q * QLD + 4 * lane) = v;
+    if (p.qn_out && blockIdx.x == 0 && q < B && lane < NCH) reinterpret_cast<float4*>(p.qn_out + (int64_t)q * D)[lane] = v;
     const float x[4] = {v.x, v.y, v.z, v.w};
     float e2 = 0.f;
 #pragma unroll
@@ -387,7 +404,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   // workgroups' part maxima are still on their way -- their accumulators wait in registers for the thresholds, their
   // epilogues run behind phase 2.  Two rounds of the stream (2 x 32 MB chip-wide, ~7 us of HBM time) move under the
   // wait instead of behind it.
-  const bool pre = ngq == 1 && n_mine >= 2;   // (wave-uniform)
+  const bool pre = !p.use_prior && ngq == 1 && n_mine >= 2;   // (wave-uniform)
   acc_t accP[2][GF::SUBS][2];
   auto unit_mfma_g0 = [&](f32x4 (&A)[16], acc_t (&out)[GF::SUBS][2]) {
 #pragma unroll
@@ -488,7 +505,11 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
     const float theta = kth ? __shfl(v, __ffsll((long long)kth) - 1) : RG_NEG_INF;
     if (lane == 0) raise_theta(q, theta);
   };
-  {  // a wave's queries: wave, wave + 8, ... -- all their part maxima are requested in one batch, again until none is missing
+  if (p.use_prior) {  // a speculative first bound: every query starts from it, nothing to wait for
+    if (lane == 0)
+      for (int c = 0; c < 4; ++c)
+        if (wave + 8 * c < B) raise_theta(wave + 8 * c, p.prior);
+  } else {  // a wave's queries: wave, wave + 8, ... -- all their part maxima are requested in one batch, again until none is missing
      // or the time limit has passed (workgroups of another process may hold the CUs some of ours still need)
     unsigned up[4];
     const unsigned long long t0 = wall_clock64();
@@ -954,7 +975,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
         s2[u] = have ? pf_s[c][u] : RG_NEG_INF;
         id2[u] = have ? pf_k[c][u] : INT_MAX;
       }
-      wave_select<2>(s2, id2, k, lane, p.idx_base, os, oi);
+      wave_select<2>(s2, id2, k, lane, p.idx_base, os, oi, kth_lds + q);
       continue;
     }
     if (n <= 256) {
@@ -963,7 +984,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
       unsigned long long held[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) held[u] = lane + 64 * u < n ? small_key64(pf_s[c][u], pf_k[c][u]) : 0ull;
-      if (small_select_held<4>(held, k, lane, p.idx_base, surv, os, oi)) continue;
+      if (small_select_held<4>(held, k, lane, p.idx_base, surv, os, oi, kth_lds + q)) continue;
     } else if (n <= 1024) {  // the list in registers: sixteen pairs per lane, all loads in flight at once
       unsigned long long held[16];
       float s16[16];
@@ -972,7 +993,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
       for (int u = 0; u < 16; ++u) load_pair(lane + 64 * u, s16[u], id16[u]);
 #pragma unroll
       for (int u = 0; u < 16; ++u) held[u] = id16[u] == INT_MAX ? 0ull : small_key64(s16[u], id16[u]);
-      if (small_select_held<16>(held, k, lane, p.idx_base, surv, os, oi)) continue;
+      if (small_select_held<16>(held, k, lane, p.idx_base, surv, os, oi, kth_lds + q)) continue;
     }
     // longer lists (and ties by the hundred: a bank of duplicates the collapsing did not see): chunks of 1024 pairs -- sixteen
     // per lane, all loads in flight -- against the running winners, which ride in a seventeenth slot between chunks (LDS)
@@ -992,7 +1013,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
         }
         __builtin_amdgcn_wave_barrier();
         if (i0 + 1024 >= n) {
-          wave_select<17>(s17, id17, k, lane, p.idx_base, os, oi);
+          wave_select<17>(s17, id17, k, lane, p.idx_base, os, oi, kth_lds + q);
         } else {
           wave_select<17>(s17, id17, k, lane, 0, ws_, wi_);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1063,13 +1084,47 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
         const int64_t pv = have ? pi4[e / k][e % k] : INT64_MAX;
         id2[u] = pv >= INT_MAX ? INT_MAX : (int)pv;
       }
-      wave_select<2>(s2, id2, k, lane, p.idx_base, p.out_s + (int64_t)q * k, p.out_i + (int64_t)q * k);
+      wave_select<2>(s2, id2, k, lane, p.idx_base, p.out_s + (int64_t)q * k, p.out_i + (int64_t)q * k, kth_lds + q);
     }
     __syncthreads();
   }
+  // the call's statistics words and -- under a prior -- the proof: a query's answer is exact iff its k-th best pair scores at
+  // least the prior (every key scoring at least that passed the filter: csrc/topk_filter.hip, filter_verify_prior_kernel);
+  // the others are listed, in query order, for the fixup launch behind this one.  (Zero queries were answered in place;
+  // a query the scan above answered is exact whatever it scores.)
+  __syncthreads();
+  if (tid == 0) {
+    int lo = INT_MAX, hi = INT_MIN, n_miss = 0;
+    for (int q = 0; q < B; ++q) {
+      if (sc_flag[q]) continue;
+      const float kth = kth_lds[q];
+      const bool scanned = (qcnt[q] >> 30) != 0;
+      if (p.use_prior && !scanned && !(kth >= p.prior)) {
+        p.miss_list[n_miss++] = q;
+        continue;
+      }
+      if (kth > RG_NEG_INF) {
+        lo = min(lo, f2ord(kth));
+        hi = max(hi, f2ord(kth));
+      }
+    }
+    if (p.miss_count) *p.miss_count = n_miss;
+    if (p.stats) {
+      for (int i = 0; i < 32; ++i) p.stats[i] = 0;
+      p.stats[0] = 0x52414753;
+      p.stats[1] = 1;
+      p.stats[14] = B;
+      p.stats[16] = p.use_prior;
+      p.stats[17] = n_miss;
+      p.stats[18] = lo;
+      p.stats[19] = hi;
+      p.stats[20] = n_over + n_miss;
+    }
+    *p.overflow = n_over + n_miss;
+  }
+  if (p.fix_done && tid < B) p.fix_done[tid] = 0;
   // leave the state zeroed for the next call (every other workgroup has finished: the ticket said so)
   for (int i = tid; i < SMALL_STATE_INTS; i += 512) p.state[i] = 0;
-  if (tid == 0) *p.overflow = n_over;
   RG_SSTAMP(12);
 #ifdef RG_SMALL_TIMING
   if (tid == 0)
@@ -1128,9 +1183,29 @@ extern "C" int ragraph_topk_cosine_small_ok(int64_t B, int64_t N, int D, int k) 
   return B >= 1 && B <= SMALL_MAX_B && (D == 64 || D == 128 || D == 256) && k >= 1 && k <= 32 && N >= 65536 && N < ((int64_t)1 << 31);
 }
 extern "C" size_t ragraph_topk_cosine_small_state_bytes(void) { return (size_t)SMALL_STATE_INTS * sizeof(int); }
+// workspace: the queries' pair lists | normalised queries [B,D] | miss count + list | tickets and partial winners of the fixup
+// launch (sized for its slicing: up to 32 listed queries x 16 slices x 32) | the call's 32 statistics words (the LAST 128 bytes)
+struct SmallWs {
+  size_t lists, qn, miss, done, part_s, part_i, stats, total;
+};
+static SmallWs small_ws(int64_t B, int D) {
+  SmallWs w{};
+  size_t at = 0;
+  auto take = [&](size_t n) { const size_t a = at; at += align_up(n, 256); return a; };
+  w.lists = take((size_t)B * SMALL_LIST_CAP * (sizeof(float) + sizeof(int)));
+  w.qn = take((size_t)B * D * sizeof(float));
+  w.miss = take((size_t)(1 + SMALL_MAX_B) * sizeof(int));
+  w.done = take((size_t)1024 * sizeof(int));
+  w.part_s = take((size_t)SMALL_MAX_B * 16 * 32 * sizeof(float));
+  w.part_i = take((size_t)SMALL_MAX_B * 16 * 32 * sizeof(int64_t));
+  w.stats = at;      // (exactly the last 128 bytes: callers find the words there)
+  at += 128;
+  w.total = at;
+  return w;
+}
 extern "C" size_t ragraph_topk_cosine_small_workspace_bytes(int64_t B, int D, int k) {
   if (B < 1 || B > SMALL_MAX_B) return 0;
-  return (size_t)B * SMALL_LIST_CAP * (sizeof(float) + sizeof(int));
+  return small_ws(B, D).total;
 }
 
 static bool small_uses_i8(int D) {
@@ -1182,11 +1257,23 @@ extern "C" int ragraph_topk_cosine_small_f32(const float* Q, int64_t B, const fl
   p.bound_units = prefix / unit_b;
   // (parts = the workgroups the units are dealt over, min(units, 64 .. grid): at least k of them)
   RG_REQUIRE(p.bound_units >= 2 * k, RAGRAPH_EUNSUPPORTED, "topk_cosine_small: the bank is too short for a bound pass of k = %d parts", k);
+  const float prior = filter_thread_prior();
+  const bool spec = prior == prior && prior > -2.f && prior < 2.f;
+  const SmallWs wsl = small_ws(B, D);
+  char* wb = static_cast<char*>(ws);
+  p.use_prior = spec ? 1 : 0;
+  p.prior = spec ? prior : 0.f;
+  p.qn_out = spec ? reinterpret_cast<float*>(wb + wsl.qn) : nullptr;
+  p.miss_count = reinterpret_cast<int*>(wb + wsl.miss);
+  p.miss_list = p.miss_count + 1;
+  p.fix_done = reinterpret_cast<int*>(wb + wsl.done);
+  p.stats = reinterpret_cast<int*>(wb + wsl.stats);
+  if (spec) p.bound_units = 0;   // (no bound pass: no units, no parts, nothing published or awaited)
   p.parts = 0;   // (set below, once the grid is known)
   p.nunits = cdiv(N, (int64_t)unit_f);   // (the copies are padded to whole units: 256 keys)
   p.wait_ticks = wait_ticks;
   p.state = state;
-  p.list_s = reinterpret_cast<float*>(ws);
+  p.list_s = reinterpret_cast<float*>(ws);   // (SmallWs::lists = 0)
   p.list_k = reinterpret_cast<int*>(p.list_s + (size_t)B * SMALL_LIST_CAP);
   p.out_s = out_scores;
   p.out_i = out_idx;
@@ -1198,9 +1285,15 @@ extern "C" int ragraph_topk_cosine_small_f32(const float* Q, int64_t B, const fl
     int64_t gb = p.bound_units < 64 ? p.bound_units : (cdiv(p.bound_units, (int64_t)8) < 64 ? (int64_t)64 : cdiv(p.bound_units, (int64_t)8));
     p.parts = (int)(gb < grid ? gb : grid);
   }
-  RG_REQUIRE(p.parts >= k, RAGRAPH_EUNSUPPORTED, "topk_cosine_small: %d workgroups cannot make a bound of k = %d parts", p.parts, k);
+  if (spec) p.parts = 0;
+  RG_REQUIRE(spec || p.parts >= k, RAGRAPH_EUNSUPPORTED, "topk_cosine_small: %d workgroups cannot make a bound of k = %d parts", p.parts, k);
   hipStream_t st = as_stream(stream);
-  if (D == 256) return i8 ? launch_small<256, true>(p, (int)grid, st) : launch_small<256, false>(p, (int)grid, st);
-  if (D == 128) return i8 ? launch_small<128, true>(p, (int)grid, st) : launch_small<128, false>(p, (int)grid, st);
-  return launch_small<64, false>(p, (int)grid, st);
+  int rc;
+  if (D == 256) rc = i8 ? launch_small<256, true>(p, (int)grid, st) : launch_small<256, false>(p, (int)grid, st);
+  else if (D == 128) rc = i8 ? launch_small<128, true>(p, (int)grid, st) : launch_small<128, false>(p, (int)grid, st);
+  else rc = launch_small<64, false>(p, (int)grid, st);
+  if (rc != RAGRAPH_OK || !spec) return rc;
+  // the queries the prior was too high for (none, as a rule: the launch returns at once): exact scans in key slices
+  return launch_overflow_fixup(D, p.qn_out, Kn, N, k, idx_base, p.miss_count, p.miss_list, out_scores, out_idx, p.fix_done,
+                               reinterpret_cast<float*>(wb + wsl.part_s), reinterpret_cast<int64_t*>(wb + wsl.part_i), B, stream);
 }

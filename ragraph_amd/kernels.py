@@ -443,9 +443,13 @@ def small_state_ready(device) -> bool:
     return _small_state_buf(device) is not None
 
 
-def topk_cosine_small(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf16: torch.Tensor, k: int, idx_base: int = 0):
+def topk_cosine_small(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf16: torch.Tensor, k: int, idx_base: int = 0,
+                      return_stats: bool = False):
     """Exact top-k (same bits as topk_cosine) of up to 32 queries in ONE launch (ragraph_topk_cosine_small_f32).  Returns
-    (scores, idx, overflow): overflow = 1-element int32 device tensor, the queries answered by the exact scan."""
+    (scores, idx, overflow): overflow = 1-element int32 device tensor, the queries answered by an exact scan.  Under this
+    thread's speculative first bound (set_filter_prior) the launch has no bound phase and a second, normally empty launch
+    scans for the queries the prior was too high for.  return_stats=True: + a [32] int32 view of the call's statistics words
+    ([16] speculative, [17] misses, [18] / [19] smallest / largest k-th best score: filter_stats / ord2f)."""
     L = _ready()
     q = _f32c(q, "topk_cosine_small.q")
     kn = _f32c(keys_normalized, "topk_cosine_small.keys")
@@ -471,6 +475,8 @@ def topk_cosine_small(q: torch.Tensor, keys_normalized: torch.Tensor, keys_bf16:
     if rc != 0:   # (a launch that did not happen leaves the words as they were; after any error: zero them again)
         state.zero_()
     N.check(rc, "topk_cosine_small")
+    if return_stats:
+        return scores, idx, overflow, ws[nbytes - 128:nbytes].view(torch.int32)   # (the workspace's last 128 bytes)
     return scores, idx, overflow
 
 

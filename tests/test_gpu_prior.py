@@ -124,8 +124,8 @@ def test_key_index_derives_the_prior_and_withdraws_it_after_a_miss(dev):
     assert index2.last_prior is None and torch.equal(i, i32) and torch.equal(s, s32)
 
 
-def test_prior_is_ignored_where_it_does_not_apply(dev):
-    """The sharded entry and calls without a bound pass ignore the prior; a call of the single-launch kernel never sees it."""
+def test_a_prior_far_too_high_only_costs_scans(dev):
+    """A prior above every score: every query misses and is answered by the sliced exact scan -- the same bits."""
     from ragraph_amd import kernels as K
 
     kn, g = _bank(dev, 70_000, 256, 3)
@@ -136,7 +136,7 @@ def test_prior_is_ignored_where_it_does_not_apply(dev):
     finally:
         K.set_filter_prior(None)
     s32, i32 = K.topk_cosine(q, kn, 10)
-    assert torch.equal(i, i32) and torch.equal(s, s32) and int(over) == 0
+    assert torch.equal(i, i32) and torch.equal(s, s32) and int(over) == 8
 
 
 def test_a_loose_prior_costs_one_call_and_nothing_else(dev):
@@ -165,3 +165,55 @@ def test_a_loose_prior_costs_one_call_and_nothing_else(dev):
     assert st["used"] >= 1
     assert not index._i8_off and not index._filter_off              # whatever the prior did, the copies are not blamed
     assert index.overflowed_queries == 0 or st["off_at"] is not None
+
+
+@pytest.mark.parametrize("B,N,D,k", [(1, 300_000, 256, 10), (7, 200_000, 128, 5), (16, 300_000, 256, 10), (32, 150_000, 64, 8),
+                                      (3, 100_000, 256, 32)])
+def test_small_kernel_under_forced_priors(dev, B, N, D, k):
+    """The single-launch kernel with a speculative first bound (no bound units, no wait; the last workgroup proves every answer
+    and lists the misses for the sliced scan launched behind it): exact for any prior, statistics words as the filtered call's."""
+    from ragraph_amd import kernels as K
+
+    kn, g = _bank(dev, N, D, 7 * B + D)
+    kb = K.keys_to_bf16(kn)
+    q = torch.randn(B, D, device=dev, generator=g)
+    if B >= 7:
+        q[2] = 0.0                                               # a zero query: answered in place, never judged
+    s32, i32 = K.topk_cosine(q, kn, k)
+    kth = s32[:, k - 1]
+    live = kth[kth != 0.0] if B >= 7 else kth
+    lo, hi = float(live.min()), float(live.max())
+    nz = B - (1 if B >= 7 else 0)
+    for what, prior, misses in (("below every k-th best", lo - 0.01, 0), ("far below", lo - 0.1, 0),
+                                ("above every k-th best: every query is scanned", hi + 0.02, nz),
+                                ("between", 0.5 * (lo + hi), int((live < 0.5 * (lo + hi)).sum()))):
+        K.set_filter_prior(prior)
+        try:
+            s, i, over, st = K.topk_cosine_small(q, kn, kb, k, return_stats=True)
+        finally:
+            K.set_filter_prior(None)
+        assert torch.equal(i, i32) and torch.equal(s, s32), what
+        w = st.cpu().tolist()
+        assert w[0] == K.FILTER_STATS_MAGIC and w[16] == 1 and w[17] == misses and int(over) == misses, (what, w[14:20], int(over))
+    s, i, over, st = K.topk_cosine_small(q, kn, kb, k, return_stats=True)    # no prior: the bound phase, the same words
+    w = st.cpu().tolist()
+    assert torch.equal(i, i32) and torch.equal(s, s32) and int(over) == 0
+    assert w[16] == 0 and w[17] == 0 and abs(K.ord2f(w[18]) - lo) < 1e-6 and abs(K.ord2f(w[19]) - hi) < 1e-6
+    assert int(K._small_state_buf(q.device).abs().sum()) == 0
+
+
+def test_key_index_speculates_on_single_query_calls(dev):
+    """Graph classification retrieves ONE query per forward: the index derives its prior from such calls alone."""
+    from ragraph_amd import kernels as K
+
+    kn, g = _bank(dev, 400_000, 256, 77)
+    index = K.KeyIndex(kn)
+    used = 0
+    for c in range(80):
+        q = torch.randn(1 + c % 3, 256, device=dev, generator=g)
+        s, i = index.topk(q, 10)
+        torch.cuda.synchronize()
+        used += index.last_prior is not None
+        s32, i32 = K.topk_cosine(q, kn, 10)
+        assert torch.equal(i, i32) and torch.equal(s, s32)
+    assert used >= 30 and index.overflowed_queries <= 3          # (a miss now and then is a scan, not an error)
