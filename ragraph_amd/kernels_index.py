@@ -1,6 +1,8 @@
 """Bank-side dispatch of the exact top-k (torch only: importable on a CPU box for the gloo tests)."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 
@@ -88,7 +90,7 @@ class KeyIndex:
         # query count at which it was withdrawn (None: in use), "after": re-probe interval, "cand": candidates per query of
         # the last polled call WITH a bound pass, "failed": misses so far}
         self._spec = {}
-        self.spec_enabled = True
+        self.spec_enabled = os.environ.get("RAGRAPH_SPEC", "1") != "0"   # (RAGRAPH_SPEC=0: every call with its bound pass -- A/B)
         self._notes = 0                  # calls offered to _note_overflow (small calls report every fourth once settled)
         self.last_stats = None           # device view of the last filtered call's statistics words (this index, this stream)
         self.last_prior = None           # the speculative first bound the last filtered call ran with (None: a bound pass)
