@@ -38,21 +38,31 @@ def pytest_collection_finish(session):
     logs = [open(os.path.join(out, f"rank{r}.log"), "w") for r in range(2)]
     procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), out], env=env, stdout=logs[r],
                               stderr=subprocess.STDOUT) for r in range(2)]
-    _two_rank = (procs, out, logs)
+    # ... and the four ranks of the hybrid layout (2 query groups x 2 key shards): tests/hybrid_worker.py
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port4 = s.getsockname()[1]
+    out4 = tempfile.mkdtemp(prefix="ragraph_hybrid_")
+    worker4 = os.path.join(ROOT, "tests", "hybrid_worker.py")
+    logs4 = [open(os.path.join(out4, f"rank{r}.log"), "w") for r in range(4)]
+    procs4 = [subprocess.Popen([sys.executable, worker4, str(r), "4", str(port4), out4], env=env, stdout=logs4[r],
+                               stderr=subprocess.STDOUT) for r in range(4)]
+    _two_rank = (procs, out, logs, procs4, out4, logs4)
 
 
 def pytest_sessionfinish(session, exitstatus):
     if _two_rank is not None:
         import shutil
 
-        for p in _two_rank[0]:
+        for p in list(_two_rank[0]) + list(_two_rank[3]):
             if p.poll() is None:
                 p.kill()
             p.wait()
-        for f in _two_rank[2]:
+        for f in list(_two_rank[2]) + list(_two_rank[5]):
             f.close()
         if exitstatus == 0:   # (a failed session keeps the workers' logs and reports for the post-mortem)
             shutil.rmtree(_two_rank[1], ignore_errors=True)
+            shutil.rmtree(_two_rank[4], ignore_errors=True)
 
 
 @pytest.fixture(scope="session")

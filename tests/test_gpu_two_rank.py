@@ -31,3 +31,24 @@ def test_two_ranks_on_the_hip_library_match_single_process(dev, two_rank_job):
         # scores instead of flooding the lists: nothing may end in the exact scan on this ordinary bank)
         assert rep["small_launch_overflowed"] == 0, rep
         assert rep["exchange_count"].get("0", 0) >= 2, rep   # phase-0 exchange: once per key-sharded retrieval
+
+
+def test_four_ranks_hybrid_layout(dev, two_rank_job):
+    """2 query groups x 2 key shards (HybridLayout) with four real processes on the real library: every rank's gathered
+    [n, C] output equals the single-process forward bit for bit, and the exchanges stayed inside the key groups."""
+    assert two_rank_job is not None and len(two_rank_job) >= 6, "conftest did not start the hybrid job"
+    procs, out = two_rank_job[3], two_rank_job[4]
+    for p in procs:
+        p.wait(timeout=900)
+    reports = []
+    for r in range(len(procs)):
+        path = os.path.join(out, f"rank{r}.json")
+        assert os.path.exists(path), f"rank {r} left no report (exit code {procs[r].returncode})"
+        reports.append(json.load(open(path)))
+    for r, rep in enumerate(reports):
+        assert rep["ok"], rep.get("error")
+        assert rep["world"] == 4 and rep["q_s"] == [r // 2, r % 2] and rep["layout"].startswith("hybrid 2x2")
+        assert rep["hybrid_forward_equal"], rep
+        assert rep["exchange_count"].get("0", 0) >= 1, rep
+    for g in (0, 2):   # the two ranks of a key group went through the same exchanges
+        assert reports[g]["exchange_count"] == reports[g + 1]["exchange_count"]
