@@ -55,9 +55,47 @@ __host__ __device__ constexpr int64_t filter_block_offset(int64_t subtile, int D
 // blocks of 1 KiB; block 2 t + h of sub-tile u: lane j + 16 g owns the 16 bytes holding elements 64 t + 16 g .. + 15 of
 // key 32 u + 16 h + j (A operand of v_mfma_i32_16x16x64_i8; any fixed assignment of the 64 elements to the four lane
 // groups is right as long as the query operand uses the same one: the integer sum does not depend on the order).
-// Tail of the int8 copy (one row): [0] max_k |dk|^2 (float bits), [1] s_k (float), [2] max |k_i| (float bits, >= 0).
+// TWO SCALES (round 5).  One scale for the whole bank means one heavy-tailed row (a one-hot key: |k_i| = 1) puts every
+// ordinary row on a grid three times too coarse, and even a Gaussian bank pays for its single largest entry.  So the copy
+// is cut into GRANULES of one ring stage (32 KiB of int8 rows: 128 / 256 / 512 keys at D = 256 / 128 / 64) and every
+// granule belongs to one of two classes: NORMAL (its largest |k_i| <= cut: quantised with s_N = cut / 127) or HEAVY (the
+// rest: s_H = max |k_i| / 127, the old scale).  The cut minimises a model of the candidates the two bounds admit
+// (i8_cut_kernel).  Each class has its own largest |dk| and hence its own eps and integer threshold per query; a kernel
+// picks the threshold by the class BIT of the granule it is in (one bit per granule behind the tail row) -- a select per
+// stage / unit, nothing per score.  Scored candidate lists carry the class in bit 0 of their integer ((I << 1) | class).
+// Tail of the int8 copy (one row): [0] max |dk|^2 over the NORMAL granules' keys (float bits), [1] s_N (float), [2] max
+// |k_i| of the bank (float bits, >= 0), [3] max |dk|^2 over the HEAVY granules' keys, [4] s_H, [5] the cut (float bits),
+// [6] heavy granules, [7] granules.  Behind the tail row: the granules' largest |k_i| (floats), then the class bits.
 __host__ __device__ constexpr int64_t filter_i8_block_offset(int64_t subtile, int D, int t, int h) {
   return (subtile * (D / 32) + 2 * t + h) * 1024;
+}
+__host__ __device__ constexpr int filter_i8_granule_keys(int D) { return FILTER_STAGE_BYTES / D; }
+__host__ __device__ constexpr int64_t filter_pad_keys(int64_t n) { return (n + FILTER_PAD_KEYS - 1) / FILTER_PAD_KEYS * FILTER_PAD_KEYS; }
+// The pieces of a bank copy (ragraph_keys_to_bf16's buffer) that belong to the int8 image
+struct FilterI8View {
+  const signed char* K8;   // the image: filter_pad_keys(N) rows of D bytes, fragment order
+  const unsigned* tail8;   // the tail row (above)
+  const float* gmax;       // [granules] largest |k_i| of each granule
+  const unsigned* cls;     // [ceil(granules / 32)] class bits: bit (g & 31) of word g >> 5 set = granule g is HEAVY
+  int64_t granules;
+};
+inline int64_t filter_i8_granules(int64_t N, int D) {
+  const int gk = filter_i8_granule_keys(D);
+  return (filter_pad_keys(N) + gk - 1) / gk;
+}
+inline size_t filter_i8_table_bytes(int64_t N, int D) {  // gmax floats (16-B aligned) + class words + one spare word
+  const int64_t g = filter_i8_granules(N, D);
+  return (size_t)((g * 4 + 15) / 16 * 16) + (size_t)((g + 31) / 32 * 4) + 16;
+}
+inline FilterI8View filter_i8_view(const uint16_t* Kb, int64_t N, int D) {
+  const int64_t npad = filter_pad_keys(N);
+  FilterI8View v;
+  v.K8 = reinterpret_cast<const signed char*>(Kb + (npad + 1) * D);
+  v.tail8 = reinterpret_cast<const unsigned*>(v.K8 + npad * D);
+  v.granules = filter_i8_granules(N, D);
+  v.gmax = reinterpret_cast<const float*>(reinterpret_cast<const char*>(v.tail8) + (size_t)D * 2);
+  v.cls = reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(v.gmax) + (v.granules * 4 + 15) / 16 * 16);
+  return v;
 }
 
 // rint(x * inv_scale) clamped to [-127, 127], inv_scale = 1 / scale computed ONCE per row with one fp32 division: a multiply
@@ -103,6 +141,7 @@ struct FilterThr {
   const float* eq8;
   const float* qscale;
   const unsigned* tail8;
+  const unsigned* cls8;       // the int8 copy's class bits (FilterI8View::cls)
   const unsigned char* flag;  // [B] non-zero: the query's final answer comes from the exact scan anyway (a list of an
                               // earlier level overflowed, or it is a ZERO query -- every score +0, every key within any
                               // bound: filter_prep_kernel marks it) -- nothing passes the filter for it
@@ -134,21 +173,27 @@ __device__ __forceinline__ float filter_threshold(const FilterThr& t, int64_t q)
 // The int8 levels' integer threshold: a key can only belong to the exact top-k if I = sum qi ki >= the result (see the
 // layout comment above).  INT_MIN: everything passes (a zero BANK, whose scale is 0; zero queries are flagged and pass nothing).
 // (_at: for a given lower bound theta of the query's exact k-th best score)
-__device__ __forceinline__ int filter_threshold_i8_at(const FilterThr& t, int64_t q, float theta) {
-  const float ek = sqrtf(__uint_as_float(t.tail8[0]));
-  const float e = t.eq8[q];
+// (heavy: for keys of a HEAVY granule -- that class's error and scale, tail words 3 / 4)
+__device__ __forceinline__ int filter_threshold_i8_of(float theta, float e, float ek, float sc) {
   const float eps = fmaf(fmaf(e, ek, e + ek), 1.0009765625f, FILTER_EPS_SLACK);
-  const float sc = t.qscale[q] * __uint_as_float(t.tail8[1]);
   if (!(sc > 0.f)) return INT_MIN;
   const float x = __fsub_rn(theta, eps) / sc;
   if (!(x > -8.4e6f)) return INT_MIN;   // (also NaN)
   if (x > 8.4e6f) return INT_MAX;       // beyond any |I| <= 127^2 * 256: nothing can pass
   return (int)floorf(x) - 2;
 }
-__device__ __forceinline__ int filter_threshold_i8(const FilterThr& t, int64_t q) {
+__device__ __forceinline__ int filter_threshold_i8_at(const FilterThr& t, int64_t q, float theta, int heavy) {
+  return filter_threshold_i8_of(theta, t.eq8[q], sqrtf(__uint_as_float(t.tail8[heavy ? 3 : 0])),
+                                t.qscale[q] * __uint_as_float(t.tail8[heavy ? 4 : 1]));
+}
+__device__ __forceinline__ int filter_threshold_i8(const FilterThr& t, int64_t q, int heavy) {
   const unsigned char fl = t.flag ? t.flag[q] : 0;
-  const int thr = filter_threshold_i8_at(t, q, filter_theta(t, q));
+  const int thr = filter_threshold_i8_at(t, q, filter_theta(t, q), heavy);
   return (t.ablate == 1 || fl) ? INT_MAX : thr;
+}
+// the class of the granule a key lies in, from the class words (any thread; a cached 4-byte read)
+__device__ __forceinline__ int filter_i8_class(const unsigned* cls, int64_t granule) {
+  return (int)((cls[granule >> 5] >> (granule & 31)) & 1u);
 }
 
 // Candidate counters of a call of fewer than 2048 queries.  A returning atomicAdd costs ~11 ns per operation on ONE address

@@ -142,31 +142,94 @@ __global__ void __launch_bounds__(256) keys_to_bf16_kernel(const float* __restri
     atomicMax(max_err2, __float_as_uint(e2));
 }
 
-// The int8 copy (filter_common.h): the bank's largest |k_i| first (the one scale), then quantise + lay out + the largest
-// |dk|^2.  tail8: [0] max |dk|^2, [1] s_k, [2] max |k_i| -- zeroed by the caller before the first kernel.
-__global__ void __launch_bounds__(256) bank_absmax_kernel(const float* __restrict__ Kn, int64_t n4, unsigned* __restrict__ tail8) {
+// The int8 copy (filter_common.h, "TWO SCALES"): the granules' largest |k_i| (and the bank's), the cut between the two classes,
+// then quantise + lay out + each class's largest |dk|^2 + the class bits.  The tail row and the class words are zeroed by the
+// caller before the first kernel.
+template <int D>
+__global__ void __launch_bounds__(256) i8_granule_absmax_kernel(const float* __restrict__ Kn, int64_t N, float* __restrict__ gmax,
+                                                                unsigned* __restrict__ tail8) {
+  constexpr int GK = filter_i8_granule_keys(D);
+  const int64_t row0 = (int64_t)blockIdx.x * GK;
+  const int64_t rows = N - row0 < GK ? N - row0 : GK;   // (<= 0: a granule of padding)
+  const int64_t n4 = rows > 0 ? rows * (D / 4) : 0;
+  const float4* src = reinterpret_cast<const float4*>(Kn + row0 * D);
   unsigned m = 0u;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    const float4 v = reinterpret_cast<const float4*>(Kn)[i];
+  for (int64_t i = threadIdx.x; i < n4; i += 256) {
+    const float4 v = src[i];
     m = max(max(m, __float_as_uint(fabsf(v.x))), max(__float_as_uint(fabsf(v.y)), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w)))));
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
-  if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(tail8 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(tail8 + 2, m);
+  __shared__ unsigned wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+    gmax[blockIdx.x] = __uint_as_float(m);
+    if (m > __hip_atomic_load(tail8 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(tail8 + 2, m);
+  }
+}
+
+// The cut (one workgroup).  A histogram of the granules' maxima over the upper 15 bits of their (non-negative) float
+// patterns -- bins 1.6 % wide -- then, for every occupied bin's upper edge x as the cut, the modelled candidates
+//   (granules <= x) f(x) + (granules > x) f(x_max),   f(x) = exp(lambda |dk|(x)),  |dk|(x) = (x / 127) sqrt(D / 12)
+// (uniform rounding errors of a row quantised on the grid x / 127; lambda = 60: the bench bank's candidates triple when eps
+// grows from the bf16 bound's 0.004 to the single scale's 0.0215).  Whatever comes out is only a matter of speed: every
+// class's error is MEASURED by the quantising kernel and the bounds use the measurements.  one_scale: cut = the maximum.
+constexpr int I8_CUT_BINS = 1 << 14;
+__global__ void __launch_bounds__(1024) i8_cut_kernel(const float* __restrict__ gmax, int64_t granules, int D, int one_scale,
+                                                      unsigned* __restrict__ tail8) {
+  __shared__ int hist[I8_CUT_BINS];
+  for (int i = threadIdx.x; i < I8_CUT_BINS; i += 1024) hist[i] = 0;
+  __syncthreads();
+  for (int64_t i = threadIdx.x; i < granules; i += 1024) atomicAdd(hist + (__float_as_uint(gmax[i]) >> 17), 1);
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const float xmax = __uint_as_float(tail8[2]);
+  float cut = xmax;
+  if (!one_scale && xmax > 0.f) {
+    const float c = 60.f * sqrtf((float)D / 12.f) / 127.f;
+    const float fmax_ = expf(c * xmax);
+    const int top = (int)(__float_as_uint(xmax) >> 17);
+    float best = (float)granules * fmax_;
+    int64_t below = 0;
+    for (int e = 0; e < top; ++e) {
+      if (hist[e] == 0) continue;
+      below += hist[e];
+      const float edge = __uint_as_float((unsigned)(e + 1) << 17);   // every maximum of bins <= e lies below it
+      const float cost = (float)below * expf(c * edge) + (float)(granules - below) * fmax_;
+      if (cost < best) {
+        best = cost;
+        cut = edge;
+      }
+    }
+  }
+  tail8[5] = __float_as_uint(cut);
+  tail8[1] = __float_as_uint(cut / 127.f);
+  tail8[4] = __float_as_uint(xmax / 127.f);
+  tail8[7] = granules > INT_MAX ? (unsigned)INT_MAX : (unsigned)granules;
 }
 
 template <int D>
 __global__ void __launch_bounds__(256) keys_to_i8_kernel(const float* __restrict__ Kn, int64_t N, int64_t Npad,
-                                                         signed char* __restrict__ Kb8, unsigned* __restrict__ tail8) {
+                                                         signed char* __restrict__ Kb8, unsigned* __restrict__ tail8,
+                                                         const float* __restrict__ gmax, unsigned* __restrict__ cls) {
   constexpr int TPR = D / 16;  // threads per row (one thread = 16 elements = one lane's piece of a block): 4 / 8 / 16
+  constexpr int GK = filter_i8_granule_keys(D);
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t row = i / TPR;
-  const float sk = __uint_as_float(tail8[2]) / 127.f;
+  const int64_t gr = row / GK;
+  const bool live = i < Npad * TPR;
+  const bool heavy = live && gmax[gr] > __uint_as_float(tail8[5]);
+  const float sk = __uint_as_float(tail8[heavy ? 4 : 1]);
   const float inv_sk = sk > 0.f ? 1.f / sk : 0.f;
-  if (i == 0) tail8[1] = __float_as_uint(sk);
+  if (heavy && row == gr * GK && i == row * TPR) {   // the granule's first thread: its class bit
+    atomicOr(cls + (gr >> 5), 1u << (gr & 31));
+    atomicAdd(tail8 + 6, 1u);
+  }
   unsigned w[4] = {0u, 0u, 0u, 0u};
   float e2 = 0.f;
-  if (i < Npad * TPR && row < N && sk > 0.f) {
+  if (live && row < N && sk > 0.f) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float4 a = reinterpret_cast<const float4*>(Kn)[4 * i + c];
@@ -179,9 +242,8 @@ __global__ void __launch_bounds__(256) keys_to_i8_kernel(const float* __restrict
         e2 = fmaf(d, d, e2);
       }
     }
-  } else if (i < Npad * TPR && row < N) {  // an all-zero bank: the copy is zero, the error is the row itself (0)
-  }
-  if (i < Npad * TPR) {
+  }  // (an all-zero bank: the copy is zero, the error is the row itself: 0)
+  if (live) {
     const int c = (int)(i % TPR);  // piece c = 4 t + g of the row
     const int64_t dst = filter_i8_block_offset(row >> 5, D, c >> 2, (int)(row >> 4) & 1) + (((c & 3) * 16 + (int)(row & 15)) << 4);
     *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Kb8) + dst) = make_uint4(w[0], w[1], w[2], w[3]);
@@ -189,8 +251,9 @@ __global__ void __launch_bounds__(256) keys_to_i8_kernel(const float* __restrict
 #pragma unroll
   for (int off = TPR / 2; off >= 1; off >>= 1) e2 += __shfl_xor(e2, off);
   e2 *= 1.000001f;  // (the fmaf's rounding of each difference)
-  if ((threadIdx.x & (TPR - 1)) == 0 && __float_as_uint(e2) > __hip_atomic_load(tail8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-    atomicMax(tail8, __float_as_uint(e2));
+  unsigned* slot = tail8 + (heavy ? 3 : 0);
+  if ((threadIdx.x & (TPR - 1)) == 0 && __float_as_uint(e2) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(slot, __float_as_uint(e2));
 }
 
 // Everything a call needs before its first filter launch, in ONE launch (one wave per query): the normalised query row
@@ -592,11 +655,12 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     RG_RSTAMP(1);
     // padded queries never pass: +inf threshold
     float thr[NG];
-    int thr8[NG];  // (int8 levels) the integer threshold
+    int thr8[NG], thr8h[NG];  // (int8 levels) the integer thresholds: keys of NORMAL / of HEAVY granules (filter_common.h)
 #pragma unroll
     for (int gq = 0; gq < NG; ++gq) {
       thr[gq] = (!BOUND && !I8 && q_lo + 16 * gq < p.B) ? filter_threshold(p.thr, q_lo + 16 * gq) : __builtin_huge_valf();
-      thr8[gq] = (I8 && q_lo + 16 * gq < p.B) ? filter_threshold_i8(p.thr, q_lo + 16 * gq) : INT_MAX;
+      thr8[gq] = (I8 && q_lo + 16 * gq < p.B) ? filter_threshold_i8(p.thr, q_lo + 16 * gq, 0) : INT_MAX;
+      thr8h[gq] = (I8 && q_lo + 16 * gq < p.B) ? filter_threshold_i8(p.thr, q_lo + 16 * gq, 1) : INT_MAX;
     }
     // bound pass: running maxima of the current group (group g = stages [ceil(g n / G), ceil((g+1) n / G)) of the range)
     float gm[NG];
@@ -675,11 +739,22 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
     RG_RSTAMP(2);
 #pragma unroll
-    for (int gq = 0; gq < NG; ++gq) asm volatile("" : "+v"(thr[gq]), "+v"(thr8[gq]));
+    for (int gq = 0; gq < NG; ++gq) asm volatile("" : "+v"(thr[gq]), "+v"(thr8[gq]), "+v"(thr8h[gq]));
+    // thr_i: the threshold IN FORCE (int8: of the class of the stage being multiplied -- set at the top of a stage from
+    // thr_n / thr_h when the class changes); thr_p (PIPE, whose epilogue of a stage's last sub-tile runs inside the next
+    // stage): the previous stage's.  The two classes' integers are on different grids: a sub-tile is only ever tested
+    // against the thresholds of its own granule's class.
     int thr_i[NG];
+    [[maybe_unused]] int thr_n[NG], thr_h[NG], thr_p[NG];
 #pragma unroll
-    for (int gq = 0; gq < NG; ++gq)  // (int8: INT_MIN / INT_MAX -- everything / nothing passes -- clamped beyond any |I| < 2^23)
+    for (int gq = 0; gq < NG; ++gq) {  // (int8: INT_MIN / INT_MAX -- everything / nothing passes -- clamped beyond any |I| < 2^23)
       thr_i[gq] = I8 ? max(-(1 << 24), min(1 << 24, thr8[gq])) : (thr[gq] >= 0.f ? __float_as_int(thr[gq]) : INT_MIN);
+      thr_n[gq] = thr_i[gq];
+      thr_h[gq] = max(-(1 << 24), min(1 << 24, thr8h[gq]));
+      thr_p[gq] = thr_i[gq];
+    }
+    [[maybe_unused]] unsigned cls_word = 0u;   // class bits of the 32 stages around the current one (SGPR)
+    [[maybe_unused]] int cls_cur = 0, cls_prev = 0, cls_state = 0;
 
     // ---- ring prologue ------------------------------------------------------------------------------------------
     const int pro = nstages < C::SLOTS - 1 ? nstages : C::SLOTS - 1;
@@ -740,19 +815,35 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
           grp_end = ((int64_t)(grp + 1) * p.nstages_total + p.ngroups - 1) / p.ngroups;
         }
       }
+      if constexpr (I8) {  // the stage's class: one scalar word per 32 stages, a select per group only when the class changes
+        const int64_t stage_abs = p.stage_base + st0 + s;
+        const int sa = __builtin_amdgcn_readfirstlane((int)(stage_abs & 31));
+        if (s == 0 || sa == 0) cls_word = p.thr.cls8[__builtin_amdgcn_readfirstlane((int)(stage_abs >> 5))];
+        cls_prev = s > 0 ? cls_cur : 0;
+        cls_cur = (int)((cls_word >> sa) & 1u);
+        const int state = cls_cur | (cls_prev << 1);
+        if (state != cls_state) {  // (wave-uniform; never taken on a bank without heavy granules)
+          cls_state = state;
+#pragma unroll
+          for (int gq = 0; gq < NG; ++gq) {
+            thr_i[gq] = cls_cur ? thr_h[gq] : thr_n[gq];
+            if constexpr (PIPE) thr_p[gq] = cls_prev ? thr_h[gq] : thr_n[gq];
+          }
+        }
+      }
       RG_FT(t0);
       fring_wait(full + slot, (unsigned)(C::WAVES * (gen + 1)));
       RG_FT(t1);
       // epilogue of sub-tile u: a[h][gq][r] = approximate score of key 16 h + 4 g + r of the sub-tile for query j of group gq
       using acc_t = typename std::conditional<I8, i32x4, f32x4>::type;
-      auto pass_mask = [&](const acc_t (&a)[2][NG], int gq) {  // float scores against thr, integer sums against thr_i
+      auto pass_mask = [&](const acc_t (&a)[2][NG], int gq, [[maybe_unused]] int th_i8) {  // float scores against thr, integer sums against th_i8
         unsigned mk = 0;
         if constexpr (I8) {
           // bit = the sign of (thr - 1) - I, in unsigned arithmetic (|I| < 2^23 and thr_i is clamped to +-2^24: no wrap),
           // shifted into the mask by v_alignbit ({mask, e} >> 31 = mask << 1 | sign(e)): two plain VALU instructions per
           // score where compare + select + or through VCC is three plus a wait state, on a path that half of the last
           // level's sub-tiles take (and every sub-tile of the first)
-          const unsigned tm1 = (unsigned)(thr_i[gq] - 1);
+          const unsigned tm1 = (unsigned)(th_i8 - 1);
 #pragma unroll
           for (int b = 7; b >= 0; --b) mk = __builtin_amdgcn_alignbit(mk, tm1 - (unsigned)a[b >> 2][gq][b & 3], 31);
           return mk;
@@ -768,8 +859,9 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
       };
       // the groups' entries of one sub-tile: ballots first, ONE buffer check per (up to) four groups -- a flush is ~60
       // instructions and every copy of it sits in the stage loop's instruction stream
-      // (SCORED: the lane's largest sum rides in the entry's upper 24 bits -- |I| <= 127^2 * 256 < 2^23)
-      auto push_groups = [&](const unsigned (&km)[NG], const int (&mi)[NG], unsigned off) {
+      // (SCORED: the lane's largest sum and the class of the keys' granule ride in the entry's upper 24 bits as (I << 1) | class
+      // -- |I| <= 127^2 * 256 < 2^22)
+      auto push_groups = [&](const unsigned (&km)[NG], const int (&mi)[NG], unsigned off, [[maybe_unused]] int cls_of) {
         constexpr int GB = NG < 4 ? NG : (NG % 4 == 0 ? 4 : 3);  // groups per check: at most 64 GB = 256 entries < CAND_BUF
 #pragma unroll
         for (int g0 = 0; g0 < NG; g0 += GB) {
@@ -788,7 +880,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
               const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm[i] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm[i], 0u));
               if (km[g0 + i])
                 wbuf[pos] = make_uint2(((unsigned)(j + 16 * (g0 + i)) << 25) | off,
-                                       SCORED ? (km[g0 + i] | ((unsigned)mi[g0 + i] << 8)) : km[g0 + i]);
+                                       SCORED ? (km[g0 + i] | ((unsigned)((mi[g0 + i] << 1) | cls_of) << 8)) : km[g0 + i]);
               wcnt += __popcll(bm[i]);
             }
           }
@@ -838,7 +930,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
 #pragma unroll
           for (int gq = 0; gq < NG; ++gq) {
             km[gq] = 0;
-            if (__any(mi[gq] >= thr_i[gq])) km[gq] = pass_mask(a, gq);
+            if (__any(mi[gq] >= thr_i[gq])) km[gq] = pass_mask(a, gq, thr_i[gq]);
           }
           if (stage_key0 + C::STAGE_KEYS > (int)p.N) {  // the range's last stage: keys >= N (padding, or the next level's)
             unsigned vm = 0;
@@ -847,27 +939,28 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
 #pragma unroll
             for (int gq = 0; gq < NG; ++gq) km[gq] &= vm;
           }
-          push_groups(km, mi, (unsigned)(key_base - key_org));
+          push_groups(km, mi, (unsigned)(key_base - key_org), cls_cur);
         }
       };
       // PIPE: the same epilogue in pieces -- one group's maxima per step, then the candidate path -- over the OTHER set
-      auto epi_fast = [&](const acc_t (&a)[2][NG], int gq) {
+      // (th: the thresholds of the sub-tile's own stage -- thr_p for the previous stage's last sub-tile, else thr_i)
+      auto epi_fast = [&](const acc_t (&a)[2][NG], int gq, const int (&th)[NG]) {
         int m = as_bits(a[0][gq][0]);
 #pragma unroll
         for (int r = 1; r < 4; ++r) m = max(m, as_bits(a[0][gq][r]));
 #pragma unroll
         for (int r = 0; r < 4; ++r) m = max(m, as_bits(a[1][gq][r]));
         pmi[gq] = m;
-        phit = phit || (m >= thr_i[gq]);
+        phit = phit || (m >= th[gq]);
       };
-      auto epi_slow = [&](const acc_t (&a)[2][NG], int stage_key0, int u) {
+      auto epi_slow = [&](const acc_t (&a)[2][NG], int stage_key0, int u, int cls_of, const int (&th)[NG]) {
         if (__any(phit)) {
           const int key_base = stage_key0 + 32 * u + 4 * g;
           unsigned km[NG];
 #pragma unroll
           for (int gq = 0; gq < NG; ++gq) {
             km[gq] = 0;
-            if (__any(pmi[gq] >= thr_i[gq])) km[gq] = pass_mask(a, gq);
+            if (__any(pmi[gq] >= th[gq])) km[gq] = pass_mask(a, gq, th[gq]);
           }
           if (stage_key0 + C::STAGE_KEYS > (int)p.N) {
             unsigned vm = 0;
@@ -876,7 +969,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
 #pragma unroll
             for (int gq = 0; gq < NG; ++gq) km[gq] &= vm;
           }
-          push_groups(km, pmi, (unsigned)(key_base - key_org));
+          push_groups(km, pmi, (unsigned)(key_base - key_org), cls_of);
         }
         phit = false;
       };
@@ -928,9 +1021,10 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     if constexpr ((n_) + 4 < C::NSTEP) RG_FREAD((n_) + 4);                                                  \
     if constexpr (PIPE) {                                                                                  \
       /* the previous sub-tile (the other set): group r - 1 behind step r, the candidate path behind step NG + 1 */ \
-      if constexpr (r_ >= 1 && r_ <= NG) epi_fast(accp[set_ ^ 1], r_ - 1);                                 \
+      if constexpr (r_ >= 1 && r_ <= NG) epi_fast(accp[set_ ^ 1], r_ - 1, RG_PTHR(u_));                    \
       if constexpr (r_ == NG + 1) {                                                                        \
-        epi_slow(accp[set_ ^ 1], u_ == 0 ? stage_key0_now - C::STAGE_KEYS : stage_key0_now, u_ == 0 ? C::SUBS - 1 : u_ - 1); \
+        epi_slow(accp[set_ ^ 1], u_ == 0 ? stage_key0_now - C::STAGE_KEYS : stage_key0_now, u_ == 0 ? C::SUBS - 1 : u_ - 1, \
+                 u_ == 0 ? cls_prev : cls_cur, RG_PTHR(u_));                                                \
         if constexpr (u_ == 0) {                                                                           \
           if ((s & 0x7FFF) == 0 && s > 0) { /* keep the entries' key offsets inside 25 bits */             \
             flush();                                                                                       \
@@ -948,6 +1042,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
         __hip_atomic_store(prog + wave, s * C::SUBS + u_ + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
     }                                                                                                      \
   }
+#define RG_PTHR(u_) ((u_) == 0 ? thr_p : thr_i)
 #define RG_FSTEP8(n_) RG_FSTEP(n_) RG_FSTEP((n_) + 1) RG_FSTEP((n_) + 2) RG_FSTEP((n_) + 3) \
     RG_FSTEP((n_) + 4) RG_FSTEP((n_) + 5) RG_FSTEP((n_) + 6) RG_FSTEP((n_) + 7)
       // (a wave whose 64 queries all lie beyond the batch -- the tail of a ragged last tile: 300 queries fill 4.7 of a
@@ -965,8 +1060,8 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
         if constexpr (PIPE) {  // the segment's last sub-tile: no next sub-tile for its epilogue to ride in
           if (s == nstages - 1) {
 #pragma unroll
-            for (int gq = 0; gq < NG; ++gq) epi_fast(accp[(C::SUBS - 1) & 1], gq);
-            epi_slow(accp[(C::SUBS - 1) & 1], stage_key0_now, C::SUBS - 1);
+            for (int gq = 0; gq < NG; ++gq) epi_fast(accp[(C::SUBS - 1) & 1], gq, thr_i);
+            epi_slow(accp[(C::SUBS - 1) & 1], stage_key0_now, C::SUBS - 1, cls_cur, thr_i);
           }
         }
         if (lead) {
@@ -978,6 +1073,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
         }
       }
 #undef RG_FSTEP8
+#undef RG_PTHR
 #undef RG_FSTEP
 #undef RG_FWAIT
 #undef RG_FREAD
@@ -1245,7 +1341,10 @@ __device__ __forceinline__ bool rescore_scored_query(const float4* __restrict__ 
     kl = (unsigned)__builtin_amdgcn_readlane((int)wl, src);
   }
   const float theta_e = n_w >= k ? select_unord(kh) : RG_NEG_INF;
-  const int t_e = filter_threshold_i8_at(thr, b, theta_e);
+  // (an entry's integer is (I << 1) | class of its key's granule: each class has its own bound -- compared on the doubled scale)
+  const int t_e0 = filter_threshold_i8_at(thr, b, theta_e, 0), t_e1 = filter_threshold_i8_at(thr, b, theta_e, 1);
+  auto twice = [](int t) { return t <= -(1 << 24) ? INT_MIN : (t >= (1 << 24) ? INT_MAX : 2 * t); };
+  const int t2_e0 = twice(t_e0), t2_e1 = twice(t_e1);
   // round 2, four slots (256 entries) at a time: the entries outside round 1 whose I reaches t_e are compacted into the
   // wave's list and scored in batches of 64; those that beat W's k-th pair (a handful) are kept, one per lane of the
   // "beaters" row
@@ -1257,7 +1356,7 @@ __device__ __forceinline__ bool rescore_scored_query(const float4* __restrict__ 
 #pragma unroll
     for (int u = u0; u < (u0 + 4 < NS ? u0 + 4 : NS); ++u) {
       const bool in_r1 = lane_r1 && key[u] == bkey;
-      const bool keep = key[u] >= 0 && !in_r1 && iv[u] >= t_e;
+      const bool keep = key[u] >= 0 && !in_r1 && iv[u] >= ((iv[u] & 1) ? t2_e1 : t2_e0);
       const unsigned long long bm = __ballot(keep);
       const int pos = ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
       if (keep) surv[pos] = key[u];
@@ -2300,21 +2399,29 @@ extern "C" int ragraph_keys_to_bf16(const float* Kn, int64_t N, int D, uint16_t*
   else if (D == 128) hipLaunchKernelGGL(keys_to_bf16_kernel<128>, grid, dim3(256), 0, st, Kn, N, npad, Kb, tail);
   else hipLaunchKernelGGL(keys_to_bf16_kernel<64>, grid, dim3(256), 0, st, Kn, N, npad, Kb, tail);
   RG_CHECK_LAUNCH("keys_to_bf16");
-  // the int8 copy behind it (filter_common.h): the bank's largest |k_i| -> one scale, then quantise + lay out
-  signed char* Kb8 = reinterpret_cast<signed char*>(Kb + (npad + 1) * D);
-  unsigned* tail8 = reinterpret_cast<unsigned*>(Kb8 + npad * D);
-  if (hipMemsetAsync(tail8, 0, (size_t)D * sizeof(uint16_t), st) != hipSuccess) {
+  // the int8 copy behind it (filter_common.h): the granules' largest |k_i| -> the cut and the two scales, then quantise + lay out
+  const FilterI8View v8 = filter_i8_view(Kb, N, D);
+  signed char* Kb8 = const_cast<signed char*>(v8.K8);
+  unsigned* tail8 = const_cast<unsigned*>(v8.tail8);
+  if (hipMemsetAsync(tail8, 0, (size_t)D * sizeof(uint16_t) + filter_i8_table_bytes(N, D), st) != hipSuccess) {
     set_error("keys_to_bf16: memset failed");
     return RAGRAPH_EDEVICE;
   }
-  const int64_t n4 = N * D / 4;
-  int64_t ab = cdiv(n4, (int64_t)256);
-  if (ab > 4096) ab = 4096;
-  hipLaunchKernelGGL(bank_absmax_kernel, dim3((unsigned)ab), dim3(256), 0, st, Kn, n4, tail8);
+  float* gmax = const_cast<float*>(v8.gmax);
+  unsigned* cls = const_cast<unsigned*>(v8.cls);
+  const dim3 gridg((unsigned)v8.granules);
+  if (D == 256) hipLaunchKernelGGL(i8_granule_absmax_kernel<256>, gridg, dim3(256), 0, st, Kn, N, gmax, tail8);
+  else if (D == 128) hipLaunchKernelGGL(i8_granule_absmax_kernel<128>, gridg, dim3(256), 0, st, Kn, N, gmax, tail8);
+  else hipLaunchKernelGGL(i8_granule_absmax_kernel<64>, gridg, dim3(256), 0, st, Kn, N, gmax, tail8);
+  static const int one_scale = [] {   // (experiments: RAGRAPH_I8_ONE_SCALE=1 -- the single scale of rounds 3 / 4)
+    const char* e = getenv("RAGRAPH_I8_ONE_SCALE");
+    return e && e[0] == '1' ? 1 : 0;
+  }();
+  hipLaunchKernelGGL(i8_cut_kernel, dim3(1), dim3(1024), 0, st, gmax, v8.granules, D, one_scale, tail8);
   const dim3 grid8((unsigned)cdiv(npad * (D / 16), 256));
-  if (D == 256) hipLaunchKernelGGL(keys_to_i8_kernel<256>, grid8, dim3(256), 0, st, Kn, N, npad, Kb8, tail8);
-  else if (D == 128) hipLaunchKernelGGL(keys_to_i8_kernel<128>, grid8, dim3(256), 0, st, Kn, N, npad, Kb8, tail8);
-  else hipLaunchKernelGGL(keys_to_i8_kernel<64>, grid8, dim3(256), 0, st, Kn, N, npad, Kb8, tail8);
+  if (D == 256) hipLaunchKernelGGL(keys_to_i8_kernel<256>, grid8, dim3(256), 0, st, Kn, N, npad, Kb8, tail8, gmax, cls);
+  else if (D == 128) hipLaunchKernelGGL(keys_to_i8_kernel<128>, grid8, dim3(256), 0, st, Kn, N, npad, Kb8, tail8, gmax, cls);
+  else hipLaunchKernelGGL(keys_to_i8_kernel<64>, grid8, dim3(256), 0, st, Kn, N, npad, Kb8, tail8, gmax, cls);
   RG_CHECK_LAUNCH("keys_to_bf16(int8 copy)");
   return RAGRAPH_OK;
 }
@@ -2327,7 +2434,9 @@ extern "C" int64_t ragraph_keys_bf16_rows(int64_t N) {
   const int64_t npad = filter_round_up(N);
   // + FILTER_COPY_SLACK_ROWS: at D = 64 a stage of the int8 copy is 512 keys, so the last stage of a bank padded to an odd
   // multiple of 256 keys reads 16 KB past the copy's rows (keys >= N never pass): the buffer must own those bytes
-  return npad + 1 + npad / 2 + 1 + FILTER_COPY_SLACK_ROWS;
+  // + the int8 copy's granule table (filter_i8_table_bytes: < 5 bytes per 32 KiB of int8 rows, i.e. per 64 rows of 2 D bytes at
+  // most -- whatever D)
+  return npad + 1 + npad / 2 + 1 + (npad / 4096 + 8) + FILTER_COPY_SLACK_ROWS;
 }
 
 extern "C" int ragraph_topk_cosine_filtered_cap(int k) { return 2048; }
@@ -2795,8 +2904,9 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   int* stats = reinterpret_cast<int*>(w + ragraph_topk_cosine_filtered_stats_offset(ws_bytes));
   const unsigned* max_kerr2 = reinterpret_cast<const unsigned*>(Kb + filter_round_up(N) * D);
   // the int8 copy lies behind the bf16 copy and its tail row (ragraph_keys_to_bf16)
-  const signed char* Kb8 = reinterpret_cast<const signed char*>(Kb + (filter_round_up(N) + 1) * D);
-  const unsigned* tail8 = reinterpret_cast<const unsigned*>(Kb8 + filter_round_up(N) * D);
+  const FilterI8View v8 = filter_i8_view(Kb, N, D);
+  const signed char* Kb8 = v8.K8;
+  const unsigned* tail8 = v8.tail8;
   sc.i8_levels = filter_i8_levels(sc, B, D, plan_N);
   // a speculative first bound (this thread's prior; single banks whose schedule has a bound pass to save): no bound pass,
   // theta = prior for every query, every level filters with max(prior, the running k-th best), and the verify launch
@@ -2834,6 +2944,7 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   thr.eq8 = f.eq8;
   thr.qscale = f.qscale;
   thr.tail8 = tail8;
+  thr.cls8 = v8.cls;
   thr.flag = f.flag;
   thr.k = k;
   const int parts = bound ? filter_bound_parts(k, sc.bound_keys, D, B, exchange ? n_shards : 1) : k;

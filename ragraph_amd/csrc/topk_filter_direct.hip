@@ -48,7 +48,7 @@ struct DirectCfg {
 #endif
   static constexpr int LA = KS32 < RG_DIRECT_LA ? KS32 : RG_DIRECT_LA;  // B-operand reads in flight ahead of their MFMAs
   static constexpr size_t lds_bytes(int groups_in_lds) {
-    return (size_t)groups_in_lds * GROUP_BYTES + (size_t)WAVES * CAND_BUF * 8 + 256 * sizeof(float) + WAVES * sizeof(int);
+    return (size_t)groups_in_lds * GROUP_BYTES + (size_t)WAVES * CAND_BUF * 8 + 512 * sizeof(float) + WAVES * sizeof(int);
   }
 };
 
@@ -94,7 +94,8 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
   const int ngl = QREG ? 0 : p.qgroups;
   char* qlds = smem;                                                             // [ngl][KS32][64] x 16 B
   uint2* wbuf_all = reinterpret_cast<uint2*>(smem + (size_t)ngl * C::GROUP_BYTES);  // [WAVES][CAND_BUF]
-  float* thr_lds = reinterpret_cast<float*>(wbuf_all + C::WAVES * C::CAND_BUF);     // [256]
+  float* thr_lds = reinterpret_cast<float*>(wbuf_all + C::WAVES * C::CAND_BUF);     // [512]: [256] thresholds (int8: for keys of
+                                                                                    // NORMAL granules), [256] int8: of HEAVY ones
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -102,10 +103,10 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
   const int j = lane & 15, g = lane >> 4;
 
   // ---- thresholds (one per query of the tile) and, beyond 32 queries, the B operands in LDS -------------------------
-  if (tid < 256) {
-    if constexpr (I8) {  // (the integer threshold, kept as bits in the float array)
+  if (tid < (I8 ? 512 : 256)) {
+    if constexpr (I8) {  // (the integer thresholds of the two classes of granules, kept as bits in the float array)
       int t = INT_MAX;
-      if (tid < p.B) t = filter_threshold_i8(p.thr, tid);
+      if ((tid & 255) < p.B) t = filter_threshold_i8(p.thr, tid & 255, tid >> 8);
       thr_lds[tid] = __int_as_float(t);
     } else {
       float t = __builtin_huge_valf();  // padded queries never pass
@@ -169,7 +170,8 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
       const int i = i0 + lane;
       if (i < wcnt) {
         const uint2 e = wbuf[i];
-        // (int8 entries: mask | query << 8 | ceil(I / 256) << 16 -- the lane's largest sum as an upper bound in units of 256)
+        // (int8 entries: mask | query << 8 | (ceil(I / 256) << 1 | class) << 16 -- the lane's largest sum as an upper bound in
+        // units of 256, and the class of the unit's granule)
         const int64_t q = I8 ? ((e.y >> 8) & 0xFFu) : (e.y >> 16);
         unsigned mk = I8 ? (e.y & 0xFFu) : (e.y & 0xFFFFu);
         int slot = atomicAdd(p.count + q * FILTER_COUNT_STRIDE + sub, __popc(mk));
@@ -182,7 +184,8 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
           if (slot < p.subcap) {
             const int64_t at = q * p.cap + sub * p.subcap + slot;
             const int key = (int)e.x + (r & 3) + 16 * (r >> 2);
-            if (I8 && p.scored) reinterpret_cast<int2*>(p.cand)[at] = make_int2(key, (int)(((int)e.y >> 16) * 256));
+            // (scored lists carry (I << 1) | class; the entry's upper half is (ceil(I / 256) << 1) | class)
+            if (I8 && p.scored) reinterpret_cast<int2*>(p.cand)[at] = make_int2(key, (((int)e.y >> 17) * 512) | (int)((e.y >> 16) & 1u));
             else p.cand[at] = key;
           }
           ++slot;
@@ -205,6 +208,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
 
   // epilogue of a 32-key sub-tile against one group of 16 queries: a[h][r] = approximate score of key 16 h + 4 g + r of the
   // sub-tile for query 16 gq + j
+  [[maybe_unused]] int cls_unit = 0;  // (int8) class of the granule the unit in process lies in (wave-uniform)
   auto epilogue = [&](const acc_t (&a)[2], int gq, int64_t unit, int sub, int part) {
 #if defined(RG_DIRECT_ABL) && (RG_DIRECT_ABL & 1)   // timing build: no epilogue (results invalid); the scores stay live
     if (a[0][0] + a[1][3] == 123456) wbuf[0] = make_uint2(1u, 2u);
@@ -216,7 +220,7 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
       for (int r = 1; r < 4; ++r) m = max(m, a[0][r]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) m = max(m, a[1][r]);
-      const int th = __float_as_int(thr_lds[16 * gq + j]);
+      const int th = __float_as_int(thr_lds[256 * cls_unit + 16 * gq + j]);
       if (__any(m >= th)) {
         // (the pass bits by subtract + v_alignbit, as the ring kernel's pass_mask: th clamped beyond any |I| < 2^23)
         unsigned mk = 0;
@@ -233,7 +237,8 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
         const unsigned long long bal = __ballot(mk != 0);
         if (bal) {
           const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-          if (mk) wbuf[pos] = make_uint2((unsigned)key_base, mk | ((unsigned)(16 * gq + j) << 8) | ((unsigned)((m + 255) >> 8) << 16));
+          if (mk) wbuf[pos] = make_uint2((unsigned)key_base, mk | ((unsigned)(16 * gq + j) << 8) |
+                                                             ((unsigned)((((m + 255) >> 8) << 1) | cls_unit) << 16));
           wcnt += __popcll(bal);
         }
       }
@@ -286,7 +291,11 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
   // last LA reads run past it into the candidate buffers and are never used), as asm loads with counted lgkmcnt waits
   // (hipcc's own schedule keeps one read ahead and idles the matrix pipe).
   const unsigned qaddr0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)qlds + lane16;
-  auto process = [&](f32x4 (&A)[16], int64_t unit, auto next_tag) {
+  auto process = [&](f32x4 (&A)[16], int64_t unit, [[maybe_unused]] unsigned cw, auto next_tag) {
+    if constexpr (I8) {  // the unit's granule = unit / 2; its class word was requested with the unit's blocks
+      // (settled here, in front of the counted LDS reads below)
+      cls_unit = __builtin_amdgcn_readfirstlane((int)((cw >> ((unit >> 1) & 31)) & 1u));
+    }
     int part0 = 0;
     if constexpr (BOUND) part0 = (int)(((unit - p.unit0) * C::SUBS) * p.ngroups / (p.nunits * C::SUBS));
     // (sub-tiles of one unit lie in one part or in two neighbouring ones: the division is per unit, not per sub-tile)
@@ -376,21 +385,29 @@ __global__ void __launch_bounds__(512, 2) topk_filter_direct_kernel(DirectParams
     }
   };
 
+  // (int8) the class word of unit u's granule: a scalar load, requested a whole unit ahead like the blocks
+  auto cls_word = [&](int64_t u) -> unsigned {
+    if constexpr (I8) return p.thr.cls8[__builtin_amdgcn_readfirstlane((int)(u >> 6))];
+    else return 0u;
+  };
   if (n_mine > 0) {
     const int64_t u0 = p.unit0 + ubase;
     RG_DLOAD(A0, u0);
+    unsigned w0 = cls_word(u0), w1 = 0u;
     int64_t i = 0;
     for (; i + 2 <= n_mine; i += 2) {  // pairs: A0 then A1, the other buffer's loads always in flight
       RG_DLOAD(A1, u0 + (i + 1) * ustride);
-      process(A0, u0 + i * ustride, std::true_type{});
+      w1 = cls_word(u0 + (i + 1) * ustride);
+      process(A0, u0 + i * ustride, w0, std::true_type{});
       if (i + 2 < n_mine) {
         RG_DLOAD(A0, u0 + (i + 2) * ustride);
-        process(A1, u0 + (i + 1) * ustride, std::true_type{});
+        w0 = cls_word(u0 + (i + 2) * ustride);
+        process(A1, u0 + (i + 1) * ustride, w1, std::true_type{});
       } else {
-        process(A1, u0 + (i + 1) * ustride, std::false_type{});
+        process(A1, u0 + (i + 1) * ustride, w1, std::false_type{});
       }
     }
-    if (i < n_mine) process(A0, u0 + i * ustride, std::false_type{});  // odd count: the last unit, nothing behind it
+    if (i < n_mine) process(A0, u0 + i * ustride, w0, std::false_type{});  // odd count: the last unit, nothing behind it
   }
   RG_DSTAMP(2);
   if constexpr (BOUND) {

@@ -63,7 +63,8 @@ struct SmallParams {
   const uint16_t* Kb;      // bf16 copy, fragment order (filter_common.h)
   const signed char* Kb8;  // int8 copy behind it
   const unsigned* max_kerr2;  // bf16 copy's tail: max |dk|^2
-  const unsigned* tail8;      // int8 copy's tail: max |dk|^2, s_k
+  const unsigned* tail8;      // int8 copy's tail: max |dk|^2, s_k of the NORMAL / HEAVY granules (filter_common.h)
+  const unsigned* cls8;       // its class bits
   int64_t N, idx_base;
   int B, k;
   int64_t bound_units;     // bound pass: units [0, bound_units) of the bf16 copy ...
@@ -214,6 +215,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
                                                               // [4] rounds of a flood (0: none), [8..24) compaction counts
 
   float* kth_lds = reinterpret_cast<float*>(misc + 32);       // [32] the queries' final k-th best scores (the last workgroup)
+  float* thrh_lds = kth_lds + 32;                             // [32] int8: pass thresholds for keys of HEAVY granules (filter_common.h)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -235,6 +237,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   }
   // (the copies' error rows: requested now, used by the thresholds)
   const unsigned tail_b = *p.max_kerr2, tail_8e = I8 ? p.tail8[0] : 0u, tail_8s = I8 ? p.tail8[1] : 0u;
+  const unsigned tail_8eh = I8 ? p.tail8[3] : 0u, tail_8sh = I8 ? p.tail8[4] : 0u;   // (the HEAVY granules' error and scale)
   // The bound pass's units are dealt over the first G_b workgroups -- at least 64 of them when there are that many units
   // (parts = workgroups: the bound wants >= 4 k of them), one unit per wave before a workgroup takes a second round: unit u
   // belongs to workgroup u % G_b, wave (u / G_b) % 8.  This wave's first unit: its loads need no query -- in flight during
@@ -247,6 +250,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   if (tid < 32) {
     qcnt[tid] = 0;
     thr_lds[tid] = I8 ? __int_as_float(tid < p.B ? INT_MIN : INT_MAX) : (tid < p.B ? RG_NEG_INF : __builtin_huge_valf());
+    thrh_lds[tid] = thr_lds[tid];
     theta_lds[tid] = RG_NEG_INF;
   }
   if (tid < 32) {
@@ -400,6 +404,12 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   const int64_t n_mine = gw < p.nunits ? (p.nunits - gw + W - 1) / W : 0;
   const char* fbase = I8 ? reinterpret_cast<const char*>(p.Kb8) : reinterpret_cast<const char*>(p.Kb);
   if (n_mine > 0) RG_SLOAD(A0, fbase, gw);
+  // (int8) the class word of unit u's granule (granule = u / 2: filter_common.h), requested a unit ahead like the unit's blocks
+  auto cls_word = [&](int64_t u) -> unsigned {
+    if constexpr (I8) return p.cls8[__builtin_amdgcn_readfirstlane((int)(u >> 6))];
+    else return 0u;
+  };
+  [[maybe_unused]] unsigned cw0 = n_mine > 0 ? cls_word(gw) : 0u, cw1 = 0u, cwP[2] = {0u, 0u};
   // Up to 16 queries (one MFMA query group): the first TWO units of the stream are multiplied right here, while the other
   // workgroups' part maxima are still on their way -- their accumulators wait in registers for the thresholds, their
   // epilogues run behind phase 2.  Two rounds of the stream (2 x 32 MB chip-wide, ~7 us of HBM time) move under the
@@ -433,6 +443,8 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   const float ek_b = sqrtf(__uint_as_float(tail_b));
   const float ek_8 = I8 ? sqrtf(__uint_as_float(tail_8e)) : 0.f;
   const float sk_8 = I8 ? __uint_as_float(tail_8s) : 0.f;
+  const float ek_8h = I8 ? sqrtf(__uint_as_float(tail_8eh)) : 0.f;
+  const float sk_8h = I8 ? __uint_as_float(tail_8sh) : 0.f;
   // threshold of query q from the part maxima published so far (one wave; every lane returns with thr_lds[q] written)
   // this lane's parts of query q as published so far: parts lane, lane + 64, ... (0: nothing yet); the largest of them is the
   // maximum of a coarser part (64 of them: one per lane); *missing = some part of this lane is still unpublished
@@ -470,19 +482,15 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
     float out;
     if (sc_flag[q]) {
       out = I8 ? __int_as_float(INT_MAX) : __builtin_huge_valf();   // a zero query passes nothing (answered at the end)
+      thrh_lds[q] = out;
     } else if constexpr (I8) {
-      const float e8 = sc_eq8[q];
-      const float eps = fmaf(fmaf(e8, ek_8, e8 + ek_8), 1.0009765625f, FILTER_EPS_SLACK);
-      const float sc = sc_qs[q] * sk_8;
-      int t;
-      if (!(sc > 0.f)) t = INT_MIN;
-      else {
-        const float xq = __fsub_rn(theta, eps) / sc;
-        t = !(xq > -8.4e6f) ? INT_MIN : (xq > 8.4e6f ? INT_MAX : (int)floorf(xq) - 2);
-      }
       // (never below a threshold already in force: a list that passed its cap has raised it to INT_MAX)
+      const int t = filter_threshold_i8_of(theta, sc_eq8[q], ek_8, sc_qs[q] * sk_8);
       const int old = __float_as_int(thr_lds[q]);
       out = __int_as_float(t > old ? t : old);
+      const int th = filter_threshold_i8_of(theta, sc_eq8[q], ek_8h, sc_qs[q] * sk_8h);   // keys of HEAVY granules
+      const int oldh = __float_as_int(thrh_lds[q]);
+      thrh_lds[q] = __int_as_float(th > oldh ? th : oldh);
     } else {
       const float e = sc_eqb[q];
       const float eps_b = fmaf(fmaf(e, ek_b, e + ek_b), 1.0009765625f, FILTER_EPS_SLACK);
@@ -522,8 +530,13 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
       for (int c = 0; c < 4; ++c) issue_parts(wave + 8 * c, raw[c]);
       if (pre) {
         RG_SLOAD(A1, fbase, gw + W);
+        cwP[0] = cw0;
+        cwP[1] = cls_word(gw + W);
         unit_mfma_g0(A0, accP[0]);
-        if (n_mine > 2) RG_SLOAD(A0, fbase, gw + 2 * W);
+        if (n_mine > 2) {
+          RG_SLOAD(A0, fbase, gw + 2 * W);
+          cw0 = cls_word(gw + 2 * W);
+        }
         unit_mfma_g0(A1, accP[1]);
       }
       bool mc[4];
@@ -571,6 +584,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
       __hip_atomic_store(p.list_k + (int64_t)q * SMALL_LIST_CAP + pos, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       thr_lds[q] = I8 ? __int_as_float(INT_MAX) : __builtin_huge_valf();   // the exact scan answers this query: pass nothing more
+      thrh_lds[q] = thr_lds[q];
     }
   };
   // mid-stream flush (the buffer filled up: a flood): every lane scores its entries' keys itself
@@ -615,6 +629,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
     }
     wcnt = 0;
   };
+  [[maybe_unused]] int cls_unit = 0;   // (int8) class of the granule the unit in process lies in (wave-uniform; granule = unit / 2)
   auto epilogue = [&](const acc_t (&a)[2], int gq, int64_t unit, int sub) {
     const int64_t key_base = (unit * GF::SUBS + sub) * 32 + 4 * g;  // the lane's keys: + r + 16 h  (mask bit 4 h + r)
     unsigned mk = 0;
@@ -625,7 +640,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
       for (int r = 1; r < 4; ++r) m = max(m, a[0][r]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) m = max(m, a[1][r]);
-      const int th = __float_as_int(thr_lds[16 * gq + j]);
+      const int th = __float_as_int((cls_unit ? thrh_lds : thr_lds)[16 * gq + j]);
       any = __any(m >= th);
       if (any) {
         const unsigned tm1 = (unsigned)(max(-(1 << 24), min(1 << 24, th)) - 1);
@@ -662,7 +677,11 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
       wcnt += __popcll(bal);
     }
   };
-  auto process = [&](f32x4 (&A)[16], int64_t unit) {
+  auto set_class = [&]([[maybe_unused]] unsigned cw, [[maybe_unused]] int64_t unit) {
+    if constexpr (I8) cls_unit = (int)((cw >> ((unit >> 1) & 31)) & 1u);
+  };
+  auto process = [&](f32x4 (&A)[16], int64_t unit, unsigned cw) {
+    set_class(cw, unit);
     if (wcnt > L::CAND_BUF - 128 * GF::SUBS) flush_slow();  // two groups x SUBS sub-tiles x <= 64 entries
 #pragma unroll
     for (int sub = 0; sub < GF::SUBS; ++sub) {
@@ -692,16 +711,22 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
     int64_t i = 0;
     if (pre) {  // the two units multiplied before the thresholds existed
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < 2; ++u) {
+        set_class(cwP[u], gw + u * W);
 #pragma unroll
         for (int sub = 0; sub < GF::SUBS; ++sub) epilogue(accP[u][sub], 0, gw + u * W, sub);
+      }
       i = 2;
     }
     for (; i + 2 <= n_mine; i += 2) {  // pairs: A0 then A1, the other buffer's loads always in flight
       RG_SLOAD(A1, fbase, gw + (i + 1) * W);
-      process(A0, gw + i * W);
-      if (i + 2 < n_mine) RG_SLOAD(A0, fbase, gw + (i + 2) * W);
-      process(A1, gw + (i + 1) * W);
+      cw1 = cls_word(gw + (i + 1) * W);
+      process(A0, gw + i * W, cw0);
+      if (i + 2 < n_mine) {
+        RG_SLOAD(A0, fbase, gw + (i + 2) * W);
+        cw0 = cls_word(gw + (i + 2) * W);
+      }
+      process(A1, gw + (i + 1) * W, cw1);
       if (refresh && (i & 6) == 6) {   // (wave 0 of a workgroup that moved on early) the others' maxima may have arrived
         bool any_missing = false;
         for (int q = 0; q < B; ++q) {
@@ -713,7 +738,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
         refresh = any_missing;
       }
     }
-    if (i < n_mine) process(A0, gw + i * W);  // odd count: the last unit, nothing behind it
+    if (i < n_mine) process(A0, gw + i * W, cw0);  // odd count: the last unit, nothing behind it
   }
 #undef RG_SLOAD
 
@@ -1244,8 +1269,10 @@ extern "C" int ragraph_topk_cosine_small_f32(const float* Q, int64_t B, const fl
   p.Kn = Kn;
   p.Kb = Kb;
   p.max_kerr2 = reinterpret_cast<const unsigned*>(Kb + npad * D);
-  p.Kb8 = reinterpret_cast<const signed char*>(Kb + (npad + 1) * D);
-  p.tail8 = reinterpret_cast<const unsigned*>(p.Kb8 + npad * D);
+  const FilterI8View v8 = filter_i8_view(Kb, N, D);
+  p.Kb8 = v8.K8;
+  p.tail8 = v8.tail8;
+  p.cls8 = v8.cls;
   p.N = N;
   p.idx_base = idx_base;
   p.B = (int)B;

@@ -183,6 +183,17 @@ def bank_copy_errors(keys_bf16: torch.Tensor, n_keys: int):
     return float(t16[0]) ** 0.5, float(t8[0]) ** 0.5, float(t8[1])
 
 
+def int8_copy_classes(keys_bf16: torch.Tensor, n_keys: int) -> dict:
+    """The int8 copy's two classes of granules (csrc/filter_common.h "TWO SCALES"; one synchronisation): NORMAL granules --
+    32 KiB of int8 rows whose largest |k_i| is at most `cut` -- are quantised with `scale`, the HEAVY rest with
+    `scale_heavy` = the bank's largest |k_i| / 127; each class has its own measured max |dk| and hence its own bound."""
+    npad = -(-n_keys // 256) * 256
+    row = keys_bf16[npad + 1 + npad // 2, :16].contiguous()
+    f, i = row.view(torch.float32).cpu(), row.view(torch.int32).cpu()
+    return {"err": float(f[0]) ** 0.5, "scale": float(f[1]), "max_abs": float(f[2]), "err_heavy": float(f[3]) ** 0.5,
+            "scale_heavy": float(f[4]), "cut": float(f[5]), "heavy_granules": int(i[6]), "granules": int(i[7])}
+
+
 def filtered_i8_levels(B: int, n_keys: int, D: int, k: int) -> int:
     """How many trailing levels of a filtered call of this shape run on the int8 copy (under this thread's current cap)."""
     return N.lib().ragraph_topk_cosine_filtered_i8_levels(B, n_keys, D, k)

@@ -75,7 +75,8 @@ class KeyIndex:
         self._packed = None
         self._bf16 = None
         self._filter_off = False  # set when this bank defeats the filter (see _poll_overflow)
-        self._i8_off = False      # set when this bank defeats the INT8 levels only (heavy-tailed rows: one scale for all keys)
+        self._i8_off = False      # set when this bank defeats the INT8 levels only (clustered keys: too many within the int8 bound)
+        self.i8_classes = None    # the int8 copy's two classes of granules as read for _i8_ok (kernels.int8_copy_classes)
         self._pending = None      # (pinned word, event, batch, had int8 levels) of the last filtered call's overflow count
         self._i8_ok = None        # the int8 copy's error row read (once, lazily): accurate enough for int8 levels?
         self._seen_i8, self._seen_bf16 = [0, 0], [0, 0]   # [queries, overflowed] of the polled calls with / without int8
@@ -307,8 +308,12 @@ class KeyIndex:
         if cap is None:
             return None, False
         if self._i8_ok is None and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
-            _, e8, _ = self.ops.bank_copy_errors(self._bf16, self.keys_normalized.shape[0])
-            self._i8_ok = e8 <= self.I8_MAX_ERR
+            # (the copy has two scales, csrc/filter_common.h: the NORMAL granules' error decides, unless more than a quarter
+            # of the granules are HEAVY ones with a useless bound -- a bank of heavy-tailed rows throughout)
+            c = self.ops.int8_copy_classes(self._bf16, self.keys_normalized.shape[0])
+            many_heavy = 4 * c["heavy_granules"] > c["granules"] and c["err_heavy"] > self.I8_MAX_ERR
+            self._i8_ok = c["err"] <= self.I8_MAX_ERR and not many_heavy
+            self.i8_classes = c
         allowed = bool(self._i8_ok) and not self._i8_off
         cap(-1 if allowed else 0)
         return cap, allowed

@@ -449,7 +449,8 @@ def test_topk_cosine_filtered_bit_exact(dev, B, N, k):
     knd = _t(kn, dev)
     kb = K.keys_to_bf16(knd)
     npad = -(-N // 256) * 256   # bf16 copy padded to whole stages + its error row, then the int8 copy (half the rows) + its row
-    assert kb.shape[0] == npad + 1 + npad // 2 + 1 + 256   # (+ slack the int8 levels' last stage may read)
+    # (+ the int8 copy's granule table, + slack the int8 levels' last stage may read)
+    assert kb.shape[0] == npad + 1 + npad // 2 + 1 + (npad // 4096 + 8) + 256
     s, i, over = K.topk_cosine_filtered(_t(q, dev), knd, kb, k, idx_base=9)
     assert over == 0
     rs, ri = cref.topk_cosine(q, kn, k, idx_base=9)
@@ -839,52 +840,27 @@ def test_int8_levels_at_d64_start_at_whole_stages(dev):
 
 
 def test_int8_copy_scale_and_error_bound(dev):
-    """The int8 copy's tail row: the bank's scale = max |k_i| / 127 and max_k |dk|^2 of the dequantised rows, against numpy;
-    heavy-tailed rows (one large entry) widen the scale for the whole bank -- the bound follows, the result stays exact."""
+    """The int8 copy's tail row on a bank of ordinary rows: the scale = cut / 127 with the cut at most the bank's largest |k_i|
+    and at least every NORMAL granule's, and max_k |dk|^2 of the rows dequantised on that grid, against numpy.  (Heavy-tailed
+    rows get a scale of their own: tests/test_gpu_i8_classes.py.)"""
     from ragraph_amd import kernels as K
 
     rng = _rng(41)
     N, D = 3000, 256
     kn = _bank(rng, N, D)
-    kn[17] = 0
-    kn[17, 5] = 1.0                                         # a one-hot key: |k_i| = 1 sets the scale
     knd = _t(kn, dev)
     kb = K.keys_to_bf16(knd)
-    npad = -(-N // 256) * 256
-    tail = kb[npad + 1 + npad // 2].cpu().numpy().view(np.float32)
-    sk = np.float32(np.abs(kn).max()) / np.float32(127.0)
-    assert tail[1] == sk
-    ki = np.clip(np.rint(kn / sk), -127, 127).astype(np.float32)
-    err2 = ((ki * sk - kn).astype(np.float64) ** 2).sum(1).max()
-    assert abs(tail[0] - err2) <= 1e-5 * err2 and tail[0] >= err2 * (1 - 1e-6)
-
-
-def test_key_index_keeps_heavy_tailed_banks_off_int8(dev):
-    """One scale serves the whole int8 copy, so a bank with a one-hot row quantises its ordinary rows on a grid set by that
-    row: KeyIndex reads the copy's measured error once and keeps such a bank's levels on bf16 (exactness never depends on
-    it: both answers are the oracle's); a Gaussian bank takes the int8 levels."""
-    from ragraph_amd import kernels as K
-
-    rng = _rng(77)
-    N, D, B, k = 70000, 256, 1100, 10
-    kn = _bank(rng, N, D)
-    q = rng.standard_normal((B, D), dtype=np.float32)
-    idx = K.KeyIndex(_t(kn, dev))
-    s, i = idx.topk(_t(q, dev), k)
-    assert idx._i8_ok is True
-    rs, ri = cref.topk_cosine(q[:300], kn, k)
-    assert np.array_equal(i.cpu().numpy()[:300], ri) and np.array_equal(s.cpu().numpy()[:300], rs)
-    kn2 = kn.copy()
-    kn2[123] = 0
-    kn2[123, 9] = 1.0
-    idx2 = K.KeyIndex(_t(kn2, dev))
-    s2, i2 = idx2.topk(_t(q, dev), k)
-    assert idx2._i8_ok is False
-    e16, e8, sk = K.bank_copy_errors(idx2._bf16, N)
-    assert e8 > K.KeyIndex.I8_MAX_ERR and abs(sk - 1.0 / 127.0) < 1e-9 and e16 < 0.004
-    rs2, ri2 = cref.topk_cosine(q[:300], kn2, k)
-    assert np.array_equal(i2.cpu().numpy()[:300], ri2) and np.array_equal(s2.cpu().numpy()[:300], rs2)
-    assert K.N.lib().ragraph_topk_cosine_filtered_max_i8_levels(-1) == -1     # the cap does not leak out of a call
+    c = K.int8_copy_classes(kb, N)
+    assert c["max_abs"] == float(np.abs(kn).max()) and c["cut"] <= c["max_abs"]
+    assert np.float32(c["scale"]) == np.float32(c["cut"]) / np.float32(127.0)
+    gk = 32768 // D
+    cls = np.repeat(np.abs(np.concatenate([kn, np.zeros((-N % gk, D), np.float32)])).reshape(-1, gk * D).max(1) > c["cut"], gk)[:N]
+    assert int(cls.sum()) == c["heavy_granules"] * gk or cls[-1]           # (the last granule may be ragged)
+    sk = np.float32(c["scale"])
+    rows = kn[~cls]
+    ki = np.clip(np.rint(rows * (np.float32(1.0) / sk)), -127, 127).astype(np.float32)
+    err2 = ((ki * sk - rows).astype(np.float64) ** 2).sum(1).max()
+    assert abs(c["err"] ** 2 - err2) <= 1e-4 * err2
 
 
 def test_key_index_drops_int8_before_the_filter_when_a_bank_overflows(dev):
