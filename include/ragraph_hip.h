@@ -111,8 +111,13 @@ int ragraph_topk_cosine_bank_f32(const float* Q, int64_t B, const float* Kn, con
  *   ones: fewer, steeper levels -- ragraph_topk_cosine_filtered_plan).  The result has the same bits as
  *   ragraph_topk_cosine_f32.  D in {64,128,256}, k <= 32.
  *   Kb   bf16 copy of Kn made by ragraph_keys_to_bf16 (ragraph_keys_bf16_rows(N) rows x D, uint16 storage: the bf16 rows
- *        padded to a multiple of 256 keys, a tail row, the int8 rows, their tail row, and 256 rows of slack that the last
- *        stage of an int8 level may read).
+ *        padded to a multiple of 256 keys, a tail row, the int8 rows, their tail row, the int8 copy's granule table, and
+ *        256 rows of slack that the last stage of an int8 level may read).  The int8 rows come in two classes of granules
+ *        of 32 KiB (128 / 256 / 512 keys at D = 256 / 128 / 64), each class on its own scale with its own measured error:
+ *        their tail row (32-bit words) = [0] max |dk|^2 and [1] scale of the NORMAL granules, [2] the bank's largest |k_i|,
+ *        [3] / [4] the HEAVY granules' max |dk|^2 / scale, [5] the cut between the classes (largest |k_i| a normal granule
+ *        may hold), [6] heavy granules, [7] granules; behind it the granules' largest |k_i| (floats, padded to 16 bytes)
+ *        and one class bit per granule (set = heavy).
  *   Kp   optional packed fp32 copy (ragraph_pack_keys_f32) for the fp32 level, or NULL.
  *   overflow  device int, set by the call: number of queries whose candidate list exceeded its capacity
  *        (ragraph_topk_cosine_filtered_cap(k) keys per list; a batch of <= 64 queries keeps up to 8 such lists per query,
@@ -154,10 +159,11 @@ int ragraph_topk_cosine_filtered_plan(int64_t B, int64_t N, int D, int k, int64_
  * error bound, so ~3x the candidates -- the late levels of batches of >= 1024 queries at D = 128 / 256). */
 int ragraph_topk_cosine_filtered_i8_levels(int64_t B, int64_t N, int D, int k);
 /* Cap on the int8 levels of the CALLING THREAD's following filtered calls (thread-local; -1 = the built-in rule, 0 = none);
- * returns the previous value.  For callers that know their bank: the int8 bound is only as tight as the bank's LARGEST
- * entry allows (one scale for all keys), so a heavy-tailed bank passes many more candidates on int8 than on bf16 -- still
- * exact, but slower.  ragraph_amd/kernels_index.py sets it per bank from the copy's measured error row and from calls whose
- * candidate lists overflowed. */
+ * returns the previous value.  For callers that know their bank: the int8 bound is only as tight as the largest entries
+ * of the bank's ordinary granules allow (two scales: a few heavy-tailed rows cost their own granules only), so a bank of
+ * heavy-tailed rows THROUGHOUT passes many more candidates on int8 than on bf16 -- still exact, but slower.
+ * ragraph_amd/kernels_index.py sets it per bank from the copy's measured error row and from calls whose candidate lists
+ * overflowed. */
 int ragraph_topk_cosine_filtered_max_i8_levels(int n);
 /* A SPECULATIVE first bound for the CALLING THREAD's following filtered calls (thread-local; NaN = none, the default);
  * returns the previous value.  A call on a single bank whose schedule starts with a bound pass (plan[1] == 2) then skips

@@ -41,8 +41,9 @@ __host__ __device__ constexpr int64_t filter_block_offset(int64_t subtile, int D
 // The INT8 copy behind the bf16 copy (ragraph_keys_to_bf16 makes both).  v_mfma_i32_16x16x64_i8 issues at the cycles of the
 // bf16 MFMA with twice the K: in the filter's own inner loop it sustains 3.29 - 3.53 Pop/s where bf16 sustains 1.68 PFLOP/s
 // (tools/microbench/mfma_i8_bench.hip) -- twice the (query, key) pairs per second -- and a key is 1 byte per element.
-//   * keys: ONE scale for the bank, s_k = max |k_i| / 127 (a per-key scale would have to be applied to every score before
-//     the threshold test; the bound below only depends on the LARGEST key error anyway), ki = rint(k / s_k);
+//   * keys: one scale per CLASS of granules (two classes: "TWO SCALES" below; s_k stands for the class's scale and max |dk|
+//     for the class's largest error), s_k = max |k_i| / 127 over the class (a per-key scale would have to be applied to every
+//     score before the threshold test; the bound below only depends on the LARGEST key error anyway), ki = rint(k / s_k);
 //   * queries: a scale per query, s_q = max |q_i| / 127, qi = rint(q / s_q) (a query's scale folds into its threshold);
 //   * the approximate score is s~ = s_q s_k I with I = sum qi ki an EXACT integer (|I| <= 127^2 D < 2^23), and with
 //     q^ = s_q qi = q + dq, k^ = s_k ki = k + dk:  |s~ - s| <= |q^||dk| + |dq||k| <= |dq| + max|dk| + |dq| max|dk| (+ the

@@ -175,9 +175,9 @@ __global__ void __launch_bounds__(256) i8_granule_absmax_kernel(const float* __r
 //   (granules <= x) f(x) + (granules > x) f(x_max),   f(x) = exp(lambda |dk|(x)),  |dk|(x) = (x / 127) sqrt(D / 12)
 // (uniform rounding errors of a row quantised on the grid x / 127; lambda = 60: the bench bank's candidates triple when eps
 // grows from the bf16 bound's 0.004 to the single scale's 0.0215).  Whatever comes out is only a matter of speed: every
-// class's error is MEASURED by the quantising kernel and the bounds use the measurements.  one_scale: cut = the maximum.
+// class's error is MEASURED by the quantising kernel and the bounds use the measurements.  lambda <= 0: cut = the maximum.
 constexpr int I8_CUT_BINS = 1 << 14;
-__global__ void __launch_bounds__(1024) i8_cut_kernel(const float* __restrict__ gmax, int64_t granules, int D, int one_scale,
+__global__ void __launch_bounds__(1024) i8_cut_kernel(const float* __restrict__ gmax, int64_t granules, int D, float lambda,
                                                       unsigned* __restrict__ tail8) {
   __shared__ int hist[I8_CUT_BINS];
   for (int i = threadIdx.x; i < I8_CUT_BINS; i += 1024) hist[i] = 0;
@@ -187,8 +187,8 @@ __global__ void __launch_bounds__(1024) i8_cut_kernel(const float* __restrict__ 
   if (threadIdx.x != 0) return;
   const float xmax = __uint_as_float(tail8[2]);
   float cut = xmax;
-  if (!one_scale && xmax > 0.f) {
-    const float c = 60.f * sqrtf((float)D / 12.f) / 127.f;
+  if (lambda > 0.f && xmax > 0.f) {
+    const float c = lambda * sqrtf((float)D / 12.f) / 127.f;
     const float fmax_ = expf(c * xmax);
     const int top = (int)(__float_as_uint(xmax) >> 17);
     float best = (float)granules * fmax_;
@@ -2413,11 +2413,13 @@ extern "C" int ragraph_keys_to_bf16(const float* Kn, int64_t N, int D, uint16_t*
   if (D == 256) hipLaunchKernelGGL(i8_granule_absmax_kernel<256>, gridg, dim3(256), 0, st, Kn, N, gmax, tail8);
   else if (D == 128) hipLaunchKernelGGL(i8_granule_absmax_kernel<128>, gridg, dim3(256), 0, st, Kn, N, gmax, tail8);
   else hipLaunchKernelGGL(i8_granule_absmax_kernel<64>, gridg, dim3(256), 0, st, Kn, N, gmax, tail8);
-  static const int one_scale = [] {   // (experiments: RAGRAPH_I8_ONE_SCALE=1 -- the single scale of rounds 3 / 4)
+  static const float lambda = [] {   // (experiments: RAGRAPH_I8_ONE_SCALE=1 -- the single scale of rounds 3 / 4; RAGRAPH_I8_CUT_LAMBDA)
     const char* e = getenv("RAGRAPH_I8_ONE_SCALE");
-    return e && e[0] == '1' ? 1 : 0;
+    if (e && e[0] == '1') return 0.f;
+    const char* l = getenv("RAGRAPH_I8_CUT_LAMBDA");
+    return l ? (float)atof(l) : 60.f;
   }();
-  hipLaunchKernelGGL(i8_cut_kernel, dim3(1), dim3(1024), 0, st, gmax, v8.granules, D, one_scale, tail8);
+  hipLaunchKernelGGL(i8_cut_kernel, dim3(1), dim3(1024), 0, st, gmax, v8.granules, D, lambda, tail8);
   const dim3 grid8((unsigned)cdiv(npad * (D / 16), 256));
   if (D == 256) hipLaunchKernelGGL(keys_to_i8_kernel<256>, grid8, dim3(256), 0, st, Kn, N, npad, Kb8, tail8, gmax, cls);
   else if (D == 128) hipLaunchKernelGGL(keys_to_i8_kernel<128>, grid8, dim3(256), 0, st, Kn, N, npad, Kb8, tail8, gmax, cls);

@@ -31,7 +31,7 @@ while time.time() - t0 < budget:
          ri(2048, 6000))[ri(0, 13)]
     if B * N > 3e9:
         B = max(1, int(3e9 // N))
-    kind = ri(0, 4)
+    kind = ri(0, 5)
     keys = torch.randn(N, D, device=dev, generator=g)
     if kind == 1:    # clustered bank: 50 centres + noise (dense top of the score distribution)
         c = torch.randn(50, D, device=dev, generator=g)
@@ -42,8 +42,15 @@ while time.time() - t0 < budget:
     elif kind == 3:  # a block of near-duplicates of one row
         m = min(N // 4, 1500)
         keys[N // 2:N // 2 + m] = keys[7] + 1e-3 * torch.randn(m, D, device=dev, generator=g)
+    elif kind == 5:  # heavy-tailed rows (one dominant entry): a few, a run of them, or every 97th -- the int8 copy's HEAVY granules
+        m = (1, 7, ri(2, 2000), N // 97)[ri(0, 3)]
+        rows = torch.randint(0, N, (m,), device=dev, generator=g) if ri(0, 1) else (torch.arange(m, device=dev) * 97 + ri(0, 96)) % N
+        keys[rows] = 0.03 * keys[rows]
+        keys[rows, torch.randint(0, D, (rows.numel(),), device=dev, generator=g)] = 1.0
     kn = K.normalize_rows(keys)
     q = torch.randn(B, D, device=dev, generator=g)
+    if kind == 5 and B > 4:   # some queries next to heavy rows: heavy keys among the winners
+        q[3] = keys[rows[0]] + 0.05 * q[3]
     if kind == 1:
         q = kn[torch.randint(0, N, (B,), device=dev, generator=g)] + 0.2 * q
     if kind == 3 and B > 2:
