@@ -2255,6 +2255,11 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
       // (a candidate costs ~0.4 ns while a level's rescoring is a latency chain -- up to ~1000 queries -- and ~0.18 ns once it
       // is bound by the row gathers: 100 000 queries x ~130 candidates x 1 KiB in 1.8 ms)
       const double per_cand = 0.18e-3 + 0.22e-3 * (B <= 1024 ? 1.0 : 1024.0 / (double)B);
+      // (int8 candidates per bf16 candidate.  3.0 until the copy got its two scales and the calls their speculative bounds; 2.0
+      // fits what tools/i8_rule_grid.py measures now -- 105 shapes of 300 .. 16 384 queries x 70 k .. 1 M keys x D = 64 / 128 /
+      // 256, KeyIndex in its steady state, geomean 0.971 of the old rule's time; the banks of 150 k - 500 k keys that moved to
+      // int8 0.77 - 0.9 (1100 x 300 k x 256: 0.188 -> 0.144 ms); 1.5 loses up to 1.6 x on 70 k-key banks.  profiles/r5_i8_rule_grid.txt)
+      static const double i8_candf = [] { const char* e = getenv("RAGRAPH_FILTER_I8_CANDF"); return e ? atof(e) : 2.0; }();  // A/B
       // (mid_i8 -- D = 256 banks of 32 768 .. 65 535 keys: the constants below were fitted on million-key banks and overprice
       // these shapes' candidates; what measured faster there is the bf16 plan with every level moved to int8: see below)
       for (int i8 = 0; i8 <= (i8_ok && !mid_i8 ? (L < 2 || scored ? L : 2) : 0); ++i8) {
@@ -2263,7 +2268,7 @@ static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_
         for (int l = 0; l < L; ++l) {
           e = l + 1 == L ? (double)N : e * r;
           const bool q8 = l >= L - i8;
-          const double cands = 1.3 * k * r * (q8 ? 3.0 : 1.0);
+          const double cands = 1.3 * k * r * (q8 ? i8_candf : 1.0);
           if (cands > cap / 2 && !(force_n0 > 0 && force_L > 0)) fits = false;
           cost += 60.0 + (e - e_prev) * (double)B * 2.0 * D / (q8 ? 2.4e9 : 1.25e9) +
                   (double)B * cands * per_cand * (q8 && scored ? scored_cand : 1.0);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Banks below the int8 levels' cut-offs (32 768 keys at D = 256 from 2048 queries, 65 536 otherwise): ms per filtered call
 with the levels forced onto bf16 (RAGRAPH_FILTER_I8=0), forced onto int8 (= the number of levels) and as the rule decides.
-    python tools/i8_small_bank_ab.py"""
+    python tools/i8_small_bank_ab.py [mid]      (mid: banks of 70 k - 500 k keys whose batches the rule keeps on bf16)"""
 import ctypes
 import os
 import sys
@@ -13,7 +13,9 @@ from ragraph_amd import kernels as K  # noqa: E402
 
 dev = torch.device("cuda", 0)
 L = K.N.lib()
-for B, N, D in [(2048, 20000, 256), (8192, 20000, 256), (16384, 20000, 256), (8192, 30000, 256), (1024, 40000, 256), (512, 60000, 256),
+MID = [(512, 150000, 256), (512, 300000, 256), (1100, 150000, 256), (1100, 300000, 256), (1100, 500000, 256), (2048, 70000, 256),
+       (4096, 70000, 256), (700, 200000, 128), (2048, 200000, 128), (4096, 100000, 128), (2048, 300000, 64), (8192, 100000, 64)]
+for B, N, D in MID if len(sys.argv) > 1 and sys.argv[1] == "mid" else [(2048, 20000, 256), (8192, 20000, 256), (16384, 20000, 256), (8192, 30000, 256), (1024, 40000, 256), (512, 60000, 256),
                 (4096, 50000, 128), (16384, 50000, 128), (65536, 40000, 128), (8192, 40000, 64), (16384, 60000, 64), (65536, 50000, 64)]:
     g = torch.Generator(device=dev).manual_seed(B + N + D)
     kn = K.normalize_rows(torch.randn(N, D, device=dev, generator=g))
