@@ -402,6 +402,17 @@ def memory_block(tgb):
         rec["bf16_image"] = min(both, (npad + 1) * D * 2)
         rec["int8_image"] = max(0, both - rec["bf16_image"])
         rec["packed_fp32"] = nb(inner._packed)
+        if inner._bf16 is not None and D in (64, 128, 256):
+            from ragraph_amd import kernels as K
+            c = K.int8_copy_classes(inner._bf16, N)   # (kept out of `total`: not bytes)
+            int8_classes = {"granule_keys": 32768 // D, "granules": c["granules"], "heavy_granules": c["heavy_granules"],
+                            "cut": round(c["cut"], 5), "max_abs": round(c["max_abs"], 5), "max_dk": round(c["err"], 5),
+                            "max_dk_heavy": round(c["err_heavy"], 5),
+                            "what": "the int8 image's two scales (csrc/filter_common.h): granules whose largest |k_i| <= cut are "
+                                    "quantised on the grid cut / 127, the heavy rest on max_abs / 127; max_dk = the measured "
+                                    "largest |dk| of each class, which is what each class's proven bound uses"}
+        else:
+            int8_classes = None
         if idx._collapsed:
             rec["unique_rows_fp32"] = nb(inner.keys_normalized)
             rec["duplicate_groups"] = nb(idx._collapsed[1]) + nb(idx._collapsed[2])
@@ -409,6 +420,8 @@ def memory_block(tgb):
             rec["padded_keys_fp32"] = nb(idx.keys_normalized)
     total = sum(v for v in rec.values())
     rec["total"] = total
+    if inner is not None and int8_classes is not None:
+        rec["int8_classes"] = int8_classes
     rec["reference_bank"] = ref
     rec["ratio_to_reference_bank"] = round(total / max(ref, 1), 3)
     rec["what"] = ("bytes on the device; reference_bank = keys + values + labels as the reference holds them; the normalised keys, "
