@@ -316,7 +316,10 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   RG_SSTAMP(1);
 
   // the bound pass's B operands (bf16): lane j + 16 g of k-step t of group gq = elements 32 t + 8 g .. + 7 of query 16 gq + j
+  // (under a speculative first bound there is no bound pass: the int8 filter pass then needs none of this)
+  const bool with_bound = !p.use_prior;   // (block-uniform)
   bf16x8 bqb[2 * GB::KS];
+  if (with_bound || !I8)
 #pragma unroll
   for (int gq = 0; gq < 2; ++gq)
 #pragma unroll
@@ -335,7 +338,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   // parts non-zero has the final maxima in the same round trip.  (The first version published by atomicMax, announced
   // itself on a counter after waiting for its atomics, and read the maxima after the counter filled: five agent-scope
   // round trips of 2 - 3 us each between a workgroup's bound unit and its thresholds; now two.) ------------------------
-  {
+  if (with_bound) {
     float* wmax = tile_all;                                       // [8][32] the wave's maxima over its units
     if (lane < 32) wmax[wave * 32 + lane] = RG_NEG_INF;
     for (int64_t u = u_first; u < p.bound_units; u += (int64_t)G_b * 8) {
@@ -403,6 +406,8 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   const int64_t gw = (int64_t)blockIdx.x * 8 + wave;
   const int64_t n_mine = gw < p.nunits ? (p.nunits - gw + W - 1) / W : 0;
   const char* fbase = I8 ? reinterpret_cast<const char*>(p.Kb8) : reinterpret_cast<const char*>(p.Kb);
+  // (under a speculative first bound the loads could fly from the kernel's first instruction on -- measured: 51.7 -> 53.0 us
+  // for one query; sixteen loads in front of the query rows' delay the prepare phase by more than they hide)
   if (n_mine > 0) RG_SLOAD(A0, fbase, gw);
   // (int8) the class word of unit u's granule (granule = u / 2: filter_common.h), requested a unit ahead like the unit's blocks
   auto cls_word = [&](int64_t u) -> unsigned {

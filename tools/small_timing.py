@@ -17,5 +17,11 @@ for B in [int(a) for a in sys.argv[1:]] or [1, 16]:
     q = torch.randn(B, D, device=dev, generator=torch.Generator(device=dev).manual_seed(4321 + B))
     for rep in range(3):
         print(f"B = {B} call {rep}", file=sys.stderr, flush=True)
-        K.topk_cosine_small(q, kn, kb, k)
+        prior = os.environ.get("SMALL_TIMING_PRIOR")   # (a forced speculative first bound: the product's steady state)
+        if prior:
+            K.set_filter_prior(float(prior))
+        try:
+            K.topk_cosine_small(q, kn, kb, k)
+        finally:
+            K.set_filter_prior(None)
         torch.cuda.synchronize()
