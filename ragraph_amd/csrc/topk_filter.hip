@@ -518,6 +518,18 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
   static_assert(QW == 32 || QW == 64 || QW == 96 || QW == 128, "two, four, six or eight query groups of 16 per wave");
   constexpr int QT = C::WAVES * QW;
   constexpr int NG = QW / 16;  // query groups per wave: each A fragment (16 keys x 32 elements) feeds NG MFMAs
+  // FOLD (int8 levels without the pipelined epilogue): a sub-tile's accumulators start at -T instead of 0 -- the MFMA adds
+  // its integer sums to them exactly -- so "does any score reach its query's threshold" is ONE sign test over the maxima of all
+  // groups instead of a compare per group: a third fewer vector instructions on the path every sub-tile takes.
+#ifndef RG_RING_FOLD
+#define RG_RING_FOLD 1
+#endif
+  // The start values are the MFMAs' C operands straight from registers (a quad of -T per group, rebuilt when the stage's
+  // class changes): four more registers per group and no instruction -- so only where it pays: D = 64, whose sub-tiles are
+  // two MFMAs per group against the same epilogue (4096 x 4M x 64: 0.935 -> 0.913 ms, 65 536: 13.99 -> 13.86; at D = 128 the
+  // same change measured +- 0; D = 256 with six groups has no registers to spare: the quads spilled, and start values moved
+  // into the accumulators by v_mov cost four times what the fold saves).  tools/gpu_fold_ab.sh
+  constexpr bool FOLD = RG_RING_FOLD && I8 && !PIPE && !BOUND && D == 64;
   extern __shared__ float4 fsmem4[];
   char* smem = reinterpret_cast<char*>(fsmem4);
   unsigned* full = reinterpret_cast<unsigned*>(smem + C::SLOTS * C::STAGE_BYTES);  // [SLOTS] then freec [SLOTS]
@@ -744,17 +756,22 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     // thr_n / thr_h when the class changes); thr_p (PIPE, whose epilogue of a stage's last sub-tile runs inside the next
     // stage): the previous stage's.  The two classes' integers are on different grids: a sub-tile is only ever tested
     // against the thresholds of its own granule's class.
+    // (registers: the other class's thresholds are kept as thr_x = normal XOR heavy -- a class change toggles thr_i with it)
     int thr_i[NG];
-    [[maybe_unused]] int thr_n[NG], thr_h[NG], thr_p[NG];
+    [[maybe_unused]] int thr_x[NG], thr_p[NG];
 #pragma unroll
     for (int gq = 0; gq < NG; ++gq) {  // (int8: INT_MIN / INT_MAX -- everything / nothing passes -- clamped beyond any |I| < 2^23)
       thr_i[gq] = I8 ? max(-(1 << 24), min(1 << 24, thr8[gq])) : (thr[gq] >= 0.f ? __float_as_int(thr[gq]) : INT_MIN);
-      thr_n[gq] = thr_i[gq];
-      thr_h[gq] = max(-(1 << 24), min(1 << 24, thr8h[gq]));
+      thr_x[gq] = thr_i[gq] ^ max(-(1 << 24), min(1 << 24, thr8h[gq]));
       thr_p[gq] = thr_i[gq];
     }
+    [[maybe_unused]] i32x4 ntq[FOLD ? NG : 1];   // FOLD: {-T, -T, -T, -T} per group, the accumulators' start values
+    if constexpr (FOLD) {
+#pragma unroll
+      for (int gq = 0; gq < NG; ++gq) ntq[gq] = i32x4{-thr_i[gq], -thr_i[gq], -thr_i[gq], -thr_i[gq]};
+    }
     [[maybe_unused]] unsigned cls_word = 0u;   // class bits of the 32 stages around the current one (SGPR)
-    [[maybe_unused]] int cls_cur = 0, cls_prev = 0, cls_state = 0;
+    [[maybe_unused]] int cls_cur = 0, cls_prev = 0, cls_state = 0, cls_inforce = 0;   // cls_inforce: the class thr_i holds
 
     // ---- ring prologue ------------------------------------------------------------------------------------------
     const int pro = nstages < C::SLOTS - 1 ? nstages : C::SLOTS - 1;
@@ -824,10 +841,13 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
         const int state = cls_cur | (cls_prev << 1);
         if (state != cls_state) {  // (wave-uniform; never taken on a bank without heavy granules)
           cls_state = state;
+          const bool toggle = cls_cur != cls_inforce, other = cls_prev != cls_cur;
+          cls_inforce = cls_cur;
 #pragma unroll
           for (int gq = 0; gq < NG; ++gq) {
-            thr_i[gq] = cls_cur ? thr_h[gq] : thr_n[gq];
-            if constexpr (PIPE) thr_p[gq] = cls_prev ? thr_h[gq] : thr_n[gq];
+            if (toggle) thr_i[gq] ^= thr_x[gq];
+            if constexpr (PIPE) thr_p[gq] = other ? thr_i[gq] ^ thr_x[gq] : thr_i[gq];
+            if constexpr (FOLD) ntq[gq] = i32x4{-thr_i[gq], -thr_i[gq], -thr_i[gq], -thr_i[gq]};
           }
         }
       }
@@ -843,6 +863,11 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
           // shifted into the mask by v_alignbit ({mask, e} >> 31 = mask << 1 | sign(e)): two plain VALU instructions per
           // score where compare + select + or through VCC is three plus a wait state, on a path that half of the last
           // level's sub-tiles take (and every sub-tile of the first)
+          if constexpr (FOLD) {  // (the accumulators hold I - T: the bit is the sign of ~(I - T))
+#pragma unroll
+            for (int b = 7; b >= 0; --b) mk = __builtin_amdgcn_alignbit(mk, ~(unsigned)a[b >> 2][gq][b & 3], 31);
+            return mk;
+          }
           const unsigned tm1 = (unsigned)(th_i8 - 1);
 #pragma unroll
           for (int b = 7; b >= 0; --b) mk = __builtin_amdgcn_alignbit(mk, tm1 - (unsigned)a[b >> 2][gq][b & 3], 31);
@@ -909,6 +934,13 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
             for (int r = 0; r < 4; ++r) m[gq] = fmaxf(m[gq], (float)a[1][gq][r]);
             gm[gq] = fmaxf(gm[gq], m[gq]);
           }
+        } else if constexpr (FOLD) {  // one chain of maxima over every group's I - T, one sign test
+          int mall = as_bits(a[0][0][0]);
+#pragma unroll
+          for (int gq = 0; gq < NG; ++gq)
+#pragma unroll
+            for (int e = (gq == 0 ? 1 : 0); e < 8; ++e) mall = max(mall, as_bits(a[e >> 2][gq][e & 3]));
+          hit = mall >= 0;
         } else {
 #pragma unroll
           for (int gq = 0; gq < NG; ++gq) {
@@ -927,6 +959,19 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
           // (a group without a passing lane skips its compares: at the later levels a sub-tile that has a candidate at
           // all usually has it in one group only)
           unsigned km[NG];
+          if constexpr (FOLD) {  // the groups' own maxima, only now; scored entries carry I itself: + T
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) {
+              mi[gq] = as_bits(a[0][gq][0]);
+#pragma unroll
+              for (int r = 1; r < 4; ++r) mi[gq] = max(mi[gq], as_bits(a[0][gq][r]));
+#pragma unroll
+              for (int r = 0; r < 4; ++r) mi[gq] = max(mi[gq], as_bits(a[1][gq][r]));
+              km[gq] = 0;
+              if (__any(mi[gq] >= 0)) km[gq] = pass_mask(a, gq, 0);
+              mi[gq] += thr_i[gq];
+            }
+          } else
 #pragma unroll
           for (int gq = 0; gq < NG; ++gq) {
             km[gq] = 0;
@@ -994,6 +1039,9 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
     if constexpr (r_ == 0) {                                                                               \
       if constexpr (PIPE) {                                                                                \
         _Pragma("unroll") for (int gq = 0; gq < NG; ++gq) accp[set_][0][gq] = accp[set_][1][gq] = acc_t{0, 0, 0, 0}; \
+      } else if constexpr (FOLD) {                                                                         \
+        _Pragma("unroll") for (int gq = 0; gq < NG; ++gq)                                                  \
+          acc[0][gq] = acc[1][gq] = __builtin_bit_cast(acc_t, ntq[gq]);                                    \
       } else {                                                                                             \
         _Pragma("unroll") for (int gq = 0; gq < NG; ++gq) acc[0][gq] = acc[1][gq] = acc_t{0, 0, 0, 0};     \
       }                                                                                                    \
