@@ -176,34 +176,65 @@ __global__ void __launch_bounds__(256) i8_granule_absmax_kernel(const float* __r
 // (uniform rounding errors of a row quantised on the grid x / 127; lambda = 60: the bench bank's candidates triple when eps
 // grows from the bf16 bound's 0.004 to the single scale's 0.0215).  Whatever comes out is only a matter of speed: every
 // class's error is MEASURED by the quantising kernel and the bounds use the measurements.  lambda <= 0: cut = the maximum.
-constexpr int I8_CUT_BINS = 1 << 14;
+constexpr int I8_CUT_BINS = 1 << 13;   // (unit rows: |k_i| <= 1 = bin 8128; anything larger shares the last bin, which is never a cut)
 __global__ void __launch_bounds__(1024) i8_cut_kernel(const float* __restrict__ gmax, int64_t granules, int D, float lambda,
                                                       unsigned* __restrict__ tail8) {
   __shared__ int hist[I8_CUT_BINS];
-  for (int i = threadIdx.x; i < I8_CUT_BINS; i += 1024) hist[i] = 0;
+  __shared__ int tsum[1024];
+  __shared__ float tcost[1024];
+  __shared__ int tbin[1024];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < I8_CUT_BINS; i += 1024) hist[i] = 0;
   __syncthreads();
-  for (int64_t i = threadIdx.x; i < granules; i += 1024) atomicAdd(hist + (__float_as_uint(gmax[i]) >> 17), 1);
+  for (int64_t i = tid; i < granules; i += 1024) atomicAdd(hist + min((int)(__float_as_uint(gmax[i]) >> 17), I8_CUT_BINS - 1), 1);
   __syncthreads();
-  if (threadIdx.x != 0) return;
+  // thread t owns bins 16 t .. 16 t + 15: their sum, an exclusive prefix over the threads, then the cost of every occupied bin's
+  // upper edge as the cut; the cheapest (ties: the lowest) wins
+  constexpr int PER = I8_CUT_BINS / 1024;
+  int mine = 0;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) mine += hist[tid * PER + e];
+  tsum[tid] = mine;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // (Hillis-Steele inclusive scan)
+    const int v = tid >= off ? tsum[tid - off] : 0;
+    __syncthreads();
+    tsum[tid] += v;
+    __syncthreads();
+  }
   const float xmax = __uint_as_float(tail8[2]);
-  float cut = xmax;
+  const int top = min((int)(__float_as_uint(xmax) >> 17), I8_CUT_BINS - 1);
+  const float c = lambda * sqrtf((float)D / 12.f) / 127.f;
+  const float fmax_ = expf(c * xmax);
+  float best = __builtin_huge_valf();
+  int best_bin = -1;
   if (lambda > 0.f && xmax > 0.f) {
-    const float c = lambda * sqrtf((float)D / 12.f) / 127.f;
-    const float fmax_ = expf(c * xmax);
-    const int top = (int)(__float_as_uint(xmax) >> 17);
-    float best = (float)granules * fmax_;
-    int64_t below = 0;
-    for (int e = 0; e < top; ++e) {
+    int64_t below = tsum[tid] - mine;
+    for (int e = tid * PER; e < tid * PER + PER && e < top; ++e) {
       if (hist[e] == 0) continue;
       below += hist[e];
       const float edge = __uint_as_float((unsigned)(e + 1) << 17);   // every maximum of bins <= e lies below it
       const float cost = (float)below * expf(c * edge) + (float)(granules - below) * fmax_;
       if (cost < best) {
         best = cost;
-        cut = edge;
+        best_bin = e;
       }
     }
   }
+  tcost[tid] = best;
+  tbin[tid] = best_bin;
+  __syncthreads();
+  for (int off = 512; off >= 1; off >>= 1) {
+    if (tid < off && (tcost[tid + off] < tcost[tid] || (tcost[tid + off] == tcost[tid] && tbin[tid + off] >= 0 &&
+                                                         (tbin[tid] < 0 || tbin[tid + off] < tbin[tid])))) {
+      tcost[tid] = tcost[tid + off];
+      tbin[tid] = tbin[tid + off];
+    }
+    __syncthreads();
+  }
+  if (tid != 0) return;
+  float cut = xmax;   // (one class: no occupied bin below the top one, lambda <= 0, a zero bank -- or no cut beats it)
+  if (tbin[0] >= 0 && tcost[0] < (float)granules * fmax_) cut = __uint_as_float((unsigned)(tbin[0] + 1) << 17);
   tail8[5] = __float_as_uint(cut);
   tail8[1] = __float_as_uint(cut / 127.f);
   tail8[4] = __float_as_uint(xmax / 127.f);
