@@ -48,6 +48,24 @@ def test_pure_host_entry_points_work_without_gpu():
     assert rc == N.EINVAL and b"null" in L.ragraph_last_error()
 
 
+def test_bank_copy_buffer_holds_the_int8_granule_table():
+    """ragraph_keys_bf16_rows(N) does not know D, yet the buffer it sizes (rows of 2 D bytes) must hold, behind the int8 rows and
+    their tail row, the granules' maxima (floats, padded to 16 bytes), one class bit per granule (whole words) and still the
+    16 KB the last int8 stage of a D = 64 level may read past the rows (csrc/filter_common.h: FilterI8View)."""
+    from ragraph_amd import _native as N
+
+    L = N.lib()
+    for n in (1, 2, 255, 256, 257, 511, 513, 4096, 65535, 65537, 1_000_000, 4_000_003, 100_000_000, 2_000_000_000):
+        rows = L.ragraph_keys_bf16_rows(n)
+        npad = -(-n // 256) * 256
+        for D in (64, 128, 256):
+            gk = 32768 // D
+            granules = -(-npad // gk)
+            table = -(-granules * 4 // 16) * 16 + -(-granules // 32) * 4 + 16
+            used = (npad + 1 + npad // 2 + 1) * 2 * D + table
+            assert rows * 2 * D >= used + 16384, (n, D, rows)
+
+
 def test_filtered_topk_plan_is_well_formed():
     """Schedule of the bf16-filtered exact top-k (host arithmetic, include/ragraph_hip.h): for every shape the levels
     partition [0, N) in increasing multiples of 256 that start behind the exact sample, a level's expected candidates
