@@ -519,9 +519,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
     if (lane == 0) raise_theta(q, theta);
   };
   if (p.use_prior) {  // a speculative first bound: every query starts from it, nothing to wait for
-    if (lane == 0)
-      for (int c = 0; c < 4; ++c)
-        if (wave + 8 * c < B) raise_theta(wave + 8 * c, p.prior);
+    if (lane < 4 && wave + 8 * lane < B) raise_theta(wave + 8 * lane, p.prior);   // (a wave's queries: wave, wave + 8, ...)
   } else {  // a wave's queries: wave, wave + 8, ... -- all their part maxima are requested in one batch, again until none is missing
      // or the time limit has passed (workgroups of another process may hold the CUs some of ours still need)
     unsigned up[4];
@@ -1056,10 +1054,14 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   __syncthreads();
   RG_SSTAMP(11);
   // overflowed queries: the exact scan (four waves stage rows through 64-row tiles; the others wait at the barriers)
-  int n_over = 0;
-  for (int q = 0; q < B; ++q) {
-    if (!(qcnt[q] >> 30)) continue;  // (block-uniform)
-    ++n_over;
+  // (which queries: one ballot per wave over the queries' counters -- block-uniform, every wave reads the same words -- instead of
+  // a serial walk with an LDS round trip per query: 1 us of every sixteen-query call)
+  unsigned over_mask = (unsigned)__ballot(lane < B && (qcnt[lane < 32 ? lane : 0] >> 30) != 0);
+  over_mask = (unsigned)__builtin_amdgcn_readfirstlane((int)over_mask);
+  const int n_over = __popc(over_mask);
+  while (over_mask) {
+    const int q = __ffs(over_mask) - 1;
+    over_mask &= over_mask - 1;
     const float4* qs = reinterpret_cast<const float4*>(qn + q * QLD);
     float (*tile4)[64 * RESCORE_LD] = reinterpret_cast<float (*)[64 * RESCORE_LD]>(smem + L::scan_tile);
     float (*ps4)[32] = reinterpret_cast<float (*)[32]>(ps);
@@ -1123,34 +1125,38 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   // the others are listed, in query order, for the fixup launch behind this one.  (Zero queries were answered in place;
   // a query the scan above answered is exact whatever it scores.)
   __syncthreads();
-  if (tid == 0) {
-    int lo = INT_MAX, hi = INT_MIN, n_miss = 0;
-    for (int q = 0; q < B; ++q) {
-      if (sc_flag[q]) continue;
-      const float kth = kth_lds[q];
-      const bool scanned = (qcnt[q] >> 30) != 0;
-      if (p.use_prior && !scanned && !(kth >= p.prior)) {
-        p.miss_list[n_miss++] = q;
-        continue;
-      }
-      if (kth > RG_NEG_INF) {
-        lo = min(lo, f2ord(kth));
-        hi = max(hi, f2ord(kth));
-      }
+  if (wave == 0) {  // lane q judges query q; the wave combines (misses in query order by ballot + prefix count)
+    const int q = lane < 32 ? lane : 0;
+    const bool live = lane < B && !sc_flag[q];
+    const float kth = kth_lds[q];
+    const bool scanned = (qcnt[q] >> 30) != 0;
+    const bool miss = live && p.use_prior && !scanned && !(kth >= p.prior);
+    const unsigned long long mm = __ballot(miss);
+    const int n_miss = __popcll(mm);
+    if (miss) p.miss_list[(int)__builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u))] = q;
+    const bool counts = live && !miss && kth > RG_NEG_INF;
+    int lo = counts ? f2ord(kth) : INT_MAX, hi = counts ? f2ord(kth) : INT_MIN;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) {
+      lo = min(lo, __shfl_xor(lo, off));
+      hi = max(hi, __shfl_xor(hi, off));
     }
-    if (p.miss_count) *p.miss_count = n_miss;
-    if (p.stats) {
-      for (int i = 0; i < 32; ++i) p.stats[i] = 0;
-      p.stats[0] = 0x52414753;
-      p.stats[1] = 1;
-      p.stats[14] = B;
-      p.stats[16] = p.use_prior;
-      p.stats[17] = n_miss;
-      p.stats[18] = lo;
-      p.stats[19] = hi;
-      p.stats[20] = n_over + n_miss;
+    if (p.stats && lane < 32) {
+      int v = 0;
+      if (lane == 0) v = 0x52414753;
+      else if (lane == 1) v = 1;
+      else if (lane == 14) v = B;
+      else if (lane == 16) v = p.use_prior;
+      else if (lane == 17) v = n_miss;
+      else if (lane == 18) v = lo;
+      else if (lane == 19) v = hi;
+      else if (lane == 20) v = n_over + n_miss;
+      p.stats[lane] = v;
     }
-    *p.overflow = n_over + n_miss;
+    if (lane == 0) {
+      if (p.miss_count) *p.miss_count = n_miss;
+      *p.overflow = n_over + n_miss;
+    }
   }
   if (p.fix_done && tid < B) p.fix_done[tid] = 0;
   // leave the state zeroed for the next call (every other workgroup has finished: the ticket said so)
