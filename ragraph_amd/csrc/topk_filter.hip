@@ -540,6 +540,9 @@ __device__ unsigned long long g_filter_timing[8];
 // PIPE (int8 levels at D = 256): the epilogue of sub-tile u runs INSIDE the MFMA stream of sub-tile u + 1 -- two sets of
 // accumulators, the maxima of one query group after each of the next sub-tile's first steps, the candidate path behind them --
 // so a wave's vector work sits beside its OWN matrix work instead of waiting for the SIMD partner to be in the other phase.
+#ifndef RG_RING_FOLD   // (-DRG_RING_FOLD=0: the D = 64 int8 levels without the folded thresholds -- A/B builds)
+#define RG_RING_FOLD 1
+#endif
 template <int D, int QW, bool BOUND = false, bool I8 = false, bool SCORED = false, bool PIPE = false>
 __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
   using C = FilterCfg<I8 ? D / 2 : D>;
@@ -552,9 +555,6 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
   // FOLD (int8 levels without the pipelined epilogue): a sub-tile's accumulators start at -T instead of 0 -- the MFMA adds
   // its integer sums to them exactly -- so "does any score reach its query's threshold" is ONE sign test over the maxima of all
   // groups instead of a compare per group: a third fewer vector instructions on the path every sub-tile takes.
-#ifndef RG_RING_FOLD
-#define RG_RING_FOLD 1
-#endif
   // The start values are the MFMAs' C operands straight from registers (a quad of -T per group, rebuilt when the stage's
   // class changes): four more registers per group and no instruction -- so only where it pays: D = 64, whose sub-tiles are
   // two MFMAs per group against the same epilogue (4096 x 4M x 64: 0.935 -> 0.913 ms, 65 536: 13.99 -> 13.86; at D = 128 the
