@@ -183,6 +183,8 @@ __device__ unsigned long long g_small_t[2][16];
 #define RG_SSTAMP(i_)
 #endif
 
+#define RG_LIKELY(x) __builtin_expect(!!(x), 1)
+#define RG_UNLIKELY(x) __builtin_expect(!!(x), 0)
 template <int D, bool I8>
 __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
 #ifdef RG_SMALL_TIMING
@@ -338,7 +340,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   // parts non-zero has the final maxima in the same round trip.  (The first version published by atomicMax, announced
   // itself on a counter after waiting for its atomics, and read the maxima after the counter filled: five agent-scope
   // round trips of 2 - 3 us each between a workgroup's bound unit and its thresholds; now two.) ------------------------
-  if (with_bound) {
+  if (RG_UNLIKELY(with_bound)) {   // (the steady state of a bank runs under its prior: cold blocks are laid out behind the hot path)
     float* wmax = tile_all;                                       // [8][32] the wave's maxima over its units
     if (lane < 32) wmax[wave * 32 + lane] = RG_NEG_INF;
     for (int64_t u = u_first; u < p.bound_units; u += (int64_t)G_b * 8) {
@@ -518,7 +520,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
     const float theta = kth ? __shfl(v, __ffsll((long long)kth) - 1) : RG_NEG_INF;
     if (lane == 0) raise_theta(q, theta);
   };
-  if (p.use_prior) {  // a speculative first bound: every query starts from it, nothing to wait for
+  if (RG_LIKELY(p.use_prior)) {  // a speculative first bound: every query starts from it, nothing to wait for
     if (lane < 4 && wave + 8 * lane < B) raise_theta(wave + 8 * lane, p.prior);   // (a wave's queries: wave, wave + 8, ...)
   } else {  // a wave's queries: wave, wave + 8, ... -- all their part maxima are requested in one batch, again until none is missing
      // or the time limit has passed (workgroups of another process may hold the CUs some of ours still need)
@@ -846,13 +848,14 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) np += __shfl_xor(np, off);
     const bool flooding = np > SMALL_WG_LIST / 8;   // (wave-uniform)
-    if (flooding) {
+    if (RG_UNLIKELY(flooding)) {
       if (lane == 0) atomicMax(misc + 4, (wcnt + 7) / 8);
     } else {
       for (int i0 = 0; i0 < wcnt; i0 += 64) score_entries(i0, i0 + 64 < wcnt ? i0 + 64 : wcnt);
     }
     __syncthreads();
     const int nrounds = misc[4];   // (block-uniform; 0: nobody floods)
+    if (RG_UNLIKELY(nrounds > 0))
     for (int rd = 0; rd < nrounds; ++rd) {
       const int n = misc[0] < SMALL_WG_LIST ? misc[0] : SMALL_WG_LIST;
       if (n >= SMALL_PRUNE_MIN) {   // (block-uniform)
@@ -901,7 +904,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   RG_SSTAMP(7);
   {  // one reservation per query for the workgroup's pairs
     const int n = misc[0] < SMALL_WG_LIST ? misc[0] : SMALL_WG_LIST;
-    if (n >= SMALL_PRUNE_MIN) {  // (block-uniform) many pairs: only this workgroup's k best of a query can be among the winners
+    if (RG_UNLIKELY(n >= SMALL_PRUNE_MIN)) {  // (block-uniform) many pairs: only this workgroup's k best of a query can be among the winners
       prune_list(n);
       __syncthreads();
     }
@@ -1059,7 +1062,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   unsigned over_mask = (unsigned)__ballot(lane < B && (qcnt[lane < 32 ? lane : 0] >> 30) != 0);
   over_mask = (unsigned)__builtin_amdgcn_readfirstlane((int)over_mask);
   const int n_over = __popc(over_mask);
-  while (over_mask) {
+  while (RG_UNLIKELY(over_mask != 0u)) {
     const int q = __ffs(over_mask) - 1;
     over_mask &= over_mask - 1;
     const float4* qs = reinterpret_cast<const float4*>(qn + q * QLD);
