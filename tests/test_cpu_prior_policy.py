@@ -94,3 +94,38 @@ def test_loose_priors_and_overflowing_lists_withdraw_it_too():
     idx = index()
     assert idx._judge_prior(10, 512, words(0, 0, 0.25, 0.28), 30) == 30      # ... with a bound pass: the lists' own
     assert idx._spec[10]["hist"] == []                                       # and such a call is no ground for a prior
+
+
+def test_int8_gate_judges_the_normal_granules_of_a_two_scale_copy():
+    """KeyIndex._cap_i8 on synthetic class records (kernels.int8_copy_classes): the NORMAL granules' measured error decides;
+    a few heavy granules with a useless bound do not matter, a bank that is heavy throughout leaves int8, and the per-thread cap
+    is what the call sees."""
+    class CapOps(Ops):
+        def __init__(self, rec):
+            super().__init__()
+            self.rec, self.caps = rec, []
+
+        def int8_copy_classes(self, kb, n):
+            return dict(self.rec)
+
+        def set_max_i8_levels(self, n):
+            self.caps.append(n)
+            return -1
+
+    def gate(rec):
+        idx = KeyIndex(torch.zeros(4, 64), ops=CapOps(rec), dedup=False)
+        idx._bf16 = torch.zeros(1, 64, dtype=torch.int16)
+        cap, allowed = idx._cap_i8()
+        return allowed, idx.ops.caps[-1], idx
+
+    base = {"err": 0.0116, "scale": 0.0022, "max_abs": 0.35, "err_heavy": 0.0141, "scale_heavy": 0.0028, "cut": 0.28,
+            "heavy_granules": 218, "granules": 1564}
+    assert gate(base)[:2] == (True, -1)                                              # a Gaussian bank
+    one_hot = dict(base, max_abs=1.0, err_heavy=0.040, scale_heavy=1 / 127, heavy_granules=11)
+    allowed, cap, idx = gate(one_hot)
+    assert (allowed, cap) == (True, -1) and idx.i8_classes["heavy_granules"] == 11   # a one-hot row costs its granules only
+    assert gate(dict(one_hot, heavy_granules=400))[:2] == (False, 0)                 # heavy throughout: > 1/4 of the granules
+    assert gate(dict(base, err=0.03))[:2] == (False, 0)                              # ordinary rows too coarse: as before
+    allowed, cap, idx = gate(base)
+    idx._i8_off = True                                                               # demoted by its calls: the cap follows
+    assert idx._cap_i8()[1] is False and idx.ops.caps[-1] == 0
