@@ -24,10 +24,14 @@
 //      fetched cooperatively, 16 at a time), the workgroup reserves list space with ONE atomic per query and stores the
 //      exact (score, key) pairs.  There are no candidate lists of approximate hits, hence no sub-lists and no list
 //      overflow from the approximate filter; a query whose exact-pair list passes SMALL_LIST_CAP (a bank of near-
-//      duplicates) stops passing keys and is answered by an exact scan (5 below).
+//      duplicates) stops passing keys and is answered by an exact scan (6 below).
 //   5. the LAST workgroup to finish (a ticket) selects every query's canonical top-k from its pair list (a lane-maxima bound
-//      prunes the list to <= 128 pairs, ranks by counting), answers zero queries (scores +0, rows in order) and
-//      overflowed ones (exact scan by four waves), and leaves the state buffer zeroed for the next call.
+//      prunes the list to <= 128 pairs, ranks by counting), answers zero queries (scores +0, rows in order), LISTS the
+//      overflowed ones and -- under a speculative first bound -- the queries the bound was too high for, writes the call's
+//      statistics words, and leaves the state buffer zeroed for the next call.
+//   6. behind the kernel, every call: topk_overflow_fixup_kernel (topk_filter.hip) -- exact scans of the listed queries, cut
+//      into key slices over the whole chip; the list is empty as a rule and the launch returns at once.  (Until late in
+//      round 5 the last workgroup scanned overflowed queries itself: 25 ms a query.)
 //
 // The result has the bits of ragraph_topk_cosine_f32: every output score is the fp32 chain, the selection the canonical
 // one; the approximate phases only decide which keys are scored.
@@ -40,7 +44,7 @@ constexpr int SMALL_MAX_B = 32;
 // exact (score, key) pairs per query in the workspace.  A workgroup contributes at most its own k best per query from its
 // LDS list (pruned before the reservation) plus what a flood appended directly while its bound was still rising -- 256
 // workgroups x 32 + slack; beyond the cap (every workgroup moving on without a bound AND passing its whole share, for
-// several queries) the query is answered by the exact scan, as before.
+// several queries) the query is answered by the exact scan of the fixup launch.
 #ifndef RG_SMALL_LIST_CAP
 #define RG_SMALL_LIST_CAP 16384
 #endif
@@ -114,12 +118,7 @@ struct SmallLds {
   static constexpr size_t wg_q = wg_k + (size_t)SMALL_WG_LIST * 4;
   static constexpr size_t small = wg_q + (size_t)SMALL_WG_LIST * 4;   // per-query scalars
   static constexpr size_t bytes_stream = small + 32 * 4 * 12;
-  // the last workgroup's exact scan: four 64-row tiles + partial lists, over everything but the query rows
-  static constexpr size_t scan_tile = wbuf;
-  static constexpr size_t scan_ps = scan_tile + (size_t)4 * 64 * RESCORE_LD * 4;
-  static constexpr size_t scan_pi = scan_ps + 4 * 32 * 4;
-  static constexpr size_t bytes_scan = scan_pi + 4 * 32 * 8;
-  static constexpr size_t bytes = bytes_stream > bytes_scan ? bytes_stream : bytes_scan;
+  static constexpr size_t bytes = bytes_stream;
 };
 
 // canonical 64-bit key of a pair (rescore_common.h: wave_select's order)
@@ -940,8 +939,6 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   __syncthreads();
   if (!misc[2]) return;
   RG_SSTAMP(10);
-  float* ps = reinterpret_cast<float*>(smem + L::scan_ps);      // [4][32] (also: a wave's staging row for wave_select)
-  int64_t* pi = reinterpret_cast<int64_t*>(smem + L::scan_pi);  // [4][32]
   // per-wave staging for the selection (the stream's buffers are free now): 512 canonical keys + winners
   unsigned long long* surv = reinterpret_cast<unsigned long long*>(pair_all + wave * SMALL_PAIRBUF);
   // a wave's queries: wave, wave + 8, ...; their counts and first 256 pairs are requested before the first is used
@@ -1056,77 +1053,14 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   }
   __syncthreads();
   RG_SSTAMP(11);
-  // overflowed queries: the exact scan (four waves stage rows through 64-row tiles; the others wait at the barriers)
-  // (which queries: one ballot per wave over the queries' counters -- block-uniform, every wave reads the same words -- instead of
-  // a serial walk with an LDS round trip per query: 1 us of every sixteen-query call)
-  unsigned over_mask = (unsigned)__ballot(lane < B && (qcnt[lane < 32 ? lane : 0] >> 30) != 0);
-  over_mask = (unsigned)__builtin_amdgcn_readfirstlane((int)over_mask);
-  const int n_over = __popc(over_mask);
-  while (RG_UNLIKELY(over_mask != 0u)) {
-    const int q = __ffs(over_mask) - 1;
-    over_mask &= over_mask - 1;
-    const float4* qs = reinterpret_cast<const float4*>(qn + q * QLD);
-    float (*tile4)[64 * RESCORE_LD] = reinterpret_cast<float (*)[64 * RESCORE_LD]>(smem + L::scan_tile);
-    float (*ps4)[32] = reinterpret_cast<float (*)[32]>(ps);
-    int64_t (*pi4)[32] = reinterpret_cast<int64_t (*)[32]>(pi);
-    const int w = wave;
-    float es = RG_NEG_INF;
-    int ei = INT_MAX;
-    if (w < 4) {
-      float kth_s = RG_NEG_INF;
-      int kth_i = INT_MAX;
-      for (int64_t base = (int64_t)w * 64; base < p.N; base += 256) {
-        const int key = base + lane < p.N ? (int)(base + lane) : -1;
-        const float sc = coop_scores<D>(qs, p.Kn, key, lane, tile4[w]);
-        unsigned long long pend = __ballot(key >= 0 && cand_better(sc, key, kth_s, kth_i));
-        while (pend) {
-          const int src = __ffsll((long long)pend) - 1;
-          pend &= pend - 1;
-          const float s = __shfl(sc, src);
-          const int id = __shfl(key, src);
-          const unsigned long long ahead = __ballot(lane < k && cand_better(es, ei, s, id));
-          const int pos = __popcll(ahead);
-          const float us = __shfl_up(es, 1);
-          const int ui = __shfl_up(ei, 1);
-          if (pos < k) {
-            if (lane == pos) {
-              es = s;
-              ei = id;
-            } else if (lane > pos && lane < k) {
-              es = us;
-              ei = ui;
-            }
-          }
-          kth_s = __shfl(es, k - 1);
-          kth_i = __shfl(ei, k - 1);
-          pend &= __ballot(key >= 0 && cand_better(sc, key, kth_s, kth_i));
-        }
-      }
-      if (lane < 32) {
-        ps4[w][lane] = lane < k ? es : RG_NEG_INF;
-        pi4[w][lane] = (lane < k && ei != INT_MAX) ? (int64_t)ei : INT64_MAX;
-      }
-    }
-    __syncthreads();
-    if (w == 0) {  // 4 k <= 128 partial winners: two per lane
-      float s2[2];
-      int id2[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int e = lane + 64 * u;
-        const bool have = e < 4 * k;
-        s2[u] = have ? ps4[e / k][e % k] : RG_NEG_INF;
-        const int64_t pv = have ? pi4[e / k][e % k] : INT64_MAX;
-        id2[u] = pv >= INT_MAX ? INT_MAX : (int)pv;
-      }
-      wave_select<2>(s2, id2, k, lane, p.idx_base, p.out_s + (int64_t)q * k, p.out_i + (int64_t)q * k, kth_lds + q);
-    }
-    __syncthreads();
-  }
+  // overflowed queries (a list beyond its cap: floods of several queries at once -- rare): which ones, by one ballot per wave over
+  // the queries' counters (block-uniform).  They are LISTED with the prior's misses for the sliced exact scan of the fixup
+  // launch behind this kernel (<= 2 ms a query; until round 5 this workgroup scanned the bank itself: 25 ms a query).
+  const int n_over = __popc((unsigned)__ballot(lane < B && (qcnt[lane < 32 ? lane : 0] >> 30) != 0));
   // the call's statistics words and -- under a prior -- the proof: a query's answer is exact iff its k-th best pair scores at
   // least the prior (every key scoring at least that passed the filter: csrc/topk_filter.hip, filter_verify_prior_kernel);
   // the others are listed, in query order, for the fixup launch behind this one.  (Zero queries were answered in place;
-  // a query the scan above answered is exact whatever it scores.)
+  // a query whose list overflowed is listed whatever it scores.)
   __syncthreads();
   if (wave == 0) {  // lane q judges query q; the wave combines (misses in query order by ballot + prefix count)
     const int q = lane < 32 ? lane : 0;
@@ -1134,10 +1068,11 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
     const float kth = kth_lds[q];
     const bool scanned = (qcnt[q] >> 30) != 0;
     const bool miss = live && p.use_prior && !scanned && !(kth >= p.prior);
-    const unsigned long long mm = __ballot(miss);
-    const int n_miss = __popcll(mm);
-    if (miss) p.miss_list[(int)__builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u))] = q;
-    const bool counts = live && !miss && kth > RG_NEG_INF;
+    const bool listed = miss || (live && scanned);   // (a list beyond its cap: also the fixup launch's)
+    const unsigned long long mm = __ballot(listed);
+    const int n_miss = __popcll(__ballot(miss)), n_listed = __popcll(mm);
+    if (listed) p.miss_list[(int)__builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u))] = q;
+    const bool counts = live && !listed && kth > RG_NEG_INF;
     int lo = counts ? f2ord(kth) : INT_MAX, hi = counts ? f2ord(kth) : INT_MIN;
 #pragma unroll
     for (int off = 16; off >= 1; off >>= 1) {
@@ -1157,7 +1092,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
       p.stats[lane] = v;
     }
     if (lane == 0) {
-      if (p.miss_count) *p.miss_count = n_miss;
+      if (p.miss_count) *p.miss_count = n_listed;
       *p.overflow = n_over + n_miss;
     }
   }
@@ -1304,7 +1239,7 @@ extern "C" int ragraph_topk_cosine_small_f32(const float* Q, int64_t B, const fl
   char* wb = static_cast<char*>(ws);
   p.use_prior = spec ? 1 : 0;
   p.prior = spec ? prior : 0.f;
-  p.qn_out = spec ? reinterpret_cast<float*>(wb + wsl.qn) : nullptr;
+  p.qn_out = reinterpret_cast<float*>(wb + wsl.qn);   // (the normalised rows, for the fixup launch's scans)
   p.miss_count = reinterpret_cast<int*>(wb + wsl.miss);
   p.miss_list = p.miss_count + 1;
   p.fix_done = reinterpret_cast<int*>(wb + wsl.done);
@@ -1333,8 +1268,9 @@ extern "C" int ragraph_topk_cosine_small_f32(const float* Q, int64_t B, const fl
   if (D == 256) rc = i8 ? launch_small<256, true>(p, (int)grid, st) : launch_small<256, false>(p, (int)grid, st);
   else if (D == 128) rc = i8 ? launch_small<128, true>(p, (int)grid, st) : launch_small<128, false>(p, (int)grid, st);
   else rc = launch_small<64, false>(p, (int)grid, st);
-  if (rc != RAGRAPH_OK || !spec) return rc;
-  // the queries the prior was too high for (none, as a rule: the launch returns at once): exact scans in key slices
+  if (rc != RAGRAPH_OK) return rc;
+  // the queries the prior was too high for and those whose lists overflowed (none, as a rule: the launch returns at once):
+  // exact scans in key slices
   return launch_overflow_fixup(D, p.qn_out, Kn, N, k, idx_base, p.miss_count, p.miss_list, out_scores, out_idx, p.fix_done,
                                reinterpret_cast<float*>(wb + wsl.part_s), reinterpret_cast<int64_t*>(wb + wsl.part_i), B, stream);
 }
