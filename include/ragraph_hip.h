@@ -230,8 +230,10 @@ int ragraph_topk_cosine_filtered_sharded_f32(const float* Q, int64_t B, const fl
  * workgroups' shares (no grid barrier: the k-th largest of whatever maxima are published is a valid bound), streams its
  * share of the int8 copy (bf16 when ragraph_topk_cosine_filtered_max_i8_levels(0) is in force for the thread, or D = 64),
  * scores its own candidates exactly (fp32 chains) and appends the exact pairs to per-query lists; the last workgroup to
- * finish (a ticket) selects every query's canonical top-k, answers zero queries and -- for a query whose list of exact pairs
- * passes its capacity (near-duplicate banks) -- runs the exact scan.  ragraph_amd/csrc/topk_small.hip.
+ * finish (a ticket) selects every query's canonical top-k, answers zero queries and LISTS the queries whose list of exact
+ * pairs passed its capacity (near-duplicate banks) and, under a speculative first bound, those the bound was too high for; a
+ * second launch behind it (every call; empty as a rule) answers the listed queries by exact scans cut into key slices.
+ * ragraph_amd/csrc/topk_small.hip.
  *   Q [B,D] raw queries, 1 <= B <= 32; Kn [N,D] unit rows, N >= 65536; Kb = ragraph_keys_to_bf16(Kn); D in {64,128,256}; k <= 32
  *   (ragraph_topk_cosine_small_ok).  overflow: device int, set to the number of queries answered by the exact scan.
  *   state: ragraph_topk_cosine_small_state_bytes() bytes, ZERO before the first call; every call leaves them zero (one
