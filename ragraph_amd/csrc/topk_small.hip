@@ -76,6 +76,7 @@ struct SmallParams {
   int64_t nunits;          // filter pass: units of the copy it streams
   unsigned wait_ticks;     // 10 ns ticks a workgroup waits for the others' bound units at most
   int* state;
+  int list_cap;            // pairs a query's list may hold: SMALL_LIST_CAP (RAGRAPH_SMALL_LIST_CAP: fewer -- the tests' way to an overflow)
   float* list_s;           // [B][SMALL_LIST_CAP] exact scores ...
   int* list_k;             // ... and keys
   float* out_s;
@@ -583,7 +584,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
   };
   auto append_global = [&](int q, int key, float s) {  // one atomic per pair: only where a workgroup's LDS list is full
     const int pos = atomicAdd(cnt_g + 32 * q, 1);
-    if (pos < SMALL_LIST_CAP) {
+    if (pos < p.list_cap) {
       __hip_atomic_store(p.list_s + (int64_t)q * SMALL_LIST_CAP + pos, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(p.list_k + (int64_t)q * SMALL_LIST_CAP + pos, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
@@ -922,7 +923,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
       if (i < n && wg_q[i] >= 0) {
         const int q = wg_q[i];
         const int pos = qbase[q] + r[c];
-        if (pos < SMALL_LIST_CAP) {  // (agent-scope stores: written through, visible to the last workgroup without a fence)
+        if (pos < p.list_cap) {  // (agent-scope stores: written through, visible to the last workgroup without a fence)
           __hip_atomic_store(p.list_s + (int64_t)q * SMALL_LIST_CAP + pos, wg_s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(p.list_k + (int64_t)q * SMALL_LIST_CAP + pos, wg_k[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -980,7 +981,7 @@ __global__ void __launch_bounds__(512, 2) topk_small_kernel(SmallParams p) {
       continue;
     }
     const int n = nq[c];
-    if (n > SMALL_LIST_CAP) {
+    if (n > p.list_cap) {
       if (lane == 0) atomicOr(qcnt + q, 1 << 30);  // (marks the query for the scan below; qcnt is free now)
       continue;
     }
@@ -1251,6 +1252,11 @@ extern "C" int ragraph_topk_cosine_small_f32(const float* Q, int64_t B, const fl
   p.state = state;
   p.list_s = reinterpret_cast<float*>(ws);   // (SmallWs::lists = 0)
   p.list_k = reinterpret_cast<int*>(p.list_s + (size_t)B * SMALL_LIST_CAP);
+  p.list_cap = SMALL_LIST_CAP;
+  if (const char* e = getenv("RAGRAPH_SMALL_LIST_CAP")) {   // (test hook, read per call: lists that overflow on an ordinary bank)
+    const int v = atoi(e);
+    if (v >= 1 && v < SMALL_LIST_CAP) p.list_cap = v;
+  }
   p.out_s = out_scores;
   p.out_i = out_idx;
   p.overflow = overflow;

@@ -161,3 +161,48 @@ def test_key_index_sends_a_handful_of_queries_to_the_single_launch(dev, monkeypa
         assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs)
     assert calls == [1, 1]                        # one query more: the multi-launch filtered call
     assert not K.small_helps(1, 60_000, 256, 10) and not K.small_helps(1, 200_000, 96, 10)
+
+
+@pytest.mark.parametrize("B", [1, 5, 16, 32])
+def test_overflowed_lists_take_the_sliced_scan_behind_the_kernel(dev, monkeypatch, B):
+    """A query whose list of exact pairs passes its cap is LISTED by the last workgroup and answered by the fixup launch that
+    follows every call (exact scans cut into key slices over the whole chip) -- until late in round 5 the last workgroup
+    scanned the bank itself, 25 ms a query.  RAGRAPH_SMALL_LIST_CAP=64 (read per call) makes lists overflow on an ordinary
+    bank: with the bound pass and under forced priors -- below every query's k-th best, among them (misses AND overflowed
+    lists in one call) -- the fp32 kernel's bits, *overflow == statistics word 20, and no scan-sized call."""
+    from ragraph_amd import kernels as K
+
+    g = torch.Generator(device=dev).manual_seed(9 + B)
+    N, D, k = 300_000, 256, 10
+    kn = K.normalize_rows(torch.randn(N, D, device=dev, generator=g))
+    kb = K.keys_to_bf16(kn)
+    q = torch.randn(B, D, device=dev, generator=g)
+    if B > 2:
+        q[1] = 0.0
+    s0, i0 = K.topk_cosine(q, kn, k)
+    kth = s0[:, k - 1]
+    lo = float(kth[kth > 0].min())
+    monkeypatch.setenv("RAGRAPH_SMALL_LIST_CAP", "64")
+    seen_over = 0
+    for prior in (None, lo - 0.15, lo - 0.02, lo + 0.01):
+        K.set_filter_prior(prior)
+        try:
+            s, i, over, st = K.topk_cosine_small(q, kn, kb, k, return_stats=True)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                K.topk_cosine_small(q, kn, kb, k)
+            e1.record()
+            torch.cuda.synchronize()
+        finally:
+            K.set_filter_prior(None)
+        w = st.cpu().tolist()
+        assert torch.equal(i, i0) and torch.equal(s, s0), prior
+        assert int(over) == w[20] and w[17] <= int(over)
+        assert e0.elapsed_time(e1) / 3 <= 4.0, (prior, e0.elapsed_time(e1) / 3)
+        seen_over += int(over)
+    assert seen_over > 0                      # the cap of 64 did make lists overflow
+    monkeypatch.delenv("RAGRAPH_SMALL_LIST_CAP")
+    s, i, over = K.topk_cosine_small(q, kn, kb, k)
+    assert torch.equal(i, i0) and torch.equal(s, s0) and int(over) == 0
