@@ -200,7 +200,8 @@ def test_overflowed_lists_take_the_sliced_scan_behind_the_kernel(dev, monkeypatc
         w = st.cpu().tolist()
         assert torch.equal(i, i0) and torch.equal(s, s0), prior
         assert int(over) == w[20] and w[17] <= int(over)
-        assert e0.elapsed_time(e1) / 3 <= 4.0, (prior, e0.elapsed_time(e1) / 3)
+        # (31 listed queries of 32 take 2.7 ms of sliced scans; the last workgroup's own scans took 50 - 95 ms for such calls)
+        assert e0.elapsed_time(e1) / 3 <= 10.0, (prior, e0.elapsed_time(e1) / 3)
         seen_over += int(over)
     assert seen_over > 0                      # the cap of 64 did make lists overflow
     monkeypatch.delenv("RAGRAPH_SMALL_LIST_CAP")
