@@ -18,7 +18,11 @@ layout (bank replicated, QUERY batch split, no data-path collective) is timed ri
 `query_sharded`; `--shard queries` makes it the headline instead.  `--backend gloo` runs the same job over gloo (device
 tensors staged through the host: two ranks on ONE GPU, tests/test_gpu_two_rank.py).
 
-After the timed region (outside it) the step's retrieval is CHECKED: a fixed sample of 64 of the queries is re-scored on
+The steps cycle `--batches` (8) DISTINCT feature tensors (seeds 4321, 4322, ...: same distribution) through warm-up and the
+timed region, so the filtered call's learnt first bound meets queries it has not seen; `first_bound` reports the prior each
+timed step ran under and the queries its verify launch had to scan (`repeated_batch`: round 5's one-batch replay, secondary).
+
+After the timed region (outside it) the LAST timed batch's retrieval is CHECKED: 1024 evenly spaced queries are re-scored on
 the exact fp32 kernel (same indices and score bits required) and 4 of them against the CPU oracle (`verified`).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` for the dominant kernel (the bf16 MFMA
@@ -52,7 +56,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: ~2.5 PF dense = 1024 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz
 INT8_MFMA_PEAK_TOPS = 5033.2    # same guide, Matrix cores: I8 "the cycles of the BF16 form at 2x the K, so 2x BF16 per clock"
 HBM_PEAK_GBS = 8000.0           # spec; ~6300 achievable
-TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", f"r{r}_pmc_traffic.json") for r in (5, 4)) if os.path.exists(p)),
+VERIFY_ROWS = 1024              # rows of the timed path re-scored on the exact fp32 kernel after the timed region
+TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", f"r{r}_pmc_traffic.json") for r in (6, 5, 4)) if os.path.exists(p)),
                     os.path.join(ROOT, "profiles", "r5_pmc_traffic.json"))
 
 
@@ -68,6 +73,9 @@ def parse():
     ap.add_argument("--dim", type=int, default=256)
     ap.add_argument("--classes", type=int, default=3)
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--batches", type=int, default=8,
+                    help="distinct query batches (feature tensors of different seeds, same distribution) cycled through the "
+                         "warm-up and the timed steps; 1 = round 5's repeated batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (profiling runs)")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` and `finetune_step` blocks (c1, c3, few-shot, c5)")
@@ -586,35 +594,41 @@ def verify_retrieval(model, feats, adj, args, world, with_oracle):
     with torch.no_grad():
         h = model.pretrain_model.inference(feats, adj)
         n = h.shape[0]
-        rows = torch.linspace(0, n - 1, 64, device=h.device).long()
+        R = min(VERIFY_ROWS, n)
+        rows = torch.linspace(0, n - 1, R, device=h.device).long()
         s_all, i_all = tgb.topk(h, k)                                  # the timed path, every query
         hs = h[rows].contiguous()
         sharded = hasattr(tgb, "idx_base") and getattr(tgb, "collective", False)
         if sharded:
             s32, i32 = K.topk_cosine(hs, tgb.keys_normalized, k, idx_base=tgb.idx_base)
             gw = tgb.world   # (the ranks that hold the shards: the whole job, or this rank's key group in the hybrid layout)
-            gs = torch.empty((gw * 64, k), dtype=s32.dtype, device=s32.device)
-            gi = torch.empty((gw * 64, k), dtype=i32.dtype, device=i32.device)
+            gs = torch.empty((gw * R, k), dtype=s32.dtype, device=s32.device)
+            gi = torch.empty((gw * R, k), dtype=i32.dtype, device=i32.device)
             all_gather_into(gs, s32.contiguous(), tgb.group)
             all_gather_into(gi, i32.contiguous(), tgb.group)
-            s32, i32 = K.topk_merge(gs.view(gw, 64, k), gi.view(gw, 64, k))
+            s32, i32 = K.topk_merge(gs.view(gw, R, k), gi.view(gw, R, k))
         else:
             s32, i32 = K.topk_cosine(hs, tgb.keys_normalized, k)
     ok_i, ok_s = torch.equal(i_all[rows], i32), torch.equal(s_all[rows], s32)
     if not (ok_i and ok_s):
         raise SystemExit(f"bench.py: the timed retrieval path differs from the exact fp32 kernel on the verification sample "
                          f"(indices equal: {ok_i}, scores equal: {ok_s})")
-    rec = {"rows": 64, "of_queries": n, "vs": ["fp32_kernel"], "identical": True,
-           "what": "top-k indices and score bits of the timed (bf16-filtered) retrieval, re-run on all queries after the "
-                   "timed region; 64 evenly spaced rows against ragraph_topk_cosine_f32"}
+    ix = getattr(tgb, "_index", None)
+    ix = getattr(ix, "search_index", ix)
+    rec = {"rows": R, "of_queries": n, "vs": ["fp32_kernel"], "identical": True,
+           "prior_in_force": getattr(ix, "last_prior", None) if ix is not None else None,
+           "what": "top-k indices and score bits of the timed (MFMA-filtered) retrieval, re-run on all queries of the LAST "
+                   f"timed batch after the timed region (same dispatch state: the learnt first bound stays in force); {R} "
+                   "evenly spaced rows against ragraph_topk_cosine_f32"}
     if with_oracle and not sharded:
         from oracle import cref
 
-        os_, oi = cref.topk_cosine(hs[:4].cpu().numpy(), tgb.keys_normalized.cpu().numpy(), k)
-        if not ((i_all[rows[:4]].cpu().numpy() == oi).all() and (s_all[rows[:4]].cpu().numpy() == os_).all()):
+        orows = rows[:: max(R // 4, 1)][:4]    # (4 rows spread over the batch: 1 M x 256 keys each on the host)
+        os_, oi = cref.topk_cosine(h[orows].cpu().numpy(), tgb.keys_normalized.cpu().numpy(), k)
+        if not ((i_all[orows].cpu().numpy() == oi).all() and (s_all[orows].cpu().numpy() == os_).all()):
             raise SystemExit("bench.py: the timed retrieval path differs from the CPU oracle on the verification sample")
         rec["vs"].append("oracle")
-        rec["oracle_rows"] = 4
+        rec["oracle_rows"] = int(orows.numel())
     return rec
 
 
@@ -698,11 +712,30 @@ def main():
     filter_ms = []
     level_ms = []   # per step: [(slot, ms, int8?, keys)] of the call's filter launches (slot 3 = the bound pass)
 
+    # Distinct batches: the speculative first bound of the filtered call is learnt from the statistics of EARLIER calls, so a
+    # repeated batch could never miss it.  `--batches` feature tensors (seeds 4321, 4322, ...; same distribution) are cycled
+    # through warm-up and timed steps; with more batches than warm-up steps the timed region meets batches no call has seen.
+    nb = max(1, args.batches)
+    feats_all = [feats] + [torch.randn(args.nodes, args.feat, device=dev, generator=torch.Generator(device=dev).manual_seed(4321 + b_))
+                           for b_ in range(1, nb)]
+    step_no = [0]
+    seen_in_warmup = set()
+    step_log = []   # per timed step: (batch, prior in force or None, clone of the call's statistics words or None)
+
     def step():
+        f = feats_all[step_no[0] % nb]
+        step_no[0] += 1
         with torch.no_grad():
-            return model(feats, adj)
+            return model(f, adj)
+
+    def _index_of(tgb_):
+        ix = getattr(tgb_, "_index", None)
+        return getattr(ix, "search_index", ix) if ix is not None else None
 
     def grab_filter_ms():
+        ix = _index_of(model.toy_graph_base)
+        st_ = filt_timer.last[3].clone() if isinstance(filt_timer.last, tuple) and len(filt_timer.last) == 4 else None
+        step_log.append(((step_no[0] - 1) % nb, getattr(ix, "last_prior", None) if ix is not None else None, st_))
         ms = L.ragraph_filter_profile_last_ms(prof)  # waits for this step's filter launches (they are the step's tail)
         if ms > 0:
             filter_ms.append(ms)
@@ -715,6 +748,7 @@ def main():
         time.sleep(10 ** 6)
     for w_ in range(args.warmup):
         beat(f"warm-up step {w_}")
+        seen_in_warmup.add(step_no[0] % nb)
         step()
         torch.cuda.synchronize()   # (untimed: the dispatch settles -- overflow counts and the speculative first bound's
                                    # statistics arrive behind an event and are read at the NEXT call)
@@ -744,7 +778,7 @@ def main():
     verified = None
     if args.emulate_rank_of <= 1 and not args.exact_fp32 and not args.no_extras:
         # (every rank: the sharded check has collectives; profiling runs -- --no-extras -- keep their kernel lists clean)
-        verified = verify_retrieval(model, feats, adj, args, world,
+        verified = verify_retrieval(model, feats_all[(step_no[0] - 1) % nb], adj, args, world,
                                     with_oracle=(rank == 0 and world == 1 and not args.no_cpu_baseline))
 
     n = args.nodes
@@ -765,8 +799,9 @@ def main():
     ms_step = elapsed / args.steps * 1e3
     flops = 2.0 * n_q_local * n_local * args.dim
     filtered = len(filt_timer.events) > 0
-    traffic_unit = ("GB per launch, HBM side = (2*FETCH_SIZE + WRITE_SIZE) from rocprofv3 --pmc (separate passes), "
-                    "profiles/" + os.path.basename(TRAFFIC_JSON))
+    traffic_unit = ("GB per launch, HBM side = (2*FETCH_SIZE + WRITE_SIZE): the COMMITTED rocprofv3 --pmc record for this "
+                    "shape (separate passes, profiles/" + os.path.basename(TRAFFIC_JSON) + "), looked up by shape key -- "
+                    "NOT sampled in this run (counters cannot be read in-process)")
     if filtered:
         # Dominant kernel = the filter kernel (ragraph::topk_filter_kernel), timed per launch by events the library records
         # around its launches on the launch stream.  A call launches it once per level -- the first on the bf16 copy
@@ -860,6 +895,23 @@ def main():
                    "parallelism": "single GPU" if G == 1 else par},
         "roofline": roofline,
     }
+    # the speculative first bound over the timed steps: which prior each step filtered under and how many of its queries the
+    # verify launch sent to the exact scan because their k-th best fell below it (statistics word 17; word 20 = every query
+    # answered by a scan, overflowed lists included).  (Read here, after the timed region: the words were cloned on the stream.)
+    timed_batches = sorted({b_ for b_, _, _ in step_log})
+    spec = {"distinct_batches": nb, "timed_batches": timed_batches,
+            "timed_batches_unseen_in_warmup": sorted(set(timed_batches) - seen_in_warmup)}
+    if step_log and any(st_ is not None for _, _, st_ in step_log):
+        words = [st_.cpu().tolist() if st_ is not None else None for _, _, st_ in step_log]
+        spec["prior_per_step"] = [None if pr_ is None else round(float(pr_), 5) for _, pr_, _ in step_log]
+        spec["speculative_steps"] = sum(1 for w_ in words if w_ is not None and w_[16] != 0)
+        spec["misses_per_step"] = [None if w_ is None else int(w_[17]) for w_ in words]
+        spec["scanned_queries_per_step"] = [None if w_ is None else int(w_[20]) for w_ in words]
+        if filt_timer.events:
+            calls = [a.elapsed_time(b) for a, b in filt_timer.events]
+            spec["retrieval_call_ms_min_max"] = [round(min(calls), 3), round(max(calls), 3)]
+    result["distinct_batches"] = nb
+    result["first_bound"] = spec
     if ranks_seen is not None:
         result["ranks_seen"] = ranks_seen
         result["collectives_per_step"] = collectives
@@ -908,6 +960,16 @@ def main():
         gnn = BB.gnn_fwd_block(model, feats, adj, reps=max(args.steps, 30),
                                cpu_gnn_s=cpu["phases_one_slab"]["gnn_all_nodes_s"] if cpu else None, cpu_cores=cores)
         gnn["structured_graph"] = BB.structured_graph_row(args.feat, args.dim, model.query_graph_hop, dev)
+        if nb > 1:   # round 5's figure: ONE batch replayed (the learnt first bound cannot miss by construction)
+            def step_same():
+                with torch.no_grad():
+                    return model(feats, adj)
+            for _ in range(2):
+                step_same()
+            e_rep, _ = timed_steps(step_same, min(args.steps, 10), 1, dev)
+            result["repeated_batch"] = {"ms_per_step": round(e_rep / min(args.steps, 10) * 1e3, 3), "steps": min(args.steps, 10),
+                                        "value": round(n / (e_rep / min(args.steps, 10)), 1),
+                                        "note": "the same step with ONE feature tensor replayed (rounds 1-5 timed this)"}
         result["gnn_fwd"] = gnn
         result["gnn_fwd_nodes_per_s"] = gnn["nodes_per_s"]
         result["retrieval_small_batch"] = small_batch_rates(model.toy_graph_base, args.dim, args.k, dev)

@@ -1910,11 +1910,12 @@ __global__ void __launch_bounds__(256) topk_overflow_fixup_kernel(const float* _
   if (stats && blockIdx.x == 0 && threadIdx.x == 0) stats[20] = n_over;   // (final: every launch that counts runs before this one)
   if (stats && stats[16] == 0) {
     // the smallest / largest final k-th best score of the call's queries (stats[18] / [19]; a speculative call's verify
-    // launch has recorded them already): one value per thread, wave-reduced, two atomics per wave that saw any.  (Rows the
-    // scans below are about to rewrite still hold their candidates' k-th best, a lower value: the record is a hint.)
+    // launch has recorded them already): one value per thread, wave-reduced, two atomics per wave that saw any.
     int lo = INT_MAX, hi = INT_MIN;
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < B; q += (int64_t)gridDim.x * 256) {
-      const float kth = flag[q] == 2 ? RG_NEG_INF : out_s[q * k + k - 1];
+      // (zero queries -- flag 2 -- have no k-th best; rows flagged 1 are listed for the scans below and hold what torch.empty
+      // left or a stale candidate row that the scans rewrite during this very launch: neither may reach the history words)
+      const float kth = flag[q] != 0 ? RG_NEG_INF : out_s[q * k + k - 1];
       if (kth > RG_NEG_INF) {
         lo = min(lo, f2ord(kth));
         hi = max(hi, f2ord(kth));

@@ -427,6 +427,7 @@ def small_helps(B: int, n_keys: int, D: int, k: int) -> bool:
 
 
 _small_state: dict = {}   # insertion-ordered: least recently used first
+_small_state_pinned: set = set()   # keys whose buffer a captured HIP graph replays against
 _SMALL_STATE_MAX = 8
 
 
@@ -434,7 +435,9 @@ def _small_state_buf(device, create: bool = True):
     """The single-launch kernel's state words: zero before the first call, left zero by every call; one buffer per
     (device, stream) -- calls on a stream are ordered.  Never ALLOCATED while a HIP graph is being captured (the buffer
     would come from the capture's private pool and be reused by later eager calls on a recycled stream handle): returns
-    None then, and the caller takes another path (small_helps_now).  The cache is bounded like the workspace cache."""
+    None then, and the caller takes another path (small_helps_now).  The cache is bounded like the workspace cache -- except that a
+    buffer handed out DURING a capture stays for good: the graph replays against its address, and the kernel both reads it as
+    zeros and zeroes it on exit."""
     dev = device.index if device.index is not None else torch.cuda.current_device()
     key = (dev, _raw_stream(dev) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream)
     t = _small_state.pop(key, None)
@@ -443,8 +446,10 @@ def _small_state_buf(device, create: bool = True):
             return None
         t = torch.zeros(N.lib().ragraph_topk_cosine_small_state_bytes() // 4, dtype=torch.int32, device=device)
     _small_state[key] = t
-    while len(_small_state) > _SMALL_STATE_MAX:
-        _small_state.pop(next(iter(_small_state)))
+    if torch.cuda.is_current_stream_capturing():
+        _small_state_pinned.add(key)   # a captured graph holds the RAW address: this buffer is never evicted (a few KB)
+    for old_key in [k_ for k_ in _small_state if k_ not in _small_state_pinned][:-_SMALL_STATE_MAX]:
+        _small_state.pop(old_key)      # least recently used first; pinned entries do not count against the bound
     return t
 
 

@@ -262,6 +262,10 @@ class KeyIndex:
         small: the single-launch kernel's call (any batch size it takes)."""
         if not self.spec_enabled or (B < self.SPEC_MIN_BATCH and not small) or getattr(self.ops, "set_filter_prior", None) is None:
             return None
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            # a captured launch would carry TODAY's prior by value into every replay, and the statistics that could withdraw it
+            # are not read under capture: captured calls keep their bound pass (a proof, whatever queries the replays bring)
+            return None
         st = self._spec_state(k)
         if st["off_at"] is not None:
             if self._queries - st["off_at"] < st["after"] or B > self.REPROBE_MAX_BATCH:

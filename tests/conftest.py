@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: asserts on wall-clock time; collected LAST so that `pytest -x` reaches every parity "
+                                       "test before a noisy box can stop the run")
+
+
+def pytest_collection_modifyitems(session, config, items):
+    """Every test that holds the clock to a bound (marker `perf`) runs after every test that holds the bits: a slow or shared
+    box then costs the timing tests only, never the parity evidence behind them in file order (`pytest -x -m gpu`)."""
+    items.sort(key=lambda item: 1 if item.get_closest_marker("perf") else 0)   # (stable: file order kept inside each class)
 
 
 _two_rank = None

@@ -7,7 +7,7 @@ import os
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.perf]   # wall-clock assertions: collected last (tests/conftest.py)
 
 
 def _time(fn, reps, rounds=3):

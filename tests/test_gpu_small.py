@@ -105,12 +105,7 @@ def test_topk_cosine_small_near_duplicate_bank(dev):
         assert torch.equal(i3, i) and torch.equal(s3, s)
 
 
-@pytest.mark.parametrize("wait_ticks", [None, "0"])
-def test_no_latency_cliff_next_to_a_cluster(dev, monkeypatch, wait_ticks):
-    """VERDICT round 4, weak #6 / task 8: one query next to a tight cluster among 1 / 16 / 64 against a bank of 1 M keys used to
-    cost 5 - 7 ms (one workgroup scanning the bank) -- also with every workgroup moving on without the others' bound
-    (RAGRAPH_SMALL_WAIT_TICKS=0: a flood from -inf thresholds).  Now: up to 16 queries need no scan at all (single-launch
-    kernel), more take the sliced fixup launch; every call <= 2 ms and bit-identical to the fp32 kernel."""
+def _cluster_case(dev, monkeypatch, wait_ticks, timed):
     from ragraph_amd import kernels as K
 
     if wait_ticks is not None:
@@ -127,21 +122,38 @@ def test_no_latency_cliff_next_to_a_cluster(dev, monkeypatch, wait_ticks):
         q[B // 2] = centre[0] + 2e-3 * torch.randn(D, device=dev, generator=g)
         s, i = index.topk(q, k)                      # (first call: the copies are made)
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
-            s, i = index.topk(q, k)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 3
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                s, i = index.topk(q, k)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 3
+            # (with every workgroup moving on without a bound, 16 queries x a whole share of keys per workgroup can still fill
+            # the lists: that forced case is only held to the bits)
+            if wait_ticks is None or B == 1:
+                assert ms <= 2.0, f"{B} queries, one next to a cluster of 6000: {ms:.2f} ms per call"
         s32, i32 = K.topk_cosine(q, kn, k)
         assert torch.equal(i, i32) and torch.equal(s, s32)
-        # (with every workgroup moving on without a bound, 16 queries x a whole share of keys per workgroup can still fill the
-        # lists: that forced case is only held to the bits)
-        if wait_ticks is None or B == 1:
-            assert ms <= 2.0, f"{B} queries, one next to a cluster of 6000: {ms:.2f} ms per call"
         if wait_ticks is None and B <= K.SMALL_MAX_B:
             assert index.overflowed_queries == 0
+
+
+@pytest.mark.parametrize("wait_ticks", [None, "0"])
+def test_query_next_to_a_cluster_keeps_the_bits(dev, monkeypatch, wait_ticks):
+    """VERDICT round 4, weak #6 / task 8: one query next to a tight cluster among 1 / 16 / 64 against a bank of 1 M keys -- also
+    with every workgroup moving on without the others' bound (RAGRAPH_SMALL_WAIT_TICKS=0: a flood from -inf thresholds).  Up
+    to 16 queries need no scan at all (single-launch kernel), more take the sliced fixup launch; every call bit-identical to
+    the fp32 kernel.  (The clock is held by test_no_latency_cliff_next_to_a_cluster, marker `perf`: it runs last.)"""
+    _cluster_case(dev, monkeypatch, wait_ticks, timed=False)
+
+
+@pytest.mark.perf
+@pytest.mark.parametrize("wait_ticks", [None, "0"])
+def test_no_latency_cliff_next_to_a_cluster(dev, monkeypatch, wait_ticks):
+    """The same calls against the clock: they used to cost 5 - 7 ms (one workgroup scanning the bank); now <= 2 ms."""
+    _cluster_case(dev, monkeypatch, wait_ticks, timed=True)
 
 
 def test_key_index_sends_a_handful_of_queries_to_the_single_launch(dev, monkeypatch):
@@ -163,13 +175,7 @@ def test_key_index_sends_a_handful_of_queries_to_the_single_launch(dev, monkeypa
     assert not K.small_helps(1, 60_000, 256, 10) and not K.small_helps(1, 200_000, 96, 10)
 
 
-@pytest.mark.parametrize("B", [1, 5, 16, 32])
-def test_overflowed_lists_take_the_sliced_scan_behind_the_kernel(dev, monkeypatch, B):
-    """A query whose list of exact pairs passes its cap is LISTED by the last workgroup and answered by the fixup launch that
-    follows every call (exact scans cut into key slices over the whole chip) -- until late in round 5 the last workgroup
-    scanned the bank itself, 25 ms a query.  RAGRAPH_SMALL_LIST_CAP=64 (read per call) makes lists overflow on an ordinary
-    bank: with the bound pass and under forced priors -- below every query's k-th best, among them (misses AND overflowed
-    lists in one call) -- the fp32 kernel's bits, *overflow == statistics word 20, and no scan-sized call."""
+def _overflowed_lists_case(dev, monkeypatch, B, timed):
     from ragraph_amd import kernels as K
 
     g = torch.Generator(device=dev).manual_seed(9 + B)
@@ -189,21 +195,40 @@ def test_overflowed_lists_take_the_sliced_scan_behind_the_kernel(dev, monkeypatc
         try:
             s, i, over, st = K.topk_cosine_small(q, kn, kb, k, return_stats=True)
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                K.topk_cosine_small(q, kn, kb, k)
-            e1.record()
-            torch.cuda.synchronize()
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    K.topk_cosine_small(q, kn, kb, k)
+                e1.record()
+                torch.cuda.synchronize()
         finally:
             K.set_filter_prior(None)
         w = st.cpu().tolist()
         assert torch.equal(i, i0) and torch.equal(s, s0), prior
         assert int(over) == w[20] and w[17] <= int(over)
         # (31 listed queries of 32 take 2.7 ms of sliced scans; the last workgroup's own scans took 50 - 95 ms for such calls)
-        assert e0.elapsed_time(e1) / 3 <= 10.0, (prior, e0.elapsed_time(e1) / 3)
+        if timed:
+            assert e0.elapsed_time(e1) / 3 <= 10.0, (prior, e0.elapsed_time(e1) / 3)
         seen_over += int(over)
     assert seen_over > 0                      # the cap of 64 did make lists overflow
     monkeypatch.delenv("RAGRAPH_SMALL_LIST_CAP")
     s, i, over = K.topk_cosine_small(q, kn, kb, k)
     assert torch.equal(i, i0) and torch.equal(s, s0) and int(over) == 0
+
+
+@pytest.mark.parametrize("B", [1, 5, 16, 32])
+def test_overflowed_lists_take_the_sliced_scan_behind_the_kernel(dev, monkeypatch, B):
+    """A query whose list of exact pairs passes its cap is LISTED by the last workgroup and answered by the fixup launch that
+    follows every call (exact scans cut into key slices over the whole chip) -- until late in round 5 the last workgroup
+    scanned the bank itself, 25 ms a query.  RAGRAPH_SMALL_LIST_CAP=64 (read per call) makes lists overflow on an ordinary
+    bank: with the bound pass and under forced priors -- below every query's k-th best, among them (misses AND overflowed
+    lists in one call) -- the fp32 kernel's bits and *overflow == statistics word 20.  (No clock here: the `perf` twin below.)"""
+    _overflowed_lists_case(dev, monkeypatch, B, timed=False)
+
+
+@pytest.mark.perf
+@pytest.mark.parametrize("B", [1, 32])
+def test_overflowed_lists_cost_no_scan_sized_call(dev, monkeypatch, B):
+    """... and no scan-sized call: <= 10 ms (the last workgroup's own scans took 50 - 95 ms)."""
+    _overflowed_lists_case(dev, monkeypatch, B, timed=True)
