@@ -381,6 +381,18 @@ int ragraph_radix_sort_u64(const uint64_t* keys_in, uint64_t* keys_out, const vo
 size_t ragraph_scan_workspace_bytes(int64_t n);
 int ragraph_scan_sum_i32(const int* in, int* out, int64_t n, int inclusive, void* ws, size_t ws_bytes, void* stream);
 
+/* COO -> CSR, STABLE in the given edge order (sort_cols = 0: inside a row the edges keep their input order -- the order
+ * scatter_add_ accumulates in, RAGraph_edge/modules/utils.py:17-32; sort_cols = 1: columns ascending inside a row).  The edge
+ * flavour re-draws its edge set every training step (modules/RAGraph.py:337-343, modules/utils.py:40-53), a training SpMM
+ * needs the transposed pattern and a row gather's backward its hit lists: all of them come through here (own radix sort; no
+ * other library on any per-step path).  rowptr [n + 1]; perm [E]: the input position of CSR slot s; out_col [E] (optional,
+ * int32): the columns in CSR order.  ws: ragraph_coo_to_csr_workspace_bytes(E, n).  E < 2^31, n < 2^31. */
+size_t ragraph_coo_to_csr_workspace_bytes(int64_t E, int64_t n);
+int ragraph_coo_to_csr_i64(const int64_t* row, const int64_t* col, int64_t E, int64_t n, int sort_cols, int64_t* rowptr,
+                           int64_t* perm, int32_t* out_col, void* ws, size_t ws_bytes, void* stream);
+/* rows[e] = the row of CSR slot e (the inverse of rowptr: torch.repeat_interleave(arange(n), counts) without its prefix sum). */
+int ragraph_csr_row_ids_i64(const int64_t* rowptr, int64_t n, int64_t nnz, int64_t* rows, void* stream);
+
 /* a7, several hops  -- Propagation.py:19-25 with the features PANEL-major between the hops: [D / 32][n][32] floats (a row's
  * 32-column blocks, one 128-byte line each).  The column-panel hop gives every XCD one panel (D = 256): the rows it gathers
  * from are n x 128 bytes instead of n x 1 KiB, a third of which fit its L2 on a graph without locality (c2: L2 hit rate 15 ->

@@ -77,6 +77,9 @@ SIGNATURES = {
     "ragraph_radix_sort_u64": (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _sz, _vp]),
     "ragraph_scan_workspace_bytes": (_sz, [_i64]),
     "ragraph_scan_sum_i32": (_i32, [_vp, _vp, _i64, _i32, _vp, _sz, _vp]),
+    "ragraph_coo_to_csr_workspace_bytes": (_sz, [_i64, _i64]),
+    "ragraph_coo_to_csr_i64": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ragraph_csr_row_ids_i64": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "ragraph_spmm_csr_panels_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _i32, _vp]),
     "ragraph_csr_row_normalize_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "ragraph_segment_softmax_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),

@@ -82,7 +82,7 @@ def augment_batch(features: torch.Tensor, prob: torch.Tensor, graph_ptr: torch.T
 def _dense_blocks(g: CSRGraph, graph_ptr: torch.Tensor, pick: torch.Tensor) -> torch.Tensor:
     """adj[pick_g][:, pick_g] of every graph (ToyGraphBase.py:100): pick [G,S] global node ids -> [G,S,S] dense."""
     G, S = pick.shape
-    rows = torch.repeat_interleave(torch.arange(g.n, device=g.device), g.rowptr[1:] - g.rowptr[:-1])
+    rows = g.row_ids()
     key = rows * g.n + g.col.long()                                             # sorted (CSR order, ascending columns)
     want = (pick.unsqueeze(2) * g.n + pick.unsqueeze(1)).reshape(-1)
     pos = torch.searchsorted(key, want).clamp_(max=max(key.numel() - 1, 0))

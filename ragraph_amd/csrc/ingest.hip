@@ -125,6 +125,54 @@ __global__ void __launch_bounds__(256) pair_emit_kernel(const uint64_t* __restri
   times[e] = etime_sorted[e];
 }
 
+// ---- COO -> CSR (stable) ------------------------------------------------------------------------------------------
+// key = row (sort_cols = 0: the given edge order survives inside a row -- the order scatter_add_ accumulates in,
+// RAGraph_edge/modules/utils.py:17-32) or row * n + col (columns ascending inside a row); the value is the edge's position.
+__global__ void __launch_bounds__(256) coo_keys_kernel(const int64_t* __restrict__ row, const int64_t* __restrict__ col, int64_t E,
+                                                       int64_t n, int sort_cols, uint64_t* __restrict__ keys,
+                                                       int64_t* __restrict__ idx) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  keys[e] = sort_cols ? (uint64_t)row[e] * (uint64_t)n + (uint64_t)col[e] : (uint64_t)row[e];
+  idx[e] = e;
+}
+
+// rowptr[r] = the first sorted slot whose row is >= r: slot s writes the rows in (row(s - 1), row(s)] -- its own row and
+// the empty rows before it --, the last slot also the rows behind it.  O(E + n) stores, no histogram and no prefix sum.
+// out_col (optional): the columns in CSR order.
+__global__ void __launch_bounds__(256) coo_rowptr_kernel(const uint64_t* __restrict__ keys, const int64_t* __restrict__ perm,
+                                                         const int64_t* __restrict__ col, int64_t E, int64_t n, int sort_cols,
+                                                         int64_t* __restrict__ rowptr, int32_t* __restrict__ out_col) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= E) return;
+  const uint64_t un = (uint64_t)n;
+  const int64_t r = (int64_t)(sort_cols ? keys[s] / un : keys[s]);
+  const int64_t rp = s == 0 ? -1 : (int64_t)(sort_cols ? keys[s - 1] / un : keys[s - 1]);
+  for (int64_t x = rp + 1; x <= r; ++x) rowptr[x] = s;
+  if (s == E - 1)
+    for (int64_t x = r + 1; x <= n; ++x) rowptr[x] = E;
+  if (out_col) out_col[s] = (int32_t)(sort_cols ? (int64_t)(keys[s] % un) : col[perm[s]]);
+}
+
+__global__ void __launch_bounds__(256) fill_i64_kernel(int64_t* __restrict__ p, int64_t n, int64_t v) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// rows[e] = the row whose range [rowptr[r], rowptr[r + 1]) holds e (binary search: the last r with rowptr[r] <= e)
+__global__ void __launch_bounds__(256) csr_row_ids_kernel(const int64_t* __restrict__ rowptr, int64_t n, int64_t nnz,
+                                                          int64_t* __restrict__ rows) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= nnz) return;
+  int64_t lo = 0, hi = n;   // invariant: rowptr[lo] <= e < rowptr[hi]
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (rowptr[mid] <= e) lo = mid;
+    else hi = mid;
+  }
+  rows[e] = lo;
+}
+
 static int key_bits(uint64_t max_key) {
   int b = 1;
   while (b < 64 && (max_key >> b) != 0) ++b;
@@ -243,5 +291,45 @@ extern "C" int ragraph_binorm_edges_f32(const int64_t* users, const int64_t* ite
   hipLaunchKernelGGL(pair_emit_kernel, dim3(gM), dim3(256), 0, st, f.keys_b, f.vals_b, f.count, n, f.deg, edges, norm, times,
                      nedges);
   RG_CHECK_LAUNCH("binorm_edges");
+  return RAGRAPH_OK;
+}
+
+// COO -> CSR, stable (what torch.sort(stable) + bincount + cumsum did on the per-step paths until round 5: the edge flavour's
+// destination-sorted CSR of every re-drawn edge set, modules/RAGraph.py:337-343 + utils.py:40-53; the transposed pattern of a
+// training SpMM; the hit lists of a gather's backward).  perm[s] = the input position of CSR slot s.
+extern "C" size_t ragraph_coo_to_csr_workspace_bytes(int64_t E, int64_t n) {
+  if (E < 0 || E >= (int64_t)INT_MAX || n < 1) return 0;
+  return ingest_carve(nullptr, E > 0 ? E : 1, 1, nullptr);
+}
+
+extern "C" int ragraph_coo_to_csr_i64(const int64_t* row, const int64_t* col, int64_t E, int64_t n, int sort_cols, int64_t* rowptr,
+                                      int64_t* perm, int32_t* out_col, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(rowptr && ws && (E == 0 || (row && col && perm)), RAGRAPH_EINVAL, "coo_to_csr: null pointer");
+  RG_REQUIRE(E >= 0 && E < (int64_t)INT_MAX && n >= 1 && n < ((int64_t)1 << 31), RAGRAPH_EINVAL, "coo_to_csr: bad E/n");
+  RG_REQUIRE(ws_bytes >= ragraph_coo_to_csr_workspace_bytes(E, n), RAGRAPH_EWORKSPACE, "coo_to_csr: workspace too small");
+  hipStream_t st = as_stream(stream);
+  if (E == 0) {
+    hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)cdiv(n + 1, 256)), dim3(256), 0, st, rowptr, n + 1, (int64_t)0);
+    RG_CHECK_LAUNCH("coo_to_csr");
+    return RAGRAPH_OK;
+  }
+  IngestWs f;
+  ingest_carve(static_cast<char*>(ws), E, 1, &f);
+  const unsigned g = (unsigned)cdiv(E, 256);
+  hipLaunchKernelGGL(coo_keys_kernel, dim3(g), dim3(256), 0, st, row, col, E, n, sort_cols, f.keys_a, f.vals_a);
+  const uint64_t max_key = sort_cols ? (uint64_t)n * (uint64_t)n - 1 : (uint64_t)(n - 1);
+  const int rc = radix_sort_u64(f.keys_a, f.keys_b, f.vals_a, perm, 8, E, key_bits(max_key), f.temp, f.temp_bytes, st);
+  if (rc != RAGRAPH_OK) return rc;
+  hipLaunchKernelGGL(coo_rowptr_kernel, dim3(g), dim3(256), 0, st, f.keys_b, perm, col, E, n, sort_cols, rowptr, out_col);
+  RG_CHECK_LAUNCH("coo_to_csr");
+  return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_csr_row_ids_i64(const int64_t* rowptr, int64_t n, int64_t nnz, int64_t* rows, void* stream) {
+  RG_REQUIRE(rowptr && (rows || nnz == 0), RAGRAPH_EINVAL, "csr_row_ids: null pointer");
+  RG_REQUIRE(n >= 1 && nnz >= 0, RAGRAPH_EINVAL, "csr_row_ids: bad n/nnz");
+  if (nnz == 0) return RAGRAPH_OK;
+  hipLaunchKernelGGL(csr_row_ids_kernel, dim3((unsigned)cdiv(nnz, 256)), dim3(256), 0, as_stream(stream), rowptr, n, nnz, rows);
+  RG_CHECK_LAUNCH("csr_row_ids");
   return RAGRAPH_OK;
 }

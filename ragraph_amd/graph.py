@@ -4,8 +4,10 @@ The reference hands a DENSE n x n normalised adjacency to every layer (ragraph_u
 layers/gcn.py:36, Propagation.py:15-22): 40 GB per copy at n = 1e5.  The kernels take CSR (int64 rowptr, int32 col,
 fp32 val); `as_csr` accepts what reference callers pass (a dense tensor) or a CSRGraph, and converts once.
 
-Structure conversion (nonzero / stable sort / cumsum) uses torch ops as plumbing: it is integer bookkeeping done once
-per graph, outside the per-forward path; every floating-point result comes from libragraph_hip.so.
+Structure conversion: COO -> CSR (from_coo, transposed, permuted) runs on the library's own stable radix sort
+(ragraph_coo_to_csr_i64) -- the edge flavour rebuilds its graph on every training step; only from_dense (the reference's
+dense [n, n] input, converted once per graph) still enumerates the non-zeros with torch.nonzero.  Every floating-point
+result comes from libragraph_hip.so.
 """
 from __future__ import annotations
 
@@ -63,9 +65,15 @@ class CSRGraph:
         """CSR of A^T (row j lists the i with A[i][j] != 0, ascending i), cached: what a backward pass through the SpMM
         multiplies by, and what PageRank pulls along."""
         if self._transposed is None:
-            rows = torch.repeat_interleave(torch.arange(self.n, device=self.device), self.rowptr[1:] - self.rowptr[:-1])
-            self._transposed, _ = CSRGraph.from_coo(self.col.long(), rows, self.val, self.n, sort_cols=True)
+            # (the edges are row-major already: a STABLE sort by column alone leaves every transposed row ascending)
+            self._transposed, _ = CSRGraph.from_coo(self.col, self.row_ids(), self.val, self.n)
         return self._transposed
+
+    def row_ids(self) -> torch.Tensor:
+        """rows[e] = the row of CSR slot e (int64)."""
+        if self.rowptr.is_cuda:
+            return K.csr_row_ids(self.rowptr, self.nnz)
+        return torch.repeat_interleave(torch.arange(self.n, device=self.device), self.rowptr[1:] - self.rowptr[:-1])
 
     # ---- locality ----------------------------------------------------------------------------------------------
     def permuted(self, order: torch.Tensor) -> "CSRGraph":
@@ -77,8 +85,7 @@ class CSRGraph:
         order = order.to(self.device, torch.int64)
         inv = torch.empty_like(order)
         inv[order] = torch.arange(self.n, device=self.device)
-        rows = torch.repeat_interleave(torch.arange(self.n, device=self.device), self.rowptr[1:] - self.rowptr[:-1])
-        g, _ = CSRGraph.from_coo(inv[rows], inv[self.col.long()], self.val, self.n, sort_cols=True)
+        g, _ = CSRGraph.from_coo(inv[self.row_ids()], inv[self.col.long()], self.val, self.n, sort_cols=True)
         return g
 
     def locality_order(self) -> torch.Tensor:
@@ -108,6 +115,13 @@ class CSRGraph:
         """COO -> CSR over `rows`, STABLE in the given edge order (the order scatter_add_ accumulates in,
         RAGraph_edge/modules/utils.py:17-32).  Returns (graph, perm): perm[e'] = original edge id of CSR slot e'."""
         rows = rows.to(torch.int64)
+        if rows.is_cuda:
+            # the product path: the library's own stable radix sort (csrc/ingest.hip: ragraph_coo_to_csr_i64) -- this runs on
+            # EVERY training step of the edge flavour (a re-drawn edge set), for every training SpMM's transposed pattern and in
+            # the gather backward; no read-back, nothing from another library
+            rowptr, col, perm = K.coo_to_csr(rows, cols, n, sort_cols=sort_cols)
+            return CSRGraph(rowptr, col, vals[perm].float().contiguous(), n), perm
+        # host tensors (the CPU host-logic tests): the same construction with torch ops
         key = rows * n + cols.to(torch.int64) if sort_cols else rows
         perm = torch.sort(key, stable=True).indices
         rowptr = torch.zeros(n + 1, dtype=torch.int64, device=rows.device)

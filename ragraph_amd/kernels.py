@@ -1085,6 +1085,36 @@ def csr_sym_normalized_from_edges(edge_index: torch.Tensor, n: int):
     return rowptr, col[:m].contiguous(), val[:m].contiguous()
 
 
+def coo_to_csr(rows: torch.Tensor, cols: torch.Tensor, n: int, sort_cols: bool = False):
+    """COO -> CSR, stable (ragraph_coo_to_csr_i64): returns (rowptr int64 [n+1], col int32 [E] in CSR order, perm int64 [E] =
+    the input position of every CSR slot).  No read-back, no other library: the per-step graph rebuilds of the edge flavour,
+    the transposed patterns of training and the gather backward come through here."""
+    L = _ready()
+    r, c = _idxc(rows, "coo_to_csr.rows"), _idxc(cols, "coo_to_csr.cols")
+    E = r.numel()
+    if c.numel() != E:
+        raise RagraphNativeError("coo_to_csr: rows and cols differ in length")
+    dev = r.device
+    rowptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    perm = torch.empty(E, dtype=torch.int64, device=dev)
+    col = torch.empty(E, dtype=torch.int32, device=dev)
+    ws = _workspace(L.ragraph_coo_to_csr_workspace_bytes(E, n), dev)
+    N.check(L.ragraph_coo_to_csr_i64(r.data_ptr() if E else None, c.data_ptr() if E else None, E, n, 1 if sort_cols else 0,
+                                     rowptr.data_ptr(), perm.data_ptr() if E else None, col.data_ptr() if E else None,
+                                     ws.data_ptr(), ws.numel(), _stream()), "coo_to_csr")
+    return rowptr, col, perm
+
+
+def csr_row_ids(rowptr: torch.Tensor, nnz: int) -> torch.Tensor:
+    """rows[e] = the row of CSR slot e (ragraph_csr_row_ids_i64)."""
+    L = _ready()
+    rp = _idxc(rowptr, "csr_row_ids.rowptr")
+    rows = torch.empty(nnz, dtype=torch.int64, device=rp.device)
+    N.check(L.ragraph_csr_row_ids_i64(rp.data_ptr(), rp.numel() - 1, nnz, rows.data_ptr() if nnz else None, _stream()),
+            "csr_row_ids")
+    return rows
+
+
 def binorm_edges(users: torch.Tensor, items: torch.Tensor, step: torch.Tensor, num_users: int, num_items: int):
     """Bi-normalised bipartite adjacency as a (dst, src)-sorted edge list with per-edge time steps --
     RAGraph_edge/modules/base_model.py:34-52 + utils/dataloader.py:94,108-113.  Returns (edges [M,2] int64, norm [M],

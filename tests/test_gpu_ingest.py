@@ -112,3 +112,34 @@ def test_radix_sort_and_scan_match_numpy(dev, n, bits, val_bytes):
         ref = np.cumsum(x, dtype=np.int64)
         ref = ref if inclusive else ref - x
         assert np.array_equal(out.cpu().numpy(), ref.astype(np.int32))
+
+
+@pytest.mark.parametrize("E,n,sort_cols", [(0, 5, False), (1, 1, True), (1000, 37, False), (1000, 37, True), (300_000, 70_000, False),
+                                           (300_000, 70_000, True), (2_000_000, 1000, False), (50_000, 3_000_000, True)])
+def test_coo_to_csr_matches_the_stable_sort_formulation(dev, E, n, sort_cols):
+    """ragraph_coo_to_csr_i64 (own radix sort; every per-step graph rebuild of the edge flavour, the transposed patterns of
+    training and the gather backward) against torch.sort(stable) + bincount + cumsum on the HOST: the same row pointers, the
+    same permutation (ties keep the input order: scatter_add_'s accumulation order, modules/utils.py:17-32), the same columns;
+    empty rows at both ends and in the middle, duplicate (row, col) pairs."""
+    from ragraph_amd import kernels as K
+    from ragraph_amd.graph import CSRGraph
+
+    g = torch.Generator().manual_seed(E + n)
+    rows = torch.randint(0, n, (E,), generator=g)
+    if E > 100:
+        rows[rows == 0] = min(1, n - 1)                      # row 0 empty
+        rows[rows == n - 1] = max(n - 2, 0)                  # the last row empty
+        rows[E // 2:E // 2 + 5] = rows[E // 2]               # duplicates: the stable order decides
+    cols = torch.randint(0, n, (E,), generator=g)
+    if E > 100:
+        cols[E // 2:E // 2 + 5] = cols[E // 2]
+    vals = torch.randn(E, generator=g)
+    ref, ref_perm = CSRGraph.from_coo(rows, cols, vals, n, sort_cols=sort_cols)           # host tensors: the torch formulation
+    got, perm = CSRGraph.from_coo(rows.to(dev), cols.to(dev), vals.to(dev), n, sort_cols=sort_cols)
+    assert torch.equal(got.rowptr.cpu(), ref.rowptr) and torch.equal(perm.cpu(), ref_perm)
+    assert torch.equal(got.col.cpu(), ref.col) and torch.equal(got.val.cpu(), ref.val)
+    assert torch.equal(got.row_ids().cpu(), ref.row_ids())
+    if E and sort_cols:
+        t_ref = ref.transposed()
+        t = got.transposed()
+        assert torch.equal(t.rowptr.cpu(), t_ref.rowptr) and torch.equal(t.col.cpu(), t_ref.col) and torch.equal(t.val.cpu(), t_ref.val)

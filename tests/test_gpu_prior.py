@@ -217,3 +217,37 @@ def test_key_index_speculates_on_single_query_calls(dev):
         s32, i32 = K.topk_cosine(q, kn, 10)
         assert torch.equal(i, i32) and torch.equal(s, s32)
     assert used >= 30 and index.overflowed_queries <= 3          # (a miss now and then is a scan, not an error)
+
+
+def test_a_capture_after_warm_up_keeps_its_bound_pass(dev):
+    """an index that is already warm (a prior in force for eager calls) must not bake that prior into a HIP
+    graph -- the captured launches would carry it by value into every replay, and the statistics that could withdraw it are not
+    read under capture.  Captured calls keep their bound pass: replays with queries whose k-th best lies far BELOW the warm
+    prior are exact AND scan nothing (statistics word 16 = 0: not speculative; word 20 = 0: no query took the exact scan)."""
+    from ragraph_amd import kernels as K
+    from ragraph_amd.capture import CapturedForward
+
+    N, D, k, B = 200_000, 256, 10, 300
+    kn, g = _bank(dev, N, D, 4242)
+    index = K.KeyIndex(kn, dedup=False)
+    near = lambda: kn[torch.randint(0, N, (B,), device=dev, generator=g)] + 0.02 * torch.randn(B, D, device=dev, generator=g)
+    for _ in range(6):                                   # warm: queries next to stored keys, k-th best scores high
+        index.topk(near(), k)
+        torch.cuda.synchronize()
+    index.topk(near(), k)
+    assert index.last_prior is not None                   # eager calls do speculate by now
+    stats = torch.zeros(32, dtype=torch.int32, device=dev)
+
+    def fwd(q):
+        s, i = index.topk(q, k)
+        stats.copy_(index.last_stats[:32])               # (the call's statistics words: a view of its workspace)
+        return i
+
+    cap = CapturedForward(fwd, near())
+    far = torch.randn(B, D, device=dev, generator=g)     # random directions: k-th best around 0.25, far below the prior
+    i_rep = cap(far).clone()
+    torch.cuda.synchronize()
+    w = stats.cpu().tolist()
+    s32, i32 = K.topk_cosine(far, kn, k)
+    assert torch.equal(i_rep, i32)
+    assert w[0] == K.FILTER_STATS_MAGIC and w[16] == 0 and w[20] == 0, w[14:21]
