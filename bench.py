@@ -291,6 +291,19 @@ def build_workload(args, dev, rank, world, shard, force_dist=False):
         model.toy_graph_base.set_resources(Kb, Vb, Lb)
         _ = model.toy_graph_base.keys_normalized
         n_local = args.bank
+    if emu > 1 and shard in ("keys", "hybrid") and os.environ.get("RAGRAPH_SPEC", "1") != "0":
+        # An emulated rank has ONE shard: what its group would have learnt -- the prior comes from the MERGED k-th best scores of
+        # the whole bank, pooled over the ranks -- cannot be learnt from that shard's lists.  It is computed here once, outside
+        # every timing, from the whole bank (the policy's own rule over one batch), and the emulated rank runs under it;
+        # sharded.py skips the verdict in emulation (timing only: an emulated rank's lists are not the global top-k anyway).
+        from ragraph_amd.sharded import GroupPrior
+        with torch.no_grad():
+            h = model.pretrain_model.inference(feats, adj)
+            s_all, _ = K.KeyIndex(Kb).topk(h, args.k)
+        kth = s_all[:, args.k - 1]
+        lo_, hi_ = float(kth.min()), float(kth.max())
+        model.toy_graph_base.prior.forced = lo_ - max(GroupPrior.MARGIN * (hi_ - lo_), GroupPrior.MIN_MARGIN)
+        del s_all, h
     del Kb
     torch.cuda.synchronize()
     return model, feats, adj, n_local
@@ -632,6 +645,17 @@ def verify_retrieval(model, feats, adj, args, world, with_oracle):
     return rec
 
 
+def _group_prior_report(model):
+    """A row-sharded bank's speculative first bound (ragraph_amd.sharded.GroupPrior): calls of the group so far, how many ran
+    without bound pass / phase 0, how many were repeated because a row missed the prior."""
+    tgb = getattr(model, "toy_graph_base", None)
+    pr = getattr(tgb, "prior", None)
+    if pr is None or not hasattr(pr, "calls"):
+        return None
+    return {"group_calls": pr.calls, "speculative_calls": pr.used, "calls_repeated_after_a_miss": getattr(tgb, "reruns", 0),
+            "phase0_exchanges": getattr(tgb, "exchange_count", {}).get(0, 0)}
+
+
 def timed_steps(step, steps, world, dev, on_step=None):
     """Exactly `steps` forwards between barrier + synchronize on both sides; MAX over ranks."""
     if world > 1:
@@ -912,6 +936,9 @@ def main():
             spec["retrieval_call_ms_min_max"] = [round(min(calls), 3), round(max(calls), 3)]
     result["distinct_batches"] = nb
     result["first_bound"] = spec
+    gp = _group_prior_report(model)
+    if gp is not None:
+        result["first_bound"]["group"] = gp
     if ranks_seen is not None:
         result["ranks_seen"] = ranks_seen
         result["collectives_per_step"] = collectives
@@ -940,10 +967,17 @@ def main():
                 step2()
             beat(f"layout {sh}: timed steps")
             e2, _ = timed_steps(step2, args.steps, world, dev)
+            from ragraph_amd import sharded as SH   # what this layout's collectives cost: one more step, outside its timing
+            SH.collective_times.reset()
+            SH.collective_times.enabled = True
+            step2()
+            coll2 = SH.collective_times.report()
+            SH.collective_times.enabled = False
             name = {"keys": "key_sharded", "queries": "query_sharded", "hybrid": "hybrid"}[sh]
             result[name] = {"value": round(n / (e2 / args.steps), 1), "unit": "queries/s",
                             "ms_per_step": round(e2 / args.steps * 1e3, 3), "bank_rows_per_gpu": nl2,
                             "layout": getattr(m2, "layout_name", f"{name.replace('_', '-')} x{world}"),
+                            "collectives_per_step": coll2, "first_bound": _group_prior_report(m2),
                             "note": "same steps / warm-up as the headline layout"}
             del m2, f2, a2
             torch.cuda.empty_cache()

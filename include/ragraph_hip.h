@@ -174,8 +174,8 @@ int ragraph_topk_cosine_filtered_max_i8_levels(int n);
  * ragraph_topk_cosine_f32 for ANY prior; a prior above a query's true k-th best costs that query an exact scan (~0.1 - 2
  * ms), one far below it costs candidates.  The owner of a bank derives it from the k-th best scores its earlier calls
  * reported (statistics words [18], [19]) and withdraws it when a call reports misses (ragraph_amd/kernels_index.py).
- * The sharded entry ignores it.  The reference has no counterpart (torch.topk over the full score matrix,
- * ToyGraphBase.py:66-67): this only removes work. */
+ * The sharded entry honours it too (below): there the PROOF is the caller's, over the merged lists.  The reference has no
+ * counterpart (torch.topk over the full score matrix, ToyGraphBase.py:66-67): this only removes work. */
 float ragraph_topk_cosine_filtered_set_prior(float theta_prior);
 int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const float* Kn, const float* Kp, const uint16_t* Kb,
                                      int64_t N, int D, int k, int64_t idx_base, float* out_scores, int64_t* out_idx,
@@ -201,8 +201,25 @@ int ragraph_topk_cosine_filtered_f32(const float* Q, int64_t B, const float* Kn,
  * the number of callbacks) is computed from it, so that every rank makes the same calls; N <= plan_N <= N + 1024.
  * The result is this shard's exact top-k among its rows that can still be in the global top-k (fewer than k entries
  * are padded with -inf / INT64_MAX); ragraph_topk_merge_f32 over the shards' lists gives the global result, bit-identical
- * to one GPU.  exchange = NULL: exactly ragraph_topk_cosine_filtered_f32. */
+ * to one GPU.  exchange = NULL: exactly ragraph_topk_cosine_filtered_f32.
+ * A SPECULATIVE first bound (ragraph_topk_cosine_filtered_set_prior on the calling thread, the SAME value on every rank --
+ * a collective decision of the caller): when ragraph_topk_cosine_filtered_sharded_speculates(...) says so, the call skips its
+ * bound pass AND exchange 0 (the phases run 1 .. L - 1), starts every query from theta = theta_prior and filters each level
+ * with max(theta_prior, the pooled bound).  A shard's list then holds every key of the shard that scores at least
+ * max(theta_prior, the global k-th best): the merged lists are the exact global top-k of every query whose MERGED k-th best
+ * reaches theta_prior, which only the owner of the merged row can see -- it verifies, tells the other ranks (one tiny
+ * all_reduce) and the call is repeated without the prior when any query missed (ragraph_amd/sharded.py). */
 typedef void (*ragraph_exchange_fn)(void* ctx, int phase);
+/* The owner's verdict behind the merge (one launch): merged_scores [R, k] = the merged global lists of the R rows this rank
+ * finishes.  out5[0] = rows whose k-th best is below `prior` (speculative != 0; all-zero queries need no proof), out5[1] = -(the
+ * smallest proven k-th best), out5[2] = the largest, out5[3] = this shard's candidates per query over its levels (from the
+ * call's statistics words, or -1), out5[4] = its overflowed lists (*overflow, or 0).  all_reduce MAX over the ranks makes the
+ * five numbers the group's; a non-zero out5[0] repeats the call without the prior. */
+int ragraph_verify_merged_prior_f32(const float* merged_scores, int64_t R, int k, float prior, int speculative,
+                                    const int* stats_words, const int* overflow, float* out5, void* stream);
+/* 1 if a sharded call of this shape would skip its bound pass and exchange 0 under a valid speculative prior (the plan for
+ * plan_N has a bound pass): the same answer on every rank -- it is computed from the shared plan only. */
+int ragraph_topk_cosine_filtered_sharded_speculates(int64_t B, int64_t plan_N, int D, int k, int n_shards);
 /* ws of the sharded entry: the schedule is planned for (plan_N, n_shards), whose first sample -- hence level-0 scratch --
  * can differ from the single bank's; at least ragraph_topk_cosine_filtered_workspace_bytes(B, plan_N, D, k). */
 size_t ragraph_topk_cosine_filtered_sharded_workspace_bytes(int64_t B, int64_t plan_N, int D, int k, int n_shards);
@@ -392,6 +409,12 @@ int ragraph_coo_to_csr_i64(const int64_t* row, const int64_t* col, int64_t E, in
                            int64_t* perm, int32_t* out_col, void* ws, size_t ws_bytes, void* stream);
 /* rows[e] = the row of CSR slot e (the inverse of rowptr: torch.repeat_interleave(arange(n), counts) without its prefix sum). */
 int ragraph_csr_row_ids_i64(const int64_t* rowptr, int64_t n, int64_t nnz, int64_t* rows, void* stream);
+
+/* pos[j] = the position of the j-th non-zero byte of mask (ascending), *count = their number: the boolean indexing of the edge
+ * flavour's per-step edge dropout (RAGraph_edge/modules/utils.py:40-53, edges[mask]) on the library's own prefix sums. */
+size_t ragraph_mask_positions_workspace_bytes(int64_t E);
+int ragraph_mask_positions_i64(const unsigned char* mask, int64_t E, int64_t* pos, int64_t* count, void* ws, size_t ws_bytes,
+                               void* stream);
 
 /* a7, several hops  -- Propagation.py:19-25 with the features PANEL-major between the hops: [D / 32][n][32] floats (a row's
  * 32-column blocks, one 128-byte line each).  The column-panel hop gives every XCD one panel (D = 256): the rows it gathers

@@ -148,15 +148,20 @@ class RAGraph(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 query_embeddings = Propagation.aggregate_k_hop_features(g, emb, self.query_graph_hop, rows=(lo, hi))
-        rag_embedding, rag_label, _ = tgb.retrieve_reduced_rows(queries)
-        if not self.finetune:
-            return tgb.gather_output_rows(rag_label, n)
+        # (the filtered call may run under the group's speculative first bound: its proof -- the merged k-th best of every row
+        # against the prior, pooled over the ranks -- is read AFTER the rest of the tail has been enqueued, just before the
+        # output leaves; a miss anywhere repeats the retrieval without the prior on every rank alike)
+        rag_embedding, rag_label, _ = tgb.retrieve_reduced_rows(queries, defer_verify=True)
         if side is not None:
             main.wait_stream(side)
             query_embeddings.record_stream(main)
-        else:
+        elif self.finetune:
             query_embeddings = Propagation.aggregate_k_hop_features(g, emb, self.query_graph_hop, rows=(lo, hi))
-        return tgb.gather_output_rows(self._fuse_decode(query_embeddings, rag_embedding, rag_label), n)
+        out = self._fuse_decode(query_embeddings, rag_embedding, rag_label) if self.finetune else rag_label
+        if not tgb.confirm():
+            rag_embedding, rag_label, _ = tgb.retrieve_reduced_rows(queries)
+            out = self._fuse_decode(query_embeddings, rag_embedding, rag_label) if self.finetune else rag_label
+        return tgb.gather_output_rows(out, n)
 
 
     def _forward_hybrid(self, queries, emb, g):
@@ -178,15 +183,19 @@ class RAGraph(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 query_embeddings = Propagation.aggregate_k_hop_features(g, emb, self.query_graph_hop, rows=rows)
-        rag_embedding, rag_label, _ = H.retrieve_reduced_rows(qs, tgb, queries)
-        if not self.finetune:
-            return H.gather_output_rows(qs, tgb, rag_label, n)
+        # (speculative first bound: decided, proven and withdrawn inside the KEY group -- see _forward_key_shard; the verdict is
+        # read before any collective of the query axis, so the query groups never disagree on how many of those run)
+        rag_embedding, rag_label, _ = H.retrieve_reduced_rows(qs, tgb, queries, defer_verify=True)
         if side is not None:
             main.wait_stream(side)
             query_embeddings.record_stream(main)
-        else:
+        elif self.finetune:
             query_embeddings = Propagation.aggregate_k_hop_features(g, emb, self.query_graph_hop, rows=rows)
-        return H.gather_output_rows(qs, tgb, self._fuse_decode(query_embeddings, rag_embedding, rag_label), n)
+        out = self._fuse_decode(query_embeddings, rag_embedding, rag_label) if self.finetune else rag_label
+        if not tgb.confirm():
+            rag_embedding, rag_label, _ = H.retrieve_reduced_rows(qs, tgb, queries)
+            out = self._fuse_decode(query_embeddings, rag_embedding, rag_label) if self.finetune else rag_label
+        return H.gather_output_rows(qs, tgb, out, n)
 
 
 class RAGraphGraph(RAGraph):

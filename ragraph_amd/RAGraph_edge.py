@@ -236,15 +236,31 @@ class RAGraph(nn.Module):
         return K.linear(user_emb, item_emb)   # modules/RAGraph.py:362-364: user_emb @ item_emb.T
 
     # ---- fine-tuning step --------------------------------------------------------------------------------------------
+    dropout_rng = "host"   # "host": the reference's draw (torch.rand on the CPU generator, utils.py:46) -- the same mask as the
+                           # reference for the same seed, at the cost of one uniform per edge on the host and a copy per step
+                           # (44 M edges: ~0.3 s of a 1-s step at c5, bench `finetune_step.edge_c5.host_mask_draw_ms`);
+                           # "device": torch.rand on the device generator (another stream of random numbers, same law)
+
+    def draw_edge_mask(self):
+        """The step's edge-dropout mask (bool, on the device), or None when nothing is dropped."""
+        keep = 1.0 - self.edge_dropout
+        if keep >= 1.0:
+            return None
+        n_e = self.edges.shape[0]
+        if self.dropout_rng == "device":
+            return (torch.rand(n_e, device=self.edges.device) + keep).floor().bool()
+        return (torch.rand(n_e) + keep).floor().bool().to(self.edges.device)
+
     def cal_loss(self, batch_data):
         """modules/RAGraph.py:335-355: edge dropout (keep 1 - edge_dropout; the reference draws the mask with torch.rand on
         the CPU generator, utils.py:46), forward on the kept edges, BPR loss on (user, positive, negative) triples + L2 on
         the batch's table rows.  Returns (loss, {"rec_loss", "reg_loss"})."""
-        keep = 1.0 - self.edge_dropout
-        n_e = self.edges.shape[0]
-        mask = (torch.rand(n_e) + keep).floor().bool().to(self.edges.device) if keep < 1.0 else \
-            torch.ones(n_e, dtype=torch.bool, device=self.edges.device)
-        edges, norm, times = self.edges[mask], self.edge_norm[mask], self.edge_times[mask]
+        mask = self.draw_edge_mask()
+        if mask is None:
+            edges, norm, times = self.edges, self.edge_norm, self.edge_times
+        else:
+            kept = K.mask_positions(mask)            # (the library's own prefix sums: no other library's select on this path)
+            edges, norm, times = self.edges[kept], self.edge_norm[kept], self.edge_times[kept]
         users, pos_items, neg_items = (t.to(self.edges.device).long() for t in batch_data)
         user_emb, item_emb = self.forward(edges, norm, times)
         u = A.gather_rows(user_emb.contiguous(), users)                                        # :343-345

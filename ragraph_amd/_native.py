@@ -48,6 +48,8 @@ SIGNATURES = {
     "ragraph_topk_cosine_filtered_sharded_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32]),
     "ragraph_topk_cosine_filtered_plan": (_i32, [_i64, _i64, _i32, _i32, _vp]),
     "ragraph_topk_cosine_filtered_i8_levels": (_i32, [_i64, _i64, _i32, _i32]),
+    "ragraph_topk_cosine_filtered_sharded_speculates": (_i32, [_i64, _i64, _i32, _i32, _i32]),
+    "ragraph_verify_merged_prior_f32": (_i32, [_vp, _i64, _i32, _f32, _i32, _vp, _vp, _vp, _vp]),
     "ragraph_topk_cosine_filtered_max_i8_levels": (_i32, [_i32]),
     "ragraph_topk_cosine_filtered_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp,
                                                 _sz, _vp]),
@@ -80,6 +82,8 @@ SIGNATURES = {
     "ragraph_coo_to_csr_workspace_bytes": (_sz, [_i64, _i64]),
     "ragraph_coo_to_csr_i64": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ragraph_csr_row_ids_i64": (_i32, [_vp, _i64, _i64, _vp, _vp]),
+    "ragraph_mask_positions_workspace_bytes": (_sz, [_i64]),
+    "ragraph_mask_positions_i64": (_i32, [_vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "ragraph_spmm_csr_panels_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _i32, _vp]),
     "ragraph_csr_row_normalize_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "ragraph_segment_softmax_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),

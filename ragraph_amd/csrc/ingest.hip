@@ -173,6 +173,20 @@ __global__ void __launch_bounds__(256) csr_row_ids_kernel(const int64_t* __restr
   rows[e] = lo;
 }
 
+// ---- positions of the set elements of a byte mask (boolean indexing without another library's select) --------------
+__global__ void __launch_bounds__(256) mask_flags_kernel(const unsigned char* __restrict__ mask, int64_t E, int* __restrict__ flag) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < E) flag[e] = mask[e] ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) mask_positions_kernel(const unsigned char* __restrict__ mask, const int* __restrict__ slot,
+                                                             int64_t E, int64_t* __restrict__ pos, int64_t* __restrict__ count) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  if (mask[e]) pos[slot[e]] = e;
+  if (e == E - 1) *count = (int64_t)slot[e] + (mask[e] ? 1 : 0);
+}
+
 static int key_bits(uint64_t max_key) {
   int b = 1;
   while (b < 64 && (max_key >> b) != 0) ++b;
@@ -331,5 +345,37 @@ extern "C" int ragraph_csr_row_ids_i64(const int64_t* rowptr, int64_t n, int64_t
   if (nnz == 0) return RAGRAPH_OK;
   hipLaunchKernelGGL(csr_row_ids_kernel, dim3((unsigned)cdiv(nnz, 256)), dim3(256), 0, as_stream(stream), rowptr, n, nnz, rows);
   RG_CHECK_LAUNCH("csr_row_ids");
+  return RAGRAPH_OK;
+}
+
+// pos[j] = the position of the j-th non-zero byte of mask, ascending; *count = how many (the edge dropout of a training step,
+// modules/utils.py:40-53: edges[mask] through the library's own prefix sums).  ws: ragraph_mask_positions_workspace_bytes(E).
+extern "C" size_t ragraph_mask_positions_workspace_bytes(int64_t E) {
+  if (E < 0 || E >= (int64_t)INT_MAX) return 0;
+  const int64_t M = E > 0 ? E : 1;
+  return 2 * align_up((size_t)M * 4, 256) + scan_temp_bytes(M) + 256;
+}
+
+extern "C" int ragraph_mask_positions_i64(const unsigned char* mask, int64_t E, int64_t* pos, int64_t* count, void* ws,
+                                          size_t ws_bytes, void* stream) {
+  RG_REQUIRE(count && ws && (E == 0 || (mask && pos)), RAGRAPH_EINVAL, "mask_positions: null pointer");
+  RG_REQUIRE(E >= 0 && E < (int64_t)INT_MAX, RAGRAPH_EINVAL, "mask_positions: bad E");
+  RG_REQUIRE(ws_bytes >= ragraph_mask_positions_workspace_bytes(E), RAGRAPH_EWORKSPACE, "mask_positions: workspace too small");
+  hipStream_t st = as_stream(stream);
+  if (E == 0) {
+    hipLaunchKernelGGL(fill_i64_kernel, dim3(1), dim3(256), 0, st, count, (int64_t)1, (int64_t)0);
+    RG_CHECK_LAUNCH("mask_positions");
+    return RAGRAPH_OK;
+  }
+  char* w = static_cast<char*>(ws);
+  int* flag = reinterpret_cast<int*>(w);
+  int* slot = reinterpret_cast<int*>(w + align_up((size_t)E * 4, 256));
+  void* temp = w + 2 * align_up((size_t)E * 4, 256);
+  const unsigned g = (unsigned)cdiv(E, 256);
+  hipLaunchKernelGGL(mask_flags_kernel, dim3(g), dim3(256), 0, st, mask, E, flag);
+  const int rc = scan_sum_i32(flag, slot, E, false, temp, scan_temp_bytes(E) + 256, st);
+  if (rc != RAGRAPH_OK) return rc;
+  hipLaunchKernelGGL(mask_positions_kernel, dim3(g), dim3(256), 0, st, mask, slot, E, pos, count);
+  RG_CHECK_LAUNCH("mask_positions");
   return RAGRAPH_OK;
 }

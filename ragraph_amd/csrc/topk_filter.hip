@@ -1880,6 +1880,54 @@ __global__ void __launch_bounds__(256) filter_verify_prior_kernel(const float* _
   }
 }
 
+// Sharded banks under a speculative first bound: the verdict of the rows' OWNER, behind the merge of the shards' lists.  One
+// workgroup walks the R merged rows: a row is proven iff its k-th best reaches the prior (an all-zero query -- every score +0 --
+// is answered by index order and needs no proof); out[0] = rows that missed, out[1] = -(smallest proven k-th best), out[2] =
+// the largest, out[3] = this shard's candidates per query over its levels (the call's statistics words; -1 without them),
+// out[4] = its overflowed lists: five numbers that ONE all_reduce MAX turns into the group's (ragraph_amd/sharded.py).
+__global__ void __launch_bounds__(256) verify_merged_prior_kernel(const float* __restrict__ s, int64_t R, int k, float prior,
+                                                                  int speculative, const int* __restrict__ words,
+                                                                  const int* __restrict__ overflow, float* __restrict__ out) {
+  __shared__ float red[3][4];
+  float miss = 0.f, neg_lo = RG_NEG_INF, hi = RG_NEG_INF;
+  for (int64_t q = threadIdx.x; q < R; q += 256) {
+    const float top = s[q * k], kth = s[q * k + k - 1];
+    const bool zero = top == 0.f && kth == 0.f;
+    const bool ok = zero || !speculative || kth >= prior;
+    if (!ok) miss += 1.f;
+    else if (!zero && kth > RG_NEG_INF) {
+      neg_lo = fmaxf(neg_lo, -kth);
+      hi = fmaxf(hi, kth);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    miss += __shfl_xor(miss, off);
+    neg_lo = fmaxf(neg_lo, __shfl_xor(neg_lo, off));
+    hi = fmaxf(hi, __shfl_xor(hi, off));
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[0][w] = miss;
+    red[1][w] = neg_lo;
+    red[2][w] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    out[1] = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    out[2] = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
+    float cand = -1.f;
+    if (words && words[0] == FILTER_STATS_MAGIC) {
+      cand = 0.f;
+      for (int l = 0; l < 3; ++l)
+        if (words[5 + l] > 0) cand += (float)words[2 + l] / (float)words[5 + l];
+    }
+    out[3] = cand;
+    out[4] = overflow ? (float)*overflow : 0.f;
+  }
+}
+
 // Large batches (the one-wave-per-query rescoring kernels): the final level has listed the overflowed queries, and this
 // launch -- a fixed grid that finds an empty list on ordinary banks and returns -- runs exact_scan_query for each.
 // (Below 2048 queries the workgroup-per-query rescoring kernels call it themselves and this launch is not made.)
@@ -2185,12 +2233,20 @@ static void filter_align_ends(FilterSchedule& sc, int D) {
 // n_shards > 1 (row-sharded bank, N = the largest shard): the shards pool their first samples through the exchange, so
 // the sample is planned for the WHOLE bank and every shard scans its share of the prefix.
 static int rescore_slices(int64_t B, int k);
+// Sharded banks of up to this many shards keep the SCORED lists on their int8 levels (and the schedule that goes with them):
+// a shard's own round-1 bound comes from 1 / G of the keys while the level's threshold was pooled over all shards' earlier
+// levels -- at G = 2 the shard's bound is still the sharper one (half of the bank against a quarter), from G = 4 it is not and
+// the second round only adds latency (profiles/r3_emul.txt).  RAGRAPH_FILTER_SCORED_SHARDS: A/B.
+static int filter_scored_shards() {
+  static const int v = [] { const char* e = getenv("RAGRAPH_FILTER_SCORED_SHARDS"); return e ? atoi(e) : 2; }();
+  return v;
+}
 static FilterSchedule filter_schedule(int64_t B, int64_t N, int D, int k, int n_shards = 1) {
   FilterSchedule sc{};
   const int cap = 2048;
   // scored lists (one bank, >= 2048 queries): an int8 level's rescoring fetches about a third of its candidates' rows, which
   // makes int8 pay on EVERY level (the bench step, 2 / 3 int8 levels: 24.3 / 23.85 ms; without the scores 26.9 / 27.7)
-  const bool scored = n_shards == 1 && B >= 2048 && filter_scored_lists(B, D, k);  // (below 2048 queries the plain lists' plans
+  const bool scored = (n_shards == 1 || n_shards <= filter_scored_shards()) && B >= 2048 && filter_scored_lists(B, D, k);  // (below 2048 queries the plain lists' plans
                                                                                    // stay: a smaller first sample measured slower)
   // (the model's price of an int8 candidate under scored lists, relative to the plain lists'; fitted: 0.6 moves 8192+ queries
   // x 1M keys from two levels to three, all int8 -- 8192: 2.37 -> 2.33 ms, 16384: 4.30 -> 4.13 -- while 0.45 also shrank the
@@ -2928,6 +2984,31 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   hipStream_t st = as_stream(stream);
   const int cap = filter_cap(B, k);
   FilterSchedule sc = filter_schedule(B, plan_N, D, k, exchange ? n_shards : 1);  // (sharded banks: the same schedule on every shard)
+  // A speculative first bound (this thread's prior).  Sharded banks: whether the call speculates must be the SAME decision on
+  // every rank -- it removes the bound pass AND its exchange (phase 0) --, so it is taken from what every rank shares: the
+  // prior (the caller derives it from pooled statistics and sets it on every rank alike) and the PLAN's bound pass (plan_N),
+  // before any adjustment to this shard's own length.  The proof is the caller's too: a query is exact iff the k-th best of
+  // the MERGED lists reaches the prior (ragraph_amd/sharded.py verifies at the rows' owner and re-runs without the prior).
+  const float prior = t_prior;
+  const bool prior_ok = prior == prior && prior > -2.f && prior < 2.f;
+  const bool spec_x = exchange && prior_ok && sc.bound_keys > 0;
+  if (spec_x && sc.nlev == 2 && B <= 4096) {  // (as below for one bank: the prior IS the bound a first level would give)
+    sc.nlev = 1;
+    sc.ends[0] = plan_N;
+    if (sc.i8_levels > 1) sc.i8_levels = 1;
+  }
+  // Three levels under the prior, many shards: the first level (1 / 32 of the shard) exists to sharpen the bound pass's
+  // bound, and under the group's prior it passes about ONE candidate per query and shard (measured, 8 shards of the 1M bank) --
+  // a filter launch on the bf16 copy, a rescoring launch over every query and an exchange for nothing.  From
+  // RAGRAPH_FILTER_SPEC_SHARDS_TWO_LEVELS shards (default 2: every sharded bank; 0 = never) the call runs levels [0, N / 4) and
+  // [N / 4, N): emulated rank of 2 / 4 / 8, ms per step: 11.14 -> 10.83, 6.29 -> 5.92, 3.73 -> 3.46 (profiles/r6_multi_one_gpu.txt).
+  static const int spec_two = [] { const char* e = getenv("RAGRAPH_FILTER_SPEC_SHARDS_TWO_LEVELS"); return e ? atoi(e) : 2; }();
+  if (spec_x && sc.nlev == 3 && spec_two > 0 && n_shards >= spec_two) {
+    sc.ends[0] = sc.ends[1];
+    sc.ends[1] = sc.ends[2];
+    sc.nlev = 2;
+    if (sc.i8_levels > 2) sc.i8_levels = 2;
+  }
   // A shard SHORTER than the largest one (shards of a bank whose exact duplicates were collapsed per shard hold different
   // numbers of unique rows): the same phases -- the exchanges must line up across the ranks -- over proportionally fewer
   // keys; a shard too short for that structure takes part as an EXACT participant: its fp32 top-k once, offered at every
@@ -2959,8 +3040,8 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
     FilterThr t0{};
     t0.prev_scores = out_scores;
     t0.k = k;
-    for (int ph = 0; ph < sc.nlev; ++ph) {   // phase 0 + one exchange behind every level but the last
-      hipLaunchKernelGGL(filter_theta_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, t0, B, ph == 0 ? 1 : 0, theta);
+    for (int ph = spec_x ? 1 : 0; ph < sc.nlev; ++ph) {   // phase 0 (not under a speculative bound) + one exchange behind every level but the last
+      hipLaunchKernelGGL(filter_theta_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, t0, B, ph == (spec_x ? 1 : 0) ? 1 : 0, theta);
       RG_CHECK_LAUNCH("topk_cosine_filtered(theta)");
       exchange(ctx, ph);
     }
@@ -2998,13 +3079,12 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   // a speculative first bound (this thread's prior; single banks whose schedule has a bound pass to save): no bound pass,
   // theta = prior for every query, every level filters with max(prior, the running k-th best), and the verify launch
   // behind the last level sends the queries the prior was too high for to the exact scan
-  const float prior = t_prior;
-  const bool spec = !exchange && sc.bound_keys > 0 && prior == prior && prior > -2.f && prior < 2.f && N == plan_N;
+  const bool spec = exchange ? spec_x : (sc.bound_keys > 0 && prior_ok && N == plan_N);
   const bool bound = sc.bound_keys > 0 && !spec;
   // A first level exists to give the second a tighter bound than the bound pass could; the prior already is one.  Measured
   // with it (1M x 256, ms per call, two levels / one): 2048 queries 0.544 / 0.512, 4096: 0.920 / 0.898 -- but 16 384: 3.18 /
   // 3.85, and the three levels of 100 000 queries stay (20.5 ms per step against 22.8 with two): up to 4096 queries one level.
-  if (spec && sc.nlev == 2 && B <= 4096) {
+  if (spec && !exchange && sc.nlev == 2 && B <= 4096) {
     sc.nlev = 1;
     sc.ends[0] = N;
     if (sc.i8_levels > 1) sc.i8_levels = 1;
@@ -3020,9 +3100,11 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   // one launch: normalised queries, their bf16 rounding errors, empty lists, clear flags (+ group maxima at -inf)
   hipLaunchKernelGGL(filter_prep_kernel<D>, dim3((unsigned)cdiv(B <= FILTER_QB_MAX_B ? (B + 31) / 32 * 32 : B, 4)), dim3(256), 0, st, Q, B,
                      f.Qn, f.eq, f.count, f.flag, overflow, bound ? f.gmax : nullptr, bound ? filter_bound_parts(k, sc.bound_keys, D, B, exchange ? n_shards : 1) : k,
-                     B <= FILTER_QB_MAX_B ? f.Qb : nullptr,
+                     // (the bf16 operand image: only launches on the bf16 copy read it -- a call whose levels all run on the int8
+                     // copy and that has no bound pass, e.g. every call under a prior, saves writing 2 D bytes per query)
+                     B <= FILTER_QB_MAX_B && (B <= 256 || bound || sc.nlev > sc.i8_levels) ? f.Qb : nullptr,
                      filter_count_stride(B), sc.i8_levels > 0 ? f.eq8 : nullptr, f.qscale, B <= FILTER_QB_MAX_B ? f.Qb8 : nullptr, f.fix_done,
-                     stats, stats_init, spec ? f.theta : nullptr, prior);
+                     stats, stats_init, spec ? (exchange ? theta : f.theta) : nullptr, prior);
   RG_CHECK_LAUNCH("topk_cosine_filtered(prepare)");
 
   FilterThr thr{};
@@ -3062,7 +3144,9 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
                                       stream);
   }
   if (rc != RAGRAPH_OK) return rc;
-  if (exchange) {  // the first bound leaves through theta / out_scores, and comes back as a bound on the k-th best of ALL shards
+  if (exchange && spec) {  // theta = the prior on every shard (the prepare launch wrote it): nothing to pool, no phase 0
+    thr.theta = theta;
+  } else if (exchange) {  // the first bound leaves through theta / out_scores, and comes back as a bound on the k-th best of ALL shards
     thr.gmax = bound ? f.gmax : nullptr;
     thr.prev_scores = out_scores;
     if (bound)  // k lower bounds of distinct keys' exact scores, descending, where a level leaves its exact top-k
@@ -3087,8 +3171,7 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
     // anything round 1 can find among this shard's keys, so nothing is pruned and only the second round's latency and the
     // 16-row tiles' occupancy are lost: emulated rank of 2 / 4 / 8 GPUs 13.49 -> 13.26 / 7.61 -> 8.00 / 4.76 -> 5.24 ms per
     // step, profiles/r3_emul.txt.  RAGRAPH_FILTER_SCORED_SHARDS = largest shard count that takes them: A/B.)
-    static const int scored_shards = [] { const char* e = getenv("RAGRAPH_FILTER_SCORED_SHARDS"); return e ? atoi(e) : 0; }();
-    const bool scored = i8_level && (!exchange || n_shards <= scored_shards) && filter_scored_lists(B, D, k);
+    const bool scored = i8_level && (!exchange || n_shards <= filter_scored_shards()) && filter_scored_lists(B, D, k);
     rc = run_bf16_pass<D>(f, Kb, B, key0, sc.ends[l], thr, cap, 0, l, st, i8_level ? Kb8 : nullptr, scored);
     if (t_prof) {
       t_prof->i8[l] = l >= sc.nlev - sc.i8_levels;
@@ -3120,7 +3203,7 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
                         &fallback_done, exchange != nullptr && l > 0, st, scored ? &thr : nullptr, l < 3 ? stats + 2 + l : nullptr);
     if (rc != RAGRAPH_OK) return rc;
     key0 = sc.ends[l];
-    if (spec && l + 1 < sc.nlev) {  // the next level filters with max(prior, the exact k-th best so far)
+    if (spec && !exchange && l + 1 < sc.nlev) {  // the next level filters with max(prior, the exact k-th best so far)
       FilterThr t2 = thr;
       t2.gmax = nullptr;
       t2.theta = nullptr;
@@ -3138,7 +3221,7 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
   }
   // overflowed queries (none on ordinary banks): exact fp32 scan on the device -- no host read-back (the sliced
   // rescoring of a handful of queries has done it inside its merge launch)
-  if (spec) {
+  if (spec && !exchange) {   // (a shard's lists prove nothing alone: the owner of a row verifies the MERGED k-th best)
     hipLaunchKernelGGL(filter_verify_prior_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, out_scores, B, k, prior, 1, f.flag,
                        overflow, f.overflow_list, stats);
     RG_CHECK_LAUNCH("topk_cosine_filtered(verify)");
@@ -3193,6 +3276,21 @@ extern "C" int ragraph_topk_cosine_filtered_sharded_f32(const float* Q, int64_t 
                                                         void* ctx, int n_shards) {
   return filtered_entry(Q, B, Kn, Kp, Kb, N, D, k, idx_base, out_scores, out_idx, overflow, overflow_idx, ws, ws_bytes, stream,
                         plan_N, theta, exchange, ctx, n_shards);
+}
+
+extern "C" int ragraph_topk_cosine_filtered_sharded_speculates(int64_t B, int64_t plan_N, int D, int k, int n_shards) {
+  if (!filter_dim_ok(D) || B < 1 || plan_N < 1 || k < 1 || k > 32 || n_shards < 1) return 0;
+  return filter_schedule(B, plan_N, D, k, n_shards).bound_keys > 0 ? 1 : 0;
+}
+
+extern "C" int ragraph_verify_merged_prior_f32(const float* merged_scores, int64_t R, int k, float prior, int speculative,
+                                               const int* stats_words, const int* overflow, float* out5, void* stream) {
+  RG_REQUIRE(out5 && (merged_scores || R == 0), RAGRAPH_EINVAL, "verify_merged_prior: null pointer");
+  RG_REQUIRE(R >= 0 && k >= 1, RAGRAPH_EINVAL, "verify_merged_prior: bad R/k");
+  hipLaunchKernelGGL(verify_merged_prior_kernel, dim3(1), dim3(256), 0, as_stream(stream), merged_scores, R, k, prior, speculative,
+                     stats_words, overflow, out5);
+  RG_CHECK_LAUNCH("verify_merged_prior");
+  return RAGRAPH_OK;
 }
 
 extern "C" int ragraph_theta_sharpen_f32(const float* gathered, int G, int64_t B, int m, int k, float* theta, void* stream) {

@@ -199,6 +199,26 @@ def filtered_i8_levels(B: int, n_keys: int, D: int, k: int) -> int:
     return N.lib().ragraph_topk_cosine_filtered_i8_levels(B, n_keys, D, k)
 
 
+def sharded_speculates(B: int, plan_n: int, D: int, k: int, n_shards: int) -> bool:
+    """Would a sharded filtered call of this shape skip its bound pass and exchange 0 under a speculative prior?  (The same
+    answer on every rank: computed from the shared plan.)"""
+    return bool(N.lib().ragraph_topk_cosine_filtered_sharded_speculates(B, plan_n, D, k, n_shards))
+
+
+def verify_merged_prior(merged_scores: torch.Tensor, prior, stats=None, overflow=None) -> torch.Tensor:
+    """The owner's verdict on the merged lists of a sharded call (ragraph_verify_merged_prior_f32): a [5] float32 device
+    tensor [missed rows, -(lowest proven k-th best), highest, candidates per query of this shard, overflowed lists]."""
+    L = _ready()
+    ms = _f32c(merged_scores, "verify_merged_prior.scores")
+    R, k = ms.shape
+    out = torch.empty(5, dtype=torch.float32, device=ms.device)
+    N.check(L.ragraph_verify_merged_prior_f32(ms.data_ptr() if R else None, R, k, 0.0 if prior is None else float(prior),
+                                              0 if prior is None else 1, stats.data_ptr() if stats is not None else None,
+                                              overflow.data_ptr() if overflow is not None else None, out.data_ptr(), _stream()),
+            "verify_merged_prior")
+    return out
+
+
 def set_filter_prior(theta_prior) -> float:
     """A speculative first bound for this thread's following filtered calls (None / NaN: none); returns the old one.
     ragraph_topk_cosine_filtered_set_prior: exact for any value -- queries it is too high for take the exact scan."""
@@ -1113,6 +1133,23 @@ def csr_row_ids(rowptr: torch.Tensor, nnz: int) -> torch.Tensor:
     N.check(L.ragraph_csr_row_ids_i64(rp.data_ptr(), rp.numel() - 1, nnz, rows.data_ptr() if nnz else None, _stream()),
             "csr_row_ids")
     return rows
+
+
+def mask_positions(mask: torch.Tensor) -> torch.Tensor:
+    """Positions of the set elements of a bool / uint8 mask, ascending (ragraph_mask_positions_i64) -- x[mask] as
+    x[mask_positions(mask)] without another library's select.  Reads the count back (one synchronisation, as boolean
+    indexing does)."""
+    L = _ready()
+    if not mask.is_cuda or mask.dtype not in (torch.bool, torch.uint8):
+        raise RagraphNativeError("mask_positions: expected a bool / uint8 ROCm device tensor")
+    m = mask.contiguous().view(torch.uint8).reshape(-1)
+    E = m.numel()
+    pos = torch.empty(E, dtype=torch.int64, device=m.device)
+    count = torch.empty(1, dtype=torch.int64, device=m.device)
+    ws = _workspace(L.ragraph_mask_positions_workspace_bytes(E), m.device)
+    N.check(L.ragraph_mask_positions_i64(m.data_ptr() if E else None, E, pos.data_ptr() if E else None, count.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), _stream()), "mask_positions")
+    return pos[:int(count.item())]
 
 
 def binorm_edges(users: torch.Tensor, items: torch.Tensor, step: torch.Tensor, num_users: int, num_items: int):

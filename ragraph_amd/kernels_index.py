@@ -95,6 +95,7 @@ class KeyIndex:
         self._notes = 0                  # calls offered to _note_overflow (small calls report every fourth once settled)
         self.last_stats = None           # device view of the last filtered call's statistics words (this index, this stream)
         self.last_prior = None           # the speculative first bound the last filtered call ran with (None: a bound pass)
+        self.last_over = None            # sharded calls: the last call's overflow count (device int; the owner of the bank reads it)
         # None: duplicates not looked at yet; False: looked at, searched as it is; else (KeyIndex over the unique rows,
         # group_ptr, members)
         self._collapsed = None if dedup else False
@@ -322,11 +323,23 @@ class KeyIndex:
         cap(-1 if allowed else 0)
         return cap, allowed
 
-    def topk(self, q: torch.Tensor, k: int, idx_base: int = 0, exchange=None, plan_n: int = 0):
+    def sharded_speculates(self, B: int, k: int, plan_n: int, n_shards: int) -> bool:
+        """Would topk(..., exchange, plan_n, prior) of B queries skip its bound pass and exchange 0?  Taken from what every
+        rank shares (B, k, the padded width, plan_n, the shard count): the same answer on every rank."""
+        ops = self.ops
+        if self._width is None or getattr(ops, "set_filter_prior", None) is None or getattr(ops, "sharded_speculates", None) is None:
+            return False
+        fhelps = getattr(ops, "filter_helps", None)
+        if fhelps is None or B > self.MAX_FILTERED_BATCH or not fhelps(B, plan_n, self._width, k):
+            return False
+        return bool(ops.sharded_speculates(B, plan_n, self._width, k, n_shards))
+
+    def topk(self, q: torch.Tensor, k: int, idx_base: int = 0, exchange=None, plan_n: int = 0, prior=None):
         """exchange / plan_n: this index holds one shard of a row-sharded bank (ShardedToyGraphBase): the filtered path
         sharpens its per-query bounds across the shards through `exchange` (kernels.topk_cosine_filtered), and every
         decision that changes which collectives run is taken from plan_n -- the largest shard's size -- so that all
-        ranks take it alike."""
+        ranks take it alike.  prior (with exchange only): the speculative first bound the owner of the sharded bank chose for
+        THIS call on every rank alike (it removes the bound pass and exchange 0; the owner proves the merged rows)."""
         ops, kn = self.ops, self.keys_normalized
         if q.shape[1] != self.dim:
             raise ValueError(f"KeyIndex.topk: queries of {q.shape[1]} columns against a bank of {self.dim}")
@@ -347,7 +360,7 @@ class KeyIndex:
                 # one shard of a row-sharded bank: the unique rows take part in the exchanges (plan_n = the largest number of
                 # searched rows over the shards -- ShardedToyGraphBase asks search_rows() of every rank); the shard's list
                 # (padded with -inf / INT64_MAX where nothing can reach the global top-k any more) is expanded to bank rows
-                su, iu = inner.topk(q, k, 0, exchange, plan_n)
+                su, iu = inner.topk(q, k, 0, exchange, plan_n, prior)
                 return ops.topk_expand_groups(su, iu, group_ptr, members, k, idx_base=idx_base)
             raise RuntimeError("KeyIndex: a collapsed shard of fewer unique rows than k cannot take part in the exchanges; "
                                "ShardedToyGraphBase keeps such a shard uncollapsed (search_rows(min_unique=k))")
@@ -357,16 +370,21 @@ class KeyIndex:
                 if self._bf16 is None:
                     self._bf16 = ops.keys_to_bf16(kn)
                 cap, _ = self._cap_i8()   # (per shard: which kernel a level runs on does not change the exchanges)
+                if prior is not None:
+                    ops.set_filter_prior(prior)
                 try:
                     if getattr(ops, "FILTER_STATS", False):
-                        s, i, _, self.last_stats = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base,
-                                                                            exchange=exchange, plan_n=plan_n, return_stats=True)
+                        s, i, self.last_over, self.last_stats = ops.topk_cosine_filtered(
+                            q, kn, self._bf16, k, idx_base=idx_base, exchange=exchange, plan_n=plan_n, return_stats=True)
                     else:
-                        s, i, _ = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base, exchange=exchange,
-                                                           plan_n=plan_n)
+                        s, i, self.last_over = ops.topk_cosine_filtered(q, kn, self._bf16, k, idx_base=idx_base,
+                                                                        exchange=exchange, plan_n=plan_n)
                 finally:
                     if cap is not None:
                         cap(-1)
+                    if prior is not None:
+                        ops.set_filter_prior(None)
+                self.last_prior = prior
                 return s, i
             fhelps = None  # (fp32 kernels: the shard's own exact top-k, no exchange needed)
         self._poll_overflow()

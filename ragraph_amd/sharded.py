@@ -192,17 +192,90 @@ class HybridLayout:
         return qlo, qhi, lo, hi
 
     @staticmethod
-    def retrieve_reduced_rows(qs: "QueryShard", tgb: "ShardedToyGraphBase", search_keys, k=None):
+    def retrieve_reduced_rows(qs: "QueryShard", tgb: "ShardedToyGraphBase", search_keys, k=None, defer_verify: bool = False):
         """(sum_k V[idx], mean_k L[idx], idx) of MY rows of the batch: my group's slice of the queries against the group's
         key shards (exchanges and the all_to_all stay inside the key group)."""
         qlo, qhi = qs.bounds(search_keys.shape[0])
-        return tgb.retrieve_reduced_rows(search_keys[qlo:qhi].contiguous(), k)
+        return tgb.retrieve_reduced_rows(search_keys[qlo:qhi].contiguous(), k, defer_verify=defer_verify)
 
     @staticmethod
     def gather_output_rows(qs: "QueryShard", tgb: "ShardedToyGraphBase", local: torch.Tensor, B: int) -> torch.Tensor:
         """[hi - lo, C] per rank -> [B, C] on every rank: the key group's rows first, then the query groups' slices."""
         qlo, qhi = qs.bounds(B)
         return qs.gather_rows(tgb.gather_output_rows(local, qhi - qlo), B)
+
+
+class GroupPrior:
+    """The speculative first bound of a row-sharded bank's filtered calls: ONE decision per call for the whole group of ranks.
+    Every rank keeps this object and feeds it the same numbers -- the pooled statistics of each call (all_reduce MAX of
+    [misses, -lowest, highest merged k-th best, candidates per query, overflowed lists]) --, so every rank derives the same
+    prior, withdraws it at the same call and re-probes at the same call: the number of exchanges of a call (the prior removes
+    phase 0) can never differ between ranks.  The policy is KeyIndex's (ragraph_amd/kernels_index.py), on a clock of calls:
+    warm after WARM_CALLS calls with a bound pass, prior = lowest seen - max(MARGIN x spread, MIN_MARGIN); a call that reports a
+    miss, overflowed lists or a flood of candidates withdraws it for `after` calls (a failed re-probe quadruples that)."""
+    WARM_CALLS = 2
+    MARGIN = 0.5
+    MIN_MARGIN = 0.01
+    HISTORY = 16
+    REPROBE_CALLS = 64
+    MAX_CANDIDATES = 1.5
+    MIN_BATCH = 17
+
+    def __init__(self, enabled: bool = True):
+        import os
+        self.enabled = enabled and os.environ.get("RAGRAPH_SPEC", "1") != "0"
+        self.forced = None            # tests: a prior to use whatever the history says (None: the policy)
+        self._st = {}
+        self.calls = 0                # the clock: filtered calls of the group so far
+        self.used = self.missed_calls = 0
+
+    def _state(self, k):
+        st = self._st.get(k)
+        if st is None:
+            st = self._st[k] = {"hist": [], "off_at": None, "after": self.REPROBE_CALLS, "cand": None, "probed_at": None}
+        return st
+
+    def prior_for(self, B: int, k: int):
+        if self.forced is not None:
+            return float(self.forced)
+        if not self.enabled or B < self.MIN_BATCH:
+            return None
+        st = self._state(k)
+        if st["off_at"] is not None:
+            if self.calls - st["off_at"] < st["after"]:
+                return None
+            st["off_at"] = None
+            st["probed_at"] = self.calls
+        if len(st["hist"]) < self.WARM_CALLS:
+            return None
+        lo = min(h[0] for h in st["hist"])
+        hi = max(h[1] for h in st["hist"])
+        return lo - max(self.MARGIN * (hi - lo), self.MIN_MARGIN)
+
+    def record(self, k: int, speculative: bool, misses: int, lo: float, hi: float, cand: float, lists_over: int) -> bool:
+        """One call's pooled statistics.  Returns True when the call's result stands (no query missed the prior)."""
+        self.calls += 1
+        st = self._state(k)
+        have = lo <= hi and lo != float("inf")
+        if lists_over:
+            st["hist"] = []
+        elif have and not (speculative and misses):
+            st["hist"].append((lo, hi))
+            del st["hist"][:-self.HISTORY]
+        if not speculative:
+            if cand >= 0 and not lists_over:
+                st["cand"] = cand
+            return True
+        self.used += 1
+        loose = cand >= 0 and st["cand"] is not None and cand > self.MAX_CANDIDATES * max(st["cand"], 32.0)
+        if misses or loose or lists_over:
+            if st["probed_at"] is not None and self.calls - st["probed_at"] < st["after"]:
+                st["after"] = min(st["after"] * 4, 1 << 40)
+            st["off_at"] = self.calls
+            if misses:
+                st["hist"] = []
+                self.missed_calls += 1
+        return misses == 0
 
 
 class ShardedToyGraphBase:
@@ -234,6 +307,11 @@ class ShardedToyGraphBase:
         self.emulate_world = int(emulate_world)
         self._out_shard = None
         self.exchange_count = {}   # phase -> how many exchanges of that phase this rank has taken part in (diagnostic)
+        self.prior = GroupPrior()  # the speculative first bound: one decision per call for the whole group
+        self._pending = None       # (pinned words, event, k, speculative) of a call whose verification was deferred
+        self.reruns = 0            # calls repeated without the prior because a query missed it (diagnostic)
+        self._suppress = False     # the next call runs without a prior (it repeats a call that missed)
+        self._verify_scores = None
 
         def exchange_fn(phase, theta, scores):
             return self._exchange(phase, theta, scores)
@@ -279,6 +357,90 @@ class ShardedToyGraphBase:
             all_gather_into(gathered.view(G * B, m), local, self.group)
         self.ops.theta_sharpen(gathered, theta, k)
 
+    # ---- the speculative first bound of a sharded call: chosen, proven and withdrawn by the whole group ------------------
+    def _choose_prior(self, B: int, k: int):
+        """The prior of THIS call (None: a bound pass), the same on every rank: GroupPrior's state is fed pooled numbers
+        only, and whether the shape speculates at all comes from the shared plan."""
+        G = self.emulate_world if self.emulate_world > 1 else self.world
+        spec = getattr(self._index.search_index if hasattr(self._index, "search_index") else self._index, "sharded_speculates", None)
+        if self._suppress:          # (the repeat of a call whose prior a query missed: decided by confirm() on every rank alike)
+            self._suppress = False
+            return None
+        if spec is None or not spec(B, k, self.plan_n, G):
+            return None
+        return self.prior.prior_for(B, k)
+
+    def _post_verify(self, merged_s, k: int, prior, defer: bool) -> bool:
+        """Behind the merge: this rank's rows' merged k-th best scores against the prior (a row is proven iff it reaches the
+        prior; an all-zero query -- every score +0 -- is answered by index order and needs no proof), the smallest / largest of
+        them, this shard's candidates per query and overflowed lists; ONE all_reduce MAX of five floats makes them the group's.
+        The words travel to a pinned buffer behind an event: confirm() reads them (at once unless `defer`)."""
+        speculative = prior is not None
+        if self._verify_scores is not None:   # (emulation: see _topk_rows_once)
+            merged_s, self._verify_scores = self._verify_scores, None
+        ix = self._index.search_index if hasattr(self._index, "search_index") else self._index
+        native = getattr(self.ops, "verify_merged_prior", None)
+        if native is not None and merged_s.is_cuda:   # one launch (csrc/topk_filter.hip: verify_merged_prior_kernel)
+            st, ov = getattr(ix, "last_stats", None), getattr(ix, "last_over", None)
+            words = native(merged_s, prior, st if torch.is_tensor(st) else None, ov if torch.is_tensor(ov) else None)
+        else:                                          # the same five numbers with torch ops (the CPU tests' oracle shim)
+            kth, top = merged_s[:, k - 1], merged_s[:, 0]
+            zero = (top == 0) & (kth == 0)
+            ok = zero | (kth >= prior) if speculative else torch.ones_like(zero)
+            live = ok & ~zero & (kth > float("-inf"))
+            inf = torch.full_like(kth, float("inf"))
+            none = torch.tensor(float("-inf"), device=merged_s.device)   # (a rank without rows of this batch)
+            words = torch.stack([(~ok).sum().to(torch.float32),
+                                 -torch.where(live, kth, inf).min() if kth.numel() else none,
+                                 torch.where(live, kth, -inf).max() if kth.numel() else none,
+                                 self._cand_per_query(merged_s.device), self._lists_over(merged_s.device)])
+        if self.collective:
+            all_reduce(words, dist.ReduceOp.MAX, self.group)
+        if words.is_cuda:
+            if getattr(self, "_host_words", None) is None:
+                self._host_words = torch.zeros(5, dtype=torch.float32).pin_memory()
+                self._event = torch.cuda.Event()
+            self._host_words.copy_(words, non_blocking=True)
+            self._event.record()
+            self._pending = (self._host_words, self._event, k, speculative)
+        else:
+            self._pending = (words, None, k, speculative)
+        return True if defer else self.confirm()
+
+    def _cand_per_query(self, device):
+        ix = self._index.search_index if hasattr(self._index, "search_index") else self._index
+        st = getattr(ix, "last_stats", None)
+        if st is None or not torch.is_tensor(st) or st.numel() < 8:
+            return torch.tensor(-1.0, device=device)
+        w = st[:8].to(torch.float32)
+        return (w[2:5] / w[5:8].clamp(min=1.0)).sum()
+
+    def _lists_over(self, device):
+        ix = self._index.search_index if hasattr(self._index, "search_index") else self._index
+        ov = getattr(ix, "last_over", None)
+        if ov is None or not torch.is_tensor(ov):
+            return torch.tensor(0.0, device=device)
+        return ov.reshape(-1)[0].to(device=device, dtype=torch.float32)
+
+    def confirm(self) -> bool:
+        """The pooled verdict on the last sharded call: True = its result stands.  False = a query's merged k-th best fell
+        below the speculative prior somewhere in the group: EVERY rank sees the same words, withdraws the prior and repeats
+        the call (the caller does: topk / topk_rows themselves unless asked to defer)."""
+        p = self._pending
+        if p is None:
+            return True
+        self._pending = None
+        if p[1] is not None:
+            p[1].synchronize()
+        w = [float(x) for x in p[0].tolist()]
+        if self.emulate_world > 1:
+            w[0] = 0.0   # (timing only: the same launches, no verdict -- an emulated rank's lists are one shard's, not the group's)
+        ok = self.prior.record(p[2], p[3], int(w[0]), -w[1], w[2], w[3], int(w[4]))
+        if not ok:
+            self.reruns += 1
+            self._suppress = True
+        return ok
+
     def topk(self, search_keys, k=None):
         """Global canonical top-k: (scores [B,k], idx [B,k]) identical on every rank."""
         k = self.retrieve_num if k is None else k
@@ -286,15 +448,26 @@ class ShardedToyGraphBase:
         n_local = self.keys_normalized.shape[0]
         kl = min(k, n_local)
         sharded = self.collective or self.emulate_world > 1
-        s, i = self._index.topk(q, kl, idx_base=self.idx_base, exchange=self._exchange_fn if sharded and kl == k else None,
-                                plan_n=self.plan_n)
+        exch = self._exchange_fn if sharded and kl == k else None
+        prior = self._choose_prior(q.shape[0], k) if exch is not None else None
+        s, i = self._topk_all(q, k, kl, exch, prior)
+        if exch is not None and not self._post_verify(s, k, prior, defer=False):
+            self._suppress = False
+            s, i = self._topk_all(q, k, kl, exch, None)   # (withdrawn on every rank alike: a bound pass)
+            self._post_verify(s, k, None, defer=False)
+        return s, i
+
+    def _topk_all(self, q, k, kl, exch, prior):
+        sharded = self.collective or self.emulate_world > 1
+        s, i = self._index.topk(q, kl, idx_base=self.idx_base, exchange=exch, plan_n=self.plan_n, prior=prior)
         if kl < k:  # a shard smaller than k: pad with sentinels that lose every comparison
             pad_s = torch.full((q.shape[0], k - kl), float("-inf"), dtype=s.dtype, device=s.device)
             pad_i = torch.full((q.shape[0], k - kl), torch.iinfo(torch.int64).max, dtype=i.dtype, device=i.device)
             s, i = torch.cat([s, pad_s], 1), torch.cat([i, pad_i], 1)
         if self.emulate_world > 1:  # (timing only) the merge launch a real rank would run over the G gathered lists
             G = self.emulate_world
-            self.ops.topk_merge(s.unsqueeze(0).expand(G, *s.shape).contiguous(), i.unsqueeze(0).expand(G, *i.shape).contiguous())
+            self._verify_scores, _ = self.ops.topk_merge(s.unsqueeze(0).expand(G, *s.shape).contiguous(),
+                                                         i.unsqueeze(0).expand(G, *i.shape).contiguous())
             return s, i
         if not self.collective:
             return s, i
@@ -316,8 +489,10 @@ class ShardedToyGraphBase:
         G = self.emulate_world if self.emulate_world > 1 else self.world
         return shard_bounds(B, G, 0 if self.emulate_world > 1 else self.rank)
 
-    def topk_rows(self, search_keys, k=None):
-        """Global canonical top-k of THIS RANK'S rows of the batch: (scores, idx) [hi - lo, k], (lo, hi) = tail_bounds."""
+    def topk_rows(self, search_keys, k=None, defer_verify: bool = False):
+        """Global canonical top-k of THIS RANK'S rows of the batch: (scores, idx) [hi - lo, k], (lo, hi) = tail_bounds.
+        defer_verify: the caller enqueues more work first and calls confirm() itself before it hands out anything -- when that
+        returns False it repeats this call (RAGraph._forward_key_shard / _forward_hybrid)."""
         k = self.retrieve_num if k is None else k
         q = search_keys.reshape(1, -1) if search_keys.dim() == 1 else search_keys
         B = q.shape[0]
@@ -327,11 +502,24 @@ class ShardedToyGraphBase:
         if not sharded or min(k, n_local) < k:
             s, i = self.topk(q, k)
             return s[lo:hi].contiguous(), i[lo:hi].contiguous()
-        s, i = self._index.topk(q, k, idx_base=self.idx_base, exchange=self._exchange_fn, plan_n=self.plan_n)
+        prior = self._choose_prior(B, k)
+        ms, mi = self._topk_rows_once(q, k, lo, hi, prior)
+        if not self._post_verify(ms, k, prior, defer=defer_verify):
+            self._suppress = False
+            ms, mi = self._topk_rows_once(q, k, lo, hi, None)   # (withdrawn on every rank alike: a bound pass)
+            self._post_verify(ms, k, None, defer=False)
+        return ms, mi
+
+    def _topk_rows_once(self, q, k, lo, hi, prior):
+        B = q.shape[0]
+        s, i = self._index.topk(q, k, idx_base=self.idx_base, exchange=self._exchange_fn, plan_n=self.plan_n, prior=prior)
         if self.emulate_world > 1:  # (timing only) the merge a real rank runs over the G lists of its rows
             G = self.emulate_world
             ss, ii = s[lo:hi], i[lo:hi]
-            self.ops.topk_merge(ss.unsqueeze(0).expand(G, *ss.shape).contiguous(), ii.unsqueeze(0).expand(G, *ii.shape).contiguous())
+            # (the verdict on the prior is taken on what the merge returns, as on a real rank: G copies of this shard's list
+            # stand in for the other shards' -- a shard's own list under the pooled bound is far shorter than k)
+            self._verify_scores, _ = self.ops.topk_merge(ss.unsqueeze(0).expand(G, *ss.shape).contiguous(),
+                                                         ii.unsqueeze(0).expand(G, *ii.shape).contiguous())
             return ss.contiguous(), ii.contiguous()
         G = self.world
         bounds = [shard_bounds(B, G, r) for r in range(G)]
@@ -343,11 +531,11 @@ class ShardedToyGraphBase:
         all_to_all_single(gi, i.contiguous(), recv, send, self.group)
         return self.ops.topk_merge(gs.view(G, hi - lo, k), gi.view(G, hi - lo, k))
 
-    def retrieve_reduced_rows(self, search_keys, k=None):
+    def retrieve_reduced_rows(self, search_keys, k=None, defer_verify: bool = False):
         """(sum_k V[idx], mean_k L[idx], idx) for this rank's rows of the batch (values replicated)."""
         if not self.values_replicated:
             raise ValueError("retrieve_reduced_rows: needs the values / labels replicated on every rank")
-        _, idx = self.topk_rows(search_keys, k)
+        _, idx = self.topk_rows(search_keys, k, defer_verify=defer_verify)
         sum_v, mean_l = self.ops.gather_reduce(self.resource_values, self.resource_labels, idx)
         return sum_v, mean_l, idx
 

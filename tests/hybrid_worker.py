@@ -54,6 +54,20 @@ def main():
         res["q_s"] = [layout.q, layout.s]
         res["hybrid_forward_equal"] = bool(torch.equal(got, want))
         res["exchange_count"] = {str(p): c for p, c in tgb.exchange_count.items()}
+        # round 6: a FORCED speculative first bound that exactly one row of the batch misses (the midpoint of the two lowest
+        # k-th best scores): only the key group that answers that row repeats its retrieval -- the decision is the group's --,
+        # and the gathered output is still the single-process forward on every rank
+        with torch.no_grad():
+            h = pre.inference(feats, adj)
+        full_s, _ = K.KeyIndex(Kb).topk(h, k)
+        two = torch.sort(full_s[:, k - 1]).values[:2]
+        tgb.prior.forced = float(0.5 * (two[0] + two[1]))
+        r0 = tgb.reruns
+        with torch.no_grad():
+            got2 = model(feats, adj)
+        tgb.prior.forced = None
+        res["forced_one_forward_equal"] = bool(torch.equal(got2, want))
+        res["forced_one_reruns"] = int(tgb.reruns - r0)
         res["world"] = dist.get_world_size()
         torch.cuda.synchronize()
         dist.barrier()

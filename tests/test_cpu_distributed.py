@@ -64,6 +64,17 @@ class FilteredOracleOps(OracleOps):
     invalid (too high) bound, winners would be dropped and the merged result would differ from the single-GPU one."""
 
     calls = 0
+    _prior = None          # ragraph_topk_cosine_filtered_set_prior's thread-local, restated
+    spec_calls = 0         # calls that ran under a speculative first bound (no phase 0)
+
+    @classmethod
+    def set_filter_prior(cls, p):
+        old, cls._prior = cls._prior, p
+        return old
+
+    @staticmethod
+    def sharded_speculates(B, plan_n, D, k, n_shards):
+        return True
 
     @staticmethod
     def filter_helps(B, n_keys, D, k):
@@ -94,12 +105,18 @@ class FilteredOracleOps(OracleOps):
             return out_s, out_i
 
         n0 = min(n, max(k, n // 8))
-        theta = torch.from_numpy(np.sort(S[:, :n0], axis=1)[:, ::-1][:, k - 1].copy() if n0 >= k else np.full(B, ninf, np.float32))
         scores = torch.full((B, k), float("-inf"))
-        if n0 >= k:  # phase 0: k lower bounds of distinct keys' exact scores (here: the sample's exact top-k)
-            scores.copy_(torch.from_numpy(np.sort(S[:, :n0], axis=1)[:, ::-1][:, :k].copy()))
-        if exchange is not None:
-            exchange(0, theta, scores)
+        if cls._prior is not None and exchange is not None:
+            # a speculative first bound: theta = the prior for every query, no first sample, NO phase 0 -- a key below the
+            # prior is dropped even when it belongs to the true top-k (the owner of the merged row must notice)
+            cls.spec_calls += 1
+            theta = torch.full((B,), float(cls._prior))
+        else:
+            theta = torch.from_numpy(np.sort(S[:, :n0], axis=1)[:, ::-1][:, k - 1].copy() if n0 >= k else np.full(B, ninf, np.float32))
+            if n0 >= k:  # phase 0: k lower bounds of distinct keys' exact scores (here: the sample's exact top-k)
+                scores.copy_(torch.from_numpy(np.sort(S[:, :n0], axis=1)[:, ::-1][:, :k].copy()))
+            if exchange is not None:
+                exchange(0, theta, scores)
         e1 = n // 2
         s0, i0 = local_topk(0, e1, theta.numpy(), None)
         scores.copy_(torch.from_numpy(s0))
@@ -373,3 +390,90 @@ def test_hybrid_layout_world4_matches_single(tmp_path, world, S, B, skew):
         if S > 1:
             assert int(g["beats"]) >= 3   # the exchanges and collectives reported to the heartbeat hook
     assert (covered == 1).all()
+
+
+def _prior_worker(rank, world, port, S, N, D, B, k, out_dir):
+    """Key-sharded (S = world) or hybrid (S < world) retrieval under the group's speculative first bound: the policy's own
+    prior after two warm-up calls, then forced priors -- far below every k-th best, just above the lowest k-th best of ONE
+    rank's rows (only that rank sees a miss), above everything."""
+    import datetime
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        from ragraph_amd.sharded import HybridLayout, ShardedToyGraphBase
+
+        layout = HybridLayout(S)
+        rng = np.random.default_rng(5)
+        keys = cref.normalize_rows(rng.standard_normal((N, D), dtype=np.float32))
+        vals = torch.from_numpy(rng.standard_normal((N, D), dtype=np.float32))
+        labs = torch.from_numpy(np.eye(3, dtype=np.float32)[rng.integers(0, 3, N)])
+        lo, hi = layout.key_rows(N)
+        tgb = ShardedToyGraphBase(torch.from_numpy(keys[lo:hi]), vals, labs, lo, k, group=layout.key_group,
+                                  ops=FilteredOracleOps, values_replicated=True)
+        qs = layout.query_shard()
+        out = {}
+
+        def run(tag, q):
+            qlo, qhi, rlo, rhi = HybridLayout.rows(qs, tgb, B)
+            before = (FilteredOracleOps.calls, FilteredOracleOps.spec_calls, tgb.reruns, dict(tgb.exchange_count))
+            sv, ml, ti = HybridLayout.retrieve_reduced_rows(qs, tgb, torch.from_numpy(q))
+            full_ml = HybridLayout.gather_output_rows(qs, tgb, ml, B)
+            ex0 = tgb.exchange_count.get(0, 0) - before[3].get(0, 0)
+            out[tag] = np.array([FilteredOracleOps.calls - before[0], FilteredOracleOps.spec_calls - before[1],
+                                 tgb.reruns - before[2], ex0])
+            out[tag + "_ti"], out[tag + "_ml"], out[tag + "_rows"] = ti.numpy(), full_ml.numpy(), np.array([qlo + rlo, qlo + rhi])
+
+        qs_all = [rng.standard_normal((B, D), dtype=np.float32) for _ in range(4)]
+        for c, q in enumerate(qs_all):          # the policy: two calls with a bound pass, then the learnt prior
+            run(f"auto{c}", q)
+        out["auto_prior"] = np.array([tgb.prior.prior_for(B, k) or np.nan])
+        q = qs_all[0]
+        rs, _ = cref.topk_cosine(q, keys, k)
+        kth = rs[:, k - 1]
+        # my key group answers rows [glo, ghi); its ranks own consecutive slices: the forced "one rank misses" prior sits just
+        # above the lowest k-th best of the group's LAST rank's rows (and below every other row's, or it is skipped)
+        for tag, prior in (("low", float(kth.min()) - 0.05), ("one", float(out_one_prior(kth, qs, tgb, B))), ("high", float(kth.max()) + 0.05)):
+            tgb.prior.forced = prior
+            run(tag, q)
+        tgb.prior.forced = None
+        np.savez(os.path.join(out_dir, f"p{rank}.npz"), **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def out_one_prior(kth, qs, tgb, B):
+    """A prior that exactly ONE row of this key group's slice misses: midway between its lowest and second-lowest k-th best."""
+    qlo, qhi = qs.bounds(B)
+    part = np.sort(kth[qlo:qhi])
+    return 0.5 * (part[0] + part[1])
+
+
+@pytest.mark.parametrize("world,S", [(2, 2), (4, 4), (4, 2)])
+def test_sharded_speculative_prior_world(tmp_path, world, S):
+    """VERDICT round 5, task 1: the key-sharded entry under a speculative first bound.  Whether a call speculates, whether its
+    result stands and whether it is repeated are decisions of the whole key group: every rank runs the same number of
+    filtered calls, the same exchanges (none of phase 0 under a prior) and the same number of repeats -- also when the prior is
+    too high for ONE row that one rank owns --, and every row is the single-GPU row bit for bit."""
+    N, D, B, k = 1501, 64, 48, 10     # (24 rows per query group of the 2 x 2 layout: above the policy's smallest batch)
+    mp.spawn(_prior_worker, args=(world, _free_port(), S, N, D, B, k, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(5)
+    keys = cref.normalize_rows(rng.standard_normal((N, D), dtype=np.float32))
+    vals = rng.standard_normal((N, D), dtype=np.float32)
+    labs = np.eye(3, dtype=np.float32)[rng.integers(0, 3, N)]
+    qs_all = [rng.standard_normal((B, D), dtype=np.float32) for _ in range(4)]
+    got = [dict(np.load(tmp_path / f"p{r}.npz")) for r in range(world)]
+    for tag, q in [(f"auto{c}", qs_all[c]) for c in range(4)] + [(t, qs_all[0]) for t in ("low", "one", "high")]:
+        rs, ri = cref.topk_cosine(q, keys, k)
+        _, rml = cref.gather_reduce(vals, labs, ri)
+        for r, g in enumerate(got):
+            lo, hi = (int(x) for x in g[tag + "_rows"])
+            assert np.array_equal(g[tag + "_ti"], ri[lo:hi]) and np.array_equal(g[tag + "_ml"], rml), (tag, r)
+            partner = got[(r // S) * S + (r % S + 1) % S]
+            assert np.array_equal(g[tag], partner[tag]), (tag, r)          # the key group acted as one
+    for g in got:
+        assert list(g["auto0"]) == [1, 0, 0, 1] and list(g["auto1"]) == [1, 0, 0, 1]      # warm-up: bound pass + phase 0
+        assert g["auto2"][1] >= 1 and g["auto2"][3] == g["auto2"][2]                       # speculative: phase 0 only in a repeat
+        assert not np.isnan(g["auto_prior"][0])
+        assert list(g["low"]) == [1, 1, 0, 0]                                              # stands: one call, no phase 0
+        assert list(g["one"]) == [2, 1, 1, 1] and list(g["high"]) == [2, 1, 1, 1]          # missed: repeated once, with a bound pass

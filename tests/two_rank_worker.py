@@ -65,6 +65,40 @@ def main():
         res["key_shard_topk_equal"] = bool(torch.equal(got_i, want_i) and torch.equal(got_s, want_s))
         res["exchange_count"] = {str(p): c for p, c in sharded.exchange_count.items()}
 
+        # The group's speculative first bound (round 6): more forwards on other feature tensors let the policy learn the prior
+        # (two calls with a bound pass, then calls without phase 0); then FORCED priors through topk_rows -- far below every
+        # k-th best (stands), between the two lowest k-th best scores of the batch (exactly ONE row, owned by one rank, misses:
+        # both ranks must repeat the call), above everything (every row misses).  Every result: the single-process bits.
+        spec_equal, before0 = True, sharded.exchange_count.get(0, 0)
+        calls0 = sharded.prior.calls
+        for seed in (11, 12, 13, 14):
+            f2 = torch.randn(n, F, device=dev, generator=torch.Generator(device=dev).manual_seed(seed))
+            model.toy_graph_base = single
+            with torch.no_grad():
+                w2 = model(f2, adj)
+            model.toy_graph_base = sharded
+            with torch.no_grad():
+                g2 = model(f2, adj)
+            spec_equal = spec_equal and bool(torch.equal(g2, w2))
+        res["spec_forwards_equal"] = spec_equal
+        res["spec_calls_used"] = int(sharded.prior.used)
+        res["spec_reruns_auto"] = int(sharded.reruns)
+        res["spec_phase0_during_auto"] = int(sharded.exchange_count.get(0, 0) - before0)
+        res["spec_group_calls"] = int(sharded.prior.calls - calls0)
+        kth = want_s[:, k - 1]
+        two = torch.sort(kth).values[:2]
+        tlo, thi = sharded.tail_bounds(n)
+        forced = {}
+        for tag, prior in (("low", float(kth.min()) - 0.05), ("one", float(0.5 * (two[0] + two[1]))), ("high", float(kth.max()) + 0.05)):
+            sharded.prior.forced = prior
+            r0, e0 = sharded.reruns, sharded.exchange_count.get(0, 0)
+            rs_, ri_ = sharded.topk_rows(h, k)
+            forced[tag] = {"equal": bool(torch.equal(ri_, want_i[tlo:thi]) and torch.equal(rs_, want_s[tlo:thi])),
+                           "reruns": int(sharded.reruns - r0), "phase0": int(sharded.exchange_count.get(0, 0) - e0)}
+        sharded.prior.forced = None
+        res["spec_forced"] = forced
+        res["spec_one_row_owner"] = int(torch.argmin(kth)) >= thi or int(torch.argmin(kth)) < tlo   # True on the rank that does NOT own it
+
         # the edge flavour's width: D = 64, whose int8 levels start at whole 512-key stages (an uneven shard size on purpose)
         N64, B64 = 300_001, 6000
         g64 = torch.Generator(device=dev).manual_seed(99)

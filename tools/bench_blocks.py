@@ -559,6 +559,18 @@ def finetune_edge(dev, cores, m5, cpu=True):
         loss.backward()
         opt.step()
     ms = event_ms(step, 2, warm=1)
+    # the reference draws the dropout mask on the HOST (one uniform per edge, utils.py:46) and so does the default here: what
+    # that costs inside the step, and the step with the mask drawn on the device (RAGraph.dropout_rng = "device")
+    t0 = time.perf_counter()
+    for _ in range(2):
+        m5.draw_edge_mask()
+    torch.cuda.synchronize()
+    host_draw_ms = (time.perf_counter() - t0) / 2 * 1e3
+    m5.dropout_rng = "device"
+    try:
+        ms_dev = event_ms(step, 2, warm=1)
+    finally:
+        m5.dropout_rng = "host"
     with torch.no_grad():
         for p, s in zip(params, saved):
             p.copy_(s)
@@ -566,7 +578,11 @@ def finetune_edge(dev, cores, m5, cpu=True):
     nn_ = U + I
     rec = {"shape": f"{nn_} nodes, {m5.edges.shape[0]} directed edges (half dropped per step), {nn_} x {m5.emb_size} bank, "
                     f"k={m5.retrieve_num}, 4096 BPR triples", "ms": round(ms, 1), "steps_per_s": round(1e3 / ms, 3),
-           "what": "cal_loss (edge dropout 0.5, forward, BPR + L2) + backward + Adam.step (modules/RAGraph.py:335-355)"}
+           "host_mask_draw_ms": round(host_draw_ms, 1), "ms_with_device_mask": round(ms_dev, 1),
+           "what": "cal_loss (edge dropout 0.5, forward, BPR + L2) + backward + Adam.step (modules/RAGraph.py:335-355); `ms` "
+                   "draws the dropout mask as the reference does -- torch.rand on the HOST generator, one uniform per edge + a "
+                   "copy (`host_mask_draw_ms` of the step) --, `ms_with_device_mask` draws it on the device "
+                   "(RAGraph.dropout_rng = 'device')"}
     if cpu:
         torch.set_num_threads(cores)
         D = m5.emb_size
