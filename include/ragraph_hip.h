@@ -426,6 +426,18 @@ int ragraph_mask_positions_i64(const unsigned char* mask, int64_t E, int64_t* po
 int ragraph_spmm_csr_panels_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n, const float* X,
                                 int64_t x_rows, int x_panels, int D, int act, float alpha, float* Y, int y_panels, void* stream);
 
+/* a7 over a TILED graph (round 6; opt-in)  -- Propagation.py:19-25, layers/gcn.py:36.  The hop of ragraph_spmm_csr_panels_f32
+ * with the GRAPH cut so that what an XCD gathers from at any moment is a few MB: source rows in blocks, destination rows in C
+ * chunks of 128 RG rows whose 32-column sums stay in one workgroup's LDS, edges stored once more in (chunk, 8-lane group, source
+ * block, row, column) order as wave-batches of 64 slots (plan made once per graph: ragraph_amd/graph.py CSRGraph.tile_plan):
+ *   wp [16 C + 1] first wave-batch of (chunk, wave); col3 / val3 / row3 [(wave-batches + 1) 64]: slot 8 g + i of a wave-batch =
+ *   edge i of group g's batch -- source row, value, destination row inside the chunk (0xFFFF: no edge).  RG <= 9.
+ * A row's chain is unchanged -- ascending columns, one fmaf sequence from +0 -- so the result has the bits of the other SpMM
+ * entries; required: columns ascending inside every row, no row longer than 4096 edges (else use those entries). */
+int ragraph_spmm_csr_tiled_f32(const int* wp, const int* col3, const float* val3, const unsigned short* row3, int RG, int C,
+                               int64_t n, const float* X, int64_t x_rows, int x_panels, int D, int act, float alpha, float* Y,
+                               int y_panels, void* stream);
+
 /* a7  adj / adj.sum(dim=1, keepdim=True)  -- Propagation.py:15-16.  val_out[e] = val[e] / rowsum(row(e)), rowsum =
  *     sequential fp32 adds in CSR order.  In-place allowed.  (A zero row sum gives inf/nan exactly as the reference.) */
 int ragraph_csr_row_normalize_f32(const int64_t* rowptr, const float* val, int64_t n, float* val_out, void* stream);

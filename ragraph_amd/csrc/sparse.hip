@@ -216,6 +216,92 @@ __global__ void __launch_bounds__(256) spmm_panel_kernel(const int64_t* __restri
   reinterpret_cast<float4*>(Y + (int64_t)panel * y_panel_stride + row * y_row_stride)[lr] = total;
 }
 
+// ---- graph-tiled hops (round 6) ------------------------------------------------------------------------------------------
+// On a graph without locality an XCD gathers from a 12.8 MB panel (c2) through a 4 MiB L2: two thirds of its row gathers miss
+// (profiles/r5_gnn_plain_pmc_traffic.txt).  Here the GRAPH is tiled (ragraph_amd/graph.py: CSRGraph.tile_plan, once per
+// graph): the source rows are cut into S blocks of a few MB of 128-byte panel lines, the destination rows into chunks of
+// RC = 128 RG rows whose 32-column accumulators live in ONE workgroup's LDS (RG x 16 KiB), and the edges are stored once more
+// in (chunk, 8-lane group, source block, row, column) order.  A workgroup (one per CU; 32 per XCD) takes a chunk's edges in
+// that order: the groups of an XCD walk their runs at the same pace, so at any moment they gather from about the same source
+// block and a line fetched for one edge is hit in L2 by the others that point at it.  A row's chain is unchanged: its edges
+// are consumed in ascending column order (the CSR order of a graph with sorted columns, which the plan requires), block
+// after block, the running sum parked in LDS between the row's visits -- the same fmaf sequence from +0, the same bits as
+// spmm_csr_kernel / spmm_panel_kernel.  (Rows longer than ROW_BLOCK edges and graphs with unsorted columns have no plan.)
+// Eight lanes own RG consecutive rows of the chunk (float4 each: one 128-byte panel line per row); no barrier anywhere -- a
+// group only ever touches its own rows' sums.  The eight groups of a wave read their batch's edge words from ONE place --
+// col3 / val3 / row3 [wave-batch][64]: lane 8 g + i holds edge i of group g's batch -- three coalesced loads per 64 edges (a
+// group's run on its own lines costs the L1 twenty-four line requests per batch, streamed from HBM: 177 us instead of 125 in
+// tools/microbench/spmm_tiled_bench.hip); a group whose run is shorter than its wave's longest is padded with NULL edges
+// (row 0xFFFF: gathered from line 0, never accumulated).  What this kernel costs and why it is NOT the default: DESIGN.md 4.3.
+struct TilePlan {
+  const int* wp;                 // [C * 16 + 1] first wave-batch of (chunk, wave)
+  const int* col3;               // [(wave-batches + 1) * 64] source row of every slot
+  const float* val3;
+  const unsigned short* row3;    // destination row inside the chunk, 0xFFFF = no edge
+  int RG, C;
+};
+
+__global__ void __launch_bounds__(1024) spmm_tiled_kernel(TilePlan t, int64_t n, const float* __restrict__ Xp,
+                                                          int64_t x_panel_stride, int x_row4, float* __restrict__ Y,
+                                                          int64_t y_panel_stride, int64_t y_row_stride, int P, int act,
+                                                          float alpha) {
+  extern __shared__ float4 tile_acc[];   // [RC][8]
+  constexpr int NG = 128;
+  const int lr = threadIdx.x & 7, gi = threadIdx.x >> 3, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const unsigned xcd = blockIdx.x % 8, w = blockIdx.x / 8, wpx = gridDim.x / 8;
+  const int share = P >= 8 ? 1 : 8 / P;             // XCDs that share a panel: each takes every share-th chunk
+  const int sub = P >= 8 ? 0 : (int)(xcd / P);
+  const int RC = t.RG * NG;
+  float4* mine = tile_acc + (gi * t.RG) * 8 + lr;   // my 16 bytes of my group's first row
+#define RG_SWZ(v_, k_) __builtin_amdgcn_ds_swizzle((v_), ((k_) << 5) | 0x18)   /* lane k of every group of 8 */
+  for (int panel = P >= 8 ? (int)xcd : (int)(xcd % P); panel < P; panel += 8) {
+    const float4* X4 = reinterpret_cast<const float4*>(Xp + (int64_t)panel * x_panel_stride) + lr;
+    for (int c = sub + share * (int)w; c < t.C; c += share * (int)wpx) {
+      for (int j = 0; j < t.RG; ++j) mine[j * 8] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int b0 = t.wp[c * 16 + wv], b1 = t.wp[c * 16 + wv + 1];
+      int cur = -1;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int b = b0; b < b1; ++b) {
+        const int64_t o = (int64_t)b * 64 + lane;
+        const int my_c = t.col3[o];
+        const float my_v = t.val3[o];
+        const int my_r = t.row3[o];
+        float4 x[8];
+#define RG_LINE(k_) x[k_] = X4[(int64_t)RG_SWZ(my_c, k_) * x_row4]
+        RG_LINE(0); RG_LINE(1); RG_LINE(2); RG_LINE(3); RG_LINE(4); RG_LINE(5); RG_LINE(6); RG_LINE(7);
+#undef RG_LINE
+        // one edge into the running sum of its row (a row is visited once per source block; its sum waits in LDS in between)
+#define RG_EDGE(k_)                                                                              \
+  do {                                                                                           \
+    const int r_ = RG_SWZ(my_r, k_);                                                             \
+    const float v_ = __int_as_float(RG_SWZ(__float_as_int(my_v), k_));                           \
+    if (r_ != 0xFFFF) {                                                                          \
+      if (r_ != cur) {                                                                           \
+        if (cur >= 0) tile_acc[cur * 8 + lr] = acc;                                              \
+        acc = tile_acc[r_ * 8 + lr];                                                             \
+        cur = r_;                                                                                \
+      }                                                                                          \
+      acc.x = fmaf(v_, x[k_].x, acc.x); acc.y = fmaf(v_, x[k_].y, acc.y);                        \
+      acc.z = fmaf(v_, x[k_].z, acc.z); acc.w = fmaf(v_, x[k_].w, acc.w);                        \
+    }                                                                                            \
+  } while (0)
+        RG_EDGE(0); RG_EDGE(1); RG_EDGE(2); RG_EDGE(3); RG_EDGE(4); RG_EDGE(5); RG_EDGE(6); RG_EDGE(7);
+#undef RG_EDGE
+      }
+      if (cur >= 0) tile_acc[cur * 8 + lr] = acc;
+      const int64_t row0 = (int64_t)c * RC + (int64_t)gi * t.RG;
+      for (int j = 0; j < t.RG; ++j) {
+        if (row0 + j >= n) break;
+        float4 v = mine[j * 8];
+        v.x = apply_act(v.x, act, alpha); v.y = apply_act(v.y, act, alpha);
+        v.z = apply_act(v.z, act, alpha); v.w = apply_act(v.w, act, alpha);
+        reinterpret_cast<float4*>(Y + (int64_t)panel * y_panel_stride + (row0 + j) * y_row_stride)[lr] = v;
+      }
+    }
+  }
+#undef RG_SWZ
+}
+
 // ---- long rows, with a workspace ------------------------------------------------------------------------------------
 struct LongRows {
   int* ctr;           // [0] number of long rows, [1] number of block tasks
@@ -622,5 +708,33 @@ extern "C" int ragraph_segment_reduce_f32(const float* X, int D, const int64_t* 
     hipLaunchKernelGGL(segment_reduce_scalar_kernel, dim3((unsigned)G), dim3(256), 0, as_stream(stream), X, D, seg_ptr, w,
                        mean_mode, out);
   RG_CHECK_LAUNCH("segment_reduce");
+  return RAGRAPH_OK;
+}
+
+// a7 over a TILED graph (spmm_tiled_kernel): wp / col3 / val3 / row3 = the plan of ragraph_amd/graph.py (CSRGraph.tile_plan):
+// C chunks of 128 RG destination rows, their edges in wave-batches of 64 slots.  Layouts as ragraph_spmm_csr_panels_f32.  Same
+// bits as the other SpMM entries for a graph whose columns ascend inside every row.
+extern "C" int ragraph_spmm_csr_tiled_f32(const int* wp, const int* col3, const float* val3, const unsigned short* row3, int RG,
+                                          int C, int64_t n, const float* X, int64_t x_rows, int x_panels, int D, int act,
+                                          float alpha, float* Y, int y_panels, void* stream) {
+  RG_REQUIRE(wp && col3 && val3 && row3 && X && Y, RAGRAPH_EINVAL, "spmm_csr_tiled: null pointer");
+  RG_REQUIRE(n >= 1 && x_rows >= 1 && (D == 64 || D == 128 || D == 256 || (D % 256 == 0 && D <= 2048)), RAGRAPH_EUNSUPPORTED,
+             "spmm_csr_tiled: D=%d (panels of 32 columns: 2, 4 or a multiple of 8 of them)", D);
+  RG_REQUIRE(RG >= 1 && RG <= 9 && C >= 1 && (int64_t)C * RG * 128 >= n, RAGRAPH_EINVAL,
+             "spmm_csr_tiled: bad plan (RG=%d C=%d n=%lld)", RG, C, (long long)n);
+  RG_REQUIRE(aligned16(X) && aligned16(Y) && X != Y, RAGRAPH_EINVAL, "spmm_csr_tiled: X, Y must be 16-B aligned and distinct");
+  RG_REQUIRE(act >= RAGRAPH_ACT_NONE && act <= RAGRAPH_ACT_ELU, RAGRAPH_EINVAL, "spmm_csr_tiled: bad act %d", act);
+  static DeviceOnce once;
+  const int lds = RG * 128 * 128;   // RG x 16 KiB
+  if (raise_dynamic_lds(once, spmm_tiled_kernel, 9 * 128 * 128) != hipSuccess) {
+    set_error("spmm_csr_tiled: cannot raise the dynamic LDS limit");
+    return RAGRAPH_EDEVICE;
+  }
+  TilePlan t{wp, col3, val3, row3, RG, C};
+  const int P = D / 32;
+  hipLaunchKernelGGL(spmm_tiled_kernel, dim3((unsigned)device_cus_multiple_of_8()), dim3(1024), (size_t)lds, as_stream(stream), t, n, X,
+                     x_panels ? x_rows * 32 : (int64_t)32, x_panels ? 8 : D / 4, Y, y_panels ? n * 32 : (int64_t)32,
+                     y_panels ? (int64_t)32 : (int64_t)D, P, act, alpha);
+  RG_CHECK_LAUNCH("spmm_csr_tiled");
   return RAGRAPH_OK;
 }

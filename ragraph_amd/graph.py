@@ -18,6 +18,16 @@ import torch
 from . import kernels as K
 
 
+class TilePlan:
+    """CSRGraph.tile_plan: wp [16 C + 1] int32 (first wave-batch of every (chunk, wave)), col3 int32 / row3 int16 [slots] (64 per
+    wave-batch; row -1 = 0xFFFF = no edge), perm [nnz] (plan order -> CSR slot), slot [nnz] (plan order -> slot)."""
+
+    def __init__(self, wp, col3, row3, perm, slot, slots, RG, S, SB, C, passes):
+        self.wp, self.col3, self.row3, self.perm, self.slot, self.slots = wp, col3, row3, perm, slot, int(slots)
+        self.RG, self.S, self.SB, self.C, self.passes = int(RG), int(S), int(SB), int(C), int(passes)
+        self._val_tag, self._val2 = None, None
+
+
 @dataclass
 class CSRGraph:
     rowptr: torch.Tensor  # [n+1] int64
@@ -27,6 +37,7 @@ class CSRGraph:
     _row_normalized: torch.Tensor | None = field(default=None, repr=False)
     _has_long_rows: bool | None = field(default=None, repr=False)
     _transposed: "CSRGraph | None" = field(default=None, repr=False)
+    _tile_plans: dict = field(default_factory=dict, repr=False)
 
     @property
     def shape(self):
@@ -74,6 +85,69 @@ class CSRGraph:
         if self.rowptr.is_cuda:
             return K.csr_row_ids(self.rowptr, self.nnz)
         return torch.repeat_interleave(torch.arange(self.n, device=self.device), self.rowptr[1:] - self.rowptr[:-1])
+
+    # ---- graph tiling (csrc/sparse.hip: spmm_tiled_kernel) -------------------------------------------------------------
+    TILE_SOURCE_BYTES = int(__import__("os").environ.get("RAGRAPH_SPMM_TILE_SOURCE_BYTES", str(5 << 18)))   # 1.25 MiB (c2: 114 us per hop; 2.5 MiB: 118)
+
+    def tile_plan(self, panels: int):
+        """The plan of the graph-tiled hop for features of `panels` 32-column panels, made once per graph (cached; None when
+        the graph cannot be tiled: a row longer than ROW_BLOCK edges, columns that do not ascend inside a row -- the tiled
+        kernel consumes a row's edges source block by source block, which is the CSR order only then -- or host tensors).
+        Destination rows: C chunks of RC = 128 RG rows (RG <= 9: the chunk's 32-column sums fill a workgroup's LDS), as few
+        passes over the chunks as that allows; source rows: S blocks of at most TILE_SOURCE_BYTES of 128-byte lines; edges:
+        one stable sort (the library's own) by (chunk, 8-lane group, source block) -- inside a bucket the CSR order stays."""
+        share = 1 if panels >= 8 else 8 // max(panels, 1)
+        if share in self._tile_plans:
+            return self._tile_plans[share]
+        plan = None
+        if self.rowptr.is_cuda and self.n >= 1 and self.nnz >= 1 and self.nnz < 2 ** 31 - 16 and not self.has_long_rows:
+            rows = self.row_ids()
+            col = self.col.long()
+            unsorted = bool(((col[1:] < col[:-1]) & (rows[1:] == rows[:-1])).any()) if self.nnz > 1 else False
+            if not unsorted:
+                NG, WPX = 128, 32
+                passes = 1
+                while -(-self.n // (WPX * share * passes * NG)) > 9:
+                    passes += 1
+                RG = -(-self.n // (WPX * share * passes * NG))
+                RC = RG * NG
+                C = -(-self.n // RC)
+                S = max(1, -(-self.n * 128 // self.TILE_SOURCE_BYTES))
+                SB = -(-self.n // S)
+                bucket = ((rows // RC) * NG + (rows % RC) // RG) * S + col // SB
+                gp, col2, perm = K.coo_to_csr(bucket, col, C * NG * S)
+                # wave-batches: the eight groups of a wave keep their batch's words in ONE 64-slot record (slot 8 g + i = edge
+                # i of group g's batch); a wave walks as many batches as its longest group's run needs, the others' tails are
+                # NULL slots (row 0xFFFF, column 0)
+                grp_ptr = gp[::S].contiguous()                                   # [C * NG + 1]: the groups' runs
+                run0 = grp_ptr[:-1]
+                run_len = grp_ptr[1:] - run0
+                nb_wave = ((run_len + 7) // 8).view(C * 16, 8).max(dim=1).values   # batches per (chunk, wave)
+                wp = torch.zeros(C * 16 + 1, dtype=torch.int64, device=self.device)
+                wp[1:] = torch.cumsum(nb_wave, 0)
+                slots = (int(wp[-1]) + 1) * 64                                   # (+ one NULL wave-batch behind the last)
+                if slots > 1.5 * self.nnz + 64 * 16 * C:   # skewed degrees: a wave walks its longest group's run -- too many NULL slots
+                    self._tile_plans[share] = None
+                    return None
+                grp = K.csr_row_ids(grp_ptr, self.nnz)                           # group of every edge (plan order)
+                k = torch.arange(self.nnz, device=self.device) - run0[grp]
+                slot = (wp[grp // 8] + k // 8) * 64 + (grp % 8) * 8 + k % 8
+                col3 = torch.zeros(slots, dtype=torch.int32, device=self.device)
+                row3 = torch.full((slots,), -1, dtype=torch.int16, device=self.device)   # 0xFFFF
+                col3[slot] = col2
+                row3[slot] = (rows[perm] % RC).to(torch.int16)
+                plan = TilePlan(wp.to(torch.int32), col3, row3, perm, slot, slots, RG, S, SB, C, passes)
+        self._tile_plans[share] = plan
+        return plan
+
+    def tiled_values(self, plan, val: torch.Tensor) -> torch.Tensor:
+        """The edge values in the plan's slots (0 in the NULL slots), cached per value tensor and version."""
+        tag = (val.data_ptr(), val._version, val.numel())
+        if plan._val_tag != tag:
+            v3 = torch.zeros(plan.slots, dtype=torch.float32, device=val.device)
+            v3[plan.slot] = val[plan.perm]
+            plan._val2, plan._val_tag = v3, tag
+        return plan._val2
 
     # ---- locality ----------------------------------------------------------------------------------------------
     def permuted(self, order: torch.Tensor) -> "CSRGraph":

@@ -714,6 +714,31 @@ def spmm_csr_panels(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, 
     return y
 
 
+def spmm_csr_tiled(plan, val2: torch.Tensor, x: torch.Tensor, n: int, x_panels: bool, y_panels: bool, act: int = ACT_NONE,
+                   alpha: float = 0.0) -> torch.Tensor:
+    """act(A @ x) over a TILED graph (ragraph_spmm_csr_tiled_f32; plan = CSRGraph.tile_plan(...), val2 = the edge values in
+    plan order): the layouts of spmm_csr_panels, the same bits, the X traffic of a hop cut to (passes) x the table."""
+    L = _ready()
+    x = _f32c(x, "spmm_csr_tiled.x")
+    D = x.shape[1]
+    y = torch.empty((n, D), dtype=torch.float32, device=x.device)
+    N.check(L.ragraph_spmm_csr_tiled_f32(plan.wp.data_ptr(), plan.col3.data_ptr(), val2.data_ptr(), plan.row3.data_ptr(), plan.RG,
+                                         plan.C, n, x.data_ptr(), x.shape[0], int(x_panels), D, act, float(alpha),
+                                         y.data_ptr(), int(y_panels), _stream()), "spmm_csr_tiled")
+    return y
+
+
+def tiles_help(n: int, D: int) -> bool:
+    """A hop over a table much larger than the eight L2s on the graph-tiled kernel: D a multiple of 256 (one panel per XCD and
+    more).  Measured on c2's graph (tools/gnn_probe.py, us per hop, tiled / panel kernel): row-major in 119 / 134, panel-major in
+    114 / 118; on a uniformly random graph 125 / 135 (tools/microbench/spmm_tiled_bench.hip); D = 128 row -> row 65.7 / 66.8 (left
+    to the slice kernel).  RAGRAPH_SPMM_TILED=0: the panel kernels (A/B); =2: also D = 64 / 128."""
+    mode = os.environ.get("RAGRAPH_SPMM_TILED", "1")
+    if mode == "0" or n * D * 4 < (32 << 20):
+        return False
+    return (D % 256 == 0 and D <= 2048) or (mode == "2" and D in (64, 128))
+
+
 def panels_help(n: int, D: int, k: int) -> bool:
     """A k-hop propagation whose intermediate features are worth keeping panel-major: at least two hops over a table much
     larger than the eight L2s (c2: 100 000 x 256 -- 102 MB; a table that fits the L2s gains nothing), D = 256 (one panel per XCD)."""

@@ -16,6 +16,21 @@ class Propagation:
         if k <= 0:
             return x if rows is None else x[rows[0]:rows[1]].contiguous()
         valn = g.row_normalized_values()
+        if (not (torch.is_grad_enabled() and x.requires_grad) and x.is_cuda and x.shape[1] % 32 == 0
+                and K.tiles_help(x.shape[0], x.shape[1])):
+            # large graphs, round 6: the GRAPH is tiled (once; CSRGraph.tile_plan) so that what an XCD gathers from at any
+            # moment fits its L2 -- and the features stay panel-major between the hops as below; same bits.  The last hop of a
+            # rank's row slice takes the panel kernel over that slice of the row pointers.
+            plan = g.tile_plan(x.shape[1] // 32)
+            if plan is not None:
+                val2 = g.tiled_values(plan, valn)
+                for hop in range(int(k)):
+                    last = hop == int(k) - 1
+                    if last and rows is not None:
+                        return K.spmm_csr_panels(g.rowptr[rows[0]:rows[1] + 1], g.col, valn, x, x_panels=hop > 0, y_panels=False,
+                                                 act=K.ACT_RELU)
+                    x = K.spmm_csr_tiled(plan, val2, x, g.n, x_panels=hop > 0, y_panels=not last, act=K.ACT_RELU)
+                return x
         if (not g.has_long_rows and not (torch.is_grad_enabled() and x.requires_grad) and x.is_cuda
                 and K.panels_help(x.shape[0], x.shape[1], int(k))):
             # large graphs: the features stay panel-major between the hops (an XCD gathers one 128-byte line per neighbour

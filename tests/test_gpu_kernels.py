@@ -1039,3 +1039,59 @@ def test_propagation_rows_slice_through_panels(dev):
     for lo, hi in ((0, 12_500), (37_500, 50_000), (99_000, 100_000)):
         part = Propagation.aggregate_k_hop_features(g, x, 3, rows=(lo, hi))
         assert part.shape == (hi - lo, D) and torch.equal(part, whole[lo:hi])
+
+
+@pytest.mark.parametrize("n,D,deg", [(3000, 256, 7), (70_001, 128, 9), (70_001, 64, 5), (150_000, 256, 11), (40_000, 512, 6), (129, 256, 3)])
+def test_spmm_csr_tiled_bit_exact(dev, n, D, deg):
+    """The graph-tiled hop (csrc/sparse.hip spmm_tiled_kernel; CSRGraph.tile_plan): destination chunks whose sums stay in LDS,
+    source blocks that fit an L2, edges in (chunk, block, row, column) order -- in every layout combination the bits of the row
+    kernel and of the oracle: empty rows at both ends and inside, rows of one edge, duplicate (row, column) entries (their
+    stable order decides), several source blocks (a small TILE_SOURCE_BYTES forces them on small graphs), two hops chained."""
+    from ragraph_amd import kernels as K
+    from ragraph_amd.graph import CSRGraph
+
+    rng = _rng(n + D + deg)
+    src = rng.integers(0, n, n * deg)
+    dst = rng.integers(0, n, n * deg)
+    keep = (src != 0) & (src != n - 1) & (src != n // 2)              # three empty rows
+    src, dst = src[keep], dst[keep]
+    src = np.concatenate([src, np.full(40, 7 % n)])                   # duplicates of (7, 3): a run of equal columns
+    dst = np.concatenate([dst, np.full(40, 3 % n)])
+    order = np.lexsort((dst, src))                                    # (stable: columns ascend inside a row)
+    r, c = src[order], dst[order]
+    rowptr = np.zeros(n + 1, np.int64)
+    np.add.at(rowptr, r + 1, 1)
+    rowptr = np.cumsum(rowptr)
+    val = rng.standard_normal(r.size).astype(np.float32) * 0.3
+    X = rng.standard_normal((n, D), dtype=np.float32)
+    g = CSRGraph(_t(rowptr, dev), _t(c.astype(np.int32), dev), _t(val, dev), n)
+    Xd = _t(X, dev)
+    ref = K.spmm_csr(g.rowptr, g.col, g.val, Xd, act=K.ACT_RELU)
+    if n <= 70_001:
+        assert np.array_equal(ref.cpu().numpy(), cref.spmm_csr(rowptr, c.astype(np.int32), val, X, act=cref.ACT_RELU))
+    P = D // 32
+    for src_bytes in (CSRGraph.TILE_SOURCE_BYTES, 40_000):           # the product's blocks, and many small ones
+        g._tile_plans.clear()
+        old = CSRGraph.TILE_SOURCE_BYTES
+        CSRGraph.TILE_SOURCE_BYTES = src_bytes
+        try:
+            plan = g.tile_plan(P)
+        finally:
+            CSRGraph.TILE_SOURCE_BYTES = old
+        assert plan is not None and plan.C * plan.RG * 128 >= n and plan.perm.numel() == r.size and int((plan.row3 != -1).sum()) == r.size
+        v2 = g.tiled_values(plan, g.val)
+        to_rows = lambda y: y.view(P, n, 32).permute(1, 0, 2).reshape(n, D)
+        xp = Xd.view(n, P, 32).permute(1, 0, 2).contiguous().view(n, D)
+        assert torch.equal(K.spmm_csr_tiled(plan, v2, Xd, n, False, False, act=K.ACT_RELU), ref)             # row -> row
+        yp = K.spmm_csr_tiled(plan, v2, Xd, n, False, True, act=K.ACT_RELU)                                 # row -> panel
+        assert torch.equal(to_rows(yp), ref)
+        assert torch.equal(K.spmm_csr_tiled(plan, v2, xp, n, True, False, act=K.ACT_RELU), ref)              # panel -> row
+        assert torch.equal(to_rows(K.spmm_csr_tiled(plan, v2, xp, n, True, True, act=K.ACT_RELU)), ref)      # panel -> panel
+        two = K.spmm_csr_tiled(plan, v2, yp, n, True, False, act=K.ACT_NONE)                                # a second hop
+        assert torch.equal(two, K.spmm_csr(g.rowptr, g.col, g.val, ref, act=K.ACT_NONE))
+    # no plan: a graph whose columns do not ascend inside a row (the tiled order would not be the CSR order)
+    if r.size > 10:
+        c2 = c.copy()
+        i = int(np.flatnonzero((r[1:] == r[:-1]) & (c[1:] != c[:-1]))[0])
+        c2[i], c2[i + 1] = c2[i + 1], c2[i]
+        assert CSRGraph(_t(rowptr, dev), _t(c2.astype(np.int32), dev), _t(val, dev), n).tile_plan(P) is None

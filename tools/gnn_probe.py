@@ -44,4 +44,23 @@ for xp, yp in ((0, 0), (0, 1), (1, 1), (1, 0)):
     print(f"sliced hop D=256, x_panels={xp} y_panels={yp}: {t(lambda: K.spmm_csr_panels(g.rowptr, g.col, vn, src, bool(xp), bool(yp), act=K.ACT_RELU)):7.1f} us")
 print(f"sliced spmm D=128 row -> row:      {t(lambda: K.spmm_csr_panels(g.rowptr, g.col, g.val, X, False, False)):7.1f} us")
 from ragraph_amd.ragraph_utils import Propagation
+os.environ["RAGRAPH_SPMM_TILED"] = "0"
+print(f"3 hops (panel kernels):            {t(lambda: Propagation.aggregate_k_hop_features(g, H, 3)):7.1f} us")
+os.environ["RAGRAPH_SPMM_TILED"] = "1"
+
+# round 6: the graph-tiled kernel (CSRGraph.tile_plan) in the same layout combinations, and the source-block size
+for sb in (5 << 19, 5 << 18, 13 << 20):
+    CSRGraph.TILE_SOURCE_BYTES = sb
+    g._tile_plans.clear()
+    plan = g.tile_plan(D // 32)
+    v2 = g.tiled_values(plan, vn)
+    for xp, yp in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        src = Hp if xp else H
+        print(f"tiled hop D=256 (RG {plan.RG}, passes {plan.passes}, S {plan.S}: {sb >> 10} KiB blocks), x_panels={xp} y_panels={yp}: "
+              f"{t(lambda: K.spmm_csr_tiled(plan, v2, src, n, bool(xp), bool(yp), act=K.ACT_RELU)):7.1f} us")
+    plan4 = g.tile_plan(F // 32)
+    v4 = g.tiled_values(plan4, g.val)
+    print(f"tiled spmm D=128 row -> row (RG {plan4.RG}, passes {plan4.passes}, S {plan4.S}): {t(lambda: K.spmm_csr_tiled(plan4, v4, X, n, False, False)):7.1f} us")
+CSRGraph.TILE_SOURCE_BYTES = 5 << 18
+g._tile_plans.clear()
 print(f"3 hops (product path):             {t(lambda: Propagation.aggregate_k_hop_features(g, H, 3)):7.1f} us")
