@@ -69,7 +69,9 @@ class RAGraph(nn.Module):
         # a side stream, where its SpMM launches fill the latency-bound rescoring phases between the retrieval's matrix
         # passes instead of running behind them (c2: 0.4 ms of 37.5).  Same kernels, same bits; one fork / join.
         side = None
-        if (self.finetune and not torch.is_grad_enabled() and not add_noise and queries.is_cuda
+        # (training too: the encoder's output is detached -- preprompt.py:62 -- so the hops carry no tape; only a caller that
+        # does ask gradients of the embeddings keeps them on the main stream, inside autograd's stream bookkeeping)
+        if (self.finetune and not (torch.is_grad_enabled() and pretrain_embedddings.requires_grad) and queries.is_cuda
                 and queries.shape[0] >= self.OVERLAP_MIN_NODES):
             # (small forwards gain nothing from the fork, captured in a HIP graph or not: Cora-sized replay 0.163 ms
             # without, 0.172 with the hops on a parallel branch -- round 3)
