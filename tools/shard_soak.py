@@ -11,7 +11,10 @@ from ragraph_amd.sharded import shard_bounds
 dev = torch.device("cuda:0")
 
 
-def run_shape(G, B, N, D, k, seed):
+def run_shape(G, B, N, D, k, seed, prior_mode=0):
+    """prior_mode: 0 = bound pass; 1 = a speculative prior below every query's k-th best (every row proven); 2 = a prior at
+    the 30 % quantile of the k-th best scores (the rows below it are NOT proven: the owner's verdict must name exactly them,
+    and every proven row must carry the single-GPU bits)."""
     g = torch.Generator(device=dev).manual_seed(seed)
     kn = K.normalize_rows(torch.randn(N, D, device=dev, generator=g))
     q = torch.randn(B, D, device=dev, generator=g)
@@ -20,6 +23,11 @@ def run_shape(G, B, N, D, k, seed):
     plan_n = max(hi - lo for lo, hi in bounds)
     shards = [kn[lo:hi].contiguous() for lo, hi in bounds]
     copies = [K.keys_to_bf16(s) for s in shards]
+    prior = None
+    if prior_mode and K.sharded_speculates(B, plan_n, D, k, G):
+        kth = full_s[:, k - 1]
+        live = kth[full_s[:, 0] != 0] if bool((full_s[:, 0] != 0).any()) else kth
+        prior = float(live.min()) - 0.01 if prior_mode == 1 else float(torch.quantile(live.float(), 0.3))
     torch.cuda.synchronize()
     barrier = threading.Barrier(G)
     slots, out, errs = [None] * G, [None] * G, []
@@ -42,8 +50,12 @@ def run_shape(G, B, N, D, k, seed):
     def run(r):
         try:
             with torch.cuda.stream(torch.cuda.Stream()):
-                s, i, over = K.topk_cosine_filtered(q, shards[r], copies[r], k, idx_base=bounds[r][0],
-                                                    exchange=exchange_for(r), plan_n=plan_n)
+                K.set_filter_prior(prior)          # (thread-local: every shard's thread sets the group's prior)
+                try:
+                    s, i, over = K.topk_cosine_filtered(q, shards[r], copies[r], k, idx_base=bounds[r][0],
+                                                        exchange=exchange_for(r), plan_n=plan_n)
+                finally:
+                    K.set_filter_prior(None)
                 torch.cuda.current_stream().synchronize()
                 out[r] = (s, i, int(over))
         except BaseException as e:  # noqa: BLE001
@@ -58,9 +70,21 @@ def run_shape(G, B, N, D, k, seed):
     if errs:
         raise errs[0]
     ms, mi = K.topk_merge(torch.stack([o[0] for o in out]), torch.stack([o[1] for o in out]))
-    bad = (mi != full_i).any(dim=1).nonzero().flatten()
-    ok = bad.numel() == 0 and torch.equal(ms, full_s)
-    return ok, bad[:6].tolist(), [o[2] for o in out]
+    if prior is None:
+        bad = (mi != full_i).any(dim=1).nonzero().flatten()
+        ok = bad.numel() == 0 and torch.equal(ms, full_s)
+        return ok, bad[:6].tolist(), [o[2] for o in out]
+    # under a prior: the owner's verdict (ragraph_verify_merged_prior_f32) names the rows that are not proven; every other
+    # row must be the single-GPU row, and a row IS proven exactly when its true k-th best reaches the prior
+    words = K.verify_merged_prior(ms, prior).cpu().tolist()
+    zero = (full_s[:, 0] == 0) & (full_s[:, k - 1] == 0)
+    proven = zero | (full_s[:, k - 1] >= prior)
+    differs = (mi != full_i).any(dim=1) | (ms != full_s).any(dim=1)
+    bad = (differs & proven).nonzero().flatten()
+    ok = bad.numel() == 0 and int(words[0]) == int((~proven).sum())
+    if prior_mode == 1:
+        ok = ok and int(words[0]) == 0 and not bool(differs.any())
+    return ok, bad[:6].tolist(), [o[2] for o in out] + [f"prior {prior:.4f} missed {int(words[0])} not-proven {int((~proven).sum())}"]
 
 
 if sys.argv[1] == "soak":
@@ -79,7 +103,7 @@ if sys.argv[1] == "soak":
         if not K.filter_helps(B, -(-N // G), D, k):
             continue
         try:
-            ok, bad, over = run_shape(G, B, N, D, k, seed + n)
+            ok, bad, over = run_shape(G, B, N, D, k, seed + n, prior_mode=ri(0, 2))
         except BaseException as e:  # noqa: BLE001
             print(f"ERROR G={G} B={B} N={N} D={D} k={k} seed={seed + n}: {e}", flush=True)
             sys.exit(1)
