@@ -10,7 +10,11 @@ N > 1 (one rank per GPU; `python bench.py --gpus N` starts the ranks itself when
 metric's own 1M-key bank.  Default layout = north_star's: the KEY BANK is row-sharded, every rank scores all queries
 against its shard, and between the phases of that call (first bound, every filter level) the ranks pool their bounds: an
 all_gather of each rank's best m = 2 ceil(k/G) lower bounds per query + the k-th largest of the union
-(ragraph_theta_sharpen_f32), so a shard filters with (nearly) the global threshold.  The tail is query-sharded: ONE
+(ragraph_theta_sharpen_f32), so a shard filters with (nearly) the global threshold.  Since round 6 the call runs under the
+GROUP's speculative first bound once two calls have reported where the merged k-th best scores lie (ragraph_amd.sharded.GroupPrior:
+no bound pass, no phase-0 exchange; the rows' owners prove the merged lists, one 5-float all_reduce makes the verdict the group's,
+a miss anywhere repeats the call without the prior on every rank) -- `first_bound.group` and every layout's `first_bound` count the
+calls, the speculative ones and the repeats.  The tail is query-sharded: ONE
 all_to_all carries the per-shard lists of a rank's rows to it, the canonical merge, value gathers, last hop and decoder
 run on B/G rows, and one all_gather of the [n, C] outputs completes the step (ragraph_amd/sharded.py,
 RAGraph._forward_key_shard); values / labels are replicated (1 GB), the cheap GNN part runs on every rank.  The other
