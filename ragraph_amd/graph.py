@@ -89,10 +89,13 @@ class CSRGraph:
     # ---- graph tiling (csrc/sparse.hip: spmm_tiled_kernel) -------------------------------------------------------------
     TILE_SOURCE_BYTES = int(__import__("os").environ.get("RAGRAPH_SPMM_TILE_SOURCE_BYTES", str(5 << 18)))   # 1.25 MiB (c2: 114 us per hop; 2.5 MiB: 118)
 
+    TILE_NEAR_ROWS = 4096
+
     def tile_plan(self, panels: int):
         """The plan of the graph-tiled hop for features of `panels` 32-column panels, made once per graph (cached; None when
-        the graph cannot be tiled: a row longer than ROW_BLOCK edges, columns that do not ascend inside a row -- the tiled
-        kernel consumes a row's edges source block by source block, which is the CSR order only then -- or host tensors).
+        the graph cannot or should not be tiled: a row longer than ROW_BLOCK edges, columns that do not ascend inside a row -- the
+        tiled kernel consumes a row's edges source block by source block, which is the CSR order only then --, a numbering
+        that already keeps most neighbours within TILE_NEAR_ROWS rows, skewed degrees, or host tensors).
         Destination rows: C chunks of RC = 128 RG rows (RG <= 9: the chunk's 32-column sums fill a workgroup's LDS), as few
         passes over the chunks as that allows; source rows: S blocks of at most TILE_SOURCE_BYTES of 128-byte lines; edges:
         one stable sort (the library's own) by (chunk, 8-lane group, source block) -- inside a bucket the CSR order stays."""
@@ -104,7 +107,12 @@ class CSRGraph:
             rows = self.row_ids()
             col = self.col.long()
             unsorted = bool(((col[1:] < col[:-1]) & (rows[1:] == rows[:-1])).any()) if self.nnz > 1 else False
-            if not unsorted:
+            # a numbering that already keeps neighbours close (a community graph after locality_order(), a banded matrix) is
+            # served from L1 / L2 by the panel kernel, whose per-edge cost is lower: measured on the reordered community graph
+            # of bench.py's gnn_fwd.structured_graph, forward 0.492 ms on the panel kernels, 0.556 tiled; c2's graph (self loop
+            # + ring: 27 % of the edges near) 0.545 / 0.534.  Tiled only when fewer than half of the edges are near.
+            near = float(((col - rows).abs() <= self.TILE_NEAR_ROWS).float().mean()) if self.nnz else 1.0
+            if not unsorted and near < 0.5:
                 NG, WPX = 128, 32
                 passes = 1
                 while -(-self.n // (WPX * share * passes * NG)) > 9:

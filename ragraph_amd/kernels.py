@@ -729,11 +729,14 @@ def spmm_csr_tiled(plan, val2: torch.Tensor, x: torch.Tensor, n: int, x_panels: 
 
 
 def tiles_help(n: int, D: int) -> bool:
-    """A hop over a table much larger than the eight L2s on the graph-tiled kernel: D a multiple of 256 (one panel per XCD and
-    more).  Measured on c2's graph (tools/gnn_probe.py, us per hop, tiled / panel kernel): row-major in 119 / 134, panel-major in
-    114 / 118; on a uniformly random graph 125 / 135 (tools/microbench/spmm_tiled_bench.hip); D = 128 row -> row 65.7 / 66.8 (left
-    to the slice kernel).  RAGRAPH_SPMM_TILED=0: the panel kernels (A/B); =2: also D = 64 / 128."""
-    mode = os.environ.get("RAGRAPH_SPMM_TILED", "1")
+    """A hop over a table much larger than the eight L2s on the graph-tiled kernel -- OPT-IN (RAGRAPH_SPMM_TILED=1: D a multiple
+    of 256; =2: also D = 64 / 128).  Measured on c2's graph (tools/gnn_probe.py, us per hop, tiled / panel kernel): row-major in
+    119 / 134, panel-major in 114 / 118, the GNN forward alone 0.534 / 0.545 ms; on a uniformly random graph 125 / 135
+    (tools/microbench/spmm_tiled_bench.hip).  Not the default because inside the full c2 step the hops run on a side stream UNDER
+    the retrieval, and a tiled workgroup holds a CU's whole LDS for the length of the launch: the filter kernel's workgroup for
+    that CU starts late -- 20.54 - 20.59 ms per step on the panel kernels, 20.55 - 20.69 tiled (A/B on one box,
+    profiles/r6_spmm_tiled.txt)."""
+    mode = os.environ.get("RAGRAPH_SPMM_TILED", "0")
     if mode == "0" or n * D * 4 < (32 << 20):
         return False
     return (D % 256 == 0 and D <= 2048) or (mode == "2" and D in (64, 128))

@@ -232,6 +232,62 @@ def test_edge_cal_loss_gradients_match_torch(dev):
 
 
 
+@pytest.mark.parametrize("rng", ["host", "device"])
+def test_edge_cal_loss_with_edge_dropout_rebuilds_its_graph_natively(dev, rng):
+    """The fine-tuning step WITH edge dropout (modules/RAGraph.py:337-343, utils.py:40-53): every step draws a mask, keeps the
+    set edges (ragraph_mask_positions_i64) and rebuilds the destination-sorted CSR (ragraph_coo_to_csr_i64) -- against a
+    restatement of the same step on the SAME mask with torch ops: the loss to 1e-5, finite gradients on every parameter.  Mask on
+    the host generator (the reference's draw) and on the device."""
+    from ragraph_amd import kernels as K
+    from ragraph_amd.data import synthetic_bipartite
+    from ragraph_amd.RAGraph_edge import RAGraph as RAGraphEdge
+
+    U, I, D = 300, 200, 64
+    edges, norm, times = synthetic_bipartite(U, I, edges_per_user=6, seed=12, device=dev)
+
+    class DS:
+        num_users, num_items = U, I
+    DS.edges, DS.edge_norm, DS.edge_times = edges, norm, times
+
+    class Pre:
+        def generate(self):
+            g = torch.Generator(device=dev).manual_seed(5)
+            return 0.1 * torch.randn(U, D, device=dev, generator=g), 0.1 * torch.randn(I, D, device=dev, generator=g)
+
+    torch.manual_seed(3)
+    m = RAGraphEdge(DS, Pre(), phase="finetune", use_RAG=False, use_LoRA=False, retrieve_num=5, device=dev).train()
+    m.edge_dropout, m.dropout_rng = 0.5, rng
+    masks = []
+    real = m.draw_edge_mask
+    m.draw_edge_mask = lambda: (masks.append(real()), masks[-1])[1]
+    batch = (torch.randint(0, U, (64,)), torch.randint(0, I, (64,)), torch.randint(0, I, (64,)))
+    loss, _ = m.cal_loss(batch)
+    loss.backward()
+    mask = masks[0]
+    assert mask.is_cuda and mask.dtype == torch.bool and 0.35 < float(mask.float().mean()) < 0.65
+    assert torch.equal(K.mask_positions(mask), torch.nonzero(mask).reshape(-1))
+    for name in ("user_embedding", "item_embedding", "gating_weight", "gating_bias"):
+        gr = getattr(m, name).grad
+        assert gr is not None and torch.isfinite(gr).all() and float(gr.abs().max()) > 0, name
+    # the same step on the same kept edges, torch ops
+    e, w, t = edges[mask], norm[mask], times[mask]
+    with torch.no_grad():
+        tn = m._relative_edge_time_encoding(e, t)
+        en = w * 0.5 + tn * 0.5
+        x = torch.cat([m.user_embedding, m.item_embedding])
+        x = x * torch.sigmoid(x @ m.gating_weight + m.gating_bias)
+        res = [x]
+        for _ in range(3):
+            res.append(torch.zeros_like(x).index_add_(0, e[:, 1], res[-1][e[:, 0]] * en[:, None]))
+        tot = sum(res)
+        ueo, ieo = tot[:U], tot[U:]
+        us, ps, ns = (b.to(dev) for b in batch)
+        pos, neg = (ueo[us] * ieo[ps]).sum(1), (ueo[us] * ieo[ns]).sum(1)
+        rec = (-torch.log(1e-10 + torch.sigmoid(pos - neg))).mean()
+        reg = 0.5 * (m.user_embedding[us].norm(2) ** 2 + m.item_embedding[ps].norm(2) ** 2 + m.item_embedding[ns].norm(2) ** 2) / 64.0
+    assert abs(float(loss) - float(rec + 1e-4 * reg)) < 1e-5
+
+
 @pytest.mark.parametrize("flavour", ["node", "graph"])
 def test_downprompt_weight_gradients_match_torch(dev, flavour):
     """The prompt weight is the trainable parameter of downstreamprompt (RAGraph_node/downprompt.py:118-130 with ELU,

@@ -143,3 +143,41 @@ def test_coo_to_csr_matches_the_stable_sort_formulation(dev, E, n, sort_cols):
         t_ref = ref.transposed()
         t = got.transposed()
         assert torch.equal(t.rowptr.cpu(), t_ref.rowptr) and torch.equal(t.col.cpu(), t_ref.col) and torch.equal(t.val.cpu(), t_ref.val)
+
+
+@pytest.mark.parametrize("E,p", [(0, 0.5), (1, 1.0), (1000, 0.0), (100_003, 0.5), (3_000_000, 0.31)])
+def test_mask_positions_matches_nonzero(dev, E, p):
+    """ragraph_mask_positions_i64 (the edge flavour's per-step edge dropout, modules/utils.py:40-53, on the library's own prefix
+    sums) against torch.nonzero: the same positions in the same order, bool and uint8 masks, nothing set, everything set."""
+    from ragraph_amd import kernels as K
+
+    g = torch.Generator(device=dev).manual_seed(E + 7)
+    mask = torch.rand(E, device=dev, generator=g) < p
+    want = torch.nonzero(mask).reshape(-1)
+    assert torch.equal(K.mask_positions(mask), want)
+    assert torch.equal(K.mask_positions(mask.to(torch.uint8)), want)
+
+
+def test_verify_merged_prior_matches_the_formula(dev):
+    """ragraph_verify_merged_prior_f32 (the owner's verdict on the merged lists of a sharded call): rows below the prior are
+    counted, all-zero queries need no proof, the smallest / largest proven k-th best and the statistics words' candidates."""
+    from ragraph_amd import kernels as K
+
+    g = torch.Generator(device=dev).manual_seed(5)
+    R, k = 10_001, 10
+    s = torch.sort(torch.rand(R, k, device=dev, generator=g), dim=1, descending=True).values
+    s[7] = 0.0                                  # a zero query: every score +0
+    s[9, k - 1] = float("-inf")                 # fewer than k candidates: never proven under a prior
+    kth = s[:, k - 1]
+    prior = float(torch.quantile(kth[torch.isfinite(kth)], 0.2))
+    words = torch.zeros(32, dtype=torch.int32, device=dev)
+    words[0], words[2], words[3], words[5], words[6] = K.FILTER_STATS_MAGIC, 300, 90, 10, 9
+    over = torch.tensor([3], dtype=torch.int32, device=dev)
+    for pr in (None, prior):
+        out = K.verify_merged_prior(s, pr, words, over).cpu().tolist()
+        zero = (s[:, 0] == 0) & (kth == 0)
+        ok = zero | (kth >= pr) if pr is not None else torch.ones_like(zero)
+        live = ok & ~zero & torch.isfinite(kth)
+        assert out[0] == float((~ok).sum()) and out[1] == -float(kth[live].min()) and out[2] == float(kth[live].max())
+        assert abs(out[3] - 40.0) < 1e-5 and out[4] == 3.0
+    assert K.verify_merged_prior(s[:0], prior).cpu().tolist()[0] == 0.0

@@ -1041,6 +1041,27 @@ def test_propagation_rows_slice_through_panels(dev):
         assert part.shape == (hi - lo, D) and torch.equal(part, whole[lo:hi])
 
 
+def test_propagation_through_the_tiled_hops_opt_in(dev, monkeypatch):
+    """RAGRAPH_SPMM_TILED=1: aggregate_k_hop_features on the graph-tiled kernel (row-major in, panel-major between the hops,
+    row-major out; the last hop of a rank's row slice on the panel kernel) -- the default path's bits."""
+    from ragraph_amd import data
+    from ragraph_amd.graph import CSRGraph
+    from ragraph_amd.ragraph_utils import Propagation
+
+    n, D = 100_000, 256
+    g = CSRGraph.from_edge_index_sym_normalized(data.synthetic_big_graph(n, 10, seed=5, device=dev), n)
+    x = torch.randn(n, D, device=dev)
+    whole = Propagation.aggregate_k_hop_features(g, x, 3)
+    assert not g._tile_plans                                  # (the default path made no plan)
+    monkeypatch.setenv("RAGRAPH_SPMM_TILED", "1")
+    tiled = Propagation.aggregate_k_hop_features(g, x, 3)
+    assert g._tile_plans and next(iter(g._tile_plans.values())) is not None
+    assert torch.equal(tiled, whole)
+    part = Propagation.aggregate_k_hop_features(g, x, 3, rows=(37_500, 50_000))
+    assert torch.equal(part, whole[37_500:50_000])
+    assert torch.equal(Propagation.aggregate_k_hop_features(g, x, 1), Propagation.aggregate_k_hop_features(g, x, 1))
+
+
 @pytest.mark.parametrize("n,D,deg", [(3000, 256, 7), (70_001, 128, 9), (70_001, 64, 5), (150_000, 256, 11), (40_000, 512, 6), (129, 256, 3)])
 def test_spmm_csr_tiled_bit_exact(dev, n, D, deg):
     """The graph-tiled hop (csrc/sparse.hip spmm_tiled_kernel; CSRGraph.tile_plan): destination chunks whose sums stay in LDS,
@@ -1072,12 +1093,12 @@ def test_spmm_csr_tiled_bit_exact(dev, n, D, deg):
     P = D // 32
     for src_bytes in (CSRGraph.TILE_SOURCE_BYTES, 40_000):           # the product's blocks, and many small ones
         g._tile_plans.clear()
-        old = CSRGraph.TILE_SOURCE_BYTES
-        CSRGraph.TILE_SOURCE_BYTES = src_bytes
+        old, old_near = CSRGraph.TILE_SOURCE_BYTES, CSRGraph.TILE_NEAR_ROWS
+        CSRGraph.TILE_SOURCE_BYTES, CSRGraph.TILE_NEAR_ROWS = src_bytes, -1   # (small graphs: every edge is "near" -- judged below)
         try:
             plan = g.tile_plan(P)
         finally:
-            CSRGraph.TILE_SOURCE_BYTES = old
+            CSRGraph.TILE_SOURCE_BYTES, CSRGraph.TILE_NEAR_ROWS = old, old_near
         assert plan is not None and plan.C * plan.RG * 128 >= n and plan.perm.numel() == r.size and int((plan.row3 != -1).sum()) == r.size
         v2 = g.tiled_values(plan, g.val)
         to_rows = lambda y: y.view(P, n, 32).permute(1, 0, 2).reshape(n, D)
@@ -1089,9 +1110,19 @@ def test_spmm_csr_tiled_bit_exact(dev, n, D, deg):
         assert torch.equal(to_rows(K.spmm_csr_tiled(plan, v2, xp, n, True, True, act=K.ACT_RELU)), ref)      # panel -> panel
         two = K.spmm_csr_tiled(plan, v2, yp, n, True, False, act=K.ACT_NONE)                                # a second hop
         assert torch.equal(two, K.spmm_csr(g.rowptr, g.col, g.val, ref, act=K.ACT_NONE))
+    # no plan: a numbering that keeps neighbours close (the panel kernel serves it from L1 / L2 at a lower cost per edge)
+    if n >= 40_000:
+        rr = np.repeat(np.arange(n), 4)
+        cc = np.sort(np.clip(rr.reshape(n, 4) + rng.integers(-50, 51, (n, 4)), 0, n - 1), axis=1).reshape(-1)
+        rp = np.arange(0, 4 * n + 1, 4, dtype=np.int64)
+        assert CSRGraph(_t(rp, dev), _t(cc.astype(np.int32), dev), _t(np.ones(4 * n, np.float32), dev), n).tile_plan(P) is None
     # no plan: a graph whose columns do not ascend inside a row (the tiled order would not be the CSR order)
     if r.size > 10:
         c2 = c.copy()
         i = int(np.flatnonzero((r[1:] == r[:-1]) & (c[1:] != c[:-1]))[0])
         c2[i], c2[i + 1] = c2[i + 1], c2[i]
-        assert CSRGraph(_t(rowptr, dev), _t(c2.astype(np.int32), dev), _t(val, dev), n).tile_plan(P) is None
+        old_near, CSRGraph.TILE_NEAR_ROWS = CSRGraph.TILE_NEAR_ROWS, -1
+        try:
+            assert CSRGraph(_t(rowptr, dev), _t(c2.astype(np.int32), dev), _t(val, dev), n).tile_plan(P) is None
+        finally:
+            CSRGraph.TILE_NEAR_ROWS = old_near
