@@ -28,6 +28,20 @@ class GcnLayers(nn.Module):
             out = self.convs[i]((out, adj))
         return out.unsqueeze(dim=0)
 
+    @torch.no_grad()
+    def forward_rows(self, seq, adj, lo: int, hi: int):
+        """Rows [lo, hi) of forward(seq, adj, False): every layer but the last over all rows (the last layer's rows gather
+        from all of its input), the last over the slice.  None when the graph has hub rows (their blocks are spread by the
+        whole-graph entry)."""
+        from .graph import as_csr
+        g = as_csr(adj)
+        if g.has_long_rows:
+            return None
+        out = torch.squeeze(seq, dim=0)
+        for i in range(self.num_layers_num - 1):
+            out = self.convs[i]((out, g))
+        return self.convs[self.num_layers_num - 1].forward_rows(out, g, lo, hi)
+
     # few-shot split (RAGraph_node_fewshot/models/gcnlayers.py:62-85): encode = layer 0, decode = layer 1
     @torch.no_grad()
     def encode(self, seq, adj):

@@ -97,6 +97,19 @@ class GCN(nn.Module):
             self._wt_cache = (tag, w.detach().t().contiguous())
         return self._wt_cache[1]
 
+    def forward_rows(self, x, adj, lo: int, hi: int):
+        """Rows [lo, hi) of forward((x, adj)) -- inference only: the aggregation runs over that slice of the row pointers
+        (gathering from all of x, or of x W^T), the dense part on hi - lo rows.  Row for row the arithmetic of forward(): a
+        rank that answers a slice of the queries (ragraph_amd.sharded) needs only these rows before its retrieval can start."""
+        g = as_csr(adj)
+        rp = g.rowptr[lo:hi + 1]
+        xs = sparse_features(x, probe=False)
+        if xs is None and aggregate_first(x.shape[1], self.fc.weight.shape[0]):
+            agg = K.spmm_csr(rp, g.col, g.val, x)
+            return K.linear(agg, self.fc.weight, self.bias, act=K.ACT_PRELU, alpha=self._alpha())
+        seq_fts = K.spmm_csr(xs[0], xs[1], xs[2], self._weight_t()) if xs is not None else K.linear(x, self.fc.weight)
+        return K.spmm_csr(rp, g.col, g.val, seq_fts, bias=self.bias, act=K.ACT_PRELU, alpha=self._alpha())
+
     def forward(self, input, sparse=False):
         """input = (seq [n,F], adj): adj dense as in the reference (layers/gcn.py:26-40) or a CSRGraph.  The `sparse`
         flag is accepted for signature compatibility; aggregation is always the CSR SpMM kernel."""

@@ -27,6 +27,14 @@ class PrePrompt(nn.Module):
         sparse_features(features)
         return self.gcn(features, adj, False, False).squeeze(0).detach()
 
+    @torch.no_grad()
+    def inference_rows(self, features, adj, lo: int, hi: int):
+        """Rows [lo, hi) of inference(features, adj), bit for bit, at the cost of those rows (+ the earlier layers): what a rank
+        that answers a slice of the queries needs before its retrieval can start (None: take the whole-graph call)."""
+        sparse_features(features)
+        h = self.gcn.forward_rows(features, adj, lo, hi)
+        return None if h is None else h.detach()
+
     def encode(self, features, adj):  # RAGraph_node_fewshot/preprompt.py:74-75
         sparse_features(features)
         return self.gcn.encode(features, adj)
