@@ -403,3 +403,26 @@ def test_randomised_soaks_short(dev, tool, args):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", tool)] + args, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok:" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("F,order", [(128, None), (128, "1"), (300, None)])
+def test_inference_rows_are_the_rows_of_inference(dev, monkeypatch, F, order):
+    """PrePrompt.inference_rows (a query-sharded rank encodes ITS rows before its retrieval starts; the whole-graph encode runs
+    beside it): rows [lo, hi) of inference(), bit for bit -- the aggregate-first association (F = 128 -> 256), the reference's
+    order (RAGRAPH_GCN_REFERENCE_ORDER=1), a width that keeps the reference order anyway (300), and two layers."""
+    from ragraph_amd import data
+    from ragraph_amd.graph import CSRGraph
+    from ragraph_amd.preprompt import PrePrompt
+
+    if order:
+        monkeypatch.setenv("RAGRAPH_GCN_REFERENCE_ORDER", order)
+    n, D = 30_000, 256
+    torch.manual_seed(1)
+    g = CSRGraph.from_edge_index_sym_normalized(data.synthetic_big_graph(n, 10, seed=3, device=dev), n)
+    x = torch.randn(n, F, device=dev)
+    for layers in (1, 2):
+        pre = PrePrompt(F, D, "prelu", layers, 0.3).to(dev)
+        whole = pre.inference(x, g)
+        for lo, hi in ((0, 3750), (11_000, 19_001), (n - 1, n)):
+            part = pre.inference_rows(x, g, lo, hi)
+            assert part.shape == (hi - lo, D) and torch.equal(part, whole[lo:hi])
