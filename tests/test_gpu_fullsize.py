@@ -318,13 +318,16 @@ def test_sharded_filtered_exchange_matches_single_gpu(dev, G, B, pool):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B", [3000, 300])
-def test_sharded_unequal_shards_of_a_duplicate_bank(dev, B):
+@pytest.mark.parametrize("B,prior_mode", [(3000, None), (300, None), (3000, "low"), (3000, "mid"), (300, "low")])
+def test_sharded_unequal_shards_of_a_duplicate_bank(dev, B, prior_mode):
     """Three row shards of a bank of duplicates, each collapsed by its own KeyIndex to a different number of unique rows: one
     searched as it is (200 000 distinct rows = plan_n), one at a quarter of that (the same phases over proportionally
     fewer keys), one tiny (an exact participant: its fp32 top-k offered at every exchange).  Threads as ranks, exchanges
     through a barrier as in the test above; the expanded per-shard lists merge to the fp32 kernel's result over all
-    600 000 rows, bit for bit."""
+    600 000 rows, bit for bit.  prior_mode (round 6): the same under the group's speculative first bound -- every shard's thread
+    sets the same prior, no phase-0 exchange happens (the short shard, an exact participant, skips it too) -- "low": below every
+    query's k-th best, every row proven; "mid": at the 30 % quantile, where the owner's verdict must name exactly the rows whose
+    true k-th best is below it and every other row must carry the fp32 kernel's bits."""
     import threading
 
     from ragraph_amd import kernels as K
@@ -351,13 +354,21 @@ def test_sharded_unequal_shards_of_a_duplicate_bank(dev, B):
     searched = [ix.search_rows(min_unique=64) for ix in idx]
     assert searched[0] == n and 40_000 < searched[1] < 70_000 and searched[2] < 16_000
     plan_n = max(searched)
+    prior = None
+    if prior_mode is not None:
+        assert idx[0].sharded_speculates(B, k, plan_n, G)
+        kth = full_s[:, k - 1]
+        live = kth[full_s[:, 0] != 0]
+        prior = float(live.min()) - 0.01 if prior_mode == "low" else float(torch.quantile(live, 0.3))
     barrier = threading.Barrier(G)
     slots = [None] * G
     out, errs = [None] * G, []
+    phases_seen = []
     m = min(k, 2 * (-(-k // G)))
 
     def exchange_for(r):
         def exchange(phase, theta, scores):
+            phases_seen.append(phase)
             torch.cuda.current_stream().synchronize()
             slots[r] = scores[:, :m].clone()
             torch.cuda.current_stream().synchronize()
@@ -371,7 +382,7 @@ def test_sharded_unequal_shards_of_a_duplicate_bank(dev, B):
     def run(r):
         try:
             with torch.cuda.stream(torch.cuda.Stream()):
-                s, i = idx[r].topk(q, k, idx_base=r * n, exchange=exchange_for(r), plan_n=plan_n)
+                s, i = idx[r].topk(q, k, idx_base=r * n, exchange=exchange_for(r), plan_n=plan_n, prior=prior)
                 torch.cuda.current_stream().synchronize()
                 out[r] = (s, i)
         except BaseException as e:  # noqa: BLE001
@@ -385,7 +396,21 @@ def test_sharded_unequal_shards_of_a_duplicate_bank(dev, B):
         t.join()
     assert not errs, errs
     ms, mi = K.topk_merge(torch.stack([o[0] for o in out]), torch.stack([o[1] for o in out]))
-    assert torch.equal(mi, full_i) and torch.equal(ms, full_s)
+    if prior is None:
+        assert torch.equal(mi, full_i) and torch.equal(ms, full_s)
+        assert 0 in phases_seen
+        return
+    assert 0 not in phases_seen and len(phases_seen) % G == 0        # no first-bound exchange on ANY shard, the rest line up
+    words = K.verify_merged_prior(ms, prior).cpu().tolist()
+    zero = (full_s[:, 0] == 0) & (full_s[:, k - 1] == 0)
+    proven = zero | (full_s[:, k - 1] >= prior)
+    differs = (mi != full_i).any(dim=1) | (ms != full_s).any(dim=1)
+    assert not bool((differs & proven).any())                          # every proven row: the fp32 kernel's bits
+    assert int(words[0]) == int((~proven).sum())                       # the verdict names exactly the others
+    if prior_mode == "low":
+        assert int(words[0]) == 0 and not bool(differs.any())
+    else:
+        assert int(words[0]) > 0
 
 
 @pytest.mark.gpu
