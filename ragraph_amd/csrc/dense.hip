@@ -418,7 +418,14 @@ static int launch_linear_stream(const float* X, int64_t M, const float* W, int64
   int64_t wgs = wgs_target / col_blocks;
   if (wgs < 1) wgs = 1;
   int64_t per = cdiv(total_stages, wgs);
-  if (per < 4) per = 4;
+  // (a short stream -- a rank's slice of the rows: 12 500 x 128 -> 256 is 196 stages -- used to keep "at least 4 stages per
+  // workgroup so the pipeline fills": 49 workgroups on 256 CUs, 54 us where the whole 100 000-row stream takes 96.  Fewer
+  // stages per workgroup and all CUs busy; RAGRAPH_LINEAR_MIN_STAGES: A/B)
+  static const int64_t min_stages = [] {
+    const char* e = getenv("RAGRAPH_LINEAR_MIN_STAGES");
+    return e ? (int64_t)atoll(e) : (int64_t)1;
+  }();
+  if (per < min_stages) per = min_stages;
   wgs = cdiv(total_stages, per);
   hipLaunchKernelGGL(linear_stream_kernel<KD>, dim3((unsigned)wgs, (unsigned)col_blocks), dim3(C::THREADS), C::LDS_BYTES,
                      st, X, M, W, N, bias, act, alpha, Y, per);
