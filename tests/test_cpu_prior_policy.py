@@ -129,3 +129,46 @@ def test_int8_gate_judges_the_normal_granules_of_a_two_scale_copy():
     allowed, cap, idx = gate(base)
     idx._i8_off = True                                                               # demoted by its calls: the cap follows
     assert idx._cap_i8()[1] is False and idx.ops.caps[-1] == 0
+
+
+def test_group_prior_policy_is_a_function_of_the_pooled_numbers():
+    """ragraph_amd.sharded.GroupPrior (round 6): two ranks that feed the same pooled words derive the same prior at the same
+    call, withdraw it at the same call after a miss / a flood of candidates / overflowed lists, re-probe after the same number
+    of calls and back off four-fold when the re-probe fails -- the number of exchanges of a sharded call can never differ
+    between ranks."""
+    from ragraph_amd.sharded import GroupPrior
+
+    a, b = GroupPrior(), GroupPrior()
+    k, B = 10, 1000
+    feed = [  # (speculative?, misses, lo, hi, cand, lists_over) as the all_reduce leaves them on every rank
+        (False, 0, 0.240, 0.280, 50.0, 0), (False, 0, 0.238, 0.279, 52.0, 0),
+    ]
+    for ga in (a, b):
+        assert ga.prior_for(B, k) is None and ga.prior_for(5, k) is None
+        for w in feed:
+            assert ga.record(k, *w) is True
+    pa, pb = a.prior_for(B, k), b.prior_for(B, k)
+    assert pa == pb and abs(pa - (0.238 - 0.5 * (0.280 - 0.238))) < 1e-12
+    assert a.prior_for(16, k) is None                                  # below the smallest speculative batch
+    for ga in (a, b):
+        assert ga.record(k, True, 0, 0.239, 0.281, 60.0, 0) is True     # a speculative call that stands
+        assert ga.prior_for(B, k) is not None
+        assert ga.record(k, True, 3, 0.250, 0.281, 60.0, 0) is False    # three rows missed: the call is repeated ...
+        assert ga.prior_for(B, k) is None                               # ... and the prior withdrawn on every rank alike
+    # the history restarts: two calls with a bound pass, but the withdrawal lasts REPROBE_CALLS calls
+    for ga in (a, b):
+        for _ in range(GroupPrior.REPROBE_CALLS - 1):
+            ga.record(k, False, 0, 0.24, 0.28, 50.0, 0)
+            assert ga.prior_for(B, k) is None
+        ga.record(k, False, 0, 0.24, 0.28, 50.0, 0)
+        assert ga.prior_for(B, k) is not None                           # the re-probe
+        assert ga.record(k, True, 0, 0.24, 0.28, 500.0, 0) is True      # a flood of candidates: stands, but withdrawn again
+        assert ga.prior_for(B, k) is None and ga._state(k)["after"] == 4 * GroupPrior.REPROBE_CALLS
+    assert a.calls == b.calls and a.used == b.used == 3 and a.missed_calls == 1
+    c = GroupPrior()
+    c.forced = 0.3
+    assert c.prior_for(3, k) == 0.3                                      # (tests force a prior whatever the history says)
+    c.forced = None
+    c.record(k, False, 0, 0.2, 0.3, 40.0, 2)                             # overflowed lists are no ground for a prior
+    c.record(k, False, 0, 0.2, 0.3, 40.0, 0)
+    assert c.prior_for(B, k) is None
