@@ -426,6 +426,15 @@ int ragraph_mask_positions_i64(const unsigned char* mask, int64_t E, int64_t* po
 int ragraph_spmm_csr_panels_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n, const float* X,
                                 int64_t x_rows, int x_panels, int D, int act, float alpha, float* Y, int y_panels, void* stream);
 
+/* a4 in ONE launch, inference association  -- layers/gcn.py:36-40 evaluated as (A_hat X) W^T (a layer at most half as wide in as
+ * out; same sum, another order: DESIGN.md section 2).  The dense layer's stream kernel makes its stages itself: the lanes that
+ * would copy a row of the aggregated table into LDS walk that row's edges and leave the sum there, under the other stage's
+ * MFMAs -- the aggregated [M, K] table never exists in HBM.  rowptr [M + 1] (a slice of a graph's row pointers gives those
+ * rows), col / val the graph's, X [*, K] the table gathered from, W [N, K] (nn.Linear layout), Y [M, N] = act((A X) W^T + bias).
+ * K in {64, 128}.  The bits of ragraph_spmm_csr_f32 followed by ragraph_linear_f32 (hub rows summed in blocks of 4096). */
+int ragraph_spmm_linear_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t M, const float* X, int K,
+                            const float* W, int64_t N, const float* bias, int act, float alpha, float* Y, void* stream);
+
 /* a7 over a TILED graph (round 6; opt-in)  -- Propagation.py:19-25, layers/gcn.py:36.  The hop of ragraph_spmm_csr_panels_f32
  * with the GRAPH cut so that what an XCD gathers from at any moment is a few MB: source rows in blocks, destination rows in C
  * chunks of 128 RG rows whose 32-column sums stay in one workgroup's LDS, edges stored once more in (chunk, 8-lane group, source

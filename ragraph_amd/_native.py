@@ -85,6 +85,7 @@ SIGNATURES = {
     "ragraph_mask_positions_workspace_bytes": (_sz, [_i64]),
     "ragraph_mask_positions_i64": (_i32, [_vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "ragraph_spmm_csr_panels_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _i32, _vp]),
+    "ragraph_spmm_linear_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _i32, _f32, _vp, _vp]),
     "ragraph_spmm_csr_tiled_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _i32, _vp]),
     "ragraph_csr_row_normalize_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "ragraph_segment_softmax_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),

@@ -395,6 +395,306 @@ __global__ void __launch_bounds__(512, 2) linear_stream_kernel(const float* __re
   }
 }
 
+// ---- the aggregate-first GCN layer in ONE launch (round 6): Y = act((A X) W^T + b) ---------------------------------------
+// layers/gcn.py:36-40 evaluated as (A_hat X) W^T (inference of a layer at most half as wide in as out) was
+// two launches -- the narrow aggregation writes [n, KD], the dense layer reads it back -- of 67 + 90 us at c2 (100 000 x 128 ->
+// 256), one bound by the CUs' gather path, the other by the matrix pipe.  Here a workgroup is 16 waves of two kinds: waves 8-15
+// make the stages -- a group of KD / 4 lanes walks an output row's edges (the fmaf chain of spmm_csr_kernel: edge order, from
+// +0; rows in pairs, eight 16-byte gathers per row in flight per lane) and leaves the aggregated row in the LDS stage buffer in
+// the dense kernel's [even k | odd k] layout -- while waves 0-7 run linear_stream_kernel's MFMA chains on the stage before: the
+// bits of the two-launch form, the aggregated table never in HBM, gathers and MFMAs on the same CU at the same time.  The
+// gather waves keep two prefetches ahead of themselves (the row pointers of the stage after next, the first KD / 4 (col, val)
+// pairs of the next stage's rows: one load covers a row of up to KD / 4 edges), so a stage waits for ONE dependent latency,
+// the gathers themselves.  Rows longer than ROW_BLOCK edges are summed in blocks as everywhere (csrc/sparse.hip).
+constexpr int AGG_ROW_BLOCK = 4096;   // = sparse.hip's ROW_BLOCK (the oracle's ORACLE_ROW_BLOCK)
+template <int KD>
+struct AggLinCfg {
+  static constexpr int THREADS = 1024, MFMA_THREADS = 512;
+  static constexpr int LPR = KD / 4;                       // lanes per aggregated row (a float4 each)
+  static constexpr int GROUPS = (THREADS - MFMA_THREADS) / LPR;
+  static constexpr int R = 2;                              // rows per lane group per stage (one pair)
+  static constexpr int STAGE_ROWS = R * GROUPS;            // 32 (KD = 128) / 64 (KD = 64)
+  static constexpr int TILES = STAGE_ROWS / 32;
+  static constexpr int ROW = KD + 4;                       // padded LDS row (floats)
+  static constexpr int STAGE_FLOATS = STAGE_ROWS * ROW;
+#ifndef RG_AGGLIN_NB
+#define RG_AGGLIN_NB 4
+#endif
+  static constexpr int NB = RG_AGGLIN_NB;                  // ring of stage buffers: the gather half runs up to 3 stages ahead
+  static constexpr size_t LDS_BYTES = sizeof(float) * NB * STAGE_FLOATS + sizeof(int) * 2 * NB;
+};
+
+// the two halves meet through counters in LDS, not barriers: ready[b] counts the gather waves that have finished a stage in
+// buffer b, freed[b] the MFMA waves that are done reading one (both only grow: stage s of buffer b = s % NB is complete at
+// ready[b] = 8 (s / NB + 1) and may be overwritten at freed[b] = 8 (s / NB + 1)).  A stage's gathers take one to three
+// dependent round trips depending on its longest row, its MFMAs a fixed time: in lockstep every stage cost the slower of
+// the two (136 us at c2), with the ring the sums overlap.
+__device__ __forceinline__ void agglin_wait(int* f, int target) {
+  int spins = 0;
+  while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1 << 26)) __builtin_trap();   // (seconds: a lost count is a bug, not a wait)
+  }
+}
+__device__ __forceinline__ void agglin_signal(int* f, int lane) {
+  if (lane == 0) __hip_atomic_fetch_add(f, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int KD>
+__global__ void __launch_bounds__(1024, 1) spmm_linear_stream_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                                     const float* __restrict__ val, const float* __restrict__ X,
+                                                                     int64_t M, const float* __restrict__ W, int64_t N,
+                                                                     const float* __restrict__ bias, int act, float alpha,
+                                                                     float* __restrict__ Y) {
+  using C = AggLinCfg<KD>;
+  extern __shared__ float4 lin_smem4[];
+  float* smem = reinterpret_cast<float*>(lin_smem4);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t total_stages = (M + C::STAGE_ROWS - 1) / C::STAGE_ROWS;
+  const int64_t st0 = (int64_t)blockIdx.x * total_stages / gridDim.x;          // stages dealt evenly: counts differ by one at most
+  const int64_t st1 = (int64_t)(blockIdx.x + 1) * total_stages / gridDim.x;
+  if (st0 >= st1) return;
+  const int nstages = (int)(st1 - st0);
+  int* ready = reinterpret_cast<int*>(smem + C::NB * C::STAGE_FLOATS);
+  int* freed = ready + C::NB;
+  if (tid < 2 * C::NB) ready[tid] = 0;
+  __syncthreads();
+
+  if (wave < 8) {
+    // ---- the dense half: linear_stream_kernel's chains on the stage the other half finished one barrier ago ----
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t n = (int64_t)blockIdx.y * 256 + wave * 32 + j;  // this lane's output column
+    float breg[KD / 2];   // B operand: row n of W, k-slots h, h + 2, ... (as linear_stream_kernel)
+    {
+      const float4* wp = reinterpret_cast<const float4*>(W + (n < N ? n : N - 1) * KD);
+#pragma unroll
+      for (int c0 = 0; c0 < KD / 4; c0 += 16) {
+#pragma unroll
+        for (int c = c0; c < c0 + 16 && c < KD / 4; ++c) {
+          const float4 v = wp[c];
+          breg[2 * c] = h ? v.y : v.x;
+          breg[2 * c + 1] = h ? v.w : v.z;
+        }
+#pragma unroll
+        for (int c = c0; c < c0 + 16 && c < KD / 4; ++c) asm volatile("" : "+v"(breg[2 * c]), "+v"(breg[2 * c + 1]));
+        asm volatile("" ::: "memory");
+      }
+    }
+    const float bv = (bias && n < N) ? bias[n] : 0.f;
+#ifdef RG_AGGLIN_PRIO
+    __builtin_amdgcn_s_setprio(RG_AGGLIN_PRIO);
+#endif
+    for (int s = 0; s < nstages; ++s) {
+      const int buf = s % C::NB;
+      agglin_wait(ready + buf, 8 * (s / C::NB + 1));
+#ifndef RG_AGGLIN_NO_MFMA   // (diagnostic build: the gather half alone)
+#pragma unroll 1
+      for (int t = 0; t < C::TILES; ++t) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* arow = smem + buf * C::STAGE_FLOATS + (t * 32 + j) * C::ROW + h * (KD / 2);
+#pragma unroll
+        for (int c = 0; c < KD / 8; ++c) {
+          const float4 v = *reinterpret_cast<const float4*>(arow + 4 * c);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, breg[4 * c], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, breg[4 * c + 1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, breg[4 * c + 2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, breg[4 * c + 3], acc, 0, 0, 0);
+        }
+        if (t == C::TILES - 1) agglin_signal(freed + buf, lane);   // (every read of the buffer has returned: the MFMAs took them)
+        const int64_t m_base = (st0 + s) * C::STAGE_ROWS + t * 32 + 4 * h;
+        if (n < N) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t m = m_base + (r & 3) + 8 * (r >> 2);
+            if (m < M) {
+              float v = acc[r];
+              if (bias) v = __fadd_rn(v, bv);
+              Y[m * N + n] = apply_act(v, act, alpha);
+            }
+          }
+        }
+      }
+#else
+      agglin_signal(freed + buf, lane);
+#endif
+    }
+    return;
+  }
+
+  // ---- the gather half ----
+  constexpr int LPR = C::LPR;
+  const int gt = tid - C::MFMA_THREADS;
+  const int grp = gt / LPR, lr = gt % LPR, gbase = (lane / LPR) * LPR;   // gbase: first lane of my group in the wave
+  const float4* X4 = reinterpret_cast<const float4*>(X);
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto fma4 = [](float v, const float4& x, float4& a) {
+    a.x = fmaf(v, x.x, a.x); a.y = fmaf(v, x.y, a.y); a.z = fmaf(v, x.z, a.z); a.w = fmaf(v, x.w, a.w);
+  };
+  // a block of one row by itself (hub rows): the (col, val) pairs of a chunk loaded by the group's first lanes
+  auto chain_one = [&](int64_t e0, int cnt) {
+    float4 acc = zero4;
+    for (int base = 0; base < cnt; base += 8) {
+      int my_c = 0;
+      float my_v = 0.f;
+      if (lr < 8 && base + lr < cnt) {
+        my_c = col[e0 + base + lr];
+        my_v = val[e0 + base + lr];
+      }
+      float4 x[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = __shfl(my_c, gbase + k);
+        x[k] = base + k < cnt ? X4[(int64_t)c * LPR + lr] : zero4;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float v = __shfl(my_v, gbase + k);
+        if (base + k < cnt) fma4(v, x[k], acc);
+      }
+    }
+    return acc;
+  };
+  // per-row state: cur = the stage being made (row pointers + the first LPR pairs in registers, lane lr holding edge lr),
+  // nxt = the stage after it (row pointers only: its pairs are fetched while cur is gathered)
+  int64_t cur_e0[2], nxt_e0[2];
+  int cur_deg[2], nxt_deg[2];   // (saturated: a hub row reads its exact length again)
+  int cur_c[2];
+  float cur_v[2];
+  auto load_rowptr = [&](int stage, int64_t* e0, int* deg) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t r = (st0 + stage) * C::STAGE_ROWS + grp + C::GROUPS * i;
+      e0[i] = 0;
+      deg[i] = 0;
+      if (stage < nstages && r < M) {
+        e0[i] = rowptr[r];
+        const int64_t d64 = rowptr[r + 1] - e0[i];
+        deg[i] = d64 > AGG_ROW_BLOCK ? AGG_ROW_BLOCK + 1 : (int)d64;
+      }
+    }
+  };
+  auto load_pairs = [&](const int64_t* e0, const int* deg, int* c, float* v) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      c[i] = 0;
+      v[i] = 0.f;
+      if (lr < deg[i]) {
+        c[i] = col[e0[i] + lr];
+        v[i] = val[e0[i] + lr];
+      }
+    }
+  };
+  auto make_stage = [&](int stage) {   // rows of `stage` = A x into LDS buffer stage & 1; cur <- the stage after
+    int nc[2];
+    float nv[2];
+    int64_t nn_e0[2];
+    int nn_deg[2];
+    load_pairs(nxt_e0, nxt_deg, nc, nv);            // (in flight under the gathers below)
+    load_rowptr(stage + 2, nn_e0, nn_deg);
+    float4 a = zero4, b = zero4;
+    if (cur_deg[0] > AGG_ROW_BLOCK || cur_deg[1] > AGG_ROW_BLOCK) {
+      // a hub row in the pair: blocks of AGG_ROW_BLOCK edges, each its own chain, the block sums added in order
+#pragma unroll 1
+      for (int i = 0; i < 2; ++i) {
+        const int64_t r = (st0 + stage) * C::STAGE_ROWS + grp + C::GROUPS * i;
+        const int64_t e0 = i ? cur_e0[1] : cur_e0[0];
+        const int64_t deg = (i ? cur_deg[1] : cur_deg[0]) > AGG_ROW_BLOCK ? rowptr[r + 1] - e0 : (int64_t)(i ? cur_deg[1] : cur_deg[0]);
+        float4 tot = zero4;
+#pragma unroll 1
+        for (int64_t b0 = 0; b0 < deg; b0 += AGG_ROW_BLOCK) {
+          const float4 p = chain_one(e0 + b0, (int)(deg - b0 < AGG_ROW_BLOCK ? deg - b0 : AGG_ROW_BLOCK));
+          if (b0) {
+            tot.x = __fadd_rn(tot.x, p.x); tot.y = __fadd_rn(tot.y, p.y); tot.z = __fadd_rn(tot.z, p.z); tot.w = __fadd_rn(tot.w, p.w);
+          } else {
+            tot = p;
+          }
+        }
+        if (i) b = tot; else a = tot;
+      }
+    } else {
+      const int dA = cur_deg[0], dB = cur_deg[1];
+      int cA = cur_c[0], cB = cur_c[1];
+      float vA = cur_v[0], vB = cur_v[1];
+#ifdef RG_AGGLIN_NO_GATHER   // (diagnostic build: the dense half alone)
+      const int dmax = 0;
+#else
+      const int dmax = dA > dB ? dA : dB;
+#endif
+      for (int base = 0; base < dmax; base += 8) {
+        const int off = base % LPR;
+        if (base && off == 0) {   // past the pairs in registers: the next LPR of them
+          cA = 0; vA = 0.f; cB = 0; vB = 0.f;
+          if (base + lr < dA) { cA = col[cur_e0[0] + base + lr]; vA = val[cur_e0[0] + base + lr]; }
+          if (base + lr < dB) { cB = col[cur_e0[1] + base + lr]; vB = val[cur_e0[1] + base + lr]; }
+        }
+        float4 xa[8], xb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int c = __shfl(cA, gbase + off + k);   // (0 past the row's end: row 0 is loaded and not used -- a load under
+          xa[k] = X4[(int64_t)c * LPR + lr];            //  a condition is a branch and a wait of its own per load)
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int c = __shfl(cB, gbase + off + k);
+          xb[k] = X4[(int64_t)c * LPR + lr];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float v = __shfl(vA, gbase + off + k);
+          if (base + k < dA) fma4(v, xa[k], a);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float v = __shfl(vB, gbase + off + k);
+          if (base + k < dB) fma4(v, xb[k], b);
+        }
+      }
+    }
+    const int buf = stage % C::NB;
+    if (stage >= C::NB) agglin_wait(freed + buf, 8 * (stage / C::NB));   // the MFMA half is done with the stage NB before
+    float* d = smem + buf * C::STAGE_FLOATS + grp * C::ROW + ((4 * lr) >> 1);
+    d[0] = a.x; d[1] = a.z;
+    d[KD / 2] = a.y; d[KD / 2 + 1] = a.w;
+    d += C::GROUPS * C::ROW;
+    d[0] = b.x; d[1] = b.z;
+    d[KD / 2] = b.y; d[KD / 2 + 1] = b.w;
+    agglin_signal(ready + buf, lane);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      cur_e0[i] = nxt_e0[i]; cur_deg[i] = nxt_deg[i]; cur_c[i] = nc[i]; cur_v[i] = nv[i];
+      nxt_e0[i] = nn_e0[i]; nxt_deg[i] = nn_deg[i];
+    }
+  };
+
+  load_rowptr(0, cur_e0, cur_deg);
+  load_rowptr(1, nxt_e0, nxt_deg);
+  load_pairs(cur_e0, cur_deg, cur_c, cur_v);
+#pragma unroll 1
+  for (int s = 0; s < nstages; ++s) make_stage(s);
+}
+
+template <int KD>
+static int launch_spmm_linear(const int64_t* rowptr, const int32_t* col, const float* val, const float* X, int64_t M, const float* W,
+                              int64_t N, const float* bias, int act, float alpha, float* Y, hipStream_t st) {
+  using C = AggLinCfg<KD>;
+  static DeviceOnce lds_once;
+  if (hipError_t e = raise_dynamic_lds(lds_once, &spmm_linear_stream_kernel<KD>, (int)C::LDS_BYTES); e != hipSuccess) {
+    set_error("spmm_linear: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+    return RAGRAPH_EDEVICE;
+  }
+  const int64_t total_stages = cdiv(M, C::STAGE_ROWS);
+  const int64_t col_blocks = cdiv(N, 256);
+  int64_t wgs = device_cus_multiple_of_8() / col_blocks;   // one workgroup per CU (every column block aggregates its rows again)
+  if (wgs < 1) wgs = 1;
+  if (wgs > total_stages) wgs = total_stages;
+  hipLaunchKernelGGL(spmm_linear_stream_kernel<KD>, dim3((unsigned)wgs, (unsigned)col_blocks), dim3(C::THREADS), C::LDS_BYTES, st,
+                     rowptr, col, val, X, M, W, N, bias, act, alpha, Y);
+  RG_CHECK_LAUNCH("spmm_linear");
+  return RAGRAPH_OK;
+}
+
 template <int KD>
 static int launch_linear_stream(const float* X, int64_t M, const float* W, int64_t N, const float* bias, int act,
                                 float alpha, float* Y, hipStream_t st) {
@@ -585,4 +885,21 @@ extern "C" int ragraph_linear_f32(const float* X, int64_t M, int K, const float*
   hipLaunchKernelGGL(linear_kernel, grid, dim3(256), 0, as_stream(stream), X, M, K, W, N, bias, act, alpha, Y);
   RG_CHECK_LAUNCH("linear");
   return RAGRAPH_OK;
+}
+
+// a4, inference association (A_hat X) W^T in one launch  -- layers/gcn.py:36-40 (a layer at most half as
+// wide in as out).  rowptr [M + 1] (a slice of a larger graph's row pointers gives those rows), col / val the graph's, X [*, K]
+// the table gathered from, W [N, K], Y [M, N] = act((A X) W^T + bias).  K in {64, 128}; the bits of ragraph_spmm_csr_f32
+// followed by ragraph_linear_f32.
+extern "C" int ragraph_spmm_linear_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t M, const float* X, int K,
+                                       const float* W, int64_t N, const float* bias, int act, float alpha, float* Y, void* stream) {
+  RG_REQUIRE(rowptr && col && val && X && W && Y, RAGRAPH_EINVAL, "spmm_linear: null pointer");
+  RG_REQUIRE(M >= 1 && N >= 1, RAGRAPH_EINVAL, "spmm_linear: M, N must be >= 1");
+  RG_REQUIRE(K == 64 || K == 128, RAGRAPH_EUNSUPPORTED, "spmm_linear: K=%d not in {64, 128}", K);
+  RG_REQUIRE(aligned16(X) && aligned16(W) && X != Y, RAGRAPH_EINVAL, "spmm_linear: X, W must be 16-B aligned, Y distinct from X");
+  RG_REQUIRE(act >= RAGRAPH_ACT_NONE && act <= RAGRAPH_ACT_ELU, RAGRAPH_EINVAL, "spmm_linear: bad act %d", act);
+  RG_REQUIRE(cdiv(N, 256) <= 65535, RAGRAPH_EUNSUPPORTED, "spmm_linear: N=%lld too large for one launch", (long long)N);
+  hipStream_t st = as_stream(stream);
+  return K == 128 ? launch_spmm_linear<128>(rowptr, col, val, X, M, W, N, bias, act, alpha, Y, st)
+                  : launch_spmm_linear<64>(rowptr, col, val, X, M, W, N, bias, act, alpha, Y, st);
 }

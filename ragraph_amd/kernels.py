@@ -714,6 +714,34 @@ def spmm_csr_panels(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, 
     return y
 
 
+def spmm_linear(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, x: torch.Tensor, weight: torch.Tensor,
+                bias: torch.Tensor | None = None, act: int = ACT_NONE, alpha: float = 0.0) -> torch.Tensor:
+    """act((A @ x) @ weight^T + bias) in ONE launch (ragraph_spmm_linear_f32: the aggregate-first GCN layer; x of 64 or 128
+    columns): the bits of spmm_csr followed by linear, without the aggregated table in HBM."""
+    L = _ready()
+    rowptr = _idxc(rowptr, "spmm_linear.rowptr")
+    col = _idxc(col, "spmm_linear.col", torch.int32)
+    val = _f32c(val, "spmm_linear.val")
+    x = _f32c(x, "spmm_linear.x")
+    w = _f32c(weight, "spmm_linear.weight")
+    b = _f32c(bias, "spmm_linear.bias") if bias is not None else None
+    m, n_out = rowptr.numel() - 1, w.shape[0]
+    if w.shape[1] != x.shape[1]:
+        raise ValueError(f"spmm_linear: weight [{w.shape[0]}, {w.shape[1]}] does not take x of {x.shape[1]} columns")
+    y = torch.empty((m, n_out), dtype=torch.float32, device=x.device)
+    if m:
+        N.check(L.ragraph_spmm_linear_f32(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), m, x.data_ptr(), x.shape[1], w.data_ptr(),
+                                          n_out, b.data_ptr() if b is not None else None, act, float(alpha), y.data_ptr(), _stream()),
+                 "spmm_linear")
+    return y
+
+
+def spmm_linear_helps(n_rows: int, f_in: int, f_out: int) -> bool:
+    """The aggregate-first layer in one launch: widths the fused kernel takes, enough rows to fill the chip, one block of output
+    columns (every 256-column block would aggregate its rows again).  RAGRAPH_SPMM_LINEAR=0: the two launches (A/B)."""
+    return f_in in (64, 128) and f_out <= 256 and n_rows >= 4096 and os.environ.get("RAGRAPH_SPMM_LINEAR", "1") != "0"
+
+
 def spmm_csr_tiled(plan, val2: torch.Tensor, x: torch.Tensor, n: int, x_panels: bool, y_panels: bool, act: int = ACT_NONE,
                    alpha: float = 0.0) -> torch.Tensor:
     """act(A @ x) over a TILED graph (ragraph_spmm_csr_tiled_f32; plan = CSRGraph.tile_plan(...), val2 = the edge values in

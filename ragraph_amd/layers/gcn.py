@@ -105,6 +105,8 @@ class GCN(nn.Module):
         rp = g.rowptr[lo:hi + 1]
         xs = sparse_features(x, probe=False)
         if xs is None and aggregate_first(x.shape[1], self.fc.weight.shape[0]):
+            if x.is_cuda and K.spmm_linear_helps(hi - lo, x.shape[1], self.fc.weight.shape[0]):   # (one launch, same bits)
+                return K.spmm_linear(rp, g.col, g.val, x, self.fc.weight, self.bias, act=K.ACT_PRELU, alpha=self._alpha())
             agg = K.spmm_csr(rp, g.col, g.val, x)
             return K.linear(agg, self.fc.weight, self.bias, act=K.ACT_PRELU, alpha=self._alpha())
         seq_fts = K.spmm_csr(xs[0], xs[1], xs[2], self._weight_t()) if xs is not None else K.linear(x, self.fc.weight)
@@ -126,6 +128,9 @@ class GCN(nn.Module):
             # narrow features (c2: 128 -> 256): A_hat (X W^T) = (A_hat X) W^T, and the gathers of the aggregation -- what a
             # hop costs -- move half the bytes on the narrow side; bias + PReLU ride in the dense
             # kernel's epilogue.  Another association of the same sum (oracle/pipeline.py gcn_layer(order="aggregate_first")).
+            if x.is_cuda and K.spmm_linear_helps(x.shape[0], x.shape[1], self.fc.weight.shape[0]):
+                # one launch: the aggregated row is made in the dense kernel's LDS stage and never written (same bits)
+                return K.spmm_linear(g.rowptr, g.col, g.val, x, self.fc.weight, self.bias, act=K.ACT_PRELU, alpha=self._alpha())
             if not g.has_long_rows and x.is_cuda and K.slices_help(x.shape[0], x.shape[1]):
                 agg = K.spmm_csr_panels(g.rowptr, g.col, g.val, x, x_panels=False, y_panels=False)   # (same bits)
             else:

@@ -221,6 +221,44 @@ def test_csr_row_normalize_and_segment_softmax(dev):
     assert np.allclose(sums, 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize("Kd,n,Nout,act", [(128, 5000, 256, 2), (64, 4097, 256, 1), (128, 300, 70, 0), (64, 1, 3, 3), (128, 777, 300, 2)])
+def test_spmm_linear_one_launch_bit_exact(dev, Kd, n, Nout, act):
+    """The aggregate-first GCN layer in one launch (ragraph_spmm_linear_f32) = ragraph_spmm_csr_f32 followed by
+    ragraph_linear_f32, bit for bit, and = the oracle's two steps: empty rows, a long row, a hub row past the 4096-edge block,
+    ragged last stage, an output wider than one 256-column block, a slice of the row pointers."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(Kd + n + Nout)
+    ncols = max(n, 50)
+    rowptr, col, val = _rand_csr(rng, n, ncols, 7)
+    if n > 100:   # a hub row: 2 blocks + a tail
+        deg = np.diff(rowptr)
+        deg[50] = 2 * 4096 + 19
+        rowptr = np.zeros(n + 1, dtype=np.int64)
+        rowptr[1:] = np.cumsum(deg)
+        col = rng.integers(0, ncols, rowptr[-1]).astype(np.int32)
+        val = (rng.random(rowptr[-1], dtype=np.float32) - 0.3)
+    X = rng.standard_normal((ncols, Kd), dtype=np.float32)
+    W = (rng.standard_normal((Nout, Kd), dtype=np.float32) * 0.1).astype(np.float32)
+    b = rng.standard_normal(Nout, dtype=np.float32)
+    args = (_t(rowptr, dev), _t(col, dev), _t(val, dev), _t(X, dev))
+    for bias in (b, None):
+        bd = None if bias is None else _t(bias, dev)
+        got = K.spmm_linear(*args, _t(W, dev), bd, act=act, alpha=0.25).cpu().numpy()
+        two = K.linear(K.spmm_csr(*args, long_rows=False), _t(W, dev), bd, act=act, alpha=0.25).cpu().numpy()
+        assert np.array_equal(got, two), "one launch != two launches"
+        ref = cref.linear(cref.spmm_csr(rowptr, col, val, X), W, bias=bias, act=act, alpha=0.25)
+        assert np.array_equal(got, ref), "one launch != oracle"
+    if n > 100:   # rows [lo, hi) through a slice of the row pointers (what a query-sharded rank encodes first)
+        lo, hi = 37, n - 11
+        got = K.spmm_linear(_t(rowptr, dev)[lo:hi + 1], *args[1:], _t(W, dev), _t(b, dev), act=act, alpha=0.25).cpu().numpy()
+        assert np.array_equal(got, ref_rows(rowptr, col, val, X, W, b, act, lo, hi))
+
+
+def ref_rows(rowptr, col, val, X, W, b, act, lo, hi):
+    return cref.linear(cref.spmm_csr(rowptr, col, val, X), W, bias=b, act=act, alpha=0.25)[lo:hi]
+
+
 @pytest.mark.parametrize("D", [64, 256, 20])
 def test_spmm_and_softmax_hub_rows_bit_exact(dev, D):
     """Power-law shape: a few rows hold thousands of edges (one of them most of the graph).  Rows longer than 4096 edges

@@ -1,11 +1,11 @@
 #!/bin/bash
-# the c2 step with the hops on the tiled kernel (default) and on the panel kernels, alternating, same box; then the whole GPU suite
-R=$(pwd); O=$R/gpurun_out/r6g; mkdir -p $O
-for i in 1 2 3; do
-  for t in 1 0; do
-    RAGRAPH_SPMM_TILED=$t python bench.py --no-extras --steps 20 --warmup 5 2>/dev/null | python -c "
-import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('tiled=$t run $i: ms_per_step', d['ms_per_step'])"
-  done
+# round 6, session 2: the one-launch aggregate-first encoder (ragraph_spmm_linear_f32): parity + A/B
+R=$(pwd)
+O=$R/gpurun_out/r6g
+mkdir -p $O
+timeout 120 python -m pytest tests/test_gpu_kernels.py -x -q -k "spmm_linear_one" 2>&1 | tail -5 > $O/tests.log
+timeout 300 python tools/spmm_linear_probe.py > $O/probe.txt 2>&1
+for v in 1 0; do
+  RAGRAPH_SPMM_LINEAR=$v timeout 300 python tools/prof_gnn.py 50 2>&1 | tail -2 > $O/gnn_$v.txt
 done
-python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+cat $O/tests.log $O/probe.txt $O/gnn_1.txt $O/gnn_0.txt
