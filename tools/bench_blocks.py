@@ -26,7 +26,8 @@ HBM_ACHIEVABLE_GBS = 6300.0
 FP32_MFMA_PEAK_TFLOPS = 157.3
 BF16_MFMA_PEAK_TFLOPS = 2516.6
 INT8_MFMA_PEAK_TOPS = 5033.2
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r5_pmc_traffic.json")
+TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", f"r{r}_pmc_traffic.json") for r in (6, 5)) if os.path.exists(p)),
+                    os.path.join(ROOT, "profiles", "r5_pmc_traffic.json"))
 
 
 def event_ms(fn, reps, warm=3):
@@ -65,14 +66,16 @@ def _traffic(key):
 
 
 # ---- GNN forward ------------------------------------------------------------------------------------------------------
-def gnn_bytes(n, F, D, nnz, hops):
+def gnn_bytes(n, F, D, nnz, hops, one_launch=False):
     """SURVEY section 8(d), GNN forward.  `ideal`: every feature row read once (ideal reuse) -- the encoder as this
     implementation associates it, (A X) W^T: aggregation over the NARROW features (CSR + 4 n F read + 4 n F written), the
     dense part (4 n F read + the weights + 4 n D written), and per hop CSR + 4 n D read + 4 n D written.  `no_reuse`: the
-    third term of every aggregation replaced by 4 nnz width (each neighbour row fetched once per edge)."""
+    third term of every aggregation replaced by 4 nnz width (each neighbour row fetched once per edge).  one_launch: the
+    encoder is ragraph_spmm_linear_f32 -- the aggregated table is never written or read back (8 n F bytes fewer)."""
     csr = nnz * 8 + 8 * (n + 1)
-    enc_agg, dense, hop = csr + 8 * n * F, 4 * n * F + 4 * F * D + 4 * n * D, csr + 8 * n * D
-    enc_agg_nr, hop_nr = csr + 4 * nnz * F + 4 * n * F, csr + 4 * nnz * D + 4 * n * D
+    table = 0 if one_launch else 8 * n * F
+    enc_agg, dense, hop = csr + 4 * n * F + table, 4 * F * D + 4 * n * D, csr + 8 * n * D
+    enc_agg_nr, hop_nr = csr + 4 * nnz * F + table, csr + 4 * nnz * D + 4 * n * D
     return {"encode_ideal": enc_agg + dense, "hop_ideal": hop, "forward_ideal": enc_agg + dense + hops * hop,
             "forward_no_reuse": enc_agg_nr + dense + hops * hop_nr, "hop_no_reuse": hop_nr, "encode_flops": 2.0 * n * F * D + 2.0 * nnz * F,
             "hop_flops": 2.0 * nnz * D}
@@ -95,8 +98,12 @@ def gnn_fwd_block(model, feats, adj, reps=30, cpu_gnn_s=None, cpu_cores=None):
     n, F = feats.shape
     D, hops, nnz = model.emb_size, model.query_graph_hop, adj.nnz
     t_enc, t_hops, t_full = _gnn_times(model.pretrain_model, feats, adj, hops, reps)
-    b = gnn_bytes(n, F, D, nnz, hops)
-    rec = {"nodes": n, "nnz": nnz, "feat": F, "dim": D, "hops": hops,
+    from ragraph_amd import kernels as K
+    from ragraph_amd.layers.gcn import aggregate_first
+
+    one_launch = aggregate_first(F, D) and K.spmm_linear_helps(n, F, D)
+    b = gnn_bytes(n, F, D, nnz, hops, one_launch)
+    rec = {"nodes": n, "nnz": nnz, "feat": F, "dim": D, "hops": hops, "encoder_one_launch": bool(one_launch),
            "ms": round(t_full, 4), "nodes_per_s": round(n / t_full * 1e3, 1),
            "encode_ms": round(t_enc, 4), "encode_nodes_per_s": round(n / t_enc * 1e3, 1),
            "hop_ms": round(t_hops / max(hops, 1), 4),
@@ -114,7 +121,7 @@ def gnn_fwd_block(model, feats, adj, reps=30, cpu_gnn_s=None, cpu_cores=None):
            "what": "bytes_ideal = SURVEY 8(d)'s ideal-reuse model (CSR + every feature row read once + the result written, per "
                    "aggregation; + the dense part's operands) of encode + hops; frac = bytes_ideal / ms / 8 TB/s.  bytes_counter = "
                    "HBM-side bytes (2 FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc in separate passes) of the same kernels, from "
-                   "profiles/r5_pmc_traffic.json: above bytes_ideal by the L2 misses of the row gathers"}
+                   f"profiles/{os.path.basename(TRAFFIC_JSON)}: above bytes_ideal by the L2 misses of the row gathers"}
     tr = _traffic(f"gnn_forward n={n} F={F} D={D} hops={hops}")
     rec["bytes_counter"] = None if tr is None else tr.get("hbm_side_bytes")
     if tr is not None:
@@ -180,7 +187,10 @@ def structured_graph_row(feat, dim, hops, dev, n=100_000, reps=20):
     X = torch.randn(n, feat, device=dev, generator=torch.Generator(device=dev).manual_seed(99))
     probe = locality_probe(g)
     t_enc, t_hops, t_full = _gnn_times(pre, X, g, hops, reps)
-    b = gnn_bytes(n, feat, dim, g.nnz, hops)
+    from ragraph_amd import kernels as K
+    from ragraph_amd.layers.gcn import aggregate_first
+
+    b = gnn_bytes(n, feat, dim, g.nnz, hops, aggregate_first(feat, dim) and K.spmm_linear_helps(n, feat, dim))
     rec = {"graph": f"{n} nodes, 512-node communities, 90 % intra-community edges, shuffled ids, nnz {g.nnz}",
            "probe": probe, "reorder": reorder_pays(probe),
            "given_order": {"ms": round(t_full, 4), "hop_ms": round(t_hops / hops, 4), "nodes_per_s": round(n / t_full * 1e3, 1),
