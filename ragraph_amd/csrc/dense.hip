@@ -430,6 +430,9 @@ struct AggLinCfg {
 // dependent round trips depending on its longest row, its MFMAs a fixed time: in lockstep every stage cost the slower of
 // the two (136 us at c2), with the ring the sums overlap.
 __device__ __forceinline__ void agglin_wait(int* f, int target) {
+#ifdef RG_AGGLIN_FREE_RUN   // (diagnostic build: the halves never wait for each other -- wrong results, the cost of sharing a CU)
+  return;
+#endif
   int spins = 0;
   while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
     __builtin_amdgcn_s_sleep(1);
@@ -481,9 +484,6 @@ __global__ void __launch_bounds__(1024, 1) spmm_linear_stream_kernel(const int64
       }
     }
     const float bv = (bias && n < N) ? bias[n] : 0.f;
-#ifdef RG_AGGLIN_PRIO
-    __builtin_amdgcn_s_setprio(RG_AGGLIN_PRIO);
-#endif
     for (int s = 0; s < nstages; ++s) {
       const int buf = s % C::NB;
       agglin_wait(ready + buf, 8 * (s / C::NB + 1));
@@ -524,6 +524,9 @@ __global__ void __launch_bounds__(1024, 1) spmm_linear_stream_kernel(const int64
   }
 
   // ---- the gather half ----
+  // (the gather waves' stages are chains of dependent round trips, the MFMA waves have slack: whoever of the two can issue,
+  // these go first -- 126 -> 121 us at c2; raising the MFMA waves instead changed nothing)
+  __builtin_amdgcn_s_setprio(3);
   constexpr int LPR = C::LPR;
   const int gt = tid - C::MFMA_THREADS;
   const int grp = gt / LPR, lr = gt % LPR, gbase = (lane / LPR) * LPR;   // gbase: first lane of my group in the wave
