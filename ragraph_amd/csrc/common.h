@@ -105,4 +105,53 @@ __device__ __forceinline__ float apply_act(float x, int act, float alpha) {
   }
 }
 
+// ---- wave-wide reductions without LDS (gfx9 wave64 DPP) ----------------------------------------------------------------
+// __shfl_xor is a ds_bpermute_b32 -- an LDS round trip per step, six dependent ones per butterfly.  Inside a row of 16 lanes the
+// same exchanges are DPP operands of the adding instruction itself.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f32(float old, float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL,
+                                                               ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ unsigned dpp_u32(unsigned old, unsigned src) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, 0xF, false);
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E;            // quad_perm [1,0,3,2] / [2,3,0,1]
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128;
+constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+// Sum over the 64 lanes in ANY association (error norms that carry their own slack): row sums by shifts, rows joined by the
+// two broadcasts, the total read from lane 63 -- every lane gets it.
+__device__ __forceinline__ float wave_sum_any_order(float v) {
+  v = __fadd_rn(v, dpp_f32<DPP_ROW_SHR1>(0.f, v));
+  v = __fadd_rn(v, dpp_f32<DPP_ROW_SHR2>(0.f, v));
+  v = __fadd_rn(v, dpp_f32<DPP_ROW_SHR4>(0.f, v));
+  v = __fadd_rn(v, dpp_f32<DPP_ROW_SHR8>(0.f, v));
+  v = __fadd_rn(v, dpp_f32<DPP_ROW_BCAST15, 0xA>(0.f, v));
+  v = __fadd_rn(v, dpp_f32<DPP_ROW_BCAST31, 0xC>(0.f, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = max(v, dpp_u32<DPP_ROW_SHR1>(0u, v));
+  v = max(v, dpp_u32<DPP_ROW_SHR2>(0u, v));
+  v = max(v, dpp_u32<DPP_ROW_SHR4>(0u, v));
+  v = max(v, dpp_u32<DPP_ROW_SHR8>(0u, v));
+  v = max(v, dpp_u32<DPP_ROW_BCAST15, 0xA>(0u, v));
+  v = max(v, dpp_u32<DPP_ROW_BCAST31, 0xC>(0u, v));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// The FIXED 64-lane tree of the row norms (butterfly over xor 32, 16, 8, 4, 2, 1: DESIGN.md section 2), bit for bit: after the
+// levels 32 and 16 (two bpermutes) every lane of a class i mod 16 holds the same partial sum, so the partner at xor 8 / xor 4 can
+// be ANY lane of the partner's class -- the row rotations by 8 and 4 pick one -- and a + b = b + a exactly.
+__device__ __forceinline__ float wave_sum_fixed_tree(float p) {
+  p = __fadd_rn(p, __shfl_xor(p, 32));
+  p = __fadd_rn(p, __shfl_xor(p, 16));
+  p = __fadd_rn(p, dpp_f32<DPP_ROW_ROR8>(0.f, p));
+  p = __fadd_rn(p, dpp_f32<DPP_ROW_ROR4>(0.f, p));
+  p = __fadd_rn(p, dpp_f32<DPP_QUAD_XOR2>(0.f, p));
+  p = __fadd_rn(p, dpp_f32<DPP_QUAD_XOR1>(0.f, p));
+  return p;
+}
+
 }  // namespace ragraph

@@ -67,8 +67,7 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
   p = fmaf(v.y, v.y, p);
   p = fmaf(v.z, v.z, p);
   p = fmaf(v.w, v.w, p);
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) p = __fadd_rn(p, __shfl_xor(p, off));
+  p = wave_sum_fixed_tree(p);   // (the bits of six __shfl_xor steps: common.h)
   const float d = fmaxf(sqrtf(p), 1e-12f);
   v.x = v.x / d; v.y = v.y / d; v.z = v.z / d; v.w = v.w / d;
   if (lane < NCH && q < B) reinterpret_cast<float4*>(Qn + q * D)[lane] = v;
@@ -92,12 +91,10 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
       e2 = fmaf(dd, dd, e2);
     }
   }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) e2 += __shfl_xor(e2, off);
+  e2 = wave_sum_any_order(e2);
   float e8 = 0.f, sq = 0.f;
   unsigned am = max(max(__float_as_uint(fabsf(v.x)), __float_as_uint(fabsf(v.y))), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w))));
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, off));
+  am = wave_max_u32(am);
   if (eq8) {  // (kernel-uniform) the query's int8 scale and rounding error (filter_common.h; the ring kernel re-quantises
               // the row with the SAME expression, so this is the error of the operands it multiplies)
     sq = __uint_as_float(am) / 127.f;
@@ -119,8 +116,7 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
       char* base = reinterpret_cast<char*>(Qb8) + ((q >> 4) * (D / 64) + (c >> 2)) * 1024 + ((c & 3) * 16 + (int)(q & 15)) * 16 + (lane & 3) * 4;
       *reinterpret_cast<unsigned*>(base) = w8;
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) e8 += __shfl_xor(e8, off);
+    e8 = wave_sum_any_order(e8);
   }
   if (q >= B) return;
   if (lane == 0) {
@@ -213,8 +209,8 @@ __global__ void __launch_bounds__(256) theta_sharpen_kernel(const float* __restr
   float v = RG_NEG_INF;
   if (lane < n) v = gathered[((int64_t)(lane / m) * B + b) * m + (lane % m)];
   int rank = 0;
-  for (int o = 0; o < n; ++o) {
-    const float u = __shfl(v, o);
+  for (int o = 0; o < n; ++o) {   // (o is wave-uniform: a v_readlane, not an LDS round trip per step)
+    const float u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), o));
     rank += (u > v || (u == v && o < lane)) ? 1 : 0;
   }
   if (lane < n && rank == k - 1) theta[b] = fmaxf(theta[b], v);
