@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256) filter_bound_scores_kernel(FilterThr t, i
     if (64 * w >= G) break;  // (wave-uniform)
     const int on = G - 64 * w < 64 ? G - 64 * w : 64;
     for (int o = 0; o < on; ++o) {
-      const float x = __shfl(v[w], o);
+      const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[w]), o));   // (o: wave-uniform)
       const int xi = o + 64 * w;
 #pragma unroll
       for (int u = 0; u < 2; ++u) rank[u] += (x > v[u] || (x == v[u] && xi < lane + 64 * u)) ? 1 : 0;
