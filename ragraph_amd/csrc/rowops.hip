@@ -78,8 +78,12 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restric
 }
 
 // ---- a8: sum_k V[idx], mean_k L[idx] (RAGraph.py:48-49); one wave per query, winners added in rank order -------------
-// Gather-bound (B*k random 1 KiB rows): 16 B per lane so one wave-instruction fetches a whole row at D = 256, and the
-// loads of 8 winners are issued before the first add so 8 row gathers are in flight per wave.
+// Gather-bound (B*k random 1 KiB rows): 16 B per lane so one wave-instruction fetches a whole row at D = 256.  The wave
+// reads its k indices FIRST (one coalesced load, lane u = winner u; blocks of 64 for larger k) and hands them out through
+// v_readlane: a row's address is then a scalar base + the lane's offset and the loads of 8 winners go out back to back.
+// (Round 6: with each index loaded right before its row the compiler's s_waitcnt vmcnt(0) for the index also waited for the
+// row before it -- ONE gather in flight per wave where the source said eight; 218 -> see DESIGN.md section 4.7.)  Winners outside
+// [base, base + N) -- another shard's -- read row 0 and add +0, which leaves every partial sum unchanged.
 template <bool VEC4>
 __global__ void __launch_bounds__(256) gather_reduce_kernel(const float* __restrict__ V, int D,
                                                             const float* __restrict__ L, int C, int64_t N,
@@ -90,25 +94,42 @@ __global__ void __launch_bounds__(256) gather_reduce_kernel(const float* __restr
   const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
   const int64_t* ib = idx + b * k;
+  auto row_of = [&](int64_t mine, int u) {   // winner u of the block whose rows the lanes hold (u wave-uniform); -1: not mine
+    return ((int64_t)__builtin_amdgcn_readlane((int)(mine >> 32), u) << 32) | (unsigned)__builtin_amdgcn_readlane((int)mine, u);
+  };
+  auto load_block = [&](int jb) {            // lane u: row of winner jb + u inside this shard, or -1
+    int64_t r = -1;
+    if (jb + lane < k) {
+      r = ib[jb + lane] - base;
+      if (r < 0 || r >= N) r = -1;
+    }
+    return r;
+  };
   if (VEC4) {
     const int D4 = D >> 2;
-    for (int c = lane; c < D4; c += 64) {
+    for (int c = lane; c < ((D4 + 63) / 64) * 64; c += 64) {   // (uniform trip count: readlanes inside)
+      const bool colok = c < D4;
+      const int cc = colok ? c : 0;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int j0 = 0; j0 < k; j0 += 8) {
-        float4 v[8];
+      for (int jb = 0; jb < k; jb += 64) {
+        const int64_t mine = load_block(jb);
+        const int nb = k - jb < 64 ? k - jb : 64;
+        for (int j0 = 0; j0 < nb; j0 += 8) {
+          float4 v[8];
+          bool ok[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (j0 + u < k) {
-            const int64_t r = ib[j0 + u] - base;
-            if (r >= 0 && r < N) v[u] = reinterpret_cast<const float4*>(V + r * D)[c];
+          for (int u = 0; u < 8; ++u) {
+            const int64_t r = j0 + u < nb ? row_of(mine, j0 + u) : -1;
+            ok[u] = r >= 0;
+            v[u] = reinterpret_cast<const float4*>(V + (ok[u] ? r : 0) * D)[cc];
           }
-        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (j0 + u < k) {  // out-of-shard winners add +0, which leaves every partial sum unchanged
-            acc.x = __fadd_rn(acc.x, v[u].x); acc.y = __fadd_rn(acc.y, v[u].y);
-            acc.z = __fadd_rn(acc.z, v[u].z); acc.w = __fadd_rn(acc.w, v[u].w);
+          for (int u = 0; u < 8; ++u) {
+            if (j0 + u < nb) {
+              const float4 x = ok[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+              acc.x = __fadd_rn(acc.x, x.x); acc.y = __fadd_rn(acc.y, x.y);
+              acc.z = __fadd_rn(acc.z, x.z); acc.w = __fadd_rn(acc.w, x.w);
+            }
           }
         }
       }
@@ -116,7 +137,7 @@ __global__ void __launch_bounds__(256) gather_reduce_kernel(const float* __restr
         acc.x = __fmul_rn(acc.x, v_scale); acc.y = __fmul_rn(acc.y, v_scale);
         acc.z = __fmul_rn(acc.z, v_scale); acc.w = __fmul_rn(acc.w, v_scale);
       }
-      reinterpret_cast<float4*>(sumV + b * D)[c] = acc;
+      if (colok) reinterpret_cast<float4*>(sumV + b * D)[c] = acc;
     }
   } else {
     for (int e = lane; e < D; e += 64) {
@@ -129,13 +150,18 @@ __global__ void __launch_bounds__(256) gather_reduce_kernel(const float* __restr
     }
   }
   if (L && meanL) {
-    for (int c = lane; c < C; c += 64) {
+    for (int c = lane; c < ((C + 63) / 64) * 64; c += 64) {
+      const bool colok = c < C;
       float acc = 0.f;
-      for (int jx = 0; jx < k; ++jx) {
-        const int64_t r = ib[jx] - base;
-        if (r >= 0 && r < N) acc = __fadd_rn(acc, L[r * C + c]);
+      for (int jb = 0; jb < k; jb += 64) {
+        const int64_t mine = load_block(jb);
+        const int nb = k - jb < 64 ? k - jb : 64;
+        for (int jx = 0; jx < nb; ++jx) {
+          const int64_t r = row_of(mine, jx);
+          if (r >= 0 && colok) acc = __fadd_rn(acc, L[r * C + c]);
+        }
       }
-      meanL[b * C + c] = acc / (float)k;
+      if (colok) meanL[b * C + c] = acc / (float)k;
     }
   }
 }

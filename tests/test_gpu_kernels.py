@@ -153,6 +153,24 @@ def test_gather_rows_and_reduce(dev):
     assert np.array_equal(m.cpu().numpy(), rm)
 
 
+@pytest.mark.parametrize("D,k,C", [(256, 1, 3), (64, 10, 7), (128, 64, 2), (256, 65, 3), (64, 200, 70), (512, 9, 3)])
+def test_gather_reduce_index_blocks(dev, D, k, C):
+    """Sum_k V[idx] / mean_k L[idx] with the wave's indices read first and handed out lane by lane (blocks of 64 winners): one
+    winner, a full block, one past a block, several blocks, more label columns than lanes, two float4 columns per lane; winners of
+    another shard (idx_base) and a ragged last workgroup -- the oracle's bits."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(D + 7 * k + C)
+    N, B = 777, 41
+    V = rng.standard_normal((N, D), dtype=np.float32)
+    L = rng.standard_normal((N, C), dtype=np.float32)
+    idx = rng.integers(0, 2 * N, (B, k))            # half of the winners belong to "another shard"
+    for base in (0, N):
+        sv, ml = K.gather_reduce(_t(V, dev), _t(L, dev), _t(idx, dev), idx_base=base, v_scale=0.5)
+        rsv, rml = cref.gather_reduce(V, L, idx, base, 0.5)
+        assert np.array_equal(sv.cpu().numpy(), rsv) and np.array_equal(ml.cpu().numpy(), rml)
+
+
 @pytest.mark.parametrize("M,K_,N_,act", [(1, 1, 1, 0), (33, 18, 256, 2), (200, 1433, 256, 0), (130, 256, 3, 3),
                                          (65, 256, 256, 3), (64, 64, 64, 1),
                                          # the 128 x 128 tile kernel (M, N >= 128, K % 4 == 0): ragged tiles, K not a
