@@ -345,6 +345,14 @@ int ragraph_gather_rows_f32(const float* V, int64_t N, int D, const int64_t* idx
 int ragraph_gather_reduce_f32(const float* V, int D, const float* L, int C, int64_t N, const int64_t* idx, int64_t B,
                               int k, int64_t idx_base, float v_scale, float* sum_V, float* mean_L, void* stream);
 
+/* a8  the reduction and the prompt fusion in ONE launch  -- RAGraph_node/RAGraph.py:48-49 + :53:
+ *       out[b,:] = A[b,:] * wa + (v_scale * sum_{j<k} V[idx[b,j]]) * wb;   mean_L as above.
+ *     The bits of ragraph_gather_reduce_f32 followed by ragraph_axpby_f32(A, wa, sum_V, wb) (two multiplies and an add, not
+ *     contracted), without sum_V in memory.  A, out [B,D], out must not alias A. */
+int ragraph_gather_reduce_mix_f32(const float* V, int D, const float* L, int C, int64_t N, const int64_t* idx, int64_t B,
+                                  int k, int64_t idx_base, float v_scale, const float* A, float wa, float wb, float* out,
+                                  float* mean_L, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * a4/a9/a1  dense  Y = act(X @ W^T + b)   -- layers/gcn.py:32 (self.fc, no bias), TaskDecoder.py:15-16
  *           (fc1+LeakyReLU, fc2), and the materialised score matrix of SimilarityFunctions.py:14 (X=Qn, W=Kn).

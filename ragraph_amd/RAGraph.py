@@ -3,6 +3,8 @@
 Same constructor and forward signatures as the reference (including its `feture_size` spelling); hyper-parameters are
 the reference's hard-coded constants exposed as attributes.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -87,6 +89,17 @@ class RAGraph(nn.Module):
             with torch.cuda.stream(side):
                 query_embeddings = self._pool(
                     Propagation.aggregate_k_hop_features(g, pretrain_embedddings, self.query_graph_hop), g)
+        if (side is not None and not add_noise and not torch.is_grad_enabled() and self.flavour == "node"
+                and type(tgb).retrieve_reduced is ToyGraphBase.retrieve_reduced
+                and os.environ.get("RAGRAPH_GATHER_MIX", "1") != "0"):   # (=0: the separate entries, A/B)
+            # a large inference forward: the winners' value sum goes straight into the prompt fusion (:48-49 + :53 in one
+            # launch -- the [n, D] sum is never written, the axpby launch is gone); same bits as the separate entries below
+            _, idx = tgb.topk(queries, tgb.retrieve_num)                                       # :43
+            main.wait_stream(side)
+            query_embeddings.record_stream(main)
+            hidden, rag_label = K.gather_reduce_mix(tgb.resource_values, tgb.resource_labels, idx, query_embeddings,
+                                                    1 - self.retrieve_weight, self.retrieve_weight)
+            return A.softmax_mix(self.decoder(hidden), rag_label, self.label_weight)           # :54-57
         if add_noise:
             rag_embedding, rag_label = tgb.retrieve_reduced_noisy(queries)                     # :43,48-49 (noise branch)
         else:

@@ -71,6 +71,7 @@ SIGNATURES = {
     "ragraph_topk_expand_groups_f32": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _i64, _i64, _i32, _i64, _vp, _vp, _vp]),
     "ragraph_gather_rows_f32": (_i32, [_vp, _i64, _i32, _vp, _i64, _i64, _vp, _vp]),
     "ragraph_gather_reduce_f32": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp, _i64, _i32, _i64, _f32, _vp, _vp, _vp]),
+    "ragraph_gather_reduce_mix_f32": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp, _i64, _i32, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp]),
     "ragraph_linear_f32": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _i32, _f32, _vp, _vp]),
     "ragraph_linear_tn_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "ragraph_linear_tn_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),

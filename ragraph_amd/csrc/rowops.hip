@@ -89,7 +89,10 @@ __global__ void __launch_bounds__(256) gather_reduce_kernel(const float* __restr
                                                             const float* __restrict__ L, int C, int64_t N,
                                                             const int64_t* __restrict__ idx, int64_t B, int k,
                                                             int64_t base, float v_scale, float* __restrict__ sumV,
-                                                            float* __restrict__ meanL) {
+                                                            float* __restrict__ meanL, const float* __restrict__ mixA,
+                                                            float wa, float wb) {
+  // mixA: the row written is mixA[b] * wa + (v_scale * sum) * wb -- ragraph_axpby_f32 behind the reduction (two multiplies
+  // and an add, uncontracted), without the sum in memory (ragraph_gather_reduce_mix_f32)
   const int lane = threadIdx.x & 63;
   const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -137,6 +140,11 @@ __global__ void __launch_bounds__(256) gather_reduce_kernel(const float* __restr
         acc.x = __fmul_rn(acc.x, v_scale); acc.y = __fmul_rn(acc.y, v_scale);
         acc.z = __fmul_rn(acc.z, v_scale); acc.w = __fmul_rn(acc.w, v_scale);
       }
+      if (mixA && colok) {
+        const float4 a = reinterpret_cast<const float4*>(mixA + b * D)[c];
+        acc.x = __fadd_rn(__fmul_rn(a.x, wa), __fmul_rn(acc.x, wb)); acc.y = __fadd_rn(__fmul_rn(a.y, wa), __fmul_rn(acc.y, wb));
+        acc.z = __fadd_rn(__fmul_rn(a.z, wa), __fmul_rn(acc.z, wb)); acc.w = __fadd_rn(__fmul_rn(a.w, wa), __fmul_rn(acc.w, wb));
+      }
       if (colok) reinterpret_cast<float4*>(sumV + b * D)[c] = acc;
     }
   } else {
@@ -146,7 +154,8 @@ __global__ void __launch_bounds__(256) gather_reduce_kernel(const float* __restr
         const int64_t r = ib[jx] - base;
         if (r >= 0 && r < N) acc = __fadd_rn(acc, V[r * D + e]);
       }
-      sumV[b * D + e] = (v_scale == 1.f) ? acc : __fmul_rn(acc, v_scale);
+      acc = (v_scale == 1.f) ? acc : __fmul_rn(acc, v_scale);
+      sumV[b * D + e] = mixA ? __fadd_rn(__fmul_rn(mixA[b * D + e], wa), __fmul_rn(acc, wb)) : acc;
     }
   }
   if (L && meanL) {
@@ -518,23 +527,38 @@ extern "C" int ragraph_gather_rows_f32(const float* V, int64_t N, int D, const i
   return RAGRAPH_OK;
 }
 
-extern "C" int ragraph_gather_reduce_f32(const float* V, int D, const float* L, int C, int64_t N, const int64_t* idx,
-                                         int64_t B, int k, int64_t idx_base, float v_scale, float* sum_V,
-                                         float* mean_L, void* stream) {
+static int launch_gather_reduce(const float* V, int D, const float* L, int C, int64_t N, const int64_t* idx, int64_t B, int k,
+                                int64_t idx_base, float v_scale, float* sum_V, float* mean_L, const float* A, float wa, float wb,
+                                void* stream) {
   RG_REQUIRE(V && idx && sum_V, RAGRAPH_EINVAL, "gather_reduce: null pointer");
   RG_REQUIRE(D >= 1 && k >= 1 && B >= 0 && N >= 0, RAGRAPH_EINVAL, "gather_reduce: bad shape");
   RG_REQUIRE((L == nullptr) == (mean_L == nullptr), RAGRAPH_EINVAL, "gather_reduce: L and mean_L go together");
   RG_REQUIRE(!L || C >= 1, RAGRAPH_EINVAL, "gather_reduce: C=%d", C);
   if (B == 0) return RAGRAPH_OK;
-  const bool vec = (D % 4 == 0) && aligned16(V) && aligned16(sum_V);
+  const bool vec = (D % 4 == 0) && aligned16(V) && aligned16(sum_V) && (!A || aligned16(A));
   if (vec)
     hipLaunchKernelGGL(gather_reduce_kernel<true>, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, as_stream(stream), V, D, L,
-                       C, N, idx, B, k, idx_base, v_scale, sum_V, mean_L);
+                       C, N, idx, B, k, idx_base, v_scale, sum_V, mean_L, A, wa, wb);
   else
     hipLaunchKernelGGL(gather_reduce_kernel<false>, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, as_stream(stream), V, D, L,
-                       C, N, idx, B, k, idx_base, v_scale, sum_V, mean_L);
+                       C, N, idx, B, k, idx_base, v_scale, sum_V, mean_L, A, wa, wb);
   RG_CHECK_LAUNCH("gather_reduce");
   return RAGRAPH_OK;
+}
+
+extern "C" int ragraph_gather_reduce_f32(const float* V, int D, const float* L, int C, int64_t N, const int64_t* idx,
+                                         int64_t B, int k, int64_t idx_base, float v_scale, float* sum_V,
+                                         float* mean_L, void* stream) {
+  return launch_gather_reduce(V, D, L, C, N, idx, B, k, idx_base, v_scale, sum_V, mean_L, nullptr, 0.f, 0.f, stream);
+}
+
+// a8, the reduction and the prompt fusion in one launch  -- RAGraph.py:48-49 + :53: out = A * wa + (v_scale * sum_k V[idx]) * wb
+extern "C" int ragraph_gather_reduce_mix_f32(const float* V, int D, const float* L, int C, int64_t N, const int64_t* idx,
+                                             int64_t B, int k, int64_t idx_base, float v_scale, const float* A, float wa,
+                                             float wb, float* out, float* mean_L, void* stream) {
+  RG_REQUIRE(A, RAGRAPH_EINVAL, "gather_reduce_mix: null pointer");
+  RG_REQUIRE(A != out, RAGRAPH_EINVAL, "gather_reduce_mix: out must not alias A");
+  return launch_gather_reduce(V, D, L, C, N, idx, B, k, idx_base, v_scale, out, mean_L, A, wa, wb, stream);
 }
 
 extern "C" int ragraph_axpby_f32(const float* a, float wa, const float* b, float wb, int64_t n, float* out,

@@ -614,6 +614,30 @@ def gather_reduce(v: torch.Tensor, labels: torch.Tensor | None, idx: torch.Tenso
     return sum_v, mean_l
 
 
+def gather_reduce_mix(v: torch.Tensor, labels: torch.Tensor | None, idx: torch.Tensor, a: torch.Tensor, wa: float, wb: float,
+                      idx_base: int = 0, v_scale: float = 1.0):
+    """(a * wa + (v_scale * sum_k v[idx]) * wb, mean_k labels[idx]) -- RAGraph.py:48-49 + :53 in one launch: the bits of
+    gather_reduce followed by axpby(a, wa, sum, wb), without the sum in memory."""
+    L = _ready()
+    v = _f32c(v, "gather_reduce_mix.v")
+    idx = _idxc(idx, "gather_reduce_mix.idx")
+    a = _f32c(a, "gather_reduce_mix.a")
+    B, k = idx.shape
+    if tuple(a.shape) != (B, v.shape[1]):
+        raise RagraphNativeError(f"gather_reduce_mix: a is {tuple(a.shape)}, the reduction [{B}, {v.shape[1]}]")
+    out = torch.empty((B, v.shape[1]), dtype=torch.float32, device=v.device)
+    mean_l = None
+    C = 0
+    if labels is not None:
+        labels = _f32c(labels, "gather_reduce_mix.labels")
+        C = labels.shape[1]
+        mean_l = torch.empty((B, C), dtype=torch.float32, device=v.device)
+    N.check(L.ragraph_gather_reduce_mix_f32(v.data_ptr(), v.shape[1], _ptr(labels), C, v.shape[0], idx.data_ptr(), B, k, idx_base,
+                                            float(v_scale), a.data_ptr(), float(wa), float(wb), out.data_ptr(), _ptr(mean_l),
+                                            _stream()), "gather_reduce_mix")
+    return out, mean_l
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None, act: int = ACT_NONE,
            alpha: float = 0.0) -> torch.Tensor:
     """act(x @ weight.T + bias) -- layers/gcn.py:32, TaskDecoder.py:15-16."""

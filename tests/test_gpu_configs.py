@@ -28,6 +28,48 @@ def T(a, dev):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def test_large_inference_forward_mixes_behind_the_gather(dev, monkeypatch):
+    """A node forward of more than RAGraph.OVERLAP_MIN_NODES nodes (hops on the side stream, one-launch encoder, the winners'
+    value sum mixed into the prompt behind the gather: ragraph_gather_reduce_mix_f32) gives the bits of the path that keeps the
+    entries apart (RAGRAPH_GATHER_MIX=0, RAGRAPH_SPMM_LINEAR=0), and of the pieces called one by one."""
+    from ragraph_amd import autograd as A
+    from ragraph_amd import kernels as K
+    from ragraph_amd.data import synthetic_big_graph
+    from ragraph_amd.graph import CSRGraph
+    from ragraph_amd.preprompt import PrePrompt
+    from ragraph_amd.RAGraph import RAGraph
+    from ragraph_amd.ragraph_utils import Propagation
+
+    n, F, D, C, N, k = 20_011, 128, 256, 3, 30_000, 10
+    torch.manual_seed(3)
+    adj = CSRGraph.from_edge_index_sym_normalized(synthetic_big_graph(n, 8, seed=11, device=dev), n)
+    g = torch.Generator(device=dev).manual_seed(71)
+    X = torch.randn(n, F, device=dev, generator=g)
+    model = RAGraph(PrePrompt(F, D, "prelu", 1, 0.3).to(dev), None, F, C, D, finetune=True, device=dev).eval()
+    assert n >= model.OVERLAP_MIN_NODES
+    tgb = model.toy_graph_base
+    tgb.retrieve_num = k
+    tgb.add_resources(torch.nn.functional.normalize(torch.randn(N, D, device=dev, generator=g), dim=-1),
+                      torch.randn(N, D, device=dev, generator=g),
+                      torch.nn.functional.one_hot(torch.randint(0, C, (N,), device=dev, generator=g), C).float())
+    with torch.no_grad():
+        fused = model(X, adj)
+        monkeypatch.setenv("RAGRAPH_GATHER_MIX", "0")
+        monkeypatch.setenv("RAGRAPH_SPMM_LINEAR", "0")
+        apart = model(X, adj)
+        monkeypatch.delenv("RAGRAPH_GATHER_MIX")
+        monkeypatch.delenv("RAGRAPH_SPMM_LINEAR")
+        torch.cuda.synchronize()
+        assert torch.equal(fused, apart)
+        h = model.pretrain_model.inference(X, adj)
+        qe = Propagation.aggregate_k_hop_features(adj, h, model.query_graph_hop)
+        rag, lab, _ = tgb.retrieve_reduced(h)
+        hidden = K.axpby(qe, 1 - model.retrieve_weight, rag, model.retrieve_weight)
+        by_hand = A.softmax_mix(model.decoder(hidden), lab, model.label_weight)
+    assert torch.equal(fused, by_hand)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def test_c1_cora_shaped_forward_matches_oracle(dev):
     from ragraph_amd.data import synthetic_big_graph
     from ragraph_amd.graph import CSRGraph

@@ -171,6 +171,28 @@ def test_gather_reduce_index_blocks(dev, D, k, C):
         assert np.array_equal(sv.cpu().numpy(), rsv) and np.array_equal(ml.cpu().numpy(), rml)
 
 
+@pytest.mark.parametrize("D,k", [(256, 10), (64, 70), (30, 5)])
+def test_gather_reduce_mix_is_reduce_then_axpby(dev, D, k):
+    """ragraph_gather_reduce_mix_f32 = ragraph_gather_reduce_f32 followed by ragraph_axpby_f32, bit for bit (RAGraph.py:48-49 +
+    :53 in one launch), label means included; vectorised and scalar widths, winners of another shard."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(D * k)
+    N, B, C = 500, 77, 3
+    V = rng.standard_normal((N, D), dtype=np.float32)
+    L = rng.standard_normal((N, C), dtype=np.float32)
+    Aq = rng.standard_normal((B, D), dtype=np.float32)
+    idx = rng.integers(0, N + 100, (B, k))
+    Vd, Ld, id_, Ad = _t(V, dev), _t(L, dev), _t(idx, dev), _t(Aq, dev)
+    for vs in (1.0, 0.25):
+        s, ml = K.gather_reduce(Vd, Ld, id_, v_scale=vs)
+        two = K.axpby(Ad, 0.3, s, 0.7)
+        one, ml1 = K.gather_reduce_mix(Vd, Ld, id_, Ad, 0.3, 0.7, v_scale=vs)
+        assert torch.equal(one, two) and torch.equal(ml1, ml)
+    one, none = K.gather_reduce_mix(Vd, None, id_, Ad, 0.5, 0.5)
+    assert none is None and torch.equal(one, K.axpby(Ad, 0.5, K.gather_reduce(Vd, None, id_)[0], 0.5))
+
+
 @pytest.mark.parametrize("M,K_,N_,act", [(1, 1, 1, 0), (33, 18, 256, 2), (200, 1433, 256, 0), (130, 256, 3, 3),
                                          (65, 256, 256, 3), (64, 64, 64, 1),
                                          # the 128 x 128 tile kernel (M, N >= 128, K % 4 == 0): ragged tiles, K not a

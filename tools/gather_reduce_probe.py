@@ -23,3 +23,7 @@ V64 = torch.randn(4_000_000, 64, device=dev, generator=g)
 idx2 = torch.randint(0, 4_000_000, (B, k), device=dev, generator=g)
 us = t(lambda: K.gather_reduce(V64, None, idx2, v_scale=0.1))
 print(f"gather_reduce B={B} k={k} D=64 (edge flavour): {us:.1f} us")
+A = torch.randn(B, D, device=dev, generator=g)
+two = t(lambda: K.axpby(A, 0.5, K.gather_reduce(V, L, idx)[0], 0.5))
+one = t(lambda: K.gather_reduce_mix(V, L, idx, A, 0.5, 0.5))
+print(f"reduce + axpby: {two:.1f} us; gather_reduce_mix: {one:.1f} us")
