@@ -99,6 +99,72 @@ __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ X
   }
 }
 
+// ---- tall X, a handful of output columns (the class head: TaskDecoder's fc2, 256 -> C) --------------------------------------
+// 100 000 x 256 -> 3 through the 64 x 64 MFMA tiles is 61 idle columns of 64 and 51 us for 100 MB of X; the work is reading X.
+// A wave owns 64 rows, lane = row: X passes through a wave-private LDS tile (coalesced 16-byte loads in, the lane's row out --
+// rows 33 floats apart, conflict-free), W sits in LDS and is read as a broadcast, and every output is the plain fmaf chain
+// over k = 0 .. K - 1 from +0 -- what the MFMA kernels compute, so the same bits.  The next chunk's loads are in flight under
+// the chains of the current one.
+constexpr int NARROW_MAX_N = 8, NARROW_KC = 32, NARROW_LD = NARROW_KC + 1;
+template <int NN>
+__global__ void __launch_bounds__(256) linear_narrow_kernel(const float* __restrict__ X, int64_t M, int K,
+                                                            const float* __restrict__ W, const float* __restrict__ bias, int act,
+                                                            float alpha, float* __restrict__ Y) {
+  extern __shared__ float4 lin_smem4[];
+  float* Ws = reinterpret_cast<float*>(lin_smem4);               // [NN][K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* tile = Ws + NN * K + wave * (64 * NARROW_LD);            // this wave's [64][NARROW_LD]
+  for (int e = tid; e < NN * K; e += 256) Ws[e] = W[e];
+  __syncthreads();
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 64;     // the wave's rows
+  if (row0 >= M) return;
+  // staging: load u of a chunk brings rows 8 u + lane / 8, floats 4 (lane % 8) .. + 3 of the chunk (8 x 128 B per instruction)
+  const int sr = lane >> 3, sc = 4 * (lane & 7);
+  float4 pre[8];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t r = row0 + 8 * u + sr;
+      pre[u] = *reinterpret_cast<const float4*>(X + (r < M ? r : M - 1) * K + k0 + sc);
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float* d = tile + (8 * u + sr) * NARROW_LD + sc;
+      d[0] = pre[u].x; d[1] = pre[u].y; d[2] = pre[u].z; d[3] = pre[u].w;
+    }
+  };
+  float acc[NN];
+#pragma unroll
+  for (int c = 0; c < NN; ++c) acc[c] = 0.f;
+  gload(0);
+  for (int k0 = 0; k0 < K; k0 += NARROW_KC) {
+    sstore();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (k0 + NARROW_KC < K) gload(k0 + NARROW_KC);
+    const float* xr = tile + lane * NARROW_LD;
+#pragma unroll 8
+    for (int kk = 0; kk < NARROW_KC; ++kk) {
+      const float x = xr[kk];
+#pragma unroll
+      for (int c = 0; c < NN; ++c) acc[c] = fmaf(x, Ws[c * K + k0 + kk], acc[c]);
+    }
+    __builtin_amdgcn_wave_barrier();   // (the tile is rewritten next round: every lane has read its row)
+  }
+  const int64_t m = row0 + lane;
+  if (m < M) {
+#pragma unroll
+    for (int c = 0; c < NN; ++c) {
+      float v = acc[c];
+      if (bias) v = __fadd_rn(v, bias[c]);
+      Y[m * NN + c] = apply_act(v, act, alpha);
+    }
+  }
+}
+
 // ---- few output tiles, long K: 32 x 32 block tile, one 16 x 16 MFMA tile per wave -----------------------------------
 // A 64 x 64 block of linear_kernel is a chain of K/2 dependent v_mfma_f32_32x32x2_f32 per wave (64 cycles each): the GCN
 // encode of a Cora-sized graph (2708 x 1433 -> 128: 86 blocks on 256 CUs, 717 dependent MFMAs) took 50 us with two
@@ -853,6 +919,30 @@ extern "C" int ragraph_linear_f32(const float* X, int64_t M, int K, const float*
     const char* e = getenv("RAGRAPH_LINEAR_TILE");
     return !(e && atoi(e) == 0);
   }();
+  // tall X, a handful of output columns: the row-streaming kernel (RAGRAPH_LINEAR_NARROW=0: the MFMA tiles, A/B)
+  static const bool narrow_ok = [] { const char* e = getenv("RAGRAPH_LINEAR_NARROW"); return !(e && atoi(e) == 0); }();
+  if (narrow_ok && N <= NARROW_MAX_N && M >= 4096 && K % NARROW_KC == 0 && K <= 2048 && aligned16(X)) {
+    const size_t lds = sizeof(float) * ((size_t)N * K + 4 * 64 * NARROW_LD);
+    dim3 grid((unsigned)cdiv(M, 256));
+    hipStream_t st = as_stream(stream);
+#define RG_NARROW(NN_)                                                                                                    \
+  case NN_: {                                                                                                               \
+    static DeviceOnce once;                                                                                                 \
+    if (hipError_t e = raise_dynamic_lds(once, &linear_narrow_kernel<NN_>, (int)(sizeof(float) * ((size_t)NN_ * 2048 + 4 * 64 * NARROW_LD))); \
+        e != hipSuccess) {                                                                                                  \
+      set_error("linear: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));                                        \
+      return RAGRAPH_EDEVICE;                                                                                               \
+    }                                                                                                                       \
+    hipLaunchKernelGGL(linear_narrow_kernel<NN_>, grid, dim3(256), lds, st, X, M, K, W, bias, act, alpha, Y);               \
+    break;                                                                                                                  \
+  }
+    switch ((int)N) {
+      RG_NARROW(1) RG_NARROW(2) RG_NARROW(3) RG_NARROW(4) RG_NARROW(5) RG_NARROW(6) RG_NARROW(7) RG_NARROW(8)
+    }
+#undef RG_NARROW
+    RG_CHECK_LAUNCH("linear(narrow)");
+    return RAGRAPH_OK;
+  }
   // tall X against blocks of 256 columns; the last block's idle waves must stay under 25 % of all of them
   if (tile_ok && M >= 4096 && (K == 64 || K == 128 || K == 256) && aligned16(X) && aligned16(W) &&
       4 * N >= 3 * 256 * cdiv(N, 256) && cdiv(N, 256) <= 65535) {

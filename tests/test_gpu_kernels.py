@@ -171,6 +171,21 @@ def test_gather_reduce_index_blocks(dev, D, k, C):
         assert np.array_equal(sv.cpu().numpy(), rsv) and np.array_equal(ml.cpu().numpy(), rml)
 
 
+@pytest.mark.parametrize("M,K_,N_,act", [(4096, 256, 3, 0), (5001, 256, 7, 3), (4100, 32, 1, 2), (9999, 512, 8, 1), (4097, 64, 2, 0)])
+def test_linear_narrow_heads_bit_exact(dev, M, K_, N_, act):
+    """Tall X against a handful of output columns (TaskDecoder's fc2 on every node of a large graph): the row-streaming kernel
+    gives the oracle's fmaf chains bit for bit -- ragged last wave, every width 1..8, bias or none, every epilogue."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(M + K_ + N_)
+    X = rng.standard_normal((M, K_), dtype=np.float32)
+    W = (rng.standard_normal((N_, K_), dtype=np.float32) * 0.2).astype(np.float32)
+    b = rng.standard_normal(N_, dtype=np.float32)
+    for bias in (b, None):
+        got = K.linear(_t(X, dev), _t(W, dev), None if bias is None else _t(bias, dev), act=act, alpha=0.2).cpu().numpy()
+        assert np.array_equal(got, cref.linear(X, W, bias=bias, act=act, alpha=0.2))
+
+
 @pytest.mark.parametrize("D,k", [(256, 10), (64, 70), (30, 5)])
 def test_gather_reduce_mix_is_reduce_then_axpby(dev, D, k):
     """ragraph_gather_reduce_mix_f32 = ragraph_gather_reduce_f32 followed by ragraph_axpby_f32, bit for bit (RAGraph.py:48-49 +
