@@ -31,7 +31,10 @@ struct FilterStatsInit {
 constexpr int FILTER_FIX_MAX_Q = 1024;  // overflowed queries whose scan topk_overflow_fixup_kernel may cut into slices
 constexpr int FILTER_FIX_SLICES = 16;   // at most (16 x 32 partial winners: eight per lane of the merging wave)
 
-template <int D>
+// R rows per wave: one wave per query row is 100 000 waves of a microsecond of work at c2 -- the launch is bound by how fast waves
+// start, not by its 200 MB; with R = 4 a wave has its four row loads in flight at once and a quarter of the waves exist
+// (calls of FILTER_PREP_WIDE_B queries and more; small calls keep one row per wave: they want every CU at once).
+template <int D, int R = 1>
 __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restrict__ Q, int64_t B, float* __restrict__ Qn,
                                                           float* __restrict__ eq, int* __restrict__ count,
                                                           unsigned char* __restrict__ flag, int* __restrict__ overflow,
@@ -42,7 +45,17 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
                                                           int* __restrict__ stats, FilterStatsInit si,
                                                           float* __restrict__ theta_init, float prior) {
   const int lane = threadIdx.x & 63;
-  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  constexpr int NCH = D / 4;  // float4 chunks per row: 16 / 32 / 64 -- at most one per lane
+  const int64_t q_first = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  float4 vpre[R];
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) {
+    vpre[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < NCH && q_first + rr < B) vpre[rr] = reinterpret_cast<const float4*>(Q + (q_first + rr) * D)[lane];
+  }
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) {
+  const int64_t q = q_first + rr;
   if (q == 0 && lane == 0) *overflow = 0;
   if (q == 0 && lane < FILTER_STATS_INTS && stats) {
     int v = 0;
@@ -58,10 +71,8 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
   }
   if (theta_init && q < B && lane == 0) theta_init[q] = prior;   // a speculative first bound: the same for every query
   if (q < FILTER_FIX_MAX_Q && lane == 0) fix_done[q] = 0;  // tickets of topk_overflow_fixup_kernel
-  if (q >= (Qb ? (B + 31) / 32 * 32 : B)) return;
-  constexpr int NCH = D / 4;  // float4 chunks per row: 16 / 32 / 64 -- at most one per lane
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (lane < NCH && q < B) v = reinterpret_cast<const float4*>(Q + q * D)[lane];
+  if (q >= (Qb ? (B + 31) / 32 * 32 : B)) continue;
+  float4 v = vpre[rr];
   float p = 0.f;
   p = fmaf(v.x, v.x, p);
   p = fmaf(v.y, v.y, p);
@@ -118,7 +129,7 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
     }
     e8 = wave_sum_any_order(e8);
   }
-  if (q >= B) return;
+  if (q >= B) continue;
   if (lane == 0) {
     eq[q] = sqrtf(e2) * 1.0000002f;  // (any summation order of the squares stays below this)
     // a ZERO query scores +0 against every key: within any bound of its k-th best, i.e. its lists can only overflow -- it
@@ -135,6 +146,7 @@ __global__ void __launch_bounds__(256) filter_prep_kernel(const float* __restric
   if (lane < cstride) count[q * cstride + lane] = 0;
   if (gmax)
     for (int gi = lane; gi < ngroups; gi += 64) gmax[q * ngroups + gi] = f2ord(RG_NEG_INF);
+  }   // rows of this wave
 }
 
 // Sharded banks (ragraph_topk_cosine_filtered_sharded_f32): the bound a level filters with is kept in theta[B] so that

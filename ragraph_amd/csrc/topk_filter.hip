@@ -877,13 +877,18 @@ static int run_filtered(const float* Q, int64_t B, const float* Kn, const float*
     stats_init.keys[l] = lk > INT_MAX ? INT_MAX : (int)lk;
   }
   // one launch: normalised queries, their bf16 rounding errors, empty lists, clear flags (+ group maxima at -inf)
-  hipLaunchKernelGGL(filter_prep_kernel<D>, dim3((unsigned)cdiv(B <= FILTER_QB_MAX_B ? (B + 31) / 32 * 32 : B, 4)), dim3(256), 0, st, Q, B,
-                     f.Qn, f.eq, f.count, f.flag, overflow, bound ? f.gmax : nullptr, bound ? filter_bound_parts(k, sc.bound_keys, D, B, exchange ? n_shards : 1) : k,
-                     // (the bf16 operand image: only launches on the bf16 copy read it -- a call whose levels all run on the int8
-                     // copy and that has no bound pass, e.g. every call under a prior, saves writing 2 D bytes per query)
-                     B <= FILTER_QB_MAX_B && (B <= 256 || bound || sc.nlev > sc.i8_levels) ? f.Qb : nullptr,
-                     filter_count_stride(B), sc.i8_levels > 0 ? f.eq8 : nullptr, f.qscale, B <= FILTER_QB_MAX_B ? f.Qb8 : nullptr, f.fix_done,
-                     stats, stats_init, spec ? (exchange ? theta : f.theta) : nullptr, prior);
+  static const int64_t prep_wide_b = [] { const char* e = getenv("RAGRAPH_FILTER_PREP_WIDE_B"); return e ? (int64_t)atoll(e) : (int64_t)8192; }();   // A/B
+#define RG_PREP(R_)                                                                                                                     \
+  hipLaunchKernelGGL((filter_prep_kernel<D, R_>), dim3((unsigned)cdiv(B <= FILTER_QB_MAX_B ? (B + 31) / 32 * 32 : B, 4 * (R_))), dim3(256), 0, st, Q, B, \
+                     f.Qn, f.eq, f.count, f.flag, overflow, bound ? f.gmax : nullptr, bound ? filter_bound_parts(k, sc.bound_keys, D, B, exchange ? n_shards : 1) : k, \
+                     /* (the bf16 operand image: only launches on the bf16 copy read it -- a call whose levels all run on the int8 */ \
+                     /* copy and that has no bound pass, e.g. every call under a prior, saves writing 2 D bytes per query) */           \
+                     B <= FILTER_QB_MAX_B && (B <= 256 || bound || sc.nlev > sc.i8_levels) ? f.Qb : nullptr,                           \
+                     filter_count_stride(B), sc.i8_levels > 0 ? f.eq8 : nullptr, f.qscale, B <= FILTER_QB_MAX_B ? f.Qb8 : nullptr, f.fix_done, \
+                     stats, stats_init, spec ? (exchange ? theta : f.theta) : nullptr, prior)
+  if (B >= prep_wide_b) RG_PREP(4);   // (100 000 x 256: 120 us with one row per wave, 74 with two or four, 162 with eight)
+  else RG_PREP(1);
+#undef RG_PREP
   RG_CHECK_LAUNCH("topk_cosine_filtered(prepare)");
 
   FilterThr thr{};
