@@ -29,5 +29,5 @@ f=$(find $O/fn -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python3 $R/t
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/em8 -o s -- python3 $R/bench.py --emulate-rank-of 8 --shard keys --no-extras --steps 5 --warmup 5 > $O/emul_keys_8.log 2>&1
 f=$(find $O/em8 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python3 $R/tools/summarize_rocprof.py $f $O/emul_keys_8_kernel_stats.csv; rm -rf $O/em8
 cd $R
-cut -c1-300 $O/bench.json; cat $O/emul.txt; tail -1 $O/ft_node.log $O/ft_edge.log | cut -c1-200
-grep -il "rocprim\|hipcub\|cub::" $O/ft_*.csv
+cut -c1-300 $O/bench.json; cat $O/emul.txt; for f in $O/ft_node.log $O/ft_edge.log; do tail -n 1 $f | cut -c1-200; done
+grep -il "rocprim\|hipcub\|cub::" $O/ft_*.csv || true
