@@ -530,7 +530,7 @@ __global__ void __launch_bounds__(1024, 1) spmm_linear_stream_kernel(const int64
   __syncthreads();
 
   if (wave < 8) {
-    // ---- the dense half: linear_stream_kernel's chains on the stage the other half finished one barrier ago ----
+    // ---- the dense half: linear_stream_kernel's chains on the stages the other half has marked ready ----
     const int j = lane & 31, h = lane >> 5;
     const int64_t n = (int64_t)blockIdx.y * 256 + wave * 32 + j;  // this lane's output column
     float breg[KD / 2];   // B operand: row n of W, k-slots h, h + 2, ... (as linear_stream_kernel)
