@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) gather_reduce_kernel(const float* __restr
       const bool colok = c < D4;
       const int cc = colok ? c : 0;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int jb = 0; jb < k; jb += 64) {
+      for (int jb = 0; jb < k && N > 0; jb += 64) {   // (an empty shard has no row 0 to read)
         const int64_t mine = load_block(jb);
         const int nb = k - jb < 64 ? k - jb : 64;
         for (int j0 = 0; j0 < nb; j0 += 8) {
