@@ -1082,8 +1082,12 @@ extern "C" int ragraph_theta_sharpen_f32(const float* gathered, int G, int64_t B
   RG_REQUIRE(G >= 1 && m >= 1 && k >= 1 && G * m <= 64 && G * m >= k, RAGRAPH_EINVAL,
              "theta_sharpen: need k <= G*m <= 64 (G=%d m=%d k=%d)", G, m, k);
   if (B <= 0) return RAGRAPH_OK;
-  hipLaunchKernelGGL(theta_sharpen_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, as_stream(stream), gathered, G, B, m, k,
-                     theta);
+  if (G * m <= 32 && B >= 4096)
+    hipLaunchKernelGGL(theta_sharpen2_kernel, dim3((unsigned)cdiv(B, 8)), dim3(256), 0, as_stream(stream), gathered, G, B, m, k,
+                       theta);
+  else
+    hipLaunchKernelGGL(theta_sharpen_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, as_stream(stream), gathered, G, B, m, k,
+                       theta);
   RG_CHECK_LAUNCH("theta_sharpen");
   return RAGRAPH_OK;
 }

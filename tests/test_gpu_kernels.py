@@ -186,6 +186,22 @@ def test_linear_narrow_heads_bit_exact(dev, M, K_, N_, act):
         assert np.array_equal(got, cref.linear(X, W, bias=bias, act=act, alpha=0.2))
 
 
+@pytest.mark.parametrize("G,m,B,k", [(8, 4, 5001, 10), (8, 2, 4096, 10), (2, 10, 7777, 10), (8, 4, 100, 10), (5, 8, 6000, 10), (4, 16, 5000, 3)])
+def test_theta_sharpen_kth_of_the_union(dev, G, m, B, k):
+    """theta[b] = max(theta[b], k-th largest of the union of every shard's m scores of query b): one query per wave, and two per
+    wave where G m <= 32 and the batch is large -- duplicates count as often as they occur, an odd last query, -inf slots."""
+    from ragraph_amd import kernels as K
+
+    rng = _rng(G * 100 + m + B)
+    g = rng.standard_normal((G, B, m)).astype(np.float32)
+    g[:, ::7, :] = np.round(g[:, ::7, :], 1)            # ties
+    g[0, 5, :] = -np.inf
+    th = rng.standard_normal(B).astype(np.float32)
+    kth = np.sort(g.transpose(1, 0, 2).reshape(B, G * m), axis=1)[:, ::-1][:, k - 1]
+    got = K.theta_sharpen(_t(g, dev), _t(th.copy(), dev), k).cpu().numpy()
+    assert np.array_equal(got, np.maximum(th, kth))
+
+
 @pytest.mark.parametrize("D,k", [(256, 10), (64, 70), (30, 5)])
 def test_gather_reduce_mix_is_reduce_then_axpby(dev, D, k):
     """ragraph_gather_reduce_mix_f32 = ragraph_gather_reduce_f32 followed by ragraph_axpby_f32, bit for bit (RAGraph.py:48-49 +
