@@ -464,13 +464,30 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
             for (int r = 0; r < 4; ++r) m[gq] = fmaxf(m[gq], (float)a[1][gq][r]);
             gm[gq] = fmaxf(gm[gq], m[gq]);
           }
-        } else if constexpr (FOLD) {  // one chain of maxima over every group's I - T, one sign test
+        } else if constexpr (FOLD) {  // the groups' maxima of I - T, their maximum, one sign test
+#ifdef RG_FOLD_ONE_CHAIN   // (A/B build: one chain over all 8 NG values -- the groups' own maxima are then made again on a hit)
           int mall = as_bits(a[0][0][0]);
 #pragma unroll
           for (int gq = 0; gq < NG; ++gq)
 #pragma unroll
             for (int e = (gq == 0 ? 1 : 0); e < 8; ++e) mall = max(mall, as_bits(a[e >> 2][gq][e & 3]));
           hit = mall >= 0;
+#else
+          // (at D = 64 a sub-tile is 32 keys x QW queries for only two MFMAs per group: with pass rates of a few 1e-4 most
+          // sub-tiles have a hit somewhere, and a single chain over everything meant the groups' maxima were computed twice)
+#pragma unroll
+          for (int gq = 0; gq < NG; ++gq) {
+            mi[gq] = as_bits(a[0][gq][0]);
+#pragma unroll
+            for (int r = 1; r < 4; ++r) mi[gq] = max(mi[gq], as_bits(a[0][gq][r]));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mi[gq] = max(mi[gq], as_bits(a[1][gq][r]));
+          }
+          int mall = mi[0];
+#pragma unroll
+          for (int gq = 1; gq < NG; ++gq) mall = max(mall, mi[gq]);
+          hit = mall >= 0;
+#endif
         } else {
 #pragma unroll
           for (int gq = 0; gq < NG; ++gq) {
@@ -489,14 +506,16 @@ __global__ void __launch_bounds__(512, 2) topk_filter_kernel(FilterParams p) {
           // (a group without a passing lane skips its compares: at the later levels a sub-tile that has a candidate at
           // all usually has it in one group only)
           unsigned km[NG];
-          if constexpr (FOLD) {  // the groups' own maxima, only now; scored entries carry I itself: + T
+          if constexpr (FOLD) {  // scored entries carry I itself: + T
 #pragma unroll
             for (int gq = 0; gq < NG; ++gq) {
+#ifdef RG_FOLD_ONE_CHAIN
               mi[gq] = as_bits(a[0][gq][0]);
 #pragma unroll
               for (int r = 1; r < 4; ++r) mi[gq] = max(mi[gq], as_bits(a[0][gq][r]));
 #pragma unroll
               for (int r = 0; r < 4; ++r) mi[gq] = max(mi[gq], as_bits(a[1][gq][r]));
+#endif
               km[gq] = 0;
               if (__any(mi[gq] >= 0)) km[gq] = pass_mask(a, gq, 0);
               mi[gq] += thr_i[gq];
